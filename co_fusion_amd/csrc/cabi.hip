@@ -1,0 +1,566 @@
+// cabi.hip -- C-ABI (include/cofusion_hip.h) over the gfx950 kernels: context, tracker objects,
+// stand-alone reduction steps.  No allocation happens on the per-frame path: every device buffer
+// is created with the ctx / odom / model object that owns it.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "cf_host.h"
+
+using namespace cf;
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->set_error(std::string(#call) + ": " + hipGetErrorString(e_));               \
+            return CF_EHIP;                                                                    \
+        }                                                                                      \
+    } while (0)
+
+#define LAUNCHCHK(ctx) HIPCHK(ctx, hipGetLastError())
+
+void cf_ctx::set_error(const std::string& m) { last_error = m; }
+
+template <typename T>
+static int dmalloc(cf_ctx* ctx, T** p, size_t count)
+{
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    HIPCHK(ctx, hipMemsetAsync(*p, 0, count * sizeof(T), ctx->stream));
+    return CF_OK;
+}
+
+extern "C" {
+
+int cf_create(const cf_config* cfg, cf_ctx** out)
+{
+    if (!cfg || !out || cfg->width <= 0 || cfg->height <= 0 || (cfg->width % 16) || (cfg->height % 4)) return CF_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CF_EHIP;  // fail loudly: no CPU fallback
+    cf_ctx* ctx = new cf_ctx();
+    ctx->cfg = *cfg;
+    if (ctx->cfg.max_models <= 0) ctx->cfg.max_models = 1;
+    *out = ctx;
+    HIPCHK(ctx, hipSetDevice(cfg->device));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    ctx->icp_launch = IcpLaunch{256, 1};
+    if (int r = dmalloc(ctx, &ctx->d_acc_a, (size_t)kGroups * 32)) return r;
+    if (int r = dmalloc(ctx, &ctx->d_acc_b, (size_t)kGroups * 32)) return r;
+    if (int r = dmalloc(ctx, &ctx->d_out, 64)) return r;
+    if (int r = dmalloc(ctx, &ctx->d_scratch_state, 1)) return r;
+    if (int r = dmalloc(ctx, &ctx->d_model_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
+    if (int r = dmalloc(ctx, &ctx->d_cand_scratch, (size_t)cfg->width * cfg->height)) return r;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scratch_state), sizeof(OdomDev)));
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_model_ptrs), sizeof(OdomDev*) * (ctx->cfg.max_models + 1)));
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_out), sizeof(unsigned long long) * 64));
+    ctx->prof.capacity = 8192;
+    ctx->prof.events = new hipEvent_t[ctx->prof.capacity];
+    for (int i = 0; i < ctx->prof.capacity; i++) HIPCHK(ctx, hipEventCreate(&ctx->prof.events[i]));
+    ctx->prof.used = 0; ctx->prof.enabled = 0; ctx->prof.bytes = 0; ctx->prof.launches = 0;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
+}
+
+void cf_destroy(cf_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->d_acc_a); (void)hipFree(ctx->d_acc_b); (void)hipFree(ctx->d_out);
+    (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_cand_scratch);
+    (void)hipHostFree(ctx->h_scratch_state); (void)hipHostFree(ctx->h_model_ptrs); (void)hipHostFree(ctx->h_out);
+    if (ctx->prof.events) {
+        for (int i = 0; i < ctx->prof.capacity; i++) (void)hipEventDestroy(ctx->prof.events[i]);
+        delete[] ctx->prof.events;
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* cf_last_error(const cf_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+int cf_set_stream(cf_ctx* ctx, void* s) { if (!ctx) return CF_EINVAL; ctx->stream = s ? (hipStream_t)s : ctx->own_stream; return CF_OK; }
+void* cf_get_stream(cf_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int cf_synchronize(cf_ctx* ctx) { if (!ctx) return CF_EINVAL; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return CF_OK; }
+int cf_malloc(cf_ctx* ctx, uint64_t bytes, void** dptr)
+{
+    if (!ctx || !dptr) return CF_EINVAL;
+    HIPCHK(ctx, hipMalloc(dptr, bytes));
+    HIPCHK(ctx, hipMemsetAsync(*dptr, 0, bytes, ctx->stream));
+    return CF_OK;
+}
+int cf_free(cf_ctx* ctx, void* dptr) { if (!ctx) return CF_EINVAL; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(dptr)); return CF_OK; }
+int cf_memcpy_h2d(cf_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+    if (!ctx) return CF_EINVAL;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
+}
+int cf_memcpy_d2h(cf_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+    if (!ctx) return CF_EINVAL;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
+}
+
+int cf_set_icp_launch(cf_ctx* ctx, int threads, int ppt)
+{
+    if (!ctx || (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024) ||
+        (ppt != 1 && ppt != 2 && ppt != 4))
+        return CF_EINVAL;
+    ctx->icp_launch = IcpLaunch{threads, ppt};
+    return CF_OK;
+}
+
+int cf_profile_enable(cf_ctx* ctx, int on) { if (!ctx) return CF_EINVAL; ctx->prof.enabled = on; return CF_OK; }
+int cf_profile_read(cf_ctx* ctx, cf_profile* out, int reset)
+{
+    if (!ctx || !out) return CF_EINVAL;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double ms = ctx->prof_ms_accum;
+    for (int i = 0; i + 1 < ctx->prof.used; i += 2) {
+        float t = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&t, ctx->prof.events[i], ctx->prof.events[i + 1]));
+        ms += t;
+    }
+    ctx->prof_ms_accum = ms;
+    ctx->prof.used = 0;
+    out->icp_ms_total = ms; out->icp_launches = ctx->prof.launches; out->icp_bytes = ctx->prof.bytes;
+    if (reset) { ctx->prof_ms_accum = 0; ctx->prof.launches = 0; ctx->prof.bytes = 0; }
+    return CF_OK;
+}
+
+// ---------------------------------------------------------------- map preparation ----
+#define PREP_PROLOGUE if (!ctx) return CF_EINVAL
+int cf_create_vmap(cf_ctx* ctx, const float* depth, int cols, int rows, cf_cam intr, float cutoff, float* vmap)
+{ PREP_PROLOGUE; launch_vmap(ctx->stream, depth, cols, rows, intr, cutoff, vmap); LAUNCHCHK(ctx); return CF_OK; }
+int cf_create_nmap(cf_ctx* ctx, const float* vmap, int cols, int rows, float* nmap)
+{ PREP_PROLOGUE; launch_nmap(ctx->stream, vmap, cols, rows, nmap); LAUNCHCHK(ctx); return CF_OK; }
+int cf_copy_maps(cf_ctx* ctx, const float* v4, const float* n4, int cols, int rows, float* vmap, float* nmap)
+{ PREP_PROLOGUE; launch_copy_maps(ctx->stream, v4, n4, cols, rows, vmap, nmap); LAUNCHCHK(ctx); return CF_OK; }
+int cf_resize_map(cf_ctx* ctx, const float* in, int in_cols, int in_rows, float* out, int normalize)
+{ PREP_PROLOGUE; launch_resize_map(ctx->stream, in, in_cols, in_rows, out, normalize != 0); LAUNCHCHK(ctx); return CF_OK; }
+int cf_transform_maps(cf_ctx* ctx, float* vmap, float* nmap, int cols, int rows, const float R[9], const float t[3])
+{ PREP_PROLOGUE; launch_transform_maps(ctx->stream, vmap, nmap, cols, rows, R, t); LAUNCHCHK(ctx); return CF_OK; }
+int cf_vertices_to_depth(cf_ctx* ctx, const float* v4, int cols, int rows, float cutoff, float* depth)
+{ PREP_PROLOGUE; launch_vertices_to_depth(ctx->stream, v4, cols, rows, cutoff, depth); LAUNCHCHK(ctx); return CF_OK; }
+int cf_pyrdown_gauss_f32(cf_ctx* ctx, const float* src, int scols, int srows, float* dst)
+{ PREP_PROLOGUE; launch_pyrdown_f32(ctx->stream, src, scols, srows, dst); LAUNCHCHK(ctx); return CF_OK; }
+int cf_pyrdown_gauss_u8(cf_ctx* ctx, const uint8_t* src, int scols, int srows, uint8_t* dst)
+{ PREP_PROLOGUE; launch_pyrdown_u8(ctx->stream, src, scols, srows, dst); LAUNCHCHK(ctx); return CF_OK; }
+int cf_rgba_to_intensity(cf_ctx* ctx, const uint8_t* rgba, int cols, int rows, uint8_t* dst)
+{ PREP_PROLOGUE; launch_intensity(ctx->stream, rgba, cols, rows, dst); LAUNCHCHK(ctx); return CF_OK; }
+int cf_sobel(cf_ctx* ctx, const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy)
+{ PREP_PROLOGUE; launch_sobel(ctx->stream, src, cols, rows, dx, dy); LAUNCHCHK(ctx); return CF_OK; }
+int cf_project_cloud(cf_ctx* ctx, const float* depth, int cols, int rows, cf_cam il, float* cloud3)
+{ PREP_PROLOGUE; launch_cloud(ctx->stream, depth, cols, rows, il, cloud3); LAUNCHCHK(ctx); return CF_OK; }
+int cf_depth_pyramid(cf_ctx* ctx, const float* depth_filtered, int cols, int rows, float* l1, float* l2)
+{
+    PREP_PROLOGUE;
+    launch_pyrdown_f32(ctx->stream, depth_filtered, cols, rows, l1);
+    launch_pyrdown_f32(ctx->stream, l1, cols / 2, rows / 2, l2);
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+// ------------------------------------------------------------ stand-alone reductions ----
+static void se3_unpack_host(const unsigned long long* t, int F, float* A, float* b, float* residual)
+{  // reduce.cu:481-498
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const float value = (float)ldexp((double)(long long)t[shift++], -F);
+            if (j == 6) { if (b) b[i] = value; }
+            else if (A) A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+    if (residual) { residual[0] = (float)ldexp((double)(long long)t[27], -F); residual[1] = (float)(long long)t[28]; }
+}
+
+// Runs one kernel family on the ctx scratch state (single model, level 0 geometry = cols x rows).
+static int scratch_begin(cf_ctx* ctx, int cols, int rows)
+{
+    OdomDev* h = ctx->h_scratch_state;
+    memset(h, 0, sizeof(*h));
+    h->width = cols; h->height = rows;
+    h->icp_acc = ctx->d_acc_a; h->rgb_acc = ctx->d_acc_b;
+    h->icp = 1; h->rgb = 1;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_acc_a, 0, sizeof(unsigned long long) * kGroups * 32, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_acc_b, 0, sizeof(unsigned long long) * kGroups * 32, ctx->stream));
+    return CF_OK;
+}
+static int scratch_commit(cf_ctx* ctx)
+{
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_scratch_state, ctx->h_scratch_state, sizeof(OdomDev), hipMemcpyHostToDevice, ctx->stream));
+    ctx->h_model_ptrs[0] = ctx->d_scratch_state;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_model_ptrs, ctx->h_model_ptrs, sizeof(OdomDev*), hipMemcpyHostToDevice, ctx->stream));
+    return CF_OK;
+}
+static int fetch_totals(cf_ctx* ctx, const unsigned long long* acc, int words)
+{
+    launch_acc_total(ctx->stream, acc, ctx->d_out);
+    LAUNCHCHK(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
+}
+
+int cf_icp_step(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], const float* vmap_curr, const float* nmap_curr,
+                const float Rprev_inv[9], const float tprev[3], cf_cam intr, const float* vmap_g_prev,
+                const float* nmap_g_prev, float dist_thres, float angle_thres, int cols, int rows, float* A_host,
+                float* b_host, float* residual_host, int64_t* sums_host, float* err_surface)
+{
+    if (!ctx || !vmap_curr || !nmap_curr || !vmap_g_prev || !nmap_g_prev || (cols % 4)) return CF_EINVAL;
+    if (int r = scratch_begin(ctx, cols, rows)) return r;
+    OdomDev* h = ctx->h_scratch_state;
+    memcpy(h->Rcurr, Rcurr, 36); memcpy(h->tcurr, tcurr, 12); memcpy(h->Rprev_inv, Rprev_inv, 36); memcpy(h->tprev, tprev, 12);
+    h->intr = intr; h->vmap_curr[0] = vmap_curr; h->nmap_curr[0] = nmap_curr; h->vmap_g_prev[0] = vmap_g_prev;
+    h->nmap_g_prev[0] = nmap_g_prev; h->distThres = dist_thres; h->angleThres = angle_thres; h->err_surface = err_surface;
+    if (int r = scratch_commit(ctx)) return r;
+    launch_icp_models(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, 1, cols, rows, 0, err_surface ? 1 : 0);
+    LAUNCHCHK(ctx);
+    if (int r = fetch_totals(ctx, ctx->d_acc_a, 32)) return r;
+    se3_unpack_host(ctx->h_out, CF_FIX_ICP, A_host, b_host, residual_host);
+    if (sums_host) memcpy(sums_host, ctx->h_out, sizeof(int64_t) * 32);
+    return CF_OK;
+}
+
+int cf_rgb_residual(cf_ctx* ctx, float min_scale, const int16_t* dIdx, const int16_t* dIdy, const float* last_depth,
+                    const float* next_depth, const uint8_t* last_image, const uint8_t* next_image, cf_dataterm* corres,
+                    float max_depth_delta, const float kt[3], const float krkinv[9], int cols, int rows,
+                    int* sigma_sum_host, int* count_host)
+{
+    if (!ctx || !corres || (size_t)cols * rows > (size_t)ctx->cfg.width * ctx->cfg.height) return CF_EINVAL;
+    if (int r = scratch_begin(ctx, cols, rows)) return r;
+    launch_rgb_cand(ctx->stream, dIdx, dIdy, next_depth, next_image, min_scale, cols, rows, ctx->d_cand_scratch);
+    OdomDev* h = ctx->h_scratch_state;
+    h->cand[0] = ctx->d_cand_scratch; h->lastDepth[0] = last_depth; h->nextDepth[0] = next_depth;
+    h->lastImage[0] = last_image; h->nextImage[0] = next_image; h->corres[0] = corres;
+    h->maxDepthDeltaRGB = max_depth_delta; memcpy(h->kt, kt, 12); memcpy(h->krkInv, krkinv, 36);
+    if (int r = scratch_commit(ctx)) return r;
+    launch_rgb_residual_models(ctx->stream, ctx->d_model_ptrs, 1, cols, rows, 0);
+    LAUNCHCHK(ctx);
+    if (int r = fetch_totals(ctx, ctx->d_acc_a, 32)) return r;
+    if (count_host) *count_host = (int)ctx->h_out[29];
+    if (sigma_sum_host) *sigma_sum_host = (int)ctx->h_out[30];
+    return CF_OK;
+}
+
+int cf_rgb_step(cf_ctx* ctx, const cf_dataterm* corres, float sigma, const float* cloud3, float fx, float fy,
+                const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows, float* A_host,
+                float* b_host, int64_t* sums_host)
+{
+    if (!ctx || !corres) return CF_EINVAL;
+    if (int r = scratch_begin(ctx, cols, rows)) return r;
+    OdomDev* h = ctx->h_scratch_state;
+    h->corres[0] = const_cast<cf_dataterm*>(corres); h->cloud[0] = cloud3; h->dIdx[0] = dIdx; h->dIdy[0] = dIdy;
+    h->sobelScale = sobel_scale; h->intr = cf_cam{fx, fy, 0, 0};
+    // rgb_step_kernel derives sigma from words 29/30 of the ICP accumulator (count, sum diff^2);
+    // encode the caller's sigma so that the same rule reproduces it: sigma == -1 -> rgbOnly,
+    // sigma == 1 -> (count 1, sigma 0) [tmpError == 0 branch], otherwise count = sigma.
+    unsigned long long seed[2] = {0, 0};
+    if (sigma == -1.f) h->rgbOnly = 1;
+    else if (sigma == 1.f) { seed[0] = 1; seed[1] = 0; }
+    else { seed[0] = (unsigned long long)(long long)(int)sigma; seed[1] = 1; }
+    if ((float)(int)sigma != sigma) return CF_EINVAL;  // the reference only ever passes -1, 1 or an integer count
+    if (int r = scratch_commit(ctx)) return r;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_acc_a + 29, seed, sizeof(seed), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // seed is on the host stack
+    launch_rgb_step_models(ctx->stream, ctx->d_model_ptrs, 1, cols, rows, 0);
+    LAUNCHCHK(ctx);
+    if (int r = fetch_totals(ctx, ctx->d_acc_b, 32)) return r;
+    se3_unpack_host(ctx->h_out, CF_FIX_RGB, A_host, b_host, nullptr);
+    if (sums_host) memcpy(sums_host, ctx->h_out, sizeof(int64_t) * 32);
+    return CF_OK;
+}
+
+int cf_so3_step(cf_ctx* ctx, const uint8_t* last_image, const uint8_t* next_image, const float image_basis[9],
+                const float kinv[9], const float krlr[9], int cols, int rows, float* A_host, float* b_host,
+                float* residual_host, int64_t* sums_host)
+{
+    if (!ctx) return CF_EINVAL;
+    launch_so3_step(ctx->stream, last_image, next_image, image_basis, kinv, krlr, cols, rows, ctx->d_out);
+    LAUNCHCHK(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long* t = ctx->h_out;
+    int shift = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) {  // reduce.cu:1161-1172
+            const float value = (float)ldexp((double)(long long)t[shift++], -CF_FIX_SO3);
+            if (j == 3) { if (b_host) b_host[i] = value; }
+            else if (A_host) A_host[j * 3 + i] = A_host[i * 3 + j] = value;
+        }
+    if (residual_host) { residual_host[0] = (float)ldexp((double)(long long)t[9], -CF_FIX_SO3); residual_host[1] = (float)(long long)t[10]; }
+    if (sums_host) memcpy(sums_host, t, sizeof(int64_t) * 16);
+    return CF_OK;
+}
+
+// ----------------------------------------------------------------------- RGBDOdometry ----
+int cf_odom_create(cf_ctx* ctx, cf_odom** out)
+{
+    if (!ctx || !out) return CF_EINVAL;
+    cf_odom* od = new cf_odom();
+    od->ctx = ctx;
+    *out = od;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    const size_t n0 = (size_t)W * H;
+    if (int r = dmalloc(ctx, &od->vmaps_tmp, n0 * 4)) return r;
+    if (int r = dmalloc(ctx, &od->nmaps_tmp, n0 * 4)) return r;
+    for (int i = 0; i < CF_NUM_PYRS; i++) {
+        const size_t n = (size_t)(W >> i) * (H >> i);
+        if (int r = dmalloc(ctx, &od->vmap_g_prev[i], n * 3)) return r;
+        if (int r = dmalloc(ctx, &od->nmap_g_prev[i], n * 3)) return r;
+        if (int r = dmalloc(ctx, &od->vmap_curr[i], n * 3)) return r;
+        if (int r = dmalloc(ctx, &od->nmap_curr[i], n * 3)) return r;
+        if (int r = dmalloc(ctx, &od->lastDepth[i], n)) return r;
+        if (int r = dmalloc(ctx, &od->nextDepth[i], n)) return r;
+        if (int r = dmalloc(ctx, &od->lastImage[i], n)) return r;
+        if (int r = dmalloc(ctx, &od->nextImage[i], n)) return r;
+        if (int r = dmalloc(ctx, &od->lastNextImage[i], n)) return r;
+        if (int r = dmalloc(ctx, &od->dIdx[i], n)) return r;
+        if (int r = dmalloc(ctx, &od->dIdy[i], n)) return r;
+        if (int r = dmalloc(ctx, &od->cloud[i], n * 3)) return r;
+        if (int r = dmalloc(ctx, &od->corres[i], n)) return r;
+        if (int r = dmalloc(ctx, &od->cand[i], n)) return r;
+        od->ext_vmap_curr[i] = nullptr; od->ext_nmap_curr[i] = nullptr;
+    }
+    if (int r = dmalloc(ctx, &od->icp_acc, (size_t)kGroups * 32)) return r;
+    if (int r = dmalloc(ctx, &od->rgb_acc, (size_t)kGroups * 32)) return r;
+    if (int r = dmalloc(ctx, &od->d_state, 1)) return r;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&od->h_state), sizeof(OdomDev)));
+    memset(od->h_state, 0, sizeof(OdomDev));
+    // RGBDOdometry ctor defaults: RGBDOdometry.h:45-46, RGBDOdometry.cpp:31-36,103-105
+    od->distThres = 0.10f;
+    od->angleThres = (float)sin(20.f * 3.14159254f / 180.f);
+    od->sobelScale = (float)(1.0 / pow(2.0, 3));
+    od->maxDepthDeltaRGB = 0.07f; od->maxDepthRGB = 6.0f;
+    od->minGrad[0] = 5; od->minGrad[1] = 3; od->minGrad[2] = 1;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
+}
+
+void cf_odom_destroy(cf_odom* od)
+{
+    if (!od) return;
+    (void)hipStreamSynchronize(od->ctx->stream);
+    (void)hipFree(od->vmaps_tmp); (void)hipFree(od->nmaps_tmp);
+    for (int i = 0; i < CF_NUM_PYRS; i++) {
+        (void)hipFree(od->vmap_g_prev[i]); (void)hipFree(od->nmap_g_prev[i]); (void)hipFree(od->vmap_curr[i]);
+        (void)hipFree(od->nmap_curr[i]); (void)hipFree(od->lastDepth[i]); (void)hipFree(od->nextDepth[i]);
+        (void)hipFree(od->lastImage[i]); (void)hipFree(od->nextImage[i]); (void)hipFree(od->lastNextImage[i]);
+        (void)hipFree(od->dIdx[i]); (void)hipFree(od->dIdy[i]); (void)hipFree(od->cloud[i]); (void)hipFree(od->corres[i]);
+        (void)hipFree(od->cand[i]);
+    }
+    (void)hipFree(od->icp_acc); (void)hipFree(od->rgb_acc); (void)hipFree(od->d_state);
+    (void)hipHostFree(od->h_state);
+    delete od;
+}
+
+// RGBDOdometry::initICPModel, RGBDOdometry.cpp:143-175.  The reference copies the GL textures into
+// vmaps_tmp/nmaps_tmp first (two 4.9 MB interop copies); vmaps_tmp is kept because initRGBModel /
+// initRGB read depth from it afterwards (:179).
+int cf_odom_init_icp_model(cf_odom* od, const float* pred_v4, const float* pred_n4, const float pose[16])
+{
+    if (!od || !pred_v4 || !pred_n4 || !pose) return CF_EINVAL;
+    cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    HIPCHK(ctx, hipMemcpyAsync(od->vmaps_tmp, pred_v4, (size_t)W * H * 16, hipMemcpyDeviceToDevice, s));
+    launch_copy_maps(s, od->vmaps_tmp, pred_n4, W, H, od->vmap_g_prev[0], od->nmap_g_prev[0]);
+    for (int i = 1; i < CF_NUM_PYRS; ++i) {
+        launch_resize_map(s, od->vmap_g_prev[i - 1], W >> (i - 1), H >> (i - 1), od->vmap_g_prev[i], false);
+        launch_resize_map(s, od->nmap_g_prev[i - 1], W >> (i - 1), H >> (i - 1), od->nmap_g_prev[i], true);
+    }
+    const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+    const float t[3] = {pose[3], pose[7], pose[11]};
+    for (int i = 0; i < CF_NUM_PYRS; ++i) launch_transform_maps(s, od->vmap_g_prev[i], od->nmap_g_prev[i], W >> i, H >> i, R, t);
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+// RGBDOdometry::populateRGBDData, RGBDOdometry.cpp:177-194
+static int populate_rgbd(cf_odom* od, const uint8_t* rgba, float* const* depths, uint8_t* const* images)
+{
+    cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    launch_vertices_to_depth(s, od->vmaps_tmp, W, H, od->maxDepthRGB, depths[0]);
+    for (int i = 0; i + 1 < CF_NUM_PYRS; i++) launch_pyrdown_f32(s, depths[i], W >> i, H >> i, depths[i + 1]);
+    launch_intensity(s, rgba, W, H, images[0]);
+    for (int i = 0; i + 1 < CF_NUM_PYRS; i++) launch_pyrdown_u8(s, images[i], W >> i, H >> i, images[i + 1]);
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+int cf_odom_init_rgb_model(cf_odom* od, const uint8_t* pred_rgba) { if (!od || !pred_rgba) return CF_EINVAL; return populate_rgbd(od, pred_rgba, od->lastDepth, od->lastImage); }
+int cf_odom_init_rgb(cf_odom* od, const uint8_t* rgba) { if (!od || !rgba) return CF_EINVAL; return populate_rgbd(od, rgba, od->nextDepth, od->nextImage); }
+
+int cf_odom_init_first_rgb(cf_odom* od, const uint8_t* rgba)
+{  // RGBDOdometry.cpp:206-215
+    if (!od || !rgba) return CF_EINVAL;
+    cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    launch_intensity(s, rgba, W, H, od->lastNextImage[0]);
+    for (int i = 0; i + 1 < CF_NUM_PYRS; i++) launch_pyrdown_u8(s, od->lastNextImage[i], W >> i, H >> i, od->lastNextImage[i + 1]);
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+int cf_odom_init_icp(cf_odom* od, const float* const depth_pyr[CF_NUM_PYRS], float depth_cutoff)
+{  // RGBDOdometry.cpp:110-118
+    if (!od || !depth_pyr) return CF_EINVAL;
+    cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    const cf_cam intr = {ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy};
+    for (int i = 0; i < CF_NUM_PYRS; ++i) {
+        const int div = 1 << i;
+        const cf_cam il = {intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
+        launch_vmap(s, depth_pyr[i], W >> i, H >> i, il, depth_cutoff, od->vmap_curr[i]);
+        launch_nmap(s, od->vmap_curr[i], W >> i, H >> i, od->nmap_curr[i]);
+        od->ext_vmap_curr[i] = nullptr; od->ext_nmap_curr[i] = nullptr;
+    }
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+int cf_odom_bind_frame_maps(cf_odom* od, const float* const vmaps[CF_NUM_PYRS], const float* const nmaps[CF_NUM_PYRS])
+{
+    if (!od) return CF_EINVAL;
+    for (int i = 0; i < CF_NUM_PYRS; i++) { od->ext_vmap_curr[i] = vmaps[i]; od->ext_nmap_curr[i] = nmaps[i]; }
+    return CF_OK;
+}
+
+static void inv33f_host(const float a[9], float o[9])
+{  // Rprev.inverse() (RGBDOdometry.cpp:316), cofactor form
+    float c00 = a[4] * a[8] - a[5] * a[7];
+    float c01 = a[5] * a[6] - a[3] * a[8];
+    float c02 = a[3] * a[7] - a[4] * a[6];
+    float det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    float id = 1.0f / det;
+    o[0] = c00 * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    o[3] = c01 * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    o[6] = c02 * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+}
+
+// enqueue everything one model needs before the lock-step GN loop
+static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* opts, float* err_surface)
+{
+    cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    const bool icp = !opts->rgb_only && opts->icp_weight > 0;
+    const bool rgb = opts->rgb_only || opts->icp_weight < 100;
+    const cf_cam intr = {ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy};
+    if (rgb) {
+        for (int i = 0; i < CF_NUM_PYRS; i++) {
+            const int div = 1 << i;
+            const cf_cam il = {intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
+            launch_sobel(s, od->nextImage[i], W >> i, H >> i, od->dIdx[i], od->dIdy[i]);  // RGBDOdometry.cpp:231-235
+            const float minScale = (float)(pow((double)od->minGrad[i], 2.0) / pow((double)od->sobelScale, 2.0));
+            launch_rgb_cand(s, od->dIdx[i], od->dIdy[i], od->nextDepth[i], od->nextImage[i], minScale, W >> i, H >> i, od->cand[i]);
+            launch_cloud(s, od->lastDepth[i], W >> i, H >> i, il, od->cloud[i]);  // :333
+        }
+    }
+    OdomDev* h = od->h_state;
+    for (int i = 0; i < CF_NUM_PYRS; i++) {
+        h->vmap_curr[i] = od->ext_vmap_curr[i] ? od->ext_vmap_curr[i] : od->vmap_curr[i];
+        h->nmap_curr[i] = od->ext_nmap_curr[i] ? od->ext_nmap_curr[i] : od->nmap_curr[i];
+        h->vmap_g_prev[i] = od->vmap_g_prev[i]; h->nmap_g_prev[i] = od->nmap_g_prev[i];
+        h->lastDepth[i] = od->lastDepth[i]; h->nextDepth[i] = od->nextDepth[i];
+        h->lastImage[i] = od->lastImage[i]; h->nextImage[i] = od->nextImage[i]; h->lastNextImage[i] = od->lastNextImage[i];
+        h->dIdx[i] = od->dIdx[i]; h->dIdy[i] = od->dIdy[i]; h->cloud[i] = od->cloud[i]; h->corres[i] = od->corres[i];
+        h->cand[i] = od->cand[i];
+        h->minGrad[i] = od->minGrad[i];
+    }
+    h->icp_acc = od->icp_acc; h->rgb_acc = od->rgb_acc; h->err_surface = err_surface;
+    h->intr = intr; h->width = W; h->height = H;
+    h->distThres = od->distThres; h->angleThres = od->angleThres; h->sobelScale = od->sobelScale;
+    h->maxDepthDeltaRGB = od->maxDepthDeltaRGB; h->icpWeight = opts->icp_weight;
+    h->icp = icp; h->rgb = rgb; h->rgbOnly = opts->rgb_only;
+    const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+    const float t[3] = {pose[3], pose[7], pose[11]};
+    memcpy(h->Rprev, R, 36); memcpy(h->tprev, t, 12); memcpy(h->Rcurr, R, 36); memcpy(h->tcurr, t, 12);
+    inv33f_host(R, h->Rprev_inv);
+    memset(&h->stats, 0, sizeof(h->stats));
+    HIPCHK(ctx, hipMemcpyAsync(od->d_state, h, sizeof(OdomDev), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemsetAsync(od->icp_acc, 0, sizeof(unsigned long long) * kGroups * 32, s));
+    HIPCHK(ctx, hipMemsetAsync(od->rgb_acc, 0, sizeof(unsigned long long) * kGroups * 32, s));
+    od->pending_so3_swap = opts->so3 != 0;
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const float* const* poses_in,
+                              const cf_track_opts* opts, float* const* err_surfaces)
+{
+    if (!ctx || !ods || n <= 0 || n > ctx->cfg.max_models || !poses_in || !opts) return CF_EINVAL;
+    for (int m = 0; m < n; m++) {
+        if (int r = odom_prepare(ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr)) return r;
+        ctx->h_model_ptrs[m] = ods[m]->d_state;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_model_ptrs, ctx->h_model_ptrs, sizeof(OdomDev*) * n, hipMemcpyHostToDevice, ctx->stream));
+    const bool icp = !opts->rgb_only && opts->icp_weight > 0;
+    const bool rgb = opts->rgb_only || opts->icp_weight < 100;
+    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, n, ctx->cfg.width, ctx->cfg.height, opts->so3 != 0,
+                    opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, &ctx->prof);
+    LAUNCHCHK(ctx);
+    for (int m = 0; m < n; m++)
+        HIPCHK(ctx, hipMemcpyAsync(ods[m]->h_state, ods[m]->d_state, sizeof(OdomDev), hipMemcpyDeviceToHost, ctx->stream));
+    return CF_OK;
+}
+
+int cf_odom_fetch_result(cf_odom* od, float trans[3], float rot[9], cf_track_stats* stats)
+{
+    if (!od) return CF_EINVAL;
+    cf_ctx* ctx = od->ctx;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (trans) memcpy(trans, od->h_state->tcurr, 12);
+    if (rot) memcpy(rot, od->h_state->Rcurr, 36);
+    if (stats) *stats = od->h_state->stats;
+    if (od->pending_so3_swap) {  // RGBDOdometry.cpp:469-473
+        for (int i = 0; i < CF_NUM_PYRS; i++) std::swap(od->lastNextImage[i], od->nextImage[i]);
+        od->pending_so3_swap = false;
+    }
+    return CF_OK;
+}
+
+int cf_odom_get_incremental_transformation(cf_odom* od, float trans[3], float rot[9], const cf_track_opts* opts,
+                                           float* icp_err_surface, cf_track_stats* stats)
+{
+    if (!od || !trans || !rot || !opts) return CF_EINVAL;
+    const float pose[16] = {rot[0], rot[1], rot[2], trans[0], rot[3], rot[4], rot[5], trans[1],
+                            rot[6], rot[7], rot[8], trans[2], 0, 0, 0, 1};
+    const float* poses[1] = {pose};
+    float* errs[1] = {icp_err_surface};
+    cf_odom* ods[1] = {od};
+    if (int r = cf_odom_track_batch_async(od->ctx, ods, 1, poses, opts, errs)) return r;
+    return cf_odom_fetch_result(od, trans, rot, stats);
+}
+
+int cf_odom_buffer(cf_odom* od, int which, int level, void** dptr, uint64_t* bytes)
+{
+    if (!od || level < 0 || level >= CF_NUM_PYRS || !dptr) return CF_EINVAL;
+    const size_t n = (size_t)(od->ctx->cfg.width >> level) * (od->ctx->cfg.height >> level);
+    void* p = nullptr; size_t b = 0;
+    switch (which) {
+        case 0: p = od->ext_vmap_curr[level] ? (void*)od->ext_vmap_curr[level] : od->vmap_curr[level]; b = n * 12; break;
+        case 1: p = od->ext_nmap_curr[level] ? (void*)od->ext_nmap_curr[level] : od->nmap_curr[level]; b = n * 12; break;
+        case 2: p = od->vmap_g_prev[level]; b = n * 12; break;
+        case 3: p = od->nmap_g_prev[level]; b = n * 12; break;
+        case 4: p = od->lastDepth[level]; b = n * 4; break;
+        case 5: p = od->nextDepth[level]; b = n * 4; break;
+        case 6: p = od->lastImage[level]; b = n; break;
+        case 7: p = od->nextImage[level]; b = n; break;
+        case 8: p = od->lastNextImage[level]; b = n; break;
+        case 9: p = od->dIdx[level]; b = n * 2; break;
+        case 10: p = od->dIdy[level]; b = n * 2; break;
+        case 11: p = od->cloud[level]; b = n * 12; break;
+        case 12: p = od->corres[level]; b = n * 16; break;
+        default: return CF_EINVAL;
+    }
+    *dptr = p; if (bytes) *bytes = b;
+    return CF_OK;
+}
+
+}  // extern "C"

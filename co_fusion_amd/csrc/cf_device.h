@@ -1,0 +1,287 @@
+// cf_device.h -- device-side math for the CDNA4 (gfx950) kernels.
+//
+// All per-element arithmetic is plain IEEE f32/f64 (+ - * / sqrt) compiled with
+// -ffp-contract=off, in the operation order of the reference's CUDA kernels
+// (Core/Cuda/operators.cuh:55-91), so integer decisions (gating, rounding to
+// pixels, validity) are reproducible bit-for-bit against the CPU oracle.
+//
+// Normal-equation sums are accumulated EXACTLY: each product row_i*row_j is
+// formed in f64 (exact for f32 inputs), scaled by 2^F and rounded once to an
+// integer with the "magic number" trick, then added into wrapping 64-bit
+// integers.  Integer sums are order independent => the result does not depend
+// on launch shape, wave scheduling or GPU count.  (The reference sums f32 in a
+// launch-shape dependent tree, Core/Cuda/reduce.cu:90-165.)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cf {
+
+constexpr int kFixICP = 32;
+constexpr int kFixRGB = 32;
+constexpr int kFixSO3 = 12;
+constexpr int kSE3Words = 32;  // 27 products, residual, inliers, 3 pad
+constexpr int kSO3Words = 16;  // 9 products, residual, inliers, pad
+
+struct f3 { float x, y, z; };
+struct m33 { float m[9]; };  // row-major == reference mat33 (types.cuh:61-73)
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b)
+{
+    return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float norm(f3 a) { return __fsqrt_rn(dot(a, a)); }
+__device__ __forceinline__ f3 normalized(f3 a)
+{
+    const float rn = 1.0f / __fsqrt_rn(dot(a, a));
+    return f3{a.x * rn, a.y * rn, a.z * rn};
+}
+__device__ __forceinline__ f3 mul(const m33& m, f3 a)
+{
+    return f3{m.m[0] * a.x + m.m[1] * a.y + m.m[2] * a.z, m.m[3] * a.x + m.m[4] * a.y + m.m[5] * a.z,
+              m.m[6] * a.x + m.m[7] * a.y + m.m[8] * a.z};
+}
+
+__device__ __forceinline__ float qnan() { return __int_as_float(0x7fffffff); }
+__device__ __forceinline__ bool is_nan(float v) { return v != v; }
+__device__ __forceinline__ bool is_finite(float v) { return fabsf(v) < __int_as_float(0x7f800000); }
+
+// __float2int_rn semantics: round-half-even, saturating, NaN -> 0
+__device__ __forceinline__ int f2i_rn(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)rintf(v);
+}
+
+// ---- exact fixed-point accumulation --------------------------------------------
+// bits(1.5*2^52 + q) = bits(1.5*2^52) + q for |q| < 2^51, so adding the raw bit
+// patterns accumulates q; the n*bits(magic) offset is removed once per thread.
+constexpr double kMagic = 6755399441055744.0;                 // 1.5 * 2^52
+constexpr unsigned long long kMagicBits = 0x4338000000000000ull;
+
+template <int F>
+__device__ __forceinline__ unsigned long long fix_bits(double a_scaled /* a*2^F */, double b)
+{
+    // p = a*b*2^F is exact in f64 (48-bit product, power-of-two scale); clamp to +-2^50
+    double p = a_scaled * b;
+    p = fmin(fmax(p, -1125899906842624.0), 1125899906842624.0);  // NaN -> -2^50?  callers never pass NaN
+    return (unsigned long long)__double_as_longlong(p + kMagic);
+}
+
+// 64-lane butterfly that reduces NV (<=32, power of two) 64-bit values per lane to one
+// total per lane: after the call lane l holds the wave total of value index
+// (l >> (6 - log2(NV)... see below) in acc[0].
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor((int)lo, mask, 64);
+    hi = __shfl_xor((int)hi, mask, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Reduce acc[0..31] across the 64 lanes of a wave.  Returns, in lane l, the wave
+// total of value index ((l >> 1) & 31).  31 + 1 exchanges instead of 32 * 6.
+__device__ __forceinline__ unsigned long long wave_reduce32_u64(unsigned long long (&acc)[32], int lane)
+{
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const int m = 32 >> s;      // lane xor distance
+        const int half = 16 >> s;   // values kept after this step
+        const bool upper = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < half; i++) {
+            unsigned long long send = upper ? acc[i] : acc[i + half];
+            unsigned long long keep = upper ? acc[i + half] : acc[i];
+            acc[i] = keep + shfl_xor_u64(send, m);
+        }
+    }
+    return acc[0] + shfl_xor_u64(acc[0], 1);
+}
+
+// 16-value flavour (SO3): lane l ends with the total of value index ((l >> 2) & 15)
+__device__ __forceinline__ unsigned long long wave_reduce16_u64(unsigned long long (&acc)[16], int lane)
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int m = 32 >> s;
+        const int half = 8 >> s;
+        const bool upper = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < half; i++) {
+            unsigned long long send = upper ? acc[i] : acc[i + half];
+            unsigned long long keep = upper ? acc[i + half] : acc[i];
+            acc[i] = keep + shfl_xor_u64(send, m);
+        }
+    }
+    unsigned long long v = acc[0] + shfl_xor_u64(acc[0], 2);
+    return v + shfl_xor_u64(v, 1);
+}
+
+// ---- deterministic f64 sin/cos (same spec as oracle/orc_math.h: orc_sincos) ------
+__device__ __forceinline__ void det_sincos(double x, double* s, double* c)
+{
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_1 = 1.57079632673412561417e+00;
+    const double pio2_1t = 6.07710050650619224932e-11;
+    double fn = rint(x * two_over_pi);
+    double r = (x - fn * pio2_1) - fn * pio2_1t;
+    long long n = (long long)fn;
+    double r2 = r * r;
+    double sp = -1.0 / 355687428096000.0;
+    sp = sp * r2 + 1.0 / 1307674368000.0;
+    sp = sp * r2 - 1.0 / 6227020800.0;
+    sp = sp * r2 + 1.0 / 39916800.0;
+    sp = sp * r2 - 1.0 / 362880.0;
+    sp = sp * r2 + 1.0 / 5040.0;
+    sp = sp * r2 - 1.0 / 120.0;
+    sp = sp * r2 + 1.0 / 6.0;
+    double sr = r - r * r2 * sp;
+    double cp = 1.0 / 20922789888000.0;
+    cp = cp * r2 - 1.0 / 87178291200.0;
+    cp = cp * r2 + 1.0 / 479001600.0;
+    cp = cp * r2 - 1.0 / 3628800.0;
+    cp = cp * r2 + 1.0 / 40320.0;
+    cp = cp * r2 - 1.0 / 720.0;
+    cp = cp * r2 + 1.0 / 24.0;
+    cp = cp * r2 - 1.0 / 2.0;
+    double cr = 1.0 + r2 * cp;
+    switch ((int)(n & 3)) {
+        case 0: *s = sr; *c = cr; break;
+        case 1: *s = cr; *c = -sr; break;
+        case 2: *s = -sr; *c = -cr; break;
+        default: *s = -cr; *c = sr; break;
+    }
+}
+
+// OdometryProvider::rodrigues (Core/Utils/OdometryProvider.h:32-67)
+__device__ inline void rodrigues(const double w[3], double R[9])
+{
+    double rx = w[0], ry = w[1], rz = w[2];
+    double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    if (theta >= 2.2204460492503131e-16) {
+        double s, c;
+        det_sincos(theta, &s, &c);
+        double c1 = 1.0 - c;
+        double itheta = 1.0 / theta;
+        rx *= itheta; ry *= itheta; rz *= itheta;
+        const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+        const double rx_[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * rx_[k];
+    }
+}
+
+template <typename T>
+__device__ inline void inv33(const T a[9], T o[9])
+{
+    T c00 = a[4] * a[8] - a[5] * a[7];
+    T c01 = a[5] * a[6] - a[3] * a[8];
+    T c02 = a[3] * a[7] - a[4] * a[6];
+    T det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    T id = (T)1 / det;
+    o[0] = c00 * id;
+    o[1] = (a[2] * a[7] - a[1] * a[8]) * id;
+    o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    o[3] = c01 * id;
+    o[4] = (a[0] * a[8] - a[2] * a[6]) * id;
+    o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    o[6] = c02 * id;
+    o[7] = (a[1] * a[6] - a[0] * a[7]) * id;
+    o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+}
+
+template <typename T>
+__device__ inline void mul33(const T a[9], const T b[9], T o[9])
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            o[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
+}
+
+__device__ inline void mul44(const double a[16], const double b[16], double o[16])
+{
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = a[i * 4 + 0] * b[0 * 4 + j];
+            s = s + a[i * 4 + 1] * b[1 * 4 + j];
+            s = s + a[i * 4 + 2] * b[2 * 4 + j];
+            s = s + a[i * 4 + 3] * b[3 * 4 + j];
+            o[i * 4 + j] = s;
+        }
+}
+
+__device__ inline void inv44_affine(const double a[16], double o[16])
+{
+    double L[9] = {a[0], a[1], a[2], a[4], a[5], a[6], a[8], a[9], a[10]}, Li[9];
+    inv33<double>(L, Li);
+    for (int i = 0; i < 3; i++) {
+        o[i * 4 + 0] = Li[i * 3 + 0]; o[i * 4 + 1] = Li[i * 3 + 1]; o[i * 4 + 2] = Li[i * 3 + 2];
+        o[i * 4 + 3] = -(Li[i * 3 + 0] * a[3] + Li[i * 3 + 1] * a[7] + Li[i * 3 + 2] * a[11]);
+    }
+    o[12] = 0; o[13] = 0; o[14] = 0; o[15] = 1;
+}
+
+// LDL^T with diagonal pivoting; zero pivots -> zero solution component (the
+// ldlt().solve() behaviour the reference relies on, RGBDOdometry.cpp:435).
+template <typename T, int N>
+__device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tiny)
+{
+    T A[N * N], y[N], d[N];
+    int perm[N];
+    for (int i = 0; i < N * N; i++) A[i] = Ain[i];
+    for (int i = 0; i < N; i++) perm[i] = i;
+    for (int k = 0; k < N; k++) {
+        int p = k;
+        T best = A[k * N + k] < 0 ? -A[k * N + k] : A[k * N + k];
+        for (int i = k + 1; i < N; i++) {
+            T v = A[i * N + i] < 0 ? -A[i * N + i] : A[i * N + i];
+            if (v > best) { best = v; p = i; }
+        }
+        if (p != k) {
+            for (int j = 0; j < N; j++) { T t = A[k * N + j]; A[k * N + j] = A[p * N + j]; A[p * N + j] = t; }
+            for (int i = 0; i < N; i++) { T t = A[i * N + k]; A[i * N + k] = A[i * N + p]; A[i * N + p] = t; }
+            int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+        }
+        T akk = A[k * N + k];
+        d[k] = akk;
+        T aabs = akk < 0 ? -akk : akk;
+        if (aabs > tiny) {
+            for (int i = k + 1; i < N; i++) A[i * N + k] = A[i * N + k] / akk;
+            for (int i = k + 1; i < N; i++)
+                for (int j = k + 1; j <= i; j++) {
+                    A[i * N + j] = A[i * N + j] - A[i * N + k] * akk * A[j * N + k];
+                    A[j * N + i] = A[i * N + j];
+                }
+        } else {
+            for (int i = k + 1; i < N; i++) A[i * N + k] = 0;
+        }
+    }
+    for (int i = 0; i < N; i++) {
+        T s = b[perm[i]];
+        for (int j = 0; j < i; j++) s = s - A[i * N + j] * y[j];
+        y[i] = s;
+    }
+    for (int i = 0; i < N; i++) {
+        T aabs = d[i] < 0 ? -d[i] : d[i];
+        y[i] = (aabs > tiny) ? y[i] / d[i] : (T)0;
+    }
+    for (int i = N - 1; i >= 0; i--) {
+        T s = y[i];
+        for (int j = i + 1; j < N; j++) s = s - A[j * N + i] * y[j];
+        y[i] = s;
+    }
+    for (int i = 0; i < N; i++) x[perm[i]] = y[i];
+}
+
+// exact conversion of a fixed-point sum to the reference's f32 host value
+__device__ __forceinline__ float fix_to_f32(long long q, int F) { return (float)ldexp((double)q, -F); }
+
+}  // namespace cf

@@ -1,0 +1,57 @@
+// cf_host.h -- host-side object definitions behind the opaque C-ABI handles.
+#pragma once
+
+#include <string>
+
+#include "cf_kernels.h"
+
+struct cf_ctx {
+    cf_config cfg{};
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string last_error;
+    cf::IcpLaunch icp_launch{256, 1};
+    // scratch for the stand-alone reduction steps
+    unsigned long long* d_acc_a = nullptr;
+    unsigned long long* d_acc_b = nullptr;
+    unsigned long long* d_out = nullptr;
+    unsigned long long* h_out = nullptr;  // pinned
+    cf::OdomDev* d_scratch_state = nullptr;
+    cf::OdomDev* h_scratch_state = nullptr;  // pinned
+    cf::OdomDev** d_model_ptrs = nullptr;
+    cf::OdomDev** h_model_ptrs = nullptr;  // pinned
+    uint8_t* d_cand_scratch = nullptr;
+    cf::ProfSink prof{};
+    double prof_ms_accum = 0;
+    void set_error(const std::string& m);
+};
+
+// Device-resident RGBDOdometry (Core/Utils/RGBDOdometry.h:78-137)
+struct cf_odom {
+    cf_ctx* ctx = nullptr;
+    float* vmaps_tmp = nullptr;
+    float* nmaps_tmp = nullptr;
+    float* vmap_g_prev[3]{};
+    float* nmap_g_prev[3]{};
+    float* vmap_curr[3]{};
+    float* nmap_curr[3]{};
+    const float* ext_vmap_curr[3]{};  // frame-shared current maps (all models track the same frame)
+    const float* ext_nmap_curr[3]{};
+    float* lastDepth[3]{};
+    float* nextDepth[3]{};
+    uint8_t* lastImage[3]{};
+    uint8_t* nextImage[3]{};
+    uint8_t* lastNextImage[3]{};
+    int16_t* dIdx[3]{};
+    int16_t* dIdy[3]{};
+    float* cloud[3]{};
+    cf_dataterm* corres[3]{};
+    uint8_t* cand[3]{};
+    unsigned long long* icp_acc = nullptr;
+    unsigned long long* rgb_acc = nullptr;
+    cf::OdomDev* d_state = nullptr;
+    cf::OdomDev* h_state = nullptr;  // pinned
+    float distThres = 0, angleThres = 0, sobelScale = 0, maxDepthDeltaRGB = 0, maxDepthRGB = 0;
+    float minGrad[3]{};
+    bool pending_so3_swap = false;
+};

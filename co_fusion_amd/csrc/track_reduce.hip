@@ -1,0 +1,739 @@
+// track_reduce.hip -- the dense-tracking reductions and the device-resident Gauss-Newton loop.
+//
+// MI355X-native replacement of Core/Cuda/reduce.cu (icpStep / computeRgbResidual / rgbStep /
+// so3Step) and of the host loop RGBDOdometry::getIncrementalTransformation
+// (Core/Utils/RGBDOdometry.cpp:217-477).
+//
+// Design (DESIGN.md "tracking"):
+//  * The reference does, per GN iteration, 3 x (kernel -> 1-block reduceSum -> cudaDeviceSynchronize
+//    -> D2H) and solves the 6x6 system on the host: <= 67 host round trips per model per frame.
+//    Here the pose, the 6x6 solve (f64 LDL^T) and the SE3 update live on the device; one frame's
+//    whole schedule (SO3 pre-alignment + 4/5/10 iterations) is enqueued without any host wait,
+//    and all active models advance in lock-step inside the same launches (blockIdx.y = model).
+//  * Reductions are wave64 butterflies over *integer* (fixed-point) partial sums followed by
+//    grouped 64-bit atomics: exact, order independent, identical for every launch shape / GPU count.
+//  * ICP is HBM/L2-bound streaming (48 B/pixel: 6 coalesced plane loads + 6 gathered loads);
+//    blockIdx -> pixel-range mapping is XCD-aware: workgroup b runs on XCD b%8, and XCD x owns
+//    the x-th horizontal band of the image, so the gathered model-map rows stay in that XCD's
+//    4 MiB L2 across the 19 iterations of a frame.
+#include "cf_device.h"
+#include "cf_kernels.h"
+
+namespace cf {
+
+__device__ __forceinline__ cf_cam cam_level(cf_cam c, int level)
+{  // CameraModel::operator(), types.cuh:94-98
+    const int div = 1 << level;
+    return cf_cam{c.fx / div, c.fy / div, c.cx / div, c.cy / div};
+}
+
+__device__ __forceinline__ float clamp_row(float v, float lim) { return fminf(fmaxf(v, -lim), lim); }
+
+// acc[k] += RNE(row_i*row_j*2^F) for the 27 upper-triangular SE3 products + residual
+template <int F>
+__device__ __forceinline__ void se3_accumulate(const float (&row)[7], unsigned long long (&acc)[32])
+{
+    constexpr float lim = (float)(1 << ((50 - F) / 2));
+    constexpr float scale = (F == 32) ? 4294967296.0f : (float)(1u << (F & 31));
+    double r[7], rs[6];
+#pragma unroll
+    for (int i = 0; i < 7; i++) r[i] = (double)clamp_row(row[i], lim);
+#pragma unroll
+    for (int i = 0; i < 6; i++) rs[i] = (double)(clamp_row(row[i], lim) * scale);
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 7; j++) acc[k++] += (unsigned long long)__double_as_longlong(fma(rs[i], r[j], kMagic));
+    acc[27] += (unsigned long long)__double_as_longlong(fma(r[6] * (double)scale, r[6], kMagic));
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross-wave combine + grouped atomics.  v = wave total of word ((lane>>1)&31) (wave_reduce32_u64).
+template <int MAXW>
+__device__ __forceinline__ void block_commit32(unsigned long long v, int lane, int wave, int nwaves,
+                                               unsigned long long* __restrict__ dst /* [32] of this group */)
+{
+    __shared__ unsigned long long lds[MAXW][32];
+    if ((lane & 1) == 0) lds[wave][lane >> 1] = v;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        unsigned long long t = 0;
+        for (int w = 0; w < nwaves; w++) t += lds[w][threadIdx.x];
+        if (t != 0) atomicAdd(&dst[threadIdx.x], t);
+    }
+}
+
+// ================================================================================================
+// ICP:  ICPReduction::search + getProducts, reduce.cu:283-394
+// ================================================================================================
+struct IcpPix { float row[7]; float err; int found; };
+
+__device__ __forceinline__ void icp_pixel(const m33& Rcurr, const f3& tcurr, const m33& Rprev_inv, const f3& tprev,
+                                          const cf_cam& intr, float distThres, float angleThres, int cols, int rows, int N,
+                                          const float* __restrict__ vp, const float* __restrict__ np, f3 vcurr, f3 ncurr,
+                                          float (&row)[7], float& err, int& found)
+{
+#pragma unroll
+    for (int i = 0; i < 7; i++) row[i] = 0.f;
+    err = 0.f; found = 0;
+    const f3 vcurr_g = mul(Rcurr, vcurr) + tcurr;
+    const f3 vcurr_cp = mul(Rprev_inv, vcurr_g - tprev);
+    const int ux = f2i_rn(vcurr_cp.x * intr.fx / vcurr_cp.z + intr.cx);
+    const int uy = f2i_rn(vcurr_cp.y * intr.fy / vcurr_cp.z + intr.cy);
+    if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0) return;
+    const int g = uy * cols + ux;
+    const f3 vprev_g = {vp[g], vp[g + N], vp[g + 2 * N]};
+    const f3 nprev_g = {np[g], np[g + N], np[g + 2 * N]};
+    const f3 ncurr_g = mul(Rcurr, ncurr);
+    const float dist = norm(vprev_g - vcurr_g);
+    const float sine = norm(cross(ncurr_g, nprev_g));
+    err = is_finite(dist) ? dist : 0.0f;
+    found = (sine < angleThres && dist <= distThres && !is_nan(ncurr.x) && !is_nan(nprev_g.x)) ? 1 : 0;
+    if (found) {
+        const f3 s_cp = mul(Rprev_inv, vcurr_g - tprev);
+        const f3 d_cp = mul(Rprev_inv, vprev_g - tprev);
+        const f3 n_cp = mul(Rprev_inv, nprev_g);
+        const f3 cr = cross(s_cp, n_cp);
+        row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
+        row[3] = cr.x; row[4] = cr.y; row[5] = cr.z;
+        row[6] = dot(n_cp, s_cp - d_cp);
+    }
+}
+
+template <int PPT> struct VecF;
+template <> struct VecF<1> { using T = float; };
+template <> struct VecF<2> { using T = float2; };
+template <> struct VecF<4> { using T = float4; };
+
+template <int PPT>
+__device__ __forceinline__ void load_vec(const float* p, float (&o)[PPT])
+{
+    using V = typename VecF<PPT>::T;
+    const V v = *reinterpret_cast<const V*>(p);
+    const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+    for (int i = 0; i < PPT; i++) o[i] = f[i];
+}
+
+// XCD-aware logical block id: hardware block b lands on XCD b%8; give XCD x the x-th contiguous
+// range of logical blocks (= a horizontal band of the image).
+__device__ __forceinline__ int xcd_logical_block(int b, int nlog)
+{
+    const int per = (nlog + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+template <int PPT, int LEVEL_TAG>
+__global__ void __launch_bounds__(1024) icp_reduce_kernel(OdomDev* const* __restrict__ models, int level, int write_err)
+{
+    const OdomDev* __restrict__ od = models[blockIdx.y];
+    if (!od->icp || od->level_done) return;
+    const int cols = od->width >> level, rows = od->height >> level, N = cols * rows;
+    const int T = blockDim.x;
+    const int nlog = (N + T * PPT - 1) / (T * PPT);
+    const int lb = xcd_logical_block(blockIdx.x, nlog);
+    if (lb >= nlog) return;
+
+    m33 Rcurr, Rprev_inv;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { Rcurr.m[i] = od->Rcurr[i]; Rprev_inv.m[i] = od->Rprev_inv[i]; }
+    const f3 tcurr = {od->tcurr[0], od->tcurr[1], od->tcurr[2]};
+    const f3 tprev = {od->tprev[0], od->tprev[1], od->tprev[2]};
+    const cf_cam intr = cam_level(od->intr, level);
+    const float distThres = od->distThres, angleThres = od->angleThres;
+    const float* __restrict__ vc = od->vmap_curr[level];
+    const float* __restrict__ nc = od->nmap_curr[level];
+    const float* __restrict__ vp = od->vmap_g_prev[level];
+    const float* __restrict__ np = od->nmap_g_prev[level];
+    float* __restrict__ errs = write_err ? od->err_surface : nullptr;
+
+    unsigned long long acc[32];
+#pragma unroll
+    for (int k = 0; k < 28; k++) acc[k] = 0ull - (unsigned long long)PPT * kMagicBits;
+    acc[28] = acc[29] = acc[30] = acc[31] = 0;
+
+    const int i0 = (lb * T + threadIdx.x) * PPT;
+    if (i0 < N) {  // N is a multiple of PPT (cols is), so the whole vector is in range
+        float vx[PPT], vy[PPT], vz[PPT], nx[PPT], ny[PPT], nz[PPT];
+        load_vec<PPT>(vc + i0, vx); load_vec<PPT>(vc + i0 + N, vy); load_vec<PPT>(vc + i0 + 2 * N, vz);
+        load_vec<PPT>(nc + i0, nx); load_vec<PPT>(nc + i0 + N, ny); load_vec<PPT>(nc + i0 + 2 * N, nz);
+#pragma unroll
+        for (int p = 0; p < PPT; p++) {
+            float row[7], err; int found;
+            icp_pixel(Rcurr, tcurr, Rprev_inv, tprev, intr, distThres, angleThres, cols, rows, N, vp, np,
+                      f3{vx[p], vy[p], vz[p]}, f3{nx[p], ny[p], nz[p]}, row, err, found);
+            if (errs) errs[i0 + p] = err;
+            se3_accumulate<kFixICP>(row, acc);
+            acc[28] += (unsigned long long)found;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc[k] = 0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long v = wave_reduce32_u64(acc, lane);
+    block_commit32<16>(v, lane, wave, T >> 6, od->icp_acc + (size_t)(lb % kGroups) * 32);
+}
+
+// ================================================================================================
+// RGB residual: RGBResidual::getProducts, reduce.cu:785-865
+// ================================================================================================
+// The iteration-invariant half of the validity test (window non-zero, gradient magnitude, d1 valid)
+// is hoisted into a per-frame candidate mask; the reference re-evaluates it every iteration.
+__global__ void __launch_bounds__(256) rgb_cand_kernel(const int16_t* __restrict__ dIdx, const int16_t* __restrict__ dIdy,
+                                                       const float* __restrict__ next_depth,
+                                                       const uint8_t* __restrict__ next_image, float min_scale, int cols,
+                                                       int rows, uint8_t* __restrict__ cand)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cols * rows) return;
+    const int i = k / cols, j0 = k - i * cols;
+    uint8_t ok = 0;
+    if (j0 < cols - 5 && i < rows - 1) {
+        bool valid = true;
+        for (int u = max(i - 2, 0); u < min(i + 2, rows); u++)
+            for (int v = max(j0 - 2, 0); v < min(j0 + 2, cols); v++) valid = valid && (next_image[u * cols + v] > 0);
+        if (valid) {
+            const int valx = dIdx[k], valy = dIdy[k];
+            const float mTwo = (float)((valx * valx) + (valy * valy));
+            if (mTwo >= min_scale && !is_nan(next_depth[k])) ok = 1;
+        }
+    }
+    cand[k] = ok;
+}
+
+__global__ void __launch_bounds__(256) rgb_residual_kernel(OdomDev* const* __restrict__ models, int level)
+{
+    const OdomDev* __restrict__ od = models[blockIdx.y];
+    if (!od->rgb || od->level_done) return;
+    const int cols = od->width >> level, rows = od->height >> level, N = cols * rows;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    int cnt = 0, sig = 0;
+    if (k < N) {
+        cf_dataterm c; c.zero_x = c.zero_y = c.one_x = c.one_y = 0; c.diff = 0.f; c.valid = 0;
+        if (od->cand[level][k]) {
+            const int y = k / cols, x = k - y * cols;
+            const float* krk = od->krkInv; const float* kt = od->kt;
+            const float d1 = od->nextDepth[level][k];
+            const float transformed_d1 = (float)(d1 * (krk[6] * x + krk[7] * y + krk[8]) + kt[2]);
+            const int u0 = f2i_rn((d1 * (krk[0] * x + krk[1] * y + krk[2]) + kt[0]) / transformed_d1);
+            const int v0 = f2i_rn((d1 * (krk[3] * x + krk[4] * y + krk[5]) + kt[1]) / transformed_d1);
+            if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+                const float d0 = od->lastDepth[level][v0 * cols + u0];
+                const uint8_t li = od->lastImage[level][v0 * cols + u0];
+                if (d0 > 0 && fabsf(transformed_d1 - d0) <= od->maxDepthDeltaRGB && li != 0) {
+                    c.zero_x = (int16_t)u0; c.zero_y = (int16_t)v0; c.one_x = (int16_t)x; c.one_y = (int16_t)y;
+                    c.diff = (float)od->nextImage[level][k] - (float)li;
+                    c.valid = 1;
+                    cnt = 1;
+                    sig = (int)(c.diff * c.diff);
+                }
+            }
+        }
+        *reinterpret_cast<int4*>(&od->corres[level][k]) = *reinterpret_cast<const int4*>(&c);
+    }
+    // block reduce (count, sigma) -> grouped atomics into words 29/30 of the ICP accumulator
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); sig += __shfl_xor(sig, o, 64); }
+    __shared__ int s_cnt[4], s_sig[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_cnt[wave] = cnt; s_sig[wave] = sig; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int c4 = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        const int g4 = s_sig[0] + s_sig[1] + s_sig[2] + s_sig[3];
+        unsigned long long* dst = od->icp_acc + (size_t)(blockIdx.x % kGroups) * 32;
+        if (c4) atomicAdd(&dst[29], (unsigned long long)c4);
+        if (g4) atomicAdd(&dst[30], (unsigned long long)(long long)g4);
+    }
+}
+
+// sum of word `w` over the groups (wave 0 only; result valid in all lanes of wave 0)
+__device__ __forceinline__ unsigned long long group_sum(const unsigned long long* acc, int w, int lane)
+{
+    unsigned long long v = acc[(size_t)lane * 32 + w];  // kGroups == 64 == lanes
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += shfl_xor_u64(v, o);
+    return v;
+}
+
+// sigma handed to rgbStep (RGBDOdometry.cpp:373-385): (tmpError == 0) ? 1 : count   (sic: the COUNT)
+__device__ __forceinline__ float sigma_val_from(int count, int sigma, int rgbOnly)
+{
+    if (rgbOnly) return -1.f;
+    // tmpError = sqrt(sigma)/count is 0 iff sigma == 0 and count != 0 (0/0 is NaN, NaN != 0)
+    return (sigma == 0 && count != 0) ? 1.f : (float)count;
+}
+
+// ================================================================================================
+// RGB step: RGBReduction::getProducts, reduce.cu:521-604
+// ================================================================================================
+__global__ void __launch_bounds__(256) rgb_step_kernel(OdomDev* const* __restrict__ models, int level)
+{
+    const OdomDev* __restrict__ od = models[blockIdx.y];
+    if (!od->rgb || od->level_done) return;
+    const int cols = od->width >> level, rows = od->height >> level, N = cols * rows;
+    __shared__ float s_sigma;
+    if (threadIdx.x < 64) {
+        const long long cnt = (long long)group_sum(od->icp_acc, 29, threadIdx.x);
+        const long long sg = (long long)group_sum(od->icp_acc, 30, threadIdx.x);
+        if (threadIdx.x == 0) s_sigma = sigma_val_from((int)cnt, (int)sg, od->rgbOnly);
+    }
+    __syncthreads();
+    const float sigma = s_sigma;
+    const cf_cam il = cam_level(od->intr, level);
+    unsigned long long acc[32];
+#pragma unroll
+    for (int k = 0; k < 28; k++) acc[k] = 0ull - kMagicBits;
+    acc[28] = acc[29] = acc[30] = acc[31] = 0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float row[7] = {0, 0, 0, 0, 0, 0, 0};
+    int found = 0;
+    if (i < N) {
+        const int4 raw = *reinterpret_cast<const int4*>(&od->corres[level][i]);
+        const cf_dataterm c = *reinterpret_cast<const cf_dataterm*>(&raw);
+        if (c.valid) {
+            found = 1;
+            float w = sigma + fabsf(c.diff);
+            w = w > 1.19209290E-07F ? 1.0f / w : 1.0f;
+            if (sigma == -1) w = 1;
+            row[6] = -w * c.diff;
+            const float* cp = od->cloud[level] + (size_t)(c.zero_y * cols + c.zero_x) * 3;
+            const float px = cp[0], py = cp[1], pz = cp[2];
+            const float invz = 1.0f / pz;
+            const int o = c.one_y * cols + c.one_x;
+            const float dI_dx_val = w * od->sobelScale * (float)od->dIdx[level][o];
+            const float dI_dy_val = w * od->sobelScale * (float)od->dIdy[level][o];
+            const float v0 = dI_dx_val * il.fx * invz;
+            const float v1 = dI_dy_val * il.fy * invz;
+            const float v2 = -(v0 * px + v1 * py) * invz;
+            row[0] = v0; row[1] = v1; row[2] = v2;
+            row[3] = -pz * v1 + py * v2;
+            row[4] = pz * v0 - px * v2;
+            row[5] = -py * v0 + px * v1;
+        }
+    }
+    se3_accumulate<kFixRGB>(row, acc);
+    acc[28] = (unsigned long long)found;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long v = wave_reduce32_u64(acc, lane);
+    block_commit32<4>(v, lane, wave, 4, od->rgb_acc + (size_t)(blockIdx.x % kGroups) * 32);
+}
+
+// ================================================================================================
+// SO3: SO3Reduction::getProducts, reduce.cu:1007-1090
+// ================================================================================================
+__device__ __forceinline__ void so3_gradient(const uint8_t* __restrict__ img, int cols, int x, int y, float& gx, float& gy)
+{  // reduce.cu:989-1005
+    const float actu = (float)img[y * cols + x];
+    float back = (float)img[y * cols + x - 1], fore = (float)img[y * cols + x + 1];
+    gx = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+    back = (float)img[(y - 1) * cols + x]; fore = (float)img[(y + 1) * cols + x];
+    gy = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+}
+
+// one pass over the level-2 images by a single workgroup; totals[0..10] valid in thread 0..15 of LDS
+__device__ __forceinline__ void so3_pass(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
+                                         const m33& B, const m33& Ki, const float* __restrict__ krlr, int cols, int rows,
+                                         unsigned long long (*lds)[16], unsigned long long* totals)
+{
+    constexpr float lim = (float)(1 << ((50 - kFixSO3) / 2));
+    constexpr float scale = (float)(1 << kFixSO3);
+    const int N = cols * rows, T = blockDim.x;
+    unsigned long long acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[k] = 0;
+    const float a = krlr[0], b = krlr[1], c = krlr[2], d = krlr[3], e = krlr[4], f = krlr[5], g = krlr[6], h = krlr[7],
+                ii = krlr[8];
+    for (int k = threadIdx.x; k < N; k += T) {
+        const int y = k / cols, x = k - y * cols;
+        const f3 unwarped = {(float)x, (float)y, 1.0f};
+        const f3 warped = mul(B, unwarped);
+        const int wx = f2i_rn(warped.x / warped.z), wy = f2i_rn(warped.y / warped.z);
+        if (!(wx >= 1 && wx < cols - 1 && wy >= 1 && wy < rows - 1 && x >= 1 && x < cols - 1 && y >= 1 && y < rows - 1))
+            continue;
+        float gnx, gny, glx, gly;
+        so3_gradient(nextImage, cols, wx, wy, gnx, gny);
+        so3_gradient(lastImage, cols, x, y, glx, gly);
+        const float gx = (gnx + glx) / 2.0f, gy = (gny + gly) / 2.0f;
+        const f3 point = mul(Ki, unwarped);
+        const float z2 = point.z * point.z;
+        const f3 left = {((point.z * (d * gy + a * gx)) - (gy * g * y) - (gx * g * x)) / z2,
+                         ((point.z * (e * gy + b * gx)) - (gy * h * y) - (gx * h * x)) / z2,
+                         ((point.z * (f * gy + c * gx)) - (gy * ii * y) - (gx * ii * x)) / z2};
+        const f3 jac = cross(left, point);
+        const float row[4] = {jac.x, jac.y, jac.z, -((float)nextImage[wy * cols + wx] - (float)lastImage[y * cols + x])};
+        double r[4], rs[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { r[q] = (double)clamp_row(row[q], lim); rs[q] = (double)(clamp_row(row[q], lim) * scale); }
+        int s = 0;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = p; q < 4; q++)
+                acc[s++] += (unsigned long long)__double_as_longlong(fma(rs[p], r[q], kMagic)) - kMagicBits;
+        acc[9] += (unsigned long long)__double_as_longlong(fma(rs[3], r[3], kMagic)) - kMagicBits;
+        acc[10] += 1;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long v = wave_reduce16_u64(acc, lane);
+    if ((lane & 3) == 0) lds[wave][lane >> 2] = v;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        unsigned long long t = 0;
+        for (int w = 0; w < (T >> 6); w++) t += lds[w][threadIdx.x];
+        totals[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+// reduce.cu:1158-1175 host unpack, on device
+__device__ inline void so3_unpack(const unsigned long long* t, float A[9], float b[3], float residual[2])
+{
+    int shift = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) {
+            const float value = fix_to_f32((long long)t[shift++], kFixSO3);
+            if (j == 3) b[i] = value;
+            else A[j * 3 + i] = A[i * 3 + j] = value;
+        }
+    residual[0] = fix_to_f32((long long)t[9], kFixSO3);
+    residual[1] = (float)(long long)t[10];
+}
+
+__device__ inline void k_matrix(cf_cam c, double K[9])
+{
+    for (int i = 0; i < 9; i++) K[i] = 0;
+    K[0] = c.fx; K[4] = c.fy; K[2] = c.cx; K[5] = c.cy; K[8] = 1;
+}
+
+// krkInv / kt for the next iteration (RGBDOdometry.cpp:347-358)
+__device__ inline void prepare_iteration(OdomDev* od, int level)
+{
+    double K[9], Kinv[9], Rt[16];
+    k_matrix(cam_level(od->intr, level), K);
+    inv33<double>(K, Kinv);
+    inv44_affine(od->resultRt, Rt);
+    const double R[9] = {Rt[0], Rt[1], Rt[2], Rt[4], Rt[5], Rt[6], Rt[8], Rt[9], Rt[10]};
+    double tmp[9], KRK[9];
+    mul33<double>(K, R, tmp);
+    mul33<double>(tmp, Kinv, KRK);
+    for (int k = 0; k < 9; k++) od->krkInv[k] = (float)KRK[k];
+    const double tv[3] = {Rt[3], Rt[7], Rt[11]};
+    for (int r = 0; r < 3; r++) od->kt[r] = (float)(K[r * 3 + 0] * tv[0] + K[r * 3 + 1] * tv[1] + K[r * 3 + 2] * tv[2]);
+}
+
+// Stand-alone single SO3 step (C-ABI so3Step): one workgroup, totals to out16
+__global__ void __launch_bounds__(1024) so3_step_kernel(const uint8_t* __restrict__ lastImage,
+                                                        const uint8_t* __restrict__ nextImage, m33 B, m33 Ki, m33 krlr,
+                                                        int cols, int rows, unsigned long long* __restrict__ out16)
+{
+    __shared__ unsigned long long lds[16][16];
+    __shared__ unsigned long long totals[16];
+    so3_pass(lastImage, nextImage, B, Ki, krlr.m, cols, rows, lds, totals);
+    if (threadIdx.x < 16) out16[threadIdx.x] = totals[threadIdx.x];
+}
+
+// Whole SO3 pre-alignment (RGBDOdometry.cpp:239-310) in ONE launch: a persistent workgroup per
+// model iterates (pass -> 3x3 solve -> Rodrigues) up to 10 times with the data-dependent early
+// exits evaluated on the device.  Also seeds resultRt and the first iteration's krkInv/kt.
+__global__ void __launch_bounds__(1024) so3_prealign_kernel(OdomDev* const* __restrict__ models, int do_so3, int first_level)
+{
+    OdomDev* od = models[blockIdx.x];
+    __shared__ unsigned long long lds[16][16];
+    __shared__ unsigned long long totals[16];
+    __shared__ float s_basis[9], s_kinv[9], s_krlr[9];
+    __shared__ int s_done;
+    __shared__ double s_resultR[9];
+    __shared__ double s_K[9], s_Kinv[9];
+    __shared__ float s_Rlr[9];
+    __shared__ float s_lastError, s_lastCount;
+    __shared__ double s_lastResultR[9];
+    const int L = 2, cols = od->width >> L, rows = od->height >> L;
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 9; k++) { s_resultR[k] = (k % 4 == 0) ? 1.0 : 0.0; s_lastResultR[k] = s_resultR[k]; s_Rlr[k] = (k % 4 == 0) ? 1.f : 0.f; }
+        k_matrix(cam_level(od->intr, L), s_K);
+        inv33<double>(s_K, s_Kinv);
+        s_lastError = 3.402823466e+38F / 2; s_lastCount = 3.402823466e+38F / 2;
+        s_done = 0;
+        od->stats.so3_iterations = 0; od->stats.last_so3_error = 0; od->stats.last_so3_count = 0;
+    }
+    __syncthreads();
+    if (do_so3) {
+        for (int it = 0; it < 10; it++) {
+            if (threadIdx.x == 0) {
+                double tmp[9], H[9];
+                mul33<double>(s_K, s_resultR, tmp);
+                mul33<double>(tmp, s_Kinv, H);
+                for (int k = 0; k < 9; k++) { s_basis[k] = (float)H[k]; s_kinv[k] = (float)s_Kinv[k]; s_krlr[k] = (float)tmp[k]; }
+            }
+            __syncthreads();
+            m33 B, Ki;
+            for (int k = 0; k < 9; k++) { B.m[k] = s_basis[k]; Ki.m[k] = s_kinv[k]; }
+            so3_pass(od->lastNextImage[L], od->nextImage[L], B, Ki, s_krlr, cols, rows, lds, totals);
+            if (threadIdx.x == 0) {
+                float jtj[9], jtr[3], residual[2];
+                so3_unpack(totals, jtj, jtr, residual);
+                od->stats.so3_iterations = it + 1;
+                float err = __fsqrt_rn(residual[0]) / residual[1];
+                float cnt = residual[1];
+                if (err < s_lastError && (double)fabsf(s_lastError - cnt) < 0.001) {
+                    s_done = 1;  // "converged" (compares error with COUNT, RGBDOdometry.cpp:285)
+                } else if ((double)err > (double)s_lastError + 0.001) {
+                    err = s_lastError; cnt = s_lastCount;
+                    for (int k = 0; k < 9; k++) s_resultR[k] = s_lastResultR[k];
+                    s_done = 1;
+                } else {
+                    s_lastError = err; s_lastCount = cnt;
+                    for (int k = 0; k < 9; k++) s_lastResultR[k] = s_resultR[k];
+                    float delta[3];
+                    ldlt_solve<float, 3>(jtj, jtr, delta, 1.17549435e-38f);
+                    const double dd[3] = {delta[0], delta[1], delta[2]};
+                    double rotUpdate[9];
+                    rodrigues(dd, rotUpdate);
+                    float ru[9], nr[9];
+                    for (int k = 0; k < 9; k++) ru[k] = (float)rotUpdate[k];
+                    mul33<float>(ru, s_Rlr, nr);
+                    for (int k = 0; k < 9; k++) { s_Rlr[k] = nr[k]; s_resultR[k] = nr[k]; }
+                }
+                od->stats.last_so3_error = err; od->stats.last_so3_count = cnt;
+            }
+            __syncthreads();
+            if (s_done) break;
+        }
+    }
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 16; k++) od->resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+        if (do_so3)
+            for (int x = 0; x < 3; x++)
+                for (int y = 0; y < 3; y++) od->resultRt[x * 4 + y] = s_resultR[x * 3 + y];
+        od->lastRGBError = 3.402823466e+38F;
+        od->level_done = 0;
+        od->residual[0] = 0; od->residual[1] = 0;
+        prepare_iteration(od, first_level);
+    }
+}
+
+// ================================================================================================
+// per-iteration solve: sums -> A,b (f32) -> f64 combine -> LDL^T -> SE3 update -> next krkInv/kt
+// (RGBDOdometry.cpp:371-461, reduce.cu:481-498, OdometryProvider.h:69-89)
+// ================================================================================================
+__device__ inline void se3_unpack(const unsigned long long* t, int F, float A[36], float b[6], float residual[2])
+{
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const float value = fix_to_f32((long long)t[shift++], F);
+            if (j == 6) b[i] = value;
+            else A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+    residual[0] = fix_to_f32((long long)t[27], F);
+    residual[1] = (float)(long long)t[28];
+}
+
+__global__ void __launch_bounds__(256) gn_solve_kernel(OdomDev* const* __restrict__ models, int level, int next_level,
+                                                       int last_of_level)
+{
+    OdomDev* od = models[blockIdx.x];
+    __shared__ unsigned long long s_icp[32], s_rgb[32];
+    __shared__ unsigned long long s_part[2][8][32];
+    // 256 threads: word = t & 31, slice = t >> 5 (8 slices of 8 groups)
+    {
+        const int w = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        unsigned long long a = 0, b = 0;
+        for (int g = sl * (kGroups / 8); g < (sl + 1) * (kGroups / 8); g++) {
+            a += od->icp_acc[(size_t)g * 32 + w];
+            b += od->rgb_acc[(size_t)g * 32 + w];
+        }
+        s_part[0][sl][w] = a; s_part[1][sl][w] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        unsigned long long a = 0, b = 0;
+        for (int sl = 0; sl < 8; sl++) { a += s_part[0][sl][threadIdx.x]; b += s_part[1][sl][threadIdx.x]; }
+        s_icp[threadIdx.x] = a; s_rgb[threadIdx.x] = b;
+    }
+    __syncthreads();
+    // zero the accumulators for the next iteration
+    for (int k = threadIdx.x; k < kGroups * 32; k += 256) { od->icp_acc[k] = 0; od->rgb_acc[k] = 0; }
+
+    if (threadIdx.x != 0) return;
+    const int skip = od->level_done;
+    if (!skip) {
+        const long long rgbSize = (long long)s_icp[29], sigma = (long long)s_icp[30];
+        const float tmpError = (float)(sqrt((double)(int)sigma) / (double)(int)rgbSize);
+        bool stop = false;
+        if (od->rgbOnly && tmpError > od->lastRGBError) { stop = true; od->level_done = 1; }
+        if (!stop) {
+            od->lastRGBError = tmpError;
+            od->stats.last_rgb_error = tmpError; od->stats.last_rgb_count = (float)(int)rgbSize;
+            float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6], dummy[2];
+            for (int k = 0; k < 36; k++) { A_icp[k] = 0; A_rgb[k] = 0; }
+            for (int k = 0; k < 6; k++) { b_icp[k] = 0; b_rgb[k] = 0; }
+            if (od->icp) se3_unpack(s_icp, kFixICP, A_icp, b_icp, od->residual);
+            od->stats.last_icp_error = __fsqrt_rn(od->residual[0]) / od->residual[1];
+            od->stats.last_icp_count = od->residual[1];
+            if (od->rgb) se3_unpack(s_rgb, kFixRGB, A_rgb, b_rgb, dummy);
+            double lastA[36], lastb[6], result[6];
+            if (od->icp && od->rgb) {
+                const double w = od->icpWeight;
+                for (int k = 0; k < 36; k++) lastA[k] = (double)A_rgb[k] + w * w * (double)A_icp[k];
+                for (int k = 0; k < 6; k++) lastb[k] = (double)b_rgb[k] + w * (double)b_icp[k];
+            } else if (od->icp) {
+                for (int k = 0; k < 36; k++) lastA[k] = A_icp[k];
+                for (int k = 0; k < 6; k++) lastb[k] = b_icp[k];
+            } else {
+                for (int k = 0; k < 36; k++) lastA[k] = A_rgb[k];
+                for (int k = 0; k < 6; k++) lastb[k] = b_rgb[k];
+            }
+            ldlt_solve<double, 6>(lastA, lastb, result, 2.2250738585072014e-308);
+            for (int k = 0; k < 36; k++) od->stats.lastA[k] = lastA[k];
+            for (int k = 0; k < 6; k++) od->stats.lastb[k] = lastb[k];
+            // computeUpdateSE3
+            double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rr[9], nrt[16];
+            const double rvec[3] = {result[3], result[4], result[5]};
+            rodrigues(rvec, Rr);
+            for (int r = 0; r < 3; r++) {
+                upd[r * 4 + 0] = Rr[r * 3 + 0]; upd[r * 4 + 1] = Rr[r * 3 + 1]; upd[r * 4 + 2] = Rr[r * 3 + 2];
+                upd[r * 4 + 3] = result[r];
+            }
+            mul44(upd, od->resultRt, nrt);
+            for (int k = 0; k < 16; k++) od->resultRt[k] = nrt[k];
+            float Ro[9], to[3];
+            for (int r = 0; r < 3; r++) {
+                Ro[r * 3 + 0] = (float)nrt[r * 4 + 0]; Ro[r * 3 + 1] = (float)nrt[r * 4 + 1]; Ro[r * 3 + 2] = (float)nrt[r * 4 + 2];
+                to[r] = (float)nrt[r * 4 + 3];
+            }
+            const float Rinv[9] = {Ro[0], Ro[3], Ro[6], Ro[1], Ro[4], Ro[7], Ro[2], Ro[5], Ro[8]};
+            float tinv[3];
+            for (int r = 0; r < 3; r++) tinv[r] = -(Rinv[r * 3 + 0] * to[0] + Rinv[r * 3 + 1] * to[1] + Rinv[r * 3 + 2] * to[2]);
+            float Rc[9];
+            mul33<float>(od->Rprev, Rinv, Rc);
+            for (int k = 0; k < 9; k++) od->Rcurr[k] = Rc[k];
+            for (int r = 0; r < 3; r++)
+                od->tcurr[r] = (od->Rprev[r * 3 + 0] * tinv[0] + od->Rprev[r * 3 + 1] * tinv[1] + od->Rprev[r * 3 + 2] * tinv[2]) + od->tprev[r];
+        }
+    }
+    if (last_of_level) { od->level_done = 0; od->lastRGBError = 3.402823466e+38F; }
+    if (next_level >= 0) prepare_iteration(od, next_level);
+}
+
+// divergence guard (RGBDOdometry.cpp:464-467)
+__global__ void gn_finish_kernel(OdomDev* const* __restrict__ models)
+{
+    OdomDev* od = models[blockIdx.x];
+    if (threadIdx.x != 0) return;
+    if (od->rgb) {
+        const float d0 = od->tcurr[0] - od->tprev[0], d1 = od->tcurr[1] - od->tprev[1], d2 = od->tcurr[2] - od->tprev[2];
+        if ((double)__fsqrt_rn(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
+            for (int k = 0; k < 9; k++) od->Rcurr[k] = od->Rprev[k];
+            for (int k = 0; k < 3; k++) od->tcurr[k] = od->tprev[k];
+        }
+    }
+}
+
+// total of the grouped accumulator -> out[32] (stand-alone steps)
+__global__ void __launch_bounds__(64) acc_total_kernel(const unsigned long long* __restrict__ acc, unsigned long long* __restrict__ out)
+{
+    for (int w = 0; w < 32; w++) {
+        const unsigned long long v = group_sum(acc, w, threadIdx.x);
+        if (threadIdx.x == 0) out[w] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------ launchers ----
+template <int TAG>
+static void launch_icp_kernel(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, int n, int N, int level, int write_err)
+{
+    const int per_block = cfg.threads * cfg.ppt;
+    const int nlog = (N + per_block - 1) / per_block;
+    const dim3 grid(((nlog + 7) / 8) * 8, n);
+    switch (cfg.ppt) {
+        case 4: icp_reduce_kernel<4, TAG><<<grid, cfg.threads, 0, s>>>(d_models, level, write_err); break;
+        case 2: icp_reduce_kernel<2, TAG><<<grid, cfg.threads, 0, s>>>(d_models, level, write_err); break;
+        default: icp_reduce_kernel<1, TAG><<<grid, cfg.threads, 0, s>>>(d_models, level, write_err); break;
+    }
+}
+
+static void launch_icp_level(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, int n, int width, int height, int level,
+                             int write_err)
+{
+    const int N = (width >> level) * (height >> level);
+    // distinct symbols per pyramid level so that rocprofv3 --stats separates them
+    if (level == 0) launch_icp_kernel<0>(s, cfg, d_models, n, N, level, write_err);
+    else if (level == 1) launch_icp_kernel<1>(s, cfg, d_models, n, N, level, write_err);
+    else launch_icp_kernel<2>(s, cfg, d_models, n, N, level, write_err);
+}
+
+void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, int n, int width, int height, bool so3,
+                     bool pyramid, bool fast_odom, bool rgb, bool icp, ProfSink* prof)
+{
+    int iterations[3];
+    iterations[0] = fast_odom ? 3 : 10;
+    iterations[1] = pyramid ? 5 : 0;
+    iterations[2] = pyramid ? 4 : 0;
+    int first_level = 2;
+    while (first_level > 0 && iterations[first_level] == 0) first_level--;
+    so3_prealign_kernel<<<n, 1024, 0, s>>>(d_models, so3 ? 1 : 0, first_level);
+    for (int i = 2; i >= 0; i--) {
+        const int N = (width >> i) * (height >> i);
+        for (int j = 0; j < iterations[i]; j++) {
+            const bool last_of_level = (j == iterations[i] - 1);
+            int next_level = i;
+            if (last_of_level) {
+                next_level = i - 1;
+                while (next_level >= 0 && iterations[next_level] == 0) next_level--;
+            }
+            if (rgb) rgb_residual_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(d_models, i);
+            if (icp) {
+                const bool timed = prof && prof->enabled && prof->used + 2 <= prof->capacity;
+                if (timed) (void)hipEventRecord(prof->events[prof->used++], s);
+                launch_icp_level(s, cfg, d_models, n, width, height, i, (i == 0 && last_of_level) ? 1 : 0);
+                if (timed) {
+                    (void)hipEventRecord(prof->events[prof->used++], s);
+                    prof->bytes += (uint64_t)N * (24 + 24 * (uint64_t)n);
+                    prof->launches += 1;
+                }
+            }
+            if (rgb) rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(d_models, i);
+            gn_solve_kernel<<<n, 256, 0, s>>>(d_models, i, next_level, last_of_level ? 1 : 0);
+        }
+    }
+    gn_finish_kernel<<<n, 64, 0, s>>>(d_models);
+}
+
+// ---- stand-alone steps (operate on a scratch OdomDev prepared by cabi.cpp) -------------------
+void launch_icp_models(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, int n, int width, int height, int level,
+                       int write_err)
+{
+    launch_icp_level(s, cfg, d_models, n, width, height, level, write_err);
+}
+void launch_rgb_residual_models(hipStream_t s, OdomDev* const* d_models, int n, int width, int height, int level)
+{
+    const int N = (width >> level) * (height >> level);
+    rgb_residual_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(d_models, level);
+}
+void launch_rgb_step_models(hipStream_t s, OdomDev* const* d_models, int n, int width, int height, int level)
+{
+    const int N = (width >> level) * (height >> level);
+    rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(d_models, level);
+}
+void launch_acc_total(hipStream_t s, const unsigned long long* acc, unsigned long long* out)
+{
+    acc_total_kernel<<<1, 64, 0, s>>>(acc, out);
+}
+void launch_rgb_cand(hipStream_t s, const int16_t* dIdx, const int16_t* dIdy, const float* next_depth,
+                     const uint8_t* next_image, float min_scale, int cols, int rows, uint8_t* cand)
+{
+    rgb_cand_kernel<<<(cols * rows + 255) / 256, 256, 0, s>>>(dIdx, dIdy, next_depth, next_image, min_scale, cols, rows, cand);
+}
+void launch_so3_step(hipStream_t s, const uint8_t* last_image, const uint8_t* next_image, const float basis[9],
+                     const float kinv[9], const float krlr[9], int cols, int rows, unsigned long long* out16)
+{
+    m33 B, Ki, Kr;
+    for (int i = 0; i < 9; i++) { B.m[i] = basis[i]; Ki.m[i] = kinv[i]; Kr.m[i] = krlr[i]; }
+    so3_step_kernel<<<1, 1024, 0, s>>>(last_image, next_image, B, Ki, Kr, cols, rows, out16);
+}
+
+}  // namespace cf

@@ -1,0 +1,50 @@
+"""ctypes loader for the C-ABI library (co_fusion_amd/lib/libcofusion_hip.so).
+
+The product path fails loudly when the HIP extension is missing or no GPU is present:
+there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcofusion_hip.so")
+
+# every symbol include/cofusion_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "cf_create", "cf_destroy", "cf_last_error", "cf_set_stream", "cf_get_stream", "cf_synchronize", "cf_malloc",
+    "cf_free", "cf_memcpy_h2d", "cf_memcpy_d2h", "cf_create_vmap", "cf_create_nmap", "cf_copy_maps", "cf_resize_map",
+    "cf_transform_maps", "cf_vertices_to_depth", "cf_pyrdown_gauss_f32", "cf_pyrdown_gauss_u8",
+    "cf_rgba_to_intensity", "cf_sobel", "cf_project_cloud", "cf_icp_step", "cf_rgb_residual", "cf_rgb_step",
+    "cf_so3_step", "cf_odom_create", "cf_odom_destroy", "cf_odom_init_icp_model", "cf_odom_init_rgb_model",
+    "cf_odom_init_rgb", "cf_odom_init_first_rgb", "cf_odom_init_icp", "cf_odom_get_incremental_transformation",
+    "cf_odom_track_batch_async", "cf_odom_fetch_result", "cf_odom_bind_frame_maps", "cf_odom_buffer",
+    "cf_depth_pyramid", "cf_set_icp_launch", "cf_profile_enable", "cf_profile_read",
+]
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the product path)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.cf_last_error.restype = C.c_char_p
+        _lib.cf_get_stream.restype = C.c_void_p
+    return _lib

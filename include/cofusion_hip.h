@@ -1,0 +1,184 @@
+/*
+ * cofusion_hip.h -- C-ABI of the MI355X-native Co-Fusion hot path (libcofusion_hip.so).
+ *
+ * Drop-in boundary.  The reference's lower seam is the set of free
+ * functions in Core/Cuda/cudafuncs.cuh:64-193 (called from Core/Utils/RGBDOdometry.cpp and
+ * Core/Model/Model.cpp:341-343) plus the GLSL passes driven by Core/Model/Model.cpp and
+ * Core/Model/ModelProjection.cpp.  Every entry point below names the reference interface it
+ * replaces.  Signatures are plain C: device pointers, sizes, host PODs; no torch, no Eigen,
+ * no OpenGL.  All functions return 0 on success or a negative CF_E* code; cf_last_error()
+ * gives the message (the reference printf+exit(-1)s instead, Core/Cuda/convenience.cuh:74-83).
+ *
+ * Layouts
+ *   depth           f32  [H*W] metres, 0 = invalid            (FrameData.depth, CV_32FC1)
+ *   rgba            u8x4 [H*W] R,G,B,A                        (GL_RGBA texture of CoFusion.cpp:179)
+ *   vertex4/normal4 f32x4 [H*W]                               (RGBA32F splat outputs)
+ *   planar map      f32  [3*H*W]: x rows, y rows, z rows      (DeviceArray2D<float>(3*rows, cols))
+ *   pose            f32[16] ROW-major T(model <- camera)      (Eigen::Matrix4f in the reference)
+ *   SE3 sums        int64[32]: 27 upper-triangular products row_i*row_j (i<6, i<=j<7) in
+ *                   Q31.32 fixed point, [27] = sum r^2 (Q31.32), [28] = inlier count
+ *   surfel          12 f32 (48 B): [x y z conf][colour24 0 initTime lastTime][nx ny nz radius]
+ *                   (Core/Shaders/Vertex.cpp:21-43)
+ */
+#ifndef COFUSION_HIP_H_
+#define COFUSION_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CF_OK 0
+#define CF_EINVAL (-1)
+#define CF_EHIP (-2)
+#define CF_ENOMEM (-3)
+#define CF_ESTATE (-4)
+
+#define CF_NUM_PYRS 3        /* RGBDOdometry::NUM_PYRS, RGBDOdometry.h:69 */
+#define CF_SE3_WORDS 32
+#define CF_SO3_WORDS 16
+#define CF_FIX_ICP 32
+#define CF_FIX_RGB 32
+#define CF_FIX_SO3 12
+
+typedef struct cf_ctx cf_ctx;
+typedef struct cf_odom cf_odom;
+typedef struct cf_model cf_model;
+
+typedef struct { float fx, fy, cx, cy; } cf_cam; /* CameraModel, Core/Cuda/types.cuh:83-99 */
+
+/* DataTerm, Core/Cuda/types.cuh:75-81 */
+typedef struct {
+    int16_t zero_x, zero_y;
+    int16_t one_x, one_y;
+    float diff;
+    int32_t valid;
+} cf_dataterm;
+
+typedef struct {
+    int width, height;
+    float fx, fy, cx, cy;     /* Intrinsics singleton, Core/Utils/Intrinsics.h */
+    int device;               /* HIP device ordinal */
+    int max_models;           /* concurrently tracked models (background + objects) */
+    int max_surfels;          /* per model; reference default 3072*3072 (Model.cpp:92-98) */
+} cf_config;
+
+/* ------------------------------------------------------------------ context ---- */
+int cf_create(const cf_config *cfg, cf_ctx **out);
+void cf_destroy(cf_ctx *ctx);
+const char *cf_last_error(const cf_ctx *ctx);
+/* all work is enqueued on this stream (default: a ctx-owned non-blocking stream) */
+int cf_set_stream(cf_ctx *ctx, void *hip_stream);
+void *cf_get_stream(cf_ctx *ctx);
+int cf_synchronize(cf_ctx *ctx);
+/* device memory helpers for hosts that do not link HIP themselves */
+int cf_malloc(cf_ctx *ctx, uint64_t bytes, void **dptr);
+int cf_free(cf_ctx *ctx, void *dptr);
+int cf_memcpy_h2d(cf_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+int cf_memcpy_d2h(cf_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+
+/* --------------------------------------------- map preparation (cudafuncs.cuh) ---- */
+/* createVMap  cudafuncs.cuh:125-130 */
+int cf_create_vmap(cf_ctx *ctx, const float *depth, int cols, int rows, cf_cam intr, float depth_cutoff, float *vmap);
+/* createNMap  cudafuncs.cuh:132-133 */
+int cf_create_nmap(cf_ctx *ctx, const float *vmap, int cols, int rows, float *nmap);
+/* copyMaps    cudafuncs.cuh:142-145 */
+int cf_copy_maps(cf_ctx *ctx, const float *vertex4, const float *normal4, int cols, int rows, float *vmap, float *nmap);
+/* resizeVMap / resizeNMap  cudafuncs.cuh:147-151 */
+int cf_resize_map(cf_ctx *ctx, const float *in, int in_cols, int in_rows, float *out, int normalize);
+/* tranformMaps cudafuncs.cuh:135-140 (in place) */
+int cf_transform_maps(cf_ctx *ctx, float *vmap, float *nmap, int cols, int rows, const float R[9], const float t[3]);
+/* verticesToDepth cudafuncs.cuh:156-158 */
+int cf_vertices_to_depth(cf_ctx *ctx, const float *vertex4, int cols, int rows, float cutoff, float *depth);
+/* pyrDownGaussF cudafuncs.cuh:174-175, pyrDownUcharGauss :177-178 */
+int cf_pyrdown_gauss_f32(cf_ctx *ctx, const float *src, int src_cols, int src_rows, float *dst);
+int cf_pyrdown_gauss_u8(cf_ctx *ctx, const uint8_t *src, int src_cols, int src_rows, uint8_t *dst);
+/* imageBGRToIntensity cudafuncs.cuh:153-154 */
+int cf_rgba_to_intensity(cf_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *dst);
+/* computeDerivativeImages cudafuncs.cuh:184-186 */
+int cf_sobel(cf_ctx *ctx, const uint8_t *src, int cols, int rows, int16_t *dx, int16_t *dy);
+/* projectToPointCloud cudafuncs.cuh:161-164 (intr already divided by 2^level) */
+int cf_project_cloud(cf_ctx *ctx, const float *depth, int cols, int rows, cf_cam intr_level, float *cloud3);
+
+/* ------------------------------------------------- reductions (cudafuncs.cuh) ---- */
+/* icpStep cudafuncs.cuh:64-82.  Device maps in, host A[36] (row-major, symmetric filled),
+ * b[6], residual[2] = {sum r^2, inliers} out (synchronous, like the reference).  sums_host
+ * (nullable) additionally receives the exact int64[32] sums.  err_surface: device f32 [rows*cols]
+ * or NULL (the cudaSurfaceObject_t of the reference). */
+int cf_icp_step(cf_ctx *ctx, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
+                const float *nmap_curr, const float Rprev_inv[9], const float tprev[3], cf_cam intr,
+                const float *vmap_g_prev, const float *nmap_g_prev, float dist_thres, float angle_thres,
+                int cols, int rows, float *A_host, float *b_host, float *residual_host, int64_t *sums_host,
+                float *err_surface);
+/* computeRgbResidual cudafuncs.cuh:102-121 */
+int cf_rgb_residual(cf_ctx *ctx, float min_scale, const int16_t *dIdx, const int16_t *dIdy, const float *last_depth,
+                    const float *next_depth, const uint8_t *last_image, const uint8_t *next_image,
+                    cf_dataterm *corres, float max_depth_delta, const float kt[3], const float krkinv[9],
+                    int cols, int rows, int *sigma_sum_host, int *count_host);
+/* rgbStep cudafuncs.cuh:84-97 */
+int cf_rgb_step(cf_ctx *ctx, const cf_dataterm *corres, float sigma, const float *cloud3, float fx, float fy,
+                const int16_t *dIdx, const int16_t *dIdy, float sobel_scale, int cols, int rows, float *A_host,
+                float *b_host, int64_t *sums_host);
+/* so3Step cudafuncs.cuh:99-110 */
+int cf_so3_step(cf_ctx *ctx, const uint8_t *last_image, const uint8_t *next_image, const float image_basis[9],
+                const float kinv[9], const float krlr[9], int cols, int rows, float *A_host, float *b_host,
+                float *residual_host, int64_t *sums_host);
+
+/* ------------------------------- RGBDOdometry (Core/Utils/RGBDOdometry.h:42-60) ---- */
+typedef struct {
+    int rgb_only, pyramid, fast_odom, so3;
+    float icp_weight;
+} cf_track_opts;
+typedef struct {
+    float last_icp_error, last_icp_count, last_rgb_error, last_rgb_count, last_so3_error, last_so3_count;
+    double lastA[36], lastb[6];
+    int so3_iterations;
+} cf_track_stats;
+
+int cf_odom_create(cf_ctx *ctx, cf_odom **out);
+void cf_odom_destroy(cf_odom *od);
+/* initICPModel(predictedVertices, predictedNormals, depthCutoff, modelPose) RGBDOdometry.h:53 */
+int cf_odom_init_icp_model(cf_odom *od, const float *pred_vertex4, const float *pred_normal4, const float pose[16]);
+/* initRGBModel(rgb) :57 / initRGB(rgb) :55 / initFirstRGB(rgb) :59 -- rgba is a device RGBA8 image */
+int cf_odom_init_rgb_model(cf_odom *od, const uint8_t *pred_rgba);
+int cf_odom_init_rgb(cf_odom *od, const uint8_t *rgba);
+int cf_odom_init_first_rgb(cf_odom *od, const uint8_t *rgba);
+/* initICP(depthPyramid, maskPyramid, depthCutoff) :48-49 (frame -> model); the mask pyramid is dead in the
+ * reference (cudafuncs.cu:119) and therefore not part of the ABI */
+int cf_odom_init_icp(cf_odom *od, const float *const depth_pyr[CF_NUM_PYRS], float depth_cutoff);
+/* getIncrementalTransformation :62-64.  trans/rot host in-out.  The whole Gauss-Newton loop (SO3
+ * pre-alignment, 4/5/10 pyramid schedule, f64 6x6 solve, SE3 update) runs device-resident; the host
+ * waits once at the end.  icp_err_surface: device f32 [H*W] or NULL. */
+int cf_odom_get_incremental_transformation(cf_odom *od, float trans[3], float rot[9], const cf_track_opts *opts,
+                                           float *icp_err_surface, cf_track_stats *stats);
+/* batched, asynchronous flavour used by the orchestrator: all `n` models advance through the
+ * GN schedule in lock-step inside the same launches (grid.y = model).  Poses are read from /
+ * written to the odom objects' device state; call cf_odom_fetch_result after cf_synchronize. */
+int cf_odom_track_batch_async(cf_ctx *ctx, cf_odom *const *ods, int n, const float *const *poses_in /* n x [16] */,
+                              const cf_track_opts *opts, float *const *icp_err_surfaces /* nullable entries */);
+int cf_odom_fetch_result(cf_odom *od, float trans[3], float rot[9], cf_track_stats *stats);
+/* test access to internal device pyramids (same `which` numbering as the oracle's orc_odom_buffer) */
+/* share the frame-wide current vertex/normal pyramids between models (all models track the same frame,
+ * cudafuncs.cu:119); pass NULL arrays to return to the odom-private maps written by cf_odom_init_icp */
+int cf_odom_bind_frame_maps(cf_odom *od, const float *const vmaps[CF_NUM_PYRS], const float *const nmaps[CF_NUM_PYRS]);
+int cf_odom_buffer(cf_odom *od, int which, int level, void **dptr, uint64_t *bytes);
+/* Model::generateCUDATextures depth half (Model.cpp:341-343): l1/l2 device outputs */
+int cf_depth_pyramid(cf_ctx *ctx, const float *depth_filtered, int cols, int rows, float *l1, float *l2);
+
+/* launch-shape tuning of the ICP reduction (GPUConfig.h:51-58 in the reference) */
+int cf_set_icp_launch(cf_ctx *ctx, int threads, int pixels_per_thread);
+
+/* timing of the most recent reductions, measured with hipEvents on the ctx stream */
+typedef struct {
+    double icp_ms_total;   /* accumulated GPU time of ICP-reduce launches since last reset */
+    uint64_t icp_launches;
+    uint64_t icp_bytes;    /* algorithmic bytes: 48 B/pixel/launch */
+} cf_profile;
+int cf_profile_enable(cf_ctx *ctx, int on);
+int cf_profile_read(cf_ctx *ctx, cf_profile *out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COFUSION_HIP_H_ */

@@ -1,0 +1,119 @@
+/*
+ * orc.h -- public declarations of the CPU ORACLE.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (co_fusion_amd/, the
+ * C-ABI library, the C++ facade) may include, link or call anything in oracle/.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * and only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (martinruenz/co-fusion) ships no tests, golden
+ * vectors or fixtures and cannot be built in this
+ * environment (needs CUDA, OpenGL/Pangolin, Eigen, OpenCV, gSLICr, densecrf).
+ * This oracle is therefore a from-scratch restatement of the reference
+ * arithmetic, function by function, each citing the reference file:line it
+ * follows.  tests/golden/ pins the oracle against itself (regression only).
+ *
+ * Data layouts (identical to the HIP C-ABI in include/cofusion_hip.h):
+ *   depth            f32  [H*W] metres, 0 = invalid
+ *   rgba image       u8x4 [H*W] (R,G,B,A)
+ *   vertex/normal 4  f32x4 [H*W]  (GL RGBA32F texture layout of the reference)
+ *   planar map       f32  [3*H*W] rows 0..H-1 = x, H..2H-1 = y, 2H..3H-1 = z
+ *                    (reference DeviceArray2D<float>(3*rows, cols), unpitched)
+ *   surfel           12 f32: [x y z conf][colour24 0 initTime lastTime][nx ny nz radius]
+ */
+#ifndef ORC_H_
+#define ORC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NUM_PYRS 3
+#define ORC_SE3_WORDS 32 /* 27 products, residual, inliers, 3 pad */
+#define ORC_SO3_WORDS 16 /* 9 products, residual, inliers, pad */
+#define ORC_FIX_ICP 32
+#define ORC_FIX_RGB 32
+#define ORC_FIX_SO3 12
+
+typedef struct { float fx, fy, cx, cy; } orc_cam;
+
+/* reference DataTerm, Core/Cuda/types.cuh:75-81 (16 bytes; `valid` is a bool + pad) */
+typedef struct {
+    int16_t zero_x, zero_y;
+    int16_t one_x, one_y;
+    float diff;
+    int32_t valid;
+} orc_dataterm;
+
+/* ------------------------------ map preparation ------------------------------ */
+void orc_create_vmap(const float *depth, int cols, int rows, orc_cam intr, float depth_cutoff, float *vmap);
+void orc_create_nmap(const float *vmap, int cols, int rows, float *nmap);
+void orc_copy_maps(const float *v4, const float *n4, int cols, int rows, float *vmap, float *nmap);
+void orc_resize_map(const float *in, int in_cols, int in_rows, float *out, int normalize);
+void orc_transform_maps(float *vmap, float *nmap, int cols, int rows, const float R[9], const float t[3]);
+void orc_vertices_to_depth(const float *v4, int cols, int rows, float cutoff, float *depth);
+void orc_pyrdown_gauss_f32(const float *src, int src_cols, int src_rows, float *dst);
+void orc_pyrdown_gauss_u8(const uint8_t *src, int src_cols, int src_rows, uint8_t *dst);
+void orc_rgba_to_intensity(const uint8_t *rgba, int cols, int rows, uint8_t *dst);
+void orc_sobel(const uint8_t *src, int cols, int rows, int16_t *dx, int16_t *dy);
+void orc_project_cloud(const float *depth, int cols, int rows, orc_cam intr_level, float *cloud3);
+
+/* -------------------------------- reductions --------------------------------- */
+/* Exact (fixed-point) statement: sums[0..26] upper-triangular products row_i*row_j
+ * (i<=j<7, i<6) in Q(63-F).F, sums[27] = residual^2 (Q.F), sums[28] = inliers (integer). */
+void orc_icp_step(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float *nmap_curr,
+                  const float Rprev_inv[9], const float tprev[3], orc_cam intr, const float *vmap_g_prev,
+                  const float *nmap_g_prev, float dist_thres, float angle_thres, int cols, int rows,
+                  int64_t sums[ORC_SE3_WORDS], float *err_surface /* nullable, [rows*cols] */);
+/* reference summation order in f32 (grid-stride + warp32 shuffle tree), reduce.cu:90-185,396-417 */
+void orc_icp_step_f32tree(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float *nmap_curr,
+                          const float Rprev_inv[9], const float tprev[3], orc_cam intr, const float *vmap_g_prev,
+                          const float *nmap_g_prev, float dist_thres, float angle_thres, int cols, int rows,
+                          int threads, int blocks, float out29[29]);
+void orc_rgb_residual(float min_scale, const int16_t *dIdx, const int16_t *dIdy, const float *last_depth,
+                      const float *next_depth, const uint8_t *last_image, const uint8_t *next_image,
+                      orc_dataterm *corres, float max_depth_delta, const float kt[3], const float krkinv[9],
+                      int cols, int rows, int *sigma_sum, int *count);
+void orc_rgb_step(const orc_dataterm *corres, float sigma, const float *cloud3, float fx, float fy,
+                  const int16_t *dIdx, const int16_t *dIdy, float sobel_scale, int cols, int rows,
+                  int64_t sums[ORC_SE3_WORDS]);
+void orc_so3_step(const uint8_t *last_image, const uint8_t *next_image, const float image_basis[9],
+                  const float kinv[9], const float krlr[9], int cols, int rows, int64_t sums[ORC_SO3_WORDS]);
+/* sums -> the reference's host outputs (reduce.cu:481-498, 1158-1175) */
+void orc_se3_sums_to_host(const int64_t sums[ORC_SE3_WORDS], int F, float A[36], float b[6], float residual[2]);
+void orc_so3_sums_to_host(const int64_t sums[ORC_SO3_WORDS], int F, float A[9], float b[3], float residual[2]);
+
+/* ----------------------- RGBDOdometry (Core/Utils/RGBDOdometry.*) ------------- */
+typedef struct orc_odometry orc_odometry;
+orc_odometry *orc_odom_create(int width, int height, float cx, float cy, float fx, float fy);
+void orc_odom_destroy(orc_odometry *o);
+void orc_odom_init_icp_model(orc_odometry *o, const float *pred_v4, const float *pred_n4, const float pose[16]);
+void orc_odom_init_rgb_model(orc_odometry *o, const uint8_t *pred_rgba);
+void orc_odom_init_icp(orc_odometry *o, const float *const depth_pyr[ORC_NUM_PYRS], float depth_cutoff);
+void orc_odom_init_rgb(orc_odometry *o, const uint8_t *rgba);
+void orc_odom_init_first_rgb(orc_odometry *o, const uint8_t *rgba);
+typedef struct {
+    int rgb_only, pyramid, fast_odom, so3;
+    float icp_weight;
+} orc_track_opts;
+typedef struct {
+    float last_icp_error, last_icp_count, last_rgb_error, last_rgb_count, last_so3_error, last_so3_count;
+    double lastA[36], lastb[6];
+    int so3_iterations;
+} orc_track_stats;
+/* trans[3]/rot[9] (row-major) in-out; err_surface nullable [H*W] */
+void orc_odom_get_incremental_transformation(orc_odometry *o, float trans[3], float rot[9], const orc_track_opts *opts,
+                                             float *icp_err_surface, orc_track_stats *stats);
+/* test access to internal pyramids: which = 0 vmap_curr,1 nmap_curr,2 vmap_g_prev,3 nmap_g_prev (planar f32),
+ * 4 lastDepth,5 nextDepth (f32), 6 lastImage,7 nextImage,8 lastNextImage (u8), 9 dIdx,10 dIdy (s16) */
+const void *orc_odom_buffer(const orc_odometry *o, int which, int level);
+
+/* Model::generateCUDATextures depth pyramid (Model.cpp:319-348) */
+void orc_depth_pyramid(const float *depth_filtered, int cols, int rows, float *l1, float *l2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORC_H_ */

@@ -1,0 +1,817 @@
+/*
+ * orc_track.c -- CPU ORACLE for the dense tracking half of the hot path.
+ * TEST INFRASTRUCTURE ONLY (see orc.h).  PARITY UNPINNED (no reference vectors exist).
+ *
+ * Restates, function by function:
+ *   Core/Cuda/cudafuncs.cu   map preparation kernels
+ *   Core/Cuda/reduce.cu      icpStep / computeRgbResidual / rgbStep / so3Step
+ *   Core/Utils/RGBDOdometry.cpp  the Gauss-Newton host loop
+ * Per-pixel arithmetic is IEEE f32 in the reference's operation order (the
+ * reference itself is built with --prec-div=false --ftz, Core/CMakeLists.txt:90,
+ * so bitwise equality with a CUDA build was never defined).  The normal-equation
+ * sums are accumulated exactly in fixed point (orc_math.h: orc_fix_prod), which is
+ * the order-independent statement the HIP kernels are held to bit-for-bit; the
+ * reference's own f32 tree order is available as orc_icp_step_f32tree to bound the
+ * reassociation spread.
+ */
+#include "orc.h"
+#include "orc_math.h"
+
+#include <float.h>
+#include <stdlib.h>
+
+static inline orc_cam cam_level(orc_cam c, int level)
+{ /* CameraModel::operator(), types.cuh:94-98 */
+    int div = 1 << level;
+    orc_cam r = {c.fx / div, c.fy / div, c.cx / div, c.cy / div};
+    return r;
+}
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* ============================ map preparation ================================= */
+
+/* computeVmapKernel, cudafuncs.cu:109-134.  The mask test is commented out in the
+ * reference (:119); invalid pixels write NaN to the x plane ONLY (:131). */
+void orc_create_vmap(const float *depth, int cols, int rows, orc_cam intr, float depth_cutoff, float *vmap)
+{
+    const float fx_inv = 1.f / intr.fx, fy_inv = 1.f / intr.fy;
+    for (int v = 0; v < rows; v++)
+        for (int u = 0; u < cols; u++) {
+            float z = depth[v * cols + u];
+            if (z != 0 && z < depth_cutoff) {
+                vmap[v * cols + u] = z * (u - intr.cx) * fx_inv;
+                vmap[(v + rows) * cols + u] = z * (v - intr.cy) * fy_inv;
+                vmap[(v + 2 * rows) * cols + u] = z;
+            } else {
+                vmap[v * cols + u] = orc_qnan();
+            }
+        }
+}
+
+/* computeNmapKernel, cudafuncs.cu:152-189 */
+void orc_create_nmap(const float *vmap, int cols, int rows, float *nmap)
+{
+    for (int v = 0; v < rows; v++)
+        for (int u = 0; u < cols; u++) {
+            if (u == cols - 1 || v == rows - 1) { nmap[v * cols + u] = orc_qnan(); continue; }
+            float x00 = vmap[v * cols + u], x01 = vmap[v * cols + u + 1], x10 = vmap[(v + 1) * cols + u];
+            if (!isnan(x00) && !isnan(x01) && !isnan(x10)) {
+                orc_f3 v00 = {x00, vmap[(v + rows) * cols + u], vmap[(v + 2 * rows) * cols + u]};
+                orc_f3 v01 = {x01, vmap[(v + rows) * cols + u + 1], vmap[(v + 2 * rows) * cols + u + 1]};
+                orc_f3 v10 = {x10, vmap[(v + 1 + rows) * cols + u], vmap[(v + 1 + 2 * rows) * cols + u]};
+                orc_f3 r = orc_f3_normalized(orc_f3_cross(orc_f3_sub(v01, v00), orc_f3_sub(v10, v00)));
+                nmap[v * cols + u] = r.x;
+                nmap[(v + rows) * cols + u] = r.y;
+                nmap[(v + 2 * rows) * cols + u] = r.z;
+            } else
+                nmap[v * cols + u] = orc_qnan();
+        }
+}
+
+/* copyMapsKernel, cudafuncs.cu:271-311: RGBA32F -> planar, z==0 -> NaN (all 3 planes) */
+void orc_copy_maps(const float *v4, const float *n4, int cols, int rows, float *vmap, float *nmap)
+{
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            const float *vs = v4 + (y * cols + x) * 4, *ns = n4 + (y * cols + x) * 4;
+            orc_f3 vd = {orc_qnan(), orc_qnan(), orc_qnan()}, nd = vd;
+            if (!(vs[2] == 0)) { vd = orc_f3_make(vs[0], vs[1], vs[2]); nd = orc_f3_make(ns[0], ns[1], ns[2]); }
+            vmap[y * cols + x] = vd.x; vmap[(y + rows) * cols + x] = vd.y; vmap[(y + 2 * rows) * cols + x] = vd.z;
+            nmap[y * cols + x] = nd.x; nmap[(y + rows) * cols + x] = nd.y; nmap[(y + 2 * rows) * cols + x] = nd.z;
+        }
+}
+
+/* resizeMapKernel<normalize>, cudafuncs.cu:366-417: 2x2 mean, NaN if any x is NaN
+ * (x plane only is written in that case). */
+void orc_resize_map(const float *in, int in_cols, int in_rows, float *out, int normalize)
+{
+    const int dcols = in_cols / 2, drows = in_rows / 2, srows = in_rows;
+    for (int y = 0; y < drows; y++)
+        for (int x = 0; x < dcols; x++) {
+            int xs = x * 2, ys = y * 2;
+            float x00 = in[ys * in_cols + xs], x01 = in[ys * in_cols + xs + 1];
+            float x10 = in[(ys + 1) * in_cols + xs], x11 = in[(ys + 1) * in_cols + xs + 1];
+            if (isnan(x00) || isnan(x01) || isnan(x10) || isnan(x11)) { out[y * dcols + x] = orc_qnan(); continue; }
+            orc_f3 n;
+            n.x = (x00 + x01 + x10 + x11) / 4;
+            n.y = (in[(ys + srows) * in_cols + xs] + in[(ys + srows) * in_cols + xs + 1] +
+                   in[(ys + srows + 1) * in_cols + xs] + in[(ys + srows + 1) * in_cols + xs + 1]) / 4;
+            n.z = (in[(ys + 2 * srows) * in_cols + xs] + in[(ys + 2 * srows) * in_cols + xs + 1] +
+                   in[(ys + 2 * srows + 1) * in_cols + xs] + in[(ys + 2 * srows + 1) * in_cols + xs + 1]) / 4;
+            if (normalize) n = orc_f3_normalized(n);
+            out[y * dcols + x] = n.x; out[(y + drows) * dcols + x] = n.y; out[(y + 2 * drows) * dcols + x] = n.z;
+        }
+}
+
+/* tranformMapsKernel, cudafuncs.cu:207-249 (in place; y/z planes untouched when x is NaN) */
+void orc_transform_maps(float *vmap, float *nmap, int cols, int rows, const float R[9], const float t[3])
+{
+    orc_m33 Rm; memcpy(Rm.m, R, sizeof(Rm.m));
+    const orc_f3 tv = {t[0], t[1], t[2]};
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            float vx = vmap[y * cols + x];
+            float outx = orc_qnan();
+            if (!isnan(vx)) {
+                orc_f3 vs = {vx, vmap[(y + rows) * cols + x], vmap[(y + 2 * rows) * cols + x]};
+                orc_f3 vd = orc_f3_add(orc_m33_mul(&Rm, vs), tv);
+                vmap[(y + rows) * cols + x] = vd.y; vmap[(y + 2 * rows) * cols + x] = vd.z; outx = vd.x;
+            }
+            vmap[y * cols + x] = outx;
+            float nx = nmap[y * cols + x];
+            outx = orc_qnan();
+            if (!isnan(nx)) {
+                orc_f3 ns = {nx, nmap[(y + rows) * cols + x], nmap[(y + 2 * rows) * cols + x]};
+                orc_f3 nd = orc_m33_mul(&Rm, ns);
+                nmap[(y + rows) * cols + x] = nd.y; nmap[(y + 2 * rows) * cols + x] = nd.z; outx = nd.x;
+            }
+            nmap[y * cols + x] = outx;
+        }
+}
+
+/* verticesToDepthKernel, cudafuncs.cu:602-613 */
+void orc_vertices_to_depth(const float *v4, int cols, int rows, float cutoff, float *depth)
+{
+    for (int i = 0; i < cols * rows; i++) {
+        float z = v4[i * 4 + 2];
+        depth[i] = (z > cutoff || z <= 0) ? orc_qnan() : z;
+    }
+}
+
+static const float kGauss25[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
+
+/* pyrDownKernelGaussF, cudafuncs.cu:333-364.  Window excludes the last source
+ * row/col (min(.., rows-1)); weights are indexed from the clamped END of the
+ * window; `count` is an int accumulating float weights (exact: they are integers). */
+void orc_pyrdown_gauss_f32(const float *src, int src_cols, int src_rows, float *dst)
+{
+    const int dcols = src_cols / 2, drows = src_rows / 2, D = 5;
+    for (int y = 0; y < drows; y++)
+        for (int x = 0; x < dcols; x++) {
+            int tx = imin(2 * x - D / 2 + D, src_cols - 1);
+            int ty = imin(2 * y - D / 2 + D, src_rows - 1);
+            float sum = 0; int count = 0;
+            for (int cy = imax(0, 2 * y - D / 2); cy < ty; ++cy)
+                for (int cx = imax(0, 2 * x - D / 2); cx < tx; ++cx) {
+                    float s = src[cy * src_cols + cx];
+                    if (!isnan(s)) {
+                        float w = kGauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                        sum += s * w;
+                        count += (int)w;
+                    }
+                }
+            dst[y * dcols + x] = (float)(sum / (float)count);
+        }
+}
+
+/* pyrDownKernelIntensityGauss, cudafuncs.cu:534-564 (skips zeros; float->u8 truncation) */
+void orc_pyrdown_gauss_u8(const uint8_t *src, int src_cols, int src_rows, uint8_t *dst)
+{
+    const int dcols = src_cols / 2, drows = src_rows / 2, D = 5;
+    for (int y = 0; y < drows; y++)
+        for (int x = 0; x < dcols; x++) {
+            int tx = imin(2 * x - D / 2 + D, src_cols - 1);
+            int ty = imin(2 * y - D / 2 + D, src_rows - 1);
+            float sum = 0; int count = 0;
+            for (int cy = imax(0, 2 * y - D / 2); cy < ty; ++cy)
+                for (int cx = imax(0, 2 * x - D / 2); cx < tx; ++cx) {
+                    uint8_t s = src[cy * src_cols + cx];
+                    if (s > 0) {
+                        float w = kGauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                        sum += (float)s * w;
+                        count += (int)w;
+                    }
+                }
+            /* count==0 -> 0/0 = NaN -> CUDA float->uchar conversion gives 0 */
+            float q = sum / (float)count;
+            dst[y * dcols + x] = (q != q) ? 0 : (uint8_t)(int)q;
+        }
+}
+
+/* bgr2IntensityKernel, cudafuncs.cu:626-639.  The texel is RGB ordered (upload
+ * CoFusion.cpp:179), so the weights land as .114 R + .299 G + .587 B. */
+void orc_rgba_to_intensity(const uint8_t *rgba, int cols, int rows, uint8_t *dst)
+{
+    for (int i = 0; i < cols * rows; i++) {
+        int value = (int)((float)rgba[i * 4 + 0] * 0.114f + (float)rgba[i * 4 + 1] * 0.299f + (float)rgba[i * 4 + 2] * 0.587f);
+        dst[i] = (uint8_t)value;
+    }
+}
+
+/* applyKernel, cudafuncs.cu:658-683 + coefficients :691-697.  kernelIndex counts
+ * DOWN from 8 over the clamped neighbourhood, so borders use a shifted subset. */
+void orc_sobel(const uint8_t *src, int cols, int rows, int16_t *dx, int16_t *dy)
+{
+    static const float gsx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+    static const float gsy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            float dxv = 0, dyv = 0; int k = 8;
+            for (int j = imax(y - 1, 0); j <= imin(y + 1, rows - 1); j++)
+                for (int i = imax(x - 1, 0); i <= imin(x + 1, cols - 1); i++) {
+                    dxv += (float)src[j * cols + i] * gsx[k];
+                    dyv += (float)src[j * cols + i] * gsy[k];
+                    --k;
+                }
+            dx[y * cols + x] = (int16_t)(int)dxv;   /* float -> short: truncation */
+            dy[y * cols + x] = (int16_t)(int)dyv;
+        }
+}
+
+/* projectPointsKernel, cudafuncs.cu:718-736 */
+void orc_project_cloud(const float *depth, int cols, int rows, orc_cam il, float *cloud3)
+{
+    const float invFx = 1.0f / il.fx, invFy = 1.0f / il.fy;
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            float z = depth[y * cols + x];
+            cloud3[(y * cols + x) * 3 + 0] = (float)((x - il.cx) * z * invFx);
+            cloud3[(y * cols + x) * 3 + 1] = (float)((y - il.cy) * z * invFy);
+            cloud3[(y * cols + x) * 3 + 2] = z;
+        }
+}
+
+/* Model::generateCUDATextures, Model.cpp:341-343 (depth half; the mask pyramid is
+ * dead because createVMap ignores the mask, cudafuncs.cu:119) */
+void orc_depth_pyramid(const float *depth_filtered, int cols, int rows, float *l1, float *l2)
+{
+    orc_pyrdown_gauss_f32(depth_filtered, cols, rows, l1);
+    orc_pyrdown_gauss_f32(l1, cols / 2, rows / 2, l2);
+}
+
+/* ================================ ICP ========================================= */
+
+typedef struct {
+    orc_m33 Rcurr, Rprev_inv; orc_f3 tcurr, tprev; orc_cam intr;
+    const float *vc, *nc, *vp, *np; float distThres, angleThres; int cols, rows;
+} icp_ctx;
+
+/* ICPReduction::search + getProducts, reduce.cu:283-394.  Returns found; row[7]
+ * is zero when not found.  err: value for the error surface (reduce.cu:301,325). */
+static int icp_row(const icp_ctx *c, int x, int y, float row[7], float *err)
+{
+    const int cols = c->cols, rows = c->rows;
+    for (int i = 0; i < 7; i++) row[i] = 0;
+    *err = 0.0f;
+    orc_f3 vcurr = {c->vc[y * cols + x], c->vc[(y + rows) * cols + x], c->vc[(y + 2 * rows) * cols + x]};
+    orc_f3 vcurr_g = orc_f3_add(orc_m33_mul(&c->Rcurr, vcurr), c->tcurr);
+    orc_f3 vcurr_cp = orc_m33_mul(&c->Rprev_inv, orc_f3_sub(vcurr_g, c->tprev));
+    int ux = orc_f2i_rn(vcurr_cp.x * c->intr.fx / vcurr_cp.z + c->intr.cx);
+    int uy = orc_f2i_rn(vcurr_cp.y * c->intr.fy / vcurr_cp.z + c->intr.cy);
+    if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0) return 0;
+    orc_f3 vprev_g = {c->vp[uy * cols + ux], c->vp[(uy + rows) * cols + ux], c->vp[(uy + 2 * rows) * cols + ux]};
+    orc_f3 ncurr = {c->nc[y * cols + x], c->nc[(y + rows) * cols + x], c->nc[(y + 2 * rows) * cols + x]};
+    orc_f3 ncurr_g = orc_m33_mul(&c->Rcurr, ncurr);
+    orc_f3 nprev_g = {c->np[uy * cols + ux], c->np[(uy + rows) * cols + ux], c->np[(uy + 2 * rows) * cols + ux]};
+    float dist = orc_f3_norm(orc_f3_sub(vprev_g, vcurr_g));
+    float sine = orc_f3_norm(orc_f3_cross(ncurr_g, nprev_g));
+    *err = isfinite(dist) ? dist : 0.0f;
+    int found = (sine < c->angleThres && dist <= c->distThres && !isnan(ncurr.x) && !isnan(nprev_g.x));
+    if (found) {
+        orc_f3 s_cp = orc_m33_mul(&c->Rprev_inv, orc_f3_sub(vcurr_g, c->tprev));
+        orc_f3 d_cp = orc_m33_mul(&c->Rprev_inv, orc_f3_sub(vprev_g, c->tprev));
+        orc_f3 n_cp = orc_m33_mul(&c->Rprev_inv, nprev_g);
+        orc_f3 cr = orc_f3_cross(s_cp, n_cp);
+        row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
+        row[3] = cr.x; row[4] = cr.y; row[5] = cr.z;
+        row[6] = orc_f3_dot(n_cp, orc_f3_sub(s_cp, d_cp));
+    }
+    return found;
+}
+
+static void icp_ctx_fill(icp_ctx *c, const float Rcurr[9], const float tcurr[3], const float *vc, const float *nc,
+                         const float Rprev_inv[9], const float tprev[3], orc_cam intr, const float *vp, const float *np,
+                         float dist_thres, float angle_thres, int cols, int rows)
+{
+    memcpy(c->Rcurr.m, Rcurr, 36); memcpy(c->Rprev_inv.m, Rprev_inv, 36);
+    c->tcurr = orc_f3_make(tcurr[0], tcurr[1], tcurr[2]); c->tprev = orc_f3_make(tprev[0], tprev[1], tprev[2]);
+    c->intr = intr; c->vc = vc; c->nc = nc; c->vp = vp; c->np = np;
+    c->distThres = dist_thres; c->angleThres = angle_thres; c->cols = cols; c->rows = rows;
+}
+
+static void se3_accumulate(const float row[7], int found, int F, int64_t sums[ORC_SE3_WORDS])
+{
+    if (!found) return; /* row is all zero: contributes nothing */
+    int k = 0;
+    for (int i = 0; i < 6; i++)
+        for (int j = i; j < 7; j++) sums[k++] += orc_fix_prod(row[i], row[j], F);
+    sums[27] += orc_fix_prod(row[6], row[6], F);
+    sums[28] += 1;
+}
+
+void orc_icp_step(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float *nmap_curr,
+                  const float Rprev_inv[9], const float tprev[3], orc_cam intr, const float *vmap_g_prev,
+                  const float *nmap_g_prev, float dist_thres, float angle_thres, int cols, int rows,
+                  int64_t sums[ORC_SE3_WORDS], float *err_surface)
+{
+    icp_ctx c;
+    icp_ctx_fill(&c, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev,
+                 dist_thres, angle_thres, cols, rows);
+    memset(sums, 0, sizeof(int64_t) * ORC_SE3_WORDS);
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            float row[7], err;
+            int found = icp_row(&c, x, y, row, &err);
+            if (err_surface) err_surface[y * cols + x] = err;
+            se3_accumulate(row, found, ORC_FIX_ICP, sums);
+        }
+}
+
+/* The reference's own order: thread t of block b sums pixels b*T+t + k*T*B in f32,
+ * then warp(32) shuffle-down tree, block tree over warps, then the second-stage
+ * reduceSum<<<1,MAX_THREADS(=512 on the host pass)>>> (reduce.cu:90-185, 396-417, 476). */
+static void tree29(float (*vals)[29], int n /* n<=32 lanes */)
+{ /* shuffle-down with width 32: lanes >= n read 0-extended (values of missing lanes are 0) */
+    for (int offset = 16; offset > 0; offset /= 2)
+        for (int l = 0; l < 32; l++)
+            for (int k = 0; k < 29; k++) {
+                float other = (l + offset < 32 && l + offset < n) ? vals[l + offset][k] : 0.0f;
+                /* __shfl_down past the warp returns the caller's own value; the reference's
+                 * result only uses lane 0, whose partners are always in range. */
+                if (l + offset < 32) vals[l][k] += other;
+            }
+}
+
+static void block_reduce29(float (*thread_vals)[29], int threads, float out[29])
+{
+    float warp_tot[32][29];
+    int nwarps = threads / 32;
+    memset(warp_tot, 0, sizeof(warp_tot));
+    for (int w = 0; w < nwarps; w++) {
+        float lanes[32][29];
+        memcpy(lanes, thread_vals + w * 32, sizeof(lanes));
+        tree29(lanes, 32);
+        memcpy(warp_tot[w], lanes[0], sizeof(float) * 29);
+    }
+    tree29(warp_tot, 32);
+    memcpy(out, warp_tot[0], sizeof(float) * 29);
+}
+
+void orc_icp_step_f32tree(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float *nmap_curr,
+                          const float Rprev_inv[9], const float tprev[3], orc_cam intr, const float *vmap_g_prev,
+                          const float *nmap_g_prev, float dist_thres, float angle_thres, int cols, int rows,
+                          int threads, int blocks, float out29[29])
+{
+    icp_ctx c;
+    icp_ctx_fill(&c, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev,
+                 dist_thres, angle_thres, cols, rows);
+    const int N = cols * rows;
+    float(*block_out)[29] = calloc((size_t)blocks, sizeof(float[29]));
+    float(*tv)[29] = calloc((size_t)threads, sizeof(float[29]));
+    for (int b = 0; b < blocks; b++) {
+        memset(tv, 0, sizeof(float[29]) * (size_t)threads);
+        for (int t = 0; t < threads; t++)
+            for (int i = b * threads + t; i < N; i += threads * blocks) {
+                int y = i / cols, x = i - y * cols;
+                float row[7], err;
+                int found = icp_row(&c, x, y, row, &err);
+                int k = 0;
+                for (int a = 0; a < 6; a++)
+                    for (int j = a; j < 7; j++) tv[t][k++] += row[a] * row[j];
+                tv[t][27] += row[6] * row[6];
+                tv[t][28] += (float)found;
+            }
+        block_reduce29(tv, threads, block_out[b]);
+    }
+    /* second stage: 512 threads grid-stride over `blocks` partials */
+    const int T2 = 512;
+    float(*tv2)[29] = calloc((size_t)T2, sizeof(float[29]));
+    for (int t = 0; t < T2; t++)
+        for (int i = t; i < blocks; i += T2)
+            for (int k = 0; k < 29; k++) tv2[t][k] += block_out[i][k];
+    block_reduce29(tv2, T2, out29);
+    free(tv2); free(tv); free(block_out);
+}
+
+/* host unpacking of the 29 sums, reduce.cu:481-498 */
+void orc_se3_sums_to_host(const int64_t sums[ORC_SE3_WORDS], int F, float A[36], float b[6], float residual[2])
+{
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            float value = (float)orc_fix_to_double(sums[shift++], F);
+            if (j == 6) b[i] = value;
+            else A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+    residual[0] = (float)orc_fix_to_double(sums[27], F);
+    residual[1] = (float)sums[28];
+}
+
+/* ============================== RGB residual ================================== */
+
+/* RGBResidual::getProducts, reduce.cu:785-865 (MASK_RGB_RESIDUAL is never defined) */
+void orc_rgb_residual(float min_scale, const int16_t *dIdx, const int16_t *dIdy, const float *last_depth,
+                      const float *next_depth, const uint8_t *last_image, const uint8_t *next_image,
+                      orc_dataterm *corres, float max_depth_delta, const float kt[3], const float krkinv[9],
+                      int cols, int rows, int *sigma_sum, int *count)
+{
+    int cnt = 0, sig = 0;
+    for (int k = 0; k < cols * rows; k++) {
+        int i = k / cols, j0 = k - i * cols;
+        orc_dataterm c; memset(&c, 0, sizeof(c));
+        if (j0 < cols - 5 && i < rows - 1) {
+            int valid = 1;
+            for (int u = imax(i - 2, 0); u < imin(i + 2, rows); u++)
+                for (int v = imax(j0 - 2, 0); v < imin(j0 + 2, cols); v++) valid = valid && (next_image[u * cols + v] > 0);
+            if (valid) {
+                int valx = dIdx[i * cols + j0], valy = dIdy[i * cols + j0];
+                float mTwo = (float)((valx * valx) + (valy * valy));
+                if (mTwo >= min_scale) {
+                    int y = i, x = j0;
+                    float d1 = next_depth[y * cols + x];
+                    if (!isnan(d1)) {
+                        float transformed_d1 = (float)(d1 * (krkinv[6] * x + krkinv[7] * y + krkinv[8]) + kt[2]);
+                        int u0 = orc_f2i_rn((d1 * (krkinv[0] * x + krkinv[1] * y + krkinv[2]) + kt[0]) / transformed_d1);
+                        int v0 = orc_f2i_rn((d1 * (krkinv[3] * x + krkinv[4] * y + krkinv[5]) + kt[1]) / transformed_d1);
+                        if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+                            float d0 = last_depth[v0 * cols + u0];
+                            if (d0 > 0 && fabsf(transformed_d1 - d0) <= max_depth_delta && last_image[v0 * cols + u0] != 0) {
+                                c.zero_x = (int16_t)u0; c.zero_y = (int16_t)v0; c.one_x = (int16_t)x; c.one_y = (int16_t)y;
+                                c.diff = (float)next_image[y * cols + x] - (float)last_image[v0 * cols + u0];
+                                c.valid = 1;
+                                cnt += 1;
+                                sig += (int)(c.diff * c.diff);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        corres[k] = c; /* flat index, pitch ignored: reduce.cu:862 */
+    }
+    *count = cnt; *sigma_sum = sig;
+}
+
+/* RGBReduction::getProducts, reduce.cu:521-604 */
+void orc_rgb_step(const orc_dataterm *corres, float sigma, const float *cloud3, float fx, float fy,
+                  const int16_t *dIdx, const int16_t *dIdy, float sobel_scale, int cols, int rows,
+                  int64_t sums[ORC_SE3_WORDS])
+{
+    memset(sums, 0, sizeof(int64_t) * ORC_SE3_WORDS);
+    for (int i = 0; i < cols * rows; i++) {
+        const orc_dataterm *c = &corres[i];
+        if (!c->valid) continue;
+        float row[7];
+        float w = sigma + fabsf(c->diff);
+        w = w > FLT_EPSILON ? 1.0f / w : 1.0f;
+        if (sigma == -1) w = 1;
+        row[6] = -w * c->diff;
+        const float *cp = cloud3 + (c->zero_y * cols + c->zero_x) * 3;
+        float invz = 1.0f / cp[2]; /* (float)(1.0/z) == 1.0f/z, both correctly rounded */
+        float dI_dx_val = w * sobel_scale * (float)dIdx[c->one_y * cols + c->one_x];
+        float dI_dy_val = w * sobel_scale * (float)dIdy[c->one_y * cols + c->one_x];
+        float v0 = dI_dx_val * fx * invz;
+        float v1 = dI_dy_val * fy * invz;
+        float v2 = -(v0 * cp[0] + v1 * cp[1]) * invz;
+        row[0] = v0; row[1] = v1; row[2] = v2;
+        row[3] = -cp[2] * v1 + cp[1] * v2;
+        row[4] = cp[2] * v0 - cp[0] * v2;
+        row[5] = -cp[1] * v0 + cp[0] * v1;
+        se3_accumulate(row, 1, ORC_FIX_RGB, sums);
+    }
+}
+
+/* ================================== SO3 ======================================= */
+
+static inline void so3_gradient(const uint8_t *img, int cols, int x, int y, float *gx, float *gy)
+{ /* SO3Reduction::getGradient, reduce.cu:989-1005 */
+    float actu = (float)img[y * cols + x];
+    float back = (float)img[y * cols + x - 1], fore = (float)img[y * cols + x + 1];
+    *gx = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+    back = (float)img[(y - 1) * cols + x]; fore = (float)img[(y + 1) * cols + x];
+    *gy = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+}
+
+/* SO3Reduction::getProducts, reduce.cu:1007-1090 */
+void orc_so3_step(const uint8_t *last_image, const uint8_t *next_image, const float image_basis[9],
+                  const float kinv[9], const float krlr[9], int cols, int rows, int64_t sums[ORC_SO3_WORDS])
+{
+    orc_m33 B, Ki; memcpy(B.m, image_basis, 36); memcpy(Ki.m, kinv, 36);
+    memset(sums, 0, sizeof(int64_t) * ORC_SO3_WORDS);
+    for (int k = 0; k < cols * rows; k++) {
+        int y = k / cols, x = k - y * cols;
+        orc_f3 unwarped = {(float)x, (float)y, 1.0f};
+        orc_f3 warped = orc_m33_mul(&B, unwarped);
+        int wx = orc_f2i_rn(warped.x / warped.z), wy = orc_f2i_rn(warped.y / warped.z);
+        if (!(wx >= 1 && wx < cols - 1 && wy >= 1 && wy < rows - 1 && x >= 1 && x < cols - 1 && y >= 1 && y < rows - 1)) continue;
+        float gnx, gny, glx, gly;
+        so3_gradient(next_image, cols, wx, wy, &gnx, &gny);
+        so3_gradient(last_image, cols, x, y, &glx, &gly);
+        float gx = (gnx + glx) / 2.0f, gy = (gny + gly) / 2.0f;
+        orc_f3 point = orc_m33_mul(&Ki, unwarped);
+        float z2 = point.z * point.z;
+        float a = krlr[0], b = krlr[1], c = krlr[2], d = krlr[3], e = krlr[4], f = krlr[5], g = krlr[6], h = krlr[7], i = krlr[8];
+        orc_f3 left = {((point.z * (d * gy + a * gx)) - (gy * g * y) - (gx * g * x)) / z2,
+                       ((point.z * (e * gy + b * gx)) - (gy * h * y) - (gx * h * x)) / z2,
+                       ((point.z * (f * gy + c * gx)) - (gy * i * y) - (gx * i * x)) / z2};
+        orc_f3 jac = orc_f3_cross(left, point);
+        float row[4] = {jac.x, jac.y, jac.z,
+                        -((float)next_image[wy * cols + wx] - (float)last_image[y * cols + x])};
+        int s = 0;
+        for (int p = 0; p < 3; p++)
+            for (int q = p; q < 4; q++) sums[s++] += orc_fix_prod(row[p], row[q], ORC_FIX_SO3);
+        sums[9] += orc_fix_prod(row[3], row[3], ORC_FIX_SO3);
+        sums[10] += 1;
+    }
+}
+
+void orc_so3_sums_to_host(const int64_t sums[ORC_SO3_WORDS], int F, float A[9], float b[3], float residual[2])
+{ /* reduce.cu:1158-1175 */
+    int shift = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) {
+            float value = (float)orc_fix_to_double(sums[shift++], F);
+            if (j == 3) b[i] = value;
+            else A[j * 3 + i] = A[i * 3 + j] = value;
+        }
+    residual[0] = (float)orc_fix_to_double(sums[9], F);
+    residual[1] = (float)sums[10];
+}
+
+/* ============================ RGBDOdometry ==================================== */
+
+struct orc_odometry {
+    int width, height; orc_cam intr;
+    float *vmaps_tmp, *nmaps_tmp;                       /* RGBA32F copies, RGBDOdometry.h:78-79 */
+    float *vmaps_g_prev[ORC_NUM_PYRS], *nmaps_g_prev[ORC_NUM_PYRS];
+    float *vmaps_curr[ORC_NUM_PYRS], *nmaps_curr[ORC_NUM_PYRS];
+    float *lastDepth[ORC_NUM_PYRS], *nextDepth[ORC_NUM_PYRS];
+    uint8_t *lastImage[ORC_NUM_PYRS], *nextImage[ORC_NUM_PYRS], *lastNextImage[ORC_NUM_PYRS];
+    int16_t *dIdx[ORC_NUM_PYRS], *dIdy[ORC_NUM_PYRS];
+    float *cloud[ORC_NUM_PYRS];
+    orc_dataterm *corres[ORC_NUM_PYRS];
+    float distThres, angleThres, sobelScale, maxDepthDeltaRGB, maxDepthRGB;
+    float minGrad[ORC_NUM_PYRS];
+};
+
+orc_odometry *orc_odom_create(int width, int height, float cx, float cy, float fx, float fy)
+{ /* RGBDOdometry ctor, RGBDOdometry.cpp:21-106; defaults RGBDOdometry.h:35-36 */
+    orc_odometry *o = calloc(1, sizeof(*o));
+    o->width = width; o->height = height;
+    o->intr.fx = fx; o->intr.fy = fy; o->intr.cx = cx; o->intr.cy = cy;
+    o->distThres = 0.10f;
+    o->angleThres = (float)sin(20.f * 3.14159254f / 180.f);
+    o->sobelScale = (float)(1.0 / pow(2.0, 3));
+    o->maxDepthDeltaRGB = 0.07f; o->maxDepthRGB = 6.0f;
+    o->minGrad[0] = 5; o->minGrad[1] = 3; o->minGrad[2] = 1;
+    size_t n0 = (size_t)width * height;
+    o->vmaps_tmp = calloc(n0 * 4, sizeof(float)); o->nmaps_tmp = calloc(n0 * 4, sizeof(float));
+    for (int i = 0; i < ORC_NUM_PYRS; i++) {
+        size_t n = (size_t)(width >> i) * (height >> i);
+        o->vmaps_g_prev[i] = calloc(n * 3, 4); o->nmaps_g_prev[i] = calloc(n * 3, 4);
+        o->vmaps_curr[i] = calloc(n * 3, 4); o->nmaps_curr[i] = calloc(n * 3, 4);
+        o->lastDepth[i] = calloc(n, 4); o->nextDepth[i] = calloc(n, 4);
+        o->lastImage[i] = calloc(n, 1); o->nextImage[i] = calloc(n, 1); o->lastNextImage[i] = calloc(n, 1);
+        o->dIdx[i] = calloc(n, 2); o->dIdy[i] = calloc(n, 2);
+        o->cloud[i] = calloc(n * 3, 4); o->corres[i] = calloc(n, sizeof(orc_dataterm));
+    }
+    return o;
+}
+
+void orc_odom_destroy(orc_odometry *o)
+{
+    if (!o) return;
+    free(o->vmaps_tmp); free(o->nmaps_tmp);
+    for (int i = 0; i < ORC_NUM_PYRS; i++) {
+        free(o->vmaps_g_prev[i]); free(o->nmaps_g_prev[i]); free(o->vmaps_curr[i]); free(o->nmaps_curr[i]);
+        free(o->lastDepth[i]); free(o->nextDepth[i]); free(o->lastImage[i]); free(o->nextImage[i]);
+        free(o->lastNextImage[i]); free(o->dIdx[i]); free(o->dIdy[i]); free(o->cloud[i]); free(o->corres[i]);
+    }
+    free(o);
+}
+
+const void *orc_odom_buffer(const orc_odometry *o, int which, int level)
+{
+    switch (which) {
+        case 0: return o->vmaps_curr[level]; case 1: return o->nmaps_curr[level];
+        case 2: return o->vmaps_g_prev[level]; case 3: return o->nmaps_g_prev[level];
+        case 4: return o->lastDepth[level]; case 5: return o->nextDepth[level];
+        case 6: return o->lastImage[level]; case 7: return o->nextImage[level]; case 8: return o->lastNextImage[level];
+        case 9: return o->dIdx[level]; case 10: return o->dIdy[level];
+        case 11: return o->cloud[level]; case 12: return o->corres[level];
+        default: return 0;
+    }
+}
+
+/* RGBDOdometry::initICPModel, RGBDOdometry.cpp:143-175 */
+void orc_odom_init_icp_model(orc_odometry *o, const float *pred_v4, const float *pred_n4, const float pose[16])
+{
+    size_t n0 = (size_t)o->width * o->height;
+    memcpy(o->vmaps_tmp, pred_v4, n0 * 16); memcpy(o->nmaps_tmp, pred_n4, n0 * 16);
+    orc_copy_maps(o->vmaps_tmp, o->nmaps_tmp, o->width, o->height, o->vmaps_g_prev[0], o->nmaps_g_prev[0]);
+    for (int i = 1; i < ORC_NUM_PYRS; ++i) {
+        orc_resize_map(o->vmaps_g_prev[i - 1], o->width >> (i - 1), o->height >> (i - 1), o->vmaps_g_prev[i], 0);
+        orc_resize_map(o->nmaps_g_prev[i - 1], o->width >> (i - 1), o->height >> (i - 1), o->nmaps_g_prev[i], 1);
+    }
+    float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+    float t[3] = {pose[3], pose[7], pose[11]};
+    for (int i = 0; i < ORC_NUM_PYRS; ++i)
+        orc_transform_maps(o->vmaps_g_prev[i], o->nmaps_g_prev[i], o->width >> i, o->height >> i, R, t);
+}
+
+/* RGBDOdometry::populateRGBDData, RGBDOdometry.cpp:177-194 (mask pyramid is dead data) */
+static void populate_rgbd(orc_odometry *o, const uint8_t *rgba, float **depths, uint8_t **images)
+{
+    orc_vertices_to_depth(o->vmaps_tmp, o->width, o->height, o->maxDepthRGB, depths[0]);
+    for (int i = 0; i + 1 < ORC_NUM_PYRS; i++) orc_pyrdown_gauss_f32(depths[i], o->width >> i, o->height >> i, depths[i + 1]);
+    orc_rgba_to_intensity(rgba, o->width, o->height, images[0]);
+    for (int i = 0; i + 1 < ORC_NUM_PYRS; i++) orc_pyrdown_gauss_u8(images[i], o->width >> i, o->height >> i, images[i + 1]);
+}
+/* initRGBModel / initRGB: both read vmaps_tmp, which holds the MODEL prediction
+ * (RGBDOdometry.cpp:196-204) -> nextDepth == lastDepth in frame-to-model tracking. */
+void orc_odom_init_rgb_model(orc_odometry *o, const uint8_t *pred_rgba) { populate_rgbd(o, pred_rgba, o->lastDepth, o->lastImage); }
+void orc_odom_init_rgb(orc_odometry *o, const uint8_t *rgba) { populate_rgbd(o, rgba, o->nextDepth, o->nextImage); }
+
+/* RGBDOdometry::initICP(depthPyramid,..), RGBDOdometry.cpp:110-118 */
+void orc_odom_init_icp(orc_odometry *o, const float *const depth_pyr[ORC_NUM_PYRS], float depth_cutoff)
+{
+    for (int i = 0; i < ORC_NUM_PYRS; ++i) {
+        orc_create_vmap(depth_pyr[i], o->width >> i, o->height >> i, cam_level(o->intr, i), depth_cutoff, o->vmaps_curr[i]);
+        orc_create_nmap(o->vmaps_curr[i], o->width >> i, o->height >> i, o->nmaps_curr[i]);
+    }
+}
+
+/* RGBDOdometry::initFirstRGB, RGBDOdometry.cpp:206-215 */
+void orc_odom_init_first_rgb(orc_odometry *o, const uint8_t *rgba)
+{
+    orc_rgba_to_intensity(rgba, o->width, o->height, o->lastNextImage[0]);
+    for (int i = 0; i + 1 < ORC_NUM_PYRS; i++)
+        orc_pyrdown_gauss_u8(o->lastNextImage[i], o->width >> i, o->height >> i, o->lastNextImage[i + 1]);
+}
+
+static void k_matrix(orc_cam c, double K[9])
+{
+    memset(K, 0, sizeof(double) * 9);
+    K[0] = c.fx; K[4] = c.fy; K[2] = c.cx; K[5] = c.cy; K[8] = 1;
+}
+
+/* RGBDOdometry::getIncrementalTransformation, RGBDOdometry.cpp:217-477 */
+void orc_odom_get_incremental_transformation(orc_odometry *o, float trans[3], float rot[9], const orc_track_opts *opts,
+                                             float *icp_err_surface, orc_track_stats *st)
+{
+    const int rgbOnly = opts->rgb_only;
+    const float icpWeight = opts->icp_weight;
+    const int icp = !rgbOnly && icpWeight > 0;
+    const int rgb = rgbOnly || icpWeight < 100;
+    orc_track_stats local; if (!st) st = &local;
+    memset(st, 0, sizeof(*st));
+
+    float Rprev[9], tprev[3], Rcurr[9], tcurr[3];
+    memcpy(Rprev, rot, 36); memcpy(tprev, trans, 12); memcpy(Rcurr, rot, 36); memcpy(tcurr, trans, 12);
+
+    if (rgb)
+        for (int i = 0; i < ORC_NUM_PYRS; i++) orc_sobel(o->nextImage[i], o->width >> i, o->height >> i, o->dIdx[i], o->dIdy[i]);
+
+    double resultR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+
+    if (opts->so3) { /* :239-310 */
+        const int L = 2, cols = o->width >> L, rows = o->height >> L;
+        float R_lr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        double K[9], Kinv[9];
+        k_matrix(cam_level(o->intr, L), K);
+        orc_inv33d(K, Kinv);
+        float lastError = FLT_MAX / 2, lastCount = FLT_MAX / 2;
+        double lastResultR[9]; memcpy(lastResultR, resultR, sizeof(resultR));
+        for (int it = 0; it < 10; it++) {
+            double tmp[9], H[9], KR[9];
+            orc_mul33d(K, resultR, tmp); orc_mul33d(tmp, Kinv, H);
+            memcpy(KR, tmp, sizeof(tmp));
+            float basis[9], kinvf[9], krlr[9];
+            for (int k = 0; k < 9; k++) { basis[k] = (float)H[k]; kinvf[k] = (float)Kinv[k]; krlr[k] = (float)KR[k]; }
+            int64_t sums[ORC_SO3_WORDS];
+            float jtj[9], jtr[3], residual[2];
+            orc_so3_step(o->lastNextImage[L], o->nextImage[L], basis, kinvf, krlr, cols, rows, sums);
+            orc_so3_sums_to_host(sums, ORC_FIX_SO3, jtj, jtr, residual);
+            st->so3_iterations = it + 1;
+            st->last_so3_error = sqrtf(residual[0]) / residual[1];
+            st->last_so3_count = residual[1];
+            /* "Converged": compares lastError with lastSO3Count (sic), :285 */
+            if (st->last_so3_error < lastError && (double)fabsf(lastError - st->last_so3_count) < 0.001) break;
+            else if ((double)st->last_so3_error > (double)lastError + 0.001) {
+                st->last_so3_error = lastError; st->last_so3_count = lastCount;
+                memcpy(resultR, lastResultR, sizeof(resultR));
+                break;
+            }
+            lastError = st->last_so3_error; lastCount = st->last_so3_count;
+            memcpy(lastResultR, resultR, sizeof(resultR));
+            float delta[3];
+            orc_ldlt_f(3, jtj, jtr, delta);
+            double dd[3] = {delta[0], delta[1], delta[2]}, rotUpdate[9];
+            orc_rodrigues(dd, rotUpdate);
+            float ru[9], nr[9];
+            for (int k = 0; k < 9; k++) ru[k] = (float)rotUpdate[k];
+            orc_mul33f(ru, R_lr, nr);
+            memcpy(R_lr, nr, sizeof(nr));
+            for (int k = 0; k < 9; k++) resultR[k] = R_lr[k];
+        }
+    }
+
+    int iterations[ORC_NUM_PYRS];
+    iterations[0] = opts->fast_odom ? 3 : 10;
+    iterations[1] = opts->pyramid ? 5 : 0;
+    iterations[2] = opts->pyramid ? 4 : 0;
+
+    float Rprev_inv[9];
+    orc_inv33f(Rprev, Rprev_inv);
+
+    double resultRt[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (opts->so3)
+        for (int x = 0; x < 3; x++)
+            for (int y = 0; y < 3; y++) resultRt[x * 4 + y] = resultR[x * 3 + y];
+
+    float residual[2] = {0, 0}; /* reference leaves this uninitialised when !icp (:401) */
+
+    for (int i = ORC_NUM_PYRS - 1; i >= 0; i--) {
+        const int cols = o->width >> i, rows = o->height >> i;
+        const orc_cam il = cam_level(o->intr, i);
+        if (rgb) orc_project_cloud(o->lastDepth[i], cols, rows, il, o->cloud[i]);
+        double K[9], Kinv[9];
+        k_matrix(il, K);
+        orc_inv33d(K, Kinv);
+        st->last_rgb_error = FLT_MAX;
+
+        for (int j = 0; j < iterations[i]; j++) {
+            double Rt[16];
+            orc_inv44_affine_d(resultRt, Rt);
+            double R[9] = {Rt[0], Rt[1], Rt[2], Rt[4], Rt[5], Rt[6], Rt[8], Rt[9], Rt[10]};
+            double tmp[9], KRK[9];
+            orc_mul33d(K, R, tmp); orc_mul33d(tmp, Kinv, KRK);
+            float krkInv[9];
+            for (int k = 0; k < 9; k++) krkInv[k] = (float)KRK[k];
+            double tv[3] = {Rt[3], Rt[7], Rt[11]};
+            float kt[3];
+            for (int r = 0; r < 3; r++) kt[r] = (float)(K[r * 3 + 0] * tv[0] + K[r * 3 + 1] * tv[1] + K[r * 3 + 2] * tv[2]);
+
+            int sigma = 0, rgbSize = 0;
+            if (rgb) {
+                float minScale = (float)(pow(o->minGrad[i], 2.0) / pow(o->sobelScale, 2.0));
+                orc_rgb_residual(minScale, o->dIdx[i], o->dIdy[i], o->lastDepth[i], o->nextDepth[i], o->lastImage[i],
+                                 o->nextImage[i], o->corres[i], o->maxDepthDeltaRGB, kt, krkInv, cols, rows, &sigma, &rgbSize);
+            }
+            float tmpError = (float)(sqrt((double)sigma) / rgbSize); /* sqrt(int)->double, / int, -> float */
+            float sigmaVal = (tmpError == 0) ? 1 : (float)rgbSize;   /* (sic) the COUNT, :374 */
+            if (rgbOnly && tmpError > st->last_rgb_error) break;
+            st->last_rgb_error = tmpError; st->last_rgb_count = (float)rgbSize;
+            if (rgbOnly) sigmaVal = -1;
+
+            float A_icp[36], b_icp[6], A_rgbd[36], b_rgbd[6];
+            memset(A_icp, 0, sizeof(A_icp)); memset(b_icp, 0, sizeof(b_icp));
+            memset(A_rgbd, 0, sizeof(A_rgbd)); memset(b_rgbd, 0, sizeof(b_rgbd));
+            if (icp) {
+                int64_t sums[ORC_SE3_WORDS];
+                orc_icp_step(Rcurr, tcurr, o->vmaps_curr[i], o->nmaps_curr[i], Rprev_inv, tprev, il, o->vmaps_g_prev[i],
+                             o->nmaps_g_prev[i], o->distThres, o->angleThres, cols, rows, sums,
+                             (i == 0 && j == iterations[i] - 1) ? icp_err_surface : 0);
+                orc_se3_sums_to_host(sums, ORC_FIX_ICP, A_icp, b_icp, residual);
+            }
+            st->last_icp_error = sqrtf(residual[0]) / residual[1];
+            st->last_icp_count = residual[1];
+            if (rgb) {
+                int64_t sums[ORC_SE3_WORDS]; float dummy[2];
+                orc_rgb_step(o->corres[i], sigmaVal, o->cloud[i], il.fx, il.fy, o->dIdx[i], o->dIdy[i], o->sobelScale,
+                             cols, rows, sums);
+                orc_se3_sums_to_host(sums, ORC_FIX_RGB, A_rgbd, b_rgbd, dummy);
+            }
+            double lastA[36], lastb[6], result[6];
+            if (icp && rgb) {
+                double w = icpWeight;
+                for (int k = 0; k < 36; k++) lastA[k] = (double)A_rgbd[k] + w * w * (double)A_icp[k];
+                for (int k = 0; k < 6; k++) lastb[k] = (double)b_rgbd[k] + w * (double)b_icp[k];
+            } else if (icp) {
+                for (int k = 0; k < 36; k++) lastA[k] = A_icp[k];
+                for (int k = 0; k < 6; k++) lastb[k] = b_icp[k];
+            } else {
+                for (int k = 0; k < 36; k++) lastA[k] = A_rgbd[k];
+                for (int k = 0; k < 6; k++) lastb[k] = b_rgbd[k];
+            }
+            orc_ldlt_d(6, lastA, lastb, result);
+            memcpy(st->lastA, lastA, sizeof(lastA)); memcpy(st->lastb, lastb, sizeof(lastb));
+
+            /* OdometryProvider::computeUpdateSE3, OdometryProvider.h:69-89 */
+            double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rr[9], nrt[16];
+            double rvec[3] = {result[3], result[4], result[5]};
+            orc_rodrigues(rvec, Rr);
+            for (int r = 0; r < 3; r++) { upd[r * 4 + 0] = Rr[r * 3 + 0]; upd[r * 4 + 1] = Rr[r * 3 + 1]; upd[r * 4 + 2] = Rr[r * 3 + 2]; upd[r * 4 + 3] = result[r]; }
+            orc_mul44d(upd, resultRt, nrt);
+            memcpy(resultRt, nrt, sizeof(nrt));
+            /* rgbOdom (Isometry3f) = float(resultRt); currentT = [Rprev|tprev] * rgbOdom^-1 with the
+             * isometry inverse [R^T | -R^T t], RGBDOdometry.cpp:452-460 */
+            float Ro[9], to[3];
+            for (int r = 0; r < 3; r++) { Ro[r * 3 + 0] = (float)resultRt[r * 4 + 0]; Ro[r * 3 + 1] = (float)resultRt[r * 4 + 1]; Ro[r * 3 + 2] = (float)resultRt[r * 4 + 2]; to[r] = (float)resultRt[r * 4 + 3]; }
+            float Rinv[9] = {Ro[0], Ro[3], Ro[6], Ro[1], Ro[4], Ro[7], Ro[2], Ro[5], Ro[8]};
+            float tinv[3];
+            for (int r = 0; r < 3; r++) tinv[r] = -(Rinv[r * 3 + 0] * to[0] + Rinv[r * 3 + 1] * to[1] + Rinv[r * 3 + 2] * to[2]);
+            orc_mul33f(Rprev, Rinv, Rcurr);
+            for (int r = 0; r < 3; r++) tcurr[r] = (Rprev[r * 3 + 0] * tinv[0] + Rprev[r * 3 + 1] * tinv[1] + Rprev[r * 3 + 2] * tinv[2]) + tprev[r];
+        }
+    }
+
+    if (rgb) { /* divergence guard :464-467 */
+        float d[3] = {tcurr[0] - tprev[0], tcurr[1] - tprev[1], tcurr[2] - tprev[2]};
+        if ((double)sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) > 0.3) { memcpy(Rcurr, Rprev, 36); memcpy(tcurr, tprev, 12); }
+    }
+    if (opts->so3) /* :469-473 */
+        for (int i = 0; i < ORC_NUM_PYRS; i++) { uint8_t *t = o->lastNextImage[i]; o->lastNextImage[i] = o->nextImage[i]; o->nextImage[i] = t; }
+    memcpy(trans, tcurr, 12); memcpy(rot, Rcurr, 36);
+}
