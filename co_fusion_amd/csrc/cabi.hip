@@ -82,7 +82,8 @@ void cf_destroy(cf_ctx* ctx)
 }
 
 const char* cf_last_error(const cf_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
-int cf_set_stream(cf_ctx* ctx, void* s) { if (!ctx) return CF_EINVAL; ctx->stream = s ? (hipStream_t)s : ctx->own_stream; return CF_OK; }
+int cf_set_stream(cf_ctx* ctx, void* s) { if (!ctx) return CF_EINVAL; ctx->stream = (hipStream_t)s; return CF_OK; }  // NULL = the legacy default stream
+int cf_use_own_stream(cf_ctx* ctx) { if (!ctx) return CF_EINVAL; ctx->stream = ctx->own_stream; return CF_OK; }
 void* cf_get_stream(cf_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int cf_synchronize(cf_ctx* ctx) { if (!ctx) return CF_EINVAL; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return CF_OK; }
 int cf_malloc(cf_ctx* ctx, uint64_t bytes, void** dptr)

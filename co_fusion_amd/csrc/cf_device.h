@@ -35,10 +35,10 @@ __device__ __forceinline__ f3 cross(f3 a, f3 b)
 {
     return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ float norm(f3 a) { return __fsqrt_rn(dot(a, a)); }
+__device__ __forceinline__ float norm(f3 a) { return sqrtf(dot(a, a)); }
 __device__ __forceinline__ f3 normalized(f3 a)
 {
-    const float rn = 1.0f / __fsqrt_rn(dot(a, a));
+    const float rn = 1.0f / sqrtf(dot(a, a));
     return f3{a.x * rn, a.y * rn, a.z * rn};
 }
 __device__ __forceinline__ f3 mul(const m33& m, f3 a)

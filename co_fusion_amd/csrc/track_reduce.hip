@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(1024) so3_prealign_kernel(OdomDev* const* __re
                 float jtj[9], jtr[3], residual[2];
                 so3_unpack(totals, jtj, jtr, residual);
                 od->stats.so3_iterations = it + 1;
-                float err = __fsqrt_rn(residual[0]) / residual[1];
+                float err = sqrtf(residual[0]) / residual[1];
                 float cnt = residual[1];
                 if (err < s_lastError && (double)fabsf(s_lastError - cnt) < 0.001) {
                     s_done = 1;  // "converged" (compares error with COUNT, RGBDOdometry.cpp:285)
@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(256) gn_solve_kernel(OdomDev* const* __restric
             for (int k = 0; k < 36; k++) { A_icp[k] = 0; A_rgb[k] = 0; }
             for (int k = 0; k < 6; k++) { b_icp[k] = 0; b_rgb[k] = 0; }
             if (od->icp) se3_unpack(s_icp, kFixICP, A_icp, b_icp, od->residual);
-            od->stats.last_icp_error = __fsqrt_rn(od->residual[0]) / od->residual[1];
+            od->stats.last_icp_error = sqrtf(od->residual[0]) / od->residual[1];
             od->stats.last_icp_count = od->residual[1];
             if (od->rgb) se3_unpack(s_rgb, kFixRGB, A_rgb, b_rgb, dummy);
             double lastA[36], lastb[6], result[6];
@@ -626,7 +626,7 @@ __global__ void gn_finish_kernel(OdomDev* const* __restrict__ models)
     if (threadIdx.x != 0) return;
     if (od->rgb) {
         const float d0 = od->tcurr[0] - od->tprev[0], d1 = od->tcurr[1] - od->tprev[1], d2 = od->tcurr[2] - od->tprev[2];
-        if ((double)__fsqrt_rn(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
+        if ((double)sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
             for (int k = 0; k < 9; k++) od->Rcurr[k] = od->Rprev[k];
             for (int k = 0; k < 3; k++) od->tcurr[k] = od->tprev[k];
         }

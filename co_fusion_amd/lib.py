@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcofusion_hip.so")
 
 # every symbol include/cofusion_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "cf_create", "cf_destroy", "cf_last_error", "cf_set_stream", "cf_get_stream", "cf_synchronize", "cf_malloc",
+    "cf_create", "cf_destroy", "cf_last_error", "cf_set_stream", "cf_use_own_stream", "cf_get_stream", "cf_synchronize", "cf_malloc",
     "cf_free", "cf_memcpy_h2d", "cf_memcpy_d2h", "cf_create_vmap", "cf_create_nmap", "cf_copy_maps", "cf_resize_map",
     "cf_transform_maps", "cf_vertices_to_depth", "cf_pyrdown_gauss_f32", "cf_pyrdown_gauss_u8",
     "cf_rgba_to_intensity", "cf_sobel", "cf_project_cloud", "cf_icp_step", "cf_rgb_residual", "cf_rgb_step",
@@ -44,6 +44,10 @@ def load() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the product path)")
+        # PyTorch bundles its own libamdhip64/libhsa-runtime64.  Device pointers and streams are only
+        # interchangeable when both sides run on ONE HIP runtime instance, so torch must be loaded
+        # first; the library's libamdhip64.so.7 dependency then resolves to the already-loaded copy.
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         _lib.cf_last_error.restype = C.c_char_p
         _lib.cf_get_stream.restype = C.c_void_p

@@ -68,8 +68,10 @@ typedef struct {
 int cf_create(const cf_config *cfg, cf_ctx **out);
 void cf_destroy(cf_ctx *ctx);
 const char *cf_last_error(const cf_ctx *ctx);
-/* all work is enqueued on this stream (default: a ctx-owned non-blocking stream) */
+/* all work is enqueued on one stream: by default a ctx-owned non-blocking stream; cf_set_stream
+ * switches to a caller-owned hipStream_t (NULL = the legacy default stream), cf_use_own_stream back */
 int cf_set_stream(cf_ctx *ctx, void *hip_stream);
+int cf_use_own_stream(cf_ctx *ctx);
 void *cf_get_stream(cf_ctx *ctx);
 int cf_synchronize(cf_ctx *ctx);
 /* device memory helpers for hosts that do not link HIP themselves */

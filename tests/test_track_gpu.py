@@ -167,9 +167,6 @@ def test_get_incremental_transformation(ctx, opts):
     from co_fusion_amd import api
     fp = common.frame_pair(noise=True)
     od, pose = _tracker_inputs(fp, noise_pose_seed=2)
-    oerr = np.zeros((480, 640), np.float32)
-    otr, orot, ost = od.track(pose[:3, 3], pose[:3, :3], err_surface=oerr, **opts)
-
     g = api.Odometry(ctx)
     d = ctx.to_device
     g.init_first_rgb(d(fp["rgba0"]))
@@ -179,13 +176,13 @@ def test_get_incremental_transformation(ctx, opts):
     g.init_rgb(d(fp["rgba1"]))
     for which in range(9):
         for lvl in range(3):
-            a, b = g.buffer(which, lvl), od.buffer(which, lvl) if which != 8 else None
-            if which == 8:
-                continue
+            a, b = g.buffer(which, lvl), od.buffer(which, lvl)
             if which <= 3:
                 a, b = _planar_valid_only(a), _planar_valid_only(b)
             _eq(a, b, f"pyramid buffer {which} L{lvl}")
-    err = torch_zeros = ctx.empty((480, 640)); err.zero_()
+    oerr = np.zeros((480, 640), np.float32)
+    otr, orot, ost = od.track(pose[:3, 3], pose[:3, :3], err_surface=oerr, **opts)
+    err = ctx.empty((480, 640)); err.zero_()
     tr, rot, st = g.track(pose[:3, 3], pose[:3, :3], err_surface=err, **opts)
     np.testing.assert_allclose(tr, otr, atol=1e-6, rtol=0)
     np.testing.assert_allclose(rot, orot, atol=1e-6, rtol=0)
