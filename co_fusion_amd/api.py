@@ -286,6 +286,11 @@ class Odometry:
                                                                             _p(err_surface), C.byref(st)))
         return np.array(t, np.float32), np.array(r, np.float32).reshape(3, 3), st
 
+    def bench_icp(self, level, iters=200):
+        us = C.c_float()
+        self.ctx._check(self.ctx.lib.cf_odom_bench_icp(self.h, level, iters, C.byref(us)))
+        return us.value
+
     def buffer(self, which, level):
         ptr = C.c_void_p(); nbytes = C.c_uint64()
         self.ctx._check(self.ctx.lib.cf_odom_buffer(self.h, which, level, C.byref(ptr), C.byref(nbytes)))

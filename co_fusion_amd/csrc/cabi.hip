@@ -222,7 +222,11 @@ int cf_icp_step(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], const f
     h->intr = intr; h->vmap_curr[0] = vmap_curr; h->nmap_curr[0] = nmap_curr; h->vmap_g_prev[0] = vmap_g_prev;
     h->nmap_g_prev[0] = nmap_g_prev; h->distThres = dist_thres; h->angleThres = angle_thres; h->err_surface = err_surface;
     if (int r = scratch_commit(ctx)) return r;
-    launch_icp_models(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, 1, cols, rows, 0, err_surface ? 1 : 0);
+    IcpArgs a{};
+    a.m[0] = IcpModelArgs{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, ctx->d_scratch_state, ctx->d_acc_a, err_surface};
+    a.cols = cols; a.rows = rows; a.intr = intr; a.distThres = dist_thres; a.angleThres = angle_thres;
+    a.flags = err_surface ? 1 : 0;
+    launch_icp_level(ctx->stream, ctx->icp_launch, a, 1, 0);
     LAUNCHCHK(ctx);
     if (int r = fetch_totals(ctx, ctx->d_acc_a, 32)) return r;
     se3_unpack_host(ctx->h_out, CF_FIX_ICP, A_host, b_host, residual_host);
@@ -492,10 +496,30 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
     return CF_OK;
 }
 
+static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3])
+{
+    const cf_cam intr = {ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy};
+    for (int l = 0; l < CF_NUM_PYRS; l++) {
+        IcpArgs& a = out[l];
+        memset(&a, 0, sizeof(a));
+        const int div = 1 << l;
+        a.cols = ctx->cfg.width >> l; a.rows = ctx->cfg.height >> l;
+        a.intr = cf_cam{intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
+        a.distThres = ods[0]->distThres; a.angleThres = ods[0]->angleThres;
+        for (int m = 0; m < n; m++) {
+            cf_odom* od = ods[m];
+            a.m[m] = IcpModelArgs{od->ext_vmap_curr[l] ? od->ext_vmap_curr[l] : od->vmap_curr[l],
+                                  od->ext_nmap_curr[l] ? od->ext_nmap_curr[l] : od->nmap_curr[l],
+                                  od->vmap_g_prev[l], od->nmap_g_prev[l], od->d_state, od->icp_acc,
+                                  od->h_state->err_surface};
+        }
+    }
+}
+
 int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const float* const* poses_in,
                               const cf_track_opts* opts, float* const* err_surfaces)
 {
-    if (!ctx || !ods || n <= 0 || n > ctx->cfg.max_models || !poses_in || !opts) return CF_EINVAL;
+    if (!ctx || !ods || n <= 0 || n > ctx->cfg.max_models || n > kMaxBatch || !poses_in || !opts) return CF_EINVAL;
     for (int m = 0; m < n; m++) {
         if (int r = odom_prepare(ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr)) return r;
         ctx->h_model_ptrs[m] = ods[m]->d_state;
@@ -503,8 +527,10 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_model_ptrs, ctx->h_model_ptrs, sizeof(OdomDev*) * n, hipMemcpyHostToDevice, ctx->stream));
     const bool icp = !opts->rgb_only && opts->icp_weight > 0;
     const bool rgb = opts->rgb_only || opts->icp_weight < 100;
-    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, n, ctx->cfg.width, ctx->cfg.height, opts->so3 != 0,
-                    opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, &ctx->prof);
+    IcpArgs icp_args[3];
+    fill_icp_args(ctx, ods, n, icp_args);
+    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, icp_args, n, ctx->cfg.width, ctx->cfg.height,
+                    opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, &ctx->prof);
     LAUNCHCHK(ctx);
     for (int m = 0; m < n; m++)
         HIPCHK(ctx, hipMemcpyAsync(ods[m]->h_state, ods[m]->d_state, sizeof(OdomDev), hipMemcpyDeviceToHost, ctx->stream));
@@ -537,6 +563,31 @@ int cf_odom_get_incremental_transformation(cf_odom* od, float trans[3], float ro
     cf_odom* ods[1] = {od};
     if (int r = cf_odom_track_batch_async(od->ctx, ods, 1, poses, opts, errs)) return r;
     return cf_odom_fetch_result(od, trans, rot, stats);
+}
+
+// Micro-benchmark: `iters` back-to-back ICP-reduce launches at `level` on the state left by the last
+// tracking call (same maps, same pose); returns the average microseconds per launch (hipEvents on the
+// launch stream, one pair around the whole batch so event overhead does not pollute the figure).
+int cf_odom_bench_icp(cf_odom* od, int level, int iters, float* avg_us)
+{
+    if (!od || level < 0 || level >= CF_NUM_PYRS || iters <= 0 || !avg_us) return CF_EINVAL;
+    cf_ctx* ctx = od->ctx;
+    const char* ab = getenv("CF_ICP_ABLATE");
+    IcpArgs all[3];
+    cf_odom* ods[1] = {od};
+    fill_icp_args(ctx, ods, 1, all);
+    IcpArgs a = all[level];
+    a.flags = ab ? (atoi(ab) << 8) : 0;
+    for (int i = 0; i < 3; i++) launch_icp_level(ctx->stream, ctx->icp_launch, a, 1, level);
+    HIPCHK(ctx, hipEventRecord(ctx->prof.events[ctx->prof.capacity - 2], ctx->stream));
+    for (int i = 0; i < iters; i++) launch_icp_level(ctx->stream, ctx->icp_launch, a, 1, level);
+    HIPCHK(ctx, hipEventRecord(ctx->prof.events[ctx->prof.capacity - 1], ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->prof.events[ctx->prof.capacity - 2], ctx->prof.events[ctx->prof.capacity - 1]));
+    *avg_us = ms * 1000.f / iters;
+    HIPCHK(ctx, hipMemsetAsync(od->icp_acc, 0, sizeof(unsigned long long) * kGroups * 32, ctx->stream));
+    return CF_OK;
 }
 
 int cf_odom_buffer(cf_odom* od, int which, int level, void** dptr, uint64_t* bytes)

@@ -1,0 +1,392 @@
+// cabi_model.hip -- C-ABI of the surfel model (Core/Model/Model.h:117-235, Core/Model/ModelProjection.h)
+// and of the frame-level pre-processing (CoFusion::filterDepth).  All buffers are allocated when the
+// model is created; nothing is allocated per frame.
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "cf_host.h"
+
+using namespace cf;
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->set_error(std::string(#call) + ": " + hipGetErrorString(e_));               \
+            return CF_EHIP;                                                                    \
+        }                                                                                      \
+    } while (0)
+#define LAUNCHCHK(ctx) HIPCHK(ctx, hipGetLastError())
+
+struct cf_model {
+    cf_ctx* ctx = nullptr;
+    uint32_t max_surfels = 0;
+    uint32_t count_host = 0;          // exact: refreshed after initialise/clean
+    float* buf[2] = {nullptr, nullptr};  // ping-pong surfel buffers (Model::vbos[2])
+    int target = 0;
+    float* staged = nullptr;          // clean staging [max_surfels + N/4]
+    unsigned* flags = nullptr;        // [max_surfels + N/4]
+    unsigned* offsets = nullptr;
+    unsigned* block_sums = nullptr;
+    unsigned* d_count = nullptr;      // device surfel count
+    unsigned* d_nfresh = nullptr;     // appended new-unstable count
+    unsigned* d_tmp2 = nullptr;       // [4] scratch counters
+    unsigned* h_counts = nullptr;     // pinned [4]
+    // per-pixel rank-ordered fusion records
+    float* records = nullptr;         // [N*12]
+    float* fresh = nullptr;           // new unstable surfels [N/4 * 12] (Model::newUnstableBuffer)
+    unsigned* new_flags = nullptr;    // [N]
+    unsigned* new_offsets = nullptr;  // [N]
+    unsigned* owner = nullptr;        // [max_surfels]
+    float* fb_rec = nullptr;          // feedback records (raw), [N*12]
+    float* fb_raw = nullptr;          // compacted raw feedback [N*12]
+    float* fb_filt = nullptr;         // compacted filtered feedback [N*12]
+    // index map (ModelProjection sparse* textures) and splat prediction
+    unsigned long long* keys = nullptr;
+    unsigned* index = nullptr;
+    float *vertConf = nullptr, *colorTime = nullptr, *normRad = nullptr;
+    uint8_t* splat_image = nullptr;
+    float *splat_vertex = nullptr, *splat_normal = nullptr;
+    uint16_t* splat_time = nullptr;
+    // FillIn textures
+    float *fill_vertex = nullptr, *fill_normal = nullptr;
+    uint8_t* fill_image = nullptr;
+    float *tcx = nullptr, *tcy = nullptr;
+    float inv_fx = 0, inv_fy = 0;
+};
+
+template <typename T>
+static int dmalloc(cf_ctx* ctx, T** p, size_t count)
+{
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    HIPCHK(ctx, hipMemsetAsync(*p, 0, count * sizeof(T), ctx->stream));
+    return CF_OK;
+}
+
+static void inv44f(const float a[16], float o[16])
+{  // pose.inverse(): linear part by cofactors (same statement as the oracle)
+    const float c00 = a[5] * a[10] - a[6] * a[9];
+    const float c01 = a[6] * a[8] - a[4] * a[10];
+    const float c02 = a[4] * a[9] - a[5] * a[8];
+    const float det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    const float id = 1.0f / det;
+    float Li[9];
+    Li[0] = c00 * id; Li[1] = (a[2] * a[9] - a[1] * a[10]) * id; Li[2] = (a[1] * a[6] - a[2] * a[5]) * id;
+    Li[3] = c01 * id; Li[4] = (a[0] * a[10] - a[2] * a[8]) * id; Li[5] = (a[2] * a[4] - a[0] * a[6]) * id;
+    Li[6] = c02 * id; Li[7] = (a[1] * a[8] - a[0] * a[9]) * id; Li[8] = (a[0] * a[5] - a[1] * a[4]) * id;
+    for (int i = 0; i < 3; i++) {
+        o[i * 4 + 0] = Li[i * 3 + 0]; o[i * 4 + 1] = Li[i * 3 + 1]; o[i * 4 + 2] = Li[i * 3 + 2];
+        o[i * 4 + 3] = -(Li[i * 3 + 0] * a[3] + Li[i * 3 + 1] * a[7] + Li[i * 3 + 2] * a[11]);
+    }
+    o[12] = 0; o[13] = 0; o[14] = 0; o[15] = 1;
+}
+
+static inline cf_cam ctx_cam(const cf_ctx* ctx) { return cf_cam{ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy}; }
+
+extern "C" {
+
+// CoFusion::filterDepth (CoFusion.cpp:567-574)
+int cf_bilateral(cf_ctx* ctx, const float* depth, int cols, int rows, float maxD, float* out)
+{
+    if (!ctx || !depth || !out) return CF_EINVAL;
+    launch_bilateral(ctx->stream, depth, cols, rows, maxD, out);
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
+{
+    if (!ctx || !out || max_surfels <= 0) return CF_EINVAL;
+    cf_model* m = new cf_model();
+    m->ctx = ctx; m->max_surfels = (uint32_t)max_surfels;
+    *out = m;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    const size_t N = (size_t)W * H, M = (size_t)max_surfels, Q = N / 4 + 64;
+    if (int r = dmalloc(ctx, &m->buf[0], M * 12)) return r;
+    if (int r = dmalloc(ctx, &m->buf[1], M * 12)) return r;
+    if (int r = dmalloc(ctx, &m->staged, (M + Q) * 12)) return r;
+    if (int r = dmalloc(ctx, &m->flags, M + Q)) return r;
+    if (int r = dmalloc(ctx, &m->offsets, M + Q)) return r;
+    if (int r = dmalloc(ctx, &m->block_sums, (M + Q) / 2048 + N / 2048 + 16)) return r;
+    if (int r = dmalloc(ctx, &m->d_count, 1)) return r;
+    if (int r = dmalloc(ctx, &m->d_nfresh, 1)) return r;
+    if (int r = dmalloc(ctx, &m->d_tmp2, 4)) return r;
+    if (int r = dmalloc(ctx, &m->records, N * 12)) return r;
+    if (int r = dmalloc(ctx, &m->fresh, Q * 12)) return r;
+    if (int r = dmalloc(ctx, &m->new_flags, N)) return r;
+    if (int r = dmalloc(ctx, &m->new_offsets, N)) return r;
+    if (int r = dmalloc(ctx, &m->owner, M)) return r;
+    HIPCHK(ctx, hipMemsetAsync(m->owner, 0xFF, M * sizeof(unsigned), ctx->stream));
+    if (int r = dmalloc(ctx, &m->fb_rec, N * 12)) return r;
+    if (int r = dmalloc(ctx, &m->fb_raw, N * 12)) return r;
+    if (int r = dmalloc(ctx, &m->fb_filt, N * 12)) return r;
+    if (int r = dmalloc(ctx, &m->keys, N)) return r;
+    if (int r = dmalloc(ctx, &m->index, N)) return r;
+    if (int r = dmalloc(ctx, &m->vertConf, N * 4)) return r;
+    if (int r = dmalloc(ctx, &m->colorTime, N * 4)) return r;
+    if (int r = dmalloc(ctx, &m->normRad, N * 4)) return r;
+    if (int r = dmalloc(ctx, &m->splat_image, N * 4)) return r;
+    if (int r = dmalloc(ctx, &m->splat_vertex, N * 4)) return r;
+    if (int r = dmalloc(ctx, &m->splat_normal, N * 4)) return r;
+    if (int r = dmalloc(ctx, &m->splat_time, N)) return r;
+    if (int r = dmalloc(ctx, &m->fill_vertex, N * 4)) return r;
+    if (int r = dmalloc(ctx, &m->fill_normal, N * 4)) return r;
+    if (int r = dmalloc(ctx, &m->fill_image, N * 4)) return r;
+    if (int r = dmalloc(ctx, &m->tcx, (size_t)W)) return r;
+    if (int r = dmalloc(ctx, &m->tcy, (size_t)H)) return r;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->h_counts), sizeof(unsigned) * 4));
+    // texcoords exactly as the reference builds its uv buffer (Model.cpp:166-170)
+    std::vector<float> tx(W), ty(H);
+    for (int i = 0; i < W; i++) tx[i] = (float)((double)((float)i / (float)W) + 1.0 / (2.0 * (double)(float)W));
+    for (int j = 0; j < H; j++) ty[j] = (float)((double)((float)j / (float)H) + 1.0 / (2.0 * (double)(float)H));
+    HIPCHK(ctx, hipMemcpyAsync(m->tcx, tx.data(), sizeof(float) * W, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(m->tcy, ty.data(), sizeof(float) * H, hipMemcpyHostToDevice, ctx->stream));
+    m->inv_fx = (float)(1.0 / (double)ctx->cfg.fx); m->inv_fy = (float)(1.0 / (double)ctx->cfg.fy);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
+}
+
+void cf_model_destroy(cf_model* m)
+{
+    if (!m) return;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    void* ptrs[] = {m->buf[0], m->buf[1], m->staged, m->flags, m->offsets, m->block_sums, m->d_count, m->d_nfresh, m->d_tmp2, m->records,
+                    m->fresh, m->new_flags, m->new_offsets, m->owner, m->fb_rec, m->fb_raw, m->fb_filt, m->keys, m->index, m->vertConf,
+                    m->colorTime, m->normRad, m->splat_image, m->splat_vertex, m->splat_normal, m->splat_time, m->fill_vertex,
+                    m->fill_normal, m->fill_image, m->tcx, m->tcy};
+    for (void* p : ptrs) (void)hipFree(p);
+    (void)hipHostFree(m->h_counts);
+    delete m;
+}
+
+static int sync_count(cf_model* m)
+{
+    cf_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipMemcpyAsync(m->h_counts, m->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    m->count_host = m->h_counts[0];
+    if (m->count_host > m->max_surfels) { ctx->set_error("surfel buffer overflow"); return CF_ENOMEM; }
+    return CF_OK;
+}
+
+// CoFusion::computeFeedbackBuffers (CoFusion.cpp:157-169) + Model::initialise (Model.cpp:227-272)
+int cf_model_initialise(cf_model* m, const uint8_t* rgba, const float* depth_raw, const float* depth_filt, int time, float maxDepth)
+{
+    if (!m || !rgba || !depth_raw || !depth_filt) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx; hipStream_t s = ctx->stream;
+    const int W = ctx->cfg.width, H = ctx->cfg.height; const long long N = (long long)W * H;
+    if ((uint32_t)N > m->max_surfels) return CF_ENOMEM;
+    const cf_cam cam = ctx_cam(ctx);
+    // raw feedback
+    launch_feedback(s, rgba, depth_raw, W, H, cam, m->inv_fx, m->inv_fy, m->tcx, m->tcy, time, maxDepth, m->fb_rec, m->new_flags);
+    launch_exclusive_scan(s, m->new_flags, N, m->new_offsets, m->block_sums, m->d_count, 0);
+    HIPCHK(ctx, hipMemsetAsync(m->fb_raw, 0, sizeof(float) * 12 * N, s));
+    launch_scatter_records(s, m->fb_rec, m->new_flags, m->new_offsets, N, m->fb_raw, 0);
+    // filtered feedback (zero-filled past its own count, like the reference's zero-initialised VBO)
+    launch_feedback(s, rgba, depth_filt, W, H, cam, m->inv_fx, m->inv_fy, m->tcx, m->tcy, time, maxDepth, m->fb_rec, m->new_flags);
+    launch_exclusive_scan(s, m->new_flags, N, m->new_offsets, m->block_sums, m->d_tmp2, 0);
+    HIPCHK(ctx, hipMemsetAsync(m->fb_filt, 0, sizeof(float) * 12 * N, s));
+    launch_scatter_records(s, m->fb_rec, m->new_flags, m->new_offsets, N, m->fb_filt, 0);
+    launch_init(s, m->fb_raw, m->fb_filt, m->d_count, N, m->buf[m->target]);
+    LAUNCHCHK(ctx);
+    return sync_count(m);
+}
+
+int cf_model_count(cf_model* m, uint32_t* count) { if (!m || !count) return CF_EINVAL; *count = m->count_host; return CF_OK; }
+
+int cf_model_predict_indices(cf_model* m, const float pose[16], int time, float maxDepth, int timeDelta)
+{
+    if (!m || !pose) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx;
+    float t_inv[16];
+    inv44f(pose, t_inv);
+    launch_predict_indices(ctx->stream, m->buf[m->target], m->d_count, m->count_host, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
+                           maxDepth, time, timeDelta, m->keys, m->index, m->vertConf, m->colorTime, m->normRad);
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+int cf_model_combined_predict(cf_model* m, const float pose[16], float maxDepth, float confThreshold, int time, int maxTime, int timeDelta)
+{
+    if (!m || !pose) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx;
+    float t_inv[16];
+    inv44f(pose, t_inv);
+    launch_combined_predict(ctx->stream, m->buf[m->target], m->d_count, m->count_host, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
+                            maxDepth, confThreshold, time, maxTime, timeDelta, m->keys, m->splat_image, m->splat_vertex, m->splat_normal,
+                            m->splat_time);
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+// Model::performFillIn (Model.cpp:901-909); depth is the FILTERED depth (CoFusion.cpp:541)
+int cf_model_perform_fill_in(cf_model* m, const uint8_t* rgba, const float* depth_filt, int passthrough_geom, int passthrough_rgb)
+{
+    if (!m || !rgba || !depth_filt) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx;
+    launch_fill_in(ctx->stream, m->splat_vertex, m->splat_normal, m->splat_image, depth_filt, rgba, ctx->cfg.width, ctx->cfg.height, ctx_cam(ctx),
+                   m->inv_fx, m->inv_fy, passthrough_geom, passthrough_rgb, m->fill_vertex, m->fill_normal, m->fill_image);
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+// CoFusion::requiresFillIn (CoFusion.cpp:547-565)
+int cf_model_requires_fill_in(cf_model* m, float ratio, int* out)
+{
+    if (!m || !out) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx;
+    launch_fill_ratio(ctx->stream, m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2);
+    LAUNCHCHK(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(m->h_counts + 2, m->d_tmp2 + 2, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = ((float)m->h_counts[2] / (float)m->h_counts[3] < ratio) ? 1 : 0;
+    return CF_OK;
+}
+
+// Model::fuse (Model.cpp:408-563).  Needs cf_model_predict_indices for the same pose first.
+int cf_model_fuse(cf_model* m, const float pose[16], int time, const uint8_t* rgba, const uint8_t* mask, const float* depth_raw,
+                  const float* depth_filt, float maxDepth, float weighting, int maskID)
+{
+    if (!m || !pose || !rgba || !mask || !depth_raw || !depth_filt) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx; hipStream_t s = ctx->stream;
+    const int W = ctx->cfg.width, H = ctx->cfg.height; const long long N = (long long)W * H;
+    SurfelFuseArgs a;
+    a.index = m->index; a.vertConf = m->vertConf; a.normRad = m->normRad; a.rgba = rgba; a.depth_raw = depth_raw; a.depth_filt = depth_filt;
+    a.mask = mask; a.tcx = m->tcx; a.tcy = m->tcy; memcpy(a.pose, pose, sizeof(a.pose)); a.cam = ctx_cam(ctx); a.inv_fx = m->inv_fx;
+    a.inv_fy = m->inv_fy; a.cols = W; a.rows = H; a.time = time; a.weighting = weighting; a.maskID = maskID; a.maxDepth = maxDepth;
+    a.records = m->records; a.new_flags = m->new_flags; a.owner = m->owner;
+    launch_associate(s, a);
+    // append the new unstable vertices in column-major draw order (transform feedback of data.geom)
+    launch_exclusive_scan(s, m->new_flags, N, m->new_offsets, m->block_sums, m->d_nfresh, 0);
+    launch_scatter_records(s, m->records, m->new_flags, m->new_offsets, N, m->fresh, 0);
+    // update.vert over all surfels into the other buffer, then swap (Model.cpp:559)
+    launch_update(s, m->buf[m->target], m->d_count, m->count_host, m->owner, m->records, time, m->buf[1 - m->target]);
+    m->target = 1 - m->target;
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+// Model::clean (Model.cpp:565-697).  Needs cf_model_predict_indices (after fuse) for the same pose first.
+int cf_model_clean(cf_model* m, const float pose[16], int time, float confThreshold, float outlierCoeff, int timeDelta, const float* depth_filt,
+                   const uint8_t* mask, int maskID, uint32_t* count_out)
+{
+    if (!m || !pose || !depth_filt || !mask) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx; hipStream_t s = ctx->stream;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    const unsigned bound = m->count_host + (unsigned)((W / 2) * (H / 2));
+    if (bound > m->max_surfels + (unsigned)(W * H / 4 + 64)) return CF_ENOMEM;
+    SurfelCleanArgs a;
+    a.index = m->index; a.vertConf = m->vertConf; a.colorTime = m->colorTime; a.depth_filt = depth_filt; a.mask = mask;
+    inv44f(pose, a.t_inv); a.cam = ctx_cam(ctx); a.cols = W; a.rows = H; a.time = time; a.confThreshold = confThreshold;
+    a.outlierCoeff = outlierCoeff; a.timeDelta = timeDelta; a.maskID = maskID;
+    launch_clean(s, m->buf[m->target], m->d_count, m->fresh, m->d_nfresh, bound, a, m->staged, m->flags);
+    launch_exclusive_scan(s, m->flags, bound, m->offsets, m->block_sums, m->d_tmp2, 0);
+    launch_scatter_records(s, m->staged, m->flags, m->offsets, bound, m->buf[1 - m->target], 0);
+    HIPCHK(ctx, hipMemcpyAsync(m->d_count, m->d_tmp2, sizeof(unsigned), hipMemcpyDeviceToDevice, s));
+    m->target = 1 - m->target;
+    LAUNCHCHK(ctx);
+    if (int r = sync_count(m)) return r;
+    if (count_out) *count_out = m->count_host;
+    return CF_OK;
+}
+
+// Model::downloadMap (Model.cpp:867-899)
+int cf_model_download_map(cf_model* m, float* host_surfels, uint32_t capacity, uint32_t* count)
+{
+    if (!m || !count) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx;
+    *count = m->count_host;
+    if (host_surfels) {
+        const uint32_t n = m->count_host < capacity ? m->count_host : capacity;
+        HIPCHK(ctx, hipMemcpyAsync(host_surfels, m->buf[m->target], (size_t)n * 48, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CF_OK;
+}
+
+int cf_model_upload_map(cf_model* m, const float* host_surfels, uint32_t count)
+{
+    if (!m || (!host_surfels && count) || count > m->max_surfels) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx;
+    if (count) HIPCHK(ctx, hipMemcpyAsync(m->buf[m->target], host_surfels, (size_t)count * 48, hipMemcpyHostToDevice, ctx->stream));
+    launch_set_count(ctx->stream, m->d_count, count);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    m->count_host = count;
+    return CF_OK;
+}
+
+// which: 0 index(u32) 1 vertConf 2 colorTime 3 normRad (f32x4) | 4 splat image (rgba8) 5 splat vertexConf 6 splat normalRad
+// (f32x4) 7 splat time (u16) | 8 fill vertex 9 fill normal (f32x4) 10 fill image (rgba8) | 11 surfels (f32x12, count entries)
+int cf_model_buffer(cf_model* m, int which, void** dptr, uint64_t* bytes)
+{
+    if (!m || !dptr) return CF_EINVAL;
+    const size_t N = (size_t)m->ctx->cfg.width * m->ctx->cfg.height;
+    void* p = nullptr; size_t b = 0;
+    switch (which) {
+        case 0: p = m->index; b = N * 4; break;
+        case 1: p = m->vertConf; b = N * 16; break;
+        case 2: p = m->colorTime; b = N * 16; break;
+        case 3: p = m->normRad; b = N * 16; break;
+        case 4: p = m->splat_image; b = N * 4; break;
+        case 5: p = m->splat_vertex; b = N * 16; break;
+        case 6: p = m->splat_normal; b = N * 16; break;
+        case 7: p = m->splat_time; b = N * 2; break;
+        case 8: p = m->fill_vertex; b = N * 16; break;
+        case 9: p = m->fill_normal; b = N * 16; break;
+        case 10: p = m->fill_image; b = N * 4; break;
+        case 11: p = m->buf[m->target]; b = (size_t)m->count_host * 48; break;
+        default: return CF_EINVAL;
+    }
+    *dptr = p; if (bytes) *bytes = b;
+    return CF_OK;
+}
+
+// Model::computeFusionWeight (Model.cpp:391-406) + Model::rodrigues2 (Model.cpp:817-865); host math.
+// The JacobiSVD re-orthonormalisation of rodrigues2 is the identity for rotation products.
+float cf_fusion_weight(const float pose[16], const float lastPose[16], float weightMultiplier)
+{
+    float pinv[16], diff[16];
+    inv44f(pose, pinv);
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float s = 0;
+            for (int k = 0; k < 4; k++) s += pinv[i * 4 + k] * lastPose[k * 4 + j];
+            diff[i * 4 + j] = s;
+        }
+    const float tn = sqrtf(diff[3] * diff[3] + diff[7] * diff[7] + diff[11] * diff[11]);
+    const float* R = diff;
+    double rx = R[2 * 4 + 1] - R[1 * 4 + 2], ry = R[0 * 4 + 2] - R[2 * 4 + 0], rz = R[1 * 4 + 0] - R[0 * 4 + 1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (double)((R[0] + R[5] + R[10]) - 1.0f) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        double t;
+        if (c > 0) rx = ry = rz = 0;
+        else {
+            t = (R[0] + 1) * 0.5; rx = sqrt(t > 0.0 ? t : 0.0);
+            t = (R[5] + 1) * 0.5; ry = sqrt(t > 0.0 ? t : 0.0) * (R[0 * 4 + 1] < 0 ? -1.0 : 1.0);
+            t = (R[10] + 1) * 0.5; rz = sqrt(t > 0.0 ? t : 0.0) * (R[0 * 4 + 2] < 0 ? -1.0 : 1.0);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[1 * 4 + 2] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        double vth = 1 / (2 * s);
+        vth *= theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    const float rv[3] = {(float)rx, (float)ry, (float)rz};
+    const float rn = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    float weighting = tn > rn ? tn : rn;
+    const float largest = 0.01f, minWeight = 0.5f;
+    if (weighting > largest) weighting = largest;
+    const float w = 1.0f - (weighting / largest);
+    weighting = (w > minWeight ? w : minWeight) * weightMultiplier;
+    return weighting;
+}
+
+}  // extern "C"

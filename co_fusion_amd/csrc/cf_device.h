@@ -86,42 +86,80 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// Reduce acc[0..31] across the 64 lanes of a wave.  Returns, in lane l, the wave
-// total of value index ((l >> 1) & 31).  31 + 1 exchanges instead of 32 * 6.
-__device__ __forceinline__ unsigned long long wave_reduce32_u64(unsigned long long (&acc)[32], int lane)
+// ---- wave64 transpose-reduce of 64-bit integer partial sums ---------------------------------
+// Halving butterfly: at the step with lane distance M, lanes with bit M set keep the upper HALF of
+// the value array, the others the lower HALF, and each adds its partner's copy of the half it
+// keeps: 31 + 1 exchanges instead of 32 values x 6 shuffle steps.  CDNA4 specifics:
+//   * distance 32 / 16: v_permlane32_swap / v_permlane16_swap exchange the halves of TWO registers
+//     in one VALU instruction and need no selects (a' + b' is the wanted sum in every lane);
+//   * distance 8 / 4 / 2 / 1: DPP moves (row_ror:8, row_half_mirror, quad_perm) -- any perfect
+//     matching between the "keeps lower" and "keeps upper" lanes of a group is a valid partner.
+// No LDS traffic (the ds_bpermute form of __shfl_xor made this reduction LDS-pipe bound).
+// All indices are static so the accumulators stay in VGPRs.
+template <int HALF, int N>
+__device__ __forceinline__ void swap32_step(unsigned long long (&acc)[N])
 {
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
-        const int m = 32 >> s;      // lane xor distance
-        const int half = 16 >> s;   // values kept after this step
-        const bool upper = (lane & m) != 0;
-#pragma unroll
-        for (int i = 0; i < half; i++) {
-            unsigned long long send = upper ? acc[i] : acc[i + half];
-            unsigned long long keep = upper ? acc[i + half] : acc[i];
-            acc[i] = keep + shfl_xor_u64(send, m);
-        }
+    for (int i = 0; i < HALF; i++) {
+        const unsigned long long a = acc[i], b = acc[i + HALF];
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(a >> 32), (unsigned)(b >> 32), false, false);
+        acc[i] = (((unsigned long long)hi[0] << 32) | lo[0]) + (((unsigned long long)hi[1] << 32) | lo[1]);
     }
-    return acc[0] + shfl_xor_u64(acc[0], 1);
+}
+template <int HALF, int N>
+__device__ __forceinline__ void swap16_step(unsigned long long (&acc)[N])
+{
+#pragma unroll
+    for (int i = 0; i < HALF; i++) {
+        const unsigned long long a = acc[i], b = acc[i + HALF];
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(a >> 32), (unsigned)(b >> 32), false, false);
+        acc[i] = (((unsigned long long)hi[0] << 32) | lo[0]) + (((unsigned long long)hi[1] << 32) | lo[1]);
+    }
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v)
+{
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int HALF, int M, int CTRL, int N>
+__device__ __forceinline__ void dpp_step(unsigned long long (&acc)[N], int lane)
+{
+    const bool upper = (lane & M) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; i++) {
+        const unsigned long long lo = acc[i], hi = acc[i + HALF];
+        const unsigned long long send = upper ? lo : hi;
+        const unsigned long long keep = upper ? hi : lo;
+        acc[i] = keep + dpp_u64<CTRL>(send);
+    }
+}
+constexpr int kDppRor8 = 0x128, kDppHalfMirror = 0x141, kDppXor2 = 0x4E, kDppXor1 = 0xB1;
+
+// Reduce acc[0..31] across the 64 lanes of a wave.  Returns, in lane l, the wave total of value
+// index ((l >> 1) & 31).
+__device__ __forceinline__ unsigned long long wave_reduce32_u64(unsigned long long (&acc)[32], int lane)
+{
+    swap32_step<16>(acc);
+    swap16_step<8>(acc);
+    dpp_step<4, 8, kDppRor8>(acc, lane);
+    dpp_step<2, 4, kDppHalfMirror>(acc, lane);
+    dpp_step<1, 2, kDppXor2>(acc, lane);
+    return acc[0] + dpp_u64<kDppXor1>(acc[0]);
 }
 
 // 16-value flavour (SO3): lane l ends with the total of value index ((l >> 2) & 15)
 __device__ __forceinline__ unsigned long long wave_reduce16_u64(unsigned long long (&acc)[16], int lane)
 {
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const int m = 32 >> s;
-        const int half = 8 >> s;
-        const bool upper = (lane & m) != 0;
-#pragma unroll
-        for (int i = 0; i < half; i++) {
-            unsigned long long send = upper ? acc[i] : acc[i + half];
-            unsigned long long keep = upper ? acc[i + half] : acc[i];
-            acc[i] = keep + shfl_xor_u64(send, m);
-        }
-    }
-    unsigned long long v = acc[0] + shfl_xor_u64(acc[0], 2);
-    return v + shfl_xor_u64(v, 1);
+    swap32_step<8>(acc);
+    swap16_step<4>(acc);
+    dpp_step<2, 8, kDppRor8>(acc, lane);
+    dpp_step<1, 4, kDppHalfMirror>(acc, lane);
+    const unsigned long long v = acc[0] + dpp_u64<kDppXor2>(acc[0]);
+    return v + dpp_u64<kDppXor1>(v);
 }
 
 // ---- deterministic f64 sin/cos (same spec as oracle/orc_math.h: orc_sincos) ------

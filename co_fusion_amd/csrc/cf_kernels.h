@@ -68,8 +68,23 @@ struct IcpLaunch { int threads; int ppt; };  // threads per workgroup, pixels pe
 
 // stand-alone steps (C-ABI parity with icpStep / computeRgbResidual / rgbStep / so3Step) run the same
 // kernels on a scratch OdomDev prepared by cabi.cpp.
-void launch_icp_models(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, int n, int width, int height, int level,
-                       int write_err);
+// ICP kernel arguments (by value, in the kernarg segment): per-model pointers + shared geometry
+constexpr int kMaxBatch = 8;
+struct IcpModelArgs {
+    const float* vc; const float* nc;   // current-frame vertex / normal planes of this level
+    const float* vp; const float* np;   // model prediction planes (global frame)
+    const OdomDev* st;                  // device-resident pose + flags
+    unsigned long long* acc;            // [kGroups][32] grouped accumulators
+    float* err;                         // nullable ICP error surface [rows*cols]
+};
+struct IcpArgs {
+    IcpModelArgs m[kMaxBatch];
+    int cols, rows;
+    cf_cam intr;                        // already divided by 2^level
+    float distThres, angleThres;
+    int flags;                          // bit0: write the error surface
+};
+void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level);
 void launch_rgb_residual_models(hipStream_t s, OdomDev* const* d_models, int n, int width, int height, int level);
 void launch_rgb_step_models(hipStream_t s, OdomDev* const* d_models, int n, int width, int height, int level);
 void launch_acc_total(hipStream_t s, const unsigned long long* acc, unsigned long long* out);
@@ -83,7 +98,47 @@ struct ProfSink {  // hipEvent pairs recorded around every ICP-reduce launch whe
 };
 
 // device-resident Gauss-Newton loop over `n` models (lock-step; blockIdx.y = model)
-void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */, int n,
-                     int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, ProfSink* prof);
+void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */,
+                     const IcpArgs icp_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom,
+                     bool rgb, bool icp, ProfSink* prof);
+
+// ---- surfel launchers (surfel.hip) ----
+struct SurfelFuseArgs {
+    const unsigned* index; const float* vertConf; const float* normRad;
+    const uint8_t* rgba; const float* depth_raw; const float* depth_filt; const uint8_t* mask;
+    const float* tcx; const float* tcy;
+    float pose[16]; cf_cam cam; float inv_fx, inv_fy;
+    int cols, rows, time; float weighting; int maskID; float maxDepth;
+    float* records; unsigned* new_flags; unsigned* owner;
+};
+struct SurfelCleanArgs {
+    const unsigned* index; const float* vertConf; const float* colorTime;
+    const float* depth_filt; const uint8_t* mask;
+    float t_inv[16]; cf_cam cam; int cols, rows, time; float confThreshold, outlierCoeff; int timeDelta, maskID;
+};
+void launch_bilateral(hipStream_t s, const float* depth, int cols, int rows, float maxD, float* out);
+void launch_exclusive_scan(hipStream_t s, const unsigned* flags, long long n, unsigned* offsets, unsigned* block_sums, unsigned* total,
+                           unsigned add_to_total);
+void launch_feedback(hipStream_t s, const uint8_t* rgba, const float* depth, int cols, int rows, cf_cam cam, float inv_fx, float inv_fy,
+                     const float* tcx, const float* tcy, int time, float maxDepth, float* rec, unsigned* flags);
+void launch_scatter_records(hipStream_t s, const float* rec, const unsigned* flags, const unsigned* offsets, long long n, float* out,
+                            unsigned out_base);
+void launch_init(hipStream_t s, const float* raw, const float* filt, const unsigned* raw_count, long long max_n, float* out);
+void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
+                            int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, unsigned* index,
+                            float* vertConf, float* colorTime, float* normRad);
+void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
+                             int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
+                             unsigned long long* keys, uint8_t* image, float* vertexConf, float* normalRad, uint16_t* time16);
+void launch_fill_in(hipStream_t s, const float* pv, const float* pn, const uint8_t* pimg, const float* depth, const uint8_t* rgba, int cols,
+                    int rows, cf_cam cam, float inv_fx, float inv_fy, int pass_geom, int pass_rgb, float* ov, float* on, uint8_t* oi);
+void launch_fill_ratio(hipStream_t s, const uint8_t* pimg, int cols, int rows, unsigned* out2);
+void launch_associate(hipStream_t s, const SurfelFuseArgs& h);
+void launch_update(hipStream_t s, const float* in, const unsigned* count, unsigned count_bound, unsigned* owner, const float* records, int time,
+                   float* out);
+void launch_clean(hipStream_t s, const float* surfels, const unsigned* count, const float* fresh, const unsigned* n_fresh, unsigned total_bound,
+                  const SurfelCleanArgs& h, float* staged, unsigned* flags);
+void launch_add_counts(hipStream_t s, const unsigned* a, const unsigned* b, unsigned* out);
+void launch_set_count(hipStream_t s, unsigned* out, unsigned v);
 
 }  // namespace cf

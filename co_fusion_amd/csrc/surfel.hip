@@ -1,0 +1,650 @@
+// surfel.hip -- the surfel half of the hot path as HIP compute kernels (no OpenGL, no interop).
+//
+// MI355X-native replacement of the GLSL passes driven by Core/Model/Model.cpp and
+// Core/Model/ModelProjection.cpp:
+//   depth_bilateral_metric.frag  -> bilateral_kernel
+//   vertex_feedback.* / init     -> feedback_kernel + ordered compaction + init_kernel
+//   index_map.*                  -> index_splat_kernel (64-bit atomicMin z|id keys) + index_resolve_kernel
+//   splat.vert/combo_splat.frag  -> splat_raster_kernel (atomicMin) + splat_resolve_kernel
+//   fill_*.frag                  -> fill_in_kernel
+//   data.* + update.vert         -> associate_kernel (+ owner atomicMin) + update_kernel
+//   copy_unstable.*              -> clean_kernel + ordered (stable) stream compaction
+//
+// The rasteriser's "nearest fragment wins, first primitive wins ties" becomes an atomicMin on a
+// 64-bit key (order-preserving depth bits << 32 | surfel id); the transform-feedback append becomes
+// a three-phase exclusive scan that preserves primitive order, so surfel ids and counts are exactly
+// those of the reference's pipeline.  All passes are streaming / gather-scatter and HBM-bound:
+// 48 B surfel records are read as 3 x float4 (16 B/lane), images are walked row-major by 256-thread
+// workgroups.  Arithmetic is bit-identical to the CPU oracle (same operation order, no FMA contraction).
+#include "cf_surfel_device.h"
+#include "cf_kernels.h"
+
+namespace cf {
+
+static constexpr int kB = 256;
+static inline int gridFor(long long n) { return (int)((n + kB - 1) / kB); }
+
+__device__ __forceinline__ unsigned sortable_bits(float z)
+{  // order-preserving float -> uint
+    const unsigned b = __float_as_uint(z);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long zkey(float z, unsigned id) { return ((unsigned long long)sortable_bits(z) << 32) | id; }
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+// ================================================================================ bilateral ====
+// depth_bilateral_metric.frag:30-75
+__global__ void __launch_bounds__(kB) bilateral_kernel(const float* __restrict__ depth, int cols, int rows, float maxD,
+                                                       float* __restrict__ out)
+{
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= cols * rows) return;
+    const int y = i / cols, x = i - y * cols;
+    const float value = depth[i];
+    if (value > maxD || value < 0.3f) { out[i] = 0; return; }
+    const int D = 13;
+    const int tx = min(x - D / 2 + D, cols), ty = min(y - D / 2 + D, rows);
+    float sum1 = 0, sum2 = 0;
+    for (int cy = max(y - D / 2, 0); cy < ty; ++cy)
+        for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
+            const float tmp = depth[cy * cols + cx];
+            const float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) + ((float)y - (float)cy) * ((float)y - (float)cy);
+            const float color2 = (value - tmp) * (value - tmp);
+            const float weight = det_expf(-(space2 * 0.024691358f + color2 * 555.556f));
+            sum1 += tmp * weight;
+            sum2 += weight;
+        }
+    out[i] = sum1 / sum2;
+}
+
+// ==================================================================== ordered compaction (scan) ====
+// Exclusive scan of u32 flags in three phases; blocks of kScanItems elements.
+static constexpr int kScanItems = 2048;  // 256 threads x 8
+__global__ void __launch_bounds__(256) scan_block_sums_kernel(const unsigned* __restrict__ flags, long long n, unsigned* __restrict__ block_sums)
+{
+    const long long base = (long long)blockIdx.x * kScanItems;
+    unsigned s = 0;
+    for (int k = 0; k < 8; k++) {
+        const long long i = base + k * 256 + threadIdx.x;
+        if (i < n) s += flags[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor((int)s, o, 64);
+    __shared__ unsigned w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+// single workgroup: exclusive scan of the block sums (nb <= 1024*64), total -> *total
+__global__ void __launch_bounds__(1024) scan_spine_kernel(unsigned* __restrict__ block_sums, int nb, unsigned* __restrict__ total,
+                                                          unsigned add_to_total)
+{
+    __shared__ unsigned part[1024];
+    const int per = (nb + 1023) / 1024;
+    const int b0 = threadIdx.x * per;
+    unsigned s = 0;
+    for (int k = 0; k < per; k++) if (b0 + k < nb) s += block_sums[b0 + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        unsigned v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - s;  // exclusive prefix of this thread's chunk
+    for (int k = 0; k < per; k++)
+        if (b0 + k < nb) { const unsigned v = block_sums[b0 + k]; block_sums[b0 + k] = run; run += v; }
+    if (threadIdx.x == 1023) *total = part[1023] + add_to_total;
+}
+// per-element exclusive offsets
+__global__ void __launch_bounds__(256) scan_offsets_kernel(const unsigned* __restrict__ flags, long long n,
+                                                           const unsigned* __restrict__ block_sums, unsigned* __restrict__ offsets)
+{
+    __shared__ unsigned wsum[4];
+    __shared__ unsigned carry;
+    const long long base = (long long)blockIdx.x * kScanItems;
+    if (threadIdx.x == 0) carry = block_sums[blockIdx.x];
+    __syncthreads();
+    for (int k = 0; k < 8; k++) {
+        const long long i = base + k * 256 + threadIdx.x;
+        const unsigned f = (i < n) ? flags[i] : 0;
+        // wave inclusive scan
+        unsigned v = f;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up((int)v, o, 64); if (lane >= o) v += t; }
+        if (lane == 63) wsum[wave] = v;
+        __syncthreads();
+        unsigned wbase = 0;
+        for (int w = 0; w < wave; w++) wbase += wsum[w];
+        const unsigned c = carry;
+        if (i < n) offsets[i] = c + wbase + v - f;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = c + wbase + v;
+        __syncthreads();
+    }
+}
+
+void launch_exclusive_scan(hipStream_t s, const unsigned* flags, long long n, unsigned* offsets, unsigned* block_sums, unsigned* total,
+                           unsigned add_to_total)
+{
+    const int nb = (int)((n + kScanItems - 1) / kScanItems);
+    if (nb > 0) scan_block_sums_kernel<<<nb, 256, 0, s>>>(flags, n, block_sums);
+    scan_spine_kernel<<<1, 1024, 0, s>>>(block_sums, nb, total, add_to_total);
+    if (nb > 0) scan_offsets_kernel<<<nb, 256, 0, s>>>(flags, n, block_sums, offsets);
+}
+
+// ============================================================================ frame-1 bootstrap ====
+// vertex_feedback.vert:40-68 (+ .geom): thread per pixel (row-major for coalescing); the record and
+// its flag are stored at the COLUMN-major rank i*rows+j, the order the reference draws the points in.
+__global__ void __launch_bounds__(kB) feedback_kernel(const uchar4* __restrict__ rgba, const float* __restrict__ depth, int cols, int rows,
+                                                      float cx, float cy, float inv_fx, float inv_fy, const float* __restrict__ tcx,
+                                                      const float* __restrict__ tcy, int time, float maxDepth,
+                                                      float4* __restrict__ rec /* [N*3] by rank */, unsigned* __restrict__ flags)
+{
+    const int q = blockIdx.x * kB + threadIdx.x;
+    if (q >= cols * rows) return;
+    const int j = q / cols, i = q - j * cols;
+    const int rank = i * rows + j;
+    const float x = tcx[i] * (float)cols, y = tcy[j] * (float)rows;
+    const f3 p = get_vertex(depth, cols, rows, i, j, x, y, cx, cy, inv_fx, inv_fy);
+    if (p.z <= 0 || p.z > maxDepth) { flags[rank] = 0; return; }
+    const f3 n = get_normal_central(p, depth, cols, rows, i, j, x, y, cx, cy, inv_fx, inv_fy);
+    const uchar4 c = rgba[q];
+    flags[rank] = 1;
+    rec[rank * 3 + 0] = make_float4(p.x, p.y, p.z, confidence(x, y, cx, cy, 1.0f));
+    rec[rank * 3 + 1] = make_float4(encode_color((float)c.x / 255.0f, (float)c.y / 255.0f, (float)c.z / 255.0f), 0.f, (float)c.z / 255.0f, (float)time);
+    rec[rank * 3 + 2] = make_float4(n.x, n.y, n.z, get_radius(p.z, n.z, inv_fx, inv_fy));
+}
+
+__global__ void __launch_bounds__(kB) scatter_records_kernel(const float4* __restrict__ rec, const unsigned* __restrict__ flags,
+                                                             const unsigned* __restrict__ offsets, long long n, float4* __restrict__ out,
+                                                             unsigned out_base)
+{
+    const long long r = (long long)blockIdx.x * kB + threadIdx.x;
+    if (r >= n || !flags[r]) return;
+    const size_t o = (size_t)(out_base + offsets[r]) * 3;
+    out[o] = rec[r * 3]; out[o + 1] = rec[r * 3 + 1]; out[o + 2] = rec[r * 3 + 2];
+}
+
+// Model::initialise (Model.cpp:227-272) + init_unstable.vert: attr 0/1 raw, attr 2 filtered, same index
+__global__ void __launch_bounds__(kB) init_kernel(const float4* __restrict__ raw, const float4* __restrict__ filt,
+                                                  const unsigned* __restrict__ raw_count, float4* __restrict__ out)
+{
+    const unsigned k = blockIdx.x * kB + threadIdx.x;
+    if (k >= *raw_count) return;
+    const float4 c = raw[k * 3 + 1];
+    out[k * 3] = raw[k * 3];
+    out[k * 3 + 1] = make_float4(c.x, 0.f, 1.f, c.w);
+    out[k * 3 + 2] = filt[k * 3 + 2];
+}
+
+// ================================================================================= index map ====
+// index_map.vert:38-63
+__device__ __forceinline__ bool index_project(const float4 pc, const float4 ct, const Mat4& t_inv, cf_cam cam, int cols, int rows,
+                                              float maxDepth, int time, int timeDelta, f3& ph, int& q)
+{
+    ph = xform_point(t_inv, f3{pc.x, pc.y, pc.z});
+    if (ph.z > maxDepth || ph.z < 0 || (float)time - ct.w > (float)timeDelta) return false;
+    const float u = ((cam.fx * ph.x) / ph.z) + cam.cx, v = ((cam.fy * ph.y) / ph.z) + cam.cy;
+    if (!(u >= 0.0f && v >= 0.0f && u < (float)cols && v < (float)rows)) return false;
+    if (!(ph.z < maxDepth)) return false;  // depth buffer cleared to 1.0, GL_LESS
+    q = (int)floorf(v) * cols + (int)floorf(u);
+    return true;
+}
+
+__global__ void __launch_bounds__(kB) index_splat_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count, Mat4 t_inv,
+                                                         cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta,
+                                                         unsigned long long* __restrict__ keys)
+{
+    const unsigned id = blockIdx.x * kB + threadIdx.x;
+    if (id >= *count) return;
+    f3 ph; int q;
+    if (!index_project(surfels[id * 3], surfels[id * 3 + 1], t_inv, cam, cols, rows, maxDepth, time, timeDelta, ph, q)) return;
+    atomicMin(&keys[q], zkey(ph.z, id));
+}
+
+__global__ void __launch_bounds__(kB) index_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_inv, int N,
+                                                           const unsigned long long* __restrict__ keys, unsigned* __restrict__ index,
+                                                           float4* __restrict__ vertConf, float4* __restrict__ colorTime,
+                                                           float4* __restrict__ normRad)
+{
+    const int q = blockIdx.x * kB + threadIdx.x;
+    if (q >= N) return;
+    const unsigned long long k = keys[q];
+    if (k == kEmptyKey) {
+        index[q] = 0;
+        vertConf[q] = colorTime[q] = normRad[q] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const unsigned id = (unsigned)k;
+    const float4 pc = surfels[id * 3], ct = surfels[id * 3 + 1], nr = surfels[id * 3 + 2];
+    const f3 ph = xform_point(t_inv, f3{pc.x, pc.y, pc.z});
+    const f3 n = normalized(xform_dir(t_inv, f3{nr.x, nr.y, nr.z}));
+    index[q] = id;
+    vertConf[q] = make_float4(ph.x, ph.y, ph.z, pc.w);
+    colorTime[q] = ct;
+    normRad[q] = make_float4(n.x, n.y, n.z, nr.w);
+}
+
+// ============================================================================ splat prediction ====
+// splat.vert:54-88 + combo_splat.frag:37-65
+struct SplatSetup { f3 ph, n; float rad, pn; int x_lo, x_hi, y_lo, y_hi; };
+
+__device__ __forceinline__ bool splat_setup(const float4 pc, const float4 ct, const float4 nr, const Mat4& t_inv, cf_cam cam, int cols,
+                                            int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
+                                            SplatSetup& s)
+{
+    s.ph = xform_point(t_inv, f3{pc.x, pc.y, pc.z});
+    if (s.ph.z > maxDepth || s.ph.z < 0 || pc.w < confThreshold || (float)time - ct.w > (float)timeDelta || ct.w > (float)maxTime) return false;
+    s.n = normalized(xform_dir(t_inv, f3{nr.x, nr.y, nr.z}));
+    s.rad = nr.w;
+    const f3 x1n = normalized(f3{s.n.y - s.n.z, -s.n.x, s.n.x});
+    const f3 x1 = {x1n.x * s.rad * 1.41421356f, x1n.y * s.rad * 1.41421356f, x1n.z * s.rad * 1.41421356f};
+    const f3 y1 = cross(s.n, x1);
+    const f3 c[4] = {s.ph + x1, s.ph + y1, s.ph - y1, s.ph - x1};
+    float px_[4], py_[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { px_[k] = ((cam.fx * c[k].x) / c[k].z) + cam.cx; py_[k] = ((cam.fy * c[k].y) / c[k].z) + cam.cy; }
+    const float xmin = fminf(px_[0], fminf(px_[1], fminf(px_[2], px_[3]))), xmax = fmaxf(px_[0], fmaxf(px_[1], fmaxf(px_[2], px_[3])));
+    const float ymin = fminf(py_[0], fminf(py_[1], fminf(py_[2], py_[3]))), ymax = fmaxf(py_[0], fmaxf(py_[1], fmaxf(py_[2], py_[3])));
+    const float size = fmaxf(0.0f, fmaxf(fabsf(xmax - xmin), fabsf(ymax - ymin)));
+    if (!(size > 0.0f) || !(size <= 4096.0f)) return false;
+    const float u = ((cam.fx * s.ph.x) / s.ph.z) + cam.cx, v = ((cam.fy * s.ph.y) / s.ph.z) + cam.cy;
+    if (!(u >= 0.0f && v >= 0.0f && u <= (float)cols && v <= (float)rows)) return false;  // points are clipped by their centre
+    const float half = size * 0.5f;
+    s.x_lo = max((int)ceilf(u - half - 0.5f), 0); s.x_hi = min((int)ceilf(u + half - 0.5f) - 1, cols - 1);
+    s.y_lo = max((int)ceilf(v - half - 0.5f), 0); s.y_hi = min((int)ceilf(v + half - 0.5f) - 1, rows - 1);
+    s.pn = dot(s.ph, s.n);
+    return true;
+}
+
+// fragment: returns false when discarded; z = corrected depth
+__device__ __forceinline__ bool splat_fragment(const SplatSetup& s, cf_cam cam, int px, int py, float maxDepth, float& z)
+{
+    const float fx_ = (float)px + 0.5f, fy_ = (float)py + 0.5f;
+    const f3 l = normalized(f3{(fx_ - cam.cx) / cam.fx, (fy_ - cam.cy) / cam.fy, 1.0f});
+    const float k = s.pn / dot(l, s.n);
+    const f3 cp = {k * l.x, k * l.y, k * l.z};
+    const f3 diff = cp - s.ph;
+    if (!(dot(diff, diff) <= s.rad * s.rad)) return false;
+    if (!(cp.z < maxDepth)) return false;
+    z = cp.z;
+    return true;
+}
+
+__global__ void __launch_bounds__(kB) splat_raster_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count, Mat4 t_inv,
+                                                          cf_cam cam, int cols, int rows, float maxDepth, float confThreshold, int time,
+                                                          int maxTime, int timeDelta, unsigned long long* __restrict__ keys)
+{
+    const unsigned id = blockIdx.x * kB + threadIdx.x;
+    if (id >= *count) return;
+    SplatSetup s;
+    if (!splat_setup(surfels[id * 3], surfels[id * 3 + 1], surfels[id * 3 + 2], t_inv, cam, cols, rows, maxDepth, confThreshold, time, maxTime,
+                     timeDelta, s))
+        return;
+    for (int py = s.y_lo; py <= s.y_hi; py++)
+        for (int px = s.x_lo; px <= s.x_hi; px++) {
+            float z;
+            if (splat_fragment(s, cam, px, py, maxDepth, z)) atomicMin(&keys[py * cols + px], zkey(z, id));
+        }
+}
+
+__global__ void __launch_bounds__(kB) splat_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_inv, cf_cam cam, int cols, int rows,
+                                                           float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
+                                                           const unsigned long long* __restrict__ keys, uchar4* __restrict__ image,
+                                                           float4* __restrict__ vertexConf, float4* __restrict__ normalRad,
+                                                           unsigned short* __restrict__ time16)
+{
+    const int q = blockIdx.x * kB + threadIdx.x;
+    if (q >= cols * rows) return;
+    const unsigned long long k = keys[q];
+    if (k == kEmptyKey) {
+        image[q] = make_uchar4(0, 0, 0, 0);
+        vertexConf[q] = normalRad[q] = make_float4(0, 0, 0, 0);
+        time16[q] = 0;
+        return;
+    }
+    const unsigned id = (unsigned)k;
+    const int py = q / cols, px = q - py * cols;
+    const float4 pc = surfels[id * 3], ct = surfels[id * 3 + 1], nr = surfels[id * 3 + 2];
+    SplatSetup s;
+    splat_setup(pc, ct, nr, t_inv, cam, cols, rows, maxDepth, confThreshold, time, maxTime, timeDelta, s);
+    float z;
+    splat_fragment(s, cam, px, py, maxDepth, z);
+    const f3 col = decode_color(ct.x);
+    image[q] = make_uchar4((unsigned char)glsl_round(col.x * 255.0f), (unsigned char)glsl_round(col.y * 255.0f),
+                           (unsigned char)glsl_round(col.z * 255.0f), 255);
+    const float fx_ = (float)px + 0.5f, fy_ = (float)py + 0.5f;
+    vertexConf[q] = make_float4((fx_ - cam.cx) * z * (1.f / cam.fx), (fy_ - cam.cy) * z * (1.f / cam.fy), z, pc.w);
+    normalRad[q] = make_float4(s.n.x, s.n.y, s.n.z, s.rad);
+    time16[q] = (unsigned short)(unsigned)ct.z;
+}
+
+// ==================================================================================== fill-in ====
+// fill_vertex.frag / fill_normal.frag / fill_rgb.frag
+__global__ void __launch_bounds__(kB) fill_in_kernel(const float4* __restrict__ pv, const float4* __restrict__ pn, const uchar4* __restrict__ pimg,
+                                                     const float* __restrict__ depth, const uchar4* __restrict__ rgba, int cols, int rows,
+                                                     float cx, float cy, float inv_fx, float inv_fy, int pass_geom, int pass_rgb,
+                                                     float4* __restrict__ ov, float4* __restrict__ on, uchar4* __restrict__ oi)
+{
+    const int q = blockIdx.x * kB + threadIdx.x;
+    if (q >= cols * rows) return;
+    const int y = q / cols, x = q - y * cols;
+    const float z = depth[q];
+    const f3 p = {((float)x - cx) * z * inv_fx, ((float)y - cy) * z * inv_fy, z};
+    const float4 v = pv[q];
+    ov[q] = (v.z == 0 || pass_geom) ? make_float4(p.x, p.y, p.z, 1.f) : v;
+    const float4 n = pn[q];
+    if (n.z == 0 || pass_geom) {
+        const float zx = depth[y * cols + min(x + 1, cols - 1)], zy = depth[min(y + 1, rows - 1) * cols + x];
+        const f3 vx = {((float)(x + 1) - cx) * zx * inv_fx, ((float)y - cy) * zx * inv_fy, zx};
+        const f3 vy = {((float)x - cx) * zy * inv_fx, ((float)(y + 1) - cy) * zy * inv_fy, zy};
+        const f3 nn = normalized(cross(vx - p, vy - p));
+        on[q] = make_float4(nn.x, nn.y, nn.z, 1.f);
+    } else
+        on[q] = n;
+    const uchar4 e = pimg[q];
+    oi[q] = (((int)e.x + (int)e.y + (int)e.z) == 0 || pass_rgb) ? rgba[q] : e;
+}
+
+// CoFusion::requiresFillIn (CoFusion.cpp:547-565): one workgroup counts the 20x down-sampled image
+__global__ void __launch_bounds__(1024) fill_ratio_kernel(const uchar4* __restrict__ pimg, int cols, int rows, unsigned* __restrict__ out2)
+{
+    const int dw = cols / 20, dh = rows / 20;
+    unsigned s = 0;
+    for (int k = threadIdx.x; k < dw * dh; k += 1024) {
+        const int j = k / dw, i = k - j * dw;
+        const int sx = nearest_texel(((float)i + 0.5f) / (float)dw, cols), sy = nearest_texel(((float)j + 0.5f) / (float)dh, rows);
+        const uchar4 p = pimg[sy * cols + sx];
+        s += (p.x > 0 && p.y > 0 && p.z > 0) ? 1u : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor((int)s, o, 64);
+    __shared__ unsigned w[16];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int k = 0; k < 16; k++) t += w[k];
+        out2[0] = t; out2[1] = (unsigned)(dw * dh);
+    }
+}
+
+// ===================================================================================== fusion ====
+// data.vert:78-211.  Thread per pixel (row-major); merge candidates race for their surfel with an
+// atomicMin on the column-major rank (= "first drawn fragment wins" on the reference's update maps).
+__device__ __forceinline__ float angle_between(f3 a, f3 b) { return det_acosf(dot(a, b) / (norm(a) * norm(b))); }
+
+struct FuseArgs {
+    const unsigned* index; const float4* vertConf; const float4* normRad;
+    const uchar4* rgba; const float* depth_raw; const float* depth_filt; const unsigned char* mask;
+    const float* tcx; const float* tcy;
+    Mat4 pose; cf_cam cam; float inv_fx, inv_fy;
+    int cols, rows, time; float weighting; int maskID; float maxDepth;
+    float4* records;      // [N*3] by rank
+    unsigned* new_flags;  // [N] by rank
+    unsigned* owner;      // [max_surfels], 0xFFFFFFFF = none
+};
+
+__global__ void __launch_bounds__(kB) associate_kernel(const FuseArgs a)
+{
+    const int q = blockIdx.x * kB + threadIdx.x;
+    const int cols = a.cols, rows = a.rows;
+    if (q >= cols * rows) return;
+    const int j = q / cols, i = q - j * cols;
+    const int rank = i * rows + j;
+    a.new_flags[rank] = 0;
+    const float tcx = a.tcx[i], tcy = a.tcy[j];
+    const float x = tcx * (float)cols, y = tcy * (float)rows;
+    if (!(((int)x % 2 == a.time % 2) && ((int)y % 2 == a.time % 2))) return;
+    if ((int)a.mask[q] != a.maskID) return;
+    const float* dr = a.depth_raw;
+    if (dr[j * cols + iclamp(i - 1, 0, cols - 1)] == 0 || dr[iclamp(j - 1, 0, rows - 1) * cols + i] == 0 ||
+        dr[j * cols + iclamp(i + 1, 0, cols - 1)] == 0 || dr[iclamp(j + 1, 0, rows - 1) * cols + i] == 0)
+        return;
+    const float cx = a.cam.cx, cy = a.cam.cy;
+    const f3 vPosLocal = get_vertex(dr, cols, rows, i, j, x, y, cx, cy, a.inv_fx, a.inv_fy);
+    if (!(vPosLocal.z > 0 && vPosLocal.z <= a.maxDepth)) return;
+
+    const f3 vPos = xform_point(a.pose, vPosLocal);
+    const f3 vPos_f = get_vertex(a.depth_filt, cols, rows, i, j, x, y, cx, cy, a.inv_fx, a.inv_fy);
+    const uchar4 c = a.rgba[q];
+    const f3 vNormLocal = get_normal_central(vPos_f, a.depth_filt, cols, rows, i, j, x, y, cx, cy, a.inv_fx, a.inv_fy);
+    const f3 nG = xform_dir(a.pose, vNormLocal);
+    const float radius = get_radius(vPos_f.z, vNormLocal.z, a.inv_fx, a.inv_fy);
+    const float conf = confidence(x, y, cx, cy, a.weighting);
+
+    const float scale = 1.0f;  // ModelProjection::FACTOR
+    const float indexXStep = (1.0f / ((float)cols * scale)) * 0.5f, indexYStep = (1.0f / ((float)rows * scale)) * 0.5f;
+    float bestDist = 1000;
+    const float windowMultiplier = 2;
+    const float xl = (x - cx) * a.inv_fx, yl = (y - cy) * a.inv_fy;
+    const float lambda = sqrtf(xl * xl + yl * yl + 1);
+    const f3 ray = {xl, yl, 1};
+    unsigned best = 0; int operation = 0;
+    for (float ii = tcx - (scale * indexXStep * windowMultiplier); ii < tcx + (scale * indexXStep * windowMultiplier); ii += indexXStep)
+        for (float jj = tcy - (scale * indexYStep * windowMultiplier); jj < tcy + (scale * indexYStep * windowMultiplier); jj += indexYStep) {
+            const unsigned current = a.index[nearest_texel(jj, rows) * cols + nearest_texel(ii, cols)];
+            if (current > 0U) {
+                const float4 vertConf = tex4_linear(a.vertConf, cols, rows, ii, jj);
+                const float zdiff = (vertConf.z - vPosLocal.z);
+                if (fabsf(zdiff * lambda) < 0.05f) {
+                    const float dist = norm(cross(ray, f3{vertConf.x, vertConf.y, vertConf.z}));
+                    const float4 normRad = tex4_linear(a.normRad, cols, rows, ii, jj);
+                    if (dist < bestDist && (fabsf(normRad.z) < 0.75f || fabsf(angle_between(f3{normRad.x, normRad.y, normRad.z}, vNormLocal)) < 0.5f)) {
+                        operation = 1; bestDist = dist; best = current;
+                    }
+                }
+            }
+        }
+    const float col = (float)(((int)c.x << 16) + ((int)c.y << 8) + (int)c.z);
+    a.records[rank * 3 + 0] = make_float4(vPos.x, vPos.y, vPos.z, conf);
+    a.records[rank * 3 + 1] = make_float4(col, 0.f, (float)a.time, operation == 1 ? -1.f : -2.f);
+    a.records[rank * 3 + 2] = make_float4(nG.x, nG.y, nG.z, radius);
+    if (operation == 1) atomicMin(&a.owner[best], (unsigned)rank);
+    else a.new_flags[rank] = 1;
+}
+
+// update.vert:38-111 (reads the winning record through the owner index; resets the owner slot)
+__global__ void __launch_bounds__(kB) update_kernel(const float4* __restrict__ in, const unsigned* __restrict__ count,
+                                                    unsigned* __restrict__ owner, const float4* __restrict__ records, int time,
+                                                    float4* __restrict__ out)
+{
+    const unsigned id = blockIdx.x * kB + threadIdx.x;
+    if (id >= *count) return;
+    const float4 pc = in[id * 3], ct = in[id * 3 + 1], nr = in[id * 3 + 2];
+    const unsigned ow = owner[id];
+    if (ow == 0xFFFFFFFFu) { out[id * 3] = pc; out[id * 3 + 1] = ct; out[id * 3 + 2] = nr; return; }
+    owner[id] = 0xFFFFFFFFu;
+    const float4 rp = records[ow * 3], rc = records[ow * 3 + 1], rn = records[ow * 3 + 2];
+    const float c_k = pc.w, a = rp.w;
+    if (rn.w < (1.0f + 0.5f) * nr.w) {
+        float4 op, oc, on;
+        op.x = ((c_k * pc.x) + (a * rp.x)) / (c_k + a);
+        op.y = ((c_k * pc.y) + (a * rp.y)) / (c_k + a);
+        op.z = ((c_k * pc.z) + (a * rp.z)) / (c_k + a);
+        op.w = c_k + a;
+        const f3 oldc = decode_color(ct.x), newc = decode_color(rc.x);
+        oc.x = encode_color(((c_k * oldc.x) + (a * newc.x)) / (c_k + a), ((c_k * oldc.y) + (a * newc.y)) / (c_k + a),
+                            ((c_k * oldc.z) + (a * newc.z)) / (c_k + a));
+        oc.y = ct.y; oc.z = ct.z; oc.w = (float)time;
+        const float n0 = ((c_k * nr.x) + (a * rn.x)) / (c_k + a), n1 = ((c_k * nr.y) + (a * rn.y)) / (c_k + a);
+        const float n2 = ((c_k * nr.z) + (a * rn.z)) / (c_k + a), n3 = ((c_k * nr.w) + (a * rn.w)) / (c_k + a);
+        const f3 nn = normalized(f3{n0, n1, n2});
+        on = make_float4(nn.x, nn.y, nn.z, n3);
+        out[id * 3] = op; out[id * 3 + 1] = oc; out[id * 3 + 2] = on;
+    } else {
+        out[id * 3] = make_float4(pc.x, pc.y, pc.z, c_k + a);
+        out[id * 3 + 1] = make_float4(ct.x, ct.y, ct.z, (float)time);
+        out[id * 3 + 2] = nr;
+    }
+}
+
+// ====================================================================================== clean ====
+// copy_unstable.vert:53-149 (deformation-graph branch dead: nodes == 0).  The tested/modified surfel
+// is written to `staged` at its input position together with its keep flag; an ordered scan + scatter
+// then reproduces the transform-feedback output order (old surfels first, appended ones after).
+struct CleanArgs {
+    const unsigned* index; const float4* vertConf; const float4* colorTime;
+    const float* depth_filt; const unsigned char* mask;
+    Mat4 t_inv; cf_cam cam; int cols, rows, time; float confThreshold, outlierCoeff; int timeDelta, maskID;
+};
+
+__global__ void __launch_bounds__(kB) clean_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count,
+                                                   const float4* __restrict__ fresh, const unsigned* __restrict__ n_fresh, const CleanArgs a,
+                                                   unsigned total_bound, float4* __restrict__ staged, unsigned* __restrict__ flags)
+{
+    const unsigned k = blockIdx.x * kB + threadIdx.x;
+    const unsigned n_old = *count, n_all = n_old + *n_fresh;
+    if (k >= n_all) { if (k < total_bound) flags[k] = 0; return; }
+    const float4* src = (k < n_old) ? surfels + (size_t)k * 3 : fresh + (size_t)(k - n_old) * 3;
+    float4 pc = src[0], ct = src[1];
+    const float4 nr = src[2];
+    const int cols = a.cols, rows = a.rows;
+    const float scale = 1.0f;
+    int test = 1;
+    const f3 localPos = xform_point(a.t_inv, f3{pc.x, pc.y, pc.z});
+    const float x = ((a.cam.fx * localPos.x) / localPos.z) + a.cam.cx, y = ((a.cam.fy * localPos.y) / localPos.z) + a.cam.cy;
+    const f3 localNorm = normalized(xform_dir(a.t_inv, f3{nr.x, nr.y, nr.z}));
+    const float x_n = x / (float)cols, y_n = y / (float)rows;
+    const float stepX = 1.0f / (float)cols, stepY = 1.0f / (float)rows;
+    const float indexXStep = stepX * 0.5f / scale, indexYStep = stepY * 0.5f / scale;
+    const float windowMultiplier = 2;
+    int cnt = 0, zCount = 0, violationCount = 0;
+    float avgViolation = 0;
+    if ((float)a.time - ct.w < (float)a.timeDelta && localPos.z > 0 && x > 0 && y > 0 && x < (float)cols && y < (float)rows) {
+        for (float i = x_n - (scale * indexXStep * windowMultiplier); i < x_n + (scale * indexXStep * windowMultiplier); i += indexXStep)
+            for (float j = y_n - (scale * indexYStep * windowMultiplier); j < y_n + (scale * indexYStep * windowMultiplier); j += indexYStep) {
+                const unsigned current = a.index[nearest_texel(j, rows) * cols + nearest_texel(i, cols)];
+                if (current > 0U) {
+                    const float4 vertConf = tex4_linear(a.vertConf, cols, rows, i, j);
+                    const float4 colorTime = tex4_linear(a.colorTime, cols, rows, i, j);
+                    const float dx = vertConf.x - localPos.x, dy = vertConf.y - localPos.y;
+                    if (colorTime.z < ct.z && vertConf.w > a.confThreshold && vertConf.z > localPos.z && vertConf.z - localPos.z < 0.01f &&
+                        sqrtf(dx * dx + dy * dy) < nr.w * 1.4f)
+                        cnt++;
+                    if (colorTime.w == (float)a.time && vertConf.w > a.confThreshold && vertConf.z > localPos.z &&
+                        vertConf.z - localPos.z > 0.01f && fabsf(localNorm.z) > 0.85f)
+                        zCount++;
+                }
+            }
+        for (float i = x_n - stepX; i <= x_n + stepX; i += stepX)
+            for (float j = y_n - stepY; j <= y_n + stepY; j += stepY) {
+                const float d = a.depth_filt[nearest_texel(j, rows) * cols + nearest_texel(i, cols)] - localPos.z;
+                if (d > 0.03f) { violationCount++; avgViolation += d; }
+            }
+    }
+    if (cnt > 8 || zCount > 4) test = 0;
+    if (ct.w == -2) ct.w = (float)a.time;
+    if ((ct.w == -1 || (((float)a.time - ct.w) > 20 && pc.w < a.confThreshold))) test = 0;
+    if (ct.w > 0 && (float)a.time - ct.w > (float)a.timeDelta) test = 1;
+    if (violationCount > 0) {
+        avgViolation /= (float)violationCount;
+        pc.w *= 1.0f / (1 + a.outlierCoeff * avgViolation);
+        const int mx = nearest_texel(x_n, cols), my = nearest_texel(y_n, rows);
+        const int maskValue = a.mask[my * cols + mx];
+        const float wDepth = a.depth_filt[my * cols + mx];
+        if (maskValue != a.maskID && (wDepth > localPos.z - 0.05f && wDepth < localPos.z + 0.05f))
+            pc.w *= (0.5f + 0.5f * (1 - a.outlierCoeff / 10.0f));
+    }
+    flags[k] = (unsigned)test;
+    staged[(size_t)k * 3] = pc; staged[(size_t)k * 3 + 1] = ct; staged[(size_t)k * 3 + 2] = nr;
+}
+
+__global__ void add_counts_kernel(const unsigned* a, const unsigned* b, unsigned* out) { *out = *a + *b; }
+__global__ void set_count_kernel(unsigned* out, unsigned v) { *out = v; }
+
+// ------------------------------------------------------------------------------- launchers ----
+void launch_bilateral(hipStream_t s, const float* depth, int cols, int rows, float maxD, float* out)
+{
+    bilateral_kernel<<<gridFor((long long)cols * rows), kB, 0, s>>>(depth, cols, rows, maxD, out);
+}
+
+static Mat4 mat4_from(const float m[16]) { Mat4 r; for (int i = 0; i < 16; i++) r.m[i] = m[i]; return r; }
+
+void launch_feedback(hipStream_t s, const uint8_t* rgba, const float* depth, int cols, int rows, cf_cam cam, float inv_fx, float inv_fy,
+                     const float* tcx, const float* tcy, int time, float maxDepth, float* rec, unsigned* flags)
+{
+    feedback_kernel<<<gridFor((long long)cols * rows), kB, 0, s>>>(reinterpret_cast<const uchar4*>(rgba), depth, cols, rows, cam.cx, cam.cy, inv_fx,
+                                                                   inv_fy, tcx, tcy, time, maxDepth, reinterpret_cast<float4*>(rec), flags);
+}
+void launch_scatter_records(hipStream_t s, const float* rec, const unsigned* flags, const unsigned* offsets, long long n, float* out,
+                            unsigned out_base)
+{
+    scatter_records_kernel<<<gridFor(n), kB, 0, s>>>(reinterpret_cast<const float4*>(rec), flags, offsets, n, reinterpret_cast<float4*>(out), out_base);
+}
+void launch_init(hipStream_t s, const float* raw, const float* filt, const unsigned* raw_count, long long max_n, float* out)
+{
+    init_kernel<<<gridFor(max_n), kB, 0, s>>>(reinterpret_cast<const float4*>(raw), reinterpret_cast<const float4*>(filt), raw_count,
+                                              reinterpret_cast<float4*>(out));
+}
+void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
+                            int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, unsigned* index,
+                            float* vertConf, float* colorTime, float* normRad)
+{
+    const int N = cols * rows;
+    (void)hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * N, s);
+    const Mat4 T = mat4_from(t_inv);
+    if (count_bound > 0)
+        index_splat_kernel<<<gridFor(count_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, cam, cols, rows, maxDepth, time,
+                                                               timeDelta, keys);
+    index_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), T, N, keys, index, reinterpret_cast<float4*>(vertConf),
+                                                   reinterpret_cast<float4*>(colorTime), reinterpret_cast<float4*>(normRad));
+}
+void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
+                             int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
+                             unsigned long long* keys, uint8_t* image, float* vertexConf, float* normalRad, uint16_t* time16)
+{
+    const int N = cols * rows;
+    (void)hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * N, s);
+    const Mat4 T = mat4_from(t_inv);
+    if (count_bound > 0)
+        splat_raster_kernel<<<gridFor(count_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, cam, cols, rows, maxDepth,
+                                                                confThreshold, time, maxTime, timeDelta, keys);
+    splat_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), T, cam, cols, rows, maxDepth, confThreshold, time, maxTime,
+                                                   timeDelta, keys, reinterpret_cast<uchar4*>(image), reinterpret_cast<float4*>(vertexConf),
+                                                   reinterpret_cast<float4*>(normalRad), time16);
+}
+void launch_fill_in(hipStream_t s, const float* pv, const float* pn, const uint8_t* pimg, const float* depth, const uint8_t* rgba, int cols,
+                    int rows, cf_cam cam, float inv_fx, float inv_fy, int pass_geom, int pass_rgb, float* ov, float* on, uint8_t* oi)
+{
+    fill_in_kernel<<<gridFor((long long)cols * rows), kB, 0, s>>>(
+        reinterpret_cast<const float4*>(pv), reinterpret_cast<const float4*>(pn), reinterpret_cast<const uchar4*>(pimg), depth,
+        reinterpret_cast<const uchar4*>(rgba), cols, rows, cam.cx, cam.cy, inv_fx, inv_fy, pass_geom, pass_rgb, reinterpret_cast<float4*>(ov),
+        reinterpret_cast<float4*>(on), reinterpret_cast<uchar4*>(oi));
+}
+void launch_fill_ratio(hipStream_t s, const uint8_t* pimg, int cols, int rows, unsigned* out2)
+{
+    fill_ratio_kernel<<<1, 1024, 0, s>>>(reinterpret_cast<const uchar4*>(pimg), cols, rows, out2);
+}
+void launch_associate(hipStream_t s, const SurfelFuseArgs& h)
+{
+    FuseArgs a;
+    a.index = h.index; a.vertConf = reinterpret_cast<const float4*>(h.vertConf); a.normRad = reinterpret_cast<const float4*>(h.normRad);
+    a.rgba = reinterpret_cast<const uchar4*>(h.rgba); a.depth_raw = h.depth_raw; a.depth_filt = h.depth_filt; a.mask = h.mask;
+    a.tcx = h.tcx; a.tcy = h.tcy; a.pose = mat4_from(h.pose); a.cam = h.cam; a.inv_fx = h.inv_fx; a.inv_fy = h.inv_fy;
+    a.cols = h.cols; a.rows = h.rows; a.time = h.time; a.weighting = h.weighting; a.maskID = h.maskID; a.maxDepth = h.maxDepth;
+    a.records = reinterpret_cast<float4*>(h.records); a.new_flags = h.new_flags; a.owner = h.owner;
+    associate_kernel<<<gridFor((long long)h.cols * h.rows), kB, 0, s>>>(a);
+}
+void launch_update(hipStream_t s, const float* in, const unsigned* count, unsigned count_bound, unsigned* owner, const float* records, int time,
+                   float* out)
+{
+    if (count_bound > 0)
+        update_kernel<<<gridFor(count_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(in), count, owner, reinterpret_cast<const float4*>(records),
+                                                          time, reinterpret_cast<float4*>(out));
+}
+void launch_clean(hipStream_t s, const float* surfels, const unsigned* count, const float* fresh, const unsigned* n_fresh, unsigned total_bound,
+                  const SurfelCleanArgs& h, float* staged, unsigned* flags)
+{
+    CleanArgs a;
+    a.index = h.index; a.vertConf = reinterpret_cast<const float4*>(h.vertConf); a.colorTime = reinterpret_cast<const float4*>(h.colorTime);
+    a.depth_filt = h.depth_filt; a.mask = h.mask; a.t_inv = mat4_from(h.t_inv); a.cam = h.cam; a.cols = h.cols; a.rows = h.rows; a.time = h.time;
+    a.confThreshold = h.confThreshold; a.outlierCoeff = h.outlierCoeff; a.timeDelta = h.timeDelta; a.maskID = h.maskID;
+    if (total_bound > 0)
+        clean_kernel<<<gridFor(total_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, reinterpret_cast<const float4*>(fresh), n_fresh,
+                                                         a, total_bound, reinterpret_cast<float4*>(staged), flags);
+}
+void launch_add_counts(hipStream_t s, const unsigned* a, const unsigned* b, unsigned* out) { add_counts_kernel<<<1, 1, 0, s>>>(a, b, out); }
+void launch_set_count(hipStream_t s, unsigned* out, unsigned v) { set_count_kernel<<<1, 1, 0, s>>>(out, v); }
+
+}  // namespace cf

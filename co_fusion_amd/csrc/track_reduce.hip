@@ -40,11 +40,12 @@ __device__ __forceinline__ void se3_accumulate(const float (&row)[7], unsigned l
     for (int i = 0; i < 7; i++) r[i] = (double)clamp_row(row[i], lim);
 #pragma unroll
     for (int i = 0; i < 6; i++) rs[i] = (double)(clamp_row(row[i], lim) * scale);
-    int k = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = i; j < 7; j++) acc[k++] += (unsigned long long)__double_as_longlong(fma(rs[i], r[j], kMagic));
+        for (int j = 0; j < 7; j++)
+            if (j >= i)  // static index: k(i,j) = 7i - i(i-1)/2 + (j-i)
+                acc[7 * i - (i * (i - 1)) / 2 + (j - i)] += (unsigned long long)__double_as_longlong(fma(rs[i], r[j], kMagic));
     acc[27] += (unsigned long long)__double_as_longlong(fma(r[6] * (double)scale, r[6], kMagic));
 }
 
@@ -124,29 +125,28 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nlog)
     return (b & 7) * per + (b >> 3);
 }
 
+// Kernel arguments by value: every pointer the kernel dereferences arrives in the kernarg segment
+// (scalar loads, global-address-space vector loads, no pointer chasing through device structs).
+// Only the pose/flags, which the solve kernel updates on the device every iteration, are read from
+// memory -- as scalar loads issued in parallel with the first coalesced map loads.
 template <int PPT, int LEVEL_TAG>
-__global__ void __launch_bounds__(1024) icp_reduce_kernel(OdomDev* const* __restrict__ models, int level, int write_err)
+__global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args)
 {
-    const OdomDev* __restrict__ od = models[blockIdx.y];
-    if (!od->icp || od->level_done) return;
-    const int cols = od->width >> level, rows = od->height >> level, N = cols * rows;
+    const IcpModelArgs& ma = args.m[blockIdx.y];
+    const OdomDev* __restrict__ st = ma.st;
+    if (!st->icp || st->level_done) return;
+    const int cols = args.cols, rows = args.rows, N = cols * rows;
     const int T = blockDim.x;
     const int nlog = (N + T * PPT - 1) / (T * PPT);
     const int lb = xcd_logical_block(blockIdx.x, nlog);
     if (lb >= nlog) return;
 
-    m33 Rcurr, Rprev_inv;
-#pragma unroll
-    for (int i = 0; i < 9; i++) { Rcurr.m[i] = od->Rcurr[i]; Rprev_inv.m[i] = od->Rprev_inv[i]; }
-    const f3 tcurr = {od->tcurr[0], od->tcurr[1], od->tcurr[2]};
-    const f3 tprev = {od->tprev[0], od->tprev[1], od->tprev[2]};
-    const cf_cam intr = cam_level(od->intr, level);
-    const float distThres = od->distThres, angleThres = od->angleThres;
-    const float* __restrict__ vc = od->vmap_curr[level];
-    const float* __restrict__ nc = od->nmap_curr[level];
-    const float* __restrict__ vp = od->vmap_g_prev[level];
-    const float* __restrict__ np = od->nmap_g_prev[level];
-    float* __restrict__ errs = write_err ? od->err_surface : nullptr;
+    const float* __restrict__ vc = ma.vc;
+    const float* __restrict__ nc = ma.nc;
+    const float* __restrict__ vp = ma.vp;
+    const float* __restrict__ np = ma.np;
+    float* __restrict__ errs = (args.flags & 1) ? ma.err : nullptr;
+    const int abl = args.flags >> 8;  // micro-benchmark ablation bits (0 in production)
 
     unsigned long long acc[32];
 #pragma unroll
@@ -158,13 +158,19 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(OdomDev* const* __rest
         float vx[PPT], vy[PPT], vz[PPT], nx[PPT], ny[PPT], nz[PPT];
         load_vec<PPT>(vc + i0, vx); load_vec<PPT>(vc + i0 + N, vy); load_vec<PPT>(vc + i0 + 2 * N, vz);
         load_vec<PPT>(nc + i0, nx); load_vec<PPT>(nc + i0 + N, ny); load_vec<PPT>(nc + i0 + 2 * N, nz);
+        m33 Rcurr, Rprev_inv;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { Rcurr.m[i] = st->Rcurr[i]; Rprev_inv.m[i] = st->Rprev_inv[i]; }
+        const f3 tcurr = {st->tcurr[0], st->tcurr[1], st->tcurr[2]};
+        const f3 tprev = {st->tprev[0], st->tprev[1], st->tprev[2]};
 #pragma unroll
         for (int p = 0; p < PPT; p++) {
             float row[7], err; int found;
-            icp_pixel(Rcurr, tcurr, Rprev_inv, tprev, intr, distThres, angleThres, cols, rows, N, vp, np,
+            icp_pixel(Rcurr, tcurr, Rprev_inv, tprev, args.intr, args.distThres, args.angleThres, cols, rows, N, vp, np,
                       f3{vx[p], vy[p], vz[p]}, f3{nx[p], ny[p], nz[p]}, row, err, found);
             if (errs) errs[i0 + p] = err;
-            se3_accumulate<kFixICP>(row, acc);
+            if (!(abl & 1)) se3_accumulate<kFixICP>(row, acc);
+            else acc[0] += __float_as_uint(row[6]) + __float_as_uint(row[3]);
             acc[28] += (unsigned long long)found;
         }
     } else {
@@ -172,8 +178,10 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(OdomDev* const* __rest
         for (int k = 0; k < 28; k++) acc[k] = 0;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (abl & 2) { if (acc[0] + acc[28] == 0x1234567ull) ma.acc[lane] = acc[5]; return; }
     const unsigned long long v = wave_reduce32_u64(acc, lane);
-    block_commit32<16>(v, lane, wave, T >> 6, od->icp_acc + (size_t)(lb % kGroups) * 32);
+    if (abl & 4) { if (v == 0x1234567ull) ma.acc[lane] = v; return; }
+    block_commit32<16>(v, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
 }
 
 // ================================================================================================
@@ -367,12 +375,12 @@ __device__ __forceinline__ void so3_pass(const uint8_t* __restrict__ lastImage, 
         double r[4], rs[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) { r[q] = (double)clamp_row(row[q], lim); rs[q] = (double)(clamp_row(row[q], lim) * scale); }
-        int s = 0;
 #pragma unroll
         for (int p = 0; p < 3; p++)
 #pragma unroll
-            for (int q = p; q < 4; q++)
-                acc[s++] += (unsigned long long)__double_as_longlong(fma(rs[p], r[q], kMagic)) - kMagicBits;
+            for (int q = 0; q < 4; q++)
+                if (q >= p)  // k(p,q) = 4p - p(p-1)/2 + (q-p)
+                    acc[4 * p - (p * (p - 1)) / 2 + (q - p)] += (unsigned long long)__double_as_longlong(fma(rs[p], r[q], kMagic)) - kMagicBits;
         acc[9] += (unsigned long long)__double_as_longlong(fma(rs[3], r[3], kMagic)) - kMagicBits;
         acc[10] += 1;
     }
@@ -644,30 +652,29 @@ __global__ void __launch_bounds__(64) acc_total_kernel(const unsigned long long*
 
 // ------------------------------------------------------------------------------ launchers ----
 template <int TAG>
-static void launch_icp_kernel(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, int n, int N, int level, int write_err)
+static void launch_icp_kernel(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n)
 {
+    const int N = args.cols * args.rows;
     const int per_block = cfg.threads * cfg.ppt;
     const int nlog = (N + per_block - 1) / per_block;
     const dim3 grid(((nlog + 7) / 8) * 8, n);
     switch (cfg.ppt) {
-        case 4: icp_reduce_kernel<4, TAG><<<grid, cfg.threads, 0, s>>>(d_models, level, write_err); break;
-        case 2: icp_reduce_kernel<2, TAG><<<grid, cfg.threads, 0, s>>>(d_models, level, write_err); break;
-        default: icp_reduce_kernel<1, TAG><<<grid, cfg.threads, 0, s>>>(d_models, level, write_err); break;
+        case 4: icp_reduce_kernel<4, TAG><<<grid, cfg.threads, 0, s>>>(args); break;
+        case 2: icp_reduce_kernel<2, TAG><<<grid, cfg.threads, 0, s>>>(args); break;
+        default: icp_reduce_kernel<1, TAG><<<grid, cfg.threads, 0, s>>>(args); break;
     }
 }
 
-static void launch_icp_level(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, int n, int width, int height, int level,
-                             int write_err)
+void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level)
 {
-    const int N = (width >> level) * (height >> level);
     // distinct symbols per pyramid level so that rocprofv3 --stats separates them
-    if (level == 0) launch_icp_kernel<0>(s, cfg, d_models, n, N, level, write_err);
-    else if (level == 1) launch_icp_kernel<1>(s, cfg, d_models, n, N, level, write_err);
-    else launch_icp_kernel<2>(s, cfg, d_models, n, N, level, write_err);
+    if (level == 0) launch_icp_kernel<0>(s, cfg, args, n);
+    else if (level == 1) launch_icp_kernel<1>(s, cfg, args, n);
+    else launch_icp_kernel<2>(s, cfg, args, n);
 }
 
-void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, int n, int width, int height, bool so3,
-                     bool pyramid, bool fast_odom, bool rgb, bool icp, ProfSink* prof)
+void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, const IcpArgs icp_args[3], int n, int width,
+                     int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, ProfSink* prof)
 {
     int iterations[3];
     iterations[0] = fast_odom ? 3 : 10;
@@ -687,9 +694,12 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, int
             }
             if (rgb) rgb_residual_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(d_models, i);
             if (icp) {
-                const bool timed = prof && prof->enabled && prof->used + 2 <= prof->capacity;
+                // the roofline figure is quoted on the dominant kernel: the level-0 instantiation
+                const bool timed = prof && prof->enabled && i == 0 && prof->used + 4 <= prof->capacity;
                 if (timed) (void)hipEventRecord(prof->events[prof->used++], s);
-                launch_icp_level(s, cfg, d_models, n, width, height, i, (i == 0 && last_of_level) ? 1 : 0);
+                IcpArgs a = icp_args[i];
+                a.flags = (i == 0 && last_of_level) ? 1 : 0;
+                launch_icp_level(s, cfg, a, n, i);
                 if (timed) {
                     (void)hipEventRecord(prof->events[prof->used++], s);
                     prof->bytes += (uint64_t)N * (24 + 24 * (uint64_t)n);
@@ -704,11 +714,6 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, int
 }
 
 // ---- stand-alone steps (operate on a scratch OdomDev prepared by cabi.cpp) -------------------
-void launch_icp_models(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, int n, int width, int height, int level,
-                       int write_err)
-{
-    launch_icp_level(s, cfg, d_models, n, width, height, level, write_err);
-}
 void launch_rgb_residual_models(hipStream_t s, OdomDev* const* d_models, int n, int width, int height, int level)
 {
     const int N = (width >> level) * (height >> level);

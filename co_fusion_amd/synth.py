@@ -2,7 +2,8 @@
 
 The reference ships no data (its sequences are external downloads,
 /root/reference/README.md:36-44), so every workload here is an analytic ray-cast
-scene: the inside of a 6 x 4 x 3 m room with static clutter boxes, plus N moving
+scene: the inside of a 3.6 x 2.2 x 3.4 m room (depths 0.8-2.8 m, the range in which Kinect-class
+noise still leaves usable normals) with static clutter boxes, plus N moving
 objects (spheres / oriented boxes) on smooth SE(3) paths, seen from a camera on a
 slow Lissajous path.  Depth is metric f32, quantised to millimetres like a .klg
 log (GUI/Tools/KlgLogReader.cpp:63-69); colour is RGB u8.
@@ -58,23 +59,23 @@ class Scene:
         rng = np.random.default_rng(seed)
         self.seed = seed
         # room interior, world frame = first camera frame (camera looks along +z, y down)
-        self.room_min = np.array([-3.0, -1.6, -1.0])
-        self.room_max = np.array([3.0, 1.4, 4.2])
+        self.room_min = np.array([-1.8, -1.2, -0.8])
+        self.room_max = np.array([1.8, 1.0, 2.6])
         # static clutter: axis-aligned boxes standing on the floor (y = room_max[1])
         self.clutter = []
         for i in range(5):
-            sx, sy, sz = rng.uniform(0.3, 0.8), rng.uniform(0.3, 0.9), rng.uniform(0.3, 0.8)
-            cx = rng.uniform(-2.2, 2.2)
-            cz = rng.uniform(2.2, 3.6)
+            sx, sy, sz = rng.uniform(0.25, 0.6), rng.uniform(0.25, 0.7), rng.uniform(0.25, 0.5)
+            cx = rng.uniform(-1.4, 1.4)
+            cz = rng.uniform(1.5, 2.3)
             lo = np.array([cx - sx / 2, self.room_max[1] - sy, cz - sz / 2])
             hi = np.array([cx + sx / 2, self.room_max[1], cz + sz / 2])
             self.clutter.append((lo, hi, rng.uniform(0.5, 1.0, size=3), 100 + i))
         self.objects = []
         for i in range(n_obj):
             kind = "sphere" if i % 2 == 0 else "box"
-            size = rng.uniform(0.15, 0.3) if kind == "sphere" else rng.uniform(0.3, 0.55, size=3)
-            c0 = np.array([rng.uniform(-1.2, 1.2), rng.uniform(-0.5, 0.5), rng.uniform(1.3, 2.4)])
-            amp = rng.uniform(0.15, 0.35, size=3) * np.array([1.0, 0.4, 0.6])
+            size = rng.uniform(0.12, 0.2) if kind == "sphere" else rng.uniform(0.2, 0.35, size=3)
+            c0 = np.array([rng.uniform(-0.7, 0.7), rng.uniform(-0.3, 0.4), rng.uniform(0.9, 1.5)])
+            amp = rng.uniform(0.10, 0.25, size=3) * np.array([1.0, 0.4, 0.5])
             freq = rng.uniform(0.02, 0.04, size=3)  # rad/frame -> <= ~1.4 cm/frame
             phase = rng.uniform(0, 6.28, size=3)
             axis = rng.normal(size=3)
@@ -85,9 +86,9 @@ class Scene:
     # -- trajectories -------------------------------------------------------
     def camera_pose(self, t: int) -> np.ndarray:
         """T(world <- camera) at frame t; identity at t = 0."""
-        pos = np.array([0.30 * math.sin(0.020 * t), 0.10 * math.sin(0.031 * t), 0.20 * math.sin(0.013 * t)])
-        yaw = 0.20 * math.sin(0.017 * t)
-        pitch = 0.08 * math.sin(0.023 * t)
+        pos = np.array([0.25 * math.sin(0.020 * t), 0.08 * math.sin(0.031 * t), 0.15 * math.sin(0.013 * t)])
+        yaw = 0.18 * math.sin(0.017 * t)
+        pitch = 0.07 * math.sin(0.023 * t)
         R = _rot_axis([0, 1, 0], yaw) @ _rot_axis([1, 0, 0], pitch)
         T = np.eye(4)
         T[:3, :3] = R

@@ -168,8 +168,50 @@ int cf_odom_buffer(cf_odom *od, int which, int level, void **dptr, uint64_t *byt
 /* Model::generateCUDATextures depth half (Model.cpp:341-343): l1/l2 device outputs */
 int cf_depth_pyramid(cf_ctx *ctx, const float *depth_filtered, int cols, int rows, float *l1, float *l2);
 
+/* ------------------------------------------------ frame pre-processing + surfel Model ---- */
+/* CoFusion::filterDepth + depth_bilateral_metric.frag (CoFusion.cpp:567-574): 13x13 bilateral, zero outside [0.3, maxD] */
+int cf_bilateral(cf_ctx *ctx, const float *depth, int cols, int rows, float maxD, float *out);
+
+/* Model (Core/Model/Model.h:117-235).  The pose lives with the caller (the CoFusion facade) and is passed
+ * explicitly, ROW-major T(model <- camera).  Two surfel buffers are ping-ponged exactly like Model::vbos[2]. */
+int cf_model_create(cf_ctx *ctx, int max_surfels, cf_model **out);
+void cf_model_destroy(cf_model *m);
+/* computeFeedbackBuffers + Model::initialise (CoFusion.cpp:157-169, Model.cpp:227-272); frame 1 only */
+int cf_model_initialise(cf_model *m, const uint8_t *rgba, const float *depth_raw, const float *depth_filtered, int time,
+                        float maxDepth);
+/* Model::lastCount (Model.cpp:815) */
+int cf_model_count(cf_model *m, uint32_t *count);
+/* Model::predictIndices -> ModelProjection::predictIndices (ModelProjection.cpp:105-157) */
+int cf_model_predict_indices(cf_model *m, const float pose[16], int time, float maxDepth, int timeDelta);
+/* Model::combinedPredict -> ModelProjection::combinedPredict (ModelProjection.cpp:192-273), ACTIVE prediction */
+int cf_model_combined_predict(cf_model *m, const float pose[16], float maxDepth, float confThreshold, int time, int maxTime,
+                              int timeDelta);
+/* Model::performFillIn (Model.cpp:901-909) */
+int cf_model_perform_fill_in(cf_model *m, const uint8_t *rgba, const float *depth_filtered, int passthrough_geom,
+                             int passthrough_rgb);
+/* CoFusion::requiresFillIn (CoFusion.cpp:547-565); out = 1 when fewer than `ratio` of the sampled pixels are set */
+int cf_model_requires_fill_in(cf_model *m, float ratio, int *out);
+/* Model::fuse (Model.cpp:408-563); weighting = Model::computeFusionWeight; maxDepth = min(depthCutoff, model maxDepth) */
+int cf_model_fuse(cf_model *m, const float pose[16], int time, const uint8_t *rgba, const uint8_t *mask, const float *depth_raw,
+                  const float *depth_filtered, float maxDepth, float weighting, int maskID);
+/* Model::clean (Model.cpp:565-697); count_out = surfels written (the GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN query) */
+int cf_model_clean(cf_model *m, const float pose[16], int time, float confThreshold, float outlierCoeff, int timeDelta,
+                   const float *depth_filtered, const uint8_t *mask, int maskID, uint32_t *count_out);
+/* Model::downloadMap (Model.cpp:867-899): `count` surfels of 12 floats */
+int cf_model_download_map(cf_model *m, float *host_surfels, uint32_t capacity, uint32_t *count);
+int cf_model_upload_map(cf_model *m, const float *host_surfels, uint32_t count);
+/* device views of the projection outputs.  which: 0 index(u32) 1 vertConf 2 colorTime 3 normRad (f32x4) | 4 splat image
+ * (rgba8) 5 splat vertexConf 6 splat normalRad (f32x4) 7 splat time (u16) | 8 fill vertex 9 fill normal (f32x4)
+ * 10 fill image (rgba8) | 11 surfels */
+int cf_model_buffer(cf_model *m, int which, void **dptr, uint64_t *bytes);
+/* Model::computeFusionWeight (Model.cpp:391-406); pure host math */
+float cf_fusion_weight(const float pose[16], const float lastPose[16], float weightMultiplier);
+
 /* launch-shape tuning of the ICP reduction (GPUConfig.h:51-58 in the reference) */
 int cf_set_icp_launch(cf_ctx *ctx, int threads, int pixels_per_thread);
+
+/* micro-benchmark of the ICP reduction on the state of the last tracking call (level 0..2) */
+int cf_odom_bench_icp(cf_odom *od, int level, int iters, float *avg_us);
 
 /* timing of the most recent reductions, measured with hipEvents on the ctx stream */
 typedef struct {

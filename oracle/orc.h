@@ -110,6 +110,29 @@ void orc_odom_get_incremental_transformation(orc_odometry *o, float trans[3], fl
  * 4 lastDepth,5 nextDepth (f32), 6 lastImage,7 nextImage,8 lastNextImage (u8), 9 dIdx,10 dIdy (s16) */
 const void *orc_odom_buffer(const orc_odometry *o, int which, int level);
 
+/* ------------------------------ surfel path (orc_surfel.c) --------------------------------- */
+void orc_inverse_pose(const float pose[16], float out[16]);
+void orc_bilateral(const float *depth, int cols, int rows, float maxD, float *out);
+int orc_vertex_feedback(const uint8_t *rgba, const float *depth, int cols, int rows, orc_cam cam, int time, float maxDepth, float *out);
+int orc_model_initialise(const float *raw_fb, int raw_count, const float *filtered_fb, float *surfels);
+void orc_predict_indices(const float *surfels, int count, const float pose[16], orc_cam cam, int cols, int rows, float maxDepth,
+                         int time, int timeDelta, uint32_t *index, float *vertConf4, float *colorTime4, float *normRad4);
+void orc_combined_predict(const float *surfels, int count, const float pose[16], orc_cam cam, int cols, int rows, float maxDepth,
+                          float confThreshold, int time, int maxTime, int timeDelta, uint8_t *image_rgba, float *vertexConf4,
+                          float *normalRad4, uint16_t *time16);
+void orc_fill_in(const float *pred_vertex4, const float *pred_normal4, const uint8_t *pred_image, const float *depth,
+                 const uint8_t *rgba, int cols, int rows, orc_cam cam, int passthrough_geom, int passthrough_rgb,
+                 float *out_vertex4, float *out_normal4, uint8_t *out_image);
+int orc_requires_fill_in(const uint8_t *pred_image, int cols, int rows, float ratio);
+void orc_fuse(const float *surfels_in, int count, const uint32_t *index, const float *vertConf4, const float *normRad4,
+              const uint8_t *rgba, const float *depth_raw, const float *depth_filt, const uint8_t *mask, const float pose[16],
+              orc_cam cam, int cols, int rows, int time, float weighting, int maskID, float maxDepth, float *surfels_out,
+              float *new_unstable, int *n_new);
+int orc_clean(const float *surfels_in, int count, const float *new_unstable, int n_new, const uint32_t *index, const float *vertConf4,
+              const float *colorTime4, const float *depth_filt, const uint8_t *mask, const float pose[16], orc_cam cam, int cols,
+              int rows, int time, float confThreshold, float outlierCoeff, int timeDelta, int maskID, float *surfels_out);
+float orc_fusion_weight(const float pose[16], const float lastPose[16], float weightMultiplier);
+
 /* Model::generateCUDATextures depth pyramid (Model.cpp:319-348) */
 void orc_depth_pyramid(const float *depth_filtered, int cols, int rows, float *l1, float *l2);
 

@@ -59,6 +59,47 @@ static inline float orc_qnan(void)
     union { uint32_t u; float f; } c; c.u = 0x7fffffffu; return c.f;  /* cudafuncs.cu:131 */
 }
 
+
+/* ---- deterministic f32 exp / acos (shared spec with the HIP kernels) ---------------------
+ * GLSL's exp()/acos() precision is implementation defined (the reference runs them inside the
+ * GL driver); both sides of the parity tests use these fixed polynomial forms instead of libm so
+ * that confidences and the 0.5 rad normal gate are reproducible bit for bit. */
+static inline float orc_expf(float x)
+{
+    if (!(x > -87.0f)) return (x != x) ? x : 0.0f;
+    if (x > 88.0f) return INFINITY;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = x - n * 0.693145751953125f;
+    r = r - n * 1.42860682030941723212e-6f;
+    float p = 1.0f / 720.0f;
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    return ldexpf(p, (int)n);
+}
+static inline float orc_acos_r(float z)
+{
+    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
+    const float p = z * (pS0 + z * (pS1 + z * pS2));
+    const float q = 1.0f + z * qS1;
+    return p / q;
+}
+static inline float orc_acosf(float x)
+{
+    const float pio2 = 1.57079637050628662109375f, pi = 3.1415927410125732421875f;
+    if (x != x || x > 1.0f || x < -1.0f) return orc_qnan();
+    if (fabsf(x) < 0.5f) return pio2 - (x + x * orc_acos_r(x * x));
+    if (x < 0.0f) {
+        const float z = (1.0f + x) * 0.5f, s = sqrtf(z);
+        return pi - 2.0f * (s + s * orc_acos_r(z));
+    }
+    const float z = (1.0f - x) * 0.5f, s = sqrtf(z);
+    return 2.0f * (s + s * orc_acos_r(z));
+}
+
 /* ---- fixed-point accumulation of normal-equation products -------------------
  * q = RNE_to_int64(a*b*2^F), a and b clamped to +-2^((50-F)/2).
  * Sums of q are order independent, so every launch shape / GPU count / the
