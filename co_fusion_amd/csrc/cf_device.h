@@ -269,11 +269,14 @@ __device__ inline void inv44_affine(const double a[16], double o[16])
 
 // LDL^T with diagonal pivoting; zero pivots -> zero solution component (the
 // ldlt().solve() behaviour the reference relies on, RGBDOdometry.cpp:435).
+// All arrays are indexed dynamically (pivoting), so the caller passes LDS storage: private arrays
+// would be demoted to scratch (global memory round trips on the single solving lane).
+// ws: N*N + 2N elements, iws: N ints; Ain/b/x should live in LDS as well.
 template <typename T, int N>
-__device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tiny)
+__device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tiny, T* ws, int* iws)
 {
-    T A[N * N], y[N], d[N];
-    int perm[N];
+    T* A = ws; T* y = ws + N * N; T* d = ws + N * N + N;
+    int* perm = iws;
     for (int i = 0; i < N * N; i++) A[i] = Ain[i];
     for (int i = 0; i < N; i++) perm[i] = i;
     for (int k = 0; k < N; k++) {

@@ -458,6 +458,8 @@ __global__ void __launch_bounds__(1024) so3_prealign_kernel(OdomDev* const* __re
     __shared__ float s_Rlr[9];
     __shared__ float s_lastError, s_lastCount;
     __shared__ double s_lastResultR[9];
+    __shared__ float s_jtj[9], s_jtr[3], s_delta[3], s_fws[15];
+    __shared__ int s_iws[3];
     const int L = 2, cols = od->width >> L, rows = od->height >> L;
     if (threadIdx.x == 0) {
         for (int k = 0; k < 9; k++) { s_resultR[k] = (k % 4 == 0) ? 1.0 : 0.0; s_lastResultR[k] = s_resultR[k]; s_Rlr[k] = (k % 4 == 0) ? 1.f : 0.f; }
@@ -495,8 +497,10 @@ __global__ void __launch_bounds__(1024) so3_prealign_kernel(OdomDev* const* __re
                 } else {
                     s_lastError = err; s_lastCount = cnt;
                     for (int k = 0; k < 9; k++) s_lastResultR[k] = s_resultR[k];
-                    float delta[3];
-                    ldlt_solve<float, 3>(jtj, jtr, delta, 1.17549435e-38f);
+                    for (int k = 0; k < 9; k++) s_jtj[k] = jtj[k];
+                    for (int k = 0; k < 3; k++) s_jtr[k] = jtr[k];
+                    ldlt_solve<float, 3>(s_jtj, s_jtr, s_delta, 1.17549435e-38f, s_fws, s_iws);
+                    const float delta[3] = {s_delta[0], s_delta[1], s_delta[2]};
                     const double dd[3] = {delta[0], delta[1], delta[2]};
                     double rotUpdate[9];
                     rodrigues(dd, rotUpdate);
@@ -546,6 +550,8 @@ __global__ void __launch_bounds__(256) gn_solve_kernel(OdomDev* const* __restric
     OdomDev* od = models[blockIdx.x];
     __shared__ unsigned long long s_icp[32], s_rgb[32];
     __shared__ unsigned long long s_part[2][8][32];
+    __shared__ double s_lastA[36], s_lastb[6], s_result[6], s_dws[48];
+    __shared__ int s_diws[6];
     // 256 threads: word = t & 31, slice = t >> 5 (8 slices of 8 groups)
     {
         const int w = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -583,7 +589,7 @@ __global__ void __launch_bounds__(256) gn_solve_kernel(OdomDev* const* __restric
             od->stats.last_icp_error = sqrtf(od->residual[0]) / od->residual[1];
             od->stats.last_icp_count = od->residual[1];
             if (od->rgb) se3_unpack(s_rgb, kFixRGB, A_rgb, b_rgb, dummy);
-            double lastA[36], lastb[6], result[6];
+            double* lastA = s_lastA; double* lastb = s_lastb; double* result = s_result;
             if (od->icp && od->rgb) {
                 const double w = od->icpWeight;
                 for (int k = 0; k < 36; k++) lastA[k] = (double)A_rgb[k] + w * w * (double)A_icp[k];
@@ -595,7 +601,7 @@ __global__ void __launch_bounds__(256) gn_solve_kernel(OdomDev* const* __restric
                 for (int k = 0; k < 36; k++) lastA[k] = A_rgb[k];
                 for (int k = 0; k < 6; k++) lastb[k] = b_rgb[k];
             }
-            ldlt_solve<double, 6>(lastA, lastb, result, 2.2250738585072014e-308);
+            ldlt_solve<double, 6>(lastA, lastb, result, 2.2250738585072014e-308, s_dws, s_diws);
             for (int k = 0; k < 36; k++) od->stats.lastA[k] = lastA[k];
             for (int k = 0; k < 6; k++) od->stats.lastb[k] = lastb[k];
             // computeUpdateSE3
