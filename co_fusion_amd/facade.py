@@ -1,0 +1,132 @@
+"""ctypes binding of the C++ facade (libcofusion.so, include/cofusion.h): the reference's
+`CoFusion` object as GUI/MainController.cpp drives it (construct, processFrame, getters)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as _libmod
+from .api import Profile
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("device", C.c_int), ("max_surfels", C.c_int), ("max_models", C.c_int), ("conf_global_init", C.c_float),
+                ("conf_object_init", C.c_float), ("depth_cutoff", C.c_float), ("icp_weight", C.c_float),
+                ("outlier_coefficient", C.c_float), ("fast_odom", C.c_int), ("so3", C.c_int), ("frame_to_frame_rgb", C.c_int),
+                ("pyramid", C.c_int), ("rgb_only", C.c_int), ("model_spawn_offset", C.c_uint), ("enable_multiple_models", C.c_int)]
+
+
+class CoFusionError(RuntimeError):
+    pass
+
+
+class CoFusion:
+    def __init__(self, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, device=0, **kw):
+        if not torch.cuda.is_available():
+            raise CoFusionError("no GPU visible: the Co-Fusion hot path has no CPU fallback")
+        self.lib = _libmod.load_host()
+        self.abi = _libmod.load()
+        cfg = Config()
+        self.lib.cofusion_default_config(C.byref(cfg))
+        cfg.width, cfg.height, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.device = width, height, fx, fy, cx, cy, device
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown CoFusion option {k}")
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.width, self.height = width, height
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.h = C.c_void_p()
+        self._check(self.lib.cofusion_create(C.byref(cfg), C.byref(self.h)))
+        self._check(self.lib.cofusion_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise CoFusionError(f"cofusion error {rc}: {self.lib.cofusion_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cofusion_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_crf(self, unary_weight_error=75.0, unary_k_error=0.0375, threshold_new=5.5, weight_appearance=7.0, weight_smoothness=2.0,
+                sigma_rgb=10.0, sigma_depth=0.9, sigma_pos=1.8, min_rel_size_new=0.015, max_rel_size_new=0.4, iterations=10):
+        f = C.c_float
+        self._check(self.lib.cofusion_set_crf(self.h, f(unary_weight_error), f(unary_k_error), f(threshold_new), f(weight_appearance),
+                                              f(weight_smoothness), f(sigma_rgb), f(sigma_depth), f(sigma_pos), f(min_rel_size_new),
+                                              f(max_rel_size_new), C.c_uint(iterations)))
+
+    def process_frame(self, depth, rgb, mask=None, in_pose=None, timestamp=0):
+        """Host numpy inputs: depth f32 [H,W] metres, rgb u8 [H,W,3], optional GT mask u8 [H,W]."""
+        d = np.ascontiguousarray(depth, np.float32); c = np.ascontiguousarray(rgb, np.uint8)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        p = None if in_pose is None else np.ascontiguousarray(in_pose, np.float32).reshape(16)
+        self._check(self.lib.cofusion_process_frame(self.h, C.c_int64(timestamp), c.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                                    None if m is None else m.ctypes.data_as(C.c_void_p),
+                                                    None if p is None else p.ctypes.data_as(C.c_void_p)))
+
+    def process_frame_device(self, depth_t, rgba_t, in_pose=None, timestamp=0):
+        """Frame already resident in HBM: torch CUDA tensors depth f32 [H,W], rgba u8 [H,W,4]."""
+        p = None if in_pose is None else np.ascontiguousarray(in_pose, np.float32).reshape(16)
+        self._check(self.lib.cofusion_process_frame_device(self.h, C.c_int64(timestamp), C.c_void_p(depth_t.data_ptr()),
+                                                           C.c_void_p(rgba_t.data_ptr()),
+                                                           None if p is None else p.ctypes.data_as(C.c_void_p)))
+
+    @property
+    def num_models(self):
+        return self.lib.cofusion_num_models(self.h)
+
+    @property
+    def tick(self):
+        return self.lib.cofusion_tick(self.h)
+
+    def model_info(self, index):
+        mid = C.c_uint(); cnt = C.c_uint(); conf = C.c_float(); pose = (C.c_float * 16)()
+        self._check(self.lib.cofusion_model_info(self.h, index, C.byref(mid), C.byref(cnt), pose, C.byref(conf)))
+        return dict(id=mid.value, count=cnt.value, pose=np.array(pose, np.float32).reshape(4, 4), conf_threshold=conf.value)
+
+    def model_icp_stats(self, index):
+        e = C.c_float(); c = C.c_float()
+        self._check(self.lib.cofusion_model_icp_stats(self.h, index, C.byref(e), C.byref(c)))
+        return e.value, c.value
+
+    def model_download(self, index):
+        n = self.model_info(index)["count"]
+        out = np.zeros((max(n, 1), 12), np.float32)
+        c = C.c_uint32()
+        self._check(self.lib.cofusion_model_download(self.h, index, out.ctypes.data_as(C.c_void_p), n, C.byref(c)))
+        return out[:n]
+
+    def mask(self):
+        ptr = self.lib.cofusion_mask_device(self.h)
+        host = np.empty(self.width * self.height, np.uint8)
+        ctx = C.c_void_p(self.lib.cofusion_context(self.h))
+        rc = self.abi.cf_memcpy_d2h(ctx, host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_uint64(host.size))
+        if rc != 0:
+            raise CoFusionError("mask readback failed")
+        return host.reshape(self.height, self.width)
+
+    # profiling hooks of the underlying C-ABI context
+    def _ctx(self):
+        return C.c_void_p(self.lib.cofusion_context(self.h))
+
+    def set_icp_launch(self, threads, ppt):
+        assert self.abi.cf_set_icp_launch(self._ctx(), threads, ppt) == 0
+
+    def profile_enable(self, on=True):
+        assert self.abi.cf_profile_enable(self._ctx(), int(on)) == 0
+
+    def profile_read(self, reset=True):
+        p = Profile()
+        assert self.abi.cf_profile_read(self._ctx(), C.byref(p), int(reset)) == 0
+        return p

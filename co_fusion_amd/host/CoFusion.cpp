@@ -1,0 +1,689 @@
+// CoFusion.cpp -- host logic of the facade (see CoFusion.h).  Restates Core/CoFusion.cpp:171-644,
+// Core/Model/Model.cpp:319-406 and Core/Segmentation/Segmentation.cpp:59-706 on top of the C-ABI.
+// Compiled with -ffp-contract=off: the host arithmetic here is mirrored by the CPU oracle.
+#include "CoFusion.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+namespace cofusion {
+
+static void check(cf_ctx* ctx, int rc, const char* what)
+{
+    if (rc != CF_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + (ctx ? cf_last_error(ctx) : ""));
+}
+
+// ------------------------------------------------------------------------------- Mat4f ----
+Mat4f Mat4f::identity()
+{
+    Mat4f r;
+    for (int i = 0; i < 16; i++) r.m[i] = (i % 5 == 0) ? 1.f : 0.f;
+    return r;
+}
+Mat4f Mat4f::inverse() const
+{
+    const float* a = m;
+    Mat4f r;
+    const float c00 = a[5] * a[10] - a[6] * a[9];
+    const float c01 = a[6] * a[8] - a[4] * a[10];
+    const float c02 = a[4] * a[9] - a[5] * a[8];
+    const float det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    const float id = 1.0f / det;
+    float Li[9];
+    Li[0] = c00 * id; Li[1] = (a[2] * a[9] - a[1] * a[10]) * id; Li[2] = (a[1] * a[6] - a[2] * a[5]) * id;
+    Li[3] = c01 * id; Li[4] = (a[0] * a[10] - a[2] * a[8]) * id; Li[5] = (a[2] * a[4] - a[0] * a[6]) * id;
+    Li[6] = c02 * id; Li[7] = (a[1] * a[8] - a[0] * a[9]) * id; Li[8] = (a[0] * a[5] - a[1] * a[4]) * id;
+    for (int i = 0; i < 3; i++) {
+        r.m[i * 4 + 0] = Li[i * 3 + 0]; r.m[i * 4 + 1] = Li[i * 3 + 1]; r.m[i * 4 + 2] = Li[i * 3 + 2];
+        r.m[i * 4 + 3] = -(Li[i * 3 + 0] * a[3] + Li[i * 3 + 1] * a[7] + Li[i * 3 + 2] * a[11]);
+    }
+    r.m[12] = 0; r.m[13] = 0; r.m[14] = 0; r.m[15] = 1;
+    return r;
+}
+Mat4f Mat4f::operator*(const Mat4f& o) const
+{
+    Mat4f r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float s = 0;
+            for (int k = 0; k < 4; k++) s += m[i * 4 + k] * o.m[k * 4 + j];
+            r.m[i * 4 + j] = s;
+        }
+    return r;
+}
+
+// ------------------------------------------------------------------------------- Model ----
+Model::Model(cf_ctx* c, unsigned char id_, float confidenceThresh, bool enableFillIn, int maxSurfels, float maxDepth_)
+    : ctx(c), pose(Mat4f::identity()), lastPose(Mat4f::identity()), confidenceThreshold(confidenceThresh), maxDepth(maxDepth_), id(id_),
+      fillIn(enableFillIn)
+{
+    check(ctx, cf_model_create(ctx, maxSurfels, &model), "cf_model_create");
+    check(ctx, cf_odom_create(ctx, &odom), "cf_odom_create");
+    // icpError texture (Model.cpp:112-117), f32 [H*W]; zero-initialised like the reference's upload (GPUTexture.cpp:48-53)
+    void* p = nullptr;
+    uint64_t bytes = 0;
+    void* indexMap = nullptr;
+    check(ctx, cf_model_buffer(model, 0, &indexMap, &bytes), "cf_model_buffer");  // the u32 index map has the same N*4 bytes
+    check(ctx, cf_malloc(ctx, bytes, &p), "cf_malloc");
+    icpError = static_cast<float*>(p);
+}
+Model::~Model()
+{
+    if (icpError) cf_free(ctx, icpError);
+    cf_odom_destroy(odom);
+    cf_model_destroy(model);
+}
+unsigned Model::lastCount() const
+{
+    uint32_t c = 0;
+    cf_model_count(model, &c);
+    return c;
+}
+void Model::initialise(const uint8_t* rgba, const float* depthRaw, const float* depthFiltered, int time, float maxD)
+{
+    check(ctx, cf_model_initialise(model, rgba, depthRaw, depthFiltered, time, maxD), "cf_model_initialise");
+}
+static const void* mbuf(cf_ctx* ctx, cf_model* m, int which)
+{
+    void* p = nullptr;
+    check(ctx, cf_model_buffer(m, which, &p, nullptr), "cf_model_buffer");
+    return p;
+}
+const float* Model::vertexConfProjection() const { return static_cast<const float*>(mbuf(ctx, model, 5)); }
+
+void Model::initICP(bool doFillIn, bool frameToFrameRGB, const float* const depthPyr[3], float depthCutoff, const uint8_t* rgba,
+                    Model* frameOwner)
+{  // Model.cpp:350-367.  WARNING initICP* must be called before initRGB* (they share vmaps_tmp)
+    const float* v; const float* n; const uint8_t* img;
+    if (doFillIn) {
+        v = static_cast<const float*>(mbuf(ctx, model, 8)); n = static_cast<const float*>(mbuf(ctx, model, 9));
+        img = static_cast<const uint8_t*>(mbuf(ctx, model, 10));
+    } else {
+        v = static_cast<const float*>(mbuf(ctx, model, 5)); n = static_cast<const float*>(mbuf(ctx, model, 6));
+        img = static_cast<const uint8_t*>(mbuf(ctx, model, (frameToFrameRGB && allowsFillIn()) ? 10 : 4));
+    }
+    check(ctx, cf_odom_init_icp_model(odom, v, n, pose.m), "initICPModel");
+    check(ctx, cf_odom_init_rgb_model(odom, img), "initRGBModel");
+    if (frameOwner == this) {
+        // the current-frame vertex/normal pyramids do not depend on the model (the mask test is commented out
+        // in createVMap, cudafuncs.cu:119): computed once, shared with every other model of this frame
+        check(ctx, cf_odom_init_icp(odom, depthPyr, depthCutoff), "initICP");
+    } else {
+        const float* vm[3]; const float* nm[3];
+        for (int l = 0; l < 3; l++) {
+            void* p = nullptr;
+            check(ctx, cf_odom_buffer(frameOwner->odom, 0, l, &p, nullptr), "cf_odom_buffer"); vm[l] = static_cast<const float*>(p);
+            check(ctx, cf_odom_buffer(frameOwner->odom, 1, l, &p, nullptr), "cf_odom_buffer"); nm[l] = static_cast<const float*>(p);
+        }
+        check(ctx, cf_odom_bind_frame_maps(odom, vm, nm), "bind_frame_maps");
+    }
+    check(ctx, cf_odom_init_rgb(odom, rgba), "initRGB");
+}
+float Model::computeFusionWeight(float weightMultiplier) const { return cf_fusion_weight(pose.m, lastPose.m, weightMultiplier); }
+
+void Model::fuse(int time, const uint8_t* rgba, const uint8_t* mask, const float* depthRaw, const float* depthFiltered, float depthCutoff,
+                 float weightMultiplier)
+{
+    const float md = depthCutoff < maxDepth ? depthCutoff : maxDepth;  // std::min(depthCutoff, maxDepth), Model.cpp:443
+    check(ctx, cf_model_fuse(model, pose.m, time, rgba, mask, depthRaw, depthFiltered, md, computeFusionWeight(weightMultiplier), (int)id),
+          "cf_model_fuse");
+}
+void Model::clean(int time, int timeDelta, float /*depthCutoff*/, const float* depthFiltered, const uint8_t* mask, float outlierCoeff)
+{
+    uint32_t c = 0;
+    check(ctx, cf_model_clean(model, pose.m, time, confidenceThreshold, outlierCoeff, timeDelta, depthFiltered, mask, (int)id, &c), "cf_model_clean");
+}
+void Model::predictIndices(int time, float depthCutoff, int timeDelta)
+{
+    check(ctx, cf_model_predict_indices(model, pose.m, time, depthCutoff, timeDelta), "predictIndices");
+}
+void Model::combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta)
+{
+    check(ctx, cf_model_combined_predict(model, pose.m, depthCutoff, confidenceThreshold, time, maxTime, timeDelta), "combinedPredict");
+}
+void Model::performFillIn(const uint8_t* rgba, const float* depthFiltered, bool frameToFrameRGB, bool lost)
+{
+    if (fillIn) check(ctx, cf_model_perform_fill_in(model, rgba, depthFiltered, lost ? 1 : 0, (lost || frameToFrameRGB) ? 1 : 0), "performFillIn");
+}
+bool Model::requiresFillIn(float ratio)
+{
+    if (!allowsFillIn()) return false;
+    int out = 0;
+    check(ctx, cf_model_requires_fill_in(model, ratio, &out), "requiresFillIn");
+    return out != 0;
+}
+std::vector<float> Model::downloadMap() const
+{
+    const unsigned n = lastCount();
+    std::vector<float> out((size_t)n * 12);
+    uint32_t c = 0;
+    check(ctx, cf_model_download_map(model, out.data(), n, &c), "downloadMap");
+    return out;
+}
+
+// ------------------------------------------------------------------------ Segmentation ----
+static const int SPIX = 16;
+
+Segmentation::Segmentation(cf_ctx* c, int w, int h) : ctx(c), width(w), height(h)
+{
+    check(ctx, cf_seg_create(ctx, &seg), "cf_seg_create");
+    memset(gtMapping, 0, sizeof(gtMapping));
+}
+Segmentation::~Segmentation() { cf_seg_destroy(seg); }
+
+SegmentationResult Segmentation::performSegmentation(ModelList& models, const FrameData& frame, const float* depth_dev, const uint8_t* rgba_dev,
+                                                     const uint8_t* rgba_first_rows, unsigned char nextModelID, bool allowNew,
+                                                     uint8_t* full_dev)
+{
+    if (frame.mask) return performSegmentationGT(models, frame, nextModelID, allowNew, full_dev);
+    return performSegmentationCRF(models, depth_dev, rgba_dev, rgba_first_rows, nextModelID, allowNew, full_dev);
+}
+
+namespace {
+struct CompData { unsigned char label; int top, right, bottom, left, size; };
+
+// ConnectedLabels.hpp:50-172
+int connectedLabels(const uint8_t* in, int cols, int rows, std::vector<int>& comp, std::vector<CompData>& stats)
+{
+    std::vector<int> roots;
+    auto newComponent = [&roots]() { int r = (int)roots.size(); roots.push_back(r); return r; };
+    auto findRoot = [&roots](int i) { while (i != roots[i]) i = roots[i]; return i; };
+    comp.assign((size_t)cols * rows, 0);
+    comp[0] = newComponent();
+    for (int c = 1; c < cols; c++) comp[c] = (in[c] == in[c - 1]) ? comp[c - 1] : newComponent();
+    for (int r = 1; r < rows; r++) {
+        const uint8_t *row = in + (size_t)r * cols, *last = in + (size_t)(r - 1) * cols;
+        int *cr = comp.data() + (size_t)r * cols, *lc = comp.data() + (size_t)(r - 1) * cols;
+        cr[0] = (row[0] == last[0]) ? lc[0] : newComponent();
+        for (int c = 1; c < cols; c++) {
+            if (row[c] == row[c - 1]) {
+                const int cLeft = cr[c - 1], cTop = lc[c];
+                if (row[c] == last[c] && cLeft != cTop) {
+                    const int r1 = findRoot(cTop), r2 = findRoot(cLeft);
+                    if (r1 < r2) { roots[r2] = r1; cr[c] = r1; } else { roots[r1] = r2; cr[c] = r2; }
+                } else cr[c] = cLeft;
+            } else if (row[c] == last[c]) cr[c] = lc[c];
+            else cr[c] = newComponent();
+        }
+    }
+    std::vector<int> mapping(roots.size());
+    int rootCnt = 0;
+    for (int id = 0; id < (int)roots.size(); id++) {
+        const int root = findRoot(id);
+        if (root == id) mapping[root] = rootCnt++;
+        else roots[id] = root;
+    }
+    for (auto& c : roots) c = mapping[c];
+    stats.assign(rootCnt, CompData{0, 2147483647, 0, 0, 2147483647, 0});
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            const int c = roots[comp[(size_t)y * cols + x]];
+            comp[(size_t)y * cols + x] = c;
+            CompData& d = stats[c];
+            d.size++; d.label = in[(size_t)y * cols + x];
+            if (y < d.top) d.top = y;
+            if (y > d.bottom) d.bottom = y;
+            if (x < d.left) d.left = x;
+            if (x > d.right) d.right = x;
+        }
+    return rootCnt;
+}
+
+// Slic::downsample<float> normalisation incl. the empty-superpixel fallback (Slic.h:63-76, 192-206)
+void finishMean(const int64_t* sumq, const uint32_t* cntOwn, const uint32_t* spixelCounts, const int32_t* resample, int K, float* out)
+{
+    for (int k = 0; k < K; k++) out[k] = (float)std::ldexp((double)sumq[k], -32);
+    for (int k = 0; k < K; k++) {
+        int cnt = (int)cntOwn[k], read = k;
+        if (cnt == 0) { read = resample[k]; cnt = (int)spixelCounts[read]; }
+        out[k] = out[read] / (float)cnt;
+    }
+}
+}  // namespace
+
+SegmentationResult Segmentation::performSegmentationCRF(ModelList& models, const float* depth_dev, const uint8_t* rgba_dev,
+                                                        const uint8_t* rgba_first_rows, unsigned char nextModelID, bool allowNew,
+                                                        uint8_t* full_dev)
+{
+    SegmentationResult result;
+    const int n_models = (int)models.size();
+    const int numLabels = allowNew ? n_models + 1 : n_models;
+    const float MAX_DEPTH = 100;
+    const int gx = width / SPIX, gy = height / SPIX, K = gx * gy;
+
+    check(ctx, cf_seg_slic(seg, rgba_dev), "cf_seg_slic");
+    std::vector<uint32_t> spc(K), dcnt(K);
+    std::vector<int64_t> dsum(K), icpSum((size_t)K * n_models), confSum((size_t)K * n_models);
+    std::vector<int32_t> resample(K);
+    std::vector<const float*> icpPtr(n_models), vcPtr(n_models);
+    {
+        int m = 0;
+        for (auto& mdl : models) { icpPtr[m] = mdl->icpErrorSurface(); vcPtr[m] = mdl->vertexConfProjection(); m++; }
+    }
+    check(ctx, cf_seg_accumulate(seg, depth_dev, n_models, icpPtr.data(), vcPtr.data(), spc.data(), dcnt.data(), dsum.data(), icpSum.data(),
+                                 confSum.data(), resample.data()),
+          "cf_seg_accumulate");
+    std::vector<float> lowDepth(K);
+    finishMean(dsum.data(), dcnt.data(), spc.data(), resample.data(), K, lowDepth.data());
+    float depthMin = 3.402823466e+38f, depthMax = 0;
+    for (int i = 0; i < K; i++) {
+        const float d = lowDepth[i];
+        if (d > MAX_DEPTH || d < 0 || !std::isfinite(d)) continue;
+        if (depthMax < d) depthMax = d;
+        if (depthMin > d) depthMin = d;
+    }
+    result.depthRange = depthMax - depthMin;
+    const float depthRange = result.depthRange;
+
+    std::vector<std::vector<float>> lowICP(n_models, std::vector<float>(K)), lowConf(n_models, std::vector<float>(K));
+    int modelIdToIndex[256];
+    for (int i = 0; i < 256; i++) modelIdToIndex[i] = 0;
+    {
+        int m = 0;
+        for (auto& mdl : models) {
+            finishMean(icpSum.data() + (size_t)m * K, spc.data(), spc.data(), resample.data(), K, lowICP[m].data());
+            finishMean(confSum.data() + (size_t)m * K, spc.data(), spc.data(), resample.data(), K, lowConf[m].data());
+            SegmentationResult::ModelData md;
+            md.id = mdl->getID(); md.modelIndex = m;
+            modelIdToIndex[md.id & 255] = m;
+            float avg = 0;
+            for (int j = 0; j < K; j++) {
+                float& c = lowConf[m][j];
+                if (!std::isfinite(c)) { c = 0; continue; }
+                avg += c;
+            }
+            md.avgConfidence = avg / (float)K;
+            result.modelData.push_back(md);
+            m++;
+        }
+    }
+    if (allowNew) {
+        modelIdToIndex[nextModelID] = n_models;
+        SegmentationResult::ModelData md;
+        md.id = nextModelID; md.modelIndex = -1;
+        result.modelData.push_back(md);
+    }
+    int n_md = (int)result.modelData.size();
+
+    const int L = numLabels;
+    std::vector<float> unary((size_t)K * L);
+    for (int k = 0; k < K; k++) {  // Segmentation.cpp:237-298
+        if ((double)lowConf[0][k] < 0.3) lowICP[0][k] = (float)((double)depthRange * 0.01);
+        for (int i = 1; i < n_models; i++)
+            if ((double)lowConf[i][k] <= 0.4) lowICP[i][k] = depthRange * unaryKError;
+        float lowestError = lowICP[0][k] / depthRange;
+        for (int i = 0; i < n_models; i++) {
+            float error = lowICP[i][k];
+            error /= depthRange;
+            if (error < lowestError) lowestError = error;
+            unary[(size_t)k * L + i] = unaryWeightError * error;
+        }
+        if (allowNew) unary[(size_t)k * L + n_models] = std::fmax(unaryThresholdNew - unaryWeightError * lowestError, 0.01f);
+    }
+    std::vector<float> f1((size_t)K * 2), f2((size_t)K * 6);
+    for (int j = 0; j < gy; j++)
+        for (int i = 0; i < gx; i++) {
+            const int index = j * gx + i;
+            f1[index * 2 + 0] = (float)i / 2.0f; f1[index * 2 + 1] = (float)j / 2.0f;
+            f2[index * 6 + 0] = (float)i * scaleFeaturesPos;
+            f2[index * 6 + 1] = (float)j * scaleFeaturesPos;
+            // colour features index the FULL-resolution image with the LOW-resolution index (Segmentation.cpp:445-447)
+            f2[index * 6 + 2] = (float)rgba_first_rows[(size_t)index * 4 + 0] * scaleFeaturesRGB;
+            f2[index * 6 + 3] = (float)rgba_first_rows[(size_t)index * 4 + 1] * scaleFeaturesRGB;
+            f2[index * 6 + 4] = (float)rgba_first_rows[(size_t)index * 4 + 2] * scaleFeaturesRGB;
+            f2[index * 6 + 5] = std::fmin(lowDepth[index] * scaleFeaturesDepth, 100.0f);
+        }
+    for (auto& u : unary) if (u <= 1e-5f) u = 1e-5f;
+    std::vector<float> Q((size_t)K * L);
+    check(ctx, cf_seg_crf(seg, unary.data(), L, f1.data(), f2.data(), weightSmoothness, weightAppearance, (int)crfIterations, Q.data()), "cf_seg_crf");
+    std::vector<uint8_t> map(K);
+    for (int i = 0; i < K; i++) {
+        int m = 0; float best = Q[(size_t)i * L];
+        for (int l = 1; l < L; l++) if (Q[(size_t)i * L + l] > best) { best = Q[(size_t)i * L + l]; m = l; }
+        map[i] = (uint8_t)result.modelData[m].id;
+    }
+
+    std::vector<int> comp; std::vector<CompData> cc;
+    const int ncc = connectedLabels(map.data(), gx, gy, comp, cc);
+    {  // onlyKeepLargest (Segmentation.cpp:496-517): every label but the smallest key keeps its largest component
+        int minLabel = 256;
+        for (int i = 0; i < ncc; i++) if (cc[i].label < minLabel) minLabel = cc[i].label;
+        for (int lab2 = 0; lab2 < 256; lab2++) {
+            if (lab2 == minLabel) continue;
+            int keep = -1;
+            for (int i = 0; i < ncc; i++) {
+                if (cc[i].label != lab2) continue;
+                if (keep < 0) { keep = i; continue; }
+                if (cc[keep].size < cc[i].size) { cc[keep].label = 255; keep = i; } else cc[i].label = 255;
+            }
+        }
+    }
+    if (allowNew) {  // :521-530
+        const int minSize = (int)((float)K * minRelSizeNew), maxSize = (int)((float)K * maxRelSizeNew);
+        for (int i = 0; i < ncc; i++)
+            if (cc[i].label == nextModelID && (cc[i].size < minSize || cc[i].size > maxSize)) cc[i].label = 255;
+    }
+    for (auto& md : result.modelData) {  // :532-547
+        for (int i = 0; i < ncc; i++) {
+            if (cc[i].label != (md.id & 255)) continue;
+            if (cc[i].left < md.left) md.left = cc[i].left;
+            if (cc[i].top < md.top) md.top = cc[i].top;
+            if (cc[i].right > md.right) md.right = cc[i].right;
+            if (cc[i].bottom > md.bottom) md.bottom = cc[i].bottom;
+        }
+        md.left = (unsigned short)(int)(md.left * SPIX + SPIX * 0.5); md.top = (unsigned short)(int)(md.top * SPIX + SPIX * 0.5);
+        md.right = (unsigned short)(int)(md.right * SPIX + SPIX * 0.5); md.bottom = (unsigned short)(int)(md.bottom * SPIX + SPIX * 0.5);
+    }
+    {
+        const unsigned borderSize = 20, fullHeight = (unsigned)height, fullWidth = (unsigned)width;  // :549-563
+        for (auto& md : result.modelData) {
+            if (md.id == 0) continue;
+            const unsigned top = (unsigned)md.top, bottom = (unsigned)md.bottom, left = (unsigned)md.left, right = (unsigned)md.right;
+            if ((top < borderSize && bottom < borderSize) || (left < borderSize && right < borderSize) ||
+                (top > fullHeight - borderSize && bottom > fullHeight - borderSize) || (left > fullWidth - borderSize && right > fullWidth - borderSize))
+                for (int i = 0; i < ncc; i++) if (cc[i].label == (md.id & 255)) cc[i].label = 255;
+        }
+    }
+    for (int i = 0; i < K; i++) map[i] = cc[comp[i]].label;
+    {  // depth statistics with one trimming pass (:570-621)
+        std::vector<float> sumsDepth(n_md, 0.f), sumsDev(n_md, 0.f);
+        std::vector<unsigned> cnts(n_md, 0);
+        for (int i = 0; i < K; i++) { if (map[i] == 255) continue; const int ix = modelIdToIndex[map[i]]; sumsDepth[ix] += lowDepth[i]; cnts[ix]++; }
+        for (int m = 0; m < n_md; m++) result.modelData[m].depthMean = cnts[m] ? sumsDepth[m] / (float)cnts[m] : 0;
+        for (int i = 0; i < K; i++) { if (map[i] == 255) continue; const int ix = modelIdToIndex[map[i]]; sumsDev[ix] += std::fabs(result.modelData[ix].depthMean - lowDepth[i]); }
+        for (int m = 0; m < n_md; m++) result.modelData[m].depthStd = cnts[m] ? sumsDev[m] / (float)cnts[m] : 0;
+        for (int i = 0; i < K; i++) {
+            if (map[i] == 255) continue;
+            const int ix = modelIdToIndex[map[i]];
+            if (ix != 0) {
+                const float d = lowDepth[i];
+                if ((double)d > 1.1 * (double)result.modelData[ix].depthStd + (double)result.modelData[ix].depthMean) {
+                    sumsDepth[ix] -= d; sumsDev[ix] -= std::fabs(result.modelData[ix].depthMean - d); cnts[ix]--;
+                }
+            }
+        }
+        for (int m = 0; m < n_md; m++) {
+            result.modelData[m].depthMean = cnts[m] ? sumsDepth[m] / (float)cnts[m] : 0;
+            result.modelData[m].depthStd = cnts[m] ? sumsDev[m] / (float)cnts[m] : 0;
+        }
+    }
+    for (int k = 0; k < K; k++) { if (map[k] == 255) continue; result.modelData[modelIdToIndex[map[k]]].superPixelCount++; }
+    if (allowNew) {
+        if (result.modelData.back().superPixelCount > 0) result.hasNewLabel = true;
+        else result.modelData.pop_back();
+    }
+    check(ctx, cf_seg_upsample(seg, map.data(), full_dev), "cf_seg_upsample");
+    result.lowMap = map;
+    return result;
+}
+
+SegmentationResult Segmentation::performSegmentationGT(ModelList& models, const FrameData& frame, unsigned char nextModelID, bool allowNew,
+                                                       uint8_t* full_dev)
+{  // Segmentation.cpp:59-119 (host O(N); frame.mask / frame.depth are host buffers)
+    SegmentationResult result;
+    const size_t N = (size_t)width * height;
+    std::vector<uint8_t> full(N, 0);
+    unsigned outIds[256];
+    int modelIdToIndex[256];
+    memset(outIds, 0, sizeof(outIds));
+    for (int i = 0; i < 256; i++) modelIdToIndex[i] = 0;
+    int mIndex = 0;
+    for (auto& m : models) modelIdToIndex[m->getID() & 255] = mIndex++;
+    modelIdToIndex[nextModelID] = mIndex;
+    for (size_t i = 0; i < N; i++) {
+        const uint8_t vIn = frame.mask[i];
+        if (vIn) {
+            if (gtMapping[vIn] != 0) { full[i] = gtMapping[vIn]; outIds[full[i]]++; }
+            else if (allowNew && !result.hasNewLabel) { full[i] = nextModelID; gtMapping[vIn] = nextModelID; result.hasNewLabel = true; outIds[full[i]]++; }
+        } else outIds[0]++;
+    }
+    int idx = 0;
+    for (auto& m : models) {
+        SegmentationResult::ModelData md;
+        md.id = m->getID(); md.modelIndex = idx++; md.superPixelCount = outIds[m->getID() & 255] / (16 * 16); md.avgConfidence = 0.4f;
+        result.modelData.push_back(md);
+    }
+    if (result.hasNewLabel) {
+        SegmentationResult::ModelData md;
+        md.id = nextModelID; md.modelIndex = -1; md.avgConfidence = 0.4f;
+        const float c = (float)(outIds[nextModelID] / (16 * 16));
+        md.superPixelCount = (unsigned)(c > 1.0f ? c : 1.0f);
+        result.modelData.push_back(md);
+    }
+    const int n_md = (int)result.modelData.size();
+    std::vector<unsigned> cnts(n_md + 1, 0);
+    for (size_t i = 0; i < N; i++) { const int ix = modelIdToIndex[full[i]]; result.modelData[ix].depthMean += frame.depth[i]; cnts[ix]++; }
+    for (int m = 0; m < n_md; m++) result.modelData[m].depthMean /= cnts[m] ? (float)cnts[m] : 1.0f;
+    for (size_t i = 0; i < N; i++) { const int ix = modelIdToIndex[full[i]]; result.modelData[ix].depthStd += std::fabs(result.modelData[ix].depthMean - frame.depth[i]); }
+    for (int m = 0; m < n_md; m++) result.modelData[m].depthStd /= cnts[m] ? (float)cnts[m] : 1.0f;
+    check(ctx, cf_memcpy_h2d(ctx, full_dev, full.data(), N), "mask upload");
+    return result;
+}
+
+// ----------------------------------------------------------------------------- CoFusion ----
+static cf_ctx* make_ctx(const CoFusion::Config& c)
+{
+    cf_config cc{};
+    cc.width = c.width; cc.height = c.height; cc.fx = c.fx; cc.fy = c.fy; cc.cx = c.cx; cc.cy = c.cy; cc.device = c.device;
+    cc.max_models = c.maxModels; cc.max_surfels = c.maxSurfels;
+    cf_ctx* ctx = nullptr;
+    const int rc = cf_create(&cc, &ctx);
+    if (rc != CF_OK) {
+        std::string msg = ctx ? cf_last_error(ctx) : "no HIP device (the Co-Fusion hot path has no CPU fallback)";
+        if (ctx) cf_destroy(ctx);
+        throw std::runtime_error("cf_create failed: " + msg);
+    }
+    return ctx;
+}
+
+CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
+{
+    labelGenerator.reset(new Segmentation(ctx, cfg.width, cfg.height));
+    const size_t N = (size_t)cfg.width * cfg.height;
+    void* p = nullptr;
+    check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); depth_dev = static_cast<float*>(p);
+    check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); depthFiltered_dev = static_cast<float*>(p);
+    check(ctx, cf_malloc(ctx, N, &p), "cf_malloc"); depthPyr1 = static_cast<float*>(p);
+    check(ctx, cf_malloc(ctx, N / 4, &p), "cf_malloc"); depthPyr2 = static_cast<float*>(p);
+    check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); rgba_dev = static_cast<uint8_t*>(p);
+    check(ctx, cf_malloc(ctx, N, &p), "cf_malloc"); mask_dev = static_cast<uint8_t*>(p);
+    rgbaHost.resize(N * 4);
+    globalModel = std::make_shared<Model>(ctx, getNextModelID(true), cfg.confGlobalInit, true, cfg.maxSurfels);
+    models.push_back(globalModel);
+}
+
+CoFusion::~CoFusion()
+{
+    models.clear(); inactiveModels.clear(); newModel.reset(); globalModel.reset();
+    cf_free(ctx, depth_dev); cf_free(ctx, depthFiltered_dev); cf_free(ctx, depthPyr1); cf_free(ctx, depthPyr2);
+    cf_free(ctx, rgba_dev); cf_free(ctx, mask_dev);
+    labelGenerator.reset();
+    cf_destroy(ctx);
+}
+
+unsigned char CoFusion::getNextModelID(bool assign)
+{  // CoFusion.cpp:628-644
+    unsigned char next = nextID;
+    if (assign) {
+        if (models.size() == 256) throw std::range_error("getNextModelID(): Maximum amount of models is already in use (256).");
+        while (true) {
+            nextID++;
+            bool isOccupied = false;
+            for (auto& m : models) if (nextID == m->getID()) isOccupied = true;
+            if (!isOccupied) break;
+        }
+    }
+    return next;
+}
+
+void CoFusion::spawnObjectModel()
+{  // CoFusion.cpp:588-598
+    newModel = std::make_shared<Model>(ctx, getNextModelID(true), cfg.confObjectInit, false, cfg.maxSurfels);
+    check(ctx, cf_odom_init_first_rgb(newModel->getFrameOdometry(), curRgba), "initFirstRGB");
+}
+void CoFusion::moveNewModelToList()
+{
+    if (newModel) { models.push_back(newModel); newModel.reset(); }
+}
+ModelList::iterator CoFusion::inactivateModel(ModelList::iterator it)
+{  // CoFusion.cpp:611-626
+    ModelPointer m = *it;
+    if (!enableSmartModelDelete || (m->lastCount() >= modelKeepMinSurfels && m->getConfidenceThreshold() > modelKeepConfThreshold))
+        inactiveModels.push_back(m);
+    return --models.erase(it);
+}
+
+void CoFusion::predict()
+{  // CoFusion.cpp:533-545
+    for (auto& model : models) {
+        model->combinedPredict(maxDepthProcessed, tick, tick, cfg.timeDelta);
+        model->performFillIn(curRgba, depthFiltered_dev, cfg.frameToFrameRGB, lost);
+    }
+}
+
+void CoFusion::trackModels(const float* const depthPyr[3])
+{  // CoFusion.cpp:213-217 + Model::performTracking (Model.cpp:369-389); all models advance in lock-step on the GPU
+    std::vector<Model*> ms;
+    for (auto& m : models) ms.push_back(m.get());
+    Model* owner = ms[0];
+    for (Model* m : ms) {
+        m->lastPose = m->pose;
+        m->initICP(m->requiresFillIn(), cfg.frameToFrameRGB, depthPyr, maxDepthProcessed, curRgba, owner);
+    }
+    cf_track_opts opts{};
+    opts.rgb_only = cfg.rgbOnly; opts.pyramid = cfg.pyramid; opts.fast_odom = cfg.fastOdom; opts.so3 = cfg.so3; opts.icp_weight = cfg.icpWeight;
+    const int B = 8;
+    for (size_t base = 0; base < ms.size(); base += B) {
+        const int n = (int)std::min<size_t>(B, ms.size() - base);
+        cf_odom* ods[B]; const float* poses[B]; float* errs[B];
+        for (int k = 0; k < n; k++) { ods[k] = ms[base + k]->odom; poses[k] = ms[base + k]->pose.m; errs[k] = ms[base + k]->icpError; }
+        check(ctx, cf_odom_track_batch_async(ctx, ods, n, poses, &opts, errs), "track_batch");
+        for (int k = 0; k < n; k++) {
+            Model* m = ms[base + k];
+            float t[3], R[9];
+            check(ctx, cf_odom_fetch_result(m->odom, t, R, &m->lastStats), "fetch_result");
+            for (int r = 0; r < 3; r++) { m->pose.m[r * 4 + 0] = R[r * 3 + 0]; m->pose.m[r * 4 + 1] = R[r * 3 + 1]; m->pose.m[r * 4 + 2] = R[r * 3 + 2]; m->pose.m[r * 4 + 3] = t[r]; }
+        }
+    }
+}
+
+bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float weightMultiplier, bool bootstrap)
+{
+    const size_t N = (size_t)cfg.width * cfg.height;
+    // upload (CoFusion.cpp:179-184); RGB -> RGBA like the GL_RGBA texture upload
+    if (frame.rgba_dev && frame.depth_dev) { curRgba = frame.rgba_dev; curDepth = frame.depth_dev; }
+    else {
+        for (size_t i = 0; i < N; i++) { rgbaHost[i * 4] = frame.rgb[i * 3]; rgbaHost[i * 4 + 1] = frame.rgb[i * 3 + 1]; rgbaHost[i * 4 + 2] = frame.rgb[i * 3 + 2]; rgbaHost[i * 4 + 3] = 255; }
+        check(ctx, cf_memcpy_h2d(ctx, rgba_dev, rgbaHost.data(), N * 4), "rgb upload");
+        check(ctx, cf_memcpy_h2d(ctx, depth_dev, frame.depth, N * 4), "depth upload");
+        curRgba = rgba_dev; curDepth = depth_dev;
+    }
+    check(ctx, cf_bilateral(ctx, curDepth, cfg.width, cfg.height, cfg.depthCutoff, depthFiltered_dev), "filterDepth");
+    if (!cfg.enableMultipleModels) {
+        std::vector<uint8_t> zeros(N, 0);
+        if (tick == 1) check(ctx, cf_memcpy_h2d(ctx, mask_dev, zeros.data(), N), "mask upload");  // stays all-zero afterwards
+    }
+
+    if (tick == 1) {
+        globalModel->initialise(curRgba, curDepth, depthFiltered_dev, tick, maxDepthProcessed);
+        check(ctx, cf_odom_init_first_rgb(globalModel->getFrameOdometry(), curRgba), "initFirstRGB");
+    } else {
+        bool trackingOk = true;
+        if (bootstrap || !inPose) {
+            check(ctx, cf_depth_pyramid(ctx, depthFiltered_dev, cfg.width, cfg.height, depthPyr1, depthPyr2), "generateCUDATextures");
+            const float* pyr[3] = {depthFiltered_dev, depthPyr1, depthPyr2};
+            trackModels(pyr);
+            if (bootstrap) globalModel->overridePose(globalModel->getPose() * (*inPose));
+
+            if (cfg.enableMultipleModels) {
+                auto getMaxDepth = [](const SegmentationResult::ModelData& d) -> float { return d.depthMean + d.depthStd * 1.2; };
+                if (spawnOffset < cfg.modelSpawnOffset) spawnOffset++;
+                // the colour features of the CRF read the first K pixels of the full-resolution image
+                const int K = (cfg.width / 16) * (cfg.height / 16);
+                std::vector<uint8_t> firstRows((size_t)K * 4);
+                if (frame.rgba_dev) check(ctx, cf_memcpy_d2h(ctx, firstRows.data(), curRgba, (size_t)K * 4), "rgb readback");
+                else memcpy(firstRows.data(), rgbaHost.data(), (size_t)K * 4);
+                SegmentationResult seg = labelGenerator->performSegmentation(models, frame, curDepth, curRgba, firstRows.data(), getNextModelID(),
+                                                                            spawnOffset >= cfg.modelSpawnOffset, mask_dev);
+                if (seg.hasNewLabel) {
+                    spawnObjectModel();
+                    spawnOffset = 0;
+                    newModel->setMaxDepth(getMaxDepth(seg.modelData.back()));
+                }
+                {
+                    auto it = models.begin();
+                    for (unsigned i = 1; i < models.size(); i++) (*++it)->setMaxDepth(getMaxDepth(seg.modelData[i]));
+                }
+                if (seg.hasNewLabel) {
+                    newModel->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
+                    newModel->fuse(tick, curRgba, mask_dev, curDepth, depthFiltered_dev, maxDepthProcessed, 100);
+                    newModel->clean(tick, cfg.timeDelta, maxDepthProcessed, depthFiltered_dev, mask_dev, cfg.outlierCoefficient);
+                    moveNewModelToList();
+                }
+                for (auto& md : seg.modelData) {  // CoFusion.cpp:284-291
+                    if (md.superPixelCount <= 0) {
+                        auto it = models.begin();
+                        std::advance(it, md.modelIndex);
+                        if ((*it)->incrementUnseenCount() > 0 && md.id != 0) {
+                            inactivateModel(it);
+                            // later entries referred to list positions that have now shifted by one
+                            for (auto& o : seg.modelData) if (o.modelIndex > md.modelIndex) o.modelIndex--;
+                        }
+                    }
+                }
+                {
+                    auto it = models.begin();
+                    for (unsigned i = 1; i < models.size(); i++) {  // :294-298 (indices into modelData are NOT re-aligned, as in the reference)
+                        const float oldConf = (*++it)->getConfidenceThreshold();
+                        (*it)->setConfidenceThreshold(std::fmin(std::fmax(oldConf, seg.modelData[i].avgConfidence), 9.0f));
+                    }
+                }
+            }
+        } else {
+            globalModel->overridePose(*inPose);
+        }
+        predict();
+        if (!cfg.rgbOnly && trackingOk && !lost) {
+            for (auto& model : models) model->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
+            for (auto& model : models) model->fuse(tick, curRgba, mask_dev, curDepth, depthFiltered_dev, maxDepthProcessed, weightMultiplier);
+            for (auto& model : models) model->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
+            for (auto& model : models) model->clean(tick, cfg.timeDelta, maxDepthProcessed, depthFiltered_dev, mask_dev, cfg.outlierCoefficient);
+        }
+    }
+    predict();
+    if (!lost) tick++;
+    moveNewModelToList();
+
+    bool first = true;
+    for (auto& model : models) {  // pose log, CoFusion.cpp:502-520
+        const Mat4f p = first ? globalModel->getPose() : globalModel->getPose() * model->getPose().inverse();
+        Model::PoseLogItem item;
+        item.ts = frame.timestamp;
+        item.p[0] = p.m[3]; item.p[1] = p.m[7]; item.p[2] = p.m[11];
+        // quaternion of the rotation block (Eigen::Quaternionf(rotObject)), Shepperd's method
+        const float m00 = p.m[0], m11 = p.m[5], m22 = p.m[10];
+        float t = m00 + m11 + m22, qx, qy, qz, qw;
+        if (t > 0) { t = std::sqrt(t + 1.0f); qw = 0.5f * t; t = 0.5f / t; qx = (p.m[9] - p.m[6]) * t; qy = (p.m[2] - p.m[8]) * t; qz = (p.m[4] - p.m[1]) * t; }
+        else {
+            int i = 0;
+            if (m11 > m00) i = 1;
+            if (m22 > p.m[i * 5]) i = 2;
+            const int j = (i + 1) % 3, k = (j + 1) % 3;
+            t = std::sqrt(p.m[i * 5] - p.m[j * 5] - p.m[k * 5] + 1.0f);
+            float q[3];
+            q[i] = 0.5f * t; t = 0.5f / t;
+            qw = (p.m[k * 4 + j] - p.m[j * 4 + k]) * t;
+            q[j] = (p.m[j * 4 + i] + p.m[i * 4 + j]) * t;
+            q[k] = (p.m[k * 4 + i] + p.m[i * 4 + k]) * t;
+            qx = q[0]; qy = q[1]; qz = q[2];
+        }
+        item.p[3] = qx; item.p[4] = qy; item.p[5] = qz; item.p[6] = qw;
+        model->poseLog.push_back(item);
+        first = false;
+    }
+    return false;
+}
+
+}  // namespace cofusion

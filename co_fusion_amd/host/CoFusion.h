@@ -1,0 +1,200 @@
+// CoFusion.h -- host-side C++ facade with the reference's class/method names over the C-ABI
+// (include/cofusion_hip.h).  This is the layer a maintainer of martinruenz/co-fusion would keep:
+//   CoFusion  <- Core/CoFusion.h:44-391      (frame orchestrator, model list, spawn/deactivate)
+//   Model     <- Core/Model/Model.h:51-285   (per-model surfel map + tracker)
+//   Segmentation <- Core/Segmentation/Segmentation.h:30-140
+// Eigen/OpenCV/Pangolin types are replaced by plain structs: poses are ROW-major float[16] (Mat4f),
+// images are {pointer,width,height} views.  Only host logic lives here; every per-pixel / per-surfel
+// operation is a call into the HIP library.
+#pragma once
+
+#include <cstdint>
+#include <list>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/cofusion_hip.h"
+
+namespace cofusion {
+
+struct Mat4f {
+    float m[16];
+    static Mat4f identity();
+    Mat4f inverse() const;             // affine inverse, linear part by cofactors (f32)
+    Mat4f operator*(const Mat4f& o) const;
+};
+
+// Core/FrameData.h:25-42 (host views; rgb is 3 bytes/pixel R,G,B; depth metres f32; mask u8 or null)
+struct FrameData {
+    int64_t timestamp = 0;
+    const uint8_t* rgb = nullptr;
+    const float* depth = nullptr;
+    const uint8_t* mask = nullptr;
+    // optional: the same frame already resident in HBM (depth f32, rgba u8x4); skips the upload
+    const float* depth_dev = nullptr;
+    const uint8_t* rgba_dev = nullptr;
+};
+
+struct SegmentationResult {
+    struct ModelData {
+        unsigned id = 0;
+        int modelIndex = -1;  // position in the model list when the segmentation ran (-1: new label)
+        unsigned superPixelCount = 0;
+        float avgConfidence = 0, depthMean = 0, depthStd = 0;
+        int top = 65535, right = 0, bottom = 0, left = 65535;
+    };
+    bool hasNewLabel = false;
+    float depthRange = 0;
+    std::vector<ModelData> modelData;
+    std::vector<uint8_t> lowMap;  // 40x30 labels after component analysis (255 = rejected)
+};
+
+class CoFusion;
+
+class Model {
+  public:
+    Model(cf_ctx* ctx, unsigned char id, float confidenceThresh, bool enableFillIn, int maxSurfels,
+          float maxDepth = 3.402823466e+38f);
+    ~Model();
+    Model(const Model&) = delete;
+    Model& operator=(const Model&) = delete;
+
+    unsigned lastCount() const;
+    void initialise(const uint8_t* rgba, const float* depthRaw, const float* depthFiltered, int time, float maxDepth);
+    // Model::initICP (Model.cpp:350-367); frame-wide current maps are owned by `frameOdom` (model 0)
+    void initICP(bool doFillIn, bool frameToFrameRGB, const float* const depthPyr[3], float depthCutoff, const uint8_t* rgba,
+                 Model* frameOwner);
+    float computeFusionWeight(float weightMultiplier) const;
+    void fuse(int time, const uint8_t* rgba, const uint8_t* mask, const float* depthRaw, const float* depthFiltered, float depthCutoff,
+              float weightMultiplier);
+    void clean(int time, int timeDelta, float depthCutoff, const float* depthFiltered, const uint8_t* mask, float outlierCoeff);
+    void predictIndices(int time, float depthCutoff, int timeDelta);
+    void combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta);
+    void performFillIn(const uint8_t* rgba, const float* depthFiltered, bool frameToFrameRGB, bool lost);
+    bool requiresFillIn(float ratio = 0.75f);
+    bool allowsFillIn() const { return fillIn; }
+    std::vector<float> downloadMap() const;  // count x 12 floats
+
+    float getConfidenceThreshold() const { return confidenceThreshold; }
+    void setConfidenceThreshold(float v) { confidenceThreshold = v; }
+    void setMaxDepth(float d) { maxDepth = d; }
+    float getMaxDepth() const { return maxDepth; }
+    const Mat4f& getPose() const { return pose; }
+    const Mat4f& getLastPose() const { return lastPose; }
+    void overridePose(const Mat4f& p) { pose = p; lastPose = p; }
+    unsigned getID() const { return id; }
+    unsigned incrementUnseenCount() { if (unseenCount < 0xFFFFFFFFu) return ++unseenCount; return unseenCount; }
+    void resetUnseenCount() { unseenCount = 0; }
+    cf_odom* getFrameOdometry() { return odom; }
+    cf_model* handle() { return model; }
+    float* icpErrorSurface() { return icpError; }
+    const float* vertexConfProjection() const;
+    cf_track_stats lastStats{};
+
+    struct PoseLogItem { int64_t ts; float p[7]; };
+    std::vector<PoseLogItem> poseLog;
+
+  private:
+    friend class CoFusion;
+    cf_ctx* ctx;
+    cf_model* model = nullptr;
+    cf_odom* odom = nullptr;
+    float* icpError = nullptr;  // device f32 [H*W] (Model::icpError texture)
+    Mat4f pose, lastPose;
+    float confidenceThreshold;
+    float maxDepth;
+    unsigned id;
+    unsigned unseenCount = 0;
+    bool fillIn;
+};
+typedef std::shared_ptr<Model> ModelPointer;
+typedef std::list<ModelPointer> ModelList;
+
+class Segmentation {
+  public:
+    Segmentation(cf_ctx* ctx, int width, int height);
+    ~Segmentation();
+    Segmentation(const Segmentation&) = delete;
+    Segmentation& operator=(const Segmentation&) = delete;
+    // Segmentation::performSegmentation (Segmentation.cpp:59-119 GT branch, :124-706 CRF branch)
+    SegmentationResult performSegmentation(ModelList& models, const FrameData& frame, const float* depth_dev, const uint8_t* rgba_dev,
+                                           const uint8_t* rgba_host_first_rows, unsigned char nextModelID, bool allowNew,
+                                           uint8_t* fullSegmentation_dev);
+    // setters (Segmentation.h:100-120); defaults are the GUI values the reference applies every frame (GUI.h:206-227)
+    float unaryWeightError = 75.f, unaryKError = 0.0375f, unaryThresholdNew = 5.5f;
+    float weightAppearance = 7.f, weightSmoothness = 2.f;
+    float scaleFeaturesRGB = 1.0f / 10, scaleFeaturesDepth = 1.0f / 0.9f, scaleFeaturesPos = 1.0f / 1.8f;
+    float minRelSizeNew = 0.015f, maxRelSizeNew = 0.4f;
+    unsigned crfIterations = 10;
+
+  private:
+    SegmentationResult performSegmentationCRF(ModelList& models, const float* depth_dev, const uint8_t* rgba_dev,
+                                              const uint8_t* rgba_first_rows, unsigned char nextModelID, bool allowNew, uint8_t* full_dev);
+    SegmentationResult performSegmentationGT(ModelList& models, const FrameData& frame, unsigned char nextModelID, bool allowNew,
+                                             uint8_t* full_dev);
+    cf_ctx* ctx;
+    cf_segmenter* seg = nullptr;
+    int width, height;
+    uint8_t gtMapping[256];
+};
+
+class CoFusion {
+  public:
+    struct Config {
+        int width = 640, height = 480;
+        float fx = 528, fy = 528, cx = 320, cy = 240;
+        int device = 0;
+        int maxSurfels = 3072 * 3072;       // Model::MAX_VERTICES default (Model.cpp:92-98)
+        int maxModels = 16;
+        int timeDelta = 2147483647 / 2;     // openLoop (MainController.cpp:328)
+        float confGlobalInit = 10.0f, confObjectInit = 0.01f;  // MainController.cpp:174-175
+        float depthCutoff = 5.0f, icpWeight = 10.0f;           // GUI.h:211-212
+        float outlierCoefficient = 3.0f;                       // GUI.h:213
+        bool fastOdom = false, so3 = true, frameToFrameRGB = false, pyramid = true, rgbOnly = false;
+        unsigned modelSpawnOffset = 22;                        // GUI.h:219
+        bool enableMultipleModels = true;
+    };
+    explicit CoFusion(const Config& cfg);
+    ~CoFusion();
+
+    // CoFusion::processFrame (Core/CoFusion.cpp:171-524)
+    bool processFrame(const FrameData& frame, const Mat4f* inPose = nullptr, float weightMultiplier = 1.f, bool bootstrap = false);
+    void predict();                                  // CoFusion.cpp:533-545
+    ModelList& getModels() { return models; }
+    ModelPointer getBackgroundModel() { return globalModel; }
+    const Mat4f& getCurrPose() const { return globalModel->getPose(); }
+    int getTick() const { return tick; }
+    const uint8_t* maskDevice() const { return mask_dev; }
+    Segmentation& segmentation() { return *labelGenerator; }
+    cf_ctx* context() { return ctx; }
+    Config cfg;
+
+  private:
+    void spawnObjectModel();
+    void moveNewModelToList();
+    ModelList::iterator inactivateModel(ModelList::iterator it);
+    unsigned char getNextModelID(bool assign = false);
+    void trackModels(const float* const depthPyr[3]);
+
+    cf_ctx* ctx = nullptr;
+    ModelList models, inactiveModels;
+    ModelPointer newModel, globalModel;
+    unsigned char nextID = 0;
+    std::unique_ptr<Segmentation> labelGenerator;
+    int tick = 1;
+    float maxDepthProcessed = 20.0f;
+    unsigned spawnOffset = 0;
+    bool lost = false;
+    // device frame buffers (CoFusion::textures)
+    float *depth_dev = nullptr, *depthFiltered_dev = nullptr, *depthPyr1 = nullptr, *depthPyr2 = nullptr;
+    uint8_t *rgba_dev = nullptr, *mask_dev = nullptr;
+    std::vector<uint8_t> rgbaHost;
+    const float* curDepth = nullptr;   // device pointers of the frame being processed
+    const uint8_t* curRgba = nullptr;
+    unsigned modelKeepMinSurfels = 4000;
+    float modelKeepConfThreshold = 0.3f;
+    bool enableSmartModelDelete = true;
+};
+
+}  // namespace cofusion

@@ -1,0 +1,114 @@
+// cofusion_c.cpp -- flat C wrapper (include/cofusion.h) around the C++ facade.
+#include "../../include/cofusion.h"
+
+#include <exception>
+#include <iterator>
+#include <string>
+
+#include "CoFusion.h"
+
+using namespace cofusion;
+
+struct cofusion_handle { CoFusion* cf; };
+static thread_local std::string g_err;
+
+#define GUARD(expr)                                  \
+    try { expr; }                                    \
+    catch (const std::exception& e) { g_err = e.what(); return -1; } \
+    catch (...) { g_err = "unknown exception"; return -1; }
+
+extern "C" {
+
+void cofusion_default_config(cofusion_config* c)
+{
+    const CoFusion::Config d;
+    c->width = d.width; c->height = d.height; c->fx = d.fx; c->fy = d.fy; c->cx = d.cx; c->cy = d.cy; c->device = d.device;
+    c->max_surfels = d.maxSurfels; c->max_models = d.maxModels; c->conf_global_init = d.confGlobalInit;
+    c->conf_object_init = d.confObjectInit; c->depth_cutoff = d.depthCutoff; c->icp_weight = d.icpWeight;
+    c->outlier_coefficient = d.outlierCoefficient; c->fast_odom = d.fastOdom; c->so3 = d.so3; c->frame_to_frame_rgb = d.frameToFrameRGB;
+    c->pyramid = d.pyramid; c->rgb_only = d.rgbOnly; c->model_spawn_offset = d.modelSpawnOffset;
+    c->enable_multiple_models = d.enableMultipleModels;
+}
+
+int cofusion_create(const cofusion_config* c, cofusion_handle** out)
+{
+    if (!c || !out) { g_err = "null argument"; return -1; }
+    CoFusion::Config d;
+    d.width = c->width; d.height = c->height; d.fx = c->fx; d.fy = c->fy; d.cx = c->cx; d.cy = c->cy; d.device = c->device;
+    d.maxSurfels = c->max_surfels; d.maxModels = c->max_models; d.confGlobalInit = c->conf_global_init;
+    d.confObjectInit = c->conf_object_init; d.depthCutoff = c->depth_cutoff; d.icpWeight = c->icp_weight;
+    d.outlierCoefficient = c->outlier_coefficient; d.fastOdom = c->fast_odom; d.so3 = c->so3; d.frameToFrameRGB = c->frame_to_frame_rgb;
+    d.pyramid = c->pyramid; d.rgbOnly = c->rgb_only; d.modelSpawnOffset = c->model_spawn_offset;
+    d.enableMultipleModels = c->enable_multiple_models;
+    GUARD(*out = new cofusion_handle{new CoFusion(d)});
+    return 0;
+}
+void cofusion_destroy(cofusion_handle* h) { if (h) { delete h->cf; delete h; } }
+const char* cofusion_last_error(void) { return g_err.c_str(); }
+int cofusion_set_stream(cofusion_handle* h, void* s) { return cf_set_stream(h->cf->context(), s); }
+
+static int run_frame(cofusion_handle* h, const FrameData& f, const float* in_pose)
+{
+    Mat4f p;
+    if (in_pose) for (int i = 0; i < 16; i++) p.m[i] = in_pose[i];
+    GUARD(h->cf->processFrame(f, in_pose ? &p : nullptr));
+    return 0;
+}
+int cofusion_process_frame(cofusion_handle* h, int64_t ts, const uint8_t* rgb, const float* depth, const uint8_t* mask, const float* in_pose)
+{
+    FrameData f; f.timestamp = ts; f.rgb = rgb; f.depth = depth; f.mask = mask;
+    return run_frame(h, f, in_pose);
+}
+int cofusion_process_frame_device(cofusion_handle* h, int64_t ts, const float* depth_dev, const uint8_t* rgba_dev, const float* in_pose)
+{
+    FrameData f; f.timestamp = ts; f.depth_dev = depth_dev; f.rgba_dev = rgba_dev;
+    return run_frame(h, f, in_pose);
+}
+int cofusion_num_models(cofusion_handle* h) { return (int)h->cf->getModels().size(); }
+int cofusion_tick(cofusion_handle* h) { return h->cf->getTick(); }
+
+static Model* model_at(cofusion_handle* h, int index)
+{
+    auto& l = h->cf->getModels();
+    if (index < 0 || index >= (int)l.size()) return nullptr;
+    auto it = l.begin();
+    std::advance(it, index);
+    return it->get();
+}
+int cofusion_model_info(cofusion_handle* h, int index, unsigned* id, unsigned* count, float pose[16], float* conf)
+{
+    Model* m = model_at(h, index);
+    if (!m) { g_err = "model index out of range"; return -1; }
+    if (id) *id = m->getID();
+    if (count) *count = m->lastCount();
+    if (pose) for (int i = 0; i < 16; i++) pose[i] = m->getPose().m[i];
+    if (conf) *conf = m->getConfidenceThreshold();
+    return 0;
+}
+int cofusion_model_download(cofusion_handle* h, int index, float* surfels, uint32_t capacity, uint32_t* count)
+{
+    Model* m = model_at(h, index);
+    if (!m) { g_err = "model index out of range"; return -1; }
+    return cf_model_download_map(m->handle(), surfels, capacity, count);
+}
+int cofusion_model_icp_stats(cofusion_handle* h, int index, float* err, float* cnt)
+{
+    Model* m = model_at(h, index);
+    if (!m) { g_err = "model index out of range"; return -1; }
+    if (err) *err = m->lastStats.last_icp_error;
+    if (cnt) *cnt = m->lastStats.last_icp_count;
+    return 0;
+}
+const uint8_t* cofusion_mask_device(cofusion_handle* h) { return h->cf->maskDevice(); }
+void* cofusion_context(cofusion_handle* h) { return h->cf->context(); }
+int cofusion_set_crf(cofusion_handle* h, float uwe, float uke, float thn, float wa, float ws, float srgb, float sdepth, float spos, float minr,
+                     float maxr, unsigned its)
+{
+    Segmentation& s = h->cf->segmentation();
+    s.unaryWeightError = uwe; s.unaryKError = uke; s.unaryThresholdNew = thn; s.weightAppearance = wa; s.weightSmoothness = ws;
+    s.scaleFeaturesRGB = 1.0f / srgb; s.scaleFeaturesDepth = 1.0f / sdepth; s.scaleFeaturesPos = 1.0f / spos;
+    s.minRelSizeNew = minr; s.maxRelSizeNew = maxr; s.crfIterations = its;
+    return 0;
+}
+
+}  // extern "C"

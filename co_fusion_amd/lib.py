@@ -24,7 +24,8 @@ SYMBOLS = [
     "cf_bilateral", "cf_model_create", "cf_model_destroy", "cf_model_initialise", "cf_model_count",
     "cf_model_predict_indices", "cf_model_combined_predict", "cf_model_perform_fill_in", "cf_model_requires_fill_in",
     "cf_model_fuse", "cf_model_clean", "cf_model_download_map", "cf_model_upload_map", "cf_model_buffer",
-    "cf_fusion_weight",
+    "cf_fusion_weight", "cf_seg_create", "cf_seg_destroy", "cf_seg_slic", "cf_seg_accumulate", "cf_seg_crf", "cf_seg_upsample",
+    "cf_seg_labels",
     "cf_depth_pyramid", "cf_set_icp_launch", "cf_profile_enable", "cf_profile_read", "cf_odom_bench_icp",
 ]
 
@@ -35,7 +36,35 @@ def build(verbose: bool = False) -> str:
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)
+    # host-side C++ facade (g++), links against the C-ABI library
+    cmd = ["make", "-C", os.path.join(_HERE, "host")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
     return LIB_PATH
+
+
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libcofusion.so")
+HOST_SYMBOLS = [
+    "cofusion_default_config", "cofusion_create", "cofusion_destroy", "cofusion_last_error", "cofusion_set_stream",
+    "cofusion_process_frame", "cofusion_process_frame_device", "cofusion_num_models", "cofusion_tick", "cofusion_model_info",
+    "cofusion_model_download", "cofusion_model_icp_stats", "cofusion_mask_device", "cofusion_context", "cofusion_set_crf",
+]
+_host = None
+
+
+def load_host() -> C.CDLL:
+    """libcofusion.so: the C++ CoFusion/Model/Segmentation facade behind a flat C wrapper (include/cofusion.h)."""
+    global _host
+    if _host is None:
+        load()  # torch first, then the C-ABI library (same HIP runtime instance)
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} is missing: run __graft_entry__.build()")
+        _host = C.CDLL(HOST_LIB_PATH)
+        _host.cofusion_last_error.restype = C.c_char_p
+        _host.cofusion_mask_device.restype = C.c_void_p
+        _host.cofusion_context.restype = C.c_void_p
+    return _host
 
 
 _lib = None

@@ -207,6 +207,31 @@ int cf_model_buffer(cf_model *m, int which, void **dptr, uint64_t *bytes);
 /* Model::computeFusionWeight (Model.cpp:391-406); pure host math */
 float cf_fusion_weight(const float pose[16], const float lastPose[16], float weightMultiplier);
 
+/* ------------------------------------------------------------- motion segmentation ---- */
+/* GPU side of Core/Segmentation (SLIC -> per-superpixel sums -> dense-CRF mean field -> up-sampling).
+ * gSLICr / densecrf are third party and absent from the reference tree (Scripts/install.sh:84-85); they are
+ * replaced by the published algorithms stated in oracle/orc_segment.c.  Superpixels are 16x16 on a regular
+ * grid (Slic.cpp:33-43): K = (width/16)*(height/16) nodes. */
+typedef struct cf_segmenter cf_segmenter;
+int cf_seg_create(cf_ctx *ctx, cf_segmenter **out);
+void cf_seg_destroy(cf_segmenter *s);
+/* Slic::setInputImage + processFrame (Slic.cpp:48-81) */
+int cf_seg_slic(cf_segmenter *s, const uint8_t *rgba);
+/* Slic::downsample / downsampleThresholded sums (Slic.h:48-120) as exact Q32 fixed point: per superpixel
+ * pixel count, count and sum of depth > 0.02, and per model the sums of the ICP error surface and of the
+ * splat confidence (vertexConf.w).  Host outputs: [K], [K], [K], [n_models*K], [n_models*K], [K]. */
+int cf_seg_accumulate(cf_segmenter *s, const float *depth, int n_models, const float *const *icp_err,
+                      const float *const *vertconf4, uint32_t *spix_count_host, uint32_t *depth_count_host,
+                      int64_t *depth_sum_host, int64_t *icp_sum_host, int64_t *conf_sum_host, int32_t *resample_labels_host);
+/* DenseCRF2D inference of Segmentation.cpp:436-480: unary [K*L], Gaussian features [K*2] and bilateral
+ * features [K*6] from the host, marginals Q [K*L] back to the host. */
+int cf_seg_crf(cf_segmenter *s, const float *unary_host, int L, const float *feat_smooth_host, const float *feat_app_host,
+               float w_smooth, float w_app, int iterations, float *Q_host);
+/* Slic::upsample<unsigned char> (Slic.h:127-139): low_map [K] host -> full-resolution mask on the device */
+int cf_seg_upsample(cf_segmenter *s, const uint8_t *low_map_host, uint8_t *full_dev);
+/* device view of the SLIC labels, int32 [H*W] */
+int cf_seg_labels(cf_segmenter *s, void **dptr, uint64_t *bytes);
+
 /* launch-shape tuning of the ICP reduction (GPUConfig.h:51-58 in the reference) */
 int cf_set_icp_launch(cf_ctx *ctx, int threads, int pixels_per_thread);
 

@@ -133,6 +133,30 @@ int orc_clean(const float *surfels_in, int count, const float *new_unstable, int
               int rows, int time, float confThreshold, float outlierCoeff, int timeDelta, int maskID, float *surfels_out);
 float orc_fusion_weight(const float pose[16], const float lastPose[16], float weightMultiplier);
 
+/* ------------------------------ segmentation (orc_segment.c) -------------------------------- */
+typedef struct {
+    float unaryWeightError, unaryKError, unaryThresholdNew; /* GUI defaults 75, 0.0375, 5.5 (GUI.h:222-224) */
+    float weightAppearance, weightSmoothness;               /* 7, 2 */
+    float scaleFeaturesRGB, scaleFeaturesDepth, scaleFeaturesPos; /* 1/10, 1/0.9, 1/1.8 */
+    float minRelSizeNew, maxRelSizeNew;                      /* 0.015, 0.4 */
+    int crfIterations;                                       /* 10 */
+} orc_seg_params;
+typedef struct {
+    unsigned id, superPixelCount;
+    float avgConfidence, depthMean, depthStd;
+    int top, right, bottom, left;
+} orc_seg_model;
+void orc_slic(const uint8_t *rgba, int cols, int rows, int32_t *labels);
+void orc_crf_meanfield(const float *unary, int L, int n, const float *feat_smooth, const float *feat_app, float w_smooth,
+                       float w_app, int iterations, float *Q);
+int orc_segment_crf(const orc_seg_params *P, int cols, int rows, const uint8_t *rgba, const float *depth, int n_models,
+                    const unsigned *model_ids, const float *const *icp_err, const float *const *vertconf4, unsigned nextModelID,
+                    int allowNew, uint8_t *full_seg, orc_seg_model *out_models, int *n_out, int *hasNewLabel, float *depthRange_out,
+                    int32_t *labels_out, uint8_t *low_map_out);
+int orc_segment_gt(const uint8_t *gt_mask, const float *depth, int cols, int rows, int n_models, const unsigned *model_ids,
+                   unsigned nextModelID, int allowNew, uint8_t *mapping, uint8_t *full_seg, orc_seg_model *out_models, int *n_out,
+                   int *hasNewLabel);
+
 /* Model::generateCUDATextures depth pyramid (Model.cpp:319-348) */
 void orc_depth_pyramid(const float *depth_filtered, int cols, int rows, float *l1, float *l2);
 
