@@ -2,17 +2,25 @@
 """Headline benchmark: frames/sec of the Co-Fusion hot path at 640x480 on MI355X.
 
 Contract (task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line from rank 0.
-A "step" is one pass of the whole per-frame hot path (bilateral filter, pyramid/map preparation, SO3 +
-ICP/RGB Gauss-Newton tracking, splat prediction + fill-in, index map, surfel fuse, index map, clean,
-prediction) over one synthetic RGB-D frame that is already resident in HBM.  For N > 1 the driver launches
-one process per GPU (torch.distributed.run); every rank then runs its own independent stream (the path
-shards over independent models/streams, no data-path collective; "scaling": "weak").
+A "step" is one CoFusion::processFrame: the whole per-frame hot path (bilateral filter, pyramid/map
+preparation, SO3 + ICP/RGB Gauss-Newton tracking of every active model, [segmentation], splat prediction +
+fill-in, index map, surfel fuse, index map, clean, prediction) over one synthetic RGB-D frame that is
+already resident in HBM, driven through the C++ facade (libcofusion.so) over the C-ABI (libcofusion_hip.so).
+
+Workloads (BASELINE.json configs):
+  static       configs[1]: single static background model (`-static`), 640x480            <- default / headline
+  objects4     configs[2]: 4 moving objects + background, motion-CRF segmentation on
+  objects4-gt  as objects4 but with ground-truth label masks (the reference's Mask####.png input mode)
+
+N > 1: one process per GPU (torch.distributed.run); every rank runs its own independent RGB-D stream --
+the path partitions over independent streams/models without a data-path collective ("scaling": "weak").
+Timing: barrier + synchronize on both sides of exactly K steps, MAX over ranks.
 
 The JSON line also carries
-  roofline      achieved algorithmic bytes/s of the dominant kernel (level-0 ICP reduction, 48 B/pixel per
-                launch, BASELINE.md section 3) from hipEvents on the launch stream, vs the HBM peak;
-  cpu_baseline  the CPU oracle's restatement of the same frame loop ("port": the reference itself cannot
-                be built in this environment), timed on this box's host cores on a bounded sample.
+  roofline      achieved algorithmic bytes/s of the dominant kernel (level-0 ICP reduction, (24 + 24*M) B/pixel
+                per launch for M lock-step models, BASELINE.md section 3) from hipEvents on the launch stream;
+  cpu_baseline  the CPU oracle's restatement of the same frame loop ("port": the reference cannot be built
+                here), timed on this box's host cores on a bounded sample.
 """
 from __future__ import annotations
 
@@ -28,17 +36,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=120)
-    ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--workload", default="static", choices=["static"])
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="static", choices=["static", "objects4", "objects4-gt"])
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--frames", type=int, default=16, help="distinct synthetic frames (played forwards then backwards)")
@@ -47,119 +54,144 @@ def parse():
     ap.add_argument("--icp-threads", type=int, default=256)
     ap.add_argument("--icp-ppt", type=int, default=1)
     ap.add_argument("--max-surfels", type=int, default=1 << 21)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def make_stream(width, height, n_frames, n_obj=0):
-    """Seeded synthetic RGB-D stream (co_fusion_amd/synth.py): noisy depth (mm-quantised) + RGBA."""
+def make_stream(width, height, n_frames, n_obj=0, seed=1234):
+    """Seeded synthetic RGB-D stream (co_fusion_amd/synth.py): noisy depth (mm-quantised), RGB, label masks."""
     warnings.filterwarnings("ignore", category=RuntimeWarning)
     from co_fusion_amd import synth
     cam = synth.Camera.scaled(width, height)
-    sc = synth.Scene(n_obj=n_obj, seed=1234)
+    sc = synth.Scene(n_obj=n_obj, seed=seed)
     frames = []
     for t in range(n_frames):
-        d, rgb, _, T = sc.render(cam, t, noise=True)
-        frames.append(dict(depth=d, rgba=synth.rgb_to_rgba(rgb), T=T))
+        d, rgb, lab, T = sc.render(cam, t, noise=True)
+        frames.append(dict(depth=d, rgb=rgb, rgba=synth.rgb_to_rgba(rgb), label=lab, T=T))
     return cam, frames
 
 
 def frame_index(i, n):
-    """0,1,..,n-1,n-2,..,1,0,1,.. : keeps inter-frame motion small for any number of steps."""
+    """0,1,..,n-1,n-2,..,1,0,1,.. : keeps the inter-frame motion small for any number of steps."""
     period = 2 * (n - 1)
     k = i % period
     return k if k < n else period - k
 
 
-def main():
-    args = parse()
+def timed_region(step_fn, steps, warmup, barrier, all_reduce_max):
+    """The driver's timing contract: W untimed steps, barrier+sync, EXACTLY K steps, barrier+sync, MAX over ranks."""
+    for i in range(warmup):
+        step_fn(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        step_fn(i)
+    barrier()
+    return all_reduce_max(time.perf_counter() - t0)
+
+
+def main(argv=None):
+    args = parse(argv)
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
-    from co_fusion_amd import api
-    from co_fusion_amd import model as M
+    from co_fusion_amd import facade
 
     W, H = args.width, args.height
-    cam, frames = make_stream(W, H, args.frames)
-    ctx = api.Context(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank)
-    ctx.set_icp_launch(args.icp_threads, args.icp_ppt)
-    pipe = M.StaticPipeline(ctx, max_surfels=args.max_surfels)
-    dev = [dict(depth=ctx.to_device(f["depth"]), rgba=ctx.to_device(f["rgba"])) for f in frames]
+    n_obj = 0 if args.workload == "static" else 4
+    cam, frames = make_stream(W, H, args.frames, n_obj=n_obj, seed=1234 + rank)
+    cf = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels,
+                         enable_multiple_models=int(n_obj > 0))
+    cf.set_icp_launch(args.icp_threads, args.icp_ppt)
+    dev = torch.device("cuda", local_rank)
+    resident = [dict(depth=torch.from_numpy(f["depth"]).to(dev), rgba=torch.from_numpy(f["rgba"]).to(dev)) for f in frames]
+    use_gt = args.workload == "objects4-gt"
     torch.cuda.synchronize()
 
     def step(i):
-        f = dev[frame_index(i, args.frames)]
-        return pipe.process_frame(f["depth"], f["rgba"])
+        k = frame_index(i, args.frames)
+        if use_gt:  # GT masks are a host-side input of the reference (FrameData.mask); depth/rgb stay host too in this mode
+            f = frames[k]
+            cf.process_frame(f["depth"], f["rgb"], mask=(f["label"] * 40).astype(np.uint8), timestamp=i)
+        else:
+            cf.process_frame_device(resident[k]["depth"], resident[k]["rgba"], timestamp=i)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    ctx.profile_enable(True)
-    ctx.profile_read(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        pose, count = step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = ctx.profile_read(reset=True)
-    ctx.profile_enable(False)
-
-    if world > 1:
-        import torch.distributed as dist
+    def all_reduce_max(dt):
+        if dist is None:
+            return dt
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        return float(tt.item())
+
+    # warm-up is untimed; profiling counters only cover the timed steps
+    for i in range(args.warmup):
+        step(i)
+    cf.profile_enable(True)
+    cf.profile_read(reset=True)
+    dt = timed_region(lambda i: step(i + args.warmup), args.steps, 0, barrier, all_reduce_max)
+    prof = cf.profile_read(reset=True)
+    cf.profile_enable(False)
     fps = args.steps * world / dt
 
     out = None
     if rank == 0:
+        n_models = cf.num_models
+        counts = [cf.model_info(i)["count"] for i in range(n_models)]
         achieved = (prof.icp_bytes / 1e9) / (prof.icp_ms_total / 1e3) if prof.icp_ms_total > 0 else 0.0
-        roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, kernel="cf::icp_reduce_kernel<PPT,0> (level 0)",
-                        launches=int(prof.icp_launches), avg_us=round(1e3 * prof.icp_ms_total / max(1, prof.icp_launches), 3),
+        roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                        traffic=None, kernel="cf::icp_reduce_kernel<PPT,0> (pyramid level 0)", launches=int(prof.icp_launches),
+                        avg_us=round(1e3 * prof.icp_ms_total / max(1, prof.icp_launches), 3),
                         bytes_per_launch=int(prof.icp_bytes / max(1, prof.icp_launches)))
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(cam, frames, min(args.cpu_frames, args.frames))
-        out = dict(metric="frames/sec at 640x480 (N active models) + ICP-reduce achieved HBM GB/s vs peak",
-                   value=round(fps, 2), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(1e3 * dt / args.steps, 4), higher_is_better=True, scaling="weak",
-                   vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=f"single static background model, {W}x{H} synthetic RGB-D (noisy), whole per-frame hot "
-                                        "path: bilateral + tracking (SO3, 4/5/10 ICP+RGB GN) + predict + fuse + clean",
-                               active_models=1, surfels=int(count), icp_launch=[args.icp_threads, args.icp_ppt]),
+            cpu = cpu_baseline(cam, frames, min(args.cpu_frames, args.frames), args.workload)
+        desc = {"static": "single static background model (-static)", "objects4": "4 moving objects + background, motion-CRF segmentation",
+                "objects4-gt": "4 moving objects + background, ground-truth label masks"}[args.workload]
+        out = dict(metric="frames/sec at 640x480 (N active models) + ICP-reduce achieved HBM GB/s vs peak", value=round(fps, 2),
+                   unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 4),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=f"{desc}, {W}x{H} synthetic noisy RGB-D, whole CoFusion::processFrame hot path "
+                                        "(bilateral, tracking SO3+4/5/10 ICP+RGB GN, predict, fuse, clean)",
+                               active_models=n_models, surfels=counts, icp_launch=[args.icp_threads, args.icp_ppt],
+                               streams_per_gpu=1),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out))
-    pipe.close()
-    ctx.close()
-    if world > 1:
-        import torch.distributed as dist
+    cf.close()
+    if dist is not None:
         dist.destroy_process_group()
     return out
 
 
-def cpu_baseline(cam, frames, n):
+def cpu_baseline(cam, frames, n, workload):
     """CPU oracle frame loop (port of the reference path) on a bounded sample of the same stream."""
+    import orc_multi as om
     import orc_pipeline as op
-    pipe = op.StaticPipeline(cam)
-    pipe.process_frame(frames[0]["depth"], frames[0]["rgba"])  # bootstrap frame (no tracking), untimed
+    if workload == "static":
+        pipe = op.StaticPipeline(cam)
+        run = lambda f: pipe.process_frame(f["depth"], f["rgba"])
+    else:
+        pipe = om.MultiPipeline(cam)
+        gt = workload == "objects4-gt"
+        run = lambda f: pipe.process_frame(f["depth"], f["rgba"], gt_mask=(f["label"] * 40).astype(np.uint8) if gt else None)
+    run(frames[0])  # bootstrap frame (no tracking), untimed
     t0 = time.perf_counter()
     for k in range(1, n):
-        pipe.process_frame(frames[k]["depth"], frames[k]["rgba"])
+        run(frames[k])
     dt = time.perf_counter() - t0
     return dict(value=round((n - 1) / dt, 3), unit="frames/s", cores=os.cpu_count(), kind="port",
-                sample=f"{n - 1} frames of the same workload; C oracle (gcc -O2), tracking + fusion single-threaded, "
+                sample=f"{n - 1} frames of the same workload; C oracle (gcc -O2): tracking + fusion single-threaded, "
                        f"bilateral filter OpenMP over {os.cpu_count()} threads")
 
 

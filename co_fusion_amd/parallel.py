@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
+
+The reference is single-GPU (no NCCL/MPI/streams anywhere), so this is new design:
+
+* Independent units shard with NO data-path collective: RGB-D streams (bench.py --gpus N) and, inside one
+  stream, object models (`assign_models`): each model tracks/predicts/fuses/cleans using only the shared frame
+  and its own surfels (Core/CoFusion.cpp:214-217, 465-488).
+* Where one model is split (image-row bands of the ICP/RGB reductions, surfel-range shards of the background
+  for very large maps) the only exchange is the 6x6 normal-equation system.  The kernels accumulate it as
+  exact 64-bit fixed-point integers, so `allreduce_se3_sums` (one [M x 32] int64 SUM all-reduce per
+  Gauss-Newton iteration for all M models of the launch) reproduces the single-GPU sums bit for bit,
+  independent of the number of ranks and of the reduction order inside RCCL.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def assign_models(model_ids: Sequence[int], world: int) -> Dict[int, List[int]]:
+    """Placement of active models on ranks: the background (id 0, by far the largest map) alone on rank 0
+    as long as there are enough ranks, objects round-robin over the remaining ranks."""
+    out: Dict[int, List[int]] = {r: [] for r in range(world)}
+    objs = [m for m in model_ids if m != 0]
+    if 0 in model_ids:
+        out[0].append(0)
+    if world == 1:
+        out[0].extend(objs)
+        return out
+    first = 1 if len(objs) >= world - 1 or world > 1 else 0
+    ranks = list(range(first, world)) or [0]
+    for k, m in enumerate(objs):
+        out[ranks[k % len(ranks)]].append(m)
+    return out
+
+
+def row_bands(rows: int, world: int, align: int = 4) -> List[range]:
+    """Contiguous image-row bands per rank (aligned so that pyramid levels split at the same place)."""
+    per = ((rows + world - 1) // world + align - 1) // align * align
+    return [range(min(r * per, rows), min((r + 1) * per, rows)) for r in range(world)]
+
+
+def allreduce_se3_sums(sums: torch.Tensor) -> torch.Tensor:
+    """SUM all-reduce of the fixed-point normal equations, int64 [M, 32] (or [32]).  Exact: integer addition
+    commutes, so every rank obtains the bits a single GPU would have produced."""
+    assert sums.dtype == torch.int64
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return sums
+
+
+def allreduce_max_seconds(seconds: float, device=None) -> float:
+    """bench.py timing contract: MAX over ranks of the timed region."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -201,8 +201,8 @@ def ideal_prediction(cam: Camera, depth: np.ndarray, rgb: np.ndarray, conf: floa
     u, v = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
     z = depth.astype(np.float32)
     vert = np.zeros((H, W, 4), dtype=np.float32)
-    vert[..., 0] = (u + np.float32(0.5) - np.float32(cam.cx)) * z / np.float32(cam.fx)
-    vert[..., 1] = (v + np.float32(0.5) - np.float32(cam.cy)) * z / np.float32(cam.fy)
+    vert[..., 0] = (u - np.float32(cam.cx)) * z / np.float32(cam.fx)  # same pixel->ray convention as createVMap (cudafuncs.cu:121)
+    vert[..., 1] = (v - np.float32(cam.cy)) * z / np.float32(cam.fy)
     vert[..., 2] = z
     vert[..., 3] = np.where(z > 0, np.float32(conf), np.float32(0))
     vert[z <= 0] = 0

@@ -1,0 +1,88 @@
+"""CPU suite: the N > 1 code paths under torch.distributed with the gloo backend, world_size 2."""
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        import common
+        import orc
+        from co_fusion_amd import parallel
+
+        # 1. bench.py timing contract: barrier on both sides, MAX over ranks, whole-job aggregate
+        def step(i):
+            time.sleep(0.002 * (rank + 1))      # rank 1 is the slow one
+        dt = bench.timed_region(step, steps=10, warmup=2, barrier=dist.barrier,
+                                all_reduce_max=lambda s: parallel.allreduce_max_seconds(s))
+        assert dt >= 10 * 0.002 * world * 0.9, dt     # everybody reports the slowest rank's time
+
+        # 2. image-row sharded ICP: per-rank partial fixed-point sums, one int64 SUM all-reduce == full-image sums
+        W, H = 160, 120
+        fp = common.frame_pair(W, H)
+        cam = fp["cam"]; ocam = orc.Cam(cam.fx, cam.fy, cam.cx, cam.cy)
+        pose = common.perturbed_pose(2)
+        od = orc.Odometry(W, H, cam.cx, cam.cy, cam.fx, cam.fy)
+        od.init_first_rgb(fp["rgba0"]); od.init_icp_model(fp["v4"], fp["n4"], pose); od.init_rgb_model(fp["img"])
+        od.init_icp(orc.depth_pyramid(fp["d1"]), 20.0); od.init_rgb(fp["rgba1"])
+        vc, nc, vp, npv = (od.buffer(k, 0) for k in range(4))
+        Rinv = np.linalg.inv(pose[:3, :3].astype(np.float64)).astype(np.float32)
+        angle = np.float32(np.sin(20.0 * 3.14159254 / 180.0))
+        full, _ = orc.icp_step(pose[:3, :3], pose[:3, 3], vc, nc, Rinv, pose[:3, 3], ocam, vp, npv, 0.10, angle)
+        band = parallel.row_bands(H, world)[rank]
+        vc_band = vc.copy()
+        keep = np.zeros(H, bool); keep[band.start:band.stop] = True
+        vc_band[:H][~keep] = np.nan                  # pixels of other ranks: NaN x plane == "not mine"
+        part, _ = orc.icp_step(pose[:3, :3], pose[:3, 3], vc_band, nc, Rinv, pose[:3, 3], ocam, vp, npv, 0.10, angle)
+        t = torch.from_numpy(part.copy())
+        parallel.allreduce_se3_sums(t)
+        assert np.array_equal(t.numpy(), full), "sharded + all-reduced sums must equal the single-device sums exactly"
+        assert part[28] < full[28]
+
+        # 3. placement
+        pl = parallel.assign_models([0, 3, 5, 9], world)
+        assert sorted(sum(pl.values(), [])) == [0, 3, 5, 9] and 0 in pl[0]
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_assign_models_and_bands_single_process():
+    from co_fusion_amd import parallel
+    assert parallel.assign_models([0, 1, 2], 1) == {0: [0, 1, 2]}
+    pl = parallel.assign_models([0, 1, 2, 3, 4, 5, 6, 7, 8], 8)
+    assert pl[0] == [0] and all(len(v) >= 1 for v in pl.values())
+    bands = parallel.row_bands(480, 8)
+    assert bands[0].start == 0 and bands[-1].stop == 480 and sum(len(b) for b in bands) == 480
