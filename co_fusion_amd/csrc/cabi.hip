@@ -223,7 +223,7 @@ int cf_icp_step(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], const f
     h->nmap_g_prev[0] = nmap_g_prev; h->distThres = dist_thres; h->angleThres = angle_thres; h->err_surface = err_surface;
     if (int r = scratch_commit(ctx)) return r;
     IcpArgs a{};
-    a.m[0] = IcpModelArgs{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, ctx->d_scratch_state, ctx->d_acc_a, err_surface};
+    a.m[0] = IcpModelArgs{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, ctx->d_scratch_state, ctx->d_acc_a, err_surface, ctx->d_acc_b};
     a.cols = cols; a.rows = rows; a.intr = intr; a.distThres = dist_thres; a.angleThres = angle_thres;
     a.flags = err_surface ? 1 : 0;
     launch_icp_level(ctx->stream, ctx->icp_launch, a, 1, 0);
@@ -511,7 +511,7 @@ static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3
             a.m[m] = IcpModelArgs{od->ext_vmap_curr[l] ? od->ext_vmap_curr[l] : od->vmap_curr[l],
                                   od->ext_nmap_curr[l] ? od->ext_nmap_curr[l] : od->nmap_curr[l],
                                   od->vmap_g_prev[l], od->nmap_g_prev[l], od->d_state, od->icp_acc,
-                                  od->h_state->err_surface};
+                                  od->h_state->err_surface, od->rgb_acc};
         }
     }
 }

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/cofusion_hip.h"
@@ -76,6 +77,13 @@ struct IcpModelArgs {
     const OdomDev* st;                  // device-resident pose + flags
     unsigned long long* acc;            // [kGroups][32] grouped accumulators
     float* err;                         // nullable ICP error surface [rows*cols]
+    unsigned long long* rgb_acc;        // the model's RGB accumulators (used by the solve kernel's arguments)
+};
+// solve-kernel arguments (by value)
+struct GnArgs {
+    OdomDev* od[kMaxBatch];
+    unsigned long long* icp_acc[kMaxBatch];
+    unsigned long long* rgb_acc[kMaxBatch];
 };
 struct IcpArgs {
     IcpModelArgs m[kMaxBatch];
@@ -84,7 +92,7 @@ struct IcpArgs {
     float distThres, angleThres;
     int flags;                          // bit0: write the error surface
 };
-void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level);
+void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void launch_rgb_residual_models(hipStream_t s, OdomDev* const* d_models, int n, int width, int height, int level);
 void launch_rgb_step_models(hipStream_t s, OdomDev* const* d_models, int n, int width, int height, int level);
 void launch_acc_total(hipStream_t s, const unsigned long long* acc, unsigned long long* out);
