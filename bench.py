@@ -151,7 +151,7 @@ def main(argv=None):
         counts = [cf.model_info(i)["count"] for i in range(n_models)]
         achieved = (prof.icp_bytes / 1e9) / (prof.icp_ms_total / 1e3) if prof.icp_ms_total > 0 else 0.0
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=None, kernel="cf::icp_reduce_kernel<PPT,0> (pyramid level 0)", launches=int(prof.icp_launches),
+                        traffic=pmc_traffic(args.workload, W * H), kernel="cf::icp_reduce_kernel<PPT,0> (pyramid level 0)", launches=int(prof.icp_launches),
                         avg_us=round(1e3 * prof.icp_ms_total / max(1, prof.icp_launches), 3),
                         bytes_per_launch=int(prof.icp_bytes / max(1, prof.icp_launches)))
         cpu = None
@@ -172,6 +172,19 @@ def main(argv=None):
     if dist is not None:
         dist.destroy_process_group()
     return out
+
+
+def pmc_traffic(workload, pixels):
+    """HBM-side bytes per launch of the level-0 ICP kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE cannot be collected from inside this process); null when no pass matches this workload/shape."""
+    path = os.path.join(ROOT, "profiles", "r01_icp_traffic.json")
+    try:
+        t = json.load(open(path))
+    except OSError:
+        return None
+    if t.get("workload") != workload or t.get("grid") != pixels:
+        return None
+    return int(t["traffic_bytes_per_launch"])
 
 
 def cpu_baseline(cam, frames, n, workload):

@@ -247,7 +247,10 @@ int cf_rgb_residual(cf_ctx* ctx, float min_scale, const int16_t* dIdx, const int
     h->lastImage[0] = last_image; h->nextImage[0] = next_image; h->corres[0] = corres;
     h->maxDepthDeltaRGB = max_depth_delta; memcpy(h->kt, kt, 12); memcpy(h->krkInv, krkinv, 36);
     if (int r = scratch_commit(ctx)) return r;
-    launch_rgb_residual_models(ctx->stream, ctx->d_model_ptrs, 1, cols, rows, 0);
+    RgbArgs ra{};
+    ra.m[0] = rgb_model_args(h, ctx->d_scratch_state, 0);
+    ra.cols = cols; ra.rows = rows; ra.maxDepthDelta = max_depth_delta;
+    launch_rgb_residual(ctx->stream, ra, 1);
     LAUNCHCHK(ctx);
     if (int r = fetch_totals(ctx, ctx->d_acc_a, 32)) return r;
     if (count_host) *count_host = (int)ctx->h_out[29];
@@ -275,7 +278,10 @@ int cf_rgb_step(cf_ctx* ctx, const cf_dataterm* corres, float sigma, const float
     if (int r = scratch_commit(ctx)) return r;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_acc_a + 29, seed, sizeof(seed), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // seed is on the host stack
-    launch_rgb_step_models(ctx->stream, ctx->d_model_ptrs, 1, cols, rows, 0);
+    RgbArgs ra{};
+    ra.m[0] = rgb_model_args(h, ctx->d_scratch_state, 0);
+    ra.cols = cols; ra.rows = rows; ra.il = cf_cam{fx, fy, 0, 0}; ra.sobelScale = sobel_scale;
+    launch_rgb_step(ctx->stream, ra, 1);
     LAUNCHCHK(ctx);
     if (int r = fetch_totals(ctx, ctx->d_acc_b, 32)) return r;
     se3_unpack_host(ctx->h_out, CF_FIX_RGB, A_host, b_host, nullptr);
@@ -489,11 +495,24 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
     inv33f_host(R, h->Rprev_inv);
     memset(&h->stats, 0, sizeof(h->stats));
     HIPCHK(ctx, hipMemcpyAsync(od->d_state, h, sizeof(OdomDev), hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemsetAsync(od->icp_acc, 0, sizeof(unsigned long long) * kGroups * 32, s));
-    HIPCHK(ctx, hipMemsetAsync(od->rgb_acc, 0, sizeof(unsigned long long) * kGroups * 32, s));
+    // the accumulators are zero here: dmalloc clears them and every solve leaves them cleared
     od->pending_so3_swap = opts->so3 != 0;
     LAUNCHCHK(ctx);
     return CF_OK;
+}
+
+static void fill_rgb_args(cf_ctx* ctx, cf_odom* const* ods, int n, RgbArgs out[3])
+{
+    const cf_cam intr{ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy};
+    for (int l = 0; l < 3; l++) {
+        RgbArgs& a = out[l];
+        memset(&a, 0, sizeof(a));
+        const int div = 1 << l;
+        a.cols = ctx->cfg.width >> l; a.rows = ctx->cfg.height >> l;
+        a.il = cf_cam{intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
+        a.sobelScale = ods[0]->sobelScale; a.maxDepthDelta = ods[0]->maxDepthDeltaRGB;
+        for (int m = 0; m < n; m++) a.m[m] = rgb_model_args(ods[m]->h_state, ods[m]->d_state, l);
+    }
 }
 
 static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3])
@@ -529,7 +548,9 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     const bool rgb = opts->rgb_only || opts->icp_weight < 100;
     IcpArgs icp_args[3];
     fill_icp_args(ctx, ods, n, icp_args);
-    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, icp_args, n, ctx->cfg.width, ctx->cfg.height,
+    RgbArgs rgb_args[3];
+    fill_rgb_args(ctx, ods, n, rgb_args);
+    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, icp_args, rgb_args, n, ctx->cfg.width, ctx->cfg.height,
                     opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, &ctx->prof);
     LAUNCHCHK(ctx);
     for (int m = 0; m < n; m++)
@@ -616,3 +637,4 @@ int cf_odom_buffer(cf_odom* od, int which, int level, void** dptr, uint64_t* byt
 }
 
 }  // extern "C"
+

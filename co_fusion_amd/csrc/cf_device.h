@@ -322,6 +322,93 @@ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tiny, T* ws,
     for (int i = 0; i < N; i++) x[perm[i]] = y[i];
 }
 
+// ---- the same 6x6 factorisation, spread over one wave -------------------------------------------------
+// Lane t < 36 owns A[t/6][t%6] in a register; pivot search, column broadcast and the substitutions use
+// v_readlane (uniform lane ids), the symmetric row/column swap and the mirror one ds_bpermute each.  Every
+// element goes through exactly the operations of ldlt_solve<double, 6> in the same order (right-looking
+// update, one update per k), so the result is bit-identical; the serial version stays for N = 3 / f32.
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// must be called by all 64 lanes of a wave; b: [6] (LDS), x: [6] (LDS, written by lane 0)
+__device__ __forceinline__ void ldlt_solve6_wave(double a, const double* b, double* x, double tiny, int lane)
+{
+    const int i = (lane < 36) ? lane / 6 : 0, j = (lane < 36) ? lane % 6 : 0;
+    int perm[6] = {0, 1, 2, 3, 4, 5};
+    double d[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        int p = k;
+        {
+            const double akk0 = readlane_f64(a, k * 7);
+            double best = akk0 < 0 ? -akk0 : akk0;
+#pragma unroll
+            for (int q = k + 1; q < 6; q++) {
+                const double aqq = readlane_f64(a, q * 7);
+                const double v = aqq < 0 ? -aqq : aqq;
+                if (v > best) { best = v; p = q; }
+            }
+        }
+        p = __builtin_amdgcn_readfirstlane(p);
+        if (p != k) {
+            const int si = (i == k) ? p : ((i == p) ? k : i), sj = (j == k) ? p : ((j == p) ? k : j);
+            a = __shfl(a, si * 6 + sj);
+            const int pk = perm[k];
+            int pp = pk;
+#pragma unroll
+            for (int q = k + 1; q < 6; q++)
+                if (q == p) { pp = perm[q]; perm[q] = pk; }
+            perm[k] = pp;
+        }
+        const double akk = readlane_f64(a, k * 7);
+        d[k] = akk;
+        const double aabs = akk < 0 ? -akk : akk;
+        if (aabs > tiny) {
+            if (j == k && i > k) a = a / akk;
+            double lik = 0, ljk = 0;
+#pragma unroll
+            for (int q = k + 1; q < 6; q++) {
+                const double c = readlane_f64(a, q * 6 + k);
+                if (i == q) lik = c;
+                if (j == q) ljk = c;
+            }
+            if (i > k && j > k && j <= i) a = a - lik * akk * ljk;
+            const double am = __shfl(a, j * 6 + i);
+            if (i > k && j > k && j > i) a = am;
+        } else {
+            if (j == k && i > k) a = 0;
+        }
+    }
+    double y[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        double s = b[perm[r]];
+#pragma unroll
+        for (int c = 0; c < r; c++) s = s - readlane_f64(a, r * 6 + c) * y[c];
+        y[r] = s;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const double aabs = d[r] < 0 ? -d[r] : d[r];
+        y[r] = (aabs > tiny) ? y[r] / d[r] : 0.0;
+    }
+#pragma unroll
+    for (int r = 5; r >= 0; r--) {
+        double s = y[r];
+#pragma unroll
+        for (int c = r + 1; c < 6; c++) s = s - readlane_f64(a, c * 6 + r) * y[c];
+        y[r] = s;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) x[perm[r]] = y[r];
+    }
+}
+
 // exact conversion of a fixed-point sum to the reference's f32 host value
 __device__ __forceinline__ float fix_to_f32(long long q, int F) { return (float)ldexp((double)q, -F); }
 

@@ -85,6 +85,25 @@ struct GnArgs {
     unsigned long long* icp_acc[kMaxBatch];
     unsigned long long* rgb_acc[kMaxBatch];
 };
+// RGB residual / RGB step arguments (by value): everything but the pose-dependent state arrives in the kernarg
+struct RgbModelArgs {
+    OdomDev* st;
+    const uint8_t* cand; const float* nextDepth; const float* lastDepth;
+    const uint8_t* lastImage; const uint8_t* nextImage;
+    cf_dataterm* corres; const float* cloud; const int16_t* dIdx; const int16_t* dIdy;
+    unsigned long long* icp_acc; unsigned long long* rgb_acc;
+};
+struct RgbArgs {
+    RgbModelArgs m[kMaxBatch];
+    int cols, rows;
+    cf_cam il;                          // intrinsics of this level
+    float sobelScale, maxDepthDelta;
+};
+inline RgbModelArgs rgb_model_args(const OdomDev* h /* host mirror */, OdomDev* d_state, int level)
+{
+    return RgbModelArgs{d_state, h->cand[level], h->nextDepth[level], h->lastDepth[level], h->lastImage[level], h->nextImage[level],
+                        h->corres[level], h->cloud[level], h->dIdx[level], h->dIdy[level], h->icp_acc, h->rgb_acc};
+}
 struct IcpArgs {
     IcpModelArgs m[kMaxBatch];
     int cols, rows;
@@ -93,8 +112,11 @@ struct IcpArgs {
     int flags;                          // bit0: write the error surface
 };
 void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-void launch_rgb_residual_models(hipStream_t s, OdomDev* const* d_models, int n, int width, int height, int level);
-void launch_rgb_step_models(hipStream_t s, OdomDev* const* d_models, int n, int width, int height, int level);
+void launch_rgb_residual(hipStream_t s, const RgbArgs& ra, int n);
+void launch_rgb_step(hipStream_t s, const RgbArgs& ra, int n);
+// algorithmic bytes per pixel and model of the RGB residual pass: candidate mask 1 + next depth 4 + next
+// intensity 1 + gathered last depth 4 + last intensity 1 + DataTerm record 16
+constexpr uint64_t kRgbResidualBytes = 27;
 void launch_acc_total(hipStream_t s, const unsigned long long* acc, unsigned long long* out);
 void launch_rgb_cand(hipStream_t s, const int16_t* dIdx, const int16_t* dIdy, const float* next_depth,
                      const uint8_t* next_image, float min_scale, int cols, int rows, uint8_t* cand);
@@ -107,8 +129,8 @@ struct ProfSink {  // hipEvent pairs recorded around every ICP-reduce launch whe
 
 // device-resident Gauss-Newton loop over `n` models (lock-step; blockIdx.y = model)
 void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */,
-                     const IcpArgs icp_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom,
-                     bool rgb, bool icp, ProfSink* prof);
+                     const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid,
+                     bool fast_odom, bool rgb, bool icp, ProfSink* prof);
 
 // ---- surfel launchers (surfel.hip) ----
 struct SurfelFuseArgs {

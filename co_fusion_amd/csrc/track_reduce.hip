@@ -125,13 +125,24 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nlog)
     return (b & 7) * per + (b >> 3);
 }
 
+__device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk);
+
+// One launch per Gauss-Newton iteration carries BOTH pose-dependent streaming passes, which are independent
+// of each other: workgroups [0, n_icp_blocks) run the ICP reduction, the rest the RGB residual pass
+// (rgb_residual_body).  At 640x480 either pass alone is launch/latency-bound (5-8 us for 8-15 MB); sharing
+// a launch overlaps their ramp-up, gather latency and atomics tail.
+//
 // Kernel arguments by value: every pointer the kernel dereferences arrives in the kernarg segment
 // (scalar loads, global-address-space vector loads, no pointer chasing through device structs).
-// Only the pose/flags, which the solve kernel updates on the device every iteration, are read from
+// Only the pose/flags, which the solve updates on the device every iteration, are read from
 // memory -- as scalar loads issued in parallel with the first coalesced map loads.
 template <int PPT, int LEVEL_TAG>
-__global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args)
+__global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, const RgbArgs ra, int n_icp_blocks)
 {
+    if ((int)blockIdx.x >= n_icp_blocks) {
+        rgb_residual_body(ra, blockIdx.y, blockIdx.x - n_icp_blocks);
+        return;
+    }
     const IcpModelArgs& ma = args.m[blockIdx.y];
     const OdomDev* __restrict__ st = ma.st;
     if (!st->icp || st->level_done) return;
@@ -211,51 +222,59 @@ __global__ void __launch_bounds__(256) rgb_cand_kernel(const int16_t* __restrict
     cand[k] = ok;
 }
 
-__global__ void __launch_bounds__(256) rgb_residual_kernel(OdomDev* const* __restrict__ models, int level)
+__device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
 {
-    const OdomDev* __restrict__ od = models[blockIdx.y];
+    const RgbModelArgs& m = ra.m[model];
+    const OdomDev* __restrict__ od = m.st;
     if (!od->rgb || od->level_done) return;
-    const int cols = od->width >> level, rows = od->height >> level, N = cols * rows;
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int cols = ra.cols, rows = ra.rows, N = cols * rows;
+    const int T = blockDim.x;
+    const int k = blk * T + threadIdx.x;
     int cnt = 0, sig = 0;
     if (k < N) {
         cf_dataterm c; c.zero_x = c.zero_y = c.one_x = c.one_y = 0; c.diff = 0.f; c.valid = 0;
-        if (od->cand[level][k]) {
+        const uint8_t* __restrict__ cand = m.cand;
+        if (cand[k]) {
+            const float* __restrict__ nextDepth = m.nextDepth;
+            const uint8_t* __restrict__ nextImage = m.nextImage;
+            const float d1 = nextDepth[k];
+            const float ni = (float)nextImage[k];
             const int y = k / cols, x = k - y * cols;
             const float* krk = od->krkInv; const float* kt = od->kt;
-            const float d1 = od->nextDepth[level][k];
             const float transformed_d1 = (float)(d1 * (krk[6] * x + krk[7] * y + krk[8]) + kt[2]);
             const int u0 = f2i_rn((d1 * (krk[0] * x + krk[1] * y + krk[2]) + kt[0]) / transformed_d1);
             const int v0 = f2i_rn((d1 * (krk[3] * x + krk[4] * y + krk[5]) + kt[1]) / transformed_d1);
             if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
-                const float d0 = od->lastDepth[level][v0 * cols + u0];
-                const uint8_t li = od->lastImage[level][v0 * cols + u0];
-                if (d0 > 0 && fabsf(transformed_d1 - d0) <= od->maxDepthDeltaRGB && li != 0) {
+                const float d0 = m.lastDepth[v0 * cols + u0];
+                const uint8_t li = m.lastImage[v0 * cols + u0];
+                if (d0 > 0 && fabsf(transformed_d1 - d0) <= ra.maxDepthDelta && li != 0) {
                     c.zero_x = (int16_t)u0; c.zero_y = (int16_t)v0; c.one_x = (int16_t)x; c.one_y = (int16_t)y;
-                    c.diff = (float)od->nextImage[level][k] - (float)li;
+                    c.diff = ni - (float)li;
                     c.valid = 1;
                     cnt = 1;
                     sig = (int)(c.diff * c.diff);
                 }
             }
         }
-        *reinterpret_cast<int4*>(&od->corres[level][k]) = *reinterpret_cast<const int4*>(&c);
+        *reinterpret_cast<int4*>(&m.corres[k]) = *reinterpret_cast<const int4*>(&c);
     }
     // block reduce (count, sigma) -> grouped atomics into words 29/30 of the ICP accumulator
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); sig += __shfl_xor(sig, o, 64); }
-    __shared__ int s_cnt[4], s_sig[4];
+    __shared__ int s_cnt[16], s_sig[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { s_cnt[wave] = cnt; s_sig[wave] = sig; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int c4 = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        const int g4 = s_sig[0] + s_sig[1] + s_sig[2] + s_sig[3];
-        unsigned long long* dst = od->icp_acc + (size_t)(blockIdx.x % kGroups) * 32;
+        int c4 = 0, g4 = 0;
+        for (int w = 0; w < (T >> 6); w++) { c4 += s_cnt[w]; g4 += s_sig[w]; }
+        unsigned long long* dst = m.icp_acc + (size_t)(blk % kGroups) * 32;
         if (c4) atomicAdd(&dst[29], (unsigned long long)c4);
         if (g4) atomicAdd(&dst[30], (unsigned long long)(long long)g4);
     }
 }
+
+__global__ void __launch_bounds__(1024) rgb_residual_kernel(const RgbArgs ra) { rgb_residual_body(ra, blockIdx.y, blockIdx.x); }
 
 // sum of word `w` over the groups (wave 0 only; result valid in all lanes of wave 0)
 __device__ __forceinline__ unsigned long long group_sum(const unsigned long long* acc, int w, int lane)
@@ -277,56 +296,59 @@ __device__ __forceinline__ float sigma_val_from(int count, int sigma, int rgbOnl
 // ================================================================================================
 // RGB step: RGBReduction::getProducts, reduce.cu:521-604
 // ================================================================================================
-__global__ void __launch_bounds__(256) rgb_step_kernel(OdomDev* const* __restrict__ models, int level)
+__global__ void __launch_bounds__(256) rgb_step_kernel(const RgbArgs ra)
 {
-    const OdomDev* __restrict__ od = models[blockIdx.y];
-    if (!od->rgb || od->level_done) return;
-    const int cols = od->width >> level, rows = od->height >> level, N = cols * rows;
-    __shared__ float s_sigma;
-    if (threadIdx.x < 64) {
-        const long long cnt = (long long)group_sum(od->icp_acc, 29, threadIdx.x);
-        const long long sg = (long long)group_sum(od->icp_acc, 30, threadIdx.x);
-        if (threadIdx.x == 0) s_sigma = sigma_val_from((int)cnt, (int)sg, od->rgbOnly);
-    }
-    __syncthreads();
-    const float sigma = s_sigma;
-    const cf_cam il = cam_level(od->intr, level);
-    unsigned long long acc[32];
-#pragma unroll
-    for (int k = 0; k < 28; k++) acc[k] = 0ull - kMagicBits;
-    acc[28] = acc[29] = acc[30] = acc[31] = 0;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    float row[7] = {0, 0, 0, 0, 0, 0, 0};
-    int found = 0;
-    if (i < N) {
-        const int4 raw = *reinterpret_cast<const int4*>(&od->corres[level][i]);
-        const cf_dataterm c = *reinterpret_cast<const cf_dataterm*>(&raw);
-        if (c.valid) {
-            found = 1;
-            float w = sigma + fabsf(c.diff);
-            w = w > 1.19209290E-07F ? 1.0f / w : 1.0f;
-            if (sigma == -1) w = 1;
-            row[6] = -w * c.diff;
-            const float* cp = od->cloud[level] + (size_t)(c.zero_y * cols + c.zero_x) * 3;
-            const float px = cp[0], py = cp[1], pz = cp[2];
-            const float invz = 1.0f / pz;
-            const int o = c.one_y * cols + c.one_x;
-            const float dI_dx_val = w * od->sobelScale * (float)od->dIdx[level][o];
-            const float dI_dy_val = w * od->sobelScale * (float)od->dIdy[level][o];
-            const float v0 = dI_dx_val * il.fx * invz;
-            const float v1 = dI_dy_val * il.fy * invz;
-            const float v2 = -(v0 * px + v1 * py) * invz;
-            row[0] = v0; row[1] = v1; row[2] = v2;
-            row[3] = -pz * v1 + py * v2;
-            row[4] = pz * v0 - px * v2;
-            row[5] = -py * v0 + px * v1;
+    const RgbModelArgs& m = ra.m[blockIdx.y];
+    OdomDev* const od = m.st;
+    if (od->rgb && !od->level_done) {
+        const int cols = ra.cols, rows = ra.rows, N = cols * rows;
+        __shared__ float s_sigma;
+        if (threadIdx.x < 64) {
+            const long long cnt = (long long)group_sum(m.icp_acc, 29, threadIdx.x);
+            const long long sg = (long long)group_sum(m.icp_acc, 30, threadIdx.x);
+            if (threadIdx.x == 0) s_sigma = sigma_val_from((int)cnt, (int)sg, od->rgbOnly);
         }
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        int4 raw = make_int4(0, 0, 0, 0);
+        if (i < N) raw = *reinterpret_cast<const int4*>(&m.corres[i]);
+        __syncthreads();
+        const float sigma = s_sigma;
+        const cf_cam il = ra.il;
+        unsigned long long acc[32];
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc[k] = 0ull - kMagicBits;
+        acc[28] = acc[29] = acc[30] = acc[31] = 0;
+        float row[7] = {0, 0, 0, 0, 0, 0, 0};
+        int found = 0;
+        if (i < N) {
+            const cf_dataterm c = *reinterpret_cast<const cf_dataterm*>(&raw);
+            if (c.valid) {
+                found = 1;
+                float w = sigma + fabsf(c.diff);
+                w = w > 1.19209290E-07F ? 1.0f / w : 1.0f;
+                if (sigma == -1) w = 1;
+                row[6] = -w * c.diff;
+                const float* cp = m.cloud + (size_t)(c.zero_y * cols + c.zero_x) * 3;
+                const float px = cp[0], py = cp[1], pz = cp[2];
+                const float invz = 1.0f / pz;
+                const int o = c.one_y * cols + c.one_x;
+                const float dI_dx_val = w * ra.sobelScale * (float)m.dIdx[o];
+                const float dI_dy_val = w * ra.sobelScale * (float)m.dIdy[o];
+                const float v0 = dI_dx_val * il.fx * invz;
+                const float v1 = dI_dy_val * il.fy * invz;
+                const float v2 = -(v0 * px + v1 * py) * invz;
+                row[0] = v0; row[1] = v1; row[2] = v2;
+                row[3] = -pz * v1 + py * v2;
+                row[4] = pz * v0 - px * v2;
+                row[5] = -py * v0 + px * v1;
+            }
+        }
+        se3_accumulate<kFixRGB>(row, acc);
+        acc[28] = (unsigned long long)found;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const unsigned long long v = wave_reduce32_u64(acc, lane);
+        block_commit32<4>(v, lane, wave, 4, m.rgb_acc + (size_t)(blockIdx.x % kGroups) * 32);
     }
-    se3_accumulate<kFixRGB>(row, acc);
-    acc[28] = (unsigned long long)found;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long v = wave_reduce32_u64(acc, lane);
-    block_commit32<4>(v, lane, wave, 4, od->rgb_acc + (size_t)(blockIdx.x % kGroups) * 32);
 }
 
 // ================================================================================================
@@ -544,90 +566,53 @@ __device__ inline void se3_unpack(const unsigned long long* t, int F, float A[36
     residual[1] = (float)(long long)t[28];
 }
 
-__device__ __forceinline__ void gn_solve_serial(OdomDev* od, const unsigned long long* s_icp, const unsigned long long* s_rgb, double* s_lastA,
-                                             double* s_lastb, double* s_result, double* s_dws, int* s_diws, int next_level, int last_of_level)
+// one word of se3_unpack: t < 27 -> A / b entry, 27 -> sum of squared residuals, 28 -> inlier count
+__device__ __forceinline__ void se3_unpack_word(const unsigned long long* sums, int t, int F, float* A, float* b, float* residual)
 {
-    const int skip = od->level_done;
-    if (!skip) {
-        const long long rgbSize = (long long)s_icp[29], sigma = (long long)s_icp[30];
-        const float tmpError = (float)(sqrt((double)(int)sigma) / (double)(int)rgbSize);
-        bool stop = false;
-        if (od->rgbOnly && tmpError > od->lastRGBError) { stop = true; od->level_done = 1; }
-        if (!stop) {
-            od->lastRGBError = tmpError;
-            od->stats.last_rgb_error = tmpError; od->stats.last_rgb_count = (float)(int)rgbSize;
-            float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6], dummy[2];
-            for (int k = 0; k < 36; k++) { A_icp[k] = 0; A_rgb[k] = 0; }
-            for (int k = 0; k < 6; k++) { b_icp[k] = 0; b_rgb[k] = 0; }
-            if (od->icp) se3_unpack(s_icp, kFixICP, A_icp, b_icp, od->residual);
-            od->stats.last_icp_error = sqrtf(od->residual[0]) / od->residual[1];
-            od->stats.last_icp_count = od->residual[1];
-            if (od->rgb) se3_unpack(s_rgb, kFixRGB, A_rgb, b_rgb, dummy);
-            double* lastA = s_lastA; double* lastb = s_lastb; double* result = s_result;
-            if (od->icp && od->rgb) {
-                const double w = od->icpWeight;
-                for (int k = 0; k < 36; k++) lastA[k] = (double)A_rgb[k] + w * w * (double)A_icp[k];
-                for (int k = 0; k < 6; k++) lastb[k] = (double)b_rgb[k] + w * (double)b_icp[k];
-            } else if (od->icp) {
-                for (int k = 0; k < 36; k++) lastA[k] = A_icp[k];
-                for (int k = 0; k < 6; k++) lastb[k] = b_icp[k];
-            } else {
-                for (int k = 0; k < 36; k++) lastA[k] = A_rgb[k];
-                for (int k = 0; k < 6; k++) lastb[k] = b_rgb[k];
-            }
-            ldlt_solve<double, 6>(lastA, lastb, result, 2.2250738585072014e-308, s_dws, s_diws);
-            for (int k = 0; k < 36; k++) od->stats.lastA[k] = lastA[k];
-            for (int k = 0; k < 6; k++) od->stats.lastb[k] = lastb[k];
-            // computeUpdateSE3
-            double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rr[9], nrt[16];
-            const double rvec[3] = {result[3], result[4], result[5]};
-            rodrigues(rvec, Rr);
-            for (int r = 0; r < 3; r++) {
-                upd[r * 4 + 0] = Rr[r * 3 + 0]; upd[r * 4 + 1] = Rr[r * 3 + 1]; upd[r * 4 + 2] = Rr[r * 3 + 2];
-                upd[r * 4 + 3] = result[r];
-            }
-            mul44(upd, od->resultRt, nrt);
-            for (int k = 0; k < 16; k++) od->resultRt[k] = nrt[k];
-            float Ro[9], to[3];
-            for (int r = 0; r < 3; r++) {
-                Ro[r * 3 + 0] = (float)nrt[r * 4 + 0]; Ro[r * 3 + 1] = (float)nrt[r * 4 + 1]; Ro[r * 3 + 2] = (float)nrt[r * 4 + 2];
-                to[r] = (float)nrt[r * 4 + 3];
-            }
-            const float Rinv[9] = {Ro[0], Ro[3], Ro[6], Ro[1], Ro[4], Ro[7], Ro[2], Ro[5], Ro[8]};
-            float tinv[3];
-            for (int r = 0; r < 3; r++) tinv[r] = -(Rinv[r * 3 + 0] * to[0] + Rinv[r * 3 + 1] * to[1] + Rinv[r * 3 + 2] * to[2]);
-            float Rc[9];
-            mul33<float>(od->Rprev, Rinv, Rc);
-            for (int k = 0; k < 9; k++) od->Rcurr[k] = Rc[k];
-            for (int r = 0; r < 3; r++)
-                od->tcurr[r] = (od->Rprev[r * 3 + 0] * tinv[0] + od->Rprev[r * 3 + 1] * tinv[1] + od->Rprev[r * 3 + 2] * tinv[2]) + od->tprev[r];
-        }
+    if (t < 27) {
+        int i = 0, rem = t;
+        while (rem >= 7 - i) { rem -= 7 - i; i++; }
+        const int j = i + rem;
+        const float value = fix_to_f32((long long)sums[t], F);
+        if (j == 6) b[i] = value;
+        else A[j * 6 + i] = A[i * 6 + j] = value;
+    } else if (residual) {
+        if (t == 27) residual[0] = fix_to_f32((long long)sums[27], F);
+        else if (t == 28) residual[1] = (float)(long long)sums[28];
     }
-    if (last_of_level) { od->level_done = 0; od->lastRGBError = 3.402823466e+38F; }
-    if (next_level >= 0) prepare_iteration(od, next_level);
 }
 
-
-__global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int level, int next_level, int last_of_level)
+// The solve is latency-bound serial work (f64 LDL^T, Rodrigues, SE3 products) on a nearly idle GPU, so:
+//  * every pointer arrives in the kernarg segment and the whole device-resident state is staged through LDS
+//    (no dependent global round trips),
+//  * the embarrassingly parallel pieces (group totals, fixed-point -> f32 unpack, f64 combine, 4x4 / 3x3
+//    products) are spread over lanes with exactly the element expressions of the serial helpers, and K^-1
+//    of the next level is formed by another wave while lane 0 factorises,
+//  * only the pivoted LDL^T + Rodrigues and the 3x3 pose composition stay on one lane.
+// The solve is latency-bound serial work (f64 LDL^T, Rodrigues, SE3 products) on a nearly idle GPU, so:
+//  * the whole device-resident state is staged through LDS (no dependent global round trips),
+//  * the parallel pieces (group totals, fixed-point -> f32 unpack, f64 combine, 4x4 / 3x3 products) are spread
+//    over lanes with exactly the element expressions of the serial helpers, the 6x6 pivoted LDL^T runs across
+//    one wave (ldlt_solve6_wave), and K^-1 of the next level is formed by another wave meanwhile,
+//  * only Rodrigues and the 3x3 pose composition stay on one lane.
+// Must be called by all 256 threads of a workgroup.
+__device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* icp_acc, unsigned long long* rgb_acc, int next_level,
+                                              int last_of_level)
 {
-    // Everything this kernel dereferences arrives in the kernarg segment, and the whole device-resident
-    // state is staged through LDS: the serial solve below then runs on LDS latency instead of a chain of
-    // dependent global round trips (measured 12.9 us -> see profiles/).
-    OdomDev* const god = args.od[blockIdx.x];
-    unsigned long long* const icp_acc = args.icp_acc[blockIdx.x];
-    unsigned long long* const rgb_acc = args.rgb_acc[blockIdx.x];
     __shared__ OdomDev s_od;
     __shared__ unsigned long long s_icp[32], s_rgb[32];
     __shared__ unsigned long long s_part[2][8][32];
-    __shared__ double s_lastA[36], s_lastb[6], s_result[6], s_dws[48];
-    __shared__ int s_diws[6];
+    __shared__ float s_Af[2][36], s_bf[2][6];  // [0] ICP, [1] RGB
+    __shared__ double s_lastA[36], s_lastb[6], s_result[6];
+    __shared__ double s_upd[16], s_nrt[16], s_K[9], s_Kinv[9], s_Rt[16], s_tmp[9];
     static_assert(sizeof(OdomDev) % 4 == 0, "OdomDev is staged as 32-bit words");
     constexpr int kWords = (int)(sizeof(OdomDev) / 4);
     constexpr int kMutableFrom = (int)(offsetof(OdomDev, Rprev) / 4);
-    for (int k = threadIdx.x; k < kWords; k += 256) reinterpret_cast<unsigned*>(&s_od)[k] = reinterpret_cast<const unsigned*>(god)[k];
-    // 256 threads: word = t & 31, slice = t >> 5 (8 slices of 8 groups)
-    {
-        const int w = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int tid = threadIdx.x;
+    OdomDev* const od = &s_od;
+    for (int k = tid; k < kWords; k += 256) reinterpret_cast<unsigned*>(&s_od)[k] = reinterpret_cast<const unsigned*>(god)[k];
+    {   // 256 threads: word = t & 31, slice = t >> 5 (8 slices of 8 groups)
+        const int w = tid & 31, sl = tid >> 5;
         unsigned long long a = 0, b = 0;
         for (int g = sl * (kGroups / 8); g < (sl + 1) * (kGroups / 8); g++) {
             a += icp_acc[(size_t)g * 32 + w];
@@ -635,34 +620,132 @@ __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int le
         }
         s_part[0][sl][w] = a; s_part[1][sl][w] = b;
     }
+    if (tid >= 64 && tid < 64 + 72) (&s_Af[0][0])[tid - 64] = 0.f;
+    if (tid >= 192 && tid < 192 + 12) (&s_bf[0][0])[tid - 192] = 0.f;
     __syncthreads();
-    if (threadIdx.x < 32) {
+    if (tid < 32) {
         unsigned long long a = 0, b = 0;
-        for (int sl = 0; sl < 8; sl++) { a += s_part[0][sl][threadIdx.x]; b += s_part[1][sl][threadIdx.x]; }
-        s_icp[threadIdx.x] = a; s_rgb[threadIdx.x] = b;
+        for (int sl = 0; sl < 8; sl++) { a += s_part[0][sl][tid]; b += s_part[1][sl][tid]; }
+        s_icp[tid] = a; s_rgb[tid] = b;
+    }
+    // zero the accumulators for the next iteration
+    for (int k = tid; k < kGroups * 32; k += 256) { icp_acc[k] = 0; rgb_acc[k] = 0; }
+    __syncthreads();
+
+    // uniform decisions (RGBDOdometry.cpp:371-392), evaluated redundantly by every lane
+    bool active = od->level_done == 0, stop = false;
+    float tmpError = 0.f; int rgbCount = 0;
+    if (active) {
+        const long long rgbSize = (long long)s_icp[29], sigma = (long long)s_icp[30];
+        rgbCount = (int)rgbSize;
+        tmpError = (float)(sqrt((double)(int)sigma) / (double)(int)rgbSize);
+        if (od->rgbOnly && tmpError > od->lastRGBError) { stop = true; active = false; }
+    }
+    const bool useIcp = od->icp != 0, useRgb = od->rgb != 0;
+    if (active) {
+        if (tid < 29 && useIcp) se3_unpack_word(s_icp, tid, kFixICP, s_Af[0], s_bf[0], od->residual);
+        if (tid >= 32 && tid < 59 && useRgb) se3_unpack_word(s_rgb, tid - 32, kFixRGB, s_Af[1], s_bf[1], nullptr);
     }
     __syncthreads();
-    // zero the accumulators for the next iteration
-    for (int k = threadIdx.x; k < kGroups * 32; k += 256) { icp_acc[k] = 0; rgb_acc[k] = 0; }
-
-    if (threadIdx.x == 0) gn_solve_serial(&s_od, s_icp, s_rgb, s_lastA, s_lastb, s_result, s_dws, s_diws, next_level, last_of_level);
+    if (tid == 0) {
+        if (stop) od->level_done = 1;
+        if (active) {
+            od->lastRGBError = tmpError;
+            od->stats.last_rgb_error = tmpError; od->stats.last_rgb_count = (float)rgbCount;
+            od->stats.last_icp_error = sqrtf(od->residual[0]) / od->residual[1];
+            od->stats.last_icp_count = od->residual[1];
+        }
+    }
+    if (active && tid < 42) {
+        const bool isA = tid < 36;
+        const int k = isA ? tid : tid - 36;
+        const float vi = isA ? s_Af[0][k] : s_bf[0][k], vr = isA ? s_Af[1][k] : s_bf[1][k];
+        double v;
+        if (useIcp && useRgb) {
+            const double w = od->icpWeight;
+            v = isA ? (double)vr + w * w * (double)vi : (double)vr + w * (double)vi;
+        } else v = useIcp ? (double)vi : (double)vr;
+        if (isA) { s_lastA[k] = v; od->stats.lastA[k] = v; }
+        else { s_lastb[k] = v; od->stats.lastb[k] = v; }
+    }
     __syncthreads();
-    for (int k = kMutableFrom + threadIdx.x; k < kWords; k += 256) reinterpret_cast<unsigned*>(god)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
-}
-
-// divergence guard (RGBDOdometry.cpp:464-467)
-__global__ void gn_finish_kernel(OdomDev* const* __restrict__ models)
-{
-    OdomDev* od = models[blockIdx.x];
-    if (threadIdx.x != 0) return;
-    if (od->rgb) {
+    if (active && tid < 64) ldlt_solve6_wave(tid < 36 ? s_lastA[tid] : 0.0, s_lastb, s_result, 2.2250738585072014e-308, tid);
+    if (active && tid == 0) {
+        // computeUpdateSE3 (OdometryProvider.h:69-89)
+        double Rr[9];
+        const double rvec[3] = {s_result[3], s_result[4], s_result[5]};
+        rodrigues(rvec, Rr);
+        for (int r = 0; r < 3; r++) {
+            s_upd[r * 4 + 0] = Rr[r * 3 + 0]; s_upd[r * 4 + 1] = Rr[r * 3 + 1]; s_upd[r * 4 + 2] = Rr[r * 3 + 2];
+            s_upd[r * 4 + 3] = s_result[r];
+        }
+        s_upd[12] = 0; s_upd[13] = 0; s_upd[14] = 0; s_upd[15] = 1;
+    }
+    if (next_level >= 0 && tid == 64) {  // another wave: intrinsics of the next iteration's level
+        double K[9], Kinv[9];
+        k_matrix(cam_level(od->intr, next_level), K);
+        inv33<double>(K, Kinv);
+        for (int k = 0; k < 9; k++) { s_K[k] = K[k]; s_Kinv[k] = Kinv[k]; }
+    }
+    __syncthreads();
+    if (active && tid < 16) {  // mul44(upd, resultRt) element (i, j)
+        const int i = tid >> 2, j = tid & 3;
+        double s = s_upd[i * 4 + 0] * od->resultRt[0 * 4 + j];
+        s = s + s_upd[i * 4 + 1] * od->resultRt[1 * 4 + j];
+        s = s + s_upd[i * 4 + 2] * od->resultRt[2 * 4 + j];
+        s = s + s_upd[i * 4 + 3] * od->resultRt[3 * 4 + j];
+        s_nrt[tid] = s;
+    }
+    __syncthreads();
+    if (active && tid < 16) od->resultRt[tid] = s_nrt[tid];
+    if (active && tid == 32) {  // pose composition in f32 (RGBDOdometry.cpp:449-461)
+        float Ro[9], to[3];
+        for (int r = 0; r < 3; r++) {
+            Ro[r * 3 + 0] = (float)s_nrt[r * 4 + 0]; Ro[r * 3 + 1] = (float)s_nrt[r * 4 + 1]; Ro[r * 3 + 2] = (float)s_nrt[r * 4 + 2];
+            to[r] = (float)s_nrt[r * 4 + 3];
+        }
+        const float Rinv[9] = {Ro[0], Ro[3], Ro[6], Ro[1], Ro[4], Ro[7], Ro[2], Ro[5], Ro[8]};
+        float tinv[3];
+        for (int r = 0; r < 3; r++) tinv[r] = -(Rinv[r * 3 + 0] * to[0] + Rinv[r * 3 + 1] * to[1] + Rinv[r * 3 + 2] * to[2]);
+        float Rc[9];
+        mul33<float>(od->Rprev, Rinv, Rc);
+        for (int k = 0; k < 9; k++) od->Rcurr[k] = Rc[k];
+        for (int r = 0; r < 3; r++)
+            od->tcurr[r] = (od->Rprev[r * 3 + 0] * tinv[0] + od->Rprev[r * 3 + 1] * tinv[1] + od->Rprev[r * 3 + 2] * tinv[2]) + od->tprev[r];
+    }
+    if (tid == 0 && last_of_level) { od->level_done = 0; od->lastRGBError = 3.402823466e+38F; }
+    __syncthreads();
+    if (next_level >= 0) {  // prepare_iteration(od, next_level), spread over lanes
+        if (tid == 0) inv44_affine(od->resultRt, s_Rt);
+        __syncthreads();
+        if (tid < 9) {  // tmp = K * R
+            const int i = tid / 3, j = tid % 3;
+            s_tmp[tid] = s_K[i * 3 + 0] * s_Rt[0 * 4 + j] + s_K[i * 3 + 1] * s_Rt[1 * 4 + j] + s_K[i * 3 + 2] * s_Rt[2 * 4 + j];
+        }
+        __syncthreads();
+        if (tid < 9) {
+            const int i = tid / 3, j = tid % 3;
+            od->krkInv[tid] = (float)(s_tmp[i * 3 + 0] * s_Kinv[0 * 3 + j] + s_tmp[i * 3 + 1] * s_Kinv[1 * 3 + j] + s_tmp[i * 3 + 2] * s_Kinv[2 * 3 + j]);
+        } else if (tid >= 16 && tid < 19) {
+            const int r = tid - 16;
+            od->kt[r] = (float)(s_K[r * 3 + 0] * s_Rt[3] + s_K[r * 3 + 1] * s_Rt[7] + s_K[r * 3 + 2] * s_Rt[11]);
+        }
+    } else if (tid == 0 && od->rgb) {  // end of the schedule: divergence guard (RGBDOdometry.cpp:464-467)
         const float d0 = od->tcurr[0] - od->tprev[0], d1 = od->tcurr[1] - od->tprev[1], d2 = od->tcurr[2] - od->tprev[2];
         if ((double)sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
             for (int k = 0; k < 9; k++) od->Rcurr[k] = od->Rprev[k];
             for (int k = 0; k < 3; k++) od->tcurr[k] = od->tprev[k];
         }
     }
+    __syncthreads();
+    for (int k = kMutableFrom + tid; k < kWords; k += 256) reinterpret_cast<unsigned*>(god)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
 }
+
+__global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int next_level, int last_of_level)
+{
+    gn_solve_body(args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level);
+}
+
 
 // total of the grouped accumulator -> out[32] (stand-alone steps)
 __global__ void __launch_bounds__(64) acc_total_kernel(const unsigned long long* __restrict__ acc, unsigned long long* __restrict__ out)
@@ -674,32 +757,45 @@ __global__ void __launch_bounds__(64) acc_total_kernel(const unsigned long long*
 }
 
 // ------------------------------------------------------------------------------ launchers ----
+// ev0/ev1 (nullable) receive the dispatch's own begin/end timestamps (the figures rocprofv3 reports), not the
+// stream time around it.  n_res_blocks > 0 appends the RGB residual workgroups to the same launch.
 template <int TAG>
-static void launch_icp_kernel(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, hipEvent_t ev0, hipEvent_t ev1)
+static void launch_icp_kernel(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, const RgbArgs& ra, bool icp, int n_res_blocks, int n,
+                              hipEvent_t ev0, hipEvent_t ev1)
 {
     const int N = args.cols * args.rows;
     const int per_block = cfg.threads * cfg.ppt;
     const int nlog = (N + per_block - 1) / per_block;
-    const dim3 grid(((nlog + 7) / 8) * 8, n);
-    // ev0/ev1 (nullable) receive the dispatch's own begin/end timestamps (the figures rocprofv3 reports),
-    // not the stream time around it
+    const int n_icp_blocks = icp ? ((nlog + 7) / 8) * 8 : 0;
+    const dim3 grid(n_icp_blocks + n_res_blocks, n);
     switch (cfg.ppt) {
-        case 4: hipExtLaunchKernelGGL((icp_reduce_kernel<4, TAG>), grid, dim3(cfg.threads), 0, s, ev0, ev1, 0, args); break;
-        case 2: hipExtLaunchKernelGGL((icp_reduce_kernel<2, TAG>), grid, dim3(cfg.threads), 0, s, ev0, ev1, 0, args); break;
-        default: hipExtLaunchKernelGGL((icp_reduce_kernel<1, TAG>), grid, dim3(cfg.threads), 0, s, ev0, ev1, 0, args); break;
+        case 4: hipExtLaunchKernelGGL((icp_reduce_kernel<4, TAG>), grid, dim3(cfg.threads), 0, s, ev0, ev1, 0, args, ra, n_icp_blocks); break;
+        case 2: hipExtLaunchKernelGGL((icp_reduce_kernel<2, TAG>), grid, dim3(cfg.threads), 0, s, ev0, ev1, 0, args, ra, n_icp_blocks); break;
+        default: hipExtLaunchKernelGGL((icp_reduce_kernel<1, TAG>), grid, dim3(cfg.threads), 0, s, ev0, ev1, 0, args, ra, n_icp_blocks); break;
     }
+}
+
+static void launch_icp_rgbres(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, const RgbArgs& ra, bool icp, bool rgb, int n, int level,
+                              hipEvent_t ev0, hipEvent_t ev1)
+{
+    const int N = (icp ? args.cols * args.rows : ra.cols * ra.rows);
+    const int n_res_blocks = rgb ? (N + cfg.threads - 1) / cfg.threads : 0;
+    // distinct symbols per pyramid level so that rocprofv3 --stats separates them
+    if (level == 0) launch_icp_kernel<0>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
+    else if (level == 1) launch_icp_kernel<1>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
+    else launch_icp_kernel<2>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
 }
 
 void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level, hipEvent_t ev0, hipEvent_t ev1)
 {
-    // distinct symbols per pyramid level so that rocprofv3 --stats separates them
-    if (level == 0) launch_icp_kernel<0>(s, cfg, args, n, ev0, ev1);
-    else if (level == 1) launch_icp_kernel<1>(s, cfg, args, n, ev0, ev1);
-    else launch_icp_kernel<2>(s, cfg, args, n, ev0, ev1);
+    launch_icp_rgbres(s, cfg, args, RgbArgs{}, true, false, n, level, ev0, ev1);
 }
 
-void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, const IcpArgs icp_args[3], int n, int width,
-                     int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, ProfSink* prof)
+// Per Gauss-Newton iteration: ONE launch for {ICP reduction || RGB residual}, then rgbStep, then the one-workgroup
+// solve.  (Letting rgbStep's last workgroup run the solve needs a device-scope release fence per workgroup, which on
+// this multi-XCD part writes back the XCD's L2: measured 53 us instead of 6 + 8 us -- kept as separate launches.)
+void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n,
+                     int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, ProfSink* prof)
 {
     int iterations[3];
     iterations[0] = fast_odom ? 3 : 10;
@@ -723,36 +819,35 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, con
                 next_level = i - 1;
                 while (next_level >= 0 && iterations[next_level] == 0) next_level--;
             }
-            if (rgb) rgb_residual_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(d_models, i);
-            if (icp) {
+            {
                 // the roofline figure is quoted on the dominant kernel: the level-0 instantiation
                 const bool timed = prof && prof->enabled && i == 0 && prof->used + 4 <= prof->capacity;
                 IcpArgs a = icp_args[i];
                 a.flags = (i == 0 && last_of_level) ? 1 : 0;
-                launch_icp_level(s, cfg, a, n, i, timed ? prof->events[prof->used] : nullptr, timed ? prof->events[prof->used + 1] : nullptr);
+                launch_icp_rgbres(s, cfg, a, rgb_args[i], icp, rgb, n, i, timed ? prof->events[prof->used] : nullptr,
+                                  timed ? prof->events[prof->used + 1] : nullptr);
                 if (timed) {
                     prof->used += 2;
-                    prof->bytes += (uint64_t)N * (24 + 24 * (uint64_t)n);
+                    prof->bytes += (uint64_t)N * ((icp ? 24 + 24 * (uint64_t)n : 0) + (rgb ? kRgbResidualBytes * (uint64_t)n : 0));
                     prof->launches += 1;
                 }
             }
-            if (rgb) rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(d_models, i);
-            gn_solve_kernel<<<n, 256, 0, s>>>(gn, i, next_level, last_of_level ? 1 : 0);
+            if (rgb) rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(rgb_args[i]);
+            gn_solve_kernel<<<n, 256, 0, s>>>(gn, next_level, last_of_level ? 1 : 0);
         }
     }
-    gn_finish_kernel<<<n, 64, 0, s>>>(d_models);
 }
 
-// ---- stand-alone steps (operate on a scratch OdomDev prepared by cabi.cpp) -------------------
-void launch_rgb_residual_models(hipStream_t s, OdomDev* const* d_models, int n, int width, int height, int level)
+// ---- stand-alone steps (C-ABI parity with computeRgbResidual / rgbStep) -------------------
+void launch_rgb_residual(hipStream_t s, const RgbArgs& ra, int n)
 {
-    const int N = (width >> level) * (height >> level);
-    rgb_residual_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(d_models, level);
+    const int N = ra.cols * ra.rows;
+    rgb_residual_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(ra);
 }
-void launch_rgb_step_models(hipStream_t s, OdomDev* const* d_models, int n, int width, int height, int level)
+void launch_rgb_step(hipStream_t s, const RgbArgs& ra, int n)
 {
-    const int N = (width >> level) * (height >> level);
-    rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(d_models, level);
+    const int N = ra.cols * ra.rows;
+    rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(ra);
 }
 void launch_acc_total(hipStream_t s, const unsigned long long* acc, unsigned long long* out)
 {
