@@ -54,6 +54,7 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     if (int r = dmalloc(ctx, &ctx->d_out, 64)) return r;
     if (int r = dmalloc(ctx, &ctx->d_scratch_state, 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_model_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
+    if (int r = dmalloc(ctx, &ctx->d_so3_sync, (size_t)ctx->cfg.max_models + 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_cand_scratch, (size_t)cfg->width * cfg->height)) return r;
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scratch_state), sizeof(OdomDev)));
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_model_ptrs), sizeof(OdomDev*) * (ctx->cfg.max_models + 1)));
@@ -71,7 +72,7 @@ void cf_destroy(cf_ctx* ctx)
     if (!ctx) return;
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_acc_a); (void)hipFree(ctx->d_acc_b); (void)hipFree(ctx->d_out);
-    (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_cand_scratch);
+    (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_cand_scratch);
     (void)hipHostFree(ctx->h_scratch_state); (void)hipHostFree(ctx->h_model_ptrs); (void)hipHostFree(ctx->h_out);
     if (ctx->prof.events) {
         for (int i = 0; i < ctx->prof.capacity; i++) (void)hipEventDestroy(ctx->prof.events[i]);
@@ -550,7 +551,7 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     fill_icp_args(ctx, ods, n, icp_args);
     RgbArgs rgb_args[3];
     fill_rgb_args(ctx, ods, n, rgb_args);
-    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, icp_args, rgb_args, n, ctx->cfg.width, ctx->cfg.height,
+    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, icp_args, rgb_args, n, ctx->cfg.width, ctx->cfg.height,
                     opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, &ctx->prof);
     LAUNCHCHK(ctx);
     for (int m = 0; m < n; m++)

@@ -55,6 +55,7 @@ struct cf_model {
     float *fill_vertex = nullptr, *fill_normal = nullptr;
     uint8_t* fill_image = nullptr;
     float *tcx = nullptr, *tcy = nullptr;
+    float* rays = nullptr;  // per-pixel view rays of the splat fragment stage, float4 [H*W]
     float inv_fx = 0, inv_fy = 0;
 };
 
@@ -137,6 +138,8 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     if (int r = dmalloc(ctx, &m->fill_image, N * 4)) return r;
     if (int r = dmalloc(ctx, &m->tcx, (size_t)W)) return r;
     if (int r = dmalloc(ctx, &m->tcy, (size_t)H)) return r;
+    if (int r = dmalloc(ctx, &m->rays, N * 4)) return r;
+    launch_splat_rays(ctx->stream, ctx_cam(ctx), W, H, m->rays);
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->h_counts), sizeof(unsigned) * 4));
     // texcoords exactly as the reference builds its uv buffer (Model.cpp:166-170)
     std::vector<float> tx(W), ty(H);
@@ -156,7 +159,7 @@ void cf_model_destroy(cf_model* m)
     void* ptrs[] = {m->buf[0], m->buf[1], m->staged, m->flags, m->offsets, m->block_sums, m->d_count, m->d_nfresh, m->d_tmp2, m->records,
                     m->fresh, m->new_flags, m->new_offsets, m->owner, m->fb_rec, m->fb_raw, m->fb_filt, m->keys, m->index, m->vertConf,
                     m->colorTime, m->normRad, m->splat_image, m->splat_vertex, m->splat_normal, m->splat_time, m->fill_vertex,
-                    m->fill_normal, m->fill_image, m->tcx, m->tcy};
+                    m->fill_normal, m->fill_image, m->tcx, m->tcy, m->rays};
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(m->h_counts);
     delete m;
@@ -216,7 +219,7 @@ int cf_model_combined_predict(cf_model* m, const float pose[16], float maxDepth,
     float t_inv[16];
     inv44f(pose, t_inv);
     launch_combined_predict(ctx->stream, m->buf[m->target], m->d_count, m->count_host, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
-                            maxDepth, confThreshold, time, maxTime, timeDelta, m->keys, m->splat_image, m->splat_vertex, m->splat_normal,
+                            maxDepth, confThreshold, time, maxTime, timeDelta, m->rays, m->keys, m->splat_image, m->splat_vertex, m->splat_normal,
                             m->splat_time);
     LAUNCHCHK(ctx);
     return CF_OK;

@@ -21,6 +21,7 @@ struct cf_ctx {
     cf::OdomDev** d_model_ptrs = nullptr;
     cf::OdomDev** h_model_ptrs = nullptr;  // pinned
     uint8_t* d_cand_scratch = nullptr;
+    cf::So3Sync* d_so3_sync = nullptr;  // [max_models]
     cf::ProfSink prof{};
     double prof_ms_accum = 0;
     void set_error(const std::string& m);

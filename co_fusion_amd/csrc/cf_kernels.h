@@ -128,7 +128,10 @@ struct ProfSink {  // hipEvent pairs recorded around every ICP-reduce launch whe
 };
 
 // device-resident Gauss-Newton loop over `n` models (lock-step; blockIdx.y = model)
-void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */,
+// cross-workgroup state of the SO3 pre-alignment (zero between launches): per-iteration totals + arrival counters
+constexpr int kSo3Blocks = 16;
+struct So3Sync { unsigned long long acc[10][16]; unsigned arrive, depart; };
+void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */, So3Sync* so3_syncs /* [n] */,
                      const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid,
                      bool fast_odom, bool rgb, bool icp, ProfSink* prof);
 
@@ -157,9 +160,10 @@ void launch_init(hipStream_t s, const float* raw, const float* filt, const unsig
 void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                             int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, unsigned* index,
                             float* vertConf, float* colorTime, float* normRad);
+void launch_splat_rays(hipStream_t s, cf_cam cam, int cols, int rows, float* rays /* [rows*cols*4] */);
 void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                              int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
-                             unsigned long long* keys, uint8_t* image, float* vertexConf, float* normalRad, uint16_t* time16);
+                             const float* rays, unsigned long long* keys, uint8_t* image, float* vertexConf, float* normalRad, uint16_t* time16);
 void launch_fill_in(hipStream_t s, const float* pv, const float* pn, const uint8_t* pimg, const float* depth, const uint8_t* rgba, int cols,
                     int rows, cf_cam cam, float inv_fx, float inv_fy, int pass_geom, int pass_rgb, float* ov, float* on, uint8_t* oi);
 void launch_fill_ratio(hipStream_t s, const uint8_t* pimg, int cols, int rows, unsigned* out2);

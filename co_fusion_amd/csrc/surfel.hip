@@ -42,18 +42,28 @@ __global__ void __launch_bounds__(kB) bilateral_kernel(const float* __restrict__
     const int y = i / cols, x = i - y * cols;
     const float value = depth[i];
     if (value > maxD || value < 0.3f) { out[i] = 0; return; }
-    const int D = 13;
-    const int tx = min(x - D / 2 + D, cols), ty = min(y - D / 2 + D, rows);
+    // The kernel is VALU-bound (169 taps x exp per pixel), so the 13x13 window is fully unrolled: the spatial term
+    // ((float)x-(float)cx)^2 + ((float)y-(float)cy)^2 is an exact small integer, hence space2 * 0.024691358f folds to
+    // a per-tap constant with the same value the shader computes at run time.  Taps outside the image are skipped
+    // (the shader's loop bounds), in the same row-major order.
     float sum1 = 0, sum2 = 0;
-    for (int cy = max(y - D / 2, 0); cy < ty; ++cy)
-        for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
-            const float tmp = depth[cy * cols + cx];
-            const float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) + ((float)y - (float)cy) * ((float)y - (float)cy);
+#pragma unroll
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int cy = y + dy;
+        if (cy < 0 || cy >= rows) continue;
+        const float* __restrict__ rowp = depth + cy * cols + x;
+#pragma unroll
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int cx = x + dx;
+            if (cx < 0 || cx >= cols) continue;
+            const float tmp = rowp[dx];
+            const float space2 = (float)(dx * dx + dy * dy);
             const float color2 = (value - tmp) * (value - tmp);
             const float weight = det_expf(-(space2 * 0.024691358f + color2 * 555.556f));
             sum1 += tmp * weight;
             sum2 += weight;
         }
+    }
     out[i] = sum1 / sum2;
 }
 
@@ -259,10 +269,14 @@ __device__ __forceinline__ bool splat_setup(const float4 pc, const float4 ct, co
 }
 
 // fragment: returns false when discarded; z = corrected depth
-__device__ __forceinline__ bool splat_fragment(const SplatSetup& s, cf_cam cam, int px, int py, float maxDepth, float& z)
+// `rays` holds normalized((px + 0.5 - cx) / fx, (py + 0.5 - cy) / fy, 1) per pixel (splat_rays_kernel): the
+// fragment shader's view ray depends only on the pixel, and its two divisions + normalisation (sqrt + 3 IEEE
+// divisions) were half of the VALU work of every fragment.
+__device__ __forceinline__ bool splat_fragment(const SplatSetup& s, const float4* __restrict__ rays, int cols, int px, int py, float maxDepth,
+                                               float& z)
 {
-    const float fx_ = (float)px + 0.5f, fy_ = (float)py + 0.5f;
-    const f3 l = normalized(f3{(fx_ - cam.cx) / cam.fx, (fy_ - cam.cy) / cam.fy, 1.0f});
+    const float4 lr = rays[py * cols + px];
+    const f3 l = {lr.x, lr.y, lr.z};
     const float k = s.pn / dot(l, s.n);
     const f3 cp = {k * l.x, k * l.y, k * l.z};
     const f3 diff = cp - s.ph;
@@ -272,9 +286,20 @@ __device__ __forceinline__ bool splat_fragment(const SplatSetup& s, cf_cam cam, 
     return true;
 }
 
+__global__ void __launch_bounds__(kB) splat_rays_kernel(cf_cam cam, int cols, int rows, float4* __restrict__ rays)
+{
+    const int q = blockIdx.x * kB + threadIdx.x;
+    if (q >= cols * rows) return;
+    const int py = q / cols, px = q - py * cols;
+    const float fx_ = (float)px + 0.5f, fy_ = (float)py + 0.5f;
+    const f3 l = normalized(f3{(fx_ - cam.cx) / cam.fx, (fy_ - cam.cy) / cam.fy, 1.0f});
+    rays[q] = make_float4(l.x, l.y, l.z, 0.f);
+}
+
 __global__ void __launch_bounds__(kB) splat_raster_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count, Mat4 t_inv,
                                                           cf_cam cam, int cols, int rows, float maxDepth, float confThreshold, int time,
-                                                          int maxTime, int timeDelta, unsigned long long* __restrict__ keys)
+                                                          int maxTime, int timeDelta, const float4* __restrict__ rays,
+                                                          unsigned long long* __restrict__ keys)
 {
     const unsigned id = blockIdx.x * kB + threadIdx.x;
     if (id >= *count) return;
@@ -285,13 +310,14 @@ __global__ void __launch_bounds__(kB) splat_raster_kernel(const float4* __restri
     for (int py = s.y_lo; py <= s.y_hi; py++)
         for (int px = s.x_lo; px <= s.x_hi; px++) {
             float z;
-            if (splat_fragment(s, cam, px, py, maxDepth, z)) atomicMin(&keys[py * cols + px], zkey(z, id));
+            if (splat_fragment(s, rays, cols, px, py, maxDepth, z)) atomicMin(&keys[py * cols + px], zkey(z, id));
         }
 }
 
 __global__ void __launch_bounds__(kB) splat_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_inv, cf_cam cam, int cols, int rows,
                                                            float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
-                                                           const unsigned long long* __restrict__ keys, uchar4* __restrict__ image,
+                                                           const float4* __restrict__ rays, const unsigned long long* __restrict__ keys,
+                                                           uchar4* __restrict__ image,
                                                            float4* __restrict__ vertexConf, float4* __restrict__ normalRad,
                                                            unsigned short* __restrict__ time16)
 {
@@ -310,7 +336,7 @@ __global__ void __launch_bounds__(kB) splat_resolve_kernel(const float4* __restr
     SplatSetup s;
     splat_setup(pc, ct, nr, t_inv, cam, cols, rows, maxDepth, confThreshold, time, maxTime, timeDelta, s);
     float z;
-    splat_fragment(s, cam, px, py, maxDepth, z);
+    splat_fragment(s, rays, cols, px, py, maxDepth, z);
     const f3 col = decode_color(ct.x);
     image[q] = make_uchar4((unsigned char)glsl_round(col.x * 255.0f), (unsigned char)glsl_round(col.y * 255.0f),
                            (unsigned char)glsl_round(col.z * 255.0f), 255);
@@ -640,17 +666,22 @@ void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned*
 }
 void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                              int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
-                             unsigned long long* keys, uint8_t* image, float* vertexConf, float* normalRad, uint16_t* time16)
+                             const float* rays, unsigned long long* keys, uint8_t* image, float* vertexConf, float* normalRad,
+                             uint16_t* time16)
 {
     const int N = cols * rows;
     (void)hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * N, s);
     const Mat4 T = mat4_from(t_inv);
     if (count_bound > 0)
         splat_raster_kernel<<<gridFor(count_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, cam, cols, rows, maxDepth,
-                                                                confThreshold, time, maxTime, timeDelta, keys);
+                                                                confThreshold, time, maxTime, timeDelta, reinterpret_cast<const float4*>(rays), keys);
     splat_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), T, cam, cols, rows, maxDepth, confThreshold, time, maxTime,
-                                                   timeDelta, keys, reinterpret_cast<uchar4*>(image), reinterpret_cast<float4*>(vertexConf),
+                                                   timeDelta, reinterpret_cast<const float4*>(rays), keys, reinterpret_cast<uchar4*>(image), reinterpret_cast<float4*>(vertexConf),
                                                    reinterpret_cast<float4*>(normalRad), time16);
+}
+void launch_splat_rays(hipStream_t s, cf_cam cam, int cols, int rows, float* rays)
+{
+    splat_rays_kernel<<<gridFor((long long)cols * rows), kB, 0, s>>>(cam, cols, rows, reinterpret_cast<float4*>(rays));
 }
 void launch_fill_in(hipStream_t s, const float* pv, const float* pn, const uint8_t* pimg, const float* depth, const uint8_t* rgba, int cols,
                     int rows, cf_cam cam, float inv_fx, float inv_fy, int pass_geom, int pass_rgb, float* ov, float* on, uint8_t* oi)

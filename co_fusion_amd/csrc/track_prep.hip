@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(kBlock) vertices_to_depth_kernel(const float4*
     depth[i] = (z > cutoff || z <= 0) ? qnan() : z;
 }
 
+constexpr int kGaussI[5] = {1, 4, 6, 4, 1};
 __constant__ float kGauss25[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
 
 // pyrDownKernelGaussF, cudafuncs.cu:333-364 (window excludes last row/col, weights anchored at the
@@ -133,17 +134,34 @@ __global__ void __launch_bounds__(kBlock) pyrdown_f32_kernel(const float* __rest
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= dcols * drows) return;
     const int y = i / dcols, x = i - y * dcols;
-    const int tx = min(2 * x - 2 + 5, scols - 1), ty = min(2 * y - 2 + 5, srows - 1);
     float sum = 0; int count = 0;
-    for (int cy = max(0, 2 * y - 2); cy < ty; ++cy)
-        for (int cx = max(0, 2 * x - 2); cx < tx; ++cx) {
-            const float s = src[cy * scols + cx];
-            if (!is_nan(s)) {
-                const float w = kGauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
-                sum += s * w;
-                count += (int)w;
+    if (2 * x - 2 >= 0 && 2 * y - 2 >= 0 && 2 * x + 3 <= scols - 1 && 2 * y + 3 <= srows - 1) {
+        // interior: the window is the full 5x5, all 25 loads are independent and the weights are literals
+        // (anchored at the window end: index 4-r, 4-c == r, c by symmetry); same row-major summation order
+        const float* __restrict__ p0 = src + (2 * y - 2) * scols + (2 * x - 2);
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const float s = p0[r * scols + c];
+                if (!is_nan(s)) {
+                    const int wi = kGaussI[r] * kGaussI[c];
+                    sum += s * (float)wi;
+                    count += wi;
+                }
             }
-        }
+    } else {
+        const int tx = min(2 * x - 2 + 5, scols - 1), ty = min(2 * y - 2 + 5, srows - 1);
+        for (int cy = max(0, 2 * y - 2); cy < ty; ++cy)
+            for (int cx = max(0, 2 * x - 2); cx < tx; ++cx) {
+                const float s = src[cy * scols + cx];
+                if (!is_nan(s)) {
+                    const float w = kGauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                    sum += s * w;
+                    count += (int)w;
+                }
+            }
+    }
     dst[i] = sum / (float)count;
 }
 
@@ -155,17 +173,32 @@ __global__ void __launch_bounds__(kBlock) pyrdown_u8_kernel(const uint8_t* __res
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= dcols * drows) return;
     const int y = i / dcols, x = i - y * dcols;
-    const int tx = min(2 * x - 2 + 5, scols - 1), ty = min(2 * y - 2 + 5, srows - 1);
     float sum = 0; int count = 0;
-    for (int cy = max(0, 2 * y - 2); cy < ty; ++cy)
-        for (int cx = max(0, 2 * x - 2); cx < tx; ++cx) {
-            const uint8_t s = src[cy * scols + cx];
-            if (s > 0) {
-                const float w = kGauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
-                sum += (float)s * w;
-                count += (int)w;
+    if (2 * x - 2 >= 0 && 2 * y - 2 >= 0 && 2 * x + 3 <= scols - 1 && 2 * y + 3 <= srows - 1) {
+        const uint8_t* __restrict__ p0 = src + (2 * y - 2) * scols + (2 * x - 2);
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const uint8_t s = p0[r * scols + c];
+                if (s > 0) {
+                    const int wi = kGaussI[r] * kGaussI[c];
+                    sum += (float)s * (float)wi;
+                    count += wi;
+                }
             }
-        }
+    } else {
+        const int tx = min(2 * x - 2 + 5, scols - 1), ty = min(2 * y - 2 + 5, srows - 1);
+        for (int cy = max(0, 2 * y - 2); cy < ty; ++cy)
+            for (int cx = max(0, 2 * x - 2); cx < tx; ++cx) {
+                const uint8_t s = src[cy * scols + cx];
+                if (s > 0) {
+                    const float w = kGauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
+                    sum += (float)s * w;
+                    count += (int)w;
+                }
+            }
+    }
     const float q = sum / (float)count;
     dst[i] = is_nan(q) ? (uint8_t)0 : (uint8_t)(int)q;
 }
@@ -190,14 +223,29 @@ __global__ void __launch_bounds__(kBlock) sobel_kernel(const uint8_t* __restrict
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= cols * rows) return;
     const int y = i / cols, x = i - y * cols;
-    float dxv = 0, dyv = 0; int k = 8;
-    for (int j = max(y - 1, 0); j <= min(y + 1, rows - 1); j++)
-        for (int c = max(x - 1, 0); c <= min(x + 1, cols - 1); c++) {
-            const float s = (float)src[j * cols + c];
-            dxv += s * kSobelX[k];
-            dyv += s * kSobelY[k];
-            --k;
-        }
+    float dxv = 0, dyv = 0;
+    constexpr float sx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+    constexpr float sy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+    if (x >= 1 && y >= 1 && x <= cols - 2 && y <= rows - 2) {  // interior: literal weights, independent loads
+        const uint8_t* __restrict__ p0 = src + (y - 1) * cols + (x - 1);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float s = (float)p0[r * cols + c];
+                dxv += s * sx[8 - (r * 3 + c)];
+                dyv += s * sy[8 - (r * 3 + c)];
+            }
+    } else {
+        int k = 8;
+        for (int j = max(y - 1, 0); j <= min(y + 1, rows - 1); j++)
+            for (int c = max(x - 1, 0); c <= min(x + 1, cols - 1); c++) {
+                const float s = (float)src[j * cols + c];
+                dxv += s * kSobelX[k];
+                dyv += s * kSobelY[k];
+                --k;
+            }
+    }
     dx[i] = (int16_t)(int)dxv;
     dy[i] = (int16_t)(int)dyv;
 }

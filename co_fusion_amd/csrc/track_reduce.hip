@@ -363,7 +363,7 @@ __device__ __forceinline__ void so3_gradient(const uint8_t* __restrict__ img, in
     gy = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
 }
 
-// one pass over the level-2 images by a single workgroup; totals[0..10] valid in thread 0..15 of LDS
+// one (grid-strided over blockIdx.x) pass over the level-2 images; this workgroup's totals[0..10] end up in LDS
 __device__ __forceinline__ void so3_pass(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
                                          const m33& B, const m33& Ki, const float* __restrict__ krlr, int cols, int rows,
                                          unsigned long long (*lds)[16], unsigned long long* totals)
@@ -376,7 +376,7 @@ __device__ __forceinline__ void so3_pass(const uint8_t* __restrict__ lastImage, 
     for (int k = 0; k < 16; k++) acc[k] = 0;
     const float a = krlr[0], b = krlr[1], c = krlr[2], d = krlr[3], e = krlr[4], f = krlr[5], g = krlr[6], h = krlr[7],
                 ii = krlr[8];
-    for (int k = threadIdx.x; k < N; k += T) {
+    for (int k = blockIdx.x * T + threadIdx.x; k < N; k += gridDim.x * T) {
         const int y = k / cols, x = k - y * cols;
         const f3 unwarped = {(float)x, (float)y, 1.0f};
         const f3 warped = mul(B, unwarped);
@@ -465,12 +465,18 @@ __global__ void __launch_bounds__(1024) so3_step_kernel(const uint8_t* __restric
     if (threadIdx.x < 16) out16[threadIdx.x] = totals[threadIdx.x];
 }
 
-// Whole SO3 pre-alignment (RGBDOdometry.cpp:239-310) in ONE launch: a persistent workgroup per
-// model iterates (pass -> 3x3 solve -> Rodrigues) up to 10 times with the data-dependent early
-// exits evaluated on the device.  Also seeds resultRt and the first iteration's krkInv/kt.
-__global__ void __launch_bounds__(1024) so3_prealign_kernel(OdomDev* const* __restrict__ models, int do_so3, int first_level)
+// Whole SO3 pre-alignment (RGBDOdometry.cpp:239-310) in ONE launch.  The pass over the 160x120 level is VALU-bound
+// on a single CU (10.5 us per iteration, measured), so kSo3Blocks co-resident workgroups per model share it:
+// each reduces its pixels, adds its 11 fixed-point totals to the iteration's slot of a global accumulator and
+// meets the others at an atomic arrival counter; every workgroup then reads the totals (device-scope atomic
+// loads) and runs the identical 3x3 solve + Rodrigues on its own LDS copy of the state, so nothing but integer
+// atomics crosses workgroups and the data-dependent early exits stay uniform.  The last workgroup to leave
+// re-zeroes the sync block for the next frame.  Also seeds resultRt and the first iteration's krkInv/kt.
+__global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __restrict__ models, So3Sync* __restrict__ syncs, int do_so3,
+                                                           int first_level)
 {
-    OdomDev* od = models[blockIdx.x];
+    OdomDev* od = models[blockIdx.y];
+    So3Sync* sync = syncs + blockIdx.y;
     __shared__ unsigned long long lds[16][16];
     __shared__ unsigned long long totals[16];
     __shared__ float s_basis[9], s_kinv[9], s_krlr[9];
@@ -483,16 +489,20 @@ __global__ void __launch_bounds__(1024) so3_prealign_kernel(OdomDev* const* __re
     __shared__ float s_jtj[9], s_jtr[3], s_delta[3], s_fws[15];
     __shared__ int s_iws[3];
     const int L = 2, cols = od->width >> L, rows = od->height >> L;
+    const bool lead = blockIdx.x == 0;  // the workgroup that publishes statistics and the final state
+    const unsigned G = gridDim.x;
     if (threadIdx.x == 0) {
         for (int k = 0; k < 9; k++) { s_resultR[k] = (k % 4 == 0) ? 1.0 : 0.0; s_lastResultR[k] = s_resultR[k]; s_Rlr[k] = (k % 4 == 0) ? 1.f : 0.f; }
         k_matrix(cam_level(od->intr, L), s_K);
         inv33<double>(s_K, s_Kinv);
         s_lastError = 3.402823466e+38F / 2; s_lastCount = 3.402823466e+38F / 2;
         s_done = 0;
-        od->stats.so3_iterations = 0; od->stats.last_so3_error = 0; od->stats.last_so3_count = 0;
+        if (lead) { od->stats.so3_iterations = 0; od->stats.last_so3_error = 0; od->stats.last_so3_count = 0; }
     }
     __syncthreads();
     if (do_so3) {
+        const uint8_t* __restrict__ lastNext = od->lastNextImage[L];
+        const uint8_t* __restrict__ next = od->nextImage[L];
         for (int it = 0; it < 10; it++) {
             if (threadIdx.x == 0) {
                 double tmp[9], H[9];
@@ -503,11 +513,30 @@ __global__ void __launch_bounds__(1024) so3_prealign_kernel(OdomDev* const* __re
             __syncthreads();
             m33 B, Ki;
             for (int k = 0; k < 9; k++) { B.m[k] = s_basis[k]; Ki.m[k] = s_kinv[k]; }
-            so3_pass(od->lastNextImage[L], od->nextImage[L], B, Ki, s_krlr, cols, rows, lds, totals);
+            so3_pass(lastNext, next, B, Ki, s_krlr, cols, rows, lds, totals);  // ends with this workgroup's totals in LDS
+            if (G > 1) {
+                if (threadIdx.x < 64) {  // wave 0: publish, arrive, wait, collect
+                    unsigned long long* slot = sync->acc[it];
+                    if (threadIdx.x < 11 && totals[threadIdx.x] != 0) atomicAdd(&slot[threadIdx.x], totals[threadIdx.x]);
+                    __threadfence();
+                    if (threadIdx.x == 0) {
+                        atomicAdd(&sync->arrive, 1u);
+                        const unsigned target = (unsigned)(it + 1) * G;
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(&sync->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                            if (++spins > (1u << 22)) break;  // never hang the GPU if the workgroups are not co-resident
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    __threadfence();
+                    if (threadIdx.x < 16) totals[threadIdx.x] = __hip_atomic_load(&slot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+            }
             if (threadIdx.x == 0) {
                 float jtj[9], jtr[3], residual[2];
                 so3_unpack(totals, jtj, jtr, residual);
-                od->stats.so3_iterations = it + 1;
+                if (lead) od->stats.so3_iterations = it + 1;
                 float err = sqrtf(residual[0]) / residual[1];
                 float cnt = residual[1];
                 if (err < s_lastError && (double)fabsf(s_lastError - cnt) < 0.001) {
@@ -531,13 +560,20 @@ __global__ void __launch_bounds__(1024) so3_prealign_kernel(OdomDev* const* __re
                     mul33<float>(ru, s_Rlr, nr);
                     for (int k = 0; k < 9; k++) { s_Rlr[k] = nr[k]; s_resultR[k] = nr[k]; }
                 }
-                od->stats.last_so3_error = err; od->stats.last_so3_count = cnt;
+                if (lead) { od->stats.last_so3_error = err; od->stats.last_so3_count = cnt; }
             }
             __syncthreads();
             if (s_done) break;
         }
+        if (G > 1 && threadIdx.x == 0) {  // last one out resets the sync block (all workgroups are past their final read)
+            if (atomicAdd(&sync->depart, 1u) == G - 1) {
+                for (int it = 0; it < 10; it++)
+                    for (int w = 0; w < 16; w++) sync->acc[it][w] = 0;
+                sync->arrive = 0; sync->depart = 0;
+            }
+        }
     }
-    if (threadIdx.x == 0) {
+    if (lead && threadIdx.x == 0) {
         for (int k = 0; k < 16; k++) od->resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
         if (do_so3)
             for (int x = 0; x < 3; x++)
@@ -794,8 +830,8 @@ void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, 
 // Per Gauss-Newton iteration: ONE launch for {ICP reduction || RGB residual}, then rgbStep, then the one-workgroup
 // solve.  (Letting rgbStep's last workgroup run the solve needs a device-scope release fence per workgroup, which on
 // this multi-XCD part writes back the XCD's L2: measured 53 us instead of 6 + 8 us -- kept as separate launches.)
-void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n,
-                     int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, ProfSink* prof)
+void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const IcpArgs icp_args[3],
+                     const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, ProfSink* prof)
 {
     int iterations[3];
     iterations[0] = fast_odom ? 3 : 10;
@@ -803,7 +839,7 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, con
     iterations[2] = pyramid ? 4 : 0;
     int first_level = 2;
     while (first_level > 0 && iterations[first_level] == 0) first_level--;
-    so3_prealign_kernel<<<n, 1024, 0, s>>>(d_models, so3 ? 1 : 0, first_level);
+    so3_prealign_kernel<<<dim3(so3 ? kSo3Blocks : 1, n), 256, 0, s>>>(d_models, so3_syncs, so3 ? 1 : 0, first_level);
     GnArgs gn{};
     for (int m = 0; m < n; m++) {
         gn.od[m] = const_cast<OdomDev*>(icp_args[0].m[m].st);
