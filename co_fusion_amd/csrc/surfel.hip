@@ -301,17 +301,27 @@ __global__ void __launch_bounds__(kB) splat_raster_kernel(const float4* __restri
                                                           int maxTime, int timeDelta, const float4* __restrict__ rays,
                                                           unsigned long long* __restrict__ keys)
 {
-    const unsigned id = blockIdx.x * kB + threadIdx.x;
+    // four lanes per surfel: the fragments of a point sprite are independent (the z-test is an atomicMin), and a
+    // lane walking a 5x5 footprint alone is a chain of 25 dependent ray loads; the set-up is recomputed per lane
+    const unsigned gt = blockIdx.x * kB + threadIdx.x;
+    const unsigned id = gt >> 2;
+    const int sub = (int)(gt & 3u);
     if (id >= *count) return;
     SplatSetup s;
     if (!splat_setup(surfels[id * 3], surfels[id * 3 + 1], surfels[id * 3 + 2], t_inv, cam, cols, rows, maxDepth, confThreshold, time, maxTime,
                      timeDelta, s))
         return;
-    for (int py = s.y_lo; py <= s.y_hi; py++)
-        for (int px = s.x_lo; px <= s.x_hi; px++) {
-            float z;
-            if (splat_fragment(s, rays, cols, px, py, maxDepth, z)) atomicMin(&keys[py * cols + px], zkey(z, id));
-        }
+    const int w = s.x_hi - s.x_lo + 1, h = s.y_hi - s.y_lo + 1;
+    if (w <= 0 || h <= 0) return;
+    int fx = sub, fy = 0;
+    while (fx >= w) { fx -= w; fy++; }
+    while (fy < h) {
+        const int px = s.x_lo + fx, py = s.y_lo + fy;
+        float z;
+        if (splat_fragment(s, rays, cols, px, py, maxDepth, z)) atomicMin(&keys[py * cols + px], zkey(z, id));
+        fx += 4;
+        while (fx >= w) { fx -= w; fy++; }
+    }
 }
 
 __global__ void __launch_bounds__(kB) splat_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_inv, cf_cam cam, int cols, int rows,
@@ -411,57 +421,141 @@ struct FuseArgs {
     unsigned* owner;      // [max_surfels], 0xFFFFFFFF = none
 };
 
+// one channel of tex4_linear (same expression), fed from staged texels
+__device__ __forceinline__ float bilerp(float a, float b, float c, float d, float wx, float wy)
+{
+    const float top = a * (1.0f - wx) + b * wx, bot = c * (1.0f - wx) + d * wx;
+    return top * (1.0f - wy) + bot * wy;
+}
+
+// Four lanes per pixel.  A lane alone walks 16 window samples, each a chain of IEEE sqrt / divisions / acos (about
+// 4400 VALU instructions per wave with only ~1 wave per SIMD in flight: 30 us of single-wave latency, measured).
+// Here the quad (a) stages the 4x4 texel neighbourhood of the window once -- index, vertConf.xyz, normRad.xyz, one
+// patch row per lane, all loads independent -- in LDS, and (b) splits the OUTER window loop: lane s evaluates the
+// outer iterations s, s+4, ... with the shader's own f32 loop counters, then the quad reduces to the candidate the
+// sequential loop would have kept (smallest distance, earliest on ties).  Lane 0 writes the record.
+static constexpr int kAssocItems = kB / 4;   // pixels per workgroup
+static constexpr int kPatchStride = 7 * 16 + 1;  // words per staged neighbourhood (+1: odd stride, no bank conflicts)
+
 __global__ void __launch_bounds__(kB) associate_kernel(const FuseArgs a)
 {
-    const int q = blockIdx.x * kB + threadIdx.x;
+    __shared__ float s_patch[kAssocItems * kPatchStride];
     const int cols = a.cols, rows = a.rows;
-    if (q >= cols * rows) return;
-    const int j = q / cols, i = q - j * cols;
-    const int rank = i * rows + j;
-    a.new_flags[rank] = 0;
-    const float tcx = a.tcx[i], tcy = a.tcy[j];
-    const float x = tcx * (float)cols, y = tcy * (float)rows;
-    if (!(((int)x % 2 == a.time % 2) && ((int)y % 2 == a.time % 2))) return;
-    if ((int)a.mask[q] != a.maskID) return;
+    // Only pixels whose integer coordinates share the parity of `time` survive the shader's first test
+    // ((int)x == i, (int)y == j: the texcoords are pixel centres), so the launch enumerates just that quarter of
+    // the image; new_flags is cleared by a memset beforehand.
+    const int par = a.time % 2;
+    const int n_i = (cols - par + 1) / 2, n_j = (rows - par + 1) / 2;
+    const int gt = blockIdx.x * kB + threadIdx.x;
+    const int t = gt >> 2, sub = gt & 3;
+    float* const P = s_patch + (threadIdx.x >> 2) * kPatchStride;  // word c of texel k: P[c * 16 + k]
+    bool alive = t < n_i * n_j;
+    int i = 0, j = 0, q = 0, rank = 0;
+    float tcx = 0, tcy = 0, x = 0, y = 0;
+    f3 vPosLocal{0, 0, 0};
+    if (alive) {
+        j = 2 * (t / n_i) + par; i = 2 * (t % n_i) + par;
+        q = j * cols + i; rank = i * rows + j;
+        tcx = a.tcx[i]; tcy = a.tcy[j];
+        x = tcx * (float)cols; y = tcy * (float)rows;
+        alive = (((int)x % 2 == a.time % 2) && ((int)y % 2 == a.time % 2)) && ((int)a.mask[q] == a.maskID);
+    }
     const float* dr = a.depth_raw;
-    if (dr[j * cols + iclamp(i - 1, 0, cols - 1)] == 0 || dr[iclamp(j - 1, 0, rows - 1) * cols + i] == 0 ||
-        dr[j * cols + iclamp(i + 1, 0, cols - 1)] == 0 || dr[iclamp(j + 1, 0, rows - 1) * cols + i] == 0)
-        return;
+    if (alive)
+        alive = !(dr[j * cols + iclamp(i - 1, 0, cols - 1)] == 0 || dr[iclamp(j - 1, 0, rows - 1) * cols + i] == 0 ||
+                  dr[j * cols + iclamp(i + 1, 0, cols - 1)] == 0 || dr[iclamp(j + 1, 0, rows - 1) * cols + i] == 0);
     const float cx = a.cam.cx, cy = a.cam.cy;
-    const f3 vPosLocal = get_vertex(dr, cols, rows, i, j, x, y, cx, cy, a.inv_fx, a.inv_fy);
-    if (!(vPosLocal.z > 0 && vPosLocal.z <= a.maxDepth)) return;
+    if (alive) {
+        vPosLocal = get_vertex(dr, cols, rows, i, j, x, y, cx, cy, a.inv_fx, a.inv_fy);
+        alive = (vPosLocal.z > 0 && vPosLocal.z <= a.maxDepth);
+    }
+    const float scale = 1.0f;  // ModelProjection::FACTOR
+    const float indexXStep = (1.0f / ((float)cols * scale)) * 0.5f, indexYStep = (1.0f / ((float)rows * scale)) * 0.5f;
+    const float windowMultiplier = 2;
+    const float iBeg = tcx - (scale * indexXStep * windowMultiplier), jBeg = tcy - (scale * indexYStep * windowMultiplier);
+    const int X0 = (int)floorf(iBeg * (float)cols - 0.5f), Y0 = (int)floorf(jBeg * (float)rows - 0.5f);
+    if (alive) {  // patch row `sub`
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int k = sub * 4 + c;
+            const int g = iclamp(Y0 + sub, 0, rows - 1) * cols + iclamp(X0 + c, 0, cols - 1);
+            const float4 vcf = a.vertConf[g];
+            const float4 nrd = a.normRad[g];
+            const unsigned idx = a.index[g];
+            P[0 * 16 + k] = vcf.x; P[1 * 16 + k] = vcf.y; P[2 * 16 + k] = vcf.z;
+            P[3 * 16 + k] = nrd.x; P[4 * 16 + k] = nrd.y; P[5 * 16 + k] = nrd.z;
+            P[6 * 16 + k] = __uint_as_float(idx);
+        }
+    }
+    __syncthreads();
+    if (!alive) return;  // the four lanes of a pixel take the same decision
 
     const f3 vPos = xform_point(a.pose, vPosLocal);
     const f3 vPos_f = get_vertex(a.depth_filt, cols, rows, i, j, x, y, cx, cy, a.inv_fx, a.inv_fy);
-    const uchar4 c = a.rgba[q];
     const f3 vNormLocal = get_normal_central(vPos_f, a.depth_filt, cols, rows, i, j, x, y, cx, cy, a.inv_fx, a.inv_fy);
-    const f3 nG = xform_dir(a.pose, vNormLocal);
-    const float radius = get_radius(vPos_f.z, vNormLocal.z, a.inv_fx, a.inv_fy);
-    const float conf = confidence(x, y, cx, cy, a.weighting);
-
-    const float scale = 1.0f;  // ModelProjection::FACTOR
-    const float indexXStep = (1.0f / ((float)cols * scale)) * 0.5f, indexYStep = (1.0f / ((float)rows * scale)) * 0.5f;
-    float bestDist = 1000;
-    const float windowMultiplier = 2;
     const float xl = (x - cx) * a.inv_fx, yl = (y - cy) * a.inv_fy;
     const float lambda = sqrtf(xl * xl + yl * yl + 1);
     const f3 ray = {xl, yl, 1};
-    unsigned best = 0; int operation = 0;
-    for (float ii = tcx - (scale * indexXStep * windowMultiplier); ii < tcx + (scale * indexXStep * windowMultiplier); ii += indexXStep)
-        for (float jj = tcy - (scale * indexYStep * windowMultiplier); jj < tcy + (scale * indexYStep * windowMultiplier); jj += indexYStep) {
-            const unsigned current = a.index[nearest_texel(jj, rows) * cols + nearest_texel(ii, cols)];
+    float bestDist = 1000;
+    unsigned best = 0; int operation = 0, bestSeq = 0;
+    // lane `sub` owns the outer iterations sub, sub+4, ...: it reaches its counter value by the same sequence of
+    // f32 additions as the shader's loop and tests the same bound (the counter is monotonic, so the test of its
+    // own value decides whether the iteration exists); the four lanes then run their inner loops simultaneously
+    float ii = iBeg;
+    for (int s4 = 0; s4 < sub; s4++) ii += indexXStep;
+    for (int outer = sub; ii < tcx + (scale * indexXStep * windowMultiplier);
+         outer += 4, ii += indexXStep, ii += indexXStep, ii += indexXStep, ii += indexXStep) {
+        int inner = 0;
+        for (float jj = jBeg; jj < tcy + (scale * indexYStep * windowMultiplier); jj += indexYStep, inner++) {
+            const int nlx = (int)floorf(ii * (float)cols) - X0, nly = (int)floorf(jj * (float)rows) - Y0;
+            const unsigned current = ((unsigned)nlx < 4u && (unsigned)nly < 4u)
+                                         ? __float_as_uint(P[6 * 16 + nly * 4 + nlx])
+                                         : a.index[nearest_texel(jj, rows) * cols + nearest_texel(ii, cols)];
             if (current > 0U) {
-                const float4 vertConf = tex4_linear(a.vertConf, cols, rows, ii, jj);
+                const float fu = ii * (float)cols - 0.5f, fv = jj * (float)rows - 0.5f;
+                const float x0f = floorf(fu), y0f = floorf(fv);
+                const int lx = (int)x0f - X0, ly = (int)y0f - Y0;
+                const bool staged = (unsigned)lx < 3u && (unsigned)ly < 3u;
+                const float wx = fu - x0f, wy = fv - y0f;
+                const float* qd = P + (ly * 4 + lx);
+                float4 vertConf;
+                if (staged) {
+                    vertConf.x = bilerp(qd[0 * 16], qd[0 * 16 + 1], qd[0 * 16 + 4], qd[0 * 16 + 5], wx, wy);
+                    vertConf.y = bilerp(qd[1 * 16], qd[1 * 16 + 1], qd[1 * 16 + 4], qd[1 * 16 + 5], wx, wy);
+                    vertConf.z = bilerp(qd[2 * 16], qd[2 * 16 + 1], qd[2 * 16 + 4], qd[2 * 16 + 5], wx, wy);
+                } else
+                    vertConf = tex4_linear(a.vertConf, cols, rows, ii, jj);
                 const float zdiff = (vertConf.z - vPosLocal.z);
                 if (fabsf(zdiff * lambda) < 0.05f) {
                     const float dist = norm(cross(ray, f3{vertConf.x, vertConf.y, vertConf.z}));
-                    const float4 normRad = tex4_linear(a.normRad, cols, rows, ii, jj);
+                    float4 normRad;
+                    if (staged) {
+                        normRad.x = bilerp(qd[3 * 16], qd[3 * 16 + 1], qd[3 * 16 + 4], qd[3 * 16 + 5], wx, wy);
+                        normRad.y = bilerp(qd[4 * 16], qd[4 * 16 + 1], qd[4 * 16 + 4], qd[4 * 16 + 5], wx, wy);
+                        normRad.z = bilerp(qd[5 * 16], qd[5 * 16 + 1], qd[5 * 16 + 4], qd[5 * 16 + 5], wx, wy);
+                    } else
+                        normRad = tex4_linear(a.normRad, cols, rows, ii, jj);
                     if (dist < bestDist && (fabsf(normRad.z) < 0.75f || fabsf(angle_between(f3{normRad.x, normRad.y, normRad.z}, vNormLocal)) < 0.5f)) {
-                        operation = 1; bestDist = dist; best = current;
+                        operation = 1; bestDist = dist; best = current; bestSeq = outer * 64 + inner;
                     }
                 }
             }
         }
+    }
+    // quad reduction to the sequential loop's survivor: smallest distance, earliest (outer, inner) on ties
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+        const int oOp = __shfl_xor(operation, o, 4), oSeq = __shfl_xor(bestSeq, o, 4);
+        const float oDist = __shfl_xor(bestDist, o, 4);
+        const unsigned oBest = (unsigned)__shfl_xor((int)best, o, 4);
+        const bool take = oOp && (!operation || oDist < bestDist || (oDist == bestDist && oSeq < bestSeq));
+        if (take) { operation = 1; bestDist = oDist; best = oBest; bestSeq = oSeq; }
+    }
+    if (sub != 0) return;
+    const uchar4 c = a.rgba[q];
+    const f3 nG = xform_dir(a.pose, vNormLocal);
+    const float radius = get_radius(vPos_f.z, vNormLocal.z, a.inv_fx, a.inv_fy);
+    const float conf = confidence(x, y, cx, cy, a.weighting);
     const float col = (float)(((int)c.x << 16) + ((int)c.y << 8) + (int)c.z);
     a.records[rank * 3 + 0] = make_float4(vPos.x, vPos.y, vPos.z, conf);
     a.records[rank * 3 + 1] = make_float4(col, 0.f, (float)a.time, operation == 1 ? -1.f : -2.f);
@@ -515,64 +609,74 @@ struct CleanArgs {
     Mat4 t_inv; cf_cam cam; int cols, rows, time; float confThreshold, outlierCoeff; int timeDelta, maskID;
 };
 
-// The 4x4 half-pixel window touches at most a 4x4 texel neighbourhood of the index map textures.  Reading
-// it sample by sample (16 x (1 + 2x4) gathers per surfel) thrashes L1 and the XCD's L2 (measured: 560 MB of
-// fabric reads per launch for 275 k surfels), so each lane first stages its neighbourhood -- vertConf.xyzw,
-// colorTime.zw and the index, 7 words x 16 texels -- in a private LDS column (lane-interleaved: no bank
-// conflicts, no barrier: a lane only reads what it wrote) with 48 independent loads issued back to back,
-// and the window loops then sample from LDS.  Texels outside the staged patch (only reachable through the
-// f32 loop-counter corner cases) fall back to the global fetch, so the result is unchanged.
-static constexpr int kCleanB = 64;
-static constexpr int kPatchWords = 7;
+// The 4x4 half-pixel window touches at most a 4x4 texel neighbourhood of the index map textures.  Reading it
+// sample by sample (16 x (1 + 2x4) gathers per surfel) thrashes L1 and the XCD's L2 (measured: 560 MB of fabric
+// reads per launch for 275 k surfels).  As in associate_kernel, four lanes share a surfel: the quad stages the
+// neighbourhood -- vertConf.xyzw, colorTime.zw and the index, one patch row per lane -- in LDS with independent
+// loads, splits the outer window loop (lane s takes iterations s, s+4, ...; the shader's f32 loop counters are
+// kept), and adds up the two vote counts, which do not depend on the order.  Texels outside the staged patch
+// (only reachable through the f32 loop-counter corner cases) fall back to the global fetch.
+static constexpr int kCleanItems = kB / 4;
 
-__device__ __forceinline__ float bilerp(float a, float b, float c, float d, float wx, float wy)
+__global__ void __launch_bounds__(kB) clean_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count,
+                                                   const float4* __restrict__ fresh, const unsigned* __restrict__ n_fresh, const CleanArgs a,
+                                                   unsigned total_bound, float4* __restrict__ staged, unsigned* __restrict__ flags)
 {
-    const float top = a * (1.0f - wx) + b * wx, bot = c * (1.0f - wx) + d * wx;
-    return top * (1.0f - wy) + bot * wy;
-}
-
-__global__ void __launch_bounds__(kCleanB) clean_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count,
-                                                        const float4* __restrict__ fresh, const unsigned* __restrict__ n_fresh, const CleanArgs a,
-                                                        unsigned total_bound, float4* __restrict__ staged, unsigned* __restrict__ flags)
-{
-    __shared__ float s_patch[kPatchWords * 16 * kCleanB];
-    float* const P = s_patch + threadIdx.x;  // word c of texel t: P[(c * 16 + t) * kCleanB]
-    const unsigned k = blockIdx.x * kCleanB + threadIdx.x;
+    __shared__ float s_patch[kCleanItems * kPatchStride];
+    float* const P = s_patch + (threadIdx.x >> 2) * kPatchStride;  // word c of texel t: P[c * 16 + t]
+    const unsigned gt = blockIdx.x * kB + threadIdx.x;
+    const unsigned k = gt >> 2;
+    const int sub = (int)(gt & 3u);
     const unsigned n_old = *count, n_all = n_old + *n_fresh;
-    if (k >= n_all) { if (k < total_bound) flags[k] = 0; return; }
-    const float4* src = (k < n_old) ? surfels + (size_t)k * 3 : fresh + (size_t)(k - n_old) * 3;
-    float4 pc = src[0], ct = src[1];
-    const float4 nr = src[2];
+    const bool exists = k < n_all;
+    if (!exists && sub == 0 && k < total_bound) flags[k] = 0;
     const int cols = a.cols, rows = a.rows;
     const float scale = 1.0f;
-    int test = 1;
-    const f3 localPos = xform_point(a.t_inv, f3{pc.x, pc.y, pc.z});
-    const float x = ((a.cam.fx * localPos.x) / localPos.z) + a.cam.cx, y = ((a.cam.fy * localPos.y) / localPos.z) + a.cam.cy;
-    const f3 localNorm = normalized(xform_dir(a.t_inv, f3{nr.x, nr.y, nr.z}));
-    const float x_n = x / (float)cols, y_n = y / (float)rows;
+    float4 pc = make_float4(0, 0, 0, 0), ct = pc, nr = pc;
+    f3 localPos{0, 0, 0}, localNorm{0, 0, 0};
+    float x = 0, y = 0, x_n = 0, y_n = 0;
     const float stepX = 1.0f / (float)cols, stepY = 1.0f / (float)rows;
     const float indexXStep = stepX * 0.5f / scale, indexYStep = stepY * 0.5f / scale;
     const float windowMultiplier = 2;
-    int cnt = 0, zCount = 0, violationCount = 0;
-    float avgViolation = 0;
-    if ((float)a.time - ct.w < (float)a.timeDelta && localPos.z > 0 && x > 0 && y > 0 && x < (float)cols && y < (float)rows) {
-        const float iBeg = x_n - (scale * indexXStep * windowMultiplier), jBeg = y_n - (scale * indexYStep * windowMultiplier);
-        const int X0 = (int)floorf(iBeg * (float)cols - 0.5f), Y0 = (int)floorf(jBeg * (float)rows - 0.5f);
+    bool window = false;
+    if (exists) {
+        const float4* src = (k < n_old) ? surfels + (size_t)k * 3 : fresh + (size_t)(k - n_old) * 3;
+        pc = src[0]; ct = src[1]; nr = src[2];
+        localPos = xform_point(a.t_inv, f3{pc.x, pc.y, pc.z});
+        x = ((a.cam.fx * localPos.x) / localPos.z) + a.cam.cx; y = ((a.cam.fy * localPos.y) / localPos.z) + a.cam.cy;
+        localNorm = normalized(xform_dir(a.t_inv, f3{nr.x, nr.y, nr.z}));
+        x_n = x / (float)cols; y_n = y / (float)rows;
+        window = (float)a.time - ct.w < (float)a.timeDelta && localPos.z > 0 && x > 0 && y > 0 && x < (float)cols && y < (float)rows;
+    }
+    const float iBeg = x_n - (scale * indexXStep * windowMultiplier), jBeg = y_n - (scale * indexYStep * windowMultiplier);
+    const int X0 = (int)floorf(iBeg * (float)cols - 0.5f), Y0 = (int)floorf(jBeg * (float)rows - 0.5f);
+    if (window) {  // patch row `sub`
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int g = iclamp(Y0 + (t >> 2), 0, rows - 1) * cols + iclamp(X0 + (t & 3), 0, cols - 1);
+        for (int c = 0; c < 4; c++) {
+            const int t = sub * 4 + c;
+            const int g = iclamp(Y0 + sub, 0, rows - 1) * cols + iclamp(X0 + c, 0, cols - 1);
             const float4 vcf = a.vertConf[g];
             const float4 ctm = a.colorTime[g];
             const unsigned idx = a.index[g];
-            P[(0 * 16 + t) * kCleanB] = vcf.x; P[(1 * 16 + t) * kCleanB] = vcf.y; P[(2 * 16 + t) * kCleanB] = vcf.z;
-            P[(3 * 16 + t) * kCleanB] = vcf.w; P[(4 * 16 + t) * kCleanB] = ctm.z; P[(5 * 16 + t) * kCleanB] = ctm.w;
-            P[(6 * 16 + t) * kCleanB] = __uint_as_float(idx);
+            P[0 * 16 + t] = vcf.x; P[1 * 16 + t] = vcf.y; P[2 * 16 + t] = vcf.z; P[3 * 16 + t] = vcf.w;
+            P[4 * 16 + t] = ctm.z; P[5 * 16 + t] = ctm.w;
+            P[6 * 16 + t] = __uint_as_float(idx);
         }
-        for (float i = iBeg; i < x_n + (scale * indexXStep * windowMultiplier); i += indexXStep)
+    }
+    __syncthreads();
+    if (!exists) return;
+    int test = 1;
+    int cnt = 0, zCount = 0, violationCount = 0;
+    float avgViolation = 0;
+    if (window) {
+        // lane `sub` owns the outer iterations sub, sub+4, ... (see associate_kernel)
+        float i = iBeg;
+        for (int s4 = 0; s4 < sub; s4++) i += indexXStep;
+        for (; i < x_n + (scale * indexXStep * windowMultiplier); i += indexXStep, i += indexXStep, i += indexXStep, i += indexXStep) {
             for (float j = jBeg; j < y_n + (scale * indexYStep * windowMultiplier); j += indexYStep) {
                 const int nlx = (int)floorf(i * (float)cols) - X0, nly = (int)floorf(j * (float)rows) - Y0;
                 const unsigned current = ((unsigned)nlx < 4u && (unsigned)nly < 4u)
-                                             ? __float_as_uint(P[(6 * 16 + nly * 4 + nlx) * kCleanB])
+                                             ? __float_as_uint(P[6 * 16 + nly * 4 + nlx])
                                              : a.index[nearest_texel(j, rows) * cols + nearest_texel(i, cols)];
                 if (current > 0U) {
                     float4 vertConf, colorTime;
@@ -581,13 +685,13 @@ __global__ void __launch_bounds__(kCleanB) clean_kernel(const float4* __restrict
                     const int lx = (int)x0f - X0, ly = (int)y0f - Y0;
                     if ((unsigned)lx < 3u && (unsigned)ly < 3u) {
                         const float wx = fu - x0f, wy = fv - y0f;
-                        const float* q = P + (ly * 4 + lx) * kCleanB;
-                        vertConf.x = bilerp(q[0 * 16 * kCleanB], q[(0 * 16 + 1) * kCleanB], q[(0 * 16 + 4) * kCleanB], q[(0 * 16 + 5) * kCleanB], wx, wy);
-                        vertConf.y = bilerp(q[1 * 16 * kCleanB], q[(1 * 16 + 1) * kCleanB], q[(1 * 16 + 4) * kCleanB], q[(1 * 16 + 5) * kCleanB], wx, wy);
-                        vertConf.z = bilerp(q[2 * 16 * kCleanB], q[(2 * 16 + 1) * kCleanB], q[(2 * 16 + 4) * kCleanB], q[(2 * 16 + 5) * kCleanB], wx, wy);
-                        vertConf.w = bilerp(q[3 * 16 * kCleanB], q[(3 * 16 + 1) * kCleanB], q[(3 * 16 + 4) * kCleanB], q[(3 * 16 + 5) * kCleanB], wx, wy);
-                        colorTime.z = bilerp(q[4 * 16 * kCleanB], q[(4 * 16 + 1) * kCleanB], q[(4 * 16 + 4) * kCleanB], q[(4 * 16 + 5) * kCleanB], wx, wy);
-                        colorTime.w = bilerp(q[5 * 16 * kCleanB], q[(5 * 16 + 1) * kCleanB], q[(5 * 16 + 4) * kCleanB], q[(5 * 16 + 5) * kCleanB], wx, wy);
+                        const float* q = P + (ly * 4 + lx);
+                        vertConf.x = bilerp(q[0 * 16], q[0 * 16 + 1], q[0 * 16 + 4], q[0 * 16 + 5], wx, wy);
+                        vertConf.y = bilerp(q[1 * 16], q[1 * 16 + 1], q[1 * 16 + 4], q[1 * 16 + 5], wx, wy);
+                        vertConf.z = bilerp(q[2 * 16], q[2 * 16 + 1], q[2 * 16 + 4], q[2 * 16 + 5], wx, wy);
+                        vertConf.w = bilerp(q[3 * 16], q[3 * 16 + 1], q[3 * 16 + 4], q[3 * 16 + 5], wx, wy);
+                        colorTime.z = bilerp(q[4 * 16], q[4 * 16 + 1], q[4 * 16 + 4], q[4 * 16 + 5], wx, wy);
+                        colorTime.w = bilerp(q[5 * 16], q[5 * 16 + 1], q[5 * 16 + 4], q[5 * 16 + 5], wx, wy);
                     } else {
                         vertConf = tex4_linear(a.vertConf, cols, rows, i, j);
                         colorTime = tex4_linear(a.colorTime, cols, rows, i, j);
@@ -601,12 +705,17 @@ __global__ void __launch_bounds__(kCleanB) clean_kernel(const float4* __restrict
                         zCount++;
                 }
             }
+        }
+        // every lane of the quad walks the 3x3 depth window (sequential f32 sum) so that all four hold the result
         for (float i = x_n - stepX; i <= x_n + stepX; i += stepX)
             for (float j = y_n - stepY; j <= y_n + stepY; j += stepY) {
                 const float d = a.depth_filt[nearest_texel(j, rows) * cols + nearest_texel(i, cols)] - localPos.z;
                 if (d > 0.03f) { violationCount++; avgViolation += d; }
             }
     }
+    cnt += __shfl_xor(cnt, 1, 4); cnt += __shfl_xor(cnt, 2, 4);
+    zCount += __shfl_xor(zCount, 1, 4); zCount += __shfl_xor(zCount, 2, 4);
+    if (sub != 0) return;
     if (cnt > 8 || zCount > 4) test = 0;
     if (ct.w == -2) ct.w = (float)a.time;
     if ((ct.w == -1 || (((float)a.time - ct.w) > 20 && pc.w < a.confThreshold))) test = 0;
@@ -673,7 +782,7 @@ void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned
     (void)hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * N, s);
     const Mat4 T = mat4_from(t_inv);
     if (count_bound > 0)
-        splat_raster_kernel<<<gridFor(count_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, cam, cols, rows, maxDepth,
+        splat_raster_kernel<<<gridFor(4ll * count_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, cam, cols, rows, maxDepth,
                                                                 confThreshold, time, maxTime, timeDelta, reinterpret_cast<const float4*>(rays), keys);
     splat_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), T, cam, cols, rows, maxDepth, confThreshold, time, maxTime,
                                                    timeDelta, reinterpret_cast<const float4*>(rays), keys, reinterpret_cast<uchar4*>(image), reinterpret_cast<float4*>(vertexConf),
@@ -703,7 +812,10 @@ void launch_associate(hipStream_t s, const SurfelFuseArgs& h)
     a.tcx = h.tcx; a.tcy = h.tcy; a.pose = mat4_from(h.pose); a.cam = h.cam; a.inv_fx = h.inv_fx; a.inv_fy = h.inv_fy;
     a.cols = h.cols; a.rows = h.rows; a.time = h.time; a.weighting = h.weighting; a.maskID = h.maskID; a.maxDepth = h.maxDepth;
     a.records = reinterpret_cast<float4*>(h.records); a.new_flags = h.new_flags; a.owner = h.owner;
-    associate_kernel<<<gridFor((long long)h.cols * h.rows), kB, 0, s>>>(a);
+    (void)hipMemsetAsync(h.new_flags, 0, sizeof(unsigned) * (size_t)h.cols * h.rows, s);
+    const int par = h.time % 2;
+    const long long n = (long long)((h.cols - par + 1) / 2) * ((h.rows - par + 1) / 2);
+    associate_kernel<<<gridFor(4 * n), kB, 0, s>>>(a);
 }
 void launch_update(hipStream_t s, const float* in, const unsigned* count, unsigned count_bound, unsigned* owner, const float* records, int time,
                    float* out)
@@ -720,7 +832,7 @@ void launch_clean(hipStream_t s, const float* surfels, const unsigned* count, co
     a.depth_filt = h.depth_filt; a.mask = h.mask; a.t_inv = mat4_from(h.t_inv); a.cam = h.cam; a.cols = h.cols; a.rows = h.rows; a.time = h.time;
     a.confThreshold = h.confThreshold; a.outlierCoeff = h.outlierCoeff; a.timeDelta = h.timeDelta; a.maskID = h.maskID;
     if (total_bound > 0)
-        clean_kernel<<<(total_bound + kCleanB - 1) / kCleanB, kCleanB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, reinterpret_cast<const float4*>(fresh), n_fresh,
+        clean_kernel<<<gridFor(4ll * total_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, reinterpret_cast<const float4*>(fresh), n_fresh,
                                                          a, total_bound, reinterpret_cast<float4*>(staged), flags);
 }
 void launch_add_counts(hipStream_t s, const unsigned* a, const unsigned* b, unsigned* out) { add_counts_kernel<<<1, 1, 0, s>>>(a, b, out); }
