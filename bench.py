@@ -17,8 +17,11 @@ the path partitions over independent streams/models without a data-path collecti
 Timing: barrier + synchronize on both sides of exactly K steps, MAX over ranks.
 
 The JSON line also carries
-  roofline      achieved algorithmic bytes/s of the dominant kernel (level-0 ICP reduction, (24 + 24*M) B/pixel
-                per launch for M lock-step models, BASELINE.md section 3) from hipEvents on the launch stream;
+  roofline      achieved algorithmic bytes/s of the dominant kernel -- the level-0 launch that carries the ICP
+                reduction ((24 + 24*M) B/pixel for M lock-step models) together with the
+                RGB residual pass (27*M B/pixel) -- from the dispatches' own begin/end timestamps (hipEvents
+                attached to the launch on the launch stream); `traffic` = HBM-side bytes per launch from the
+                committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes (profiles/r01_icp_traffic.json);
   cpu_baseline  the CPU oracle's restatement of the same frame loop ("port": the reference cannot be built
                 here), timed on this box's host cores on a bounded sample.
 """
@@ -99,7 +102,13 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("CF_BENCH_BACKEND", "nccl")  # "gloo": dry run of the multi-rank path on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    if os.environ.get("CF_BENCH_SHARE_GPU"):  # dry run only: every rank on device 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     from co_fusion_amd import facade
 
@@ -131,7 +140,7 @@ def main(argv=None):
     def all_reduce_max(dt):
         if dist is None:
             return dt
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
@@ -151,7 +160,7 @@ def main(argv=None):
         counts = [cf.model_info(i)["count"] for i in range(n_models)]
         achieved = (prof.icp_bytes / 1e9) / (prof.icp_ms_total / 1e3) if prof.icp_ms_total > 0 else 0.0
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=pmc_traffic(args.workload, W * H), kernel="cf::icp_reduce_kernel<PPT,0> (pyramid level 0)", launches=int(prof.icp_launches),
+                        traffic=pmc_traffic(args.workload, W * H), kernel="cf::icp_reduce_kernel<PPT,0>: ICP reduction || RGB residual, pyramid level 0", launches=int(prof.icp_launches),
                         avg_us=round(1e3 * prof.icp_ms_total / max(1, prof.icp_launches), 3),
                         bytes_per_launch=int(prof.icp_bytes / max(1, prof.icp_launches)))
         cpu = None
@@ -182,7 +191,7 @@ def pmc_traffic(workload, pixels):
         t = json.load(open(path))
     except OSError:
         return None
-    if t.get("workload") != workload or t.get("grid") != pixels:
+    if t.get("workload") != workload or t.get("pixels") != pixels:
         return None
     return int(t["traffic_bytes_per_launch"])
 

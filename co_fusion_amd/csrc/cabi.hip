@@ -381,15 +381,23 @@ int cf_odom_init_icp_model(cf_odom* od, const float* pred_v4, const float* pred_
     if (!od || !pred_v4 || !pred_n4 || !pose) return CF_EINVAL;
     cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
-    HIPCHK(ctx, hipMemcpyAsync(od->vmaps_tmp, pred_v4, (size_t)W * H * 16, hipMemcpyDeviceToDevice, s));
-    launch_copy_maps(s, od->vmaps_tmp, pred_n4, W, H, od->vmap_g_prev[0], od->nmap_g_prev[0]);
-    for (int i = 1; i < CF_NUM_PYRS; ++i) {
-        launch_resize_map(s, od->vmap_g_prev[i - 1], W >> (i - 1), H >> (i - 1), od->vmap_g_prev[i], false);
-        launch_resize_map(s, od->nmap_g_prev[i - 1], W >> (i - 1), H >> (i - 1), od->nmap_g_prev[i], true);
-    }
     const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
     const float t[3] = {pose[3], pose[7], pose[11]};
-    for (int i = 0; i < CF_NUM_PYRS; ++i) launch_transform_maps(s, od->vmap_g_prev[i], od->nmap_g_prev[i], W >> i, H >> i, R, t);
+    if (W % 4 == 0 && H % 4 == 0) {  // one launch: snapshot + copyMaps + resize chain + transform of every level
+        ModelMapsArgs a{};
+        a.pred_v4 = pred_v4; a.pred_n4 = pred_n4; a.snapshot = od->vmaps_tmp; a.cols = W; a.rows = H;
+        for (int i = 0; i < CF_NUM_PYRS; ++i) { a.vmap[i] = od->vmap_g_prev[i]; a.nmap[i] = od->nmap_g_prev[i]; }
+        memcpy(a.R, R, sizeof(R)); memcpy(a.t, t, sizeof(t));
+        launch_model_maps(s, a);
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(od->vmaps_tmp, pred_v4, (size_t)W * H * 16, hipMemcpyDeviceToDevice, s));
+        launch_copy_maps(s, od->vmaps_tmp, pred_n4, W, H, od->vmap_g_prev[0], od->nmap_g_prev[0]);
+        for (int i = 1; i < CF_NUM_PYRS; ++i) {
+            launch_resize_map(s, od->vmap_g_prev[i - 1], W >> (i - 1), H >> (i - 1), od->vmap_g_prev[i], false);
+            launch_resize_map(s, od->nmap_g_prev[i - 1], W >> (i - 1), H >> (i - 1), od->nmap_g_prev[i], true);
+        }
+        for (int i = 0; i < CF_NUM_PYRS; ++i) launch_transform_maps(s, od->vmap_g_prev[i], od->nmap_g_prev[i], W >> i, H >> i, R, t);
+    }
     LAUNCHCHK(ctx);
     return CF_OK;
 }
@@ -426,13 +434,16 @@ int cf_odom_init_icp(cf_odom* od, const float* const depth_pyr[CF_NUM_PYRS], flo
     cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
     const cf_cam intr = {ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy};
+    FrameMapsArgs a{};
+    a.cutoff = depth_cutoff;
     for (int i = 0; i < CF_NUM_PYRS; ++i) {
         const int div = 1 << i;
         const cf_cam il = {intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
-        launch_vmap(s, depth_pyr[i], W >> i, H >> i, il, depth_cutoff, od->vmap_curr[i]);
-        launch_nmap(s, od->vmap_curr[i], W >> i, H >> i, od->nmap_curr[i]);
+        a.depth[i] = depth_pyr[i]; a.vmap[i] = od->vmap_curr[i]; a.nmap[i] = od->nmap_curr[i];
+        a.fx_inv[i] = 1.f / il.fx; a.fy_inv[i] = 1.f / il.fy; a.cx[i] = il.cx; a.cy[i] = il.cy;
         od->ext_vmap_curr[i] = nullptr; od->ext_nmap_curr[i] = nullptr;
     }
+    launch_frame_maps(s, a, W, H);  // createVMap + createNMap of the three levels in one launch
     LAUNCHCHK(ctx);
     return CF_OK;
 }
@@ -465,14 +476,16 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
     const bool rgb = opts->rgb_only || opts->icp_weight < 100;
     const cf_cam intr = {ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy};
     if (rgb) {
+        RgbPrepArgs a{};  // computeDerivativeImages (RGBDOdometry.cpp:231-235) + candidate mask + projectToPointCloud (:333)
         for (int i = 0; i < CF_NUM_PYRS; i++) {
             const int div = 1 << i;
             const cf_cam il = {intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
-            launch_sobel(s, od->nextImage[i], W >> i, H >> i, od->dIdx[i], od->dIdy[i]);  // RGBDOdometry.cpp:231-235
-            const float minScale = (float)(pow((double)od->minGrad[i], 2.0) / pow((double)od->sobelScale, 2.0));
-            launch_rgb_cand(s, od->dIdx[i], od->dIdy[i], od->nextDepth[i], od->nextImage[i], minScale, W >> i, H >> i, od->cand[i]);
-            launch_cloud(s, od->lastDepth[i], W >> i, H >> i, il, od->cloud[i]);  // :333
+            a.nextImage[i] = od->nextImage[i]; a.nextDepth[i] = od->nextDepth[i]; a.lastDepth[i] = od->lastDepth[i];
+            a.dIdx[i] = od->dIdx[i]; a.dIdy[i] = od->dIdy[i]; a.cand[i] = od->cand[i]; a.cloud[i] = od->cloud[i];
+            a.minScale[i] = (float)(pow((double)od->minGrad[i], 2.0) / pow((double)od->sobelScale, 2.0));
+            a.fx_inv[i] = 1.0f / il.fx; a.fy_inv[i] = 1.0f / il.fy; a.cx[i] = il.cx; a.cy[i] = il.cy;
         }
+        launch_rgb_prep(s, a, W, H);
     }
     OdomDev* h = od->h_state;
     for (int i = 0; i < CF_NUM_PYRS; i++) {

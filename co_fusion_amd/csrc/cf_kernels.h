@@ -64,6 +64,31 @@ void launch_intensity(hipStream_t s, const uint8_t* rgba, int cols, int rows, ui
 void launch_sobel(hipStream_t s, const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy);
 void launch_cloud(hipStream_t s, const float* depth, int cols, int rows, cf_cam il, float* cloud3);
 
+// fused per-frame preparation used by the tracker object (all pyramid levels per launch)
+struct Level3 { int cols[3], rows[3], blk_end[3]; };  // blk_end: cumulative workgroup counts per level
+struct FrameMapsArgs {
+    Level3 L;
+    const float* depth[3]; float* vmap[3]; float* nmap[3];
+    float fx_inv[3], fy_inv[3], cx[3], cy[3];
+    float cutoff;
+};
+struct RgbPrepArgs {
+    Level3 L;
+    const uint8_t* nextImage[3]; const float* nextDepth[3]; const float* lastDepth[3];
+    int16_t* dIdx[3]; int16_t* dIdy[3]; uint8_t* cand[3]; float* cloud[3];
+    float minScale[3], fx_inv[3], fy_inv[3], cx[3], cy[3];
+};
+struct ModelMapsArgs {
+    const float* pred_v4; const float* pred_n4;  // RGBA32F prediction (vertex+conf, normal+radius)
+    float* snapshot;                             // copy of pred_v4 kept by the tracker (RGBDOdometry::vmaps_tmp)
+    float* vmap[3]; float* nmap[3];
+    int cols, rows;
+    float R[9], t[3];
+};
+void launch_model_maps(hipStream_t s, const ModelMapsArgs& a);  // needs cols % 4 == 0 && rows % 4 == 0
+void launch_frame_maps(hipStream_t s, FrameMapsArgs a, int W, int H);
+void launch_rgb_prep(hipStream_t s, RgbPrepArgs a, int W, int H);
+
 // ---- reduction launchers (track_reduce.hip) ----
 struct IcpLaunch { int threads; int ppt; };  // threads per workgroup, pixels per thread
 

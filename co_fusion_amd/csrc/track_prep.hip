@@ -263,7 +263,216 @@ __global__ void __launch_bounds__(kBlock) cloud_kernel(const float* __restrict__
     cloud3[i * 3 + 2] = z;
 }
 
+// =================================================================================================
+// Fused per-frame preparation.  The reference (and the one-function-per-entry C-ABI above) issues ~38 tiny
+// launches per tracked model and frame; each is 3-8 us of launch + latency for a few hundred KB of data.  The
+// tracker object uses the three kernels below instead: every pyramid level in ONE launch (workgroup ranges
+// per level) and dependent stages recomputed in registers with the same expressions, so the outputs -- including
+// which planes are left untouched for invalid pixels -- are bit-identical to the chain of single kernels.
+// =================================================================================================
+__device__ __forceinline__ int level_of(const Level3& L, int b, int& lb)
+{
+    const int lv = b < L.blk_end[0] ? 0 : (b < L.blk_end[1] ? 1 : 2);
+    lb = b - (lv ? L.blk_end[lv - 1] : 0);
+    return lv;
+}
+
+// vmap_kernel + nmap_kernel for the three levels (RGBDOdometry::initICP, RGBDOdometry.cpp:116-143)
+__global__ void __launch_bounds__(kBlock) frame_maps_kernel(const FrameMapsArgs a)
+{
+    int lb;
+    const int lv = level_of(a.L, blockIdx.x, lb);
+    const int cols = a.L.cols[lv], rows = a.L.rows[lv], N = cols * rows;
+    const int i = lb * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const float* __restrict__ depth = a.depth[lv];
+    float* __restrict__ vmap = a.vmap[lv];
+    float* __restrict__ nmap = a.nmap[lv];
+    const float fx_inv = a.fx_inv[lv], fy_inv = a.fy_inv[lv], cx = a.cx[lv], cy = a.cy[lv], cutoff = a.cutoff;
+    const int v = i / cols, u = i - v * cols;
+    const bool edge = (u == cols - 1 || v == rows - 1);
+    const float z = depth[i];
+    const float z01 = edge ? 0.f : depth[i + 1], z10 = edge ? 0.f : depth[i + cols];
+    float x00 = qnan();
+    if (z != 0 && z < cutoff) {
+        x00 = z * (u - cx) * fx_inv;
+        vmap[i] = x00;
+        vmap[i + N] = z * (v - cy) * fy_inv;
+        vmap[i + 2 * N] = z;
+    } else {
+        vmap[i] = qnan();
+    }
+    if (edge) { nmap[i] = qnan(); return; }
+    const float x01 = (z01 != 0 && z01 < cutoff) ? z01 * ((u + 1) - cx) * fx_inv : qnan();
+    const float x10 = (z10 != 0 && z10 < cutoff) ? z10 * (u - cx) * fx_inv : qnan();
+    if (!is_nan(x00) && !is_nan(x01) && !is_nan(x10)) {
+        const f3 v00 = {x00, z * (v - cy) * fy_inv, z};
+        const f3 v01 = {x01, z01 * (v - cy) * fy_inv, z01};
+        const f3 v10 = {x10, z10 * ((v + 1) - cy) * fy_inv, z10};
+        const f3 r = normalized(cross(v01 - v00, v10 - v00));
+        nmap[i] = r.x; nmap[i + N] = r.y; nmap[i + 2 * N] = r.z;
+    } else {
+        nmap[i] = qnan();
+    }
+}
+
+// sobel_kernel + rgb_cand_kernel + cloud_kernel for the three levels (RGBDOdometry.cpp:231-235, :333)
+__global__ void __launch_bounds__(kBlock) rgb_prep_kernel(const RgbPrepArgs a)
+{
+    int lb;
+    const int lv = level_of(a.L, blockIdx.x, lb);
+    const int cols = a.L.cols[lv], rows = a.L.rows[lv];
+    const int k = lb * kBlock + threadIdx.x;
+    if (k >= cols * rows) return;
+    const int y = k / cols, x = k - y * cols;
+    const uint8_t* __restrict__ src = a.nextImage[lv];
+    // cloud (independent of the rest)
+    {
+        const float z = a.lastDepth[lv][k];
+        float* __restrict__ cloud3 = a.cloud[lv];
+        cloud3[k * 3 + 0] = (x - a.cx[lv]) * z * a.fx_inv[lv];
+        cloud3[k * 3 + 1] = (y - a.cy[lv]) * z * a.fy_inv[lv];
+        cloud3[k * 3 + 2] = z;
+    }
+    // Sobel
+    float dxv = 0, dyv = 0;
+    constexpr float sx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+    constexpr float sy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+    if (x >= 1 && y >= 1 && x <= cols - 2 && y <= rows - 2) {
+        const uint8_t* __restrict__ p0 = src + (y - 1) * cols + (x - 1);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float s = (float)p0[r * cols + c];
+                dxv += s * sx[8 - (r * 3 + c)];
+                dyv += s * sy[8 - (r * 3 + c)];
+            }
+    } else {
+        int kk = 8;
+        for (int j = max(y - 1, 0); j <= min(y + 1, rows - 1); j++)
+            for (int c = max(x - 1, 0); c <= min(x + 1, cols - 1); c++) {
+                const float s = (float)src[j * cols + c];
+                dxv += s * kSobelX[kk];
+                dyv += s * kSobelY[kk];
+                --kk;
+            }
+    }
+    const int16_t dx16 = (int16_t)(int)dxv, dy16 = (int16_t)(int)dyv;
+    a.dIdx[lv][k] = dx16; a.dIdy[lv][k] = dy16;
+    // candidate mask
+    uint8_t ok = 0;
+    if (x < cols - 5 && y < rows - 1) {
+        bool valid = true;
+        for (int u = max(y - 2, 0); u < min(y + 2, rows); u++)
+            for (int v = max(x - 2, 0); v < min(x + 2, cols); v++) valid = valid && (src[u * cols + v] > 0);
+        if (valid) {
+            const int valx = dx16, valy = dy16;
+            const float mTwo = (float)((valx * valx) + (valy * valy));
+            if (mTwo >= a.minScale[lv] && !is_nan(a.nextDepth[lv][k])) ok = 1;
+        }
+    }
+    a.cand[lv][k] = ok;
+}
+
+// copy_maps + resize_map<false/true> x2 + transform_maps x3 (RGBDOdometry::initICPModel, RGBDOdometry.cpp:145-174):
+// one thread per level-2 pixel owns its 4x4 level-0 block.  The resize chain runs on the untransformed values,
+// every level is stored transformed; invalid pixels keep the reference's partial writes (see `emit`).
+struct MapVal { f3 p; bool have; };  // have == false: the resize bailed out on a NaN source (only the x plane is written)
+
+__device__ __forceinline__ void emit_map(float* __restrict__ map, int idx, int N, const MapVal& m, const m33& R, const f3& t, bool add_t)
+{
+    if (!m.have) { map[idx] = qnan(); return; }
+    if (!is_nan(m.p.x)) {
+        f3 d = mul(R, m.p);
+        if (add_t) d = d + t;
+        map[idx] = d.x; map[idx + N] = d.y; map[idx + 2 * N] = d.z;
+    } else {  // the stage before the transform wrote all planes, the transform only overwrites x with NaN
+        map[idx] = qnan(); map[idx + N] = m.p.y; map[idx + 2 * N] = m.p.z;
+    }
+}
+
+__device__ __forceinline__ MapVal resize4(const MapVal& a00, const MapVal& a01, const MapVal& a10, const MapVal& a11, bool normalize)
+{
+    // resize_map_kernel: the NaN test looks at the x planes of the four sources (a source whose own resize bailed
+    // out has x == NaN in memory)
+    MapVal o; o.have = false; o.p = f3{qnan(), qnan(), qnan()};
+    const float x00 = a00.have ? a00.p.x : qnan(), x01 = a01.have ? a01.p.x : qnan();
+    const float x10 = a10.have ? a10.p.x : qnan(), x11 = a11.have ? a11.p.x : qnan();
+    if (is_nan(x00) || is_nan(x01) || is_nan(x10) || is_nan(x11)) return o;
+    f3 n;
+    n.x = (a00.p.x + a01.p.x + a10.p.x + a11.p.x) / 4;
+    n.y = (a00.p.y + a01.p.y + a10.p.y + a11.p.y) / 4;
+    n.z = (a00.p.z + a01.p.z + a10.p.z + a11.p.z) / 4;
+    if (normalize) n = normalized(n);
+    o.have = true; o.p = n;
+    return o;
+}
+
+__global__ void __launch_bounds__(64) model_maps_kernel(const ModelMapsArgs a)
+{
+    const int c2 = a.cols >> 2, r2 = a.rows >> 2;
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= c2 * r2) return;
+    const int Y2 = t / c2, X2 = t - Y2 * c2;
+    const int cols = a.cols, rows = a.rows, N0 = cols * rows, c1 = cols >> 1, N1 = N0 >> 2, N2 = N0 >> 4;
+    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(a.pred_v4);
+    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(a.pred_n4);
+    float4* __restrict__ snap = reinterpret_cast<float4*>(a.snapshot);
+    m33 R; for (int k = 0; k < 9; k++) R.m[k] = a.R[k];
+    const f3 tr = {a.t[0], a.t[1], a.t[2]};
+    MapVal v1[4], n1[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {  // the four level-1 pixels of this block
+        const int y1 = 2 * Y2 + (qd >> 1), x1 = 2 * X2 + (qd & 1);
+        MapVal v0[4], n0[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int yy = 2 * y1 + (s >> 1), xx = 2 * x1 + (s & 1);
+            const int i0 = yy * cols + xx;
+            const float4 vs = v4[i0], ns = n4[i0];
+            snap[i0] = vs;
+            v0[s].have = true; n0[s].have = true;
+            if (!(vs.z == 0)) { v0[s].p = f3{vs.x, vs.y, vs.z}; n0[s].p = f3{ns.x, ns.y, ns.z}; }
+            else { v0[s].p = f3{qnan(), qnan(), qnan()}; n0[s].p = v0[s].p; }
+            emit_map(a.vmap[0], i0, N0, v0[s], R, tr, true);
+            emit_map(a.nmap[0], i0, N0, n0[s], R, tr, false);
+        }
+        v1[qd] = resize4(v0[0], v0[1], v0[2], v0[3], false);
+        n1[qd] = resize4(n0[0], n0[1], n0[2], n0[3], true);
+        const int i1 = y1 * c1 + x1;
+        emit_map(a.vmap[1], i1, N1, v1[qd], R, tr, true);
+        emit_map(a.nmap[1], i1, N1, n1[qd], R, tr, false);
+    }
+    const MapVal v2 = resize4(v1[0], v1[1], v1[2], v1[3], false);
+    const MapVal n2 = resize4(n1[0], n1[1], n1[2], n1[3], true);
+    const int i2 = Y2 * c2 + X2;
+    emit_map(a.vmap[2], i2, N2, v2, R, tr, true);
+    emit_map(a.nmap[2], i2, N2, n2, R, tr, false);
+}
+
 // ------------------------------------------------------------------ launchers ----
+static Level3 levels3(int W, int H)
+{
+    Level3 L; int acc = 0;
+    for (int i = 0; i < 3; i++) { L.cols[i] = W >> i; L.rows[i] = H >> i; acc += grid_for(L.cols[i] * L.rows[i]); L.blk_end[i] = acc; }
+    return L;
+}
+void launch_frame_maps(hipStream_t s, FrameMapsArgs a, int W, int H)
+{
+    a.L = levels3(W, H);
+    frame_maps_kernel<<<a.L.blk_end[2], kBlock, 0, s>>>(a);
+}
+void launch_rgb_prep(hipStream_t s, RgbPrepArgs a, int W, int H)
+{
+    a.L = levels3(W, H);
+    rgb_prep_kernel<<<a.L.blk_end[2], kBlock, 0, s>>>(a);
+}
+void launch_model_maps(hipStream_t s, const ModelMapsArgs& a)
+{
+    const int n = (a.cols >> 2) * (a.rows >> 2);
+    model_maps_kernel<<<(n + 63) / 64, 64, 0, s>>>(a);
+}
 void launch_vmap(hipStream_t s, const float* depth, int cols, int rows, cf_cam intr, float cutoff, float* vmap)
 {
     vmap_kernel<<<grid_for(cols * rows), kBlock, 0, s>>>(depth, cols, rows, 1.f / intr.fx, 1.f / intr.fy, intr.cx, intr.cy,
