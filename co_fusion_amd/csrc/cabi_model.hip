@@ -24,7 +24,15 @@ using namespace cf;
 struct cf_model {
     cf_ctx* ctx = nullptr;
     uint32_t max_surfels = 0;
-    uint32_t count_host = 0;          // exact: refreshed after initialise/clean
+    uint32_t count_host = 0;          // exact, or (while count_pending) an upper bound used for launch sizes
+    // The exact count after clean() travels back asynchronously (pinned copy + event): the frame loop never waits
+    // for it -- every kernel guards on the device-side count, so launches only need an upper bound -- and entry
+    // points that expose the number to the host (cf_model_count, download, buffer 11) resolve it on demand.
+    bool count_pending = false;
+    hipEvent_t count_event = nullptr;
+    // same for the fill-in ratio of the latest splat prediction (computed right after combinedPredict)
+    bool ratio_valid = false;
+    hipEvent_t ratio_event = nullptr;
     float* buf[2] = {nullptr, nullptr};  // ping-pong surfel buffers (Model::vbos[2])
     int target = 0;
     float* staged = nullptr;          // clean staging [max_surfels + N/4]
@@ -141,6 +149,8 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     if (int r = dmalloc(ctx, &m->rays, N * 4)) return r;
     launch_splat_rays(ctx->stream, ctx_cam(ctx), W, H, m->rays);
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->h_counts), sizeof(unsigned) * 4));
+    HIPCHK(ctx, hipEventCreateWithFlags(&m->count_event, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&m->ratio_event, hipEventDisableTiming));
     // texcoords exactly as the reference builds its uv buffer (Model.cpp:166-170)
     std::vector<float> tx(W), ty(H);
     for (int i = 0; i < W; i++) tx[i] = (float)((double)((float)i / (float)W) + 1.0 / (2.0 * (double)(float)W));
@@ -162,16 +172,52 @@ void cf_model_destroy(cf_model* m)
                     m->fill_normal, m->fill_image, m->tcx, m->tcy, m->rays};
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(m->h_counts);
+    if (m->count_event) (void)hipEventDestroy(m->count_event);
+    if (m->ratio_event) (void)hipEventDestroy(m->ratio_event);
     delete m;
 }
 
+static int adopt_count(cf_model* m)
+{
+    m->count_host = m->h_counts[0];
+    m->count_pending = false;
+    if (m->count_host > m->max_surfels) { m->ctx->set_error("surfel buffer overflow"); return CF_ENOMEM; }
+    return CF_OK;
+}
 static int sync_count(cf_model* m)
 {
     cf_ctx* ctx = m->ctx;
     HIPCHK(ctx, hipMemcpyAsync(m->h_counts, m->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    m->count_host = m->h_counts[0];
-    if (m->count_host > m->max_surfels) { ctx->set_error("surfel buffer overflow"); return CF_ENOMEM; }
+    return adopt_count(m);
+}
+// enqueue the read-back of the device count; until it lands count_host holds `upper_bound`
+static int post_count(cf_model* m, uint32_t upper_bound)
+{
+    cf_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipMemcpyAsync(m->h_counts, m->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(m->count_event, ctx->stream));
+    m->count_host = upper_bound;
+    m->count_pending = true;
+    return CF_OK;
+}
+// launch bound: exact when the read-back has landed, otherwise the upper bound
+static int count_bound(cf_model* m, uint32_t* out)
+{
+    if (m->count_pending) {
+        if (hipEventQuery(m->count_event) == hipSuccess) { if (int r = adopt_count(m)) return r; }
+        else (void)hipGetLastError();  // hipErrorNotReady is not an error here
+    }
+    *out = m->count_host;
+    return CF_OK;
+}
+static int exact_count(cf_model* m, uint32_t* out)
+{
+    if (m->count_pending) {
+        HIPCHK(m->ctx, hipEventSynchronize(m->count_event));
+        if (int r = adopt_count(m)) return r;
+    }
+    *out = m->count_host;
     return CF_OK;
 }
 
@@ -198,7 +244,7 @@ int cf_model_initialise(cf_model* m, const uint8_t* rgba, const float* depth_raw
     return sync_count(m);
 }
 
-int cf_model_count(cf_model* m, uint32_t* count) { if (!m || !count) return CF_EINVAL; *count = m->count_host; return CF_OK; }
+int cf_model_count(cf_model* m, uint32_t* count) { if (!m || !count) return CF_EINVAL; return exact_count(m, count); }
 
 int cf_model_predict_indices(cf_model* m, const float pose[16], int time, float maxDepth, int timeDelta)
 {
@@ -206,7 +252,9 @@ int cf_model_predict_indices(cf_model* m, const float pose[16], int time, float 
     cf_ctx* ctx = m->ctx;
     float t_inv[16];
     inv44f(pose, t_inv);
-    launch_predict_indices(ctx->stream, m->buf[m->target], m->d_count, m->count_host, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
+    uint32_t nb = 0;
+    if (int r = count_bound(m, &nb)) return r;
+    launch_predict_indices(ctx->stream, m->buf[m->target], m->d_count, nb, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
                            maxDepth, time, timeDelta, m->keys, m->index, m->vertConf, m->colorTime, m->normRad);
     LAUNCHCHK(ctx);
     return CF_OK;
@@ -218,10 +266,18 @@ int cf_model_combined_predict(cf_model* m, const float pose[16], float maxDepth,
     cf_ctx* ctx = m->ctx;
     float t_inv[16];
     inv44f(pose, t_inv);
-    launch_combined_predict(ctx->stream, m->buf[m->target], m->d_count, m->count_host, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
+    uint32_t nb = 0;
+    if (int r = count_bound(m, &nb)) return r;
+    launch_combined_predict(ctx->stream, m->buf[m->target], m->d_count, nb, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
                             maxDepth, confThreshold, time, maxTime, timeDelta, m->rays, m->keys, m->splat_image, m->splat_vertex, m->splat_normal,
                             m->splat_time);
+    // CoFusion::requiresFillIn looks at this prediction at the start of the next frame: count now, read back
+    // asynchronously, so that the question never stalls the frame loop
+    launch_fill_ratio(ctx->stream, m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2);
     LAUNCHCHK(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(m->h_counts + 2, m->d_tmp2 + 2, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(m->ratio_event, ctx->stream));
+    m->ratio_valid = true;
     return CF_OK;
 }
 
@@ -241,10 +297,14 @@ int cf_model_requires_fill_in(cf_model* m, float ratio, int* out)
 {
     if (!m || !out) return CF_EINVAL;
     cf_ctx* ctx = m->ctx;
-    launch_fill_ratio(ctx->stream, m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2);
-    LAUNCHCHK(ctx);
-    HIPCHK(ctx, hipMemcpyAsync(m->h_counts + 2, m->d_tmp2 + 2, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (m->ratio_valid) {
+        HIPCHK(ctx, hipEventSynchronize(m->ratio_event));
+    } else {
+        launch_fill_ratio(ctx->stream, m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2);
+        LAUNCHCHK(ctx);
+        HIPCHK(ctx, hipMemcpyAsync(m->h_counts + 2, m->d_tmp2 + 2, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     *out = ((float)m->h_counts[2] / (float)m->h_counts[3] < ratio) ? 1 : 0;
     return CF_OK;
 }
@@ -266,7 +326,9 @@ int cf_model_fuse(cf_model* m, const float pose[16], int time, const uint8_t* rg
     launch_exclusive_scan(s, m->new_flags, N, m->new_offsets, m->block_sums, m->d_nfresh, 0);
     launch_scatter_records(s, m->records, m->new_flags, m->new_offsets, N, m->fresh, 0);
     // update.vert over all surfels into the other buffer, then swap (Model.cpp:559)
-    launch_update(s, m->buf[m->target], m->d_count, m->count_host, m->owner, m->records, time, m->buf[1 - m->target]);
+    uint32_t nb = 0;
+    if (int r = count_bound(m, &nb)) return r;
+    launch_update(s, m->buf[m->target], m->d_count, nb, m->owner, m->records, time, m->buf[1 - m->target]);
     m->target = 1 - m->target;
     LAUNCHCHK(ctx);
     return CF_OK;
@@ -279,20 +341,22 @@ int cf_model_clean(cf_model* m, const float pose[16], int time, float confThresh
     if (!m || !pose || !depth_filt || !mask) return CF_EINVAL;
     cf_ctx* ctx = m->ctx; hipStream_t s = ctx->stream;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
-    const unsigned bound = m->count_host + (unsigned)((W / 2) * (H / 2));
+    uint32_t nb = 0;
+    if (int r = count_bound(m, &nb)) return r;
+    const unsigned bound = nb + (unsigned)((W / 2) * (H / 2));
     if (bound > m->max_surfels + (unsigned)(W * H / 4 + 64)) return CF_ENOMEM;
     SurfelCleanArgs a;
     a.index = m->index; a.vertConf = m->vertConf; a.colorTime = m->colorTime; a.depth_filt = depth_filt; a.mask = mask;
     inv44f(pose, a.t_inv); a.cam = ctx_cam(ctx); a.cols = W; a.rows = H; a.time = time; a.confThreshold = confThreshold;
     a.outlierCoeff = outlierCoeff; a.timeDelta = timeDelta; a.maskID = maskID;
     launch_clean(s, m->buf[m->target], m->d_count, m->fresh, m->d_nfresh, bound, a, m->staged, m->flags);
-    launch_exclusive_scan(s, m->flags, bound, m->offsets, m->block_sums, m->d_tmp2, 0);
+    launch_exclusive_scan(s, m->flags, bound, m->offsets, m->block_sums, m->d_count, 0);  // the kept total IS the new count
     launch_scatter_records(s, m->staged, m->flags, m->offsets, bound, m->buf[1 - m->target], 0);
-    HIPCHK(ctx, hipMemcpyAsync(m->d_count, m->d_tmp2, sizeof(unsigned), hipMemcpyDeviceToDevice, s));
     m->target = 1 - m->target;
     LAUNCHCHK(ctx);
-    if (int r = sync_count(m)) return r;
-    if (count_out) *count_out = m->count_host;
+    const uint32_t upper = bound < m->max_surfels ? bound : m->max_surfels;
+    if (int r = post_count(m, upper)) return r;
+    if (count_out) return exact_count(m, count_out);  // the GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN query: waits
     return CF_OK;
 }
 
@@ -301,7 +365,7 @@ int cf_model_download_map(cf_model* m, float* host_surfels, uint32_t capacity, u
 {
     if (!m || !count) return CF_EINVAL;
     cf_ctx* ctx = m->ctx;
-    *count = m->count_host;
+    if (int r = exact_count(m, count)) return r;
     if (host_surfels) {
         const uint32_t n = m->count_host < capacity ? m->count_host : capacity;
         HIPCHK(ctx, hipMemcpyAsync(host_surfels, m->buf[m->target], (size_t)n * 48, hipMemcpyDeviceToHost, ctx->stream));
@@ -317,7 +381,7 @@ int cf_model_upload_map(cf_model* m, const float* host_surfels, uint32_t count)
     if (count) HIPCHK(ctx, hipMemcpyAsync(m->buf[m->target], host_surfels, (size_t)count * 48, hipMemcpyHostToDevice, ctx->stream));
     launch_set_count(ctx->stream, m->d_count, count);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    m->count_host = count;
+    m->count_host = count; m->count_pending = false;
     return CF_OK;
 }
 
@@ -340,7 +404,7 @@ int cf_model_buffer(cf_model* m, int which, void** dptr, uint64_t* bytes)
         case 8: p = m->fill_vertex; b = N * 16; break;
         case 9: p = m->fill_normal; b = N * 16; break;
         case 10: p = m->fill_image; b = N * 4; break;
-        case 11: p = m->buf[m->target]; b = (size_t)m->count_host * 48; break;
+        case 11: { uint32_t c = 0; if (int r = exact_count(m, &c)) return r; p = m->buf[m->target]; b = (size_t)c * 48; break; }
         default: return CF_EINVAL;
     }
     *dptr = p; if (bytes) *bytes = b;

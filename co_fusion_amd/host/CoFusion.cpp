@@ -132,8 +132,8 @@ void Model::fuse(int time, const uint8_t* rgba, const uint8_t* mask, const float
 }
 void Model::clean(int time, int timeDelta, float /*depthCutoff*/, const float* depthFiltered, const uint8_t* mask, float outlierCoeff)
 {
-    uint32_t c = 0;
-    check(ctx, cf_model_clean(model, pose.m, time, confidenceThreshold, outlierCoeff, timeDelta, depthFiltered, mask, (int)id, &c), "cf_model_clean");
+    // the surfel count is read back asynchronously (cf_model_count resolves it on demand): no host wait here
+    check(ctx, cf_model_clean(model, pose.m, time, confidenceThreshold, outlierCoeff, timeDelta, depthFiltered, mask, (int)id, nullptr), "cf_model_clean");
 }
 void Model::predictIndices(int time, float depthCutoff, int timeDelta)
 {
