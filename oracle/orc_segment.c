@@ -176,19 +176,29 @@ static void exp_and_normalize(const float *in, float *out, int L, int n)
     }
 }
 
+/* Summation order over the n nodes (normalisation and message passing): CRF_CHUNKS contiguous chunks of
+ * ceil(n / CRF_CHUNKS) indices, index order inside a chunk, chunk totals added in chunk order.  (A fixed, blocked
+ * order: the GPU evaluates the chunks in parallel and reproduces it bit for bit.) */
+#define CRF_CHUNKS 16
+
 /* Exact Gaussian kernel with symmetric normalisation: Kn[i][j] = n_i * exp(-0.5 |f_i - f_j|^2) * n_j,
- * n_i = 1/sqrt(sum_j exp(..) + 1e-20).  Sums run over j = 0..n-1 in index order. */
+ * n_i = 1/sqrt(sum_j exp(..) + 1e-20). */
 static void crf_kernel(const float *feat, int D, int n, float *Kn)
 {
     float *norm = malloc(sizeof(float) * (size_t)n);
+    const int len = (n + CRF_CHUNKS - 1) / CRF_CHUNKS;
     for (int i = 0; i < n; i++) {
         float s = 0;
-        for (int j = 0; j < n; j++) {
-            float d2 = 0;
-            for (int d = 0; d < D; d++) { const float t = feat[(size_t)i * D + d] - feat[(size_t)j * D + d]; d2 += t * t; }
-            const float k = orc_expf(-0.5f * d2);
-            Kn[(size_t)i * n + j] = k;
-            s += k;
+        for (int c = 0; c < CRF_CHUNKS; c++) {
+            float p = 0;
+            for (int j = c * len; j < n && j < (c + 1) * len; j++) {
+                float d2 = 0;
+                for (int d = 0; d < D; d++) { const float t = feat[(size_t)i * D + d] - feat[(size_t)j * D + d]; d2 += t * t; }
+                const float k = orc_expf(-0.5f * d2);
+                Kn[(size_t)i * n + j] = k;
+                p += k;
+            }
+            s += p;
         }
         norm[i] = 1.0f / sqrtf(s + 1e-20f);
     }
@@ -202,6 +212,7 @@ void orc_crf_meanfield(const float *unary /* [n][L] */, int L, int n, const floa
 {
     float *K1 = malloc(sizeof(float) * (size_t)n * n), *K2 = malloc(sizeof(float) * (size_t)n * n);
     float *tmp = malloc(sizeof(float) * (size_t)n * L), *Qn = malloc(sizeof(float) * (size_t)n * L);
+    const int len = (n + CRF_CHUNKS - 1) / CRF_CHUNKS;
     crf_kernel(feat_smooth, 2, n, K1);
     crf_kernel(feat_app, 6, n, K2);
     for (size_t i = 0; i < (size_t)n * L; i++) tmp[i] = -unary[i];
@@ -210,7 +221,14 @@ void orc_crf_meanfield(const float *unary /* [n][L] */, int L, int n, const floa
         for (int i = 0; i < n; i++)
             for (int l = 0; l < L; l++) {
                 float a = 0, b = 0;
-                for (int j = 0; j < n; j++) { a += K1[(size_t)i * n + j] * Q[(size_t)j * L + l]; b += K2[(size_t)i * n + j] * Q[(size_t)j * L + l]; }
+                for (int c = 0; c < CRF_CHUNKS; c++) {
+                    float pa = 0, pb = 0;
+                    for (int j = c * len; j < n && j < (c + 1) * len; j++) {
+                        pa += K1[(size_t)i * n + j] * Q[(size_t)j * L + l];
+                        pb += K2[(size_t)i * n + j] * Q[(size_t)j * L + l];
+                    }
+                    a += pa; b += pb;
+                }
                 /* tmp1 = -unary; tmp1 -= (-w K Q) for each potential (Segmentation.cpp:462-469) */
                 tmp[(size_t)i * L + l] = (-unary[(size_t)i * L + l] - (-w_smooth * a)) - (-w_app * b);
             }
