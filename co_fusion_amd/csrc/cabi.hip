@@ -407,10 +407,8 @@ static int populate_rgbd(cf_odom* od, const uint8_t* rgba, float* const* depths,
 {
     cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
-    launch_vertices_to_depth(s, od->vmaps_tmp, W, H, od->maxDepthRGB, depths[0]);
-    for (int i = 0; i + 1 < CF_NUM_PYRS; i++) launch_pyrdown_f32(s, depths[i], W >> i, H >> i, depths[i + 1]);
-    launch_intensity(s, rgba, W, H, images[0]);
-    for (int i = 0; i + 1 < CF_NUM_PYRS; i++) launch_pyrdown_u8(s, images[i], W >> i, H >> i, images[i + 1]);
+    // verticesToDepth + imageBGRToIntensity, then both Gaussian pyramids: three launches for the two chains
+    launch_rgbd_pyramids(s, od->vmaps_tmp, rgba, W, H, od->maxDepthRGB, depths, images);
     LAUNCHCHK(ctx);
     return CF_OK;
 }

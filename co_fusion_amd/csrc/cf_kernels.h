@@ -87,6 +87,8 @@ struct ModelMapsArgs {
 };
 void launch_model_maps(hipStream_t s, const ModelMapsArgs& a);  // needs cols % 4 == 0 && rows % 4 == 0
 void launch_frame_maps(hipStream_t s, FrameMapsArgs a, int W, int H);
+void launch_rgbd_pyramids(hipStream_t s, const float* v4, const uint8_t* rgba, int W, int H, float cutoff, float* const depths[3],
+                          uint8_t* const images[3]);
 void launch_rgb_prep(hipStream_t s, RgbPrepArgs a, int W, int H);
 
 // ---- reduction launchers (track_reduce.hip) ----

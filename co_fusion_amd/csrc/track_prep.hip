@@ -122,85 +122,130 @@ __global__ void __launch_bounds__(kBlock) vertices_to_depth_kernel(const float4*
     depth[i] = (z > cutoff || z <= 0) ? qnan() : z;
 }
 
-constexpr int kGaussI[5] = {1, 4, 6, 4, 1};
-__constant__ float kGauss25[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
+// 1-D binomial weight {1, 4, 6, 4, 1}[k]; the 5x5 kernel of the reference is their outer product (exact integers)
+__device__ __forceinline__ int gauss_w(int k) { return k == 2 ? 6 : ((k == 0 || k == 4) ? 1 : 4); }
 
-// pyrDownKernelGaussF, cudafuncs.cu:333-364 (window excludes last row/col, weights anchored at the
-// clamped window END, int count).  The reference cudaMalloc/Free's the weights per call (:523-531).
-__global__ void __launch_bounds__(kBlock) pyrdown_f32_kernel(const float* __restrict__ src, int scols, int srows,
-                                                             float* __restrict__ dst)
+// pyrDownKernelGaussF, cudafuncs.cu:333-364 (window excludes last row/col, weights anchored at the clamped window
+// END, int count).  The reference cudaMalloc/Free's the weights per call (:523-531).  Fully unrolled 5x5 walks (25
+// independent loads, row-major summation order as the reference's loops): literal weights in the interior, weights
+// computed from the window end (ty - cy - 1, tx - cx - 1) and predicated taps on the border.
+__device__ __forceinline__ void pyrdown_f32_px(const float* __restrict__ src, int scols, int srows, float* __restrict__ dst, int i)
 {
-    const int dcols = scols / 2, drows = srows / 2;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= dcols * drows) return;
+    const int dcols = scols / 2;
     const int y = i / dcols, x = i - y * dcols;
     float sum = 0; int count = 0;
     if (2 * x - 2 >= 0 && 2 * y - 2 >= 0 && 2 * x + 3 <= scols - 1 && 2 * y + 3 <= srows - 1) {
-        // interior: the window is the full 5x5, all 25 loads are independent and the weights are literals
-        // (anchored at the window end: index 4-r, 4-c == r, c by symmetry); same row-major summation order
+        // interior: full window, literal weights (index 4-r, 4-c == r, c by symmetry)
+        constexpr int g[5] = {1, 4, 6, 4, 1};
         const float* __restrict__ p0 = src + (2 * y - 2) * scols + (2 * x - 2);
 #pragma unroll
         for (int r = 0; r < 5; r++)
 #pragma unroll
             for (int c = 0; c < 5; c++) {
                 const float s = p0[r * scols + c];
-                if (!is_nan(s)) {
-                    const int wi = kGaussI[r] * kGaussI[c];
+                if (!is_nan(s)) { sum += s * (float)(g[r] * g[c]); count += g[r] * g[c]; }
+            }
+    } else {
+        // border: same walk, predicated, weights from the clamped window end (no serial 25-iteration loop)
+        const int tx = min(2 * x - 2 + 5, scols - 1), ty = min(2 * y - 2 + 5, srows - 1);
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const int cy = 2 * y - 2 + r;
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const int cx = 2 * x - 2 + c;
+                const bool in = cy >= 0 && cy < ty && cx >= 0 && cx < tx;
+                const float s = src[in ? cy * scols + cx : 0];
+                if (in && !is_nan(s)) {
+                    const int wi = gauss_w(ty - cy - 1) * gauss_w(tx - cx - 1);
                     sum += s * (float)wi;
                     count += wi;
                 }
             }
-    } else {
-        const int tx = min(2 * x - 2 + 5, scols - 1), ty = min(2 * y - 2 + 5, srows - 1);
-        for (int cy = max(0, 2 * y - 2); cy < ty; ++cy)
-            for (int cx = max(0, 2 * x - 2); cx < tx; ++cx) {
-                const float s = src[cy * scols + cx];
-                if (!is_nan(s)) {
-                    const float w = kGauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
-                    sum += s * w;
-                    count += (int)w;
-                }
-            }
+        }
     }
     dst[i] = sum / (float)count;
 }
+__global__ void __launch_bounds__(kBlock) pyrdown_f32_kernel(const float* __restrict__ src, int scols, int srows,
+                                                             float* __restrict__ dst)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < (scols / 2) * (srows / 2)) pyrdown_f32_px(src, scols, srows, dst, i);
+}
 
 // pyrDownKernelIntensityGauss, cudafuncs.cu:534-564
-__global__ void __launch_bounds__(kBlock) pyrdown_u8_kernel(const uint8_t* __restrict__ src, int scols, int srows,
-                                                            uint8_t* __restrict__ dst)
+__device__ __forceinline__ void pyrdown_u8_px(const uint8_t* __restrict__ src, int scols, int srows, uint8_t* __restrict__ dst, int i)
 {
-    const int dcols = scols / 2, drows = srows / 2;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= dcols * drows) return;
+    const int dcols = scols / 2;
     const int y = i / dcols, x = i - y * dcols;
     float sum = 0; int count = 0;
     if (2 * x - 2 >= 0 && 2 * y - 2 >= 0 && 2 * x + 3 <= scols - 1 && 2 * y + 3 <= srows - 1) {
+        constexpr int g[5] = {1, 4, 6, 4, 1};
         const uint8_t* __restrict__ p0 = src + (2 * y - 2) * scols + (2 * x - 2);
 #pragma unroll
         for (int r = 0; r < 5; r++)
 #pragma unroll
             for (int c = 0; c < 5; c++) {
                 const uint8_t s = p0[r * scols + c];
-                if (s > 0) {
-                    const int wi = kGaussI[r] * kGaussI[c];
+                if (s > 0) { sum += (float)s * (float)(g[r] * g[c]); count += g[r] * g[c]; }
+            }
+    } else {
+        const int tx = min(2 * x - 2 + 5, scols - 1), ty = min(2 * y - 2 + 5, srows - 1);
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const int cy = 2 * y - 2 + r;
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const int cx = 2 * x - 2 + c;
+                const bool in = cy >= 0 && cy < ty && cx >= 0 && cx < tx;
+                const uint8_t s = src[in ? cy * scols + cx : 0];
+                if (in && s > 0) {
+                    const int wi = gauss_w(ty - cy - 1) * gauss_w(tx - cx - 1);
                     sum += (float)s * (float)wi;
                     count += wi;
                 }
             }
-    } else {
-        const int tx = min(2 * x - 2 + 5, scols - 1), ty = min(2 * y - 2 + 5, srows - 1);
-        for (int cy = max(0, 2 * y - 2); cy < ty; ++cy)
-            for (int cx = max(0, 2 * x - 2); cx < tx; ++cx) {
-                const uint8_t s = src[cy * scols + cx];
-                if (s > 0) {
-                    const float w = kGauss25[(ty - cy - 1) * 5 + (tx - cx - 1)];
-                    sum += (float)s * w;
-                    count += (int)w;
-                }
-            }
+        }
     }
     const float q = sum / (float)count;
     dst[i] = is_nan(q) ? (uint8_t)0 : (uint8_t)(int)q;
+}
+__global__ void __launch_bounds__(kBlock) pyrdown_u8_kernel(const uint8_t* __restrict__ src, int scols, int srows,
+                                                            uint8_t* __restrict__ dst)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < (scols / 2) * (srows / 2)) pyrdown_u8_px(src, scols, srows, dst, i);
+}
+
+// RGBDOdometry::populateRGBDData (RGBDOdometry.cpp:177-194) issues a depth chain and an intensity chain that do not
+// depend on each other: each pyramid step of both shares one launch (workgroups [0, nd) depth, the rest intensity).
+__global__ void __launch_bounds__(kBlock) rgbd_base_kernel(const float4* __restrict__ v4, const uchar4* __restrict__ rgba, int N, float cutoff,
+                                                           float* __restrict__ depth, uint8_t* __restrict__ image)
+{
+    const int nb = (N + kBlock - 1) / kBlock;
+    if ((int)blockIdx.x < nb) {  // verticesToDepthKernel, cudafuncs.cu:602-613
+        const int i = blockIdx.x * kBlock + threadIdx.x;
+        if (i >= N) return;
+        const float z = v4[i].z;
+        depth[i] = (z > cutoff || z <= 0) ? qnan() : z;
+    } else {                     // bgr2IntensityKernel, cudafuncs.cu:626-639
+        const int i = (blockIdx.x - nb) * kBlock + threadIdx.x;
+        if (i >= N) return;
+        const uchar4 s = rgba[i];
+        image[i] = (uint8_t)(int)((float)s.x * 0.114f + (float)s.y * 0.299f + (float)s.z * 0.587f);
+    }
+}
+__global__ void __launch_bounds__(kBlock) rgbd_pyrdown_kernel(const float* __restrict__ dsrc, const uint8_t* __restrict__ isrc, int scols,
+                                                              int srows, float* __restrict__ ddst, uint8_t* __restrict__ idst)
+{
+    const int n = (scols / 2) * (srows / 2), nb = (n + kBlock - 1) / kBlock;
+    if ((int)blockIdx.x < nb) {
+        const int i = blockIdx.x * kBlock + threadIdx.x;
+        if (i < n) pyrdown_f32_px(dsrc, scols, srows, ddst, i);
+    } else {
+        const int i = (blockIdx.x - nb) * kBlock + threadIdx.x;
+        if (i < n) pyrdown_u8_px(isrc, scols, srows, idst, i);
+    }
 }
 
 // bgr2IntensityKernel, cudafuncs.cu:626-639 (texel is R,G,B: .114 R + .299 G + .587 B)
@@ -472,6 +517,15 @@ void launch_model_maps(hipStream_t s, const ModelMapsArgs& a)
 {
     const int n = (a.cols >> 2) * (a.rows >> 2);
     model_maps_kernel<<<(n + 63) / 64, 64, 0, s>>>(a);
+}
+void launch_rgbd_pyramids(hipStream_t s, const float* v4, const uint8_t* rgba, int W, int H, float cutoff, float* const depths[3],
+                          uint8_t* const images[3])
+{
+    rgbd_base_kernel<<<2 * grid_for(W * H), kBlock, 0, s>>>(reinterpret_cast<const float4*>(v4), reinterpret_cast<const uchar4*>(rgba), W * H, cutoff,
+                                                            depths[0], images[0]);
+    for (int i = 0; i + 1 < 3; i++)
+        rgbd_pyrdown_kernel<<<2 * grid_for(((W >> i) / 2) * ((H >> i) / 2)), kBlock, 0, s>>>(depths[i], images[i], W >> i, H >> i, depths[i + 1],
+                                                                                         images[i + 1]);
 }
 void launch_vmap(hipStream_t s, const float* depth, int cols, int rows, cf_cam intr, float cutoff, float* vmap)
 {
