@@ -57,6 +57,8 @@ def parse(argv=None):
     ap.add_argument("--icp-threads", type=int, default=256)
     ap.add_argument("--icp-ppt", type=int, default=1)
     ap.add_argument("--max-surfels", type=int, default=1 << 21)
+    ap.add_argument("--streams", type=int, default=1, help="independent RGB-D streams per GPU (own context + HIP stream + host thread each); "
+                    "1 = the headline single-sequence figure, >1 = throughput mode")
     return ap.parse_args(argv)
 
 
@@ -80,14 +82,14 @@ def frame_index(i, n):
     return k if k < n else period - k
 
 
-def timed_region(step_fn, steps, warmup, barrier, all_reduce_max):
-    """The driver's timing contract: W untimed steps, barrier+sync, EXACTLY K steps, barrier+sync, MAX over ranks."""
-    for i in range(warmup):
-        step_fn(i)
+def timed_region(step_fn, steps, warmup, barrier, all_reduce_max, run_range=None):
+    """The driver's timing contract: W untimed steps, barrier+sync, EXACTLY K steps, barrier+sync, MAX over ranks.
+    run_range(lo, hi) (optional) executes steps lo..hi-1 itself (used for several streams per GPU)."""
+    run = run_range or (lambda lo, hi: [step_fn(i) for i in range(lo, hi)])
+    run(0, warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        step_fn(i)
+    run(warmup, warmup + steps)
     barrier()
     return all_reduce_max(time.perf_counter() - t0)
 
@@ -114,22 +116,40 @@ def main(argv=None):
 
     W, H = args.width, args.height
     n_obj = 0 if args.workload == "static" else 4
-    cam, frames = make_stream(W, H, args.frames, n_obj=n_obj, seed=1234 + rank)
-    cf = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels,
-                         enable_multiple_models=int(n_obj > 0))
-    cf.set_icp_launch(args.icp_threads, args.icp_ppt)
-    dev = torch.device("cuda", local_rank)
-    resident = [dict(depth=torch.from_numpy(f["depth"]).to(dev), rgba=torch.from_numpy(f["rgba"]).to(dev)) for f in frames]
+    import threading
+    S = max(1, args.streams)
     use_gt = args.workload == "objects4-gt"
+    dev = torch.device("cuda", local_rank)
+    streams = []
+    for si in range(S):
+        cam, frames = make_stream(W, H, args.frames, n_obj=n_obj, seed=1234 + rank * 64 + si)
+        cfi = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels,
+                              enable_multiple_models=int(n_obj > 0))
+        cfi.set_icp_launch(args.icp_threads, args.icp_ppt)
+        resident = [dict(depth=torch.from_numpy(f["depth"]).to(dev), rgba=torch.from_numpy(f["rgba"]).to(dev)) for f in frames]
+        streams.append(dict(cf=cfi, frames=frames, resident=resident))
+    cf, frames = streams[0]["cf"], streams[0]["frames"]
     torch.cuda.synchronize()
 
-    def step(i):
+    def step_stream(st, i):
         k = frame_index(i, args.frames)
         if use_gt:  # GT masks are a host-side input of the reference (FrameData.mask); depth/rgb stay host too in this mode
-            f = frames[k]
-            cf.process_frame(f["depth"], f["rgb"], mask=(f["label"] * 40).astype(np.uint8), timestamp=i)
+            f = st["frames"][k]
+            st["cf"].process_frame(f["depth"], f["rgb"], mask=(f["label"] * 40).astype(np.uint8), timestamp=i)
         else:
-            cf.process_frame_device(resident[k]["depth"], resident[k]["rgba"], timestamp=i)
+            st["cf"].process_frame_device(st["resident"][k]["depth"], st["resident"][k]["rgba"], timestamp=i)
+
+    def run_range(lo, hi):
+        """steps lo..hi-1 of every stream; streams beyond the first run on their own host threads (ctypes drops the GIL)"""
+        if S == 1:
+            for i in range(lo, hi):
+                step_stream(streams[0], i)
+            return
+        ths = [threading.Thread(target=lambda st=st: [step_stream(st, i) for i in range(lo, hi)]) for st in streams]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
 
     def barrier():
         torch.cuda.synchronize()
@@ -145,14 +165,13 @@ def main(argv=None):
         return float(tt.item())
 
     # warm-up is untimed; profiling counters only cover the timed steps
-    for i in range(args.warmup):
-        step(i)
+    run_range(0, args.warmup)
     cf.profile_enable(True)
     cf.profile_read(reset=True)
-    dt = timed_region(lambda i: step(i + args.warmup), args.steps, 0, barrier, all_reduce_max)
+    dt = timed_region(None, args.steps, 0, barrier, all_reduce_max, run_range=lambda lo, hi: run_range(lo + args.warmup, hi + args.warmup))
     prof = cf.profile_read(reset=True)
     cf.profile_enable(False)
-    fps = args.steps * world / dt
+    fps = args.steps * world * S / dt
 
     out = None
     if rank == 0:
@@ -174,10 +193,11 @@ def main(argv=None):
                    config=dict(workload=f"{desc}, {W}x{H} synthetic noisy RGB-D, whole CoFusion::processFrame hot path "
                                         "(bilateral, tracking SO3+4/5/10 ICP+RGB GN, predict, fuse, clean)",
                                active_models=n_models, surfels=counts, icp_launch=[args.icp_threads, args.icp_ppt],
-                               streams_per_gpu=1),
+                               streams_per_gpu=S),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out))
-    cf.close()
+    for st in streams:
+        st["cf"].close()
     if dist is not None:
         dist.destroy_process_group()
     return out
