@@ -126,8 +126,12 @@ def main(argv=None):
         cfi = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels,
                               enable_multiple_models=int(n_obj > 0))
         cfi.set_icp_launch(args.icp_threads, args.icp_ppt)
+        hip_stream = None
+        if S > 1:  # every stream of work on its own HIP stream (the default is torch's current stream)
+            hip_stream = torch.cuda.Stream(device=dev)
+            cfi.set_stream(hip_stream)
         resident = [dict(depth=torch.from_numpy(f["depth"]).to(dev), rgba=torch.from_numpy(f["rgba"]).to(dev)) for f in frames]
-        streams.append(dict(cf=cfi, frames=frames, resident=resident))
+        streams.append(dict(cf=cfi, frames=frames, resident=resident, hip_stream=hip_stream))
     cf, frames = streams[0]["cf"], streams[0]["frames"]
     torch.cuda.synchronize()
 

@@ -16,7 +16,8 @@ class Config(C.Structure):
                 ("device", C.c_int), ("max_surfels", C.c_int), ("max_models", C.c_int), ("conf_global_init", C.c_float),
                 ("conf_object_init", C.c_float), ("depth_cutoff", C.c_float), ("icp_weight", C.c_float),
                 ("outlier_coefficient", C.c_float), ("fast_odom", C.c_int), ("so3", C.c_int), ("frame_to_frame_rgb", C.c_int),
-                ("pyramid", C.c_int), ("rgb_only", C.c_int), ("model_spawn_offset", C.c_uint), ("enable_multiple_models", C.c_int)]
+                ("pyramid", C.c_int), ("rgb_only", C.c_int), ("model_spawn_offset", C.c_uint), ("enable_multiple_models", C.c_int),
+                ("enable_pose_logging", C.c_int)]
 
 
 class CoFusionError(RuntimeError):
@@ -47,6 +48,25 @@ class CoFusion:
     def _check(self, rc):
         if rc != 0:
             raise CoFusionError(f"cofusion error {rc}: {self.lib.cofusion_last_error().decode()}")
+
+    def set_stream(self, stream):
+        """enqueue all work of this instance on a torch.cuda.Stream (or a raw hipStream_t value)"""
+        ptr = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+        self._check(self.lib.cofusion_set_stream(self.h, C.c_void_p(ptr)))
+
+    def save_ply(self, prefix):
+        """CoFusion::savePly: <prefix>cloud-<id>.ply per model; returns the number of files"""
+        n = self.lib.cofusion_save_ply(self.h, str(prefix).encode())
+        if n < 0:
+            raise CoFusionError(self.lib.cofusion_last_error().decode())
+        return n
+
+    def export_poses(self, prefix):
+        """CoFusion::exportPoses: <prefix>poses-<id>.txt per logged model (needs enable_pose_logging=1)"""
+        n = self.lib.cofusion_export_poses(self.h, str(prefix).encode())
+        if n < 0:
+            raise CoFusionError(self.lib.cofusion_last_error().decode())
+        return n
 
     def close(self):
         if getattr(self, "h", None):

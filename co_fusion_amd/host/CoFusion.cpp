@@ -491,6 +491,7 @@ CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
     check(ctx, cf_malloc(ctx, N, &p), "cf_malloc"); mask_dev = static_cast<uint8_t*>(p);
     rgbaHost.resize(N * 4);
     globalModel = std::make_shared<Model>(ctx, getNextModelID(true), cfg.confGlobalInit, true, cfg.maxSurfels);
+    globalModel->loggingPoses = cfg.enablePoseLogging;
     models.push_back(globalModel);
 }
 
@@ -521,6 +522,7 @@ unsigned char CoFusion::getNextModelID(bool assign)
 void CoFusion::spawnObjectModel()
 {  // CoFusion.cpp:588-598
     newModel = std::make_shared<Model>(ctx, getNextModelID(true), cfg.confObjectInit, false, cfg.maxSurfels);
+    newModel->loggingPoses = cfg.enablePoseLogging;
     check(ctx, cf_odom_init_first_rgb(newModel->getFrameOdometry(), curRgba), "initFirstRGB");
 }
 void CoFusion::moveNewModelToList()
@@ -658,6 +660,7 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
 
     bool first = true;
     for (auto& model : models) {  // pose log, CoFusion.cpp:502-520
+        if (!model->isLoggingPoses()) { first = false; continue; }
         const Mat4f p = first ? globalModel->getPose() : globalModel->getPose() * model->getPose().inverse();
         Model::PoseLogItem item;
         item.ts = frame.timestamp;

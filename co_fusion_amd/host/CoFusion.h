@@ -92,8 +92,10 @@ class Model {
     const float* vertexConfProjection() const;
     cf_track_stats lastStats{};
 
-    struct PoseLogItem { int64_t ts; float p[7]; };
+    struct PoseLogItem { int64_t ts; float p[7]; };  // x,y,z, qx,qy,qz,qw (Model.h:230-233)
     std::vector<PoseLogItem> poseLog;
+    bool loggingPoses = false;
+    bool isLoggingPoses() const { return loggingPoses; }
 
   private:
     friend class CoFusion;
@@ -154,6 +156,7 @@ class CoFusion {
         bool fastOdom = false, so3 = true, frameToFrameRGB = false, pyramid = true, rgbOnly = false;
         unsigned modelSpawnOffset = 22;                        // GUI.h:219
         bool enableMultipleModels = true;
+        bool enablePoseLogging = false;                        // CoFusion ctor argument (CoFusion.h:59)
     };
     explicit CoFusion(const Config& cfg);
     ~CoFusion();
@@ -161,6 +164,9 @@ class CoFusion {
     // CoFusion::processFrame (Core/CoFusion.cpp:171-524)
     bool processFrame(const FrameData& frame, const Mat4f* inPose = nullptr, float weightMultiplier = 1.f, bool bootstrap = false);
     void predict();                                  // CoFusion.cpp:533-545
+    // CoFusion::savePly / exportPoses (CoFusion.cpp:646-783); exportDir is a prefix ("out/"); return files written or -1
+    int savePly(const std::string& exportDir);
+    int exportPoses(const std::string& exportDir);
     ModelList& getModels() { return models; }
     ModelPointer getBackgroundModel() { return globalModel; }
     const Mat4f& getCurrPose() const { return globalModel->getPose(); }

@@ -1,11 +1,13 @@
 // cofusion_c.cpp -- flat C wrapper (include/cofusion.h) around the C++ facade.
 #include "../../include/cofusion.h"
 
+#include <cstring>
 #include <exception>
 #include <iterator>
 #include <string>
 
 #include "CoFusion.h"
+#include "KlgIO.h"
 
 using namespace cofusion;
 
@@ -28,6 +30,7 @@ void cofusion_default_config(cofusion_config* c)
     c->outlier_coefficient = d.outlierCoefficient; c->fast_odom = d.fastOdom; c->so3 = d.so3; c->frame_to_frame_rgb = d.frameToFrameRGB;
     c->pyramid = d.pyramid; c->rgb_only = d.rgbOnly; c->model_spawn_offset = d.modelSpawnOffset;
     c->enable_multiple_models = d.enableMultipleModels;
+    c->enable_pose_logging = d.enablePoseLogging;
 }
 
 int cofusion_create(const cofusion_config* c, cofusion_handle** out)
@@ -40,6 +43,7 @@ int cofusion_create(const cofusion_config* c, cofusion_handle** out)
     d.outlierCoefficient = c->outlier_coefficient; d.fastOdom = c->fast_odom; d.so3 = c->so3; d.frameToFrameRGB = c->frame_to_frame_rgb;
     d.pyramid = c->pyramid; d.rgbOnly = c->rgb_only; d.modelSpawnOffset = c->model_spawn_offset;
     d.enableMultipleModels = c->enable_multiple_models;
+    d.enablePoseLogging = c->enable_pose_logging != 0;
     GUARD(*out = new cofusion_handle{new CoFusion(d)});
     return 0;
 }
@@ -110,5 +114,54 @@ int cofusion_set_crf(cofusion_handle* h, float uwe, float uke, float thn, float 
     s.minRelSizeNew = minr; s.maxRelSizeNew = maxr; s.crfIterations = its;
     return 0;
 }
+
+int cofusion_save_ply(cofusion_handle* h, const char* prefix)
+{
+    try { const int n = h->cf->savePly(prefix ? prefix : ""); if (n < 0) g_err = "savePly: cannot write"; return n; }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int cofusion_export_poses(cofusion_handle* h, const char* prefix)
+{
+    try { const int n = h->cf->exportPoses(prefix ? prefix : ""); if (n < 0) g_err = "exportPoses: cannot write"; return n; }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+struct cofusion_klg_reader { KlgLogReader r; cofusion_klg_reader(const char* f, int w, int hh, bool fl) : r(f, w, hh, fl) {} };
+struct cofusion_klg_writer { KlgLogWriter w; cofusion_klg_writer(const char* f, int ww, int hh, bool c) : w(f, ww, hh, c) {} };
+int cofusion_klg_open(const char* file, int width, int height, int flip, cofusion_klg_reader** out, int* num_frames)
+{
+    if (!file || !out || width <= 0 || height <= 0) { g_err = "cofusion_klg_open: bad arguments"; return -1; }
+    auto* r = new cofusion_klg_reader(file, width, height, flip != 0);
+    if (!r->r.ok()) { g_err = r->r.error(); delete r; return -1; }
+    if (num_frames) *num_frames = r->r.getNumFrames();
+    *out = r;
+    return 0;
+}
+int cofusion_klg_next(cofusion_klg_reader* r, int64_t* ts, float* depth_m, uint8_t* rgb)
+{
+    if (!r) return -1;
+    if (!r->r.hasMore()) return 1;  // end of log
+    if (!r->r.getNext()) { g_err = r->r.error(); return -1; }
+    if (ts) *ts = r->r.timestamp;
+    if (depth_m) memcpy(depth_m, r->r.depth.data(), r->r.depth.size() * sizeof(float));
+    if (rgb) memcpy(rgb, r->r.rgb.data(), r->r.rgb.size());
+    return 0;
+}
+void cofusion_klg_close(cofusion_klg_reader* r) { delete r; }
+int cofusion_klg_create(const char* file, int width, int height, int compress_depth, cofusion_klg_writer** out)
+{
+    if (!file || !out || width <= 0 || height <= 0) { g_err = "cofusion_klg_create: bad arguments"; return -1; }
+    auto* w = new cofusion_klg_writer(file, width, height, compress_depth != 0);
+    if (!w->w.ok()) { g_err = std::string("cannot create ") + file; delete w; return -1; }
+    *out = w;
+    return 0;
+}
+int cofusion_klg_write(cofusion_klg_writer* w, int64_t ts, const float* depth_m, const uint8_t* rgb)
+{
+    if (!w || !depth_m) return -1;
+    if (!w->w.write(ts, depth_m, rgb)) { g_err = "klg write failed"; return -1; }
+    return 0;
+}
+int cofusion_klg_finish(cofusion_klg_writer* w) { if (!w) return -1; w->w.close(); delete w; return 0; }
 
 }  // extern "C"

@@ -21,6 +21,7 @@ typedef struct {
     int fast_odom, so3, frame_to_frame_rgb, pyramid, rgb_only;
     unsigned model_spawn_offset;
     int enable_multiple_models;
+    int enable_pose_logging; /* CoFusion ctor argument enablePoseLogging (CoFusion.h:59); needed by cofusion_export_poses */
 } cofusion_config;
 
 void cofusion_default_config(cofusion_config *cfg);
@@ -49,6 +50,22 @@ void *cofusion_context(cofusion_handle *h);
 int cofusion_set_crf(cofusion_handle *h, float unary_weight_error, float unary_k_error, float threshold_new, float weight_appearance,
                      float weight_smoothness, float sigma_rgb, float sigma_depth, float sigma_pos, float min_rel_size_new,
                      float max_rel_size_new, unsigned iterations);
+
+/* CoFusion::savePly / exportPoses (CoFusion.cpp:646-783): writes <prefix>cloud-<id>.ply / <prefix>poses-<id>.txt; returns the
+ * number of files written or a negative error */
+int cofusion_save_ply(cofusion_handle *h, const char *export_dir_prefix);
+int cofusion_export_poses(cofusion_handle *h, const char *export_dir_prefix);
+
+/* .klg RGB-D logs (GUI/Tools/KlgLogReader.cpp:22-87): u16-mm depth raw or zlib, 8-bit x3 colour raw (JPEG frames are
+ * rejected: no libjpeg in this build).  depth_m [H*W] metres, rgb [H*W*3]. */
+typedef struct cofusion_klg_reader cofusion_klg_reader;
+typedef struct cofusion_klg_writer cofusion_klg_writer;
+int cofusion_klg_open(const char *file, int width, int height, int flip_colors, cofusion_klg_reader **out, int *num_frames);
+int cofusion_klg_next(cofusion_klg_reader *r, int64_t *timestamp, float *depth_m, uint8_t *rgb);
+void cofusion_klg_close(cofusion_klg_reader *r);
+int cofusion_klg_create(const char *file, int width, int height, int compress_depth, cofusion_klg_writer **out);
+int cofusion_klg_write(cofusion_klg_writer *w, int64_t timestamp, const float *depth_m, const uint8_t *rgb);
+int cofusion_klg_finish(cofusion_klg_writer *w);
 
 #ifdef __cplusplus
 }

@@ -113,3 +113,42 @@ def test_facade_multi_model_matches_oracle(use_gt_mask):
         spawned = spawned or len(ref.models) > 1
     assert spawned, "no object model was spawned: the multi-model path was not exercised"
     cf.close()
+
+
+def test_klg_driven_run_and_exporters(tmp_path):
+    """a .klg log drives the pipeline; savePly / exportPoses write the reference's formats."""
+    from co_fusion_amd import facade, klg
+    cam = synth.Camera.scaled(W, H)
+    sc = synth.Scene(n_obj=0)
+    path = tmp_path / "seq.klg"
+    with klg.KlgWriter(path, W, H) as wr:
+        for t in range(5):
+            d, rgb, _, _ = sc.render(cam, t, noise=True)
+            wr.write(33333 * t, d, rgb)
+    cf = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, max_surfels=1 << 19, conf_global_init=0.5, enable_multiple_models=0,
+                         enable_pose_logging=1)
+    ref = op.StaticPipeline(cam, conf_global=0.5)
+    for ts, d, rgb in klg.KlgReader(path, W, H):
+        cf.process_frame(d, rgb, timestamp=ts)
+        ref.process_frame(d, synth.rgb_to_rgba(rgb))       # the oracle sees the same mm-quantised frames
+    info = cf.model_info(0)
+    _same(info["pose"], ref.pose, "pose after the klg run")
+    prefix = str(tmp_path) + "/"
+    assert cf.export_poses(prefix) == 1 and cf.save_ply(prefix) == 1
+    lines = open(prefix + "poses-0.txt").read().strip().splitlines()
+    assert len(lines) == 5
+    last = np.array(lines[-1].split()[1:], np.float64)
+    assert int(lines[-1].split()[0]) == 33333 * 4
+    np.testing.assert_allclose(last[:3], info["pose"][:3, 3], rtol=0, atol=1e-6)   # background: cam -> world
+    assert abs(np.linalg.norm(last[3:]) - 1.0) < 1e-5
+    raw = open(prefix + "cloud-0.ply", "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    nv = int([l for l in head.decode().splitlines() if l.startswith("element vertex")][0].split()[-1])
+    surf = cf.model_download(0)
+    keep = surf[surf[:, 3] > info["conf_threshold"]]
+    assert nv == keep.shape[0] and len(body) == nv * 31
+    rec = np.frombuffer(body[:31], np.dtype([("p", "<f4", 3), ("c", "u1", 3), ("n", "<f4", 3), ("r", "<f4")]))[0]
+    np.testing.assert_allclose(rec["p"], keep[0, :3], atol=1e-6)      # Tp = identity for the background model
+    np.testing.assert_allclose(rec["n"], -keep[0, 8:11], atol=1e-6)
+    assert rec["r"] == keep[0, 11]
+    cf.close()
