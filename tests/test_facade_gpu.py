@@ -152,3 +152,58 @@ def test_klg_driven_run_and_exporters(tmp_path):
     np.testing.assert_allclose(rec["n"], -keep[0, 8:11], atol=1e-6)
     assert rec["r"] == keep[0, 11]
     cf.close()
+
+
+def _run_static_pair(frames, cam, Wx, Hx, max_surfels=1 << 20):
+    from co_fusion_amd import facade
+    ref = op.StaticPipeline(cam, conf_global=0.5)
+    cf = facade.CoFusion(Wx, Hx, cam.fx, cam.fy, cam.cx, cam.cy, max_surfels=max_surfels, conf_global_init=0.5, enable_multiple_models=0)
+    for t, (d, rgb) in enumerate(frames):
+        rp, rn = ref.process_frame(d, synth.rgb_to_rgba(rgb))
+        cf.process_frame(d, rgb, timestamp=t)
+        info = cf.model_info(0)
+        assert info["count"] == rn, f"frame {t}: count {info['count']} vs {rn}"
+        _same(info["pose"], rp, f"frame {t}: pose")
+        _same(cf.model_download(0), ref.surfels, f"frame {t}: surfels")
+    cf.close()
+
+
+def test_degenerate_frames_match_oracle():
+    """Edge cases of the input domain: a frame without any valid depth, a frame with a large hole and out-of-range
+    depths (< 0.3 m, > cutoff), black colour: nothing to track / fuse must behave exactly like the oracle."""
+    cam = synth.Camera.scaled(W, H)
+    sc = synth.Scene(n_obj=0)
+    frames = []
+    for t in range(6):
+        d, rgb, _, _ = sc.render(cam, t, noise=True)
+        d = d.copy(); rgb = rgb.copy()
+        if t == 2:
+            d[:] = 0                                   # sensor drop-out: no valid pixel at all
+        if t == 3:
+            d[40:160, 60:260] = 0                      # hole
+            d[:30, :] = 0.1                            # closer than the bilateral gate
+            d[-30:, :] = 9.0                           # beyond the depth cut-off
+        if t == 4:
+            rgb[:] = 0                                 # no photometric information
+        frames.append((d, rgb))
+    _run_static_pair(frames, cam, W, H)
+
+
+def test_full_resolution_matches_oracle():
+    """BASELINE.json's size (640x480), three frames, free running."""
+    Wf, Hf = 640, 480
+    cam = synth.Camera.scaled(Wf, Hf)
+    sc = synth.Scene(n_obj=0)
+    frames = [sc.render(cam, t, noise=True)[:2] for t in range(3)]
+    _run_static_pair(frames, cam, Wf, Hf, max_surfels=1 << 21)
+
+
+def test_surfel_buffer_overflow_is_an_error_not_a_crash():
+    from co_fusion_amd import facade
+    cam = synth.Camera.scaled(W, H)
+    sc = synth.Scene(n_obj=0)
+    d, rgb, _, _ = sc.render(cam, 0, noise=True)
+    cf = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, max_surfels=1 << 12, enable_multiple_models=0)   # 4096 < 320*240
+    with pytest.raises(facade.CoFusionError):
+        cf.process_frame(d, rgb, timestamp=0)
+    cf.close()
