@@ -223,21 +223,40 @@ __global__ void __launch_bounds__(256) crf_init_kernel(const float* __restrict__
     for (int l = 0; l < L; l++) { e[l] = det_expf(-unary[i * L + l] - mx); s += e[l]; }
     for (int l = 0; l < L; l++) Q[i * L + l] = e[l] / s;
 }
-// one mean-field step, part 1: chunk partials of K1*Q and K2*Q for every label; partial[((c*n + i)*2 + which)*kMaxL + l]
+// one mean-field step, part 1: chunk partials of K1*Q and K2*Q for every label; partial[((c*n + i)*2 + which)*kMaxL + l].
+// LT > 0: the label count as a compile-time constant (no predication); the chunk is walked five nodes at a time so
+// that the 10 kernel-matrix loads of a group are in flight together (the sums stay in node order).
+template <int LT>
 __global__ void __launch_bounds__(64) crf_message_kernel(int L, int n, const float* __restrict__ K1t, const float* __restrict__ K2t,
                                                          const float* __restrict__ Q, float* __restrict__ partial)
 {
+    constexpr int LL = LT > 0 ? LT : kMaxL;
     const int i = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
     if (i >= n) return;
     const int len = (n + kCrfChunks - 1) / kCrfChunks, j0 = c * len, j1 = min(n, j0 + len);
-    float a[kMaxL], b[kMaxL];
+    float a[LL], b[LL];
 #pragma unroll
-    for (int l = 0; l < kMaxL; l++) { a[l] = 0; b[l] = 0; }
-    for (int j = j0; j < j1; j++) {
+    for (int l = 0; l < LL; l++) { a[l] = 0; b[l] = 0; }
+    int j = j0;
+    for (; j + 5 <= j1; j += 5) {
+        float k1[5], k2[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) { k1[u] = K1t[(j + u) * n + i]; k2[u] = K2t[(j + u) * n + i]; }
+#pragma unroll
+        for (int u = 0; u < 5; u++)
+#pragma unroll
+            for (int l = 0; l < LL; l++)
+                if (LT > 0 || l < L) {
+                    const float q = Q[(j + u) * L + l];
+                    a[l] += k1[u] * q;
+                    b[l] += k2[u] * q;
+                }
+    }
+    for (; j < j1; j++) {
         const float k1 = K1t[j * n + i], k2 = K2t[j * n + i];
 #pragma unroll
-        for (int l = 0; l < kMaxL; l++)
-            if (l < L) {
+        for (int l = 0; l < LL; l++)
+            if (LT > 0 || l < L) {
                 const float q = Q[j * L + l];
                 a[l] += k1 * q;
                 b[l] += k2 * q;
@@ -245,8 +264,21 @@ __global__ void __launch_bounds__(64) crf_message_kernel(int L, int n, const flo
     }
     float* out = partial + ((size_t)(c * n + i) * 2) * kMaxL;
 #pragma unroll
-    for (int l = 0; l < kMaxL; l++)
-        if (l < L) { out[l] = a[l]; out[kMaxL + l] = b[l]; }
+    for (int l = 0; l < LL; l++)
+        if (LT > 0 || l < L) { out[l] = a[l]; out[kMaxL + l] = b[l]; }
+}
+static void launch_crf_message(hipStream_t st, dim3 grid, int L, int n, const float* K1t, const float* K2t, const float* Q, float* partial)
+{
+    switch (L) {
+        case 2: crf_message_kernel<2><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
+        case 3: crf_message_kernel<3><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
+        case 4: crf_message_kernel<4><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
+        case 5: crf_message_kernel<5><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
+        case 6: crf_message_kernel<6><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
+        case 7: crf_message_kernel<7><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
+        case 8: crf_message_kernel<8><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
+        default: crf_message_kernel<0><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
+    }
 }
 // part 2: chunk totals in chunk order, unary, softmax over the labels
 __global__ void __launch_bounds__(256) crf_update_kernel(const float* __restrict__ unary, int L, int n, const float* __restrict__ partial,
@@ -259,12 +291,15 @@ __global__ void __launch_bounds__(256) crf_update_kernel(const float* __restrict
     for (int l = 0; l < kMaxL; l++) {
         tmp[l] = 0;
         if (l < L) {
-            float a = 0, b = 0;
-            for (int c = 0; c < kCrfChunks; c++) {
+            float pa[kCrfChunks], pb[kCrfChunks];
+#pragma unroll
+            for (int c = 0; c < kCrfChunks; c++) {  // independent loads first, then the ordered sums
                 const float* in = partial + ((size_t)(c * n + i) * 2) * kMaxL;
-                a += in[l];
-                b += in[kMaxL + l];
+                pa[c] = in[l]; pb[c] = in[kMaxL + l];
             }
+            float a = 0, b = 0;
+#pragma unroll
+            for (int c = 0; c < kCrfChunks; c++) { a += pa[c]; b += pb[c]; }
             tmp[l] = (-unary[i * L + l] - (-w_smooth * a)) - (-w_app * b);
         }
     }
@@ -439,7 +474,7 @@ int cf_seg_crf(cf_segmenter* s, const float* unary_host, int L, const float* fea
     crf_init_kernel<<<g1, 256, 0, st>>>(s->unary, L, n, s->Q0);
     float *q = s->Q0, *qn = s->Q1;
     for (int it = 0; it < iterations; it++) {
-        crf_message_kernel<<<gc, 64, 0, st>>>(L, n, s->K1t, s->K2t, q, s->partial);
+        launch_crf_message(st, gc, L, n, s->K1t, s->K2t, q, s->partial);
         crf_update_kernel<<<g1, 256, 0, st>>>(s->unary, L, n, s->partial, w_smooth, w_app, qn);
         float* t = q; q = qn; qn = t;
     }

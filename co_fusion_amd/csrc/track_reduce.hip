@@ -159,11 +159,14 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     float* __restrict__ errs = (args.flags & 1) ? ma.err : nullptr;
     const int abl = args.flags >> 8;  // micro-benchmark ablation bits (0 in production)
 
-    unsigned long long acc[32];
+    float row[PPT][7];
+    int fnd[PPT], any_found = 0;
 #pragma unroll
-    for (int k = 0; k < 28; k++) acc[k] = 0ull - (unsigned long long)PPT * kMagicBits;
-    acc[28] = acc[29] = acc[30] = acc[31] = 0;
-
+    for (int p = 0; p < PPT; p++) {
+        fnd[p] = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) row[p][k] = 0.f;
+    }
     const int i0 = (lb * T + threadIdx.x) * PPT;
     if (i0 < N) {  // N is a multiple of PPT (cols is), so the whole vector is in range
         float vx[PPT], vy[PPT], vz[PPT], nx[PPT], ny[PPT], nz[PPT];
@@ -176,22 +179,32 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
         const f3 tprev = {st->tprev[0], st->tprev[1], st->tprev[2]};
 #pragma unroll
         for (int p = 0; p < PPT; p++) {
-            float row[7], err; int found;
+            float err;
             icp_pixel(Rcurr, tcurr, Rprev_inv, tprev, args.intr, args.distThres, args.angleThres, cols, rows, N, vp, np,
-                      f3{vx[p], vy[p], vz[p]}, f3{nx[p], ny[p], nz[p]}, row, err, found);
+                      f3{vx[p], vy[p], vz[p]}, f3{nx[p], ny[p], nz[p]}, row[p], err, fnd[p]);
             if (errs) errs[i0 + p] = err;
-            if (!(abl & 1)) se3_accumulate<kFixICP>(row, acc);
-            else acc[0] += __float_as_uint(row[6]) + __float_as_uint(row[3]);
-            acc[28] += (unsigned long long)found;
+            any_found |= fnd[p];
         }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 28; k++) acc[k] = 0;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (abl & 2) { if (acc[0] + acc[28] == 0x1234567ull) ma.acc[lane] = acc[5]; return; }
-    const unsigned long long v = wave_reduce32_u64(acc, lane);
-    if (abl & 4) { if (v == 0x1234567ull) ma.acc[lane] = v; return; }
+    // A wave without a single correspondence contributes exact zeros (all rows are zero): skip the accumulation and
+    // the butterfly.  Object models cover a small part of the image, so most of their waves take this exit.
+    unsigned long long v = 0;
+    if (__any(any_found) || abl) {
+        unsigned long long acc[32];
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc[k] = 0ull - (unsigned long long)PPT * kMagicBits;
+        acc[28] = acc[29] = acc[30] = acc[31] = 0;
+#pragma unroll
+        for (int p = 0; p < PPT; p++) {
+            if (!(abl & 1)) se3_accumulate<kFixICP>(row[p], acc);
+            else acc[0] += __float_as_uint(row[p][6]) + __float_as_uint(row[p][3]);
+            acc[28] += (unsigned long long)fnd[p];
+        }
+        if (abl & 2) { if (acc[0] + acc[28] == 0x1234567ull) ma.acc[lane] = acc[5]; return; }
+        v = wave_reduce32_u64(acc, lane);
+        if (abl & 4) { if (v == 0x1234567ull) ma.acc[lane] = v; return; }
+    }
     block_commit32<16>(v, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
 }
 
@@ -343,10 +356,13 @@ __global__ void __launch_bounds__(256) rgb_step_kernel(const RgbArgs ra)
                 row[5] = -py * v0 + px * v1;
             }
         }
-        se3_accumulate<kFixRGB>(row, acc);
-        acc[28] = (unsigned long long)found;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const unsigned long long v = wave_reduce32_u64(acc, lane);
+        unsigned long long v = 0;
+        if (__any(found)) {  // a wave without a valid correspondence adds exact zeros
+            se3_accumulate<kFixRGB>(row, acc);
+            acc[28] = (unsigned long long)found;
+            v = wave_reduce32_u64(acc, lane);
+        }
         block_commit32<4>(v, lane, wave, 4, m.rgb_acc + (size_t)(blockIdx.x % kGroups) * 32);
     }
 }

@@ -3,12 +3,23 @@
 // Compiled with -ffp-contract=off: the host arithmetic here is mirrored by the CPU oracle.
 #include "CoFusion.h"
 
+#include <chrono>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
 
 namespace cofusion {
+
+PhaseTimes& phaseTimes() { static thread_local PhaseTimes t; return t; }
+namespace {
+struct PhaseTimer {
+    int id; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit PhaseTimer(int i) : id(i) {}
+    ~PhaseTimer() { phaseTimes().ms[id] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
 
 static void check(cf_ctx* ctx, int rc, const char* what)
 {
@@ -253,6 +264,7 @@ SegmentationResult Segmentation::performSegmentationCRF(ModelList& models, const
     const float MAX_DEPTH = 100;
     const int gx = width / SPIX, gy = height / SPIX, K = gx * gy;
 
+    std::unique_ptr<PhaseTimer> pt(new PhaseTimer(PhaseTimes::SegSlicAccumulate));
     check(ctx, cf_seg_slic(seg, rgba_dev), "cf_seg_slic");
     std::vector<uint32_t> spc(K), dcnt(K);
     std::vector<int64_t> dsum(K), icpSum((size_t)K * n_models), confSum((size_t)K * n_models);
@@ -265,6 +277,7 @@ SegmentationResult Segmentation::performSegmentationCRF(ModelList& models, const
     check(ctx, cf_seg_accumulate(seg, depth_dev, n_models, icpPtr.data(), vcPtr.data(), spc.data(), dcnt.data(), dsum.data(), icpSum.data(),
                                  confSum.data(), resample.data()),
           "cf_seg_accumulate");
+    pt.reset(new PhaseTimer(PhaseTimes::SegUnary));
     std::vector<float> lowDepth(K);
     finishMean(dsum.data(), dcnt.data(), spc.data(), resample.data(), K, lowDepth.data());
     float depthMin = 3.402823466e+38f, depthMax = 0;
@@ -337,7 +350,9 @@ SegmentationResult Segmentation::performSegmentationCRF(ModelList& models, const
         }
     for (auto& u : unary) if (u <= 1e-5f) u = 1e-5f;
     std::vector<float> Q((size_t)K * L);
+    pt.reset(new PhaseTimer(PhaseTimes::SegCrf));
     check(ctx, cf_seg_crf(seg, unary.data(), L, f1.data(), f2.data(), weightSmoothness, weightAppearance, (int)crfIterations, Q.data()), "cf_seg_crf");
+    pt.reset(new PhaseTimer(PhaseTimes::SegPost));
     std::vector<uint8_t> map(K);
     for (int i = 0; i < K; i++) {
         int m = 0; float best = Q[(size_t)i * L];
@@ -596,7 +611,7 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
         if (bootstrap || !inPose) {
             check(ctx, cf_depth_pyramid(ctx, depthFiltered_dev, cfg.width, cfg.height, depthPyr1, depthPyr2), "generateCUDATextures");
             const float* pyr[3] = {depthFiltered_dev, depthPyr1, depthPyr2};
-            trackModels(pyr);
+            { PhaseTimer t(PhaseTimes::Track); trackModels(pyr); }
             if (bootstrap) globalModel->overridePose(globalModel->getPose() * (*inPose));
 
             if (cfg.enableMultipleModels) {
@@ -646,15 +661,17 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
         } else {
             globalModel->overridePose(*inPose);
         }
-        predict();
+        { PhaseTimer t(PhaseTimes::Predict); predict(); }
         if (!cfg.rgbOnly && trackingOk && !lost) {
+            PhaseTimer t(PhaseTimes::Fuse);
             for (auto& model : models) model->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
             for (auto& model : models) model->fuse(tick, curRgba, mask_dev, curDepth, depthFiltered_dev, maxDepthProcessed, weightMultiplier);
             for (auto& model : models) model->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
             for (auto& model : models) model->clean(tick, cfg.timeDelta, maxDepthProcessed, depthFiltered_dev, mask_dev, cfg.outlierCoefficient);
         }
     }
-    predict();
+    { PhaseTimer t(PhaseTimes::Predict); predict(); }
+    phaseTimes().frames++;
     if (!lost) tick++;
     moveNewModelToList();
 

@@ -52,6 +52,14 @@ struct SegmentationResult {
 
 class CoFusion;
 
+// host wall-clock per phase of processFrame (diagnostics: where the host keeps the GPU waiting)
+struct PhaseTimes {
+    enum { Prepare, Track, SegSlicAccumulate, SegUnary, SegCrf, SegPost, ModelLogic, Fuse, Predict, Count };
+    double ms[Count] = {0};
+    long frames = 0;
+};
+PhaseTimes& phaseTimes();
+
 class Model {
   public:
     Model(cf_ctx* ctx, unsigned char id, float confidenceThresh, bool enableFillIn, int maxSurfels,

@@ -115,6 +115,15 @@ int cofusion_set_crf(cofusion_handle* h, float uwe, float uke, float thn, float 
     return 0;
 }
 
+/* diagnostics: host wall-clock per processFrame phase of the calling thread (PhaseTimes order), frames counted */
+int cofusion_debug_phase_ms(double* out, int n, long* frames, int reset)
+{
+    PhaseTimes& t = phaseTimes();
+    for (int i = 0; i < n && i < PhaseTimes::Count; i++) out[i] = t.ms[i];
+    if (frames) *frames = t.frames;
+    if (reset) t = PhaseTimes();
+    return PhaseTimes::Count;
+}
 int cofusion_save_ply(cofusion_handle* h, const char* prefix)
 {
     try { const int n = h->cf->savePly(prefix ? prefix : ""); if (n < 0) g_err = "savePly: cannot write"; return n; }

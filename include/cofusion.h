@@ -51,6 +51,9 @@ int cofusion_set_crf(cofusion_handle *h, float unary_weight_error, float unary_k
                      float weight_smoothness, float sigma_rgb, float sigma_depth, float sigma_pos, float min_rel_size_new,
                      float max_rel_size_new, unsigned iterations);
 
+/* diagnostics: accumulated host wall-clock (ms) per processFrame phase on the calling thread -- prepare, track, slic+sums,
+ * unaries, crf, segmentation post-processing, model logic, fuse+clean, predict; returns the number of phases */
+int cofusion_debug_phase_ms(double *out, int n, long *frames, int reset);
 /* CoFusion::savePly / exportPoses (CoFusion.cpp:646-783): writes <prefix>cloud-<id>.ply / <prefix>poses-<id>.txt; returns the
  * number of files written or a negative error */
 int cofusion_save_ply(cofusion_handle *h, const char *export_dir_prefix);
