@@ -133,6 +133,7 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     if (int r = dmalloc(ctx, &m->fb_raw, N * 12)) return r;
     if (int r = dmalloc(ctx, &m->fb_filt, N * 12)) return r;
     if (int r = dmalloc(ctx, &m->keys, N)) return r;
+    HIPCHK(ctx, hipMemsetAsync(m->keys, 0xFF, N * sizeof(unsigned long long), ctx->stream));  // empty z-buffer; every resolve pass re-clears it
     if (int r = dmalloc(ctx, &m->index, N)) return r;
     if (int r = dmalloc(ctx, &m->vertConf, N * 4)) return r;
     if (int r = dmalloc(ctx, &m->colorTime, N * 4)) return r;

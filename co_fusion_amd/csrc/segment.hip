@@ -270,6 +270,7 @@ __global__ void __launch_bounds__(64) crf_message_kernel(int L, int n, const flo
 static void launch_crf_message(hipStream_t st, dim3 grid, int L, int n, const float* K1t, const float* K2t, const float* Q, float* partial)
 {
     switch (L) {
+        case 1: crf_message_kernel<1><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
         case 2: crf_message_kernel<2><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
         case 3: crf_message_kernel<3><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
         case 4: crf_message_kernel<4><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
@@ -280,37 +281,37 @@ static void launch_crf_message(hipStream_t st, dim3 grid, int L, int n, const fl
         default: crf_message_kernel<0><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
     }
 }
-// part 2: chunk totals in chunk order, unary, softmax over the labels
+// part 2: chunk totals in chunk order, unary, softmax over the labels.  Thread (node g, label l): 16 nodes x 16 label
+// slots per workgroup; the 32 chunk partials of a (node, label) are loaded independently and summed in chunk order,
+// the softmax runs over the node's LDS row exactly like expAndNormalize.
 __global__ void __launch_bounds__(256) crf_update_kernel(const float* __restrict__ unary, int L, int n, const float* __restrict__ partial,
                                                          float w_smooth, float w_app, float* __restrict__ Qn)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float tmp[kMaxL];
+    __shared__ float s_t[16][kMaxL];
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int i = blockIdx.x * 16 + g;
+    float tmp = 0;
+    if (i < n && l < L) {
+        float pa[kCrfChunks], pb[kCrfChunks];
 #pragma unroll
-    for (int l = 0; l < kMaxL; l++) {
-        tmp[l] = 0;
-        if (l < L) {
-            float pa[kCrfChunks], pb[kCrfChunks];
-#pragma unroll
-            for (int c = 0; c < kCrfChunks; c++) {  // independent loads first, then the ordered sums
-                const float* in = partial + ((size_t)(c * n + i) * 2) * kMaxL;
-                pa[c] = in[l]; pb[c] = in[kMaxL + l];
-            }
-            float a = 0, b = 0;
-#pragma unroll
-            for (int c = 0; c < kCrfChunks; c++) { a += pa[c]; b += pb[c]; }
-            tmp[l] = (-unary[i * L + l] - (-w_smooth * a)) - (-w_app * b);
+        for (int c = 0; c < kCrfChunks; c++) {
+            const float* in = partial + ((size_t)(c * n + i) * 2) * kMaxL;
+            pa[c] = in[l]; pb[c] = in[kMaxL + l];
         }
+        float a = 0, b = 0;
+#pragma unroll
+        for (int c = 0; c < kCrfChunks; c++) { a += pa[c]; b += pb[c]; }
+        tmp = (-unary[i * L + l] - (-w_smooth * a)) - (-w_app * b);
+        s_t[g][l] = tmp;
     }
-    float mx = tmp[0];
-#pragma unroll
-    for (int l = 1; l < kMaxL; l++) if (l < L && tmp[l] > mx) mx = tmp[l];
-    float e[kMaxL], sum = 0;
-#pragma unroll
-    for (int l = 0; l < kMaxL; l++) if (l < L) { e[l] = det_expf(tmp[l] - mx); sum += e[l]; }
-#pragma unroll
-    for (int l = 0; l < kMaxL; l++) if (l < L) Qn[i * L + l] = e[l] / sum;
+    __syncthreads();
+    if (i < n && l < L) {
+        float mx = s_t[g][0];
+        for (int k = 1; k < L; k++) if (s_t[g][k] > mx) mx = s_t[g][k];
+        float sum = 0;
+        for (int k = 0; k < L; k++) sum += det_expf(s_t[g][k] - mx);
+        Qn[i * L + l] = det_expf(tmp - mx) / sum;
+    }
 }
 
 }  // namespace cf
@@ -475,7 +476,7 @@ int cf_seg_crf(cf_segmenter* s, const float* unary_host, int L, const float* fea
     float *q = s->Q0, *qn = s->Q1;
     for (int it = 0; it < iterations; it++) {
         launch_crf_message(st, gc, L, n, s->K1t, s->K2t, q, s->partial);
-        crf_update_kernel<<<g1, 256, 0, st>>>(s->unary, L, n, s->partial, w_smooth, w_app, qn);
+        crf_update_kernel<<<(n + 15) / 16, 256, 0, st>>>(s->unary, L, n, s->partial, w_smooth, w_app, qn);
         float* t = q; q = qn; qn = t;
     }
     LAUNCHCHK(ctx);

@@ -214,13 +214,14 @@ __global__ void __launch_bounds__(kB) index_splat_kernel(const float4* __restric
 }
 
 __global__ void __launch_bounds__(kB) index_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_inv, int N,
-                                                           const unsigned long long* __restrict__ keys, unsigned* __restrict__ index,
+                                                           unsigned long long* __restrict__ keys, unsigned* __restrict__ index,
                                                            float4* __restrict__ vertConf, float4* __restrict__ colorTime,
                                                            float4* __restrict__ normRad)
 {
     const int q = blockIdx.x * kB + threadIdx.x;
     if (q >= N) return;
     const unsigned long long k = keys[q];
+    keys[q] = kEmptyKey;  // leave the z-buffer cleared for the next pass (no memset launch per projection)
     if (k == kEmptyKey) {
         index[q] = 0;
         vertConf[q] = colorTime[q] = normRad[q] = make_float4(0, 0, 0, 0);
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(kB) splat_raster_kernel(const float4* __restri
 
 __global__ void __launch_bounds__(kB) splat_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_inv, cf_cam cam, int cols, int rows,
                                                            float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
-                                                           const float4* __restrict__ rays, const unsigned long long* __restrict__ keys,
+                                                           const float4* __restrict__ rays, unsigned long long* __restrict__ keys,
                                                            uchar4* __restrict__ image,
                                                            float4* __restrict__ vertexConf, float4* __restrict__ normalRad,
                                                            unsigned short* __restrict__ time16)
@@ -334,6 +335,7 @@ __global__ void __launch_bounds__(kB) splat_resolve_kernel(const float4* __restr
     const int q = blockIdx.x * kB + threadIdx.x;
     if (q >= cols * rows) return;
     const unsigned long long k = keys[q];
+    keys[q] = kEmptyKey;  // leave the z-buffer cleared for the next pass (no memset launch per projection)
     if (k == kEmptyKey) {
         image[q] = make_uchar4(0, 0, 0, 0);
         vertexConf[q] = normalRad[q] = make_float4(0, 0, 0, 0);
@@ -765,7 +767,6 @@ void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned*
                             float* vertConf, float* colorTime, float* normRad)
 {
     const int N = cols * rows;
-    (void)hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * N, s);
     const Mat4 T = mat4_from(t_inv);
     if (count_bound > 0)
         index_splat_kernel<<<gridFor(count_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, cam, cols, rows, maxDepth, time,
@@ -779,7 +780,6 @@ void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned
                              uint16_t* time16)
 {
     const int N = cols * rows;
-    (void)hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * N, s);
     const Mat4 T = mat4_from(t_inv);
     if (count_bound > 0)
         splat_raster_kernel<<<gridFor(4ll * count_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, cam, cols, rows, maxDepth,
