@@ -844,8 +844,10 @@ void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, 
 }
 
 // Per Gauss-Newton iteration: ONE launch for {ICP reduction || RGB residual}, then rgbStep, then the one-workgroup
-// solve.  (Letting rgbStep's last workgroup run the solve needs a device-scope release fence per workgroup, which on
-// this multi-XCD part writes back the XCD's L2: measured 53 us instead of 6 + 8 us -- kept as separate launches.)
+// solve.  Letting rgbStep's last workgroup run the solve was measured twice and lost both times: with a device-scope
+// release fence per workgroup (it writes back the XCD's L2: 53 us instead of 6 + 8 us), and with returning atomics +
+// a ticket instead of the fence (correct and deterministic, but 946 instead of 1061 frames/s: every workgroup then
+// waits for its atomics' round trip).  Kept as separate launches.
 void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const IcpArgs icp_args[3],
                      const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, ProfSink* prof)
 {
