@@ -833,7 +833,12 @@ static void launch_icp_rgbres(hipStream_t s, IcpLaunch cfg, const IcpArgs& args,
     const int N = (icp ? args.cols * args.rows : ra.cols * ra.rows);
     const int n_res_blocks = rgb ? (N + cfg.threads - 1) / cfg.threads : 0;
     // distinct symbols per pyramid level so that rocprofv3 --stats separates them
-    if (level == 0) launch_icp_kernel<0>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
+    // (tag = level for one model, level + 4 for lock-step batches of several models)
+    if (n > 1) {
+        if (level == 0) launch_icp_kernel<4>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
+        else if (level == 1) launch_icp_kernel<5>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
+        else launch_icp_kernel<6>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
+    } else if (level == 0) launch_icp_kernel<0>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
     else if (level == 1) launch_icp_kernel<1>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
     else launch_icp_kernel<2>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
 }

@@ -17,11 +17,11 @@ if [ "${SKIP_MULTI:-0}" != "1" ]; then
   timeout 600 python bench.py --workload objects4-gt --warmup 60 --steps 100 --no-cpu-baseline > $O/bench_objects4gt.json 2> $O/bench_objects4gt.err; tail -1 $O/bench_objects4gt.json
 fi
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python $R/bench.py --no-cpu-baseline > $O/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python $R/bench.py --no-cpu-baseline --no-secondary > $O/prof.log 2>&1
 python $R/tools/prof_summary.py $O/prof > $O/kernel_stats.txt 2>&1; head -30 $O/kernel_stats.txt
 if [ "${SKIP_PMC:-0}" != "1" ]; then
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_fetch.log 2>&1
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_write.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $O/pmc_fetch.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $O/pmc_write.log 2>&1
   python $R/tools/pmc_summary.py $O/pmc_fetch icp_reduce > $O/pmc_icp.txt 2>&1
   python $R/tools/pmc_summary.py $O/pmc_write icp_reduce >> $O/pmc_icp.txt 2>&1
   cat $O/pmc_icp.txt

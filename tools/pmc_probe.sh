@@ -6,9 +6,9 @@ O=$R/gpurun_out/${1:-pmc}
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/f -o p -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 40 > $O/f.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/f -o p -- python $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 40 > $O/f.log 2>&1
 
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $O/s -o p -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 40 > $O/s.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $O/s -o p -- python $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 40 > $O/s.log 2>&1
 python - <<PY
 import csv, glob, collections
 for tag in ("f", "w", "s"):
