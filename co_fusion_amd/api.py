@@ -196,6 +196,17 @@ class Context:
         return (np.array(A, np.float32).reshape(6, 6), np.array(b, np.float32), np.array(res, np.float32),
                 np.array(sums, np.int64))
 
+    def icp_step_band(self, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, cam, vmap_g_prev, nmap_g_prev, dist_thres,
+                      angle_thres, row_begin, row_end):
+        """icpStep over the row band [row_begin, row_end) only: returns the exact int64[32] sums of the band"""
+        rows, cols = vmap_curr.shape[0] // 3, vmap_curr.shape[1]
+        A = (C.c_float * 36)(); b = (C.c_float * 6)(); res = (C.c_float * 2)(); sums = (C.c_int64 * 32)()
+        self._check(self.lib.cf_icp_step_band(self.h, _f(np.asarray(Rcurr).reshape(9)), _f(tcurr), _p(vmap_curr),
+                                              _p(nmap_curr), _f(np.asarray(Rprev_inv).reshape(9)), _f(tprev), cam,
+                                              _p(vmap_g_prev), _p(nmap_g_prev), C.c_float(dist_thres), C.c_float(angle_thres),
+                                              cols, rows, int(row_begin), int(row_end), A, b, res, sums, None))
+        return np.array(sums, np.int64)
+
     def rgb_residual(self, min_scale, dIdx, dIdy, last_depth, next_depth, last_image, next_image, max_depth_delta, kt,
                      krkinv):
         rows, cols = next_image.shape

@@ -216,7 +216,17 @@ int cf_icp_step(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], const f
                 const float* nmap_g_prev, float dist_thres, float angle_thres, int cols, int rows, float* A_host,
                 float* b_host, float* residual_host, int64_t* sums_host, float* err_surface)
 {
+    return cf_icp_step_band(ctx, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, dist_thres, angle_thres,
+                            cols, rows, 0, rows, A_host, b_host, residual_host, sums_host, err_surface);
+}
+
+int cf_icp_step_band(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], const float* vmap_curr, const float* nmap_curr,
+                     const float Rprev_inv[9], const float tprev[3], cf_cam intr, const float* vmap_g_prev,
+                     const float* nmap_g_prev, float dist_thres, float angle_thres, int cols, int rows, int row_begin, int row_end,
+                     float* A_host, float* b_host, float* residual_host, int64_t* sums_host, float* err_surface)
+{
     if (!ctx || !vmap_curr || !nmap_curr || !vmap_g_prev || !nmap_g_prev || (cols % 4)) return CF_EINVAL;
+    if (row_begin < 0 || row_end > rows || row_begin >= row_end) return CF_EINVAL;
     if (int r = scratch_begin(ctx, cols, rows)) return r;
     OdomDev* h = ctx->h_scratch_state;
     memcpy(h->Rcurr, Rcurr, 36); memcpy(h->tcurr, tcurr, 12); memcpy(h->Rprev_inv, Rprev_inv, 36); memcpy(h->tprev, tprev, 12);
@@ -227,6 +237,7 @@ int cf_icp_step(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], const f
     a.m[0] = IcpModelArgs{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, ctx->d_scratch_state, ctx->d_acc_a, err_surface, ctx->d_acc_b};
     a.cols = cols; a.rows = rows; a.intr = intr; a.distThres = dist_thres; a.angleThres = angle_thres;
     a.flags = err_surface ? 1 : 0;
+    a.row_begin = row_begin; a.row_end = row_end;
     launch_icp_level(ctx->stream, ctx->icp_launch, a, 1, 0);
     LAUNCHCHK(ctx);
     if (int r = fetch_totals(ctx, ctx->d_acc_a, 32)) return r;

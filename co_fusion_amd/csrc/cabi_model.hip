@@ -261,6 +261,38 @@ int cf_model_predict_indices(cf_model* m, const float pose[16], int time, float 
     return CF_OK;
 }
 
+// The two halves of predictIndices, for a surfel map sharded over several GPUs: every rank rasterises its surfel range
+// into a key map (depth-ordered 64-bit keys, empty = all ones), the ranks MIN-all-reduce the key maps (u64 order), and
+// each resolves the reduced map -- bit-identical to cf_model_predict_indices on one GPU, because the per-pixel z-test
+// is a minimum over surfels.
+int cf_model_index_keys(cf_model* m, const float pose[16], int time, float maxDepth, int timeDelta, uint32_t surfel_begin, uint32_t surfel_end,
+                        uint64_t* keys_dev)
+{
+    if (!m || !pose || !keys_dev || surfel_begin > surfel_end) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    float t_inv[16];
+    inv44f(pose, t_inv);
+    uint32_t nb = 0;
+    if (int r = count_bound(m, &nb)) return r;
+    HIPCHK(ctx, hipMemsetAsync(keys_dev, 0xFF, sizeof(uint64_t) * (size_t)W * H, ctx->stream));
+    launch_index_keys(ctx->stream, m->buf[m->target], m->d_count, surfel_begin, surfel_end < nb ? surfel_end : nb, t_inv, ctx_cam(ctx), W, H, maxDepth,
+                      time, timeDelta, reinterpret_cast<unsigned long long*>(keys_dev));
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+int cf_model_index_resolve(cf_model* m, const float pose[16], uint64_t* keys_dev)
+{
+    if (!m || !pose || !keys_dev) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx;
+    float t_inv[16];
+    inv44f(pose, t_inv);
+    launch_index_resolve(ctx->stream, m->buf[m->target], t_inv, ctx->cfg.width, ctx->cfg.height, reinterpret_cast<unsigned long long*>(keys_dev),
+                         m->index, m->vertConf, m->colorTime, m->normRad);
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
 int cf_model_combined_predict(cf_model* m, const float pose[16], float maxDepth, float confThreshold, int time, int maxTime, int timeDelta)
 {
     if (!m || !pose) return CF_EINVAL;

@@ -137,6 +137,7 @@ struct IcpArgs {
     cf_cam intr;                        // already divided by 2^level
     float distThres, angleThres;
     int flags;                          // bit0: write the error surface
+    int row_begin, row_end;             // row band to reduce; row_end == 0: all rows
 };
 void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void launch_rgb_residual(hipStream_t s, const RgbArgs& ra, int n);
@@ -184,6 +185,10 @@ void launch_feedback(hipStream_t s, const uint8_t* rgba, const float* depth, int
 void launch_scatter_records(hipStream_t s, const float* rec, const unsigned* flags, const unsigned* offsets, long long n, float* out,
                             unsigned out_base);
 void launch_init(hipStream_t s, const float* raw, const float* filt, const unsigned* raw_count, long long max_n, float* out);
+void launch_index_keys(hipStream_t s, const float* surfels, const unsigned* count, unsigned id_begin, unsigned id_end, const float t_inv[16],
+                       cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys);
+void launch_index_resolve(hipStream_t s, const float* surfels, const float t_inv[16], int cols, int rows, unsigned long long* keys,
+                          unsigned* index, float* vertConf, float* colorTime, float* normRad);
 void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                             int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, unsigned* index,
                             float* vertConf, float* colorTime, float* normRad);

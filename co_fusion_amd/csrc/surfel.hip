@@ -204,10 +204,11 @@ __device__ __forceinline__ bool index_project(const float4 pc, const float4 ct, 
 
 __global__ void __launch_bounds__(kB) index_splat_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count, Mat4 t_inv,
                                                          cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta,
-                                                         unsigned long long* __restrict__ keys)
+                                                         unsigned id_begin, unsigned id_end, unsigned long long* __restrict__ keys)
 {
-    const unsigned id = blockIdx.x * kB + threadIdx.x;
-    if (id >= *count) return;
+    // [id_begin, id_end): the surfel range of this launch (the whole map, or a rank's shard of it)
+    const unsigned id = id_begin + blockIdx.x * kB + threadIdx.x;
+    if (id >= *count || id >= id_end) return;
     f3 ph; int q;
     if (!index_project(surfels[id * 3], surfels[id * 3 + 1], t_inv, cam, cols, rows, maxDepth, time, timeDelta, ph, q)) return;
     atomicMin(&keys[q], zkey(ph.z, id));
@@ -762,17 +763,28 @@ void launch_init(hipStream_t s, const float* raw, const float* filt, const unsig
     init_kernel<<<gridFor(max_n), kB, 0, s>>>(reinterpret_cast<const float4*>(raw), reinterpret_cast<const float4*>(filt), raw_count,
                                               reinterpret_cast<float4*>(out));
 }
+void launch_index_keys(hipStream_t s, const float* surfels, const unsigned* count, unsigned id_begin, unsigned id_end, const float t_inv[16],
+                       cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys)
+{
+    const Mat4 T = mat4_from(t_inv);
+    if (id_end > id_begin)
+        index_splat_kernel<<<gridFor(id_end - id_begin), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, cam, cols, rows, maxDepth,
+                                                                     time, timeDelta, id_begin, id_end, keys);
+}
+void launch_index_resolve(hipStream_t s, const float* surfels, const float t_inv[16], int cols, int rows, unsigned long long* keys,
+                          unsigned* index, float* vertConf, float* colorTime, float* normRad)
+{
+    const int N = cols * rows;
+    index_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), mat4_from(t_inv), N, keys, index,
+                                                   reinterpret_cast<float4*>(vertConf), reinterpret_cast<float4*>(colorTime),
+                                                   reinterpret_cast<float4*>(normRad));
+}
 void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                             int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, unsigned* index,
                             float* vertConf, float* colorTime, float* normRad)
 {
-    const int N = cols * rows;
-    const Mat4 T = mat4_from(t_inv);
-    if (count_bound > 0)
-        index_splat_kernel<<<gridFor(count_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, cam, cols, rows, maxDepth, time,
-                                                               timeDelta, keys);
-    index_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), T, N, keys, index, reinterpret_cast<float4*>(vertConf),
-                                                   reinterpret_cast<float4*>(colorTime), reinterpret_cast<float4*>(normRad));
+    launch_index_keys(s, surfels, count, 0, count_bound, t_inv, cam, cols, rows, maxDepth, time, timeDelta, keys);
+    launch_index_resolve(s, surfels, t_inv, cols, rows, keys, index, vertConf, colorTime, normRad);
 }
 void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                              int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,

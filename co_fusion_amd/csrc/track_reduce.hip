@@ -148,7 +148,9 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     if (!st->icp || st->level_done) return;
     const int cols = args.cols, rows = args.rows, N = cols * rows;
     const int T = blockDim.x;
-    const int nlog = (N + T * PPT - 1) / (T * PPT);
+    // optional row band [row_begin, row_end) (a rank's share when one model's reduction is split over GPUs)
+    const int pix0 = args.row_begin * cols, pix1 = (args.row_end > 0 ? args.row_end : rows) * cols;
+    const int nlog = (pix1 - pix0 + T * PPT - 1) / (T * PPT);
     const int lb = xcd_logical_block(blockIdx.x, nlog);
     if (lb >= nlog) return;
 
@@ -167,8 +169,8 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
 #pragma unroll
         for (int k = 0; k < 7; k++) row[p][k] = 0.f;
     }
-    const int i0 = (lb * T + threadIdx.x) * PPT;
-    if (i0 < N) {  // N is a multiple of PPT (cols is), so the whole vector is in range
+    const int i0 = pix0 + (lb * T + threadIdx.x) * PPT;
+    if (i0 < pix1) {  // cols is a multiple of PPT, so the whole vector is in range
         float vx[PPT], vy[PPT], vz[PPT], nx[PPT], ny[PPT], nz[PPT];
         load_vec<PPT>(vc + i0, vx); load_vec<PPT>(vc + i0 + N, vy); load_vec<PPT>(vc + i0 + 2 * N, vz);
         load_vec<PPT>(nc + i0, nx); load_vec<PPT>(nc + i0 + N, ny); load_vec<PPT>(nc + i0 + 2 * N, nz);
@@ -815,7 +817,7 @@ template <int TAG>
 static void launch_icp_kernel(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, const RgbArgs& ra, bool icp, int n_res_blocks, int n,
                               hipEvent_t ev0, hipEvent_t ev1)
 {
-    const int N = args.cols * args.rows;
+    const int N = ((args.row_end > 0 ? args.row_end : args.rows) - args.row_begin) * args.cols;
     const int per_block = cfg.threads * cfg.ppt;
     const int nlog = (N + per_block - 1) / per_block;
     const int n_icp_blocks = icp ? ((nlog + 7) / 8) * 8 : 0;

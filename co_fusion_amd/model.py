@@ -60,6 +60,17 @@ class Model:
     def predict_indices(self, pose, time, max_depth, time_delta=TIME_DELTA):
         self.ctx._check(self.ctx.lib.cf_model_predict_indices(self.h, self._pose(pose), time, C.c_float(max_depth), time_delta))
 
+    def index_keys(self, pose, time, max_depth, surfel_begin, surfel_end, time_delta=TIME_DELTA):
+        """first half of predict_indices for the surfel range [begin, end): int64 view of the u64 z-keys, [H, W] on the device"""
+        keys = torch.empty((self.ctx.height, self.ctx.width), dtype=torch.int64, device=self.ctx.device)
+        self.ctx._check(self.ctx.lib.cf_model_index_keys(self.h, self._pose(pose), time, C.c_float(max_depth), time_delta,
+                                                         int(surfel_begin), int(surfel_end), C.c_void_p(keys.data_ptr())))
+        return keys
+
+    def index_resolve(self, pose, keys):
+        """second half: resolve a (reduced) key map into the index-map textures"""
+        self.ctx._check(self.ctx.lib.cf_model_index_resolve(self.h, self._pose(pose), C.c_void_p(keys.data_ptr())))
+
     def combined_predict(self, pose, max_depth, conf_threshold, time, max_time, time_delta=TIME_DELTA):
         self.ctx._check(self.ctx.lib.cf_model_combined_predict(self.h, self._pose(pose), C.c_float(max_depth), C.c_float(conf_threshold),
                                                                time, max_time, time_delta))

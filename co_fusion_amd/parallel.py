@@ -58,3 +58,55 @@ def allreduce_max_seconds(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def sharded_icp_sums(ctx, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, cam, vmap_g_prev, nmap_g_prev, dist_thres, angle_thres,
+                     rank: int = None, world: int = None) -> torch.Tensor:
+    """ONE model's ICP reduction split over the ranks by image-row bands: this rank reduces its band on its GPU
+    (cf_icp_step_band), the int64[32] fixed-point sums are SUM-all-reduced (RCCL on GPUs, gloo in tests).  The result is
+    bit-identical on every rank to a single-GPU cf_icp_step of the whole image."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    rows = vmap_curr.shape[0] // 3
+    band = row_bands(rows, world)[rank]
+    if len(band):
+        sums = ctx.icp_step_band(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, cam, vmap_g_prev, nmap_g_prev, dist_thres, angle_thres,
+                                 band.start, band.stop)
+    else:
+        sums = torch.zeros(32, dtype=torch.int64).numpy()
+    t = torch.from_numpy(sums.copy())
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        t = t.cuda()
+    return allreduce_se3_sums(t).cpu()
+
+
+_SIGN = -(1 << 63)
+
+
+def allreduce_min_keys(keys: torch.Tensor) -> torch.Tensor:
+    """MIN all-reduce of z-buffer key maps (u64 bit patterns held in int64 tensors).  The keys are ordered as UNSIGNED
+    integers; flipping the top bit maps that order onto the signed order the collective compares in."""
+    assert keys.dtype == torch.int64
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        k = keys ^ _SIGN
+        if dist.get_backend() != "nccl":
+            k = k.cpu()
+        dist.all_reduce(k, op=dist.ReduceOp.MIN)
+        keys.copy_(k.to(keys.device) ^ _SIGN)
+    return keys
+
+
+def sharded_predict_indices(model, pose, time, max_depth, count: int, rank: int = None, world: int = None):
+    """predictIndices of ONE surfel map whose surfels are split into contiguous ranges over the ranks: rasterise the own
+    range, MIN-all-reduce the key maps, resolve.  Bit-identical to model.predict_indices on one GPU."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    per = (count + world - 1) // world
+    keys = model.index_keys(pose, time, max_depth, min(rank * per, count), min((rank + 1) * per, count))
+    torch.cuda.synchronize()
+    keys = allreduce_min_keys(keys)
+    model.index_resolve(pose, keys)

@@ -113,6 +113,14 @@ int cf_icp_step(cf_ctx *ctx, const float Rcurr[9], const float tcurr[3], const f
                 const float *vmap_g_prev, const float *nmap_g_prev, float dist_thres, float angle_thres,
                 int cols, int rows, float *A_host, float *b_host, float *residual_host, int64_t *sums_host,
                 float *err_surface);
+/* The same reduction over the row band [row_begin, row_end) only: a rank's share when ONE model's reduction is split
+ * over several GPUs.  The int64 sums of the bands add up to the full-image sums exactly (integer arithmetic), so an
+ * all-reduce(SUM) of sums_host over the ranks reproduces cf_icp_step bit for bit.  A/b/residual are the band's own. */
+int cf_icp_step_band(cf_ctx *ctx, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
+                     const float *nmap_curr, const float Rprev_inv[9], const float tprev[3], cf_cam intr,
+                     const float *vmap_g_prev, const float *nmap_g_prev, float dist_thres, float angle_thres,
+                     int cols, int rows, int row_begin, int row_end, float *A_host, float *b_host,
+                     float *residual_host, int64_t *sums_host, float *err_surface);
 /* computeRgbResidual cudafuncs.cuh:102-121 */
 int cf_rgb_residual(cf_ctx *ctx, float min_scale, const int16_t *dIdx, const int16_t *dIdy, const float *last_depth,
                     const float *next_depth, const uint8_t *last_image, const uint8_t *next_image,
@@ -183,6 +191,12 @@ int cf_model_initialise(cf_model *m, const uint8_t *rgba, const float *depth_raw
 int cf_model_count(cf_model *m, uint32_t *count);
 /* Model::predictIndices -> ModelProjection::predictIndices (ModelProjection.cpp:105-157) */
 int cf_model_predict_indices(cf_model *m, const float pose[16], int time, float maxDepth, int timeDelta);
+/* predictIndices in two halves for a surfel map sharded over GPUs: rasterise the surfels [surfel_begin, surfel_end) into
+ * keys_dev (u64 [H*W], filled by the call; smaller key = nearer surfel, ties -> lower id, empty = all ones), MIN-all-reduce
+ * the key maps over the ranks as unsigned 64-bit integers, then resolve the reduced map into the model's index textures. */
+int cf_model_index_keys(cf_model *m, const float pose[16], int time, float maxDepth, int timeDelta, uint32_t surfel_begin,
+                        uint32_t surfel_end, uint64_t *keys_dev);
+int cf_model_index_resolve(cf_model *m, const float pose[16], uint64_t *keys_dev);
 /* Model::combinedPredict -> ModelProjection::combinedPredict (ModelProjection.cpp:192-273), ACTIVE prediction */
 int cf_model_combined_predict(cf_model *m, const float pose[16], float maxDepth, float confThreshold, int time, int maxTime,
                               int timeDelta);

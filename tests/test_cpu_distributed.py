@@ -56,7 +56,16 @@ def _worker(rank, world, port, q):
         assert np.array_equal(t.numpy(), full), "sharded + all-reduced sums must equal the single-device sums exactly"
         assert part[28] < full[28]
 
-        # 3. placement
+        # 3. surfel-range sharded z-buffer: MIN all-reduce of u64 keys held in int64 tensors (unsigned order!)
+        rng = np.random.default_rng(5)
+        allkeys = rng.integers(0, 1 << 63, size=(world, 64), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(world, 64), dtype=np.uint64)
+        allkeys[0, :8] = np.uint64(0xFFFFFFFFFFFFFFFF)      # empty pixels on rank 0
+        allkeys[:, 8:12] = np.uint64(0xFFFFFFFFFFFFFFFF)    # empty everywhere
+        mine = torch.from_numpy(allkeys[rank].view(np.int64).copy())
+        parallel.allreduce_min_keys(mine)
+        assert np.array_equal(mine.numpy().view(np.uint64), allkeys.min(axis=0)), "u64 MIN through the signed collective"
+
+        # 4. placement
         pl = parallel.assign_models([0, 3, 5, 9], world)
         assert sorted(sum(pl.values(), [])) == [0, 3, 5, 9] and 0 in pl[0]
         q.put((rank, "ok"))
