@@ -61,6 +61,10 @@ class CoFusion:
             raise CoFusionError(self.lib.cofusion_last_error().decode())
         return n
 
+    def set_export_segmentation(self, prefix):
+        """every segmented frame writes <prefix>Segmentation<tick>.png (labels, rejected superpixels as 0); '' switches it off"""
+        self._check(self.lib.cofusion_set_export_segmentation(self.h, str(prefix or "").encode()))
+
     def export_poses(self, prefix):
         """CoFusion::exportPoses: <prefix>poses-<id>.txt per logged model (needs enable_pose_logging=1)"""
         n = self.lib.cofusion_export_poses(self.h, str(prefix).encode())

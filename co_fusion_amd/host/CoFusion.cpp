@@ -624,6 +624,12 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
                 else memcpy(firstRows.data(), rgbaHost.data(), (size_t)K * 4);
                 SegmentationResult seg = labelGenerator->performSegmentation(models, frame, curDepth, curRgba, firstRows.data(), getNextModelID(),
                                                                             spawnOffset >= cfg.modelSpawnOffset, mask_dev);
+                if (!exportSegmentationPrefix.empty()) {  // CoFusion.cpp:235-240: labels > 254 (rejected) are written as 0
+                    std::vector<uint8_t> labels(N);
+                    check(ctx, cf_memcpy_d2h(ctx, labels.data(), mask_dev, N), "mask readback");
+                    for (auto& v : labels) if (v > 254) v = 0;
+                    writePngGray8(exportSegmentationPrefix + "Segmentation" + std::to_string(tick) + ".png", labels.data(), cfg.width, cfg.height);
+                }
                 if (seg.hasNewLabel) {
                     spawnObjectModel();
                     spawnOffset = 0;

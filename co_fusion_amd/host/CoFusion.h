@@ -59,6 +59,8 @@ struct PhaseTimes {
     long frames = 0;
 };
 PhaseTimes& phaseTimes();
+// 8-bit greyscale PNG (zlib), Export.cpp
+bool writePngGray8(const std::string& path, const uint8_t* data, int width, int height);
 
 class Model {
   public:
@@ -175,6 +177,8 @@ class CoFusion {
     // CoFusion::savePly / exportPoses (CoFusion.cpp:646-783); exportDir is a prefix ("out/"); return files written or -1
     int savePly(const std::string& exportDir);
     int exportPoses(const std::string& exportDir);
+    // exportSegmentation (CoFusion.cpp:235-240): when set, every segmented frame writes <prefix>Segmentation<tick>.png (8-bit labels)
+    void setExportSegmentation(const std::string& prefix) { exportSegmentationPrefix = prefix; }
     ModelList& getModels() { return models; }
     ModelPointer getBackgroundModel() { return globalModel; }
     const Mat4f& getCurrPose() const { return globalModel->getPose(); }
@@ -209,6 +213,7 @@ class CoFusion {
     unsigned modelKeepMinSurfels = 4000;
     float modelKeepConfThreshold = 0.3f;
     bool enableSmartModelDelete = true;
+    std::string exportSegmentationPrefix;
 };
 
 }  // namespace cofusion

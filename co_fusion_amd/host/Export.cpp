@@ -10,9 +10,47 @@
 #include <cstring>
 #include <fstream>
 
+#include <zlib.h>
+
+#include <vector>
+
 #include "CoFusion.h"
 
 namespace cofusion {
+
+// Minimal PNG writer: 8-bit greyscale, one zlib stream, filter type 0 on every row.
+bool writePngGray8(const std::string& path, const uint8_t* data, int width, int height)
+{
+    std::vector<uint8_t> raw((size_t)(width + 1) * height);
+    for (int y = 0; y < height; y++) {
+        raw[(size_t)y * (width + 1)] = 0;
+        memcpy(&raw[(size_t)y * (width + 1) + 1], data + (size_t)y * width, (size_t)width);
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), Z_BEST_SPEED) != Z_OK) return false;
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    auto be32 = [](uint8_t* p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; };
+    auto chunk = [&](const char* type, const uint8_t* body, uint32_t len) {
+        uint8_t head[8]; be32(head, len); memcpy(head + 4, type, 4);
+        fwrite(head, 1, 8, f);
+        if (len) fwrite(body, 1, len, f);
+        uLong c = crc32(0L, reinterpret_cast<const Bytef*>(type), 4);
+        if (len) c = crc32(c, body, len);
+        uint8_t tail[4]; be32(tail, (uint32_t)c);
+        fwrite(tail, 1, 4, f);
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    fwrite(sig, 1, 8, f);
+    uint8_t ihdr[13]; be32(ihdr, (uint32_t)width); be32(ihdr + 4, (uint32_t)height);
+    ihdr[8] = 8; ihdr[9] = 0; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;  // 8 bit, greyscale, deflate, adaptive filtering, no interlace
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), (uint32_t)zlen);
+    chunk("IEND", nullptr, 0);
+    fclose(f);
+    return true;
+}
 
 static void mul_point(const Mat4f& T, const float p[3], float o[3])
 {

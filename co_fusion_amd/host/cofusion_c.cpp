@@ -124,6 +124,11 @@ int cofusion_debug_phase_ms(double* out, int n, long* frames, int reset)
     if (reset) t = PhaseTimes();
     return PhaseTimes::Count;
 }
+int cofusion_set_export_segmentation(cofusion_handle* h, const char* prefix)
+{
+    h->cf->setExportSegmentation(prefix ? prefix : "");
+    return 0;
+}
 int cofusion_save_ply(cofusion_handle* h, const char* prefix)
 {
     try { const int n = h->cf->savePly(prefix ? prefix : ""); if (n < 0) g_err = "savePly: cannot write"; return n; }

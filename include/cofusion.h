@@ -58,6 +58,8 @@ int cofusion_debug_phase_ms(double *out, int n, long *frames, int reset);
  * number of files written or a negative error */
 int cofusion_save_ply(cofusion_handle *h, const char *export_dir_prefix);
 int cofusion_export_poses(cofusion_handle *h, const char *export_dir_prefix);
+/* exportSegmentation (CoFusion.cpp:235-240): every segmented frame writes <prefix>Segmentation<tick>.png; NULL / "" switches it off */
+int cofusion_set_export_segmentation(cofusion_handle *h, const char *export_dir_prefix);
 
 /* .klg RGB-D logs (GUI/Tools/KlgLogReader.cpp:22-87): u16-mm depth raw or zlib, 8-bit x3 colour raw (JPEG frames are
  * rejected: no libjpeg in this build).  depth_m [H*W] metres, rgb [H*W*3]. */

@@ -207,3 +207,44 @@ def test_surfel_buffer_overflow_is_an_error_not_a_crash():
     with pytest.raises(facade.CoFusionError):
         cf.process_frame(d, rgb, timestamp=0)
     cf.close()
+
+
+def _read_png_gray8(path):
+    import struct, zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w = 8, b"", 0
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+        if typ == b"IHDR":
+            w, h, depth, colour = struct.unpack(">IIBB", body[:10])
+            assert (depth, colour) == (8, 0)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w + 1)
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:]
+
+
+def test_segmentation_png_export(tmp_path):
+    """exportSegmentation (CoFusion.cpp:235-240): per segmented frame an 8-bit label PNG, rejected labels (255) as 0."""
+    from co_fusion_amd import facade
+    cam = synth.Camera.scaled(W, H)
+    sc = synth.Scene(n_obj=2)
+    cf = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, max_surfels=1 << 19, conf_global_init=0.5, model_spawn_offset=2,
+                         enable_multiple_models=1)
+    prefix = str(tmp_path) + "/"
+    cf.set_export_segmentation(prefix)
+    for t in range(5):
+        d, rgb, _, _ = sc.render(cam, t, noise=True)
+        tick = cf.tick
+        cf.process_frame(d, rgb, timestamp=t)
+        if t > 0:
+            img = _read_png_gray8(prefix + f"Segmentation{tick}.png")
+            m = cf.mask().copy()
+            m[m > 254] = 0
+            _same(img, m, f"frame {t}: exported mask")
+    cf.close()
