@@ -1,4 +1,4 @@
-// KlgIO.cpp -- see KlgIO.h.  zlib only; no OpenCV, no libjpeg.
+// KlgIO.cpp -- see KlgIO.h.  zlib + the built-in baseline JPEG decoder (Jpeg.cpp); no OpenCV, no libjpeg.
 #include "KlgIO.h"
 
 #include <zlib.h>
@@ -7,6 +7,8 @@
 #include <cstring>
 
 namespace cofusion {
+
+std::string decodeJpegRGB(const uint8_t* data, size_t size, int width, int height, uint8_t* rgb);  // Jpeg.cpp
 
 KlgLogReader::KlgLogReader(const std::string& file, int w, int h, bool flipColors) : width(w), height(h), flip(flipColors)
 {
@@ -49,8 +51,14 @@ bool KlgLogReader::getNext()
     }
     for (size_t i = 0; i < N; i++) depth[i] = (float)depthMm[i] * 0.001f;  // convertTo(CV_32FC1, 0.001): saturate_cast<float>(v * 0.001)
     if (rgbSize > 0) {
-        if ((size_t)rgbSize != N * 3) { err = "JPEG-compressed colour frame: this build has no libjpeg"; return false; }
-        memcpy(rgb.data(), rgbRaw.data(), N * 3);
+        if ((size_t)rgbSize != N * 3) {
+            const std::string e = decodeJpegRGB(rgbRaw.data(), (size_t)rgbSize, width, height, rgb.data());
+            if (!e.empty()) { err = "JPEG colour frame: " + e; return false; }
+            // JPEGLoader::readData (JPEGLoader.h:70-78) stores the decoded triple reversed
+            for (size_t i = 0; i < N; i++) { const uint8_t t = rgb[i * 3]; rgb[i * 3] = rgb[i * 3 + 2]; rgb[i * 3 + 2] = t; }
+        } else {
+            memcpy(rgb.data(), rgbRaw.data(), N * 3);
+        }
     } else {
         memset(rgb.data(), 0, N * 3);
     }

@@ -2,8 +2,9 @@
 //   int32 numFrames; per frame { int64 timestamp; int32 depthSize; int32 rgbSize; depth bytes; rgb bytes }
 // depth: u16 millimetres, raw (depthSize == W*H*2) or zlib-compressed; rgb: raw 8-bit x3 (rgbSize == W*H*3),
 // JPEG otherwise.  The reader converts depth to metres exactly as `convertTo(CV_32FC1, 0.001)` does
-// (f32(u16) * f32(0.001), KlgLogReader.cpp:63-69).  JPEG frames need libjpeg, which this image does not ship:
-// they are reported as an error instead of being decoded approximately.
+// (f32(u16) * f32(0.001), KlgLogReader.cpp:63-69).  JPEG colour frames go through the built-in baseline decoder (Jpeg.cpp;
+// libjpeg's headers are not part of this image) and are stored channel-reversed like JPEGLoader::readData does;
+// progressive JPEG is rejected.
 #pragma once
 
 #include <cstdint>

@@ -80,3 +80,49 @@ def test_klg_rejects_jpeg_and_truncation(tmp_path, klg):
         next(r)
     with pytest.raises(klg.KlgError):
         klg.KlgReader(tmp_path / "missing.klg", W, H)
+
+
+def _jpeg_log(tmp_path, klg, rgb, d, name, **save_kw):
+    import io
+    from PIL import Image
+    W, H = rgb.shape[1], rgb.shape[0]
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, format="JPEG", **save_kw)
+    jb = buf.getvalue()
+    ref = np.asarray(Image.open(io.BytesIO(jb)).convert("RGB"))
+    mm = np.rint(d * np.float32(1000.0)).astype(np.uint16)
+    path = tmp_path / name
+    path.write_bytes(struct.pack("<i", 1) + struct.pack("<qii", 9, W * H * 2, len(jb)) + mm.tobytes() + jb)
+    return path, ref
+
+
+@pytest.mark.parametrize("subsampling,quality", [(0, 95), (1, 85), (2, 75)])
+def test_klg_jpeg_colour_frames_decode_like_libjpeg(tmp_path, klg, subsampling, quality):
+    """Real .klg logs store colour as JPEG (KlgLogReader.cpp:76-79 -> libjpeg).  The built-in baseline decoder must give
+    libjpeg's pixels (Pillow bundles libjpeg-turbo: islow IDCT, fancy upsampling) -- exactly, for 4:4:4 / 4:2:2 / 4:2:0 --
+    stored channel-reversed as JPEGLoader::readData does."""
+    pytest.importorskip("PIL")
+    W, H = 96, 80   # not a multiple of the 16x16 MCU: exercises the padded edge
+    (d, rgb), = _frames(1, W, H)
+    path, ref = _jpeg_log(tmp_path, klg, rgb, d, "j.klg", quality=quality, subsampling=subsampling)
+    ts, dd, cc = next(iter(klg.KlgReader(path, W, H)))
+    assert ts == 9
+    assert np.array_equal(cc[..., ::-1], ref)
+    # flip_colors undoes the reversal (LogReader::flipColors)
+    _, _, cf = next(iter(klg.KlgReader(path, W, H, flip_colors=True)))
+    assert np.array_equal(cf, ref)
+
+
+def test_klg_jpeg_restart_intervals_and_progressive(tmp_path, klg):
+    pytest.importorskip("PIL")
+    W, H = 64, 48
+    (d, rgb), = _frames(1, W, H)
+    try:
+        path, ref = _jpeg_log(tmp_path, klg, rgb, d, "r.klg", quality=90, subsampling=2, restart_marker_blocks=2)
+    except TypeError:
+        pytest.skip("this Pillow cannot write restart markers")
+    _, _, cc = next(iter(klg.KlgReader(path, W, H)))
+    assert np.array_equal(cc[..., ::-1], ref)
+    path, _ = _jpeg_log(tmp_path, klg, rgb, d, "p.klg", quality=90, progressive=True)
+    with pytest.raises(klg.KlgError, match="progressive"):
+        next(iter(klg.KlgReader(path, W, H)))
