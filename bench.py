@@ -150,7 +150,11 @@ def main(argv=None):
             for i in range(lo, hi):
                 step_stream(streams[0], i)
             return
-        ths = [threading.Thread(target=lambda st=st: [step_stream(st, i) for i in range(lo, hi)]) for st in streams]
+        def work(st):
+            torch.cuda.set_device(local_rank)  # HIP's current device is per thread
+            for i in range(lo, hi):
+                step_stream(st, i)
+        ths = [threading.Thread(target=work, args=(st,)) for st in streams]
         for t in ths:
             t.start()
         for t in ths:
