@@ -17,7 +17,7 @@ class Config(C.Structure):
                 ("conf_object_init", C.c_float), ("depth_cutoff", C.c_float), ("icp_weight", C.c_float),
                 ("outlier_coefficient", C.c_float), ("fast_odom", C.c_int), ("so3", C.c_int), ("frame_to_frame_rgb", C.c_int),
                 ("pyramid", C.c_int), ("rgb_only", C.c_int), ("model_spawn_offset", C.c_uint), ("enable_multiple_models", C.c_int),
-                ("enable_pose_logging", C.c_int)]
+                ("enable_pose_logging", C.c_int), ("rank", C.c_int), ("world", C.c_int)]
 
 
 class CoFusionError(RuntimeError):
@@ -48,6 +48,35 @@ class CoFusion:
     def _check(self, rc):
         if rc != 0:
             raise CoFusionError(f"cofusion error {rc}: {self.lib.cofusion_last_error().decode()}")
+
+    def set_allreduce(self, fn=None):
+        """model-parallel mode (rank / world given at construction): register the SUM all-reduce of int64 buffers.
+        Default: torch.distributed.all_reduce on the default process group (gloo: CPU tensor, nccl: staged through the GPU)."""
+        import torch.distributed as dist
+
+        def default(arr):
+            t = torch.from_numpy(arr)
+            if dist.get_backend() == "nccl":
+                g = t.to(self.device)
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                t.copy_(g.cpu())
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+        impl = fn or default
+
+        def thunk(buf, n, _user):
+            try:
+                impl(np.ctypeslib.as_array(buf, shape=(n,)))
+                return 0
+            except Exception:  # noqa: BLE001 -- reported through the C return code
+                return -1
+
+        self._allreduce_cb = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int64), C.c_uint64, C.c_void_p)(thunk)  # keep alive
+        self._check(self.lib.cofusion_set_allreduce(self.h, self._allreduce_cb, None))
+
+    def model_owned(self, index):
+        return self.lib.cofusion_model_owned(self.h, index) == 1
 
     def set_stream(self, stream):
         """enqueue all work of this instance on a torch.cuda.Stream (or a raw hipStream_t value)"""

@@ -65,11 +65,19 @@ Mat4f Mat4f::operator*(const Mat4f& o) const
     return r;
 }
 
-// ------------------------------------------------------------------------------- Model ----
-Model::Model(cf_ctx* c, unsigned char id_, float confidenceThresh, bool enableFillIn, int maxSurfels, float maxDepth_)
-    : ctx(c), pose(Mat4f::identity()), lastPose(Mat4f::identity()), confidenceThreshold(confidenceThresh), maxDepth(maxDepth_), id(id_),
-      fillIn(enableFillIn)
+void Distributed::sum(int64_t* buf, uint64_t n) const
 {
+    if (!active()) return;
+    if (!allreduce_i64) throw std::runtime_error("model-parallel CoFusion: no all-reduce callback registered (cofusion_set_allreduce)");
+    if (allreduce_i64(buf, n, user) != 0) throw std::runtime_error("model-parallel CoFusion: the all-reduce callback failed");
+}
+
+// ------------------------------------------------------------------------------- Model ----
+Model::Model(cf_ctx* c, unsigned char id_, float confidenceThresh, bool enableFillIn, int maxSurfels, float maxDepth_, bool owned_)
+    : ctx(c), pose(Mat4f::identity()), lastPose(Mat4f::identity()), confidenceThreshold(confidenceThresh), maxDepth(maxDepth_), id(id_),
+      fillIn(enableFillIn), owned(owned_)
+{
+    if (!owned) return;  // shadow of a model owned by another rank: replicated state only
     check(ctx, cf_model_create(ctx, maxSurfels, &model), "cf_model_create");
     check(ctx, cf_odom_create(ctx, &odom), "cf_odom_create");
     // icpError texture (Model.cpp:112-117), f32 [H*W]; zero-initialised like the reference's upload (GPUTexture.cpp:48-53)
@@ -83,17 +91,18 @@ Model::Model(cf_ctx* c, unsigned char id_, float confidenceThresh, bool enableFi
 Model::~Model()
 {
     if (icpError) cf_free(ctx, icpError);
-    cf_odom_destroy(odom);
-    cf_model_destroy(model);
+    if (odom) cf_odom_destroy(odom);
+    if (model) cf_model_destroy(model);
 }
 unsigned Model::lastCount() const
 {
     uint32_t c = 0;
-    cf_model_count(model, &c);
+    if (owned) cf_model_count(model, &c);
     return c;
 }
 void Model::initialise(const uint8_t* rgba, const float* depthRaw, const float* depthFiltered, int time, float maxD)
 {
+    if (!owned) return;
     check(ctx, cf_model_initialise(model, rgba, depthRaw, depthFiltered, time, maxD), "cf_model_initialise");
 }
 static const void* mbuf(cf_ctx* ctx, cf_model* m, int which)
@@ -102,11 +111,12 @@ static const void* mbuf(cf_ctx* ctx, cf_model* m, int which)
     check(ctx, cf_model_buffer(m, which, &p, nullptr), "cf_model_buffer");
     return p;
 }
-const float* Model::vertexConfProjection() const { return static_cast<const float*>(mbuf(ctx, model, 5)); }
+const float* Model::vertexConfProjection() const { return owned ? static_cast<const float*>(mbuf(ctx, model, 5)) : nullptr; }
 
 void Model::initICP(bool doFillIn, bool frameToFrameRGB, const float* const depthPyr[3], float depthCutoff, const uint8_t* rgba,
                     Model* frameOwner)
 {  // Model.cpp:350-367.  WARNING initICP* must be called before initRGB* (they share vmaps_tmp)
+    if (!owned) return;
     const float* v; const float* n; const uint8_t* img;
     if (doFillIn) {
         v = static_cast<const float*>(mbuf(ctx, model, 8)); n = static_cast<const float*>(mbuf(ctx, model, 9));
@@ -137,36 +147,41 @@ float Model::computeFusionWeight(float weightMultiplier) const { return cf_fusio
 void Model::fuse(int time, const uint8_t* rgba, const uint8_t* mask, const float* depthRaw, const float* depthFiltered, float depthCutoff,
                  float weightMultiplier)
 {
+    if (!owned) return;
     const float md = depthCutoff < maxDepth ? depthCutoff : maxDepth;  // std::min(depthCutoff, maxDepth), Model.cpp:443
     check(ctx, cf_model_fuse(model, pose.m, time, rgba, mask, depthRaw, depthFiltered, md, computeFusionWeight(weightMultiplier), (int)id),
           "cf_model_fuse");
 }
 void Model::clean(int time, int timeDelta, float /*depthCutoff*/, const float* depthFiltered, const uint8_t* mask, float outlierCoeff)
 {
+    if (!owned) return;
     // the surfel count is read back asynchronously (cf_model_count resolves it on demand): no host wait here
     check(ctx, cf_model_clean(model, pose.m, time, confidenceThreshold, outlierCoeff, timeDelta, depthFiltered, mask, (int)id, nullptr), "cf_model_clean");
 }
 void Model::predictIndices(int time, float depthCutoff, int timeDelta)
 {
+    if (!owned) return;
     check(ctx, cf_model_predict_indices(model, pose.m, time, depthCutoff, timeDelta), "predictIndices");
 }
 void Model::combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta)
 {
+    if (!owned) return;
     check(ctx, cf_model_combined_predict(model, pose.m, depthCutoff, confidenceThreshold, time, maxTime, timeDelta), "combinedPredict");
 }
 void Model::performFillIn(const uint8_t* rgba, const float* depthFiltered, bool frameToFrameRGB, bool lost)
 {
-    if (fillIn) check(ctx, cf_model_perform_fill_in(model, rgba, depthFiltered, lost ? 1 : 0, (lost || frameToFrameRGB) ? 1 : 0), "performFillIn");
+    if (fillIn && owned) check(ctx, cf_model_perform_fill_in(model, rgba, depthFiltered, lost ? 1 : 0, (lost || frameToFrameRGB) ? 1 : 0), "performFillIn");
 }
 bool Model::requiresFillIn(float ratio)
 {
-    if (!allowsFillIn()) return false;
+    if (!allowsFillIn() || !owned) return false;
     int out = 0;
     check(ctx, cf_model_requires_fill_in(model, ratio, &out), "requiresFillIn");
     return out != 0;
 }
 std::vector<float> Model::downloadMap() const
 {
+    if (!owned) return {};
     const unsigned n = lastCount();
     std::vector<float> out((size_t)n * 12);
     uint32_t c = 0;
@@ -177,12 +192,21 @@ std::vector<float> Model::downloadMap() const
 // ------------------------------------------------------------------------ Segmentation ----
 static const int SPIX = 16;
 
-Segmentation::Segmentation(cf_ctx* c, int w, int h) : ctx(c), width(w), height(h)
+Segmentation::Segmentation(cf_ctx* c, int w, int h, const Distributed* d) : ctx(c), width(w), height(h), dist(d)
 {
     check(ctx, cf_seg_create(ctx, &seg), "cf_seg_create");
     memset(gtMapping, 0, sizeof(gtMapping));
+    if (dist && dist->active()) {
+        void* p = nullptr;
+        check(ctx, cf_malloc(ctx, (uint64_t)w * h * 16, &p), "cf_malloc");  // cf_malloc returns zeroed memory
+        zeroImage = static_cast<float*>(p);
+    }
 }
-Segmentation::~Segmentation() { cf_seg_destroy(seg); }
+Segmentation::~Segmentation()
+{
+    if (zeroImage) cf_free(ctx, zeroImage);
+    cf_seg_destroy(seg);
+}
 
 SegmentationResult Segmentation::performSegmentation(ModelList& models, const FrameData& frame, const float* depth_dev, const uint8_t* rgba_dev,
                                                      const uint8_t* rgba_first_rows, unsigned char nextModelID, bool allowNew,
@@ -272,11 +296,20 @@ SegmentationResult Segmentation::performSegmentationCRF(ModelList& models, const
     std::vector<const float*> icpPtr(n_models), vcPtr(n_models);
     {
         int m = 0;
-        for (auto& mdl : models) { icpPtr[m] = mdl->icpErrorSurface(); vcPtr[m] = mdl->vertexConfProjection(); m++; }
+        for (auto& mdl : models) {
+            // a shadow contributes zeros here; its owner's sums arrive through the all-reduce below
+            icpPtr[m] = mdl->isOwned() ? mdl->icpErrorSurface() : zeroImage;
+            vcPtr[m] = mdl->isOwned() ? mdl->vertexConfProjection() : zeroImage;
+            m++;
+        }
     }
     check(ctx, cf_seg_accumulate(seg, depth_dev, n_models, icpPtr.data(), vcPtr.data(), spc.data(), dcnt.data(), dsum.data(), icpSum.data(),
                                  confSum.data(), resample.data()),
           "cf_seg_accumulate");
+    if (dist && dist->active()) {  // exact: integer sums, every model has exactly one owner
+        dist->sum(icpSum.data(), icpSum.size());
+        dist->sum(confSum.data(), confSum.size());
+    }
     pt.reset(new PhaseTimer(PhaseTimes::SegUnary));
     std::vector<float> lowDepth(K);
     finishMean(dsum.data(), dcnt.data(), spc.data(), resample.data(), K, lowDepth.data());
@@ -495,7 +528,8 @@ static cf_ctx* make_ctx(const CoFusion::Config& c)
 
 CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
 {
-    labelGenerator.reset(new Segmentation(ctx, cfg.width, cfg.height));
+    dist.rank = cfg.rank; dist.world = cfg.world < 1 ? 1 : cfg.world;
+    labelGenerator.reset(new Segmentation(ctx, cfg.width, cfg.height, &dist));
     const size_t N = (size_t)cfg.width * cfg.height;
     void* p = nullptr;
     check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); depth_dev = static_cast<float*>(p);
@@ -505,7 +539,8 @@ CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
     check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); rgba_dev = static_cast<uint8_t*>(p);
     check(ctx, cf_malloc(ctx, N, &p), "cf_malloc"); mask_dev = static_cast<uint8_t*>(p);
     rgbaHost.resize(N * 4);
-    globalModel = std::make_shared<Model>(ctx, getNextModelID(true), cfg.confGlobalInit, true, cfg.maxSurfels);
+    globalModel = std::make_shared<Model>(ctx, getNextModelID(true), cfg.confGlobalInit, true, cfg.maxSurfels, 3.402823466e+38f,
+                                          dist.owner(0) == dist.rank);
     globalModel->loggingPoses = cfg.enablePoseLogging;
     models.push_back(globalModel);
 }
@@ -536,9 +571,10 @@ unsigned char CoFusion::getNextModelID(bool assign)
 
 void CoFusion::spawnObjectModel()
 {  // CoFusion.cpp:588-598
-    newModel = std::make_shared<Model>(ctx, getNextModelID(true), cfg.confObjectInit, false, cfg.maxSurfels);
+    const unsigned char nid = getNextModelID(true);
+    newModel = std::make_shared<Model>(ctx, nid, cfg.confObjectInit, false, cfg.maxSurfels, 3.402823466e+38f, dist.owner(nid) == dist.rank);
     newModel->loggingPoses = cfg.enablePoseLogging;
-    check(ctx, cf_odom_init_first_rgb(newModel->getFrameOdometry(), curRgba), "initFirstRGB");
+    if (newModel->isOwned()) check(ctx, cf_odom_init_first_rgb(newModel->getFrameOdometry(), curRgba), "initFirstRGB");
 }
 void CoFusion::moveNewModelToList()
 {
@@ -547,7 +583,9 @@ void CoFusion::moveNewModelToList()
 ModelList::iterator CoFusion::inactivateModel(ModelList::iterator it)
 {  // CoFusion.cpp:611-626
     ModelPointer m = *it;
-    if (!enableSmartModelDelete || (m->lastCount() >= modelKeepMinSurfels && m->getConfidenceThreshold() > modelKeepConfThreshold))
+    int64_t count = (int64_t)m->lastCount();  // known to the owner only: every rank needs it for the same decision
+    dist.sum(&count, 1);
+    if (!enableSmartModelDelete || ((unsigned)count >= modelKeepMinSurfels && m->getConfidenceThreshold() > modelKeepConfThreshold))
         inactiveModels.push_back(m);
     return --models.erase(it);
 }
@@ -563,11 +601,13 @@ void CoFusion::predict()
 void CoFusion::trackModels(const float* const depthPyr[3])
 {  // CoFusion.cpp:213-217 + Model::performTracking (Model.cpp:369-389); all models advance in lock-step on the GPU
     std::vector<Model*> ms;
-    for (auto& m : models) ms.push_back(m.get());
-    Model* owner = ms[0];
-    for (Model* m : ms) {
+    for (auto& m : models) {
         m->lastPose = m->pose;
-        m->initICP(m->requiresFillIn(), cfg.frameToFrameRGB, depthPyr, maxDepthProcessed, curRgba, owner);
+        if (m->isOwned()) ms.push_back(m.get());
+    }
+    if (!ms.empty()) {
+        Model* owner = ms[0];  // computes the frame-wide vertex / normal pyramids the other models of this rank share
+        for (Model* m : ms) m->initICP(m->requiresFillIn(), cfg.frameToFrameRGB, depthPyr, maxDepthProcessed, curRgba, owner);
     }
     cf_track_opts opts{};
     opts.rgb_only = cfg.rgbOnly; opts.pyramid = cfg.pyramid; opts.fast_odom = cfg.fastOdom; opts.so3 = cfg.so3; opts.icp_weight = cfg.icpWeight;
@@ -583,6 +623,33 @@ void CoFusion::trackModels(const float* const depthPyr[3])
             check(ctx, cf_odom_fetch_result(m->odom, t, R, &m->lastStats), "fetch_result");
             for (int r = 0; r < 3; r++) { m->pose.m[r * 4 + 0] = R[r * 3 + 0]; m->pose.m[r * 4 + 1] = R[r * 3 + 1]; m->pose.m[r * 4 + 2] = R[r * 3 + 2]; m->pose.m[r * 4 + 3] = t[r]; }
         }
+    }
+    exchangeTracking();
+}
+
+void CoFusion::exchangeTracking()
+{   // owners publish pose + ICP statistics as bit patterns (one 64-bit slot per float), shadows contribute zeros
+    if (!dist.active()) return;
+    const int R = 16 + 2;
+    std::vector<int64_t> buf(models.size() * R, 0);
+    size_t k = 0;
+    for (auto& m : models) {
+        if (m->isOwned()) {
+            for (int i = 0; i < 16; i++) { uint32_t b; memcpy(&b, &m->pose.m[i], 4); buf[k * R + i] = (int64_t)b; }
+            uint32_t b; memcpy(&b, &m->lastStats.last_icp_error, 4); buf[k * R + 16] = (int64_t)b;
+            memcpy(&b, &m->lastStats.last_icp_count, 4); buf[k * R + 17] = (int64_t)b;
+        }
+        k++;
+    }
+    dist.sum(buf.data(), buf.size());
+    k = 0;
+    for (auto& m : models) {
+        if (!m->isOwned()) {
+            for (int i = 0; i < 16; i++) { const uint32_t b = (uint32_t)buf[k * R + i]; memcpy(&m->pose.m[i], &b, 4); }
+            uint32_t b = (uint32_t)buf[k * R + 16]; memcpy(&m->lastStats.last_icp_error, &b, 4);
+            b = (uint32_t)buf[k * R + 17]; memcpy(&m->lastStats.last_icp_count, &b, 4);
+        }
+        k++;
     }
 }
 
@@ -605,7 +672,7 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
 
     if (tick == 1) {
         globalModel->initialise(curRgba, curDepth, depthFiltered_dev, tick, maxDepthProcessed);
-        check(ctx, cf_odom_init_first_rgb(globalModel->getFrameOdometry(), curRgba), "initFirstRGB");
+        if (globalModel->isOwned()) check(ctx, cf_odom_init_first_rgb(globalModel->getFrameOdometry(), curRgba), "initFirstRGB");
     } else {
         bool trackingOk = true;
         if (bootstrap || !inPose) {

@@ -62,10 +62,25 @@ PhaseTimes& phaseTimes();
 // 8-bit greyscale PNG (zlib), Export.cpp
 bool writePngGray8(const std::string& path, const uint8_t* data, int width, int height);
 
+// Model-parallel operation over several GPUs (one process per GPU): every rank runs the same frame loop and takes the
+// same decisions; a model's surfel map and tracker live only on its owner rank, the other ranks keep a data-less
+// shadow.  What crosses ranks -- poses and tracking statistics after tracking, per-superpixel ICP-error / confidence
+// sums before the CRF, surfel counts when a model is retired -- goes through ONE primitive: an in-place SUM
+// all-reduce of 64-bit integers (owners contribute their bit patterns, everybody else zeros), which is exact.
+struct Distributed {
+    int rank = 0, world = 1;
+    int (*allreduce_i64)(int64_t* buf, uint64_t n, void* user) = nullptr;  // 0 on success
+    void* user = nullptr;
+    bool active() const { return world > 1; }
+    // the background map (by far the largest) alone on rank 0, objects round-robin over the other ranks
+    int owner(unsigned id) const { return (world <= 1 || id == 0) ? 0 : 1 + (int)((id - 1) % (unsigned)(world - 1)); }
+    void sum(int64_t* buf, uint64_t n) const;  // throws if the collective is missing or fails
+};
+
 class Model {
   public:
     Model(cf_ctx* ctx, unsigned char id, float confidenceThresh, bool enableFillIn, int maxSurfels,
-          float maxDepth = 3.402823466e+38f);
+          float maxDepth = 3.402823466e+38f, bool owned = true);
     ~Model();
     Model(const Model&) = delete;
     Model& operator=(const Model&) = delete;
@@ -101,6 +116,7 @@ class Model {
     float* icpErrorSurface() { return icpError; }
     const float* vertexConfProjection() const;
     cf_track_stats lastStats{};
+    bool isOwned() const { return owned; }
 
     struct PoseLogItem { int64_t ts; float p[7]; };  // x,y,z, qx,qy,qz,qw (Model.h:230-233)
     std::vector<PoseLogItem> poseLog;
@@ -119,13 +135,14 @@ class Model {
     unsigned id;
     unsigned unseenCount = 0;
     bool fillIn;
+    bool owned = true;   // false: shadow of a model that lives on another rank (no device objects, only the replicated state)
 };
 typedef std::shared_ptr<Model> ModelPointer;
 typedef std::list<ModelPointer> ModelList;
 
 class Segmentation {
   public:
-    Segmentation(cf_ctx* ctx, int width, int height);
+    Segmentation(cf_ctx* ctx, int width, int height, const Distributed* dist = nullptr);
     ~Segmentation();
     Segmentation(const Segmentation&) = delete;
     Segmentation& operator=(const Segmentation&) = delete;
@@ -149,6 +166,8 @@ class Segmentation {
     cf_segmenter* seg = nullptr;
     int width, height;
     uint8_t gtMapping[256];
+    const Distributed* dist = nullptr;
+    float* zeroImage = nullptr;   // device zeros [H*W*4] standing in for the ICP error / confidence maps of shadow models
 };
 
 class CoFusion {
@@ -167,6 +186,7 @@ class CoFusion {
         unsigned modelSpawnOffset = 22;                        // GUI.h:219
         bool enableMultipleModels = true;
         bool enablePoseLogging = false;                        // CoFusion ctor argument (CoFusion.h:59)
+        int rank = 0, world = 1;                               // model-parallel operation (see Distributed)
     };
     explicit CoFusion(const Config& cfg);
     ~CoFusion();
@@ -179,6 +199,9 @@ class CoFusion {
     int exportPoses(const std::string& exportDir);
     // exportSegmentation (CoFusion.cpp:235-240): when set, every segmented frame writes <prefix>Segmentation<tick>.png (8-bit labels)
     void setExportSegmentation(const std::string& prefix) { exportSegmentationPrefix = prefix; }
+    // the collective of the model-parallel mode (cfg.world > 1); must be set before the first frame
+    void setAllreduce(int (*fn)(int64_t*, uint64_t, void*), void* user) { dist.allreduce_i64 = fn; dist.user = user; }
+    const Distributed& distributed() const { return dist; }
     ModelList& getModels() { return models; }
     ModelPointer getBackgroundModel() { return globalModel; }
     const Mat4f& getCurrPose() const { return globalModel->getPose(); }
@@ -194,6 +217,8 @@ class CoFusion {
     ModelList::iterator inactivateModel(ModelList::iterator it);
     unsigned char getNextModelID(bool assign = false);
     void trackModels(const float* const depthPyr[3]);
+    void exchangeTracking();
+    Distributed dist;
 
     cf_ctx* ctx = nullptr;
     ModelList models, inactiveModels;

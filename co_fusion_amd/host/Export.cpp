@@ -61,6 +61,7 @@ int CoFusion::savePly(const std::string& exportDir)
 {
     int written = 0;
     for (auto& model : models) {
+        if (!model->isOwned()) continue;  // model-parallel mode: the owner rank writes the cloud
         const std::string filename = exportDir + "cloud-" + std::to_string(model->getID()) + ".ply";
         const std::vector<float> map = model->downloadMap();
         const size_t n = map.size() / 12;

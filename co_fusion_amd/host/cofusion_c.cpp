@@ -31,6 +31,7 @@ void cofusion_default_config(cofusion_config* c)
     c->pyramid = d.pyramid; c->rgb_only = d.rgbOnly; c->model_spawn_offset = d.modelSpawnOffset;
     c->enable_multiple_models = d.enableMultipleModels;
     c->enable_pose_logging = d.enablePoseLogging;
+    c->rank = d.rank; c->world = d.world;
 }
 
 int cofusion_create(const cofusion_config* c, cofusion_handle** out)
@@ -44,6 +45,7 @@ int cofusion_create(const cofusion_config* c, cofusion_handle** out)
     d.pyramid = c->pyramid; d.rgbOnly = c->rgb_only; d.modelSpawnOffset = c->model_spawn_offset;
     d.enableMultipleModels = c->enable_multiple_models;
     d.enablePoseLogging = c->enable_pose_logging != 0;
+    d.rank = c->rank; d.world = c->world < 1 ? 1 : c->world;
     GUARD(*out = new cofusion_handle{new CoFusion(d)});
     return 0;
 }
@@ -93,6 +95,7 @@ int cofusion_model_download(cofusion_handle* h, int index, float* surfels, uint3
 {
     Model* m = model_at(h, index);
     if (!m) { g_err = "model index out of range"; return -1; }
+    if (!m->isOwned()) { if (count) *count = 0; return 0; }
     return cf_model_download_map(m->handle(), surfels, capacity, count);
 }
 int cofusion_model_icp_stats(cofusion_handle* h, int index, float* err, float* cnt)
@@ -115,6 +118,17 @@ int cofusion_set_crf(cofusion_handle* h, float uwe, float uke, float thn, float 
     return 0;
 }
 
+int cofusion_set_allreduce(cofusion_handle* h, cofusion_allreduce_i64_fn fn, void* user)
+{
+    h->cf->setAllreduce(fn, user);
+    return 0;
+}
+int cofusion_model_owned(cofusion_handle* h, int index)
+{
+    Model* m = model_at(h, index);
+    if (!m) { g_err = "model index out of range"; return -1; }
+    return m->isOwned() ? 1 : 0;
+}
 /* diagnostics: host wall-clock per processFrame phase of the calling thread (PhaseTimes order), frames counted */
 int cofusion_debug_phase_ms(double* out, int n, long* frames, int reset)
 {

@@ -22,6 +22,7 @@ typedef struct {
     unsigned model_spawn_offset;
     int enable_multiple_models;
     int enable_pose_logging; /* CoFusion ctor argument enablePoseLogging (CoFusion.h:59); needed by cofusion_export_poses */
+    int rank, world;         /* model-parallel operation over `world` processes / GPUs (default 0, 1); see cofusion_set_allreduce */
 } cofusion_config;
 
 void cofusion_default_config(cofusion_config *cfg);
@@ -51,6 +52,15 @@ int cofusion_set_crf(cofusion_handle *h, float unary_weight_error, float unary_k
                      float weight_smoothness, float sigma_rgb, float sigma_depth, float sigma_pos, float min_rel_size_new,
                      float max_rel_size_new, unsigned iterations);
 
+/* Model-parallel mode (cfg.world > 1, one process per GPU, every rank fed the same frames): the object models are placed
+ * round-robin on ranks 1.., the background on rank 0; every rank runs the same frame loop and keeps data-less shadows of
+ * the models it does not own.  All inter-rank traffic (poses after tracking, per-superpixel ICP / confidence sums for
+ * the CRF, surfel counts at retirement) goes through this one callback: an in-place SUM all-reduce of `n` int64 values
+ * over all ranks (e.g. ncclAllReduce / torch.distributed.all_reduce); return 0 on success.  Register before frame 1. */
+typedef int (*cofusion_allreduce_i64_fn)(int64_t *buf, uint64_t n, void *user);
+int cofusion_set_allreduce(cofusion_handle *h, cofusion_allreduce_i64_fn fn, void *user);
+/* 1 if the model at `index` lives on this rank, 0 if it is a shadow (count reads 0, download is empty) */
+int cofusion_model_owned(cofusion_handle *h, int index);
 /* diagnostics: accumulated host wall-clock (ms) per processFrame phase on the calling thread -- prepare, track, slic+sums,
  * unaries, crf, segmentation post-processing, model logic, fuse+clean, predict; returns the number of phases */
 int cofusion_debug_phase_ms(double *out, int n, long *frames, int reset);
