@@ -57,6 +57,9 @@ def parse(argv=None):
     ap.add_argument("--icp-threads", type=int, default=256)
     ap.add_argument("--icp-ppt", type=int, default=1)
     ap.add_argument("--max-surfels", type=int, default=1 << 21)
+    ap.add_argument("--parallel", default="streams", choices=["streams", "models"],
+                    help="N > 1: 'streams' = one independent sequence per GPU (weak scaling, the default); 'models' = ONE sequence, "
+                         "its object models placed on the GPUs (model-parallel frame loop, strong scaling; use an objects workload)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra configs[2] (4 objects + CRF) measurement of the default run")
     ap.add_argument("--streams", type=int, default=1, help="independent RGB-D streams per GPU (own context + HIP stream + host thread each); "
                     "1 = the headline single-sequence figure, >1 = throughput mode")
@@ -123,9 +126,12 @@ def main(argv=None):
     dev = torch.device("cuda", local_rank)
     streams = []
     for si in range(S):
-        cam, frames = make_stream(W, H, args.frames, n_obj=n_obj, seed=1234 + rank * 64 + si)
+        model_parallel = args.parallel == "models" and world > 1
+        cam, frames = make_stream(W, H, args.frames, n_obj=n_obj, seed=1234 + (0 if model_parallel else rank * 64) + si)
         cfi = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels,
-                              enable_multiple_models=int(n_obj > 0))
+                              enable_multiple_models=int(n_obj > 0), **(dict(rank=rank, world=world) if model_parallel else {}))
+        if model_parallel:
+            cfi.set_allreduce()
         cfi.set_icp_launch(args.icp_threads, args.icp_ppt)
         hip_stream = None
         if S > 1:  # every stream of work on its own HIP stream (the default is torch's current stream)
@@ -180,7 +186,8 @@ def main(argv=None):
     dt = timed_region(None, args.steps, 0, barrier, all_reduce_max, run_range=lambda lo, hi: run_range(lo + args.warmup, hi + args.warmup))
     prof = cf.profile_read(reset=True)
     cf.profile_enable(False)
-    fps = args.steps * world * S / dt
+    model_parallel = args.parallel == "models" and world > 1
+    fps = args.steps * (1 if model_parallel else world) * S / dt
 
     out = None
     if rank == 0:
@@ -198,11 +205,11 @@ def main(argv=None):
                 "objects4-gt": "4 moving objects + background, ground-truth label masks"}[args.workload]
         out = dict(metric="frames/sec at 640x480 (N active models) + ICP-reduce achieved HBM GB/s vs peak", value=round(fps, 2),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 4),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   higher_is_better=True, scaling="strong" if model_parallel else "weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload=f"{desc}, {W}x{H} synthetic noisy RGB-D, whole CoFusion::processFrame hot path "
                                         "(bilateral, tracking SO3+4/5/10 ICP+RGB GN, predict, fuse, clean)",
                                active_models=n_models, surfels=counts, icp_launch=[args.icp_threads, args.icp_ppt],
-                               streams_per_gpu=S),
+                               streams_per_gpu=S, parallel=args.parallel if world > 1 else "single"),
                    roofline=roofline, cpu_baseline=cpu)
         if world == 1 and args.workload == "static" and S == 1 and not args.no_secondary:
             # BASELINE.json's target sentence is phrased on configs[2] (4 moving objects + background, CRF on): measured too
