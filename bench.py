@@ -14,6 +14,8 @@ Workloads (BASELINE.json configs):
 
 N > 1: one process per GPU (torch.distributed.run); every rank runs its own independent RGB-D stream --
 the path partitions over independent streams/models without a data-path collective ("scaling": "weak").
+`--parallel models` instead places the object models of ONE stream on the ranks (model-parallel frame loop with
+an exact int64 all-reduce; "scaling": "strong").
 Timing: barrier + synchronize on both sides of exactly K steps, MAX over ranks.
 
 The JSON line also carries
