@@ -387,20 +387,36 @@ void cf_odom_destroy(cf_odom* od)
 // RGBDOdometry::initICPModel, RGBDOdometry.cpp:143-175.  The reference copies the GL textures into
 // vmaps_tmp/nmaps_tmp first (two 4.9 MB interop copies); vmaps_tmp is kept because initRGBModel /
 // initRGB read depth from it afterwards (:179).
+static ModelMapsArgs model_maps_args(cf_odom* od, const float* pred_v4, const float* pred_n4, const float pose[16])
+{
+    ModelMapsArgs a{};
+    a.pred_v4 = pred_v4; a.pred_n4 = pred_n4; a.snapshot = od->vmaps_tmp; a.cols = od->ctx->cfg.width; a.rows = od->ctx->cfg.height;
+    for (int i = 0; i < CF_NUM_PYRS; ++i) { a.vmap[i] = od->vmap_g_prev[i]; a.nmap[i] = od->nmap_g_prev[i]; }
+    const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+    const float t[3] = {pose[3], pose[7], pose[11]};
+    memcpy(a.R, R, sizeof(R)); memcpy(a.t, t, sizeof(t));
+    return a;
+}
+static RgbdChain rgbd_chain(cf_odom* od, const uint8_t* rgba, float* const* depths, uint8_t* const* images)
+{
+    RgbdChain c{};
+    c.v4 = od->vmaps_tmp; c.rgba = rgba;
+    for (int i = 0; i < CF_NUM_PYRS; ++i) { c.depth[i] = depths[i]; c.image[i] = images[i]; }
+    return c;
+}
+
 int cf_odom_init_icp_model(cf_odom* od, const float* pred_v4, const float* pred_n4, const float pose[16])
 {
     if (!od || !pred_v4 || !pred_n4 || !pose) return CF_EINVAL;
     cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
-    const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
-    const float t[3] = {pose[3], pose[7], pose[11]};
     if (W % 4 == 0 && H % 4 == 0) {  // one launch: snapshot + copyMaps + resize chain + transform of every level
-        ModelMapsArgs a{};
-        a.pred_v4 = pred_v4; a.pred_n4 = pred_n4; a.snapshot = od->vmaps_tmp; a.cols = W; a.rows = H;
-        for (int i = 0; i < CF_NUM_PYRS; ++i) { a.vmap[i] = od->vmap_g_prev[i]; a.nmap[i] = od->nmap_g_prev[i]; }
-        memcpy(a.R, R, sizeof(R)); memcpy(a.t, t, sizeof(t));
-        launch_model_maps(s, a);
+        ModelMapsBatch b{};
+        b.m[0] = model_maps_args(od, pred_v4, pred_n4, pose);
+        launch_model_maps(s, b, 1);
     } else {
+        const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+        const float t[3] = {pose[3], pose[7], pose[11]};
         HIPCHK(ctx, hipMemcpyAsync(od->vmaps_tmp, pred_v4, (size_t)W * H * 16, hipMemcpyDeviceToDevice, s));
         launch_copy_maps(s, od->vmaps_tmp, pred_n4, W, H, od->vmap_g_prev[0], od->nmap_g_prev[0]);
         for (int i = 1; i < CF_NUM_PYRS; ++i) {
@@ -417,14 +433,49 @@ int cf_odom_init_icp_model(cf_odom* od, const float* pred_v4, const float* pred_
 static int populate_rgbd(cf_odom* od, const uint8_t* rgba, float* const* depths, uint8_t* const* images)
 {
     cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
-    const int W = ctx->cfg.width, H = ctx->cfg.height;
     // verticesToDepth + imageBGRToIntensity, then both Gaussian pyramids: three launches for the two chains
-    launch_rgbd_pyramids(s, od->vmaps_tmp, rgba, W, H, od->maxDepthRGB, depths, images);
+    RgbdBatch b{};
+    b.c[0] = rgbd_chain(od, rgba, depths, images);
+    launch_rgbd_pyramids(s, b, 1, ctx->cfg.width, ctx->cfg.height, od->maxDepthRGB);
     LAUNCHCHK(ctx);
     return CF_OK;
 }
 int cf_odom_init_rgb_model(cf_odom* od, const uint8_t* pred_rgba) { if (!od || !pred_rgba) return CF_EINVAL; return populate_rgbd(od, pred_rgba, od->lastDepth, od->lastImage); }
 int cf_odom_init_rgb(cf_odom* od, const uint8_t* rgba) { if (!od || !rgba) return CF_EINVAL; return populate_rgbd(od, rgba, od->nextDepth, od->nextImage); }
+
+// initICPModel + initRGBModel + initRGB of `n` trackers in four launches (one grid row per tracker / chain) instead of
+// seven per tracker: what CoFusion::trackModels issues for every active model of a frame.
+int cf_odom_init_models_batch(cf_ctx* ctx, cf_odom* const* ods, int n, const float* const* pred_v4, const float* const* pred_n4,
+                              const uint8_t* const* pred_rgba, const float* const* poses, const uint8_t* frame_rgba)
+{
+    if (!ctx || !ods || n <= 0 || !pred_v4 || !pred_n4 || !pred_rgba || !poses || !frame_rgba) return CF_EINVAL;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    if (W % 4 || H % 4) {
+        for (int k = 0; k < n; k++) {
+            if (int r = cf_odom_init_icp_model(ods[k], pred_v4[k], pred_n4[k], poses[k])) return r;
+            if (int r = cf_odom_init_rgb_model(ods[k], pred_rgba[k])) return r;
+            if (int r = cf_odom_init_rgb(ods[k], frame_rgba)) return r;
+        }
+        return CF_OK;
+    }
+    hipStream_t s = ctx->stream;
+    for (int base = 0; base < n; base += kPrepBatch) {
+        const int nb = n - base < kPrepBatch ? n - base : kPrepBatch;
+        ModelMapsBatch mb{};
+        RgbdBatch rb{};
+        for (int k = 0; k < nb; k++) {
+            cf_odom* od = ods[base + k];
+            if (!od || !pred_v4[base + k] || !pred_n4[base + k] || !pred_rgba[base + k] || !poses[base + k]) return CF_EINVAL;
+            mb.m[k] = model_maps_args(od, pred_v4[base + k], pred_n4[base + k], poses[base + k]);
+            rb.c[2 * k] = rgbd_chain(od, pred_rgba[base + k], od->lastDepth, od->lastImage);   // initRGBModel
+            rb.c[2 * k + 1] = rgbd_chain(od, frame_rgba, od->nextDepth, od->nextImage);        // initRGB
+        }
+        launch_model_maps(s, mb, nb);
+        launch_rgbd_pyramids(s, rb, 2 * nb, W, H, ods[base]->maxDepthRGB);
+    }
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
 
 int cf_odom_init_first_rgb(cf_odom* od, const uint8_t* rgba)
 {  // RGBDOdometry.cpp:206-215
@@ -477,7 +528,7 @@ static void inv33f_host(const float a[9], float o[9])
 }
 
 // enqueue everything one model needs before the lock-step GN loop
-static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* opts, float* err_surface)
+static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* opts, float* err_surface, RgbPrepArgs* prep)
 {
     cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
@@ -494,7 +545,7 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
             a.minScale[i] = (float)(pow((double)od->minGrad[i], 2.0) / pow((double)od->sobelScale, 2.0));
             a.fx_inv[i] = 1.0f / il.fx; a.fy_inv[i] = 1.0f / il.fy; a.cx[i] = il.cx; a.cy[i] = il.cy;
         }
-        launch_rgb_prep(s, a, W, H);
+        *prep = a;  // launched once for all models of the batch by the caller
     }
     OdomDev* h = od->h_state;
     for (int i = 0; i < CF_NUM_PYRS; i++) {
@@ -562,10 +613,13 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
                               const cf_track_opts* opts, float* const* err_surfaces)
 {
     if (!ctx || !ods || n <= 0 || n > ctx->cfg.max_models || n > kMaxBatch || !poses_in || !opts) return CF_EINVAL;
+    const bool want_rgb = opts->rgb_only || opts->icp_weight < 100;
+    RgbPrepBatch prep{};
     for (int m = 0; m < n; m++) {
-        if (int r = odom_prepare(ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr)) return r;
+        if (int r = odom_prepare(ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr, &prep.m[m])) return r;
         ctx->h_model_ptrs[m] = ods[m]->d_state;
     }
+    if (want_rgb) launch_rgb_prep(ctx->stream, prep, n, ctx->cfg.width, ctx->cfg.height);
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_model_ptrs, ctx->h_model_ptrs, sizeof(OdomDev*) * n, hipMemcpyHostToDevice, ctx->stream));
     const bool icp = !opts->rgb_only && opts->icp_weight > 0;
     const bool rgb = opts->rgb_only || opts->icp_weight < 100;

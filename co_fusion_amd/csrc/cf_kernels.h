@@ -85,11 +85,17 @@ struct ModelMapsArgs {
     int cols, rows;
     float R[9], t[3];
 };
-void launch_model_maps(hipStream_t s, const ModelMapsArgs& a);  // needs cols % 4 == 0 && rows % 4 == 0
+// batches: one grid row per tracked model (<= kPrepBatch), so that a frame with several models still issues each
+// preparation kernel once
+constexpr int kPrepBatch = 8;
+struct ModelMapsBatch { ModelMapsArgs m[kPrepBatch]; };
+struct RgbPrepBatch { RgbPrepArgs m[kPrepBatch]; };
+struct RgbdChain { const float* v4; const uint8_t* rgba; float* depth[3]; uint8_t* image[3]; };  // verticesToDepth + intensity + pyramids
+struct RgbdBatch { RgbdChain c[2 * kPrepBatch]; };
+void launch_model_maps(hipStream_t s, const ModelMapsBatch& b, int n);  // needs cols % 4 == 0 && rows % 4 == 0
 void launch_frame_maps(hipStream_t s, FrameMapsArgs a, int W, int H);
-void launch_rgbd_pyramids(hipStream_t s, const float* v4, const uint8_t* rgba, int W, int H, float cutoff, float* const depths[3],
-                          uint8_t* const images[3]);
-void launch_rgb_prep(hipStream_t s, RgbPrepArgs a, int W, int H);
+void launch_rgbd_pyramids(hipStream_t s, const RgbdBatch& b, int n_chains, int W, int H, float cutoff);
+void launch_rgb_prep(hipStream_t s, RgbPrepBatch b, int n, int W, int H);
 
 // ---- reduction launchers (track_reduce.hip) ----
 struct IcpLaunch { int threads; int ppt; };  // threads per workgroup, pixels per thread

@@ -219,32 +219,34 @@ __global__ void __launch_bounds__(kBlock) pyrdown_u8_kernel(const uint8_t* __res
 
 // RGBDOdometry::populateRGBDData (RGBDOdometry.cpp:177-194) issues a depth chain and an intensity chain that do not
 // depend on each other: each pyramid step of both shares one launch (workgroups [0, nd) depth, the rest intensity).
-__global__ void __launch_bounds__(kBlock) rgbd_base_kernel(const float4* __restrict__ v4, const uchar4* __restrict__ rgba, int N, float cutoff,
-                                                           float* __restrict__ depth, uint8_t* __restrict__ image)
+__global__ void __launch_bounds__(kBlock) rgbd_base_kernel(const RgbdBatch b, int N, float cutoff)
 {
+    const RgbdChain& c = b.c[blockIdx.y];  // one (depth, intensity) chain per grid row: models x {prediction, frame}
+    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(c.v4);
+    const uchar4* __restrict__ rgba = reinterpret_cast<const uchar4*>(c.rgba);
     const int nb = (N + kBlock - 1) / kBlock;
     if ((int)blockIdx.x < nb) {  // verticesToDepthKernel, cudafuncs.cu:602-613
         const int i = blockIdx.x * kBlock + threadIdx.x;
         if (i >= N) return;
         const float z = v4[i].z;
-        depth[i] = (z > cutoff || z <= 0) ? qnan() : z;
+        c.depth[0][i] = (z > cutoff || z <= 0) ? qnan() : z;
     } else {                     // bgr2IntensityKernel, cudafuncs.cu:626-639
         const int i = (blockIdx.x - nb) * kBlock + threadIdx.x;
         if (i >= N) return;
         const uchar4 s = rgba[i];
-        image[i] = (uint8_t)(int)((float)s.x * 0.114f + (float)s.y * 0.299f + (float)s.z * 0.587f);
+        c.image[0][i] = (uint8_t)(int)((float)s.x * 0.114f + (float)s.y * 0.299f + (float)s.z * 0.587f);
     }
 }
-__global__ void __launch_bounds__(kBlock) rgbd_pyrdown_kernel(const float* __restrict__ dsrc, const uint8_t* __restrict__ isrc, int scols,
-                                                              int srows, float* __restrict__ ddst, uint8_t* __restrict__ idst)
+__global__ void __launch_bounds__(kBlock) rgbd_pyrdown_kernel(const RgbdBatch b, int level, int scols, int srows)
 {
+    const RgbdChain& c = b.c[blockIdx.y];
     const int n = (scols / 2) * (srows / 2), nb = (n + kBlock - 1) / kBlock;
     if ((int)blockIdx.x < nb) {
         const int i = blockIdx.x * kBlock + threadIdx.x;
-        if (i < n) pyrdown_f32_px(dsrc, scols, srows, ddst, i);
+        if (i < n) pyrdown_f32_px(c.depth[level], scols, srows, c.depth[level + 1], i);
     } else {
         const int i = (blockIdx.x - nb) * kBlock + threadIdx.x;
-        if (i < n) pyrdown_u8_px(isrc, scols, srows, idst, i);
+        if (i < n) pyrdown_u8_px(c.image[level], scols, srows, c.image[level + 1], i);
     }
 }
 
@@ -362,8 +364,9 @@ __global__ void __launch_bounds__(kBlock) frame_maps_kernel(const FrameMapsArgs 
 }
 
 // sobel_kernel + rgb_cand_kernel + cloud_kernel for the three levels (RGBDOdometry.cpp:231-235, :333)
-__global__ void __launch_bounds__(kBlock) rgb_prep_kernel(const RgbPrepArgs a)
+__global__ void __launch_bounds__(kBlock) rgb_prep_kernel(const RgbPrepBatch b)
 {
+    const RgbPrepArgs& a = b.m[blockIdx.y];  // one tracked model per grid row
     int lb;
     const int lv = level_of(a.L, blockIdx.x, lb);
     const int cols = a.L.cols[lv], rows = a.L.rows[lv];
@@ -454,8 +457,9 @@ __device__ __forceinline__ MapVal resize4(const MapVal& a00, const MapVal& a01, 
     return o;
 }
 
-__global__ void __launch_bounds__(64) model_maps_kernel(const ModelMapsArgs a)
+__global__ void __launch_bounds__(64) model_maps_kernel(const ModelMapsBatch b)
 {
+    const ModelMapsArgs& a = b.m[blockIdx.y];  // one tracked model per grid row
     const int c2 = a.cols >> 2, r2 = a.rows >> 2;
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t >= c2 * r2) return;
@@ -508,24 +512,22 @@ void launch_frame_maps(hipStream_t s, FrameMapsArgs a, int W, int H)
     a.L = levels3(W, H);
     frame_maps_kernel<<<a.L.blk_end[2], kBlock, 0, s>>>(a);
 }
-void launch_rgb_prep(hipStream_t s, RgbPrepArgs a, int W, int H)
+void launch_rgb_prep(hipStream_t s, RgbPrepBatch b, int n, int W, int H)
 {
-    a.L = levels3(W, H);
-    rgb_prep_kernel<<<a.L.blk_end[2], kBlock, 0, s>>>(a);
+    const Level3 L = levels3(W, H);
+    for (int m = 0; m < n; m++) b.m[m].L = L;
+    rgb_prep_kernel<<<dim3(L.blk_end[2], n), kBlock, 0, s>>>(b);
 }
-void launch_model_maps(hipStream_t s, const ModelMapsArgs& a)
+void launch_model_maps(hipStream_t s, const ModelMapsBatch& b, int n)
 {
-    const int n = (a.cols >> 2) * (a.rows >> 2);
-    model_maps_kernel<<<(n + 63) / 64, 64, 0, s>>>(a);
+    const int t = (b.m[0].cols >> 2) * (b.m[0].rows >> 2);
+    model_maps_kernel<<<dim3((t + 63) / 64, n), 64, 0, s>>>(b);
 }
-void launch_rgbd_pyramids(hipStream_t s, const float* v4, const uint8_t* rgba, int W, int H, float cutoff, float* const depths[3],
-                          uint8_t* const images[3])
+void launch_rgbd_pyramids(hipStream_t s, const RgbdBatch& b, int n_chains, int W, int H, float cutoff)
 {
-    rgbd_base_kernel<<<2 * grid_for(W * H), kBlock, 0, s>>>(reinterpret_cast<const float4*>(v4), reinterpret_cast<const uchar4*>(rgba), W * H, cutoff,
-                                                            depths[0], images[0]);
+    rgbd_base_kernel<<<dim3(2 * grid_for(W * H), n_chains), kBlock, 0, s>>>(b, W * H, cutoff);
     for (int i = 0; i + 1 < 3; i++)
-        rgbd_pyrdown_kernel<<<2 * grid_for(((W >> i) / 2) * ((H >> i) / 2)), kBlock, 0, s>>>(depths[i], images[i], W >> i, H >> i, depths[i + 1],
-                                                                                         images[i + 1]);
+        rgbd_pyrdown_kernel<<<dim3(2 * grid_for(((W >> i) / 2) * ((H >> i) / 2)), n_chains), kBlock, 0, s>>>(b, i, W >> i, H >> i);
 }
 void launch_vmap(hipStream_t s, const float* depth, int cols, int rows, cf_cam intr, float cutoff, float* vmap)
 {

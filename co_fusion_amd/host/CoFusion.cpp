@@ -113,11 +113,8 @@ static const void* mbuf(cf_ctx* ctx, cf_model* m, int which)
 }
 const float* Model::vertexConfProjection() const { return owned ? static_cast<const float*>(mbuf(ctx, model, 5)) : nullptr; }
 
-void Model::initICP(bool doFillIn, bool frameToFrameRGB, const float* const depthPyr[3], float depthCutoff, const uint8_t* rgba,
-                    Model* frameOwner)
-{  // Model.cpp:350-367.  WARNING initICP* must be called before initRGB* (they share vmaps_tmp)
-    if (!owned) return;
-    const float* v; const float* n; const uint8_t* img;
+void Model::trackingInputs(bool doFillIn, bool frameToFrameRGB, const float*& v, const float*& n, const uint8_t*& img) const
+{  // Model.cpp:350-367: which prediction feeds initICPModel / initRGBModel
     if (doFillIn) {
         v = static_cast<const float*>(mbuf(ctx, model, 8)); n = static_cast<const float*>(mbuf(ctx, model, 9));
         img = static_cast<const uint8_t*>(mbuf(ctx, model, 10));
@@ -125,8 +122,9 @@ void Model::initICP(bool doFillIn, bool frameToFrameRGB, const float* const dept
         v = static_cast<const float*>(mbuf(ctx, model, 5)); n = static_cast<const float*>(mbuf(ctx, model, 6));
         img = static_cast<const uint8_t*>(mbuf(ctx, model, (frameToFrameRGB && allowsFillIn()) ? 10 : 4));
     }
-    check(ctx, cf_odom_init_icp_model(odom, v, n, pose.m), "initICPModel");
-    check(ctx, cf_odom_init_rgb_model(odom, img), "initRGBModel");
+}
+void Model::bindFrameMaps(const float* const depthPyr[3], float depthCutoff, Model* frameOwner)
+{
     if (frameOwner == this) {
         // the current-frame vertex/normal pyramids do not depend on the model (the mask test is commented out
         // in createVMap, cudafuncs.cu:119): computed once, shared with every other model of this frame
@@ -140,6 +138,16 @@ void Model::initICP(bool doFillIn, bool frameToFrameRGB, const float* const dept
         }
         check(ctx, cf_odom_bind_frame_maps(odom, vm, nm), "bind_frame_maps");
     }
+}
+void Model::initICP(bool doFillIn, bool frameToFrameRGB, const float* const depthPyr[3], float depthCutoff, const uint8_t* rgba,
+                    Model* frameOwner)
+{  // Model.cpp:350-367.  WARNING initICP* must be called before initRGB* (they share vmaps_tmp)
+    if (!owned) return;
+    const float* v; const float* n; const uint8_t* img;
+    trackingInputs(doFillIn, frameToFrameRGB, v, n, img);
+    check(ctx, cf_odom_init_icp_model(odom, v, n, pose.m), "initICPModel");
+    check(ctx, cf_odom_init_rgb_model(odom, img), "initRGBModel");
+    bindFrameMaps(depthPyr, depthCutoff, frameOwner);
     check(ctx, cf_odom_init_rgb(odom, rgba), "initRGB");
 }
 float Model::computeFusionWeight(float weightMultiplier) const { return cf_fusion_weight(pose.m, lastPose.m, weightMultiplier); }
@@ -606,8 +614,18 @@ void CoFusion::trackModels(const float* const depthPyr[3])
         if (m->isOwned()) ms.push_back(m.get());
     }
     if (!ms.empty()) {
+        // Model::initICP of every model (initICPModel + initRGBModel + initICP + initRGB), batched: one launch per
+        // preparation kernel for all models of the frame
         Model* owner = ms[0];  // computes the frame-wide vertex / normal pyramids the other models of this rank share
-        for (Model* m : ms) m->initICP(m->requiresFillIn(), cfg.frameToFrameRGB, depthPyr, maxDepthProcessed, curRgba, owner);
+        std::vector<cf_odom*> ods; std::vector<const float*> pv, pn, pp; std::vector<const uint8_t*> pi;
+        for (Model* m : ms) {
+            const float* v; const float* n; const uint8_t* img;
+            m->trackingInputs(m->requiresFillIn(), cfg.frameToFrameRGB, v, n, img);
+            ods.push_back(m->odom); pv.push_back(v); pn.push_back(n); pi.push_back(img); pp.push_back(m->pose.m);
+        }
+        check(ctx, cf_odom_init_models_batch(ctx, ods.data(), (int)ods.size(), pv.data(), pn.data(), pi.data(), pp.data(), curRgba),
+              "init_models_batch");
+        for (Model* m : ms) m->bindFrameMaps(depthPyr, maxDepthProcessed, owner);
     }
     cf_track_opts opts{};
     opts.rgb_only = cfg.rgbOnly; opts.pyramid = cfg.pyramid; opts.fast_odom = cfg.fastOdom; opts.so3 = cfg.so3; opts.icp_weight = cfg.icpWeight;

@@ -90,6 +90,9 @@ class Model {
     // Model::initICP (Model.cpp:350-367); frame-wide current maps are owned by `frameOdom` (model 0)
     void initICP(bool doFillIn, bool frameToFrameRGB, const float* const depthPyr[3], float depthCutoff, const uint8_t* rgba,
                  Model* frameOwner);
+    // the two halves of initICP, used by the batched preparation of CoFusion::trackModels
+    void trackingInputs(bool doFillIn, bool frameToFrameRGB, const float*& v, const float*& n, const uint8_t*& img) const;
+    void bindFrameMaps(const float* const depthPyr[3], float depthCutoff, Model* frameOwner);
     float computeFusionWeight(float weightMultiplier) const;
     void fuse(int time, const uint8_t* rgba, const uint8_t* mask, const float* depthRaw, const float* depthFiltered, float depthCutoff,
               float weightMultiplier);

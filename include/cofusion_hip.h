@@ -154,6 +154,12 @@ int cf_odom_init_icp_model(cf_odom *od, const float *pred_vertex4, const float *
 int cf_odom_init_rgb_model(cf_odom *od, const uint8_t *pred_rgba);
 int cf_odom_init_rgb(cf_odom *od, const uint8_t *rgba);
 int cf_odom_init_first_rgb(cf_odom *od, const uint8_t *rgba);
+/* initICPModel + initRGBModel(pred_rgba[k]) + initRGB(frame_rgba) of `n` trackers at once: one launch per preparation
+ * kernel with one grid row per tracker instead of seven launches per tracker (what a frame with several active models
+ * needs before cf_odom_track_batch_async); identical results to the three single calls per tracker */
+int cf_odom_init_models_batch(cf_ctx *ctx, cf_odom *const *ods, int n, const float *const *pred_vertex4,
+                              const float *const *pred_normal4, const uint8_t *const *pred_rgba, const float *const *poses /* n x [16] */,
+                              const uint8_t *frame_rgba);
 /* initICP(depthPyramid, maskPyramid, depthCutoff) :48-49 (frame -> model); the mask pyramid is dead in the
  * reference (cudafuncs.cu:119) and therefore not part of the ABI */
 int cf_odom_init_icp(cf_odom *od, const float *const depth_pyr[CF_NUM_PYRS], float depth_cutoff);
