@@ -78,13 +78,56 @@ void cf_destroy(cf_ctx* ctx)
         for (int i = 0; i < ctx->prof.capacity; i++) (void)hipEventDestroy(ctx->prof.events[i]);
         delete[] ctx->prof.events;
     }
+    for (int i = 0; i < cf_ctx::kLanes; i++) {
+        if (ctx->lanes[i]) (void)hipStreamDestroy(ctx->lanes[i]);
+        if (ctx->lane_done[i]) (void)hipEventDestroy(ctx->lane_done[i]);
+    }
+    if (ctx->fork_point) (void)hipEventDestroy(ctx->fork_point);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
 const char* cf_last_error(const cf_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
-int cf_set_stream(cf_ctx* ctx, void* s) { if (!ctx) return CF_EINVAL; ctx->stream = (hipStream_t)s; return CF_OK; }  // NULL = the legacy default stream
-int cf_use_own_stream(cf_ctx* ctx) { if (!ctx) return CF_EINVAL; ctx->stream = ctx->own_stream; return CF_OK; }
+int cf_set_stream(cf_ctx* ctx, void* s) { if (!ctx || ctx->forked) return CF_EINVAL; ctx->stream = (hipStream_t)s; return CF_OK; }  // NULL = the legacy default stream
+int cf_use_own_stream(cf_ctx* ctx) { if (!ctx || ctx->forked) return CF_EINVAL; ctx->stream = ctx->own_stream; return CF_OK; }
+
+// Independent pieces of one frame (the surfel passes of different models) may overlap on the GPU: cf_fork(lane) routes
+// the following calls to auxiliary stream `lane`, ordered after everything enqueued on the context's stream at the first
+// fork; cf_join returns to that stream and orders it after all lanes used since.
+int cf_fork(cf_ctx* ctx, int lane)
+{
+    if (!ctx || lane < 0) return CF_EINVAL;
+    lane %= cf_ctx::kLanes;
+    if (!ctx->lanes[lane]) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->lanes[lane], hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
+    }
+    if (!ctx->fork_point) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->fork_point, hipEventDisableTiming));
+    if (!ctx->forked) {
+        ctx->forked_from = ctx->stream;
+        HIPCHK(ctx, hipEventRecord(ctx->fork_point, ctx->forked_from));
+        ctx->forked = true; ctx->lanes_used = 0;
+    }
+    if (!(ctx->lanes_used & (1u << lane))) {
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->lanes[lane], ctx->fork_point, 0));
+        ctx->lanes_used |= 1u << lane;
+    }
+    ctx->stream = ctx->lanes[lane];
+    return CF_OK;
+}
+int cf_join(cf_ctx* ctx)
+{
+    if (!ctx) return CF_EINVAL;
+    if (!ctx->forked) return CF_OK;
+    for (int lane = 0; lane < cf_ctx::kLanes; lane++)
+        if (ctx->lanes_used & (1u << lane)) {
+            HIPCHK(ctx, hipEventRecord(ctx->lane_done[lane], ctx->lanes[lane]));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->forked_from, ctx->lane_done[lane], 0));
+        }
+    ctx->stream = ctx->forked_from;
+    ctx->forked = false; ctx->lanes_used = 0;
+    return CF_OK;
+}
 void* cf_get_stream(cf_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int cf_synchronize(cf_ctx* ctx) { if (!ctx) return CF_EINVAL; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return CF_OK; }
 int cf_malloc(cf_ctx* ctx, uint64_t bytes, void** dptr)

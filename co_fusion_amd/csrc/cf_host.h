@@ -22,6 +22,14 @@ struct cf_ctx {
     cf::OdomDev** h_model_ptrs = nullptr;  // pinned
     uint8_t* d_cand_scratch = nullptr;
     cf::So3Sync* d_so3_sync = nullptr;  // [max_models]
+    // auxiliary streams for independent per-model work of one frame (cf_fork / cf_join)
+    static constexpr int kLanes = 8;
+    hipStream_t lanes[kLanes]{};
+    hipEvent_t lane_done[kLanes]{};
+    hipEvent_t fork_point = nullptr;
+    hipStream_t forked_from = nullptr;
+    bool forked = false;
+    unsigned lanes_used = 0;
     cf::ProfSink prof{};
     double prof_ms_accum = 0;
     void set_error(const std::string& m);

@@ -600,10 +600,15 @@ ModelList::iterator CoFusion::inactivateModel(ModelList::iterator it)
 
 void CoFusion::predict()
 {  // CoFusion.cpp:533-545
+    // the models' predictions are independent of each other: one auxiliary stream per model lets them overlap
+    const bool overlap = models.size() > 1 && useLanes;
+    int lane = 0;
     for (auto& model : models) {
+        if (overlap) check(ctx, cf_fork(ctx, lane++), "cf_fork");
         model->combinedPredict(maxDepthProcessed, tick, tick, cfg.timeDelta);
         model->performFillIn(curRgba, depthFiltered_dev, cfg.frameToFrameRGB, lost);
     }
+    if (overlap) check(ctx, cf_join(ctx), "cf_join");
 }
 
 void CoFusion::trackModels(const float* const depthPyr[3])
@@ -755,10 +760,18 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
         { PhaseTimer t(PhaseTimes::Predict); predict(); }
         if (!cfg.rgbOnly && trackingOk && !lost) {
             PhaseTimer t(PhaseTimes::Fuse);
-            for (auto& model : models) model->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
-            for (auto& model : models) model->fuse(tick, curRgba, mask_dev, curDepth, depthFiltered_dev, maxDepthProcessed, weightMultiplier);
-            for (auto& model : models) model->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
-            for (auto& model : models) model->clean(tick, cfg.timeDelta, maxDepthProcessed, depthFiltered_dev, mask_dev, cfg.outlierCoefficient);
+            // CoFusion.cpp:316-330 runs the four passes model by model in four loops; the passes of different models touch
+            // disjoint buffers (shared inputs: frame, mask), so each model's chain goes to its own stream and the chains overlap
+            const bool overlap = models.size() > 1 && useLanes;
+            int lane = 0;
+            for (auto& model : models) {
+                if (overlap) check(ctx, cf_fork(ctx, lane++), "cf_fork");
+                model->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
+                model->fuse(tick, curRgba, mask_dev, curDepth, depthFiltered_dev, maxDepthProcessed, weightMultiplier);
+                model->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
+                model->clean(tick, cfg.timeDelta, maxDepthProcessed, depthFiltered_dev, mask_dev, cfg.outlierCoefficient);
+            }
+            if (overlap) check(ctx, cf_join(ctx), "cf_join");
         }
     }
     { PhaseTimer t(PhaseTimes::Predict); predict(); }

@@ -9,6 +9,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 #include <list>
 #include <memory>
 #include <string>
@@ -242,6 +243,7 @@ class CoFusion {
     float modelKeepConfThreshold = 0.3f;
     bool enableSmartModelDelete = true;
     std::string exportSegmentationPrefix;
+    bool useLanes = std::getenv("CF_NO_LANES") == nullptr;  // per-model auxiliary streams (diagnostic switch)
 };
 
 }  // namespace cofusion
