@@ -103,29 +103,33 @@ int cf_fork(cf_ctx* ctx, int lane)
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
     }
     if (!ctx->fork_point) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->fork_point, hipEventDisableTiming));
-    if (!ctx->forked) {
+    if (!ctx->forked) {  // leaving the main stream: everything enqueued on it so far precedes the lane's work
         ctx->forked_from = ctx->stream;
         HIPCHK(ctx, hipEventRecord(ctx->fork_point, ctx->forked_from));
-        ctx->forked = true; ctx->lanes_used = 0;
+        ctx->forked = true;
     }
-    if (!(ctx->lanes_used & (1u << lane))) {
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->lanes[lane], ctx->fork_point, 0));
-        ctx->lanes_used |= 1u << lane;
-    }
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->lanes[lane], ctx->fork_point, 0));
+    ctx->lanes_used |= 1u << lane;
     ctx->stream = ctx->lanes[lane];
+    return CF_OK;
+}
+// back to the main stream WITHOUT waiting for the lanes (their work keeps running beside what follows); cf_join waits
+int cf_main(cf_ctx* ctx)
+{
+    if (!ctx) return CF_EINVAL;
+    if (ctx->forked) { ctx->stream = ctx->forked_from; ctx->forked = false; }
     return CF_OK;
 }
 int cf_join(cf_ctx* ctx)
 {
     if (!ctx) return CF_EINVAL;
-    if (!ctx->forked) return CF_OK;
+    if (ctx->forked) { ctx->stream = ctx->forked_from; ctx->forked = false; }
     for (int lane = 0; lane < cf_ctx::kLanes; lane++)
         if (ctx->lanes_used & (1u << lane)) {
             HIPCHK(ctx, hipEventRecord(ctx->lane_done[lane], ctx->lanes[lane]));
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->forked_from, ctx->lane_done[lane], 0));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_done[lane], 0));
         }
-    ctx->stream = ctx->forked_from;
-    ctx->forked = false; ctx->lanes_used = 0;
+    ctx->lanes_used = 0;
     return CF_OK;
 }
 void* cf_get_stream(cf_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }

@@ -210,6 +210,11 @@ Segmentation::Segmentation(cf_ctx* c, int w, int h, const Distributed* d) : ctx(
         zeroImage = static_cast<float*>(p);
     }
 }
+void Segmentation::startSlic(const uint8_t* rgba_dev)
+{
+    check(ctx, cf_seg_slic(seg, rgba_dev), "cf_seg_slic");
+    slicStarted = true;
+}
 Segmentation::~Segmentation()
 {
     if (zeroImage) cf_free(ctx, zeroImage);
@@ -297,7 +302,8 @@ SegmentationResult Segmentation::performSegmentationCRF(ModelList& models, const
     const int gx = width / SPIX, gy = height / SPIX, K = gx * gy;
 
     std::unique_ptr<PhaseTimer> pt(new PhaseTimer(PhaseTimes::SegSlicAccumulate));
-    check(ctx, cf_seg_slic(seg, rgba_dev), "cf_seg_slic");
+    if (!slicStarted) check(ctx, cf_seg_slic(seg, rgba_dev), "cf_seg_slic");  // otherwise enqueued by startSlic() beside the tracking
+    slicStarted = false;
     std::vector<uint32_t> spc(K), dcnt(K);
     std::vector<int64_t> dsum(K), icpSum((size_t)K * n_models), confSum((size_t)K * n_models);
     std::vector<int32_t> resample(K);
@@ -701,7 +707,16 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
         if (bootstrap || !inPose) {
             check(ctx, cf_depth_pyramid(ctx, depthFiltered_dev, cfg.width, cfg.height, depthPyr1, depthPyr2), "generateCUDATextures");
             const float* pyr[3] = {depthFiltered_dev, depthPyr1, depthPyr2};
+            // the superpixels only depend on the colour image: SLIC runs on an auxiliary stream beside the (latency-bound)
+            // tracking launches and is joined before the segmentation needs it
+            const bool slicAside = cfg.enableMultipleModels && !frame.mask && useLanes;
+            if (slicAside) {
+                check(ctx, cf_fork(ctx, 7), "cf_fork");
+                labelGenerator->startSlic(curRgba);
+                check(ctx, cf_main(ctx), "cf_main");
+            }
             { PhaseTimer t(PhaseTimes::Track); trackModels(pyr); }
+            if (slicAside) check(ctx, cf_join(ctx), "cf_join");
             if (bootstrap) globalModel->overridePose(globalModel->getPose() * (*inPose));
 
             if (cfg.enableMultipleModels) {

@@ -154,6 +154,8 @@ class Segmentation {
     SegmentationResult performSegmentation(ModelList& models, const FrameData& frame, const float* depth_dev, const uint8_t* rgba_dev,
                                            const uint8_t* rgba_host_first_rows, unsigned char nextModelID, bool allowNew,
                                            uint8_t* fullSegmentation_dev);
+    // enqueue SLIC for this frame's image ahead of performSegmentation (on whatever stream the context currently uses)
+    void startSlic(const uint8_t* rgba_dev);
     // setters (Segmentation.h:100-120); defaults are the GUI values the reference applies every frame (GUI.h:206-227)
     float unaryWeightError = 75.f, unaryKError = 0.0375f, unaryThresholdNew = 5.5f;
     float weightAppearance = 7.f, weightSmoothness = 2.f;
@@ -171,6 +173,7 @@ class Segmentation {
     int width, height;
     uint8_t gtMapping[256];
     const Distributed* dist = nullptr;
+    bool slicStarted = false;
     float* zeroImage = nullptr;   // device zeros [H*W*4] standing in for the ICP error / confidence maps of shadow models
 };
 

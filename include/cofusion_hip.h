@@ -75,9 +75,11 @@ int cf_use_own_stream(cf_ctx *ctx);
 void *cf_get_stream(cf_ctx *ctx);
 int cf_synchronize(cf_ctx *ctx);
 /* Overlap independent work of one frame (e.g. the surfel passes of different models): cf_fork(lane) routes the following
- * calls to auxiliary stream `lane` (0..7), ordered after everything enqueued so far on the context's stream; cf_join
- * returns to that stream and orders it after all lanes.  Calls between fork and join must not wait on the host. */
+ * calls to auxiliary stream `lane` (0..7), ordered after everything enqueued so far on the context's stream; cf_main
+ * returns to that stream without waiting (the lanes keep running beside what follows); cf_join returns to it and orders
+ * it after all lanes used since the last join.  Calls routed to a lane must not wait on the host. */
 int cf_fork(cf_ctx *ctx, int lane);
+int cf_main(cf_ctx *ctx);
 int cf_join(cf_ctx *ctx);
 /* device memory helpers for hosts that do not link HIP themselves */
 int cf_malloc(cf_ctx *ctx, uint64_t bytes, void **dptr);
