@@ -53,6 +53,9 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     if (int r = dmalloc(ctx, &ctx->d_acc_b, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &ctx->d_out, 64)) return r;
     if (int r = dmalloc(ctx, &ctx->d_scratch_state, 1)) return r;
+    if (int r = dmalloc(ctx, &ctx->d_state_pool, (size_t)cf_ctx::kStateSlots)) return r;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state_pool), sizeof(OdomDev) * cf_ctx::kStateSlots));
+    memset(ctx->h_state_pool, 0, sizeof(OdomDev) * cf_ctx::kStateSlots);
     if (int r = dmalloc(ctx, &ctx->d_model_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_so3_sync, (size_t)ctx->cfg.max_models + 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_cand_scratch, (size_t)cfg->width * cfg->height)) return r;
@@ -73,6 +76,7 @@ void cf_destroy(cf_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_acc_a); (void)hipFree(ctx->d_acc_b); (void)hipFree(ctx->d_out);
     (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_cand_scratch);
+    (void)hipFree(ctx->d_state_pool); (void)hipHostFree(ctx->h_state_pool);
     (void)hipHostFree(ctx->h_scratch_state); (void)hipHostFree(ctx->h_model_ptrs); (void)hipHostFree(ctx->h_out);
     if (ctx->prof.events) {
         for (int i = 0; i < ctx->prof.capacity; i++) (void)hipEventDestroy(ctx->prof.events[i]);
@@ -401,8 +405,15 @@ int cf_odom_create(cf_ctx* ctx, cf_odom** out)
     }
     if (int r = dmalloc(ctx, &od->icp_acc, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &od->rgb_acc, (size_t)kGroups * 32)) return r;
-    if (int r = dmalloc(ctx, &od->d_state, 1)) return r;
-    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&od->h_state), sizeof(OdomDev)));
+    for (int k = 0; k < cf_ctx::kStateSlots && od->slot < 0; k++)
+        if (!ctx->slot_used[k]) { ctx->slot_used[k] = true; od->slot = k; }
+    if (od->slot >= 0) {
+        od->d_state = ctx->d_state_pool + od->slot; od->h_state = ctx->h_state_pool + od->slot;
+        HIPCHK(ctx, hipMemsetAsync(od->d_state, 0, sizeof(OdomDev), ctx->stream));
+    } else {
+        if (int r = dmalloc(ctx, &od->d_state, 1)) return r;
+        HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&od->h_state), sizeof(OdomDev)));
+    }
     memset(od->h_state, 0, sizeof(OdomDev));
     // RGBDOdometry ctor defaults: RGBDOdometry.h:45-46, RGBDOdometry.cpp:31-36,103-105
     od->distThres = 0.10f;
@@ -426,8 +437,9 @@ void cf_odom_destroy(cf_odom* od)
         (void)hipFree(od->dIdx[i]); (void)hipFree(od->dIdy[i]); (void)hipFree(od->cloud[i]); (void)hipFree(od->corres[i]);
         (void)hipFree(od->cand[i]);
     }
-    (void)hipFree(od->icp_acc); (void)hipFree(od->rgb_acc); (void)hipFree(od->d_state);
-    (void)hipHostFree(od->h_state);
+    (void)hipFree(od->icp_acc); (void)hipFree(od->rgb_acc);
+    if (od->slot >= 0) od->ctx->slot_used[od->slot] = false;
+    else { (void)hipFree(od->d_state); (void)hipHostFree(od->h_state); }
     delete od;
 }
 
@@ -577,7 +589,7 @@ static void inv33f_host(const float a[9], float o[9])
 // enqueue everything one model needs before the lock-step GN loop
 static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* opts, float* err_surface, RgbPrepArgs* prep)
 {
-    cf_ctx* ctx = od->ctx; hipStream_t s = ctx->stream;
+    cf_ctx* ctx = od->ctx;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
     const bool icp = !opts->rgb_only && opts->icp_weight > 0;
     const bool rgb = opts->rgb_only || opts->icp_weight < 100;
@@ -615,7 +627,6 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
     memcpy(h->Rprev, R, 36); memcpy(h->tprev, t, 12); memcpy(h->Rcurr, R, 36); memcpy(h->tcurr, t, 12);
     inv33f_host(R, h->Rprev_inv);
     memset(&h->stats, 0, sizeof(h->stats));
-    HIPCHK(ctx, hipMemcpyAsync(od->d_state, h, sizeof(OdomDev), hipMemcpyHostToDevice, s));
     // the accumulators are zero here: dmalloc clears them and every solve leaves them cleared
     od->pending_so3_swap = opts->so3 != 0;
     LAUNCHCHK(ctx);
@@ -661,12 +672,26 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
 {
     if (!ctx || !ods || n <= 0 || n > ctx->cfg.max_models || n > kMaxBatch || !poses_in || !opts) return CF_EINVAL;
     const bool want_rgb = opts->rgb_only || opts->icp_weight < 100;
+    if (ctx->state_readback_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ctx->state_readback_pending = false; }
     RgbPrepBatch prep{};
     for (int m = 0; m < n; m++) {
         if (int r = odom_prepare(ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr, &prep.m[m])) return r;
         ctx->h_model_ptrs[m] = ods[m]->d_state;
     }
     if (want_rgb) launch_rgb_prep(ctx->stream, prep, n, ctx->cfg.width, ctx->cfg.height);
+    // state upload: one copy over the slot range when every tracker of the batch lives in the pool (the host copies of
+    // other trackers in the range equal their device copies: both are only written by a tracking call + its read-back)
+    int lo = cf_ctx::kStateSlots, hi = -1;
+    for (int m = 0; m < n; m++) {
+        if (ods[m]->slot < 0) { lo = -1; break; }
+        lo = ods[m]->slot < lo ? ods[m]->slot : lo; hi = ods[m]->slot > hi ? ods[m]->slot : hi;
+    }
+    if (lo >= 0) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_state_pool + lo, ctx->h_state_pool + lo, sizeof(OdomDev) * (hi - lo + 1), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        for (int m = 0; m < n; m++)
+            HIPCHK(ctx, hipMemcpyAsync(ods[m]->d_state, ods[m]->h_state, sizeof(OdomDev), hipMemcpyHostToDevice, ctx->stream));
+    }
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_model_ptrs, ctx->h_model_ptrs, sizeof(OdomDev*) * n, hipMemcpyHostToDevice, ctx->stream));
     const bool icp = !opts->rgb_only && opts->icp_weight > 0;
     const bool rgb = opts->rgb_only || opts->icp_weight < 100;
@@ -677,8 +702,13 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, icp_args, rgb_args, n, ctx->cfg.width, ctx->cfg.height,
                     opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, &ctx->prof);
     LAUNCHCHK(ctx);
-    for (int m = 0; m < n; m++)
-        HIPCHK(ctx, hipMemcpyAsync(ods[m]->h_state, ods[m]->d_state, sizeof(OdomDev), hipMemcpyDeviceToHost, ctx->stream));
+    if (lo >= 0) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_state_pool + lo, ctx->d_state_pool + lo, sizeof(OdomDev) * (hi - lo + 1), hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        for (int m = 0; m < n; m++)
+            HIPCHK(ctx, hipMemcpyAsync(ods[m]->h_state, ods[m]->d_state, sizeof(OdomDev), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ctx->state_readback_pending = true;
     return CF_OK;
 }
 
@@ -687,6 +717,7 @@ int cf_odom_fetch_result(cf_odom* od, float trans[3], float rot[9], cf_track_sta
     if (!od) return CF_EINVAL;
     cf_ctx* ctx = od->ctx;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->state_readback_pending = false;
     if (trans) memcpy(trans, od->h_state->tcurr, 12);
     if (rot) memcpy(rot, od->h_state->Rcurr, 36);
     if (stats) *stats = od->h_state->stats;

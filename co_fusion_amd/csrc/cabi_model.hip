@@ -304,8 +304,18 @@ int cf_model_combined_predict(cf_model* m, const float pose[16], float maxDepth,
     launch_combined_predict(ctx->stream, m->buf[m->target], m->d_count, nb, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
                             maxDepth, confThreshold, time, maxTime, timeDelta, m->rays, m->keys, m->splat_image, m->splat_vertex, m->splat_normal,
                             m->splat_time);
-    // CoFusion::requiresFillIn looks at this prediction at the start of the next frame: count now, read back
-    // asynchronously, so that the question never stalls the frame loop
+    LAUNCHCHK(ctx);
+    m->ratio_valid = false;  // a new prediction: any prefetched fill-in ratio is stale
+    return CF_OK;
+}
+
+// CoFusion::requiresFillIn looks at the frame's LAST prediction at the start of the next frame.  Calling this right
+// after that prediction counts its covered pixels and reads the two numbers back asynchronously, so that the question
+// never stalls the frame loop (cf_model_requires_fill_in falls back to a blocking count otherwise).
+int cf_model_prefetch_fill_ratio(cf_model* m)
+{
+    if (!m) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx;
     launch_fill_ratio(ctx->stream, m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2);
     LAUNCHCHK(ctx);
     HIPCHK(ctx, hipMemcpyAsync(m->h_counts + 2, m->d_tmp2 + 2, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->stream));

@@ -22,6 +22,13 @@ struct cf_ctx {
     cf::OdomDev** h_model_ptrs = nullptr;  // pinned
     uint8_t* d_cand_scratch = nullptr;
     cf::So3Sync* d_so3_sync = nullptr;  // [max_models]
+    // device / pinned-host pools of the trackers' state structs: a batch of trackers is uploaded / read back with ONE
+    // copy over its slot range instead of one copy per tracker
+    static constexpr int kStateSlots = 64;
+    cf::OdomDev* d_state_pool = nullptr;
+    cf::OdomDev* h_state_pool = nullptr;  // pinned
+    bool slot_used[kStateSlots]{};
+    bool state_readback_pending = false;  // a range read-back is in flight: host state must not be rewritten before it lands
     // auxiliary streams for independent per-model work of one frame (cf_fork / cf_join)
     static constexpr int kLanes = 8;
     hipStream_t lanes[kLanes]{};
@@ -60,6 +67,7 @@ struct cf_odom {
     unsigned long long* rgb_acc = nullptr;
     cf::OdomDev* d_state = nullptr;
     cf::OdomDev* h_state = nullptr;  // pinned
+    int slot = -1;                   // index into the context's state pools, -1: own allocations
     float distThres = 0, angleThres = 0, sobelScale = 0, maxDepthDeltaRGB = 0, maxDepthRGB = 0;
     float minGrad[3]{};
     bool pending_so3_swap = false;

@@ -180,6 +180,10 @@ void Model::performFillIn(const uint8_t* rgba, const float* depthFiltered, bool 
 {
     if (fillIn && owned) check(ctx, cf_model_perform_fill_in(model, rgba, depthFiltered, lost ? 1 : 0, (lost || frameToFrameRGB) ? 1 : 0), "performFillIn");
 }
+void Model::prefetchFillRatio()
+{
+    if (owned && allowsFillIn()) check(ctx, cf_model_prefetch_fill_ratio(model), "prefetch_fill_ratio");
+}
 bool Model::requiresFillIn(float ratio)
 {
     if (!allowsFillIn() || !owned) return false;
@@ -604,7 +608,7 @@ ModelList::iterator CoFusion::inactivateModel(ModelList::iterator it)
     return --models.erase(it);
 }
 
-void CoFusion::predict()
+void CoFusion::predict(bool lastOfFrame)
 {  // CoFusion.cpp:533-545
     // the models' predictions are independent of each other: one auxiliary stream per model lets them overlap
     const bool overlap = models.size() > 1 && useLanes;
@@ -612,6 +616,7 @@ void CoFusion::predict()
     for (auto& model : models) {
         if (overlap) check(ctx, cf_fork(ctx, lane++), "cf_fork");
         model->combinedPredict(maxDepthProcessed, tick, tick, cfg.timeDelta);
+        if (lastOfFrame) model->prefetchFillRatio();  // requiresFillIn() of the next frame asks about THIS prediction
         model->performFillIn(curRgba, depthFiltered_dev, cfg.frameToFrameRGB, lost);
     }
     if (overlap) check(ctx, cf_join(ctx), "cf_join");
@@ -789,7 +794,7 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
             if (overlap) check(ctx, cf_join(ctx), "cf_join");
         }
     }
-    { PhaseTimer t(PhaseTimes::Predict); predict(); }
+    { PhaseTimer t(PhaseTimes::Predict); predict(true); }
     phaseTimes().frames++;
     if (!lost) tick++;
     moveNewModelToList();

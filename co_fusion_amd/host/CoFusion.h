@@ -102,6 +102,7 @@ class Model {
     void combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta);
     void performFillIn(const uint8_t* rgba, const float* depthFiltered, bool frameToFrameRGB, bool lost);
     bool requiresFillIn(float ratio = 0.75f);
+    void prefetchFillRatio();
     bool allowsFillIn() const { return fillIn; }
     std::vector<float> downloadMap() const;  // count x 12 floats
 
@@ -200,7 +201,7 @@ class CoFusion {
 
     // CoFusion::processFrame (Core/CoFusion.cpp:171-524)
     bool processFrame(const FrameData& frame, const Mat4f* inPose = nullptr, float weightMultiplier = 1.f, bool bootstrap = false);
-    void predict();                                  // CoFusion.cpp:533-545
+    void predict(bool lastOfFrame = false);          // CoFusion.cpp:533-545
     // CoFusion::savePly / exportPoses (CoFusion.cpp:646-783); exportDir is a prefix ("out/"); return files written or -1
     int savePly(const std::string& exportDir);
     int exportPoses(const std::string& exportDir);

@@ -213,6 +213,9 @@ int cf_model_index_resolve(cf_model *m, const float pose[16], uint64_t *keys_dev
 /* Model::combinedPredict -> ModelProjection::combinedPredict (ModelProjection.cpp:192-273), ACTIVE prediction */
 int cf_model_combined_predict(cf_model *m, const float pose[16], float maxDepth, float confThreshold, int time, int maxTime,
                               int timeDelta);
+/* optional: count the covered pixels of the latest splat prediction now and read them back asynchronously, so that the
+ * next cf_model_requires_fill_in does not wait (call it after the frame's last cf_model_combined_predict) */
+int cf_model_prefetch_fill_ratio(cf_model *m);
 /* Model::performFillIn (Model.cpp:901-909) */
 int cf_model_perform_fill_in(cf_model *m, const uint8_t *rgba, const float *depth_filtered, int passthrough_geom,
                              int passthrough_rgb);
