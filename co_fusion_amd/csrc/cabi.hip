@@ -321,6 +321,15 @@ int cf_rgb_residual(cf_ctx* ctx, float min_scale, const int16_t* dIdx, const int
     return CF_OK;
 }
 
+// fraction bits of the RGB sums for a given sigma: same integer rule as cf::rgb_fix_bits (cf_device.h)
+static int rgb_fix_bits_host(float sigma)
+{
+    if (sigma == -1.0f || !(sigma >= 2.0f)) return 8;
+    unsigned u; memcpy(&u, &sigma, 4);
+    const int F = 8 + 2 * ((int)((u >> 23) & 255u) - 127);
+    return F > 32 ? 32 : F;
+}
+
 int cf_rgb_step(cf_ctx* ctx, const cf_dataterm* corres, float sigma, const float* cloud3, float fx, float fy,
                 const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows, float* A_host,
                 float* b_host, int64_t* sums_host)
@@ -347,7 +356,7 @@ int cf_rgb_step(cf_ctx* ctx, const cf_dataterm* corres, float sigma, const float
     launch_rgb_step(ctx->stream, ra, 1);
     LAUNCHCHK(ctx);
     if (int r = fetch_totals(ctx, ctx->d_acc_b, 32)) return r;
-    se3_unpack_host(ctx->h_out, CF_FIX_RGB, A_host, b_host, nullptr);
+    se3_unpack_host(ctx->h_out, rgb_fix_bits_host(sigma), A_host, b_host, nullptr);
     if (sums_host) memcpy(sums_host, ctx->h_out, sizeof(int64_t) * 32);
     return CF_OK;
 }

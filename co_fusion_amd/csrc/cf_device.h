@@ -19,7 +19,18 @@
 namespace cf {
 
 constexpr int kFixICP = 32;
-constexpr int kFixRGB = 32;
+constexpr int kFixRGB = 32;  // for sigma >= 4096; in general rgb_fix_bits(sigma)
+
+// Fraction bits of the RGB step's sums as a function of the weight scale sigma handed to rgbStep (the correspondence
+// COUNT, or -1 / 1 for unit weights; RGBDOdometry.cpp:373-385, reduce.cu:533-540): Jacobian rows scale like 1/sigma, so
+// the fixed-point window moves with it.  Integer function of sigma's bits; same spec as oracle/orc_math.h.
+__host__ __device__ inline int rgb_fix_bits(float sigma)
+{
+    if (sigma == -1.0f || !(sigma >= 2.0f)) return 8;
+    union { float f; unsigned u; } v; v.f = sigma;
+    const int F = 8 + 2 * ((int)((v.u >> 23) & 255u) - 127);
+    return F > 32 ? 32 : F;
+}
 constexpr int kFixSO3 = 12;
 constexpr int kSE3Words = 32;  // 27 products, residual, inliers, 3 pad
 constexpr int kSO3Words = 16;  // 9 products, residual, inliers, pad

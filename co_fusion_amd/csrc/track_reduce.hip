@@ -49,6 +49,23 @@ __device__ __forceinline__ void se3_accumulate(const float (&row)[7], unsigned l
     acc[27] += (unsigned long long)__double_as_longlong(fma(r[6] * (double)scale, r[6], kMagic));
 }
 
+// same with a wave-uniform run-time scale 2^F (RGB step: F follows sigma, rgb_fix_bits)
+__device__ __forceinline__ void se3_accumulate_dyn(const float (&row)[7], unsigned long long (&acc)[32], float lim, float scale)
+{
+    double r[7], rs[6];
+#pragma unroll
+    for (int i = 0; i < 7; i++) r[i] = (double)clamp_row(row[i], lim);
+#pragma unroll
+    for (int i = 0; i < 6; i++) rs[i] = (double)(clamp_row(row[i], lim) * scale);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            if (j >= i)
+                acc[7 * i - (i * (i - 1)) / 2 + (j - i)] += (unsigned long long)__double_as_longlong(fma(rs[i], r[j], kMagic));
+    acc[27] += (unsigned long long)__double_as_longlong(fma(r[6] * (double)scale, r[6], kMagic));
+}
+
 // ------------------------------------------------------------------------------------------------
 // cross-wave combine + grouped atomics.  v = wave total of word ((lane>>1)&31) (wave_reduce32_u64).
 template <int MAXW>
@@ -361,7 +378,8 @@ __global__ void __launch_bounds__(256) rgb_step_kernel(const RgbArgs ra)
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         unsigned long long v = 0;
         if (__any(found)) {  // a wave without a valid correspondence adds exact zeros
-            se3_accumulate<kFixRGB>(row, acc);
+            const int F = rgb_fix_bits(sigma);
+            se3_accumulate_dyn(row, acc, ldexpf(1.0f, (50 - F) / 2), ldexpf(1.0f, F));
             acc[28] = (unsigned long long)found;
             v = wave_reduce32_u64(acc, lane);
         }
@@ -698,7 +716,7 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
     const bool useIcp = od->icp != 0, useRgb = od->rgb != 0;
     if (active) {
         if (tid < 29 && useIcp) se3_unpack_word(s_icp, tid, kFixICP, s_Af[0], s_bf[0], od->residual);
-        if (tid >= 32 && tid < 59 && useRgb) se3_unpack_word(s_rgb, tid - 32, kFixRGB, s_Af[1], s_bf[1], nullptr);
+        if (tid >= 32 && tid < 59 && useRgb) se3_unpack_word(s_rgb, tid - 32, rgb_fix_bits(sigma_val_from(rgbCount, (int)(long long)s_icp[30], od->rgbOnly)), s_Af[1], s_bf[1], nullptr);
     }
     __syncthreads();
     if (tid == 0) {

@@ -39,7 +39,7 @@ extern "C" {
 #define CF_SE3_WORDS 32
 #define CF_SO3_WORDS 16
 #define CF_FIX_ICP 32
-#define CF_FIX_RGB 32
+#define CF_FIX_RGB 32       /* sigma >= 4096; in general 8 + 2*floor(log2 sigma) capped at 32, 8 for sigma in {-1, <2} */
 #define CF_FIX_SO3 12
 
 typedef struct cf_ctx cf_ctx;

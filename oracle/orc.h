@@ -34,7 +34,7 @@ extern "C" {
 #define ORC_SE3_WORDS 32 /* 27 products, residual, inliers, 3 pad */
 #define ORC_SO3_WORDS 16 /* 9 products, residual, inliers, pad */
 #define ORC_FIX_ICP 32
-#define ORC_FIX_RGB 32
+#define ORC_FIX_RGB 32 /* for sigma >= 4096; in general orc_rgb_fix_bits(sigma), see orc_math.h */
 #define ORC_FIX_SO3 12
 
 typedef struct { float fx, fy, cx, cy; } orc_cam;
@@ -82,6 +82,11 @@ void orc_rgb_step(const orc_dataterm *corres, float sigma, const float *cloud3, 
 void orc_so3_step(const uint8_t *last_image, const uint8_t *next_image, const float image_basis[9],
                   const float kinv[9], const float krlr[9], int cols, int rows, int64_t sums[ORC_SO3_WORDS]);
 /* sums -> the reference's host outputs (reduce.cu:481-498, 1158-1175) */
+int orc_rgb_fix_bits_of(float sigma);
+void orc_rgb_step_f32tree(const orc_dataterm *corres, float sigma, const float *cloud3, float fx, float fy, const int16_t *dIdx,
+                          const int16_t *dIdy, float sobel_scale, int cols, int rows, int threads, int blocks, float out29[29]);
+void orc_so3_step_f32tree(const uint8_t *last_image, const uint8_t *next_image, const float image_basis[9], const float kinv[9],
+                          const float krlr[9], int cols, int rows, int threads, int blocks, float out11[11]);
 void orc_se3_sums_to_host(const int64_t sums[ORC_SE3_WORDS], int F, float A[36], float b[6], float residual[2]);
 void orc_so3_sums_to_host(const int64_t sums[ORC_SO3_WORDS], int F, float A[9], float b[3], float residual[2]);
 

@@ -121,6 +121,21 @@ static inline int64_t orc_fix_prod(float a, float b, int F)
 }
 static inline double orc_fix_to_double(int64_t q, int F) { return ldexp((double)q, -F); }
 
+/* Fraction bits of the RGB step's fixed-point sums, chosen from the weight's scale: rgbStep is handed sigma = the
+ * correspondence COUNT n (RGBDOdometry.cpp:373-374), so a Jacobian row scales like 1/n; sigma = -1 (rgbOnly, w = 1,
+ * reduce.cu:537-540) and sigma = 1 (zero residual) leave the rows unscaled (|row| up to ~2^18).
+ *   F = 8                         for sigma == -1 or sigma < 2      (rows up to 2^21, sums up to 2^55)
+ *   F = min(32, 8 + 2*floor(log2 sigma))  otherwise                 (n >= 4096 -> the Q32 used for ICP)
+ * an integer function of sigma's bit pattern, shared spec with the HIP kernels (cf_device.h rgb_fix_bits). */
+static inline int orc_rgb_fix_bits(float sigma)
+{
+    if (sigma == -1.0f || !(sigma >= 2.0f)) return 8;
+    uint32_t u; memcpy(&u, &sigma, 4);
+    int e = (int)((u >> 23) & 255u) - 127;
+    int F = 8 + 2 * e;
+    return F > 32 ? 32 : F;
+}
+
 /* ---- deterministic f64 sin/cos (Cody-Waite + Taylor), shared spec with HIP ---- */
 static inline void orc_sincos(double x, double *s, double *c)
 {

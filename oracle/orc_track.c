@@ -348,6 +348,53 @@ static void block_reduce29(float (*thread_vals)[29], int threads, float out[29])
     memcpy(out, warp_tot[0], sizeof(float) * 29);
 }
 
+/* generic two-stage f32 reduction in the reference's order over a per-pixel producer of the K summed values */
+typedef void (*orc_vals_fn)(const void *ctx, int i, float vals[29]);
+static void f32tree_reduce(orc_vals_fn fn, const void *ctx, int N, int K, int threads, int blocks, float *out)
+{
+    float(*block_out)[29] = calloc((size_t)blocks, sizeof(float[29]));
+    float(*tv)[29] = calloc((size_t)threads, sizeof(float[29]));
+    for (int b = 0; b < blocks; b++) {
+        memset(tv, 0, sizeof(float[29]) * (size_t)threads);
+        for (int t = 0; t < threads; t++)
+            for (int i = b * threads + t; i < N; i += threads * blocks) {
+                float v[29];
+                fn(ctx, i, v);
+                for (int k = 0; k < K; k++) tv[t][k] += v[k];
+            }
+        block_reduce29(tv, threads, block_out[b]);
+    }
+    /* second stage: reduceSum<<<1, MAX_THREADS>>> = 512 threads grid-stride over `blocks` partials */
+    const int T2 = 512;
+    float(*tv2)[29] = calloc((size_t)T2, sizeof(float[29]));
+    for (int t = 0; t < T2; t++)
+        for (int i = t; i < blocks; i += T2)
+            for (int k = 0; k < K; k++) tv2[t][k] += block_out[i][k];
+    float tot[29];
+    block_reduce29(tv2, T2, tot);
+    memcpy(out, tot, sizeof(float) * (size_t)K);
+    free(tv2); free(tv); free(block_out);
+}
+
+static void se3_products(const float row[7], int found, float v[29])
+{ /* the JtJJtrSE3 initialiser lists of reduce.cu:352-388 / 563-599 */
+    int k = 0;
+    for (int a = 0; a < 6; a++)
+        for (int j = a; j < 7; j++) v[k++] = row[a] * row[j];
+    v[27] = row[6] * row[6];
+    v[28] = (float)found;
+}
+
+typedef struct { icp_ctx c; } icp_tree_ctx;
+static void icp_vals(const void *ctx, int i, float v[29])
+{
+    const icp_ctx *c = (const icp_ctx *)ctx;
+    int y = i / c->cols, x = i - y * c->cols;
+    float row[7], err;
+    int found = icp_row(c, x, y, row, &err);
+    se3_products(row, found, v);
+}
+
 void orc_icp_step_f32tree(const float Rcurr[9], const float tcurr[3], const float *vmap_curr, const float *nmap_curr,
                           const float Rprev_inv[9], const float tprev[3], orc_cam intr, const float *vmap_g_prev,
                           const float *nmap_g_prev, float dist_thres, float angle_thres, int cols, int rows,
@@ -356,32 +403,7 @@ void orc_icp_step_f32tree(const float Rcurr[9], const float tcurr[3], const floa
     icp_ctx c;
     icp_ctx_fill(&c, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev,
                  dist_thres, angle_thres, cols, rows);
-    const int N = cols * rows;
-    float(*block_out)[29] = calloc((size_t)blocks, sizeof(float[29]));
-    float(*tv)[29] = calloc((size_t)threads, sizeof(float[29]));
-    for (int b = 0; b < blocks; b++) {
-        memset(tv, 0, sizeof(float[29]) * (size_t)threads);
-        for (int t = 0; t < threads; t++)
-            for (int i = b * threads + t; i < N; i += threads * blocks) {
-                int y = i / cols, x = i - y * cols;
-                float row[7], err;
-                int found = icp_row(&c, x, y, row, &err);
-                int k = 0;
-                for (int a = 0; a < 6; a++)
-                    for (int j = a; j < 7; j++) tv[t][k++] += row[a] * row[j];
-                tv[t][27] += row[6] * row[6];
-                tv[t][28] += (float)found;
-            }
-        block_reduce29(tv, threads, block_out[b]);
-    }
-    /* second stage: 512 threads grid-stride over `blocks` partials */
-    const int T2 = 512;
-    float(*tv2)[29] = calloc((size_t)T2, sizeof(float[29]));
-    for (int t = 0; t < T2; t++)
-        for (int i = t; i < blocks; i += T2)
-            for (int k = 0; k < 29; k++) tv2[t][k] += block_out[i][k];
-    block_reduce29(tv2, T2, out29);
-    free(tv2); free(tv); free(block_out);
+    f32tree_reduce(icp_vals, &c, cols * rows, 29, threads, blocks, out29);
 }
 
 /* host unpacking of the 29 sums, reduce.cu:481-498 */
@@ -444,33 +466,60 @@ void orc_rgb_residual(float min_scale, const int16_t *dIdx, const int16_t *dIdy,
 }
 
 /* RGBReduction::getProducts, reduce.cu:521-604 */
+typedef struct {
+    const orc_dataterm *corres; float sigma; const float *cloud3; float fx, fy; const int16_t *dIdx, *dIdy; float sobel_scale; int cols;
+} rgb_ctx;
+/* RGBReduction::getProducts, reduce.cu:521-604: one Jacobian row, 0 when the DataTerm is not valid */
+static int rgb_row(const rgb_ctx *r, int i, float row[7])
+{
+    const orc_dataterm *c = &r->corres[i];
+    for (int k = 0; k < 7; k++) row[k] = 0.f;
+    if (!c->valid) return 0;
+    float w = r->sigma + fabsf(c->diff);
+    w = w > FLT_EPSILON ? 1.0f / w : 1.0f;
+    if (r->sigma == -1) w = 1;
+    row[6] = -w * c->diff;
+    const float *cp = r->cloud3 + (c->zero_y * r->cols + c->zero_x) * 3;
+    float invz = 1.0f / cp[2]; /* (float)(1.0/z) == 1.0f/z, both correctly rounded */
+    float dI_dx_val = w * r->sobel_scale * (float)r->dIdx[c->one_y * r->cols + c->one_x];
+    float dI_dy_val = w * r->sobel_scale * (float)r->dIdy[c->one_y * r->cols + c->one_x];
+    float v0 = dI_dx_val * r->fx * invz;
+    float v1 = dI_dy_val * r->fy * invz;
+    float v2 = -(v0 * cp[0] + v1 * cp[1]) * invz;
+    row[0] = v0; row[1] = v1; row[2] = v2;
+    row[3] = -cp[2] * v1 + cp[1] * v2;
+    row[4] = cp[2] * v0 - cp[0] * v2;
+    row[5] = -cp[1] * v0 + cp[0] * v1;
+    return 1;
+}
+
 void orc_rgb_step(const orc_dataterm *corres, float sigma, const float *cloud3, float fx, float fy,
                   const int16_t *dIdx, const int16_t *dIdy, float sobel_scale, int cols, int rows,
                   int64_t sums[ORC_SE3_WORDS])
 {
+    const rgb_ctx r = {corres, sigma, cloud3, fx, fy, dIdx, dIdy, sobel_scale, cols};
     memset(sums, 0, sizeof(int64_t) * ORC_SE3_WORDS);
     for (int i = 0; i < cols * rows; i++) {
-        const orc_dataterm *c = &corres[i];
-        if (!c->valid) continue;
         float row[7];
-        float w = sigma + fabsf(c->diff);
-        w = w > FLT_EPSILON ? 1.0f / w : 1.0f;
-        if (sigma == -1) w = 1;
-        row[6] = -w * c->diff;
-        const float *cp = cloud3 + (c->zero_y * cols + c->zero_x) * 3;
-        float invz = 1.0f / cp[2]; /* (float)(1.0/z) == 1.0f/z, both correctly rounded */
-        float dI_dx_val = w * sobel_scale * (float)dIdx[c->one_y * cols + c->one_x];
-        float dI_dy_val = w * sobel_scale * (float)dIdy[c->one_y * cols + c->one_x];
-        float v0 = dI_dx_val * fx * invz;
-        float v1 = dI_dy_val * fy * invz;
-        float v2 = -(v0 * cp[0] + v1 * cp[1]) * invz;
-        row[0] = v0; row[1] = v1; row[2] = v2;
-        row[3] = -cp[2] * v1 + cp[1] * v2;
-        row[4] = cp[2] * v0 - cp[0] * v2;
-        row[5] = -cp[1] * v0 + cp[0] * v1;
-        se3_accumulate(row, 1, ORC_FIX_RGB, sums);
+        if (rgb_row(&r, i, row)) se3_accumulate(row, 1, orc_rgb_fix_bits(sigma), sums);
     }
 }
+
+static void rgb_vals(const void *ctx, int i, float v[29])
+{
+    float row[7];
+    int found = rgb_row((const rgb_ctx *)ctx, i, row);
+    se3_products(row, found, v);
+}
+/* the same sums in the reference's f32 order (rgbKernel<<<blocks, threads>>> + reduceSum, reduce.cu:606-670) */
+void orc_rgb_step_f32tree(const orc_dataterm *corres, float sigma, const float *cloud3, float fx, float fy, const int16_t *dIdx,
+                          const int16_t *dIdy, float sobel_scale, int cols, int rows, int threads, int blocks, float out29[29])
+{
+    const rgb_ctx r = {corres, sigma, cloud3, fx, fy, dIdx, dIdy, sobel_scale, cols};
+    f32tree_reduce(rgb_vals, &r, cols * rows, 29, threads, blocks, out29);
+}
+
+int orc_rgb_fix_bits_of(float sigma) { return orc_rgb_fix_bits(sigma); }
 
 /* ================================== SO3 ======================================= */
 
@@ -483,37 +532,68 @@ static inline void so3_gradient(const uint8_t *img, int cols, int x, int y, floa
     *gy = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
 }
 
+typedef struct { const uint8_t *last_image, *next_image; orc_m33 B, Ki; const float *krlr; int cols, rows; } so3_ctx;
 /* SO3Reduction::getProducts, reduce.cu:1007-1090 */
+static int so3_row(const so3_ctx *c, int k, float row[4])
+{
+    const int cols = c->cols, rows = c->rows;
+    int y = k / cols, x = k - y * cols;
+    row[0] = row[1] = row[2] = row[3] = 0.f;
+    orc_f3 unwarped = {(float)x, (float)y, 1.0f};
+    orc_f3 warped = orc_m33_mul(&c->B, unwarped);
+    int wx = orc_f2i_rn(warped.x / warped.z), wy = orc_f2i_rn(warped.y / warped.z);
+    if (!(wx >= 1 && wx < cols - 1 && wy >= 1 && wy < rows - 1 && x >= 1 && x < cols - 1 && y >= 1 && y < rows - 1)) return 0;
+    float gnx, gny, glx, gly;
+    so3_gradient(c->next_image, cols, wx, wy, &gnx, &gny);
+    so3_gradient(c->last_image, cols, x, y, &glx, &gly);
+    float gx = (gnx + glx) / 2.0f, gy = (gny + gly) / 2.0f;
+    orc_f3 point = orc_m33_mul(&c->Ki, unwarped);
+    float z2 = point.z * point.z;
+    const float *krlr = c->krlr;
+    float a = krlr[0], b = krlr[1], cc = krlr[2], d = krlr[3], e = krlr[4], f = krlr[5], g = krlr[6], h = krlr[7], i = krlr[8];
+    orc_f3 left = {((point.z * (d * gy + a * gx)) - (gy * g * y) - (gx * g * x)) / z2,
+                   ((point.z * (e * gy + b * gx)) - (gy * h * y) - (gx * h * x)) / z2,
+                   ((point.z * (f * gy + cc * gx)) - (gy * i * y) - (gx * i * x)) / z2};
+    orc_f3 jac = orc_f3_cross(left, point);
+    row[0] = jac.x; row[1] = jac.y; row[2] = jac.z;
+    row[3] = -((float)c->next_image[wy * cols + wx] - (float)c->last_image[y * cols + x]);
+    return 1;
+}
+
 void orc_so3_step(const uint8_t *last_image, const uint8_t *next_image, const float image_basis[9],
                   const float kinv[9], const float krlr[9], int cols, int rows, int64_t sums[ORC_SO3_WORDS])
 {
-    orc_m33 B, Ki; memcpy(B.m, image_basis, 36); memcpy(Ki.m, kinv, 36);
+    so3_ctx c = {last_image, next_image, {{0}}, {{0}}, krlr, cols, rows};
+    memcpy(c.B.m, image_basis, 36); memcpy(c.Ki.m, kinv, 36);
     memset(sums, 0, sizeof(int64_t) * ORC_SO3_WORDS);
     for (int k = 0; k < cols * rows; k++) {
-        int y = k / cols, x = k - y * cols;
-        orc_f3 unwarped = {(float)x, (float)y, 1.0f};
-        orc_f3 warped = orc_m33_mul(&B, unwarped);
-        int wx = orc_f2i_rn(warped.x / warped.z), wy = orc_f2i_rn(warped.y / warped.z);
-        if (!(wx >= 1 && wx < cols - 1 && wy >= 1 && wy < rows - 1 && x >= 1 && x < cols - 1 && y >= 1 && y < rows - 1)) continue;
-        float gnx, gny, glx, gly;
-        so3_gradient(next_image, cols, wx, wy, &gnx, &gny);
-        so3_gradient(last_image, cols, x, y, &glx, &gly);
-        float gx = (gnx + glx) / 2.0f, gy = (gny + gly) / 2.0f;
-        orc_f3 point = orc_m33_mul(&Ki, unwarped);
-        float z2 = point.z * point.z;
-        float a = krlr[0], b = krlr[1], c = krlr[2], d = krlr[3], e = krlr[4], f = krlr[5], g = krlr[6], h = krlr[7], i = krlr[8];
-        orc_f3 left = {((point.z * (d * gy + a * gx)) - (gy * g * y) - (gx * g * x)) / z2,
-                       ((point.z * (e * gy + b * gx)) - (gy * h * y) - (gx * h * x)) / z2,
-                       ((point.z * (f * gy + c * gx)) - (gy * i * y) - (gx * i * x)) / z2};
-        orc_f3 jac = orc_f3_cross(left, point);
-        float row[4] = {jac.x, jac.y, jac.z,
-                        -((float)next_image[wy * cols + wx] - (float)last_image[y * cols + x])};
+        float row[4];
+        if (!so3_row(&c, k, row)) continue;
         int s = 0;
         for (int p = 0; p < 3; p++)
             for (int q = p; q < 4; q++) sums[s++] += orc_fix_prod(row[p], row[q], ORC_FIX_SO3);
         sums[9] += orc_fix_prod(row[3], row[3], ORC_FIX_SO3);
         sums[10] += 1;
     }
+}
+
+static void so3_vals(const void *ctx, int k, float v[29])
+{
+    float row[4];
+    int found = so3_row((const so3_ctx *)ctx, k, row);
+    int s = 0;
+    for (int p = 0; p < 3; p++)
+        for (int q = p; q < 4; q++) v[s++] = row[p] * row[q];
+    v[9] = row[3] * row[3];
+    v[10] = (float)found;
+}
+/* the same sums in the reference's f32 order (so3Kernel<<<blocks, threads>>> + reduceSum, reduce.cu:1092-1156) */
+void orc_so3_step_f32tree(const uint8_t *last_image, const uint8_t *next_image, const float image_basis[9], const float kinv[9],
+                          const float krlr[9], int cols, int rows, int threads, int blocks, float out11[11])
+{
+    so3_ctx c = {last_image, next_image, {{0}}, {{0}}, krlr, cols, rows};
+    memcpy(c.B.m, image_basis, 36); memcpy(c.Ki.m, kinv, 36);
+    f32tree_reduce(so3_vals, &c, cols * rows, 11, threads, blocks, out11);
 }
 
 void orc_so3_sums_to_host(const int64_t sums[ORC_SO3_WORDS], int F, float A[9], float b[3], float residual[2])
@@ -771,7 +851,7 @@ void orc_odom_get_incremental_transformation(orc_odometry *o, float trans[3], fl
                 int64_t sums[ORC_SE3_WORDS]; float dummy[2];
                 orc_rgb_step(o->corres[i], sigmaVal, o->cloud[i], il.fx, il.fy, o->dIdx[i], o->dIdy[i], o->sobelScale,
                              cols, rows, sums);
-                orc_se3_sums_to_host(sums, ORC_FIX_RGB, A_rgbd, b_rgbd, dummy);
+                orc_se3_sums_to_host(sums, orc_rgb_fix_bits(sigmaVal), A_rgbd, b_rgbd, dummy);
             }
             double lastA[36], lastb[6], result[6];
             if (icp && rgb) {

@@ -216,6 +216,11 @@ def project_cloud(depth, cam_level):
     return out
 
 
+def rgb_fix_bits(sigma):
+    """fraction bits of the RGB step's fixed-point sums for this sigma (oracle/orc_math.h orc_rgb_fix_bits)."""
+    return int(lib.orc_rgb_fix_bits_of(C.c_float(sigma)))
+
+
 def se3_to_host(sums, F=32):
     A = np.zeros(36, np.float32); b = np.zeros(6, np.float32); r = np.zeros(2, np.float32)
     lib.orc_se3_sums_to_host(P(np.ascontiguousarray(sums, np.int64)), F, P(A), P(b), P(r))
@@ -272,3 +277,45 @@ def so3_step(last_image, next_image, basis, kinv, krlr):
     lib.orc_so3_step(P(u8(last_image)), P(u8(next_image)), P(f32(basis).reshape(9)), P(f32(kinv).reshape(9)),
                      P(f32(krlr).reshape(9)), w, h, P(sums))
     return sums
+
+
+def _se3_from29(v):
+    """JtJJtrSE3's 29 floats -> A, b, residual the way icpStep / rgbStep unpack them (reduce.cu:481-498)."""
+    A = np.zeros((6, 6), np.float32); b = np.zeros(6, np.float32); k = 0
+    for i in range(6):
+        for j in range(i, 7):
+            if j == 6:
+                b[i] = v[k]
+            else:
+                A[i, j] = A[j, i] = v[k]
+            k += 1
+    return A, b, np.array(v[27:29], np.float32)
+
+
+def icp_step_ref_order(*a, threads=128, blocks=112):
+    return _se3_from29(icp_step_f32tree(*a, threads, blocks))
+
+
+def rgb_step_ref_order(corres, sigma, cloud, fx, fy, dIdx, dIdy, sobel_scale, threads=128, blocks=112):
+    h, w = dIdx.shape
+    out = np.zeros(29, np.float32)
+    lib.orc_rgb_step_f32tree(P(corres), C.c_float(sigma), P(f32(cloud)), C.c_float(fx), C.c_float(fy),
+                             P(np.ascontiguousarray(dIdx, np.int16)), P(np.ascontiguousarray(dIdy, np.int16)),
+                             C.c_float(sobel_scale), w, h, threads, blocks, P(out))
+    return _se3_from29(out)[:2]
+
+
+def so3_step_ref_order(last_image, next_image, basis, kinv, krlr, threads=160, blocks=64):
+    h, w = next_image.shape
+    out = np.zeros(11, np.float32)
+    lib.orc_so3_step_f32tree(P(u8(last_image)), P(u8(next_image)), P(f32(basis).reshape(9)), P(f32(kinv).reshape(9)),
+                             P(f32(krlr).reshape(9)), w, h, threads, blocks, P(out))
+    A = np.zeros((3, 3), np.float32); b = np.zeros(3, np.float32); k = 0
+    for i in range(3):
+        for j in range(i, 4):
+            if j == 3:
+                b[i] = out[k]
+            else:
+                A[i, j] = A[j, i] = out[k]
+            k += 1
+    return A, b, out[9:11].copy()

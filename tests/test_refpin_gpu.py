@@ -1,0 +1,129 @@
+"""GPU: the HIP path (through the C-ABI) against the REFERENCE'S OWN kernels' outputs (tests/golden/ref_v1.npz, generated from
+/root/reference by tests/golden/make_ref_golden.py).  Same bars as tests/test_cpu_refpin.py: per-pixel and integer results
+bit-exact, exact fixed-point sums within f32 rounding of the reference's summation tree."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import refpin
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_v1.npz")
+DATATERM = np.dtype([("zero_x", "<i2"), ("zero_y", "<i2"), ("one_x", "<i2"), ("one_y", "<i2"), ("diff", "<f4"), ("valid", "<i4")])
+
+
+class Hip:
+    """tests/orc.py's function names over co_fusion_amd.api.Context, numpy in / numpy out."""
+    __name__ = "hip"
+
+    def __init__(self):
+        from co_fusion_amd import api
+        self.api = api
+        self.ctx = api.Context(refpin.W, refpin.H, refpin.FX, refpin.FY, refpin.CX, refpin.CY)
+        self.d = self.ctx.to_device
+
+    def Cam(self, fx, fy, cx, cy):
+        return self.api.Cam(fx, fy, cx, cy)
+
+    @staticmethod
+    def _h(t):
+        return t.cpu().numpy()
+
+    def pyrdown_gauss_f32(self, a): return self._h(self.ctx.pyrdown_gauss_f32(self.d(a)))
+    def pyrdown_gauss_u8(self, a): return self._h(self.ctx.pyrdown_gauss_u8(self.d(a)))
+    def create_vmap(self, dep, cam, cutoff): return self._h(self.ctx.create_vmap(self.d(dep), cam, cutoff))
+    def create_nmap(self, v): return self._h(self.ctx.create_nmap(self.d(v)))
+    def resize_map(self, m, normalize): return self._h(self.ctx.resize_map(self.d(m), normalize))
+    def vertices_to_depth(self, v4, cutoff): return self._h(self.ctx.vertices_to_depth(self.d(v4), cutoff))
+    def rgba_to_intensity(self, rgba): return self._h(self.ctx.rgba_to_intensity(self.d(rgba)))
+    def project_cloud(self, dep, cam_level): return self._h(self.ctx.project_cloud(self.d(dep), cam_level))
+
+    def copy_maps(self, v4, n4):
+        v, n = self.ctx.copy_maps(self.d(v4), self.d(n4))
+        return self._h(v), self._h(n)
+
+    def transform_maps(self, v, n, R, t):
+        dv, dn = self.d(v), self.d(n)
+        self.ctx.transform_maps(dv, dn, R, t)
+        return self._h(dv), self._h(dn)
+
+    def sobel(self, img):
+        dx, dy = self.ctx.sobel(self.d(img))
+        return self._h(dx), self._h(dy)
+
+    def icp_step(self, Rc, tc, vc, nc, Rpi, tp, cam, vp, np_, dist, angle, want_err=False):
+        err = self.ctx.empty((vc.shape[0] // 3, vc.shape[1]))
+        A, b, res, sums = self.ctx.icp_step(Rc, tc, self.d(vc), self.d(nc), Rpi, tp, cam, self.d(vp), self.d(np_), dist, angle,
+                                            err_surface=err)
+        self._last = (A, b, res)
+        return sums, self._h(err)
+
+    def se3_to_host(self, sums, F=32):
+        return self._last  # unpacked on the device side of the C-ABI
+
+    def rgb_fix_bits(self, sigma):
+        return 0
+
+    def icp_step_ref_order(self, *a):
+        return self._last
+
+    def rgb_residual(self, min_scale, dx, dy, ld, nd, li, ni, max_dd, kt, krkinv):
+        cor, sig, cnt = self.ctx.rgb_residual(min_scale, self.d(dx), self.d(dy), self.d(ld), self.d(nd), self.d(li), self.d(ni), max_dd,
+                                              kt, krkinv)
+        self._cor = cor
+        return self._h(cor).view(DATATERM).reshape(-1), sig, cnt
+
+    def rgb_step(self, cor, sigma, cloud, fx, fy, dx, dy, sobel_scale):
+        A, b, sums = self.ctx.rgb_step(self._cor, sigma, self.d(cloud), fx, fy, self.d(dx), self.d(dy), sobel_scale)
+        self._last = (A, b, None)
+        return sums
+
+    def rgb_step_ref_order(self, *a):
+        return self._last[:2]
+
+    def so3_step(self, last, nxt, basis, kinv, krlr):
+        A, b, res, sums = self.ctx.so3_step(self.d(last), self.d(nxt), basis, kinv, krlr)
+        self._so3 = (A, b, res)
+        return sums
+
+    def so3_to_host(self, sums):
+        return self._so3
+
+    def so3_step_ref_order(self, *a):
+        return self._so3
+
+
+def _planar_valid_only(m):
+    """y/z planes are undefined where x is NaN (the reference writes the x plane only there)."""
+    m = m.copy()
+    h = m.shape[0] // 3
+    bad = np.isnan(m[:h])
+    m[h:2 * h][bad] = 0; m[2 * h:][bad] = 0
+    return m
+
+
+PLANAR = ("vmap", "nmap", "copy_", "resize_", "model_v", "model_n")
+
+
+def test_hip_matches_reference_kernels():
+    z = np.load(GOLDEN)
+    inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    want = {k[4:]: z[k] for k in z.files if k.startswith("ref_")}
+    hip = Hip()
+    try:
+        got = refpin.run(hip, inp, hip.Cam)
+    finally:
+        hip.ctx.close()
+    for name, w in want.items():
+        g = np.asarray(got[name])
+        if refpin.is_reduction(name):
+            assert refpin.sums_close(g, w), f"{name}: exact sums vs the reference's f32 tree: {np.abs(g - w).max()}"
+        elif name.startswith(("icp_res", "so3_res")):
+            assert g[1] == w[1] and refpin.sums_close(g[:1], w[:1]), name
+        elif name.startswith(PLANAR):
+            assert refpin.bits_equal(_planar_valid_only(g), _planar_valid_only(w)), f"{name}: differs from the reference kernel's output"
+        else:
+            assert refpin.bits_equal(g.astype(w.dtype) if g.dtype != w.dtype and g.dtype.kind != "f" else g, w), \
+                f"{name}: differs from the reference kernel's output"

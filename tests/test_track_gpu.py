@@ -143,7 +143,7 @@ def test_rgb_and_so3_steps_exact(ctx):
             osums = orc.rgb_step(ocor, sigma, cloud, 528.0 / (1 << lvl), 528.0 / (1 << lvl), dx, dy, 0.125)
             A, b, sums = ctx.rgb_step(cor, sigma, d(cloud), 528.0 / (1 << lvl), 528.0 / (1 << lvl), ddx, ddy, 0.125)
             _eq(sums[:29], osums[:29], f"RGB sums L{lvl} sigma={sigma}")
-            oA, ob, _ = orc.se3_to_host(osums)
+            oA, ob, _ = orc.se3_to_host(osums, orc.rgb_fix_bits(sigma))
             _eq(A, oA, "A rgb"); _eq(b, ob, "b rgb")
     # SO3 at level 2
     last2, next2 = od2.buffer(8, 2), od2.buffer(7, 2)
