@@ -30,6 +30,41 @@ def rewrite(text: str, fibers: bool) -> str:
     return "\n".join(out)
 
 
+SHADERS = os.path.join(REF, "Core", "Shaders")
+# the surfel passes of the hot path; geometry shaders are pass-through filters restated in ref_gl.cpp
+SHADER_FILES = ["data.vert", "update.vert", "copy_unstable.vert", "index_map.vert", "index_map.frag", "splat.vert",
+                "combo_splat.frag", "vertex_feedback.vert", "init_unstable.vert", "fill_vertex.frag", "fill_normal.frag",
+                "fill_rgb.frag", "depth_bilateral_metric.frag", "data.frag"]
+FLOAT_LIT = re.compile(r"(?<![\w.])((?:\d+\.\d*|\.\d+)(?:[eE][-+]?\d+)?|\d+[eE][-+]?\d+)(?![\w.])")
+
+
+def glsl_to_cpp(name: str) -> str:
+    """Purely syntactic GLSL -> C++ rewrite of one shader: inline #include, drop #version / layout(...), turn the in / out / uniform
+    interface into namespace-scope variables, suffix float literals with f (a GLSL 1.0 is a 32-bit float), rename main."""
+    def load(fn):
+        out = []
+        for line in open(os.path.join(SHADERS, fn)).read().split("\n"):
+            m = re.match(r'\s*#include\s+"([^"]+)"', line)
+            if m:
+                out.append(load(m.group(1)))
+            elif not line.lstrip().startswith("#version"):
+                out.append(line)
+        return "\n".join(out)
+    src = load(name)
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    lines = []
+    for line in src.split("\n"):
+        code, _, comment = line.partition("//")
+        code = re.sub(r"layout\s*\([^)]*\)\s*", "", code)
+        code = re.sub(r"^(\s*)(?:flat\s+)?(?:in|out|uniform)\s+", r"\1", code)
+        code = FLOAT_LIT.sub(lambda m: m.group(1) + "f", code)
+        code = re.sub(r"\bvoid\s+main\s*\(\s*\)", "void shader_main()", code)
+        code = re.sub(r"\bdiscard\s*;", "{ gl_Discarded = true; return; }", code)
+        lines.append(code)
+    ns = "sh_" + name.replace(".", "_")
+    return f"namespace glsl {{ namespace {ns} {{\n" + "\n".join(lines) + f"\n}} }}  // namespace glsl::{ns}\n"
+
+
 def main() -> int:
     if not os.path.isdir(CUDA):
         print(f"build_ref: {CUDA} not present, keeping any prebuilt oracle/_ref", file=sys.stderr)
@@ -52,7 +87,16 @@ def main() -> int:
             obj = os.path.join(tmp, os.path.basename(path) + ".o")
             subprocess.check_call(["g++", *flags, "-include", "cusim.h", "-c", path, "-o", obj])
             objs.append(obj)
-        subprocess.check_call(["g++", "-shared", "-o", os.path.join(OUT, "libcofusion_ref.so"), *objs])
+        # surfel shaders + their harness in one translation unit
+        gen = os.path.join(tmp, "gl_all.cpp")
+        with open(gen, "w") as f:
+            f.write('#include "glsl.h"\n' + "".join(glsl_to_cpp(n) for n in SHADER_FILES) + f'#include "{os.path.join(HERE, "ref_gl.cpp")}"\n')
+        obj = os.path.join(tmp, "gl_all.o")
+        subprocess.check_call(["g++", *flags, "-I", os.path.dirname(HERE), "-c", gen, "-o", obj])
+        objs.append(obj)
+        orc_dir = os.path.join(os.path.dirname(HERE), "_build")  # orc_inverse_pose (host-side pose inverse) comes from the oracle
+        subprocess.check_call(["g++", "-shared", "-o", os.path.join(OUT, "libcofusion_ref.so"), *objs, "-L", orc_dir, "-lorc",
+                               "-Wl,-rpath,$ORIGIN/../_build"])
     print(os.path.join(OUT, "libcofusion_ref.so"))
     return 0
 

@@ -176,3 +176,31 @@ def so3_step(last_image, next_image, basis, kinv, krlr, launch=SO3_LAUNCH):
     lib().ref_so3_step(P(u8(last_image)), P(u8(next_image)), P(f32(basis).reshape(9)), P(f32(kinv).reshape(9)),
                        P(f32(krlr).reshape(9)), w, h, launch[0], launch[1], P(A), P(b), P(r))
     return A.reshape(3, 3), b, r
+
+
+# ---- surfel passes: the reference's own GLSL shaders (oracle/ref_shim/ref_gl.cpp harness) -------------------------------------
+class _SurfelAlias:
+    """looks like tests/orc.py's `lib` to tests/orc_pipeline.py, but resolves orc_X to ref_X in the reference library
+    (orc_inverse_pose / orc_fusion_weight / orc_requires_fill_in are host code in the reference, not shaders: they stay oracle)."""
+    HOST = ("orc_inverse_pose", "orc_fusion_weight", "orc_requires_fill_in")
+
+    def __getattr__(self, name):
+        import orc
+        if name in self.HOST:
+            return getattr(orc.lib, name)
+        return getattr(lib(), name.replace("orc_", "ref_", 1))
+
+
+class surfel_passes:
+    """context manager: inside it the functions of tests/orc_pipeline.py run the reference's shaders instead of the oracle."""
+
+    def __enter__(self):
+        import orc_pipeline
+        self._mod = orc_pipeline
+        self._saved = orc_pipeline.lib
+        orc_pipeline.lib = _SurfelAlias()
+        return orc_pipeline
+
+    def __exit__(self, *exc):
+        self._mod.lib = self._saved
+        return False

@@ -159,3 +159,113 @@ SUM_RTOL = 2e-5
 def sums_close(a, b) -> bool:
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return bool(np.abs(a - b).max() <= SUM_RTOL * max(np.abs(b).max(), 1e-30))
+
+
+# =====================================================================================================================
+# surfel passes: one scripted three-frame scenario, run by three back ends
+#   * the reference's own GLSL shaders (tests/ref.py surfel_passes -> oracle/_ref)        -> tests/golden/ref_surfel_v1.npz
+#   * the CPU oracle (tests/orc_pipeline.py)                                             -> tests/test_cpu_refpin.py
+#   * the HIP path through the C-ABI (co_fusion_amd.model.Model)                         -> tests/test_refpin_gpu.py
+# =====================================================================================================================
+import hashlib
+
+SW, SH = 160, 120
+MAX_DEPTH, DEPTH_FILTER_CUTOFF, TIME_DELTA = 20.0, 5.0, 200
+CONF_SPLAT, CONF_CLEAN, OUTLIER_COEFF = 0.0, 0.9, 3.0
+
+
+def digest(a) -> np.ndarray:
+    a = np.ascontiguousarray(a)
+    if a.dtype.kind == "f":
+        a = np.where(np.isnan(a), np.float32(np.nan), a).astype(a.dtype)  # one NaN encoding
+    return np.frombuffer(hashlib.sha256(a.tobytes()).digest(), np.uint8).copy()
+
+
+def surfel_inputs():
+    import common
+    from co_fusion_amd import synth
+    cam = synth.Camera.scaled(SW, SH)
+    sc = synth.Scene(n_obj=1)
+    out = dict(cam=np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32))
+    for k, t in enumerate((0, 2, 4)):
+        d, rgb, _, _ = sc.render(cam, t, noise=True)
+        d = d.astype(np.float32)
+        if k == 1:
+            d[10:20, 30:60] = 0.0  # holes
+            d[100, 100] = 7.0      # beyond the filter cutoff
+        out[f"d{k}"] = d; out[f"rgba{k}"] = synth.rgb_to_rgba(rgb)
+    mask = np.zeros((SH, SW), np.uint8); mask[:, SW // 2:] = 1
+    out["mask"] = mask
+    out["pose1"] = common.perturbed_pose(4, 0.003, 0.2).astype(np.float32)
+    out["pose2"] = (common.perturbed_pose(6, 0.004, 0.3) @ common.perturbed_pose(4, 0.003, 0.2)).astype(np.float32)
+    return out
+
+
+class CpuSurfelBackend:
+    """tests/orc_pipeline.py functions (oracle, or the reference's shaders inside ref.surfel_passes())."""
+
+    def __init__(self, op, cam):
+        import orc
+        self.op = op; self.cam = orc.Cam(*[float(v) for v in cam]); self.surfels = None
+
+    def bilateral(self, d): return self.op.bilateral(d, DEPTH_FILTER_CUTOFF)
+
+    def bootstrap(self, rgba, d, df):
+        raw, n = self.op.vertex_feedback(rgba, d, self.cam, 1, MAX_DEPTH)
+        filt, _ = self.op.vertex_feedback(rgba, df, self.cam, 1, MAX_DEPTH)
+        self.surfels = self.op.model_initialise(raw, n, filt)
+
+    def map(self): return self.surfels
+
+    def predict_indices(self, pose, time):
+        self.idx = self.op.predict_indices(self.surfels, pose, self.cam, SW, SH, MAX_DEPTH, time, TIME_DELTA)
+        return self.idx
+
+    def combined_predict(self, pose, time):
+        self.pred = self.op.combined_predict(self.surfels, pose, self.cam, SW, SH, MAX_DEPTH, CONF_SPLAT, time, time, TIME_DELTA)
+        return self.pred
+
+    def fill_in(self, rgba, df, pg, pr):
+        img, vc, nr, _ = self.pred
+        return self.op.fill_in(vc, nr, img, df, rgba, self.cam, pg, pr)
+
+    def fuse(self, pose, time, rgba, mask, d, df, weighting, mask_id):
+        idx, vc, ct, nr = self.idx
+        self.surfels, self.new = self.op.fuse(self.surfels, idx, vc, nr, rgba, d, df, mask, pose, self.cam, time, weighting, mask_id, MAX_DEPTH)
+        return np.concatenate([self.surfels, self.new])
+
+    def clean(self, pose, time, df, mask, mask_id):
+        idx, vc, ct, nr = self.idx
+        self.surfels = self.op.clean(self.surfels, self.new, idx, vc, ct, df, mask, pose, self.cam, time, CONF_CLEAN, OUTLIER_COEFF,
+                                     TIME_DELTA, mask_id)
+        return self.surfels
+
+
+def surfel_run(be, inp):
+    """the scenario; returns {name: array} (every array is a pinned output)"""
+    out = {}
+    df = [be.bilateral(inp[f"d{k}"]) for k in range(3)]
+    for k in range(3):
+        out[f"bilateral{k}"] = df[k]
+    be.bootstrap(inp["rgba0"], inp["d0"], df[0])
+    out["bootstrap_map"] = be.map()
+    for tick, k, pose, mask_id, w in ((2, 1, inp["pose1"], 0, 0.8), (3, 2, inp["pose2"], 1, 1.0)):
+        rgba, d = inp[f"rgba{k}"], inp[f"d{k}"]
+        for name, a in zip(("image", "vertexConf", "normalRad", "time"), be.combined_predict(pose, tick)):
+            out[f"t{tick}_splat_{name}"] = a
+        for pg, pr in ((False, False), (True, True)):
+            for name, a in zip(("vertex", "normal", "image"), be.fill_in(rgba, df[k], pg, pr)):
+                out[f"t{tick}_fill{int(pg)}_{name}"] = a
+        for name, a in zip(("index", "vertConf", "colorTime", "normRad"), be.predict_indices(pose, tick)):
+            out[f"t{tick}_index_{name}"] = a
+        out[f"t{tick}_fuse_map"] = be.fuse(pose, tick, rgba, inp["mask"], d, df[k], w, mask_id)
+        be.predict_indices(pose, tick)
+        out[f"t{tick}_clean_map"] = be.clean(pose, tick, df[k], inp["mask"], mask_id)
+    return out
+
+
+def surfel_summary(out):
+    """small integers that make a degenerate scenario visible in the fixture"""
+    return np.array([out["bootstrap_map"].shape[0], int((out["t2_index_index"] > 0).sum()), int((out["t2_splat_vertexConf"][..., 2] > 0).sum()),
+                     out["t2_fuse_map"].shape[0], int((out["t2_fuse_map"][:, 7] == 2).sum()), out["t2_clean_map"].shape[0],
+                     out["t3_fuse_map"].shape[0], int((out["t3_fuse_map"][:, 7] == 3).sum()), out["t3_clean_map"].shape[0]], np.int64)

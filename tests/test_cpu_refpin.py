@@ -72,3 +72,45 @@ def test_rgb_fixed_point_window_follows_sigma():
     assert orc.rgb_fix_bits(-1.0) == 8 and orc.rgb_fix_bits(1.0) == 8 and orc.rgb_fix_bits(0.0) == 8
     assert orc.rgb_fix_bits(2.0) == 10 and orc.rgb_fix_bits(255.0) == 22 and orc.rgb_fix_bits(256.0) == 24
     assert orc.rgb_fix_bits(4095.0) == 30 and orc.rgb_fix_bits(4096.0) == 32 and orc.rgb_fix_bits(3.0e5) == 32
+
+
+# ---- surfel passes: oracle vs the reference's own GLSL shaders ---------------------------------------------------------------
+SURFEL_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_surfel_v1.npz")
+
+
+def _surfel_golden():
+    z = np.load(SURFEL_GOLDEN)
+    inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    sha = {k[4:]: z[k] for k in z.files if k.startswith("sha_")}
+    shape = {k[6:]: tuple(z[k]) for k in z.files if k.startswith("shape_")}
+    return inp, sha, shape, z["summary"]
+
+
+def test_oracle_surfel_passes_match_reference_shaders():
+    """bilateral, bootstrap, index map, splat prediction, fill-in, fuse, clean over three frames: every output array of the oracle
+    has the sha256 of what the reference's shader sources produced (bit-exact)."""
+    import orc_pipeline as op
+    inp, sha, shape, summary = _surfel_golden()
+    assert summary[4] > 1000 and summary[7] > 1000, "the merge path must be exercised"
+    assert summary[2] > 0.5 * refpin.SW * refpin.SH and summary[1] > 0.5 * refpin.SW * refpin.SH
+    got = refpin.surfel_run(refpin.CpuSurfelBackend(op, inp["cam"]), inp)
+    assert set(got) == set(sha) and len(sha) >= 36
+    assert np.array_equal(refpin.surfel_summary(got), summary)
+    for name, a in got.items():
+        assert tuple(np.asarray(a).shape) == shape[name], f"{name}: shape {np.asarray(a).shape} vs reference {shape[name]}"
+        assert np.array_equal(refpin.digest(a), sha[name]), f"{name}: differs from the reference shaders' output"
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_surfel_fixture_is_what_the_reference_shaders_produce():
+    import orc_pipeline as op
+    inp, sha, shape, summary = _surfel_golden()
+    with ref.surfel_passes() as rop:
+        want = refpin.surfel_run(refpin.CpuSurfelBackend(rop, inp["cam"]), inp)
+    got = refpin.surfel_run(refpin.CpuSurfelBackend(op, inp["cam"]), inp)
+    for name, w in want.items():
+        assert np.array_equal(refpin.digest(w), sha[name]), f"{name}: fixture is stale"
+        g = np.asarray(got[name]); w = np.asarray(w)
+        assert g.shape == w.shape, name
+        same = (g == w) | ((g != g) & (w != w)) if g.dtype.kind == "f" else (g == w)
+        assert same.all(), f"{name}: {np.count_nonzero(~same)} of {same.size} values differ from the reference shaders"
