@@ -6,12 +6,17 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
  * and only as the checker / the timed CPU baseline.
  *
- * PARITY UNPINNED: the reference (martinruenz/co-fusion) ships no tests, golden
- * vectors or fixtures and cannot be built in this
- * environment (needs CUDA, OpenGL/Pangolin, Eigen, OpenCV, gSLICr, densecrf).
- * This oracle is therefore a from-scratch restatement of the reference
- * arithmetic, function by function, each citing the reference file:line it
- * follows.  tests/golden/ pins the oracle against itself (regression only).
+ * PARITY: the reference (martinruenz/co-fusion) ships no tests, golden vectors or
+ * fixtures and its build cannot run here.  This oracle is a
+ * from-scratch restatement of the reference arithmetic, function by function, each
+ * citing the reference file:line it follows.
+ *   PINNED   orc_track.c kernels and orc_surfel.c passes: against the reference's own
+ *            CUDA kernels / GLSL shaders compiled for the CPU (oracle/ref_shim ->
+ *            oracle/_ref; fixtures tests/golden/ref_v1.npz, ref_surfel_v1.npz;
+ *            tests/test_cpu_refpin.py).
+ *   UNPINNED orc_segment.c (gSLICr / densecrf are not in the tree) and the host
+ *            Gauss-Newton loop of orc_track.c (RGBDOdometry.cpp needs Eigen):
+ *            tests/golden/oracle_v1.npz pins those against themselves only.
  *
  * Data layouts (identical to the HIP C-ABI in include/cofusion_hip.h):
  *   depth            f32  [H*W] metres, 0 = invalid

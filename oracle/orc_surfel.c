@@ -1,6 +1,8 @@
 /*
  * orc_surfel.c -- CPU ORACLE for the surfel half of the hot path (projection, fusion, cleaning,
- * bootstrap, bilateral filter, fill-in).  TEST INFRASTRUCTURE ONLY (see orc.h).  PARITY UNPINNED.
+ * bootstrap, bilateral filter, fill-in).  TEST INFRASTRUCTURE ONLY (see orc.h).  PINNED bit-exactly against the reference's
+ * own shader sources compiled to C++ (oracle/ref_shim/ref_gl.cpp, tests/test_cpu_refpin.py); the fixed-function GL
+ * choices listed below are shared with that harness and remain this oracle's own.
  *
  * Restates the GLSL passes of the reference as plain loops:
  *   depth_bilateral_metric.frag                    -> orc_bilateral

@@ -1,6 +1,7 @@
 /*
  * orc_track.c -- CPU ORACLE for the dense tracking half of the hot path.
- * TEST INFRASTRUCTURE ONLY (see orc.h).  PARITY UNPINNED (no reference vectors exist).
+ * TEST INFRASTRUCTURE ONLY (see orc.h).  Kernels PINNED against the reference's own reduce.cu / cudafuncs.cu run on the CPU
+ * (oracle/ref_shim, tests/test_cpu_refpin.py); the host Gauss-Newton loop is UNPINNED (RGBDOdometry.cpp needs Eigen).
  *
  * Restates, function by function:
  *   Core/Cuda/cudafuncs.cu   map preparation kernels

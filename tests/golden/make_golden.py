@@ -1,7 +1,8 @@
 """Generates tests/golden/oracle_v1.npz from the CPU oracle on seeded synthetic inputs.
 
-PARITY UNPINNED: the reference ships no golden vectors and cannot be built here, so these fixtures pin the
-ORACLE against itself (regression protection for the checker), not against the reference.  Large arrays are
+These fixtures pin the ORACLE against itself (regression protection for the checker, incl. the parts that stay unpinned:
+segmentation and the host GN loop).  The pins against the reference's own kernels / shaders are ref_v1.npz and
+ref_surfel_v1.npz (make_ref_golden.py, make_ref_surfel_golden.py).  Large arrays are
 stored as sha256 digests, small ones verbatim.  Run from the repo root:  python tests/golden/make_golden.py
 """
 import hashlib
