@@ -156,6 +156,7 @@ typedef struct {
     float avgConfidence, depthMean, depthStd;
     int top, right, bottom, left;
 } orc_seg_model;
+int orc_connected_labels(const uint8_t *in, int cols, int rows, int *comp, int *stats6, int max_stats);
 void orc_slic(const uint8_t *rgba, int cols, int rows, int32_t *labels);
 void orc_crf_meanfield(const float *unary, int L, int n, const float *feat_smooth, const float *feat_app, float w_smooth,
                        float w_app, int iterations, float *Q);

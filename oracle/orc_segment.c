@@ -163,6 +163,19 @@ static int connected_labels(const uint8_t *in, int cols, int rows, int *comp, co
 #undef FINDROOT
 }
 
+/* public view of connected_labels for the reference pin (tests/test_cpu_refpin.py): stats rows {label, top, right, bottom, left, size} */
+int orc_connected_labels(const uint8_t *in, int cols, int rows, int *comp, int *stats6, int max_stats)
+{
+    comp_data *st = NULL;
+    const int n = connected_labels(in, cols, rows, comp, &st);
+    for (int i = 0; i < n && i < max_stats; i++) {
+        int *o = stats6 + (size_t)i * 6;
+        o[0] = st[i].label; o[1] = st[i].top; o[2] = st[i].right; o[3] = st[i].bottom; o[4] = st[i].left; o[5] = st[i].size;
+    }
+    free(st);
+    return n;
+}
+
 /* ------------------------------------------------------------------- dense CRF ---- */
 /* expAndNormalize: column-wise softmax with max subtraction */
 static void exp_and_normalize(const float *in, float *out, int L, int n)

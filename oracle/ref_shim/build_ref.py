@@ -94,6 +94,10 @@ def main() -> int:
         obj = os.path.join(tmp, "gl_all.o")
         subprocess.check_call(["g++", *flags, "-I", os.path.dirname(HERE), "-c", gen, "-o", obj])
         objs.append(obj)
+        # the header-only connected-components pass of the segmentation stage (cv::Mat stand-in: include/opencv2/)
+        obj = os.path.join(tmp, "ref_cc.o")
+        subprocess.check_call(["g++", *flags, "-I", os.path.join(REF, "Core"), "-c", os.path.join(HERE, "ref_cc.cpp"), "-o", obj])
+        objs.append(obj)
         orc_dir = os.path.join(os.path.dirname(HERE), "_build")  # orc_inverse_pose (host-side pose inverse) comes from the oracle
         subprocess.check_call(["g++", "-shared", "-o", os.path.join(OUT, "libcofusion_ref.so"), *objs, "-L", orc_dir, "-lorc",
                                "-Wl,-rpath,$ORIGIN/../_build"])

@@ -114,3 +114,28 @@ def test_surfel_fixture_is_what_the_reference_shaders_produce():
         assert g.shape == w.shape, name
         same = (g == w) | ((g != g) & (w != w)) if g.dtype.kind == "f" else (g == w)
         assert same.all(), f"{name}: {np.count_nonzero(~same)} of {same.size} values differ from the reference shaders"
+
+
+# ---- connected components of the segmentation post-processing: the reference's header compiled as is ------------------------
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_connected_labels_match_reference_header():
+    """Core/Segmentation/ConnectedLabels.hpp (header-only, compiled against a cv::Mat stand-in) vs oracle/orc_segment.c:
+    component image and {label, bbox, size} per component identical, on label images from blobby to salt-and-pepper."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    cases = []
+    for (h, w, nlab, smooth) in ((30, 40, 3, 4), (30, 40, 5, 1), (48, 64, 2, 8), (7, 5, 4, 1), (1, 9, 3, 1), (9, 1, 2, 1), (30, 40, 1, 1)):
+        a = rng.integers(0, nlab, size=((h + smooth - 1) // smooth, (w + smooth - 1) // smooth), dtype=np.uint8)
+        a = np.kron(a, np.ones((smooth, smooth), np.uint8))[:h, :w]
+        a[rng.random(a.shape) < 0.05] = 255  # the "rejected" label
+        cases.append(np.ascontiguousarray(a))
+    for a in cases:
+        h, w = a.shape
+        res = []
+        for fn in (orc.lib.orc_connected_labels, ref.lib().ref_connected_labels):
+            comp = np.zeros((h, w), np.int32); st = np.zeros((h * w, 6), np.int32)
+            n = fn(a.ctypes.data_as(C.c_void_p), w, h, comp.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), h * w)
+            res.append((n, comp, st[:n].copy()))
+        assert res[0][0] == res[1][0], f"{h}x{w}: component count"
+        assert np.array_equal(res[0][1], res[1][1]), f"{h}x{w}: component image"
+        assert np.array_equal(res[0][2], res[1][2]), f"{h}x{w}: component statistics"
