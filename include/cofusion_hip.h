@@ -16,7 +16,8 @@
  *   planar map      f32  [3*H*W]: x rows, y rows, z rows      (DeviceArray2D<float>(3*rows, cols))
  *   pose            f32[16] ROW-major T(model <- camera)      (Eigen::Matrix4f in the reference)
  *   SE3 sums        int64[32]: 27 upper-triangular products row_i*row_j (i<6, i<=j<7) in
- *                   Q31.32 fixed point, [27] = sum r^2 (Q31.32), [28] = inlier count
+ *                   Q31.32 fixed point, [27] = sum r^2 (Q31.32), [28] = inlier count.  The RGB step's sums use
+ *                   CF_FIX_RGB fraction bits, which follow its sigma argument (see the define below)
  *   surfel          12 f32 (48 B): [x y z conf][colour24 0 initTime lastTime][nx ny nz radius]
  *                   (Core/Shaders/Vertex.cpp:21-43)
  */
@@ -133,7 +134,8 @@ int cf_rgb_residual(cf_ctx *ctx, float min_scale, const int16_t *dIdx, const int
                     const float *next_depth, const uint8_t *last_image, const uint8_t *next_image,
                     cf_dataterm *corres, float max_depth_delta, const float kt[3], const float krkinv[9],
                     int cols, int rows, int *sigma_sum_host, int *count_host);
-/* rgbStep cudafuncs.cuh:84-97 */
+/* rgbStep cudafuncs.cuh:84-97.  sigma: the correspondence count (RGBDOdometry.cpp:373-374), 1 or -1 (rgbOnly);
+ * sums_host are fixed point with 8 + 2*floor(log2 sigma) fraction bits (max 32; 8 for sigma -1 or < 2) */
 int cf_rgb_step(cf_ctx *ctx, const cf_dataterm *corres, float sigma, const float *cloud3, float fx, float fy,
                 const int16_t *dIdx, const int16_t *dIdy, float sobel_scale, int cols, int rows, float *A_host,
                 float *b_host, int64_t *sums_host);
