@@ -140,3 +140,17 @@ def test_gt_mask_segmentation_branch():
     assert abs(r["modelData"][0]["depthMean"] - 2.0) < 1e-6 and abs(r["modelData"][1]["depthMean"] - 1.0) < 1e-6
     r2 = om.segment_gt(gt, d, [0, 1], 2, True, mapping)   # label already mapped: no second spawn
     assert not r2["hasNewLabel"] and len(r2["modelData"]) == 2
+
+
+def test_rgb_only_tracking_moves_towards_the_known_motion():
+    """rgbOnly hands sigma = -1 (unit weights) to rgbStep: rows are ~count times larger than in the weighted mode.  With the
+    sigma-dependent fixed-point window the photometric-only step is finite and reduces the pose error (it wrapped before)."""
+    W, H = 320, 240
+    fp = common.frame_pair(W, H, noise=False, t0=0, t1=2)
+    pose = np.eye(4, dtype=np.float32)
+    od = _tracker(fp, W, H, fp["cam"], pose)
+    tr, rot, st = od.track(pose[:3, 3], pose[:3, :3], rgb_only=True)
+    T1 = fp["T1"]
+    assert np.isfinite(tr).all() and np.isfinite(rot).all() and st.last_rgb_count > 5000
+    assert np.linalg.norm(tr - T1[:3, 3]) < np.linalg.norm(T1[:3, 3])
+    assert np.abs(rot - T1[:3, :3]).max() < np.abs(np.eye(3) - T1[:3, :3]).max()
