@@ -70,6 +70,7 @@ def main() -> int:
         print(f"build_ref: {CUDA} not present, keeping any prebuilt oracle/_ref", file=sys.stderr)
         return 0
     os.makedirs(OUT, exist_ok=True)
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(HERE)])  # liborc.so: the harness takes the host-side pose inverse from it
     flags = ["-O2", "-g0", "-std=c++14", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w",
              "-I", os.path.join(HERE, "include"), "-I", CUDA]
     objs = []
