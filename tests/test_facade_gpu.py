@@ -248,3 +248,35 @@ def test_segmentation_png_export(tmp_path):
             m[m > 254] = 0
             _same(img, m, f"frame {t}: exported mask")
     cf.close()
+
+
+def test_long_free_run_with_spawning_and_deactivation():
+    """50 frames at 160x128 with four moving objects: object models are spawned, deactivated (too few surfels / lost) and spawned
+    again.  Free running against the oracle: model list, ids, poses, counts, surfel buffers and label masks identical every frame."""
+    from co_fusion_amd import facade
+    w, h = 160, 128  # the segmentation works on 16x16 superpixels: sizes are multiples of 16
+    cam = synth.Camera.scaled(w, h)
+    sc = synth.Scene(n_obj=4)
+    ref = om.MultiPipeline(cam, conf_global=0.5, spawn_offset=2)
+    cf = facade.CoFusion(w, h, cam.fx, cam.fy, cam.cx, cam.cy, max_surfels=1 << 17, conf_global_init=0.5, model_spawn_offset=2,
+                         enable_multiple_models=1)
+    counts = []
+    for t in range(50):
+        d, rgb, _, _ = sc.render(cam, t, noise=True)
+        ref.process_frame(d, synth.rgb_to_rgba(rgb))
+        cf.process_frame(d, rgb, timestamp=t)
+        assert cf.num_models == len(ref.models), f"frame {t}: model count {cf.num_models} vs {len(ref.models)}"
+        counts.append(len(ref.models))
+        if t > 0:
+            _same(cf.mask(), ref.mask, f"frame {t}: label mask")
+        for i, m in enumerate(ref.models):
+            info = cf.model_info(i)
+            assert info["id"] == m.id, f"frame {t} model {i}: id"
+            assert info["count"] == m.surfels.shape[0], f"frame {t} model {i}: count {info['count']} vs {m.surfels.shape[0]}"
+            _same(info["pose"], m.pose, f"frame {t} model {i}: pose")
+            if t % 5 == 4 or i > 0:
+                _same(cf.model_download(i), m.surfels, f"frame {t} model {i}: surfels")
+    cf.close()
+    ups = sum(1 for a, b in zip(counts, counts[1:]) if b > a)
+    downs = sum(1 for a, b in zip(counts, counts[1:]) if b < a)
+    assert ups >= 2 and downs >= 2, f"spawn / deactivation not exercised: {counts}"
