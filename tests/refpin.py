@@ -16,11 +16,11 @@ MIN_GRAD = (5.0, 3.0, 1.0)
 SIGMAS = ("count", 1.0, -1.0)  # what rgbStep can be handed: the correspondence count, 1 (zero residual), -1 (rgbOnly)
 
 
-def inputs():
-    """Seeded inputs.  Returns a dict of arrays (stored verbatim in the fixture)."""
+def inputs(w=W, h=H):
+    """Seeded inputs.  Returns a dict of arrays (stored verbatim in the small fixture, as digests in the full-size one)."""
     import common
-    fp = common.frame_pair(W, H, noise=True)
-    clean = common.frame_pair(W, H, noise=False)
+    fp = common.frame_pair(w, h, noise=True)
+    clean = common.frame_pair(w, h, noise=False)
     # depth: the sensor model's drop-outs (zeros) + a tenth of its noise, so that most pixels stay ICP inliers at this resolution
     dn = fp["d1"].astype(np.float32); dc = clean["d1"].astype(np.float32)
     fp = dict(fp); fp["d1"] = np.where(dn > 0, dc + np.float32(0.1) * (dn - dc), 0).astype(np.float32)
@@ -29,7 +29,8 @@ def inputs():
     T2 = (common.perturbed_pose(7, 0.004, 0.3) @ pose).astype(np.float32)
     dT = common.perturbed_pose(11, 0.003, 0.2).astype(np.float32)
     Rr = common.perturbed_pose(5, 0.0, 0.4)[:3, :3].astype(np.float32)
-    return dict(d1=fp["d1"].astype(np.float32), rgba0=fp["rgba0"], rgba1=fp["rgba1"], v4=fp["v4"].astype(np.float32),
+    s = w / float(W)
+    return dict(cam=np.array([FX * s, FY * s, CX * s, CY * s], np.float32), d1=fp["d1"].astype(np.float32), rgba0=fp["rgba0"], rgba1=fp["rgba1"], v4=fp["v4"].astype(np.float32),
                 n4=fp["n4"].astype(np.float32), img=fp["img"], pose=pose.astype(np.float32), T2=T2, dT=dT, Rr=Rr)
 
 
@@ -37,7 +38,8 @@ def run(m, inp, cam_cls):
     """Run every pinned function of module `m` (tests/ref.py = reference kernels, tests/orc.py = oracle; same names) on the
     inputs.  Returns {name: array}.  Reductions are returned as the reference returns them (A, b, residual as f32)."""
     out = {}
-    cam = cam_cls(FX, FY, CX, CY)
+    fx, fy, cx, cy = [float(v) for v in inp["cam"]] if "cam" in inp else (FX, FY, CX, CY)
+    cam = cam_cls(fx, fy, cx, cy)
     is_ref = m.__name__.endswith("ref")
 
     def level(c, l):
@@ -81,7 +83,7 @@ def run(m, inp, cam_cls):
     Rprev = pose[:3, :3]; tprev = pose[:3, 3]
     Rprev_inv = np.linalg.inv(Rprev.astype(np.float64)).astype(np.float32)
     T2 = inp["T2"]
-    K = np.array([[FX, 0, CX], [0, FY, CY], [0, 0, 1]], np.float64)
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
     dT = inp["dT"].astype(np.float64)
     for l in range(3):
         cl = level(cam, l)
@@ -181,20 +183,20 @@ def digest(a) -> np.ndarray:
     return np.frombuffer(hashlib.sha256(a.tobytes()).digest(), np.uint8).copy()
 
 
-def surfel_inputs():
+def surfel_inputs(w=SW, h=SH):
     import common
     from co_fusion_amd import synth
-    cam = synth.Camera.scaled(SW, SH)
+    cam = synth.Camera.scaled(w, h)
     sc = synth.Scene(n_obj=1)
     out = dict(cam=np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32))
     for k, t in enumerate((0, 2, 4)):
         d, rgb, _, _ = sc.render(cam, t, noise=True)
         d = d.astype(np.float32)
         if k == 1:
-            d[10:20, 30:60] = 0.0  # holes
-            d[100, 100] = 7.0      # beyond the filter cutoff
+            d[h // 12:h // 6, w * 3 // 16:w * 3 // 8] = 0.0  # holes
+            d[h * 5 // 6, w * 5 // 8] = 7.0                  # beyond the filter cutoff
         out[f"d{k}"] = d; out[f"rgba{k}"] = synth.rgb_to_rgba(rgb)
-    mask = np.zeros((SH, SW), np.uint8); mask[:, SW // 2:] = 1
+    mask = np.zeros((h, w), np.uint8); mask[:, w // 2:] = 1
     out["mask"] = mask
     out["pose1"] = common.perturbed_pose(4, 0.003, 0.2).astype(np.float32)
     out["pose2"] = (common.perturbed_pose(6, 0.004, 0.3) @ common.perturbed_pose(4, 0.003, 0.2)).astype(np.float32)
@@ -206,11 +208,12 @@ class CpuSurfelBackend:
 
     def __init__(self, op, cam):
         import orc
-        self.op = op; self.cam = orc.Cam(*[float(v) for v in cam]); self.surfels = None
+        self.op = op; self.cam = orc.Cam(*[float(v) for v in cam]); self.surfels = None; self.w = self.h = None
 
     def bilateral(self, d): return self.op.bilateral(d, DEPTH_FILTER_CUTOFF)
 
     def bootstrap(self, rgba, d, df):
+        self.h, self.w = d.shape
         raw, n = self.op.vertex_feedback(rgba, d, self.cam, 1, MAX_DEPTH)
         filt, _ = self.op.vertex_feedback(rgba, df, self.cam, 1, MAX_DEPTH)
         self.surfels = self.op.model_initialise(raw, n, filt)
@@ -218,11 +221,11 @@ class CpuSurfelBackend:
     def map(self): return self.surfels
 
     def predict_indices(self, pose, time):
-        self.idx = self.op.predict_indices(self.surfels, pose, self.cam, SW, SH, MAX_DEPTH, time, TIME_DELTA)
+        self.idx = self.op.predict_indices(self.surfels, pose, self.cam, self.w, self.h, MAX_DEPTH, time, TIME_DELTA)
         return self.idx
 
     def combined_predict(self, pose, time):
-        self.pred = self.op.combined_predict(self.surfels, pose, self.cam, SW, SH, MAX_DEPTH, CONF_SPLAT, time, time, TIME_DELTA)
+        self.pred = self.op.combined_predict(self.surfels, pose, self.cam, self.w, self.h, MAX_DEPTH, CONF_SPLAT, time, time, TIME_DELTA)
         return self.pred
 
     def fill_in(self, rgba, df, pg, pr):

@@ -18,10 +18,10 @@ class Hip:
     """tests/orc.py's function names over co_fusion_amd.api.Context, numpy in / numpy out."""
     __name__ = "hip"
 
-    def __init__(self):
+    def __init__(self, w=refpin.W, h=refpin.H, cam=(refpin.FX, refpin.FY, refpin.CX, refpin.CY)):
         from co_fusion_amd import api
         self.api = api
-        self.ctx = api.Context(refpin.W, refpin.H, refpin.FX, refpin.FY, refpin.CX, refpin.CY)
+        self.ctx = api.Context(w, h, *[float(v) for v in cam])
         self.d = self.ctx.to_device
 
     def Cam(self, fx, fy, cx, cy):
@@ -136,11 +136,11 @@ SURFEL_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_surfel_v1
 class HipSurfelBackend:
     """the scenario of refpin.surfel_run on co_fusion_amd.model.Model (C-ABI cf_model_*)"""
 
-    def __init__(self, cam):
+    def __init__(self, cam, w=refpin.SW, h=refpin.SH, max_surfels=1 << 17):
         from co_fusion_amd import api, model
         self.M = model
-        self.ctx = api.Context(refpin.SW, refpin.SH, float(cam[0]), float(cam[1]), float(cam[2]), float(cam[3]))
-        self.m = model.Model(self.ctx, 1 << 17)
+        self.ctx = api.Context(w, h, float(cam[0]), float(cam[1]), float(cam[2]), float(cam[3]))
+        self.m = model.Model(self.ctx, max_surfels)
         self.d = self.ctx.to_device
 
     def close(self):
@@ -190,3 +190,58 @@ def test_hip_surfel_passes_match_reference_shaders():
             continue  # between fuse and clean the device map holds the pending new surfels in its own layout; pinned after clean
         assert tuple(np.asarray(a).shape) == shape[name], f"{name}: shape {np.asarray(a).shape} vs reference {shape[name]}"
         assert np.array_equal(refpin.digest(a), sha[name]), f"{name}: differs from the reference shaders' output"
+
+
+# ---- the same two pins at BASELINE.json's frame size (640x480): digests of the reference kernels' / shaders' outputs ----------
+FULL_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_full_v1.npz")
+
+
+def test_hip_matches_reference_at_full_resolution():
+    z = np.load(FULL_GOLDEN)
+    w, h = int(z["size"][0]), int(z["size"][1])
+    # -- tracking kernels
+    inp = refpin.inputs(w, h)
+    for k, v in inp.items():
+        assert np.array_equal(refpin.digest(v), z["insha_" + k]), f"input generator drifted: {k}"
+    hip = Hip(w, h, inp["cam"])
+    try:
+        got = refpin.run(hip, inp, hip.Cam)
+    finally:
+        hip.ctx.close()
+    n = 0
+    for name, g in got.items():
+        g = np.asarray(g)
+        if name.endswith("_order"):
+            continue
+        if "val_" + name in z.files:
+            wv = z["val_" + name]
+            if refpin.is_reduction(name):
+                assert refpin.sums_close(g, wv), f"{name}: exact sums vs the reference's f32 tree: {np.abs(g - wv).max()}"
+            elif name.startswith(("icp_res", "so3_res")):
+                assert g[1] == wv[1] and refpin.sums_close(g[:1], wv[:1]), name
+            else:
+                assert np.array_equal(g.astype(wv.dtype), wv), name
+        else:
+            if name.startswith(PLANAR):
+                g = _planar_valid_only(g)
+            wv = z["sha_" + name]
+            if g.dtype != np.dtype(str(z["dtype_" + name])) and g.dtype.kind != "f":
+                g = g.astype(str(z["dtype_" + name]))
+            assert np.array_equal(refpin.digest(g), wv), f"{name}: differs from the reference kernel's output at {w}x{h}"
+        n += 1
+    assert n >= 80
+    # -- surfel passes
+    sinp = refpin.surfel_inputs(w, h)
+    for k, v in sinp.items():
+        assert np.array_equal(refpin.digest(v), z["sinsha_" + k]), f"input generator drifted: {k}"
+    be = HipSurfelBackend(sinp["cam"], w, h, 1 << 20)
+    try:
+        sgot = refpin.surfel_run(be, sinp)
+    finally:
+        be.close()
+    keep = [0, 1, 2, 5, 8]
+    assert np.array_equal(refpin.surfel_summary(sgot)[keep], z["ssummary"][keep])
+    for name, a in sgot.items():
+        if name.endswith("_fuse_map"):
+            continue
+        assert np.array_equal(refpin.digest(a), z["ssha_" + name]), f"{name}: differs from the reference shaders' output at {w}x{h}"
