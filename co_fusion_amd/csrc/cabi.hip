@@ -87,6 +87,7 @@ void cf_destroy(cf_ctx* ctx)
         if (ctx->lane_done[i]) (void)hipEventDestroy(ctx->lane_done[i]);
     }
     if (ctx->fork_point) (void)hipEventDestroy(ctx->fork_point);
+    for (int i = 0; i < cf_ctx::kMarks; i++) if (ctx->marks[i]) (void)hipEventDestroy(ctx->marks[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -113,6 +114,32 @@ int cf_fork(cf_ctx* ctx, int lane)
         ctx->forked = true;
     }
     HIPCHK(ctx, hipStreamWaitEvent(ctx->lanes[lane], ctx->fork_point, 0));
+    ctx->lanes_used |= 1u << lane;
+    ctx->stream = ctx->lanes[lane];
+    return CF_OK;
+}
+// cf_mark(slot) remembers the current point of the stream; cf_fork_after(lane, slot) routes the following calls to `lane`
+// ordered after that point ONLY (slot < 0: after nothing) -- for work that does not depend on what the main stream still has
+// queued, e.g. filtering the next frame while the previous frame's fusion passes run.  cf_join orders the main stream after it.
+int cf_mark(cf_ctx* ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= cf_ctx::kMarks) return CF_EINVAL;
+    if (!ctx->marks[slot]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->marks[slot], hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->marks[slot], ctx->stream));
+    ctx->mark_set[slot] = true;
+    return CF_OK;
+}
+int cf_fork_after(cf_ctx* ctx, int lane, int slot)
+{
+    if (!ctx || lane < 0 || slot >= cf_ctx::kMarks || ctx->forked) return CF_EINVAL;
+    lane %= cf_ctx::kLanes;
+    if (!ctx->lanes[lane]) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->lanes[lane], hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
+    }
+    if (slot >= 0 && ctx->mark_set[slot]) HIPCHK(ctx, hipStreamWaitEvent(ctx->lanes[lane], ctx->marks[slot], 0));
+    ctx->forked_from = ctx->stream;
+    ctx->forked = true;
     ctx->lanes_used |= 1u << lane;
     ctx->stream = ctx->lanes[lane];
     return CF_OK;

@@ -34,6 +34,9 @@ struct cf_ctx {
     hipStream_t lanes[kLanes]{};
     hipEvent_t lane_done[kLanes]{};
     hipEvent_t fork_point = nullptr;
+    static constexpr int kMarks = 4;
+    hipEvent_t marks[kMarks]{};       // cf_mark / cf_fork_after: points of the main stream a detached lane waits for
+    bool mark_set[kMarks]{};
     hipStream_t forked_from = nullptr;
     bool forked = false;
     unsigned lanes_used = 0;

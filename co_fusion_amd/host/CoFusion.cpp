@@ -551,9 +551,12 @@ CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
     const size_t N = (size_t)cfg.width * cfg.height;
     void* p = nullptr;
     check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); depth_dev = static_cast<float*>(p);
-    check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); depthFiltered_dev = static_cast<float*>(p);
-    check(ctx, cf_malloc(ctx, N, &p), "cf_malloc"); depthPyr1 = static_cast<float*>(p);
-    check(ctx, cf_malloc(ctx, N / 4, &p), "cf_malloc"); depthPyr2 = static_cast<float*>(p);
+    for (int b = 0; b < 2; b++) {
+        check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); depthFilteredBuf[b] = static_cast<float*>(p);
+        check(ctx, cf_malloc(ctx, N, &p), "cf_malloc"); depthPyr1Buf[b] = static_cast<float*>(p);
+        check(ctx, cf_malloc(ctx, N / 4, &p), "cf_malloc"); depthPyr2Buf[b] = static_cast<float*>(p);
+    }
+    depthFiltered_dev = depthFilteredBuf[0]; depthPyr1 = depthPyr1Buf[0]; depthPyr2 = depthPyr2Buf[0];
     check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); rgba_dev = static_cast<uint8_t*>(p);
     check(ctx, cf_malloc(ctx, N, &p), "cf_malloc"); mask_dev = static_cast<uint8_t*>(p);
     rgbaHost.resize(N * 4);
@@ -566,7 +569,8 @@ CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
 CoFusion::~CoFusion()
 {
     models.clear(); inactiveModels.clear(); newModel.reset(); globalModel.reset();
-    cf_free(ctx, depth_dev); cf_free(ctx, depthFiltered_dev); cf_free(ctx, depthPyr1); cf_free(ctx, depthPyr2);
+    cf_free(ctx, depth_dev);
+    for (int b = 0; b < 2; b++) { cf_free(ctx, depthFilteredBuf[b]); cf_free(ctx, depthPyr1Buf[b]); cf_free(ctx, depthPyr2Buf[b]); }
     cf_free(ctx, rgba_dev); cf_free(ctx, mask_dev);
     labelGenerator.reset();
     cf_destroy(ctx);
@@ -698,7 +702,18 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
         check(ctx, cf_memcpy_h2d(ctx, depth_dev, frame.depth, N * 4), "depth upload");
         curRgba = rgba_dev; curDepth = depth_dev;
     }
+    // filterDepth + the depth pyramid only read the new frame.  With a device-resident frame they go to an auxiliary stream that
+    // does not wait for the fusion passes of the previous frame still queued on the main stream (those read the OTHER buffer set);
+    // mark[b] = end of the last frame that used buffer set b, which is all this lane has to wait for.
+    const bool willTrack = tick > 1 && (bootstrap || !inPose);
+    const unsigned b = frameParity & 1u;
+    frameParity++;
+    depthFiltered_dev = depthFilteredBuf[b]; depthPyr1 = depthPyr1Buf[b]; depthPyr2 = depthPyr2Buf[b];
+    const bool headAside = useLanes && frame.depth_dev != nullptr;
+    if (headAside) check(ctx, cf_fork_after(ctx, 6, (int)b), "cf_fork_after");
     check(ctx, cf_bilateral(ctx, curDepth, cfg.width, cfg.height, cfg.depthCutoff, depthFiltered_dev), "filterDepth");
+    if (willTrack) check(ctx, cf_depth_pyramid(ctx, depthFiltered_dev, cfg.width, cfg.height, depthPyr1, depthPyr2), "generateCUDATextures");
+    if (headAside) check(ctx, cf_join(ctx), "cf_join");
     if (!cfg.enableMultipleModels) {
         std::vector<uint8_t> zeros(N, 0);
         if (tick == 1) check(ctx, cf_memcpy_h2d(ctx, mask_dev, zeros.data(), N), "mask upload");  // stays all-zero afterwards
@@ -710,7 +725,6 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
     } else {
         bool trackingOk = true;
         if (bootstrap || !inPose) {
-            check(ctx, cf_depth_pyramid(ctx, depthFiltered_dev, cfg.width, cfg.height, depthPyr1, depthPyr2), "generateCUDATextures");
             const float* pyr[3] = {depthFiltered_dev, depthPyr1, depthPyr2};
             // the superpixels only depend on the colour image: SLIC runs on an auxiliary stream beside the (latency-bound)
             // tracking launches and is joined before the segmentation needs it
@@ -795,6 +809,7 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
         }
     }
     { PhaseTimer t(PhaseTimes::Predict); predict(true); }
+    check(ctx, cf_mark(ctx, (int)b), "cf_mark");  // everything that reads this frame's filtered depth is enqueued
     phaseTimes().frames++;
     if (!lost) tick++;
     moveNewModelToList();

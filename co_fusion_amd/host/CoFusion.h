@@ -238,7 +238,11 @@ class CoFusion {
     unsigned spawnOffset = 0;
     bool lost = false;
     // device frame buffers (CoFusion::textures)
+    // filtered depth + its pyramid are double buffered: the filter of frame t+1 runs on an auxiliary stream while the fusion
+    // passes of frame t still read frame t's filtered depth (processFrame)
     float *depth_dev = nullptr, *depthFiltered_dev = nullptr, *depthPyr1 = nullptr, *depthPyr2 = nullptr;
+    float *depthFilteredBuf[2] = {nullptr, nullptr}, *depthPyr1Buf[2] = {nullptr, nullptr}, *depthPyr2Buf[2] = {nullptr, nullptr};
+    unsigned frameParity = 0;
     uint8_t *rgba_dev = nullptr, *mask_dev = nullptr;
     std::vector<uint8_t> rgbaHost;
     const float* curDepth = nullptr;   // device pointers of the frame being processed

@@ -82,6 +82,11 @@ int cf_synchronize(cf_ctx *ctx);
 int cf_fork(cf_ctx *ctx, int lane);
 int cf_main(cf_ctx *ctx);
 int cf_join(cf_ctx *ctx);
+/* cf_mark(slot 0..3) remembers the current point of the stream; cf_fork_after(lane, slot) routes the following calls to `lane`
+ * ordered after that point only (slot < 0: after nothing): for work that does not depend on what the stream still has queued,
+ * e.g. filtering the next frame while the previous frame's fusion passes run.  cf_join orders the stream after the lane. */
+int cf_mark(cf_ctx *ctx, int slot);
+int cf_fork_after(cf_ctx *ctx, int lane, int slot);
 /* device memory helpers for hosts that do not link HIP themselves */
 int cf_malloc(cf_ctx *ctx, uint64_t bytes, void **dptr);
 int cf_free(cf_ctx *ctx, void *dptr);
