@@ -872,7 +872,13 @@ void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, 
 // solve.  Letting rgbStep's last workgroup run the solve was measured twice and lost both times: with a device-scope
 // release fence per workgroup (it writes back the XCD's L2: 53 us instead of 6 + 8 us), and with returning atomics +
 // a ticket instead of the fence (correct and deterministic, but 946 instead of 1061 frames/s: every workgroup then
-// waits for its atomics' round trip).  Kept as separate launches.
+// waits for its atomics' round trip).  A third experiment ran the WHOLE 4/5/10 schedule as one persistent launch (256 resident
+// workgroups per model, registers carrying the partial sums across a thread's pixels, two grid barriers per iteration built
+// from integer atomics + an arrival counter, every workgroup repeating the solve on its own LDS copy of the state): bit-exact
+// for all option sets, but 640 us per frame instead of 420 us for the 57 launches -- an in-kernel timer showed ~8 us per
+// grid barrier, a chain of about five device-scope memory round trips of ~1.5 us each across the XCDs, whereas a dependent
+// launch costs ~2.5 us (tools/microbench/launch_floor.hip).  On this part the kernel boundary IS the cheapest grid barrier.
+// Kept as separate launches.
 void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const IcpArgs icp_args[3],
                      const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, ProfSink* prof)
 {
