@@ -709,7 +709,7 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
     const unsigned b = frameParity & 1u;
     frameParity++;
     depthFiltered_dev = depthFilteredBuf[b]; depthPyr1 = depthPyr1Buf[b]; depthPyr2 = depthPyr2Buf[b];
-    const bool headAside = useLanes && frame.depth_dev != nullptr;
+    const bool headAside = useLanes && cfg.deviceFramesComplete && frame.depth_dev != nullptr;
     if (headAside) check(ctx, cf_fork_after(ctx, 6, (int)b), "cf_fork_after");
     check(ctx, cf_bilateral(ctx, curDepth, cfg.width, cfg.height, cfg.depthCutoff, depthFiltered_dev), "filterDepth");
     if (willTrack) check(ctx, cf_depth_pyramid(ctx, depthFiltered_dev, cfg.width, cfg.height, depthPyr1, depthPyr2), "generateCUDATextures");

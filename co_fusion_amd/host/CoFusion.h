@@ -195,6 +195,11 @@ class CoFusion {
         bool enableMultipleModels = true;
         bool enablePoseLogging = false;                        // CoFusion ctor argument (CoFusion.h:59)
         int rank = 0, world = 1;                               // model-parallel operation (see Distributed)
+        // Device-resident frames (FrameData::depth_dev): true = the buffers are COMPLETE when processFrame is called (e.g. a ring
+        // of frames uploaded ahead); the depth filter of the new frame then runs on an auxiliary stream that is NOT ordered after
+        // the work still queued on the context's stream, i.e. beside the previous frame's fusion passes.  false (default) = they
+        // may be produced by work queued on that stream just before the call, and are consumed in stream order.
+        bool deviceFramesComplete = false;
     };
     explicit CoFusion(const Config& cfg);
     ~CoFusion();

@@ -32,6 +32,7 @@ void cofusion_default_config(cofusion_config* c)
     c->enable_multiple_models = d.enableMultipleModels;
     c->enable_pose_logging = d.enablePoseLogging;
     c->rank = d.rank; c->world = d.world;
+    c->device_frames_complete = d.deviceFramesComplete;
 }
 
 int cofusion_create(const cofusion_config* c, cofusion_handle** out)
@@ -46,6 +47,7 @@ int cofusion_create(const cofusion_config* c, cofusion_handle** out)
     d.enableMultipleModels = c->enable_multiple_models;
     d.enablePoseLogging = c->enable_pose_logging != 0;
     d.rank = c->rank; d.world = c->world < 1 ? 1 : c->world;
+    d.deviceFramesComplete = c->device_frames_complete != 0;
     GUARD(*out = new cofusion_handle{new CoFusion(d)});
     return 0;
 }

@@ -23,6 +23,9 @@ typedef struct {
     int enable_multiple_models;
     int enable_pose_logging; /* CoFusion ctor argument enablePoseLogging (CoFusion.h:59); needed by cofusion_export_poses */
     int rank, world;         /* model-parallel operation over `world` processes / GPUs (default 0, 1); see cofusion_set_allreduce */
+    int device_frames_complete; /* 1: buffers given to cofusion_process_frame_device are complete at call time (uploaded ahead), so the
+                                 * new frame's depth filter may run beside the previous frame's fusion passes; 0 (default): they may be
+                                 * produced by work queued on the context's stream and are consumed in stream order */
 } cofusion_config;
 
 void cofusion_default_config(cofusion_config *cfg);

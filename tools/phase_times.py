@@ -10,7 +10,7 @@ from co_fusion_amd import facade, lib as cflib
 wl = sys.argv[1] if len(sys.argv) > 1 else "objects4"
 n_obj = 0 if wl == "static" else 4
 cam, frames = bench.make_stream(640, 480, 16, n_obj=n_obj)
-cf = facade.CoFusion(640, 480, cam.fx, cam.fy, cam.cx, cam.cy, max_surfels=1 << 21, enable_multiple_models=int(n_obj > 0))
+cf = facade.CoFusion(640, 480, cam.fx, cam.fy, cam.cx, cam.cy, max_surfels=1 << 21, enable_multiple_models=int(n_obj > 0), device_frames_complete=1)
 dev = torch.device("cuda", 0)
 res = [dict(d=torch.from_numpy(f["depth"]).to(dev), c=torch.from_numpy(f["rgba"]).to(dev)) for f in frames]
 host = cflib.load_host()
