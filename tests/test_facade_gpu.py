@@ -280,3 +280,38 @@ def test_long_free_run_with_spawning_and_deactivation():
     ups = sum(1 for a, b in zip(counts, counts[1:]) if b > a)
     downs = sum(1 for a, b in zip(counts, counts[1:]) if b < a)
     assert ups >= 2 and downs >= 2, f"spawn / deactivation not exercised: {counts}"
+
+
+def test_device_frames_complete_overlap_changes_nothing():
+    """device_frames_complete=1 lets the next frame's depth filter run beside the previous frame's fusion passes (double-buffered,
+    auxiliary stream): poses, counts and surfel buffers must be those of the stream-ordered default, frame by frame."""
+    import torch
+    from co_fusion_amd import facade
+    cam = synth.Camera.scaled(W, H)
+    sc = synth.Scene(n_obj=2)
+    dev = torch.device("cuda", 0)
+    frames = []
+    for t in range(10):
+        d, rgb, _, _ = sc.render(cam, t, noise=True)
+        frames.append((torch.from_numpy(d.astype(np.float32)).to(dev), torch.from_numpy(synth.rgb_to_rgba(rgb)).to(dev)))
+    torch.cuda.synchronize()
+    runs = []
+    for flag in (0, 1):
+        cf = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, max_surfels=1 << 19, conf_global_init=0.5, model_spawn_offset=2,
+                             enable_multiple_models=1, device_frames_complete=flag)
+        log = []
+        for t, (d, c) in enumerate(frames):
+            cf.process_frame_device(d, c, timestamp=t)
+            log.append([(cf.model_info(i)["id"], cf.model_info(i)["count"], cf.model_info(i)["pose"].copy()) for i in range(cf.num_models)])
+        final = [cf.model_download(i).copy() for i in range(cf.num_models)]
+        cf.close()
+        runs.append((log, final))
+    (la, fa), (lb, fb) = runs
+    assert len(fa) == len(fb) and len(fa) >= 2, "object models should have been spawned"
+    for t, (a, b) in enumerate(zip(la, lb)):
+        assert len(a) == len(b), f"frame {t}: model count"
+        for (ia, ca, pa), (ib, cb, pb) in zip(a, b):
+            assert ia == ib and ca == cb, f"frame {t}: id / count"
+            _same(pa, pb, f"frame {t}: pose")
+    for i, (a, b) in enumerate(zip(fa, fb)):
+        _same(a, b, f"model {i}: final surfels")
