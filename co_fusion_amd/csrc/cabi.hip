@@ -58,6 +58,8 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     memset(ctx->h_state_pool, 0, sizeof(OdomDev) * cf_ctx::kStateSlots);
     if (int r = dmalloc(ctx, &ctx->d_model_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_so3_sync, (size_t)ctx->cfg.max_models + 1)) return r;
+    if (int r = dmalloc(ctx, &ctx->d_gn_sync, (size_t)ctx->cfg.max_models + 1)) return r;
+    if (const char* e = getenv("CF_GN_MODE")) ctx->gn_mode = atoi(e);  // diagnostic: 0 = three launches per iteration
     if (int r = dmalloc(ctx, &ctx->d_cand_scratch, (size_t)cfg->width * cfg->height)) return r;
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scratch_state), sizeof(OdomDev)));
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_model_ptrs), sizeof(OdomDev*) * (ctx->cfg.max_models + 1)));
@@ -75,7 +77,7 @@ void cf_destroy(cf_ctx* ctx)
     if (!ctx) return;
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_acc_a); (void)hipFree(ctx->d_acc_b); (void)hipFree(ctx->d_out);
-    (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_cand_scratch);
+    (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_gn_sync); (void)hipFree(ctx->d_cand_scratch);
     (void)hipFree(ctx->d_state_pool); (void)hipHostFree(ctx->h_state_pool);
     (void)hipHostFree(ctx->h_scratch_state); (void)hipHostFree(ctx->h_model_ptrs); (void)hipHostFree(ctx->h_out);
     if (ctx->prof.events) {
@@ -93,8 +95,22 @@ void cf_destroy(cf_ctx* ctx)
 }
 
 const char* cf_last_error(const cf_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
-int cf_set_stream(cf_ctx* ctx, void* s) { if (!ctx || ctx->forked) return CF_EINVAL; ctx->stream = (hipStream_t)s; return CF_OK; }  // NULL = the legacy default stream
-int cf_use_own_stream(cf_ctx* ctx) { if (!ctx || ctx->forked) return CF_EINVAL; ctx->stream = ctx->own_stream; return CF_OK; }
+// Switching streams drains the old one first: allocations zero-fill asynchronously on the stream that was current when they
+// were made, and nothing else would order that before the first use on the new stream.
+int cf_set_stream(cf_ctx* ctx, void* s)  // NULL = the legacy default stream
+{
+    if (!ctx || ctx->forked) return CF_EINVAL;
+    if (ctx->stream != (hipStream_t)s) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = (hipStream_t)s;
+    return CF_OK;
+}
+int cf_use_own_stream(cf_ctx* ctx)
+{
+    if (!ctx || ctx->forked) return CF_EINVAL;
+    if (ctx->stream != ctx->own_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
+    return CF_OK;
+}
 
 // Independent pieces of one frame (the surfel passes of different models) may overlap on the GPU: cf_fork(lane) routes
 // the following calls to auxiliary stream `lane`, ordered after everything enqueued on the context's stream at the first
@@ -314,6 +330,7 @@ int cf_icp_step_band(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], co
     IcpArgs a{};
     a.m[0] = IcpModelArgs{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, ctx->d_scratch_state, ctx->d_acc_a, err_surface, ctx->d_acc_b};
     a.cols = cols; a.rows = rows; a.intr = intr; a.distThres = dist_thres; a.angleThres = angle_thres;
+    a.angleSqLt = sqrt_gate_lt(angle_thres); a.distSqLe = sqrt_gate_le(dist_thres);
     a.flags = err_surface ? 1 : 0;
     a.row_begin = row_begin; a.row_end = row_end;
     launch_icp_level(ctx->stream, ctx->icp_launch, a, 1, 0);
@@ -414,6 +431,7 @@ int cf_so3_step(cf_ctx* ctx, const uint8_t* last_image, const uint8_t* next_imag
 int cf_odom_create(cf_ctx* ctx, cf_odom** out)
 {
     if (!ctx || !out) return CF_EINVAL;
+    if ((size_t)ctx->cfg.width * ctx->cfg.height > (1u << 22)) { ctx->set_error("tracker: frames above 2^22 pixels are not supported (22-bit pixel index in the correspondence records)"); return CF_EINVAL; }
     cf_odom* od = new cf_odom();
     od->ctx = ctx;
     *out = od;
@@ -453,7 +471,9 @@ int cf_odom_create(cf_ctx* ctx, cf_odom** out)
     memset(od->h_state, 0, sizeof(OdomDev));
     // RGBDOdometry ctor defaults: RGBDOdometry.h:45-46, RGBDOdometry.cpp:31-36,103-105
     od->distThres = 0.10f;
+    od->distSqLe = sqrt_gate_le(od->distThres);
     od->angleThres = (float)sin(20.f * 3.14159254f / 180.f);
+    od->angleSqLt = sqrt_gate_lt(od->angleThres);
     od->sobelScale = (float)(1.0 / pow(2.0, 3));
     od->maxDepthDeltaRGB = 0.07f; od->maxDepthRGB = 6.0f;
     od->minGrad[0] = 5; od->minGrad[1] = 3; od->minGrad[2] = 1;
@@ -693,6 +713,7 @@ static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3
         a.cols = ctx->cfg.width >> l; a.rows = ctx->cfg.height >> l;
         a.intr = cf_cam{intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
         a.distThres = ods[0]->distThres; a.angleThres = ods[0]->angleThres;
+        a.angleSqLt = ods[0]->angleSqLt; a.distSqLe = ods[0]->distSqLe;
         for (int m = 0; m < n; m++) {
             cf_odom* od = ods[m];
             a.m[m] = IcpModelArgs{od->ext_vmap_curr[l] ? od->ext_vmap_curr[l] : od->vmap_curr[l],
@@ -735,8 +756,8 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     fill_icp_args(ctx, ods, n, icp_args);
     RgbArgs rgb_args[3];
     fill_rgb_args(ctx, ods, n, rgb_args);
-    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, icp_args, rgb_args, n, ctx->cfg.width, ctx->cfg.height,
-                    opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, &ctx->prof);
+    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, ctx->d_gn_sync, icp_args, rgb_args, n, ctx->cfg.width,
+                    ctx->cfg.height, opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, &ctx->prof);
     LAUNCHCHK(ctx);
     if (lo >= 0) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_state_pool + lo, ctx->d_state_pool + lo, sizeof(OdomDev) * (hi - lo + 1), hipMemcpyDeviceToHost, ctx->stream));
@@ -757,10 +778,22 @@ int cf_odom_fetch_result(cf_odom* od, float trans[3], float rot[9], cf_track_sta
     if (trans) memcpy(trans, od->h_state->tcurr, 12);
     if (rot) memcpy(rot, od->h_state->Rcurr, 36);
     if (stats) *stats = od->h_state->stats;
+    const bool fault = od->h_state->stats.fault != 0;
     if (od->pending_so3_swap) {  // RGBDOdometry.cpp:469-473
         for (int i = 0; i < CF_NUM_PYRS; i++) std::swap(od->lastNextImage[i], od->nextImage[i]);
         od->pending_so3_swap = false;
     }
+    if (fault) {  // a device-side wait between co-resident workgroups expired: the pose was computed from partial sums
+        ctx->set_error("tracking: a bounded device-side wait expired (workgroups of one launch were not co-resident)");
+        return CF_ESTATE;
+    }
+    return CF_OK;
+}
+
+int cf_set_gn_mode(cf_ctx* ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 1) return CF_EINVAL;
+    ctx->gn_mode = mode;
     return CF_OK;
 }
 

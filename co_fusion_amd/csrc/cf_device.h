@@ -107,70 +107,85 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 //     matching between the "keeps lower" and "keeps upper" lanes of a group is a valid partner.
 // No LDS traffic (the ds_bpermute form of __shfl_xor made this reduction LDS-pipe bound).
 // All indices are static so the accumulators stay in VGPRs.
+// 64-bit adds are written on explicit 32-bit halves (v_add_co / v_addc): composing u64 values from shuffled halves made the
+// compiler split every add into zero-extended partial sums (about twice the instructions).
+__device__ __forceinline__ void add64(unsigned& alo, unsigned& ahi, unsigned blo, unsigned bhi)
+{
+    const unsigned lo = alo + blo;
+    const unsigned c = lo < alo ? 1u : 0u;
+    ahi = ahi + bhi + c;
+    alo = lo;
+}
 template <int HALF, int N>
-__device__ __forceinline__ void swap32_step(unsigned long long (&acc)[N])
+__device__ __forceinline__ void swap32_step(unsigned (&lo)[N], unsigned (&hi)[N])
 {
 #pragma unroll
     for (int i = 0; i < HALF; i++) {
-        const unsigned long long a = acc[i], b = acc[i + HALF];
-        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
-        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(a >> 32), (unsigned)(b >> 32), false, false);
-        acc[i] = (((unsigned long long)hi[0] << 32) | lo[0]) + (((unsigned long long)hi[1] << 32) | lo[1]);
+        const auto l = __builtin_amdgcn_permlane32_swap(lo[i], lo[i + HALF], false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi[i], hi[i + HALF], false, false);
+        unsigned a = l[0], b = h[0];
+        add64(a, b, l[1], h[1]);
+        lo[i] = a; hi[i] = b;
     }
 }
 template <int HALF, int N>
-__device__ __forceinline__ void swap16_step(unsigned long long (&acc)[N])
+__device__ __forceinline__ void swap16_step(unsigned (&lo)[N], unsigned (&hi)[N])
 {
 #pragma unroll
     for (int i = 0; i < HALF; i++) {
-        const unsigned long long a = acc[i], b = acc[i + HALF];
-        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(a >> 32), (unsigned)(b >> 32), false, false);
-        acc[i] = (((unsigned long long)hi[0] << 32) | lo[0]) + (((unsigned long long)hi[1] << 32) | lo[1]);
+        const auto l = __builtin_amdgcn_permlane16_swap(lo[i], lo[i + HALF], false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi[i], hi[i + HALF], false, false);
+        unsigned a = l[0], b = h[0];
+        add64(a, b, l[1], h[1]);
+        lo[i] = a; hi[i] = b;
     }
 }
 template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v)
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template <int HALF, int CTRL, int N>
+__device__ __forceinline__ void dpp_step(unsigned (&lo)[N], unsigned (&hi)[N], bool upper)
 {
-    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xf, 0xf, false);
-    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
-    return ((unsigned long long)hi << 32) | lo;
-}
-template <int HALF, int M, int CTRL, int N>
-__device__ __forceinline__ void dpp_step(unsigned long long (&acc)[N], int lane)
-{
-    const bool upper = (lane & M) != 0;
 #pragma unroll
     for (int i = 0; i < HALF; i++) {
-        const unsigned long long lo = acc[i], hi = acc[i + HALF];
-        const unsigned long long send = upper ? lo : hi;
-        const unsigned long long keep = upper ? hi : lo;
-        acc[i] = keep + dpp_u64<CTRL>(send);
+        const unsigned slo = upper ? lo[i] : lo[i + HALF], shi = upper ? hi[i] : hi[i + HALF];  // the half this lane gives away
+        unsigned klo = upper ? lo[i + HALF] : lo[i], khi = upper ? hi[i + HALF] : hi[i];        // the half it keeps
+        add64(klo, khi, dpp_u32<CTRL>(slo), dpp_u32<CTRL>(shi));
+        lo[i] = klo; hi[i] = khi;
     }
 }
 constexpr int kDppRor8 = 0x128, kDppHalfMirror = 0x141, kDppXor2 = 0x4E, kDppXor1 = 0xB1;
 
 // Reduce acc[0..31] across the 64 lanes of a wave.  Returns, in lane l, the wave total of value
 // index ((l >> 1) & 31).
-__device__ __forceinline__ unsigned long long wave_reduce32_u64(unsigned long long (&acc)[32], int lane)
+__device__ __forceinline__ unsigned long long wave_reduce32_u64(const unsigned long long (&acc)[32], int lane)
 {
-    swap32_step<16>(acc);
-    swap16_step<8>(acc);
-    dpp_step<4, 8, kDppRor8>(acc, lane);
-    dpp_step<2, 4, kDppHalfMirror>(acc, lane);
-    dpp_step<1, 2, kDppXor2>(acc, lane);
-    return acc[0] + dpp_u64<kDppXor1>(acc[0]);
+    unsigned lo[32], hi[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) { lo[i] = (unsigned)acc[i]; hi[i] = (unsigned)(acc[i] >> 32); }
+    swap32_step<16>(lo, hi);
+    swap16_step<8>(lo, hi);
+    dpp_step<4, kDppRor8>(lo, hi, (lane & 8) != 0);
+    dpp_step<2, kDppHalfMirror>(lo, hi, (lane & 4) != 0);
+    dpp_step<1, kDppXor2>(lo, hi, (lane & 2) != 0);
+    unsigned a = lo[0], b = hi[0];
+    add64(a, b, dpp_u32<kDppXor1>(lo[0]), dpp_u32<kDppXor1>(hi[0]));
+    return ((unsigned long long)b << 32) | a;
 }
 
 // 16-value flavour (SO3): lane l ends with the total of value index ((l >> 2) & 15)
-__device__ __forceinline__ unsigned long long wave_reduce16_u64(unsigned long long (&acc)[16], int lane)
+__device__ __forceinline__ unsigned long long wave_reduce16_u64(const unsigned long long (&acc)[16], int lane)
 {
-    swap32_step<8>(acc);
-    swap16_step<4>(acc);
-    dpp_step<2, 8, kDppRor8>(acc, lane);
-    dpp_step<1, 4, kDppHalfMirror>(acc, lane);
-    const unsigned long long v = acc[0] + dpp_u64<kDppXor2>(acc[0]);
-    return v + dpp_u64<kDppXor1>(v);
+    unsigned lo[16], hi[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { lo[i] = (unsigned)acc[i]; hi[i] = (unsigned)(acc[i] >> 32); }
+    swap32_step<8>(lo, hi);
+    swap16_step<4>(lo, hi);
+    dpp_step<2, kDppRor8>(lo, hi, (lane & 8) != 0);
+    dpp_step<1, kDppHalfMirror>(lo, hi, (lane & 4) != 0);
+    unsigned a = lo[0], b = hi[0];
+    add64(a, b, dpp_u32<kDppXor2>(lo[0]), dpp_u32<kDppXor2>(hi[0]));
+    add64(a, b, dpp_u32<kDppXor1>(a), dpp_u32<kDppXor1>(b));
+    return ((unsigned long long)b << 32) | a;
 }
 
 // ---- deterministic f64 sin/cos (same spec as oracle/orc_math.h: orc_sincos) ------

@@ -22,6 +22,8 @@ struct cf_ctx {
     cf::OdomDev** h_model_ptrs = nullptr;  // pinned
     uint8_t* d_cand_scratch = nullptr;
     cf::So3Sync* d_so3_sync = nullptr;  // [max_models]
+    cf::GnSync* d_gn_sync = nullptr;    // [max_models]
+    int gn_mode = 1;                    // launch_gn_track mode (1: two launches per Gauss-Newton iteration)
     // device / pinned-host pools of the trackers' state structs: a batch of trackers is uploaded / read back with ONE
     // copy over its slot range instead of one copy per tracker
     static constexpr int kStateSlots = 64;
@@ -72,6 +74,7 @@ struct cf_odom {
     cf::OdomDev* h_state = nullptr;  // pinned
     int slot = -1;                   // index into the context's state pools, -1: own allocations
     float distThres = 0, angleThres = 0, sobelScale = 0, maxDepthDeltaRGB = 0, maxDepthRGB = 0;
+    float angleSqLt = 0, distSqLe = 0;  // exact radicand bounds of the two ICP gates
     float minGrad[3]{};
     bool pending_so3_swap = false;
 };

@@ -85,38 +85,23 @@ __device__ __forceinline__ void block_commit32(unsigned long long v, int lane, i
 // ================================================================================================
 // ICP:  ICPReduction::search + getProducts, reduce.cu:283-394
 // ================================================================================================
-struct IcpPix { float row[7]; float err; int found; };
+// The two gates of the correspondence test compare square roots with constants (reduce.cu:321-325:
+// sine < angleThres, dist <= distThres).  sqrtf is correctly rounded and monotonic, so each gate is decided
+// exactly by comparing the radicand with a precomputed f32 bound (IcpArgs::angleSqLt / distSqLe, sqrt_gate_* below):
+// no square root per pixel unless the error surface (which stores dist itself) is requested.
+struct IcpProj { f3 vcurr_g; int g; int inb; };
 
-__device__ __forceinline__ void icp_pixel(const m33& Rcurr, const f3& tcurr, const m33& Rprev_inv, const f3& tprev,
-                                          const cf_cam& intr, float distThres, float angleThres, int cols, int rows, int N,
-                                          const float* __restrict__ vp, const float* __restrict__ np, f3 vcurr, f3 ncurr,
-                                          float (&row)[7], float& err, int& found)
+__device__ __forceinline__ IcpProj icp_project(const m33& Rcurr, const f3& tcurr, const m33& Rprev_inv, const f3& tprev, const cf_cam& intr,
+                                               int cols, int rows, f3 vcurr)
 {
-#pragma unroll
-    for (int i = 0; i < 7; i++) row[i] = 0.f;
-    err = 0.f; found = 0;
-    const f3 vcurr_g = mul(Rcurr, vcurr) + tcurr;
-    const f3 vcurr_cp = mul(Rprev_inv, vcurr_g - tprev);
+    IcpProj o;
+    o.vcurr_g = mul(Rcurr, vcurr) + tcurr;
+    const f3 vcurr_cp = mul(Rprev_inv, o.vcurr_g - tprev);
     const int ux = f2i_rn(vcurr_cp.x * intr.fx / vcurr_cp.z + intr.cx);
     const int uy = f2i_rn(vcurr_cp.y * intr.fy / vcurr_cp.z + intr.cy);
-    if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0) return;
-    const int g = uy * cols + ux;
-    const f3 vprev_g = {vp[g], vp[g + N], vp[g + 2 * N]};
-    const f3 nprev_g = {np[g], np[g + N], np[g + 2 * N]};
-    const f3 ncurr_g = mul(Rcurr, ncurr);
-    const float dist = norm(vprev_g - vcurr_g);
-    const float sine = norm(cross(ncurr_g, nprev_g));
-    err = is_finite(dist) ? dist : 0.0f;
-    found = (sine < angleThres && dist <= distThres && !is_nan(ncurr.x) && !is_nan(nprev_g.x)) ? 1 : 0;
-    if (found) {
-        const f3 s_cp = mul(Rprev_inv, vcurr_g - tprev);
-        const f3 d_cp = mul(Rprev_inv, vprev_g - tprev);
-        const f3 n_cp = mul(Rprev_inv, nprev_g);
-        const f3 cr = cross(s_cp, n_cp);
-        row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
-        row[3] = cr.x; row[4] = cr.y; row[5] = cr.z;
-        row[6] = dot(n_cp, s_cp - d_cp);
-    }
+    o.inb = !(ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0);
+    o.g = o.inb ? uy * cols + ux : 0;
+    return o;
 }
 
 template <int PPT> struct VecF;
@@ -142,7 +127,7 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nlog)
     return (b & 7) * per + (b >> 3);
 }
 
-__device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk);
+template <bool COMPACT> __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk);
 
 // One launch per Gauss-Newton iteration carries BOTH pose-dependent streaming passes, which are independent
 // of each other: workgroups [0, n_icp_blocks) run the ICP reduction, the rest the RGB residual pass
@@ -153,16 +138,20 @@ __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk);
 // (scalar loads, global-address-space vector loads, no pointer chasing through device structs).
 // Only the pose/flags, which the solve updates on the device every iteration, are read from
 // memory -- as scalar loads issued in parallel with the first coalesced map loads.
+//
+// VALU budget (the kernel is VALU-bound once several models share a launch): PPT pixels per lane feed ONE
+// 32 x u64 butterfly; a wave whose pixels cannot produce a correspondence (projection out of view, model map empty
+// there -- the common case for object models, which cover a small part of the image) leaves after the projection.
 template <int PPT, int LEVEL_TAG>
 __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, const RgbArgs ra, int n_icp_blocks)
 {
     if ((int)blockIdx.x >= n_icp_blocks) {
-        rgb_residual_body(ra, blockIdx.y, blockIdx.x - n_icp_blocks);
+        if (ra.compact) rgb_residual_body<true>(ra, blockIdx.y, blockIdx.x - n_icp_blocks);
+        else rgb_residual_body<false>(ra, blockIdx.y, blockIdx.x - n_icp_blocks);
         return;
     }
     const IcpModelArgs& ma = args.m[blockIdx.y];
     const OdomDev* __restrict__ st = ma.st;
-    if (!st->icp || st->level_done) return;
     const int cols = args.cols, rows = args.rows, N = cols * rows;
     const int T = blockDim.x;
     // optional row band [row_begin, row_end) (a rank's share when one model's reduction is split over GPUs)
@@ -178,53 +167,112 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     float* __restrict__ errs = (args.flags & 1) ? ma.err : nullptr;
     const int abl = args.flags >> 8;  // micro-benchmark ablation bits (0 in production)
 
-    float row[PPT][7];
-    int fnd[PPT], any_found = 0;
-#pragma unroll
-    for (int p = 0; p < PPT; p++) {
-        fnd[p] = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) row[p][k] = 0.f;
-    }
     const int i0 = pix0 + (lb * T + threadIdx.x) * PPT;
-    if (i0 < pix1) {  // cols is a multiple of PPT, so the whole vector is in range
-        float vx[PPT], vy[PPT], vz[PPT], nx[PPT], ny[PPT], nz[PPT];
+    const bool in_range = i0 < pix1;  // cols is a multiple of PPT, so the whole vector is in range
+    float vx[PPT], vy[PPT], vz[PPT], nx[PPT], ny[PPT], nz[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; p++) { vx[p] = vy[p] = vz[p] = nx[p] = ny[p] = nz[p] = qnan(); }
+    if (in_range) {  // the frame maps do not depend on the tracker state: issued before the state is looked at
         load_vec<PPT>(vc + i0, vx); load_vec<PPT>(vc + i0 + N, vy); load_vec<PPT>(vc + i0 + 2 * N, vz);
         load_vec<PPT>(nc + i0, nx); load_vec<PPT>(nc + i0 + N, ny); load_vec<PPT>(nc + i0 + 2 * N, nz);
-        m33 Rcurr, Rprev_inv;
+    }
+    if (!st->icp || st->level_done) return;
+    m33 Rcurr, Rprev_inv;
 #pragma unroll
-        for (int i = 0; i < 9; i++) { Rcurr.m[i] = st->Rcurr[i]; Rprev_inv.m[i] = st->Rprev_inv[i]; }
-        const f3 tcurr = {st->tcurr[0], st->tcurr[1], st->tcurr[2]};
-        const f3 tprev = {st->tprev[0], st->tprev[1], st->tprev[2]};
+    for (int i = 0; i < 9; i++) { Rcurr.m[i] = st->Rcurr[i]; Rprev_inv.m[i] = st->Rprev_inv[i]; }
+    const f3 tcurr = {st->tcurr[0], st->tcurr[1], st->tcurr[2]};
+    const f3 tprev = {st->tprev[0], st->tprev[1], st->tprev[2]};
+
+    // projection + gather of the model maps
+    IcpProj pr[PPT];
+    f3 vprev[PPT], nprev[PPT];
+    int cand = 0;
 #pragma unroll
-        for (int p = 0; p < PPT; p++) {
-            float err;
-            icp_pixel(Rcurr, tcurr, Rprev_inv, tprev, args.intr, args.distThres, args.angleThres, cols, rows, N, vp, np,
-                      f3{vx[p], vy[p], vz[p]}, f3{nx[p], ny[p], nz[p]}, row[p], err, fnd[p]);
-            if (errs) errs[i0 + p] = err;
-            any_found |= fnd[p];
+    for (int p = 0; p < PPT; p++) {
+        pr[p] = icp_project(Rcurr, tcurr, Rprev_inv, tprev, args.intr, cols, rows, f3{vx[p], vy[p], vz[p]});
+        if (!in_range) pr[p].inb = 0;
+        vprev[p] = f3{qnan(), qnan(), qnan()}; nprev[p] = f3{qnan(), qnan(), qnan()};
+        if (pr[p].inb) {
+            const int g = pr[p].g;
+            vprev[p] = f3{vp[g], vp[g + N], vp[g + 2 * N]};
+            nprev[p] = f3{np[g], np[g + N], np[g + 2 * N]};
         }
+        // necessary for a correspondence: in view, both normals valid, a finite model vertex
+        cand |= (pr[p].inb && !is_nan(nx[p]) && !is_nan(nprev[p].x) && !is_nan(vprev[p].x)) ? 1 : 0;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // A wave without a single correspondence contributes exact zeros (all rows are zero): skip the accumulation and
-    // the butterfly.  Object models cover a small part of the image, so most of their waves take this exit.
     unsigned long long v = 0;
-    if (__any(any_found) || abl) {
-        unsigned long long acc[32];
+    const bool wave_cand = __any(cand) != 0;
+    if (errs) {  // last level-0 iteration: the error surface stores dist for every pixel (0 if not finite / out of view)
 #pragma unroll
-        for (int k = 0; k < 28; k++) acc[k] = 0ull - (unsigned long long)PPT * kMagicBits;
-        acc[28] = acc[29] = acc[30] = acc[31] = 0;
+        for (int p = 0; p < PPT; p++)
+            if (in_range) {
+                float err = 0.f;
+                if (pr[p].inb) { const float dist = norm(vprev[p] - pr[p].vcurr_g); err = is_finite(dist) ? dist : 0.0f; }
+                errs[i0 + p] = err;
+            }
+    }
+    // A wave without a single candidate contributes exact zeros (all rows are zero): skip the rows, the accumulation and
+    // the butterfly.  Object models cover a small part of the image, so most of their waves take this exit.
+    if (wave_cand || abl) {
+        float row[PPT][7];
+        int fnd[PPT], any_found = 0;
 #pragma unroll
         for (int p = 0; p < PPT; p++) {
-            if (!(abl & 1)) se3_accumulate<kFixICP>(row[p], acc);
-            else acc[0] += __float_as_uint(row[p][6]) + __float_as_uint(row[p][3]);
-            acc[28] += (unsigned long long)fnd[p];
+#pragma unroll
+            for (int k = 0; k < 7; k++) row[p][k] = 0.f;
+            const f3 ncurr_g = mul(Rcurr, f3{nx[p], ny[p], nz[p]});
+            const f3 dv = vprev[p] - pr[p].vcurr_g;
+            const float dist2 = dot(dv, dv);
+            const f3 cr0 = cross(ncurr_g, nprev[p]);
+            const float sine2 = dot(cr0, cr0);
+            fnd[p] = (pr[p].inb && sine2 < args.angleSqLt && dist2 <= args.distSqLe && !is_nan(nx[p]) && !is_nan(nprev[p].x)) ? 1 : 0;
+            any_found |= fnd[p];
+            if (fnd[p]) {
+                const f3 s_cp = mul(Rprev_inv, pr[p].vcurr_g - tprev);
+                const f3 d_cp = mul(Rprev_inv, vprev[p] - tprev);
+                const f3 n_cp = mul(Rprev_inv, nprev[p]);
+                const f3 cr = cross(s_cp, n_cp);
+                row[p][0] = n_cp.x; row[p][1] = n_cp.y; row[p][2] = n_cp.z;
+                row[p][3] = cr.x; row[p][4] = cr.y; row[p][5] = cr.z;
+                row[p][6] = dot(n_cp, s_cp - d_cp);
+            }
         }
-        if (abl & 2) { if (acc[0] + acc[28] == 0x1234567ull) ma.acc[lane] = acc[5]; return; }
-        v = wave_reduce32_u64(acc, lane);
-        if (abl & 4) { if (v == 0x1234567ull) ma.acc[lane] = v; return; }
+        if (__any(any_found) || abl) {
+            unsigned long long acc[32];
+#pragma unroll
+            for (int k = 0; k < 28; k++) acc[k] = 0ull - (unsigned long long)PPT * kMagicBits;
+            acc[28] = acc[29] = acc[30] = acc[31] = 0;
+#pragma unroll
+            for (int p = 0; p < PPT; p++) {
+                if (!(abl & 1)) se3_accumulate<kFixICP>(row[p], acc);
+                else acc[0] += __float_as_uint(row[p][6]) + __float_as_uint(row[p][3]);
+                acc[28] += (unsigned long long)fnd[p];
+            }
+            if (abl & 2) { if (acc[0] + acc[28] == 0x1234567ull) ma.acc[lane] = acc[5]; return; }
+            v = wave_reduce32_u64(acc, lane);
+            if (abl & 4) { if (v == 0x1234567ull) ma.acc[lane] = v; return; }
+        }
     }
     block_commit32<16>(v, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
+}
+
+// host side: the f32 bounds that decide "sqrtf(x) < T" and "sqrtf(x) <= T" exactly (sqrtf is correctly rounded, monotonic)
+float sqrt_gate_lt(float T)
+{   // smallest x with sqrtf(x) >= T  =>  sqrtf(x) < T  <=>  x < bound
+    if (!(T > 0.f)) return 0.f;
+    float x = T * T;
+    while (sqrtf(x) >= T && x > 0.f) x = nextafterf(x, 0.f);
+    while (sqrtf(x) < T) x = nextafterf(x, INFINITY);
+    return x;
+}
+float sqrt_gate_le(float T)
+{   // largest x with sqrtf(x) <= T  =>  sqrtf(x) <= T  <=>  x <= bound
+    if (!(T >= 0.f)) return -1.f;
+    float x = T * T;
+    while (sqrtf(x) <= T) x = nextafterf(x, INFINITY);
+    while (sqrtf(x) > T) x = nextafterf(x, 0.f);
+    return x;
 }
 
 // ================================================================================================
@@ -254,59 +302,133 @@ __global__ void __launch_bounds__(256) rgb_cand_kernel(const int16_t* __restrict
     cand[k] = ok;
 }
 
+// One candidate pixel of the residual pass: the pose-dependent half of RGBResidual::getProducts.
+// Returns validity; g = flat index of the matched pixel in the last image, diff = next - last intensity.
+__device__ __forceinline__ bool rgb_residual_pixel(const RgbArgs& ra, const RgbModelArgs& m, const float* __restrict__ krk,
+                                                   const float* __restrict__ kt, int k, float d1, float ni, int& u0, int& v0, float& diff)
+{
+    const int cols = ra.cols, rows = ra.rows;
+    const int y = k / cols, x = k - y * cols;
+    const float transformed_d1 = (float)(d1 * (krk[6] * x + krk[7] * y + krk[8]) + kt[2]);
+    u0 = f2i_rn((d1 * (krk[0] * x + krk[1] * y + krk[2]) + kt[0]) / transformed_d1);
+    v0 = f2i_rn((d1 * (krk[3] * x + krk[4] * y + krk[5]) + kt[1]) / transformed_d1);
+    if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+        const float d0 = m.lastDepth[v0 * cols + u0];
+        const uint8_t li = m.lastImage[v0 * cols + u0];
+        if (d0 > 0 && fabsf(transformed_d1 - d0) <= ra.maxDepthDelta && li != 0) {
+            diff = ni - (float)li;
+            return true;
+        }
+    }
+    return false;
+}
+
+// COMPACT == false: the reference's output format, one DataTerm record per pixel (valid or not), read back by
+// rgb_step_kernel -- 16 B/pixel written and re-read although < 10 % of the records are valid.
+// COMPACT == true (the device-resident Gauss-Newton loop): four pixels per thread, and the valid correspondences of a
+// workgroup are appended to ONE list per model (8 B records; a returning atomic on the list cursor per workgroup).  The
+// order of the list depends on the schedule, the sums taken over it do not (integer accumulation).  The cursor is word 29
+// of accumulator group 0 -- the same word that counts correspondences -- so the solve sees the count where it always was.
+template <bool COMPACT>
 __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
 {
     const RgbModelArgs& m = ra.m[model];
     const OdomDev* __restrict__ od = m.st;
-    if (!od->rgb || od->level_done) return;
     const int cols = ra.cols, rows = ra.rows, N = cols * rows;
     const int T = blockDim.x;
-    const int k = blk * T + threadIdx.x;
-    int cnt = 0, sig = 0;
-    if (k < N) {
-        cf_dataterm c; c.zero_x = c.zero_y = c.one_x = c.one_y = 0; c.diff = 0.f; c.valid = 0;
-        const uint8_t* __restrict__ cand = m.cand;
-        if (cand[k]) {
-            const float* __restrict__ nextDepth = m.nextDepth;
-            const uint8_t* __restrict__ nextImage = m.nextImage;
-            const float d1 = nextDepth[k];
-            const float ni = (float)nextImage[k];
-            const int y = k / cols, x = k - y * cols;
-            const float* krk = od->krkInv; const float* kt = od->kt;
-            const float transformed_d1 = (float)(d1 * (krk[6] * x + krk[7] * y + krk[8]) + kt[2]);
-            const int u0 = f2i_rn((d1 * (krk[0] * x + krk[1] * y + krk[2]) + kt[0]) / transformed_d1);
-            const int v0 = f2i_rn((d1 * (krk[3] * x + krk[4] * y + krk[5]) + kt[1]) / transformed_d1);
-            if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
-                const float d0 = m.lastDepth[v0 * cols + u0];
-                const uint8_t li = m.lastImage[v0 * cols + u0];
-                if (d0 > 0 && fabsf(transformed_d1 - d0) <= ra.maxDepthDelta && li != 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if constexpr (!COMPACT) {
+        if (!od->rgb || od->level_done) return;
+        const int k = blk * T + threadIdx.x;
+        int cnt = 0, sig = 0;
+        if (k < N) {
+            cf_dataterm c; c.zero_x = c.zero_y = c.one_x = c.one_y = 0; c.diff = 0.f; c.valid = 0;
+            if (m.cand[k]) {
+                int u0, v0; float diff;
+                if (rgb_residual_pixel(ra, m, od->krkInv, od->kt, k, m.nextDepth[k], (float)m.nextImage[k], u0, v0, diff)) {
+                    const int y = k / cols, x = k - y * cols;
                     c.zero_x = (int16_t)u0; c.zero_y = (int16_t)v0; c.one_x = (int16_t)x; c.one_y = (int16_t)y;
-                    c.diff = ni - (float)li;
-                    c.valid = 1;
-                    cnt = 1;
-                    sig = (int)(c.diff * c.diff);
+                    c.diff = diff; c.valid = 1;
+                    cnt = 1; sig = (int)(diff * diff);
                 }
             }
+            *reinterpret_cast<int4*>(&m.corres[k]) = *reinterpret_cast<const int4*>(&c);
         }
-        *reinterpret_cast<int4*>(&m.corres[k]) = *reinterpret_cast<const int4*>(&c);
-    }
-    // block reduce (count, sigma) -> grouped atomics into words 29/30 of the ICP accumulator
+        // block reduce (count, sigma) -> grouped atomics into words 29/30 of the ICP accumulator
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); sig += __shfl_xor(sig, o, 64); }
-    __shared__ int s_cnt[16], s_sig[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { s_cnt[wave] = cnt; s_sig[wave] = sig; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int c4 = 0, g4 = 0;
-        for (int w = 0; w < (T >> 6); w++) { c4 += s_cnt[w]; g4 += s_sig[w]; }
-        unsigned long long* dst = m.icp_acc + (size_t)(blk % kGroups) * 32;
-        if (c4) atomicAdd(&dst[29], (unsigned long long)c4);
-        if (g4) atomicAdd(&dst[30], (unsigned long long)(long long)g4);
+        for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); sig += __shfl_xor(sig, o, 64); }
+        __shared__ int s_cnt[16], s_sig[16];
+        if (lane == 0) { s_cnt[wave] = cnt; s_sig[wave] = sig; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int c4 = 0, g4 = 0;
+            for (int w = 0; w < (T >> 6); w++) { c4 += s_cnt[w]; g4 += s_sig[w]; }
+            unsigned long long* dst = m.icp_acc + (size_t)(blk % kGroups) * 32;
+            if (c4) atomicAdd(&dst[29], (unsigned long long)c4);
+            if (g4) atomicAdd(&dst[30], (unsigned long long)(long long)g4);
+        }
+    } else {
+        __shared__ int s_n, s_sig, s_base;
+        const int k0 = (blk * T + threadIdx.x) * 4;  // cols % 4 == 0: the four pixels share a row
+        unsigned cw = 0;
+        if (k0 < N) cw = *reinterpret_cast<const unsigned*>(m.cand + k0);
+        if (threadIdx.x == 0) { s_n = 0; s_sig = 0; }
+        const bool on = od->rgb && !od->level_done;  // uniform
+        if (!on) return;
+        __syncthreads();
+        int g[4], dq[4], nvalid = 0, sig = 0;
+        if (__any(cw != 0)) {
+            float d1[4] = {0, 0, 0, 0}; unsigned iw = 0;
+            if (cw) {
+                const float4 dv = *reinterpret_cast<const float4*>(m.nextDepth + k0);
+                d1[0] = dv.x; d1[1] = dv.y; d1[2] = dv.z; d1[3] = dv.w;
+                iw = *reinterpret_cast<const unsigned*>(m.nextImage + k0);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                g[p] = -1; dq[p] = 0;
+                if ((cw >> (8 * p)) & 0xffu) {
+                    int u0, v0; float diff;
+                    if (rgb_residual_pixel(ra, m, od->krkInv, od->kt, k0 + p, d1[p], (float)((iw >> (8 * p)) & 0xffu), u0, v0, diff)) {
+                        g[p] = v0 * cols + u0; dq[p] = (int)diff;  // next - last intensity: an integer in [-255, 255]
+                        nvalid++; sig += (int)(diff * diff);
+                    }
+                }
+            }
+            // wave totals, one LDS atomic per wave for the slot offset
+            int wn = nvalid, ws = sig;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { wn += __shfl_xor(wn, o, 64); ws += __shfl_xor(ws, o, 64); }
+            if (wn) {
+                // exclusive prefix of nvalid inside the wave
+                int incl = nvalid;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+                int wbase = 0;
+                if (lane == 0) { wbase = atomicAdd(&s_n, wn); atomicAdd(&s_sig, ws); }
+                wbase = __shfl(wbase, 0, 64);
+                nvalid = wbase + incl - nvalid;  // from here on: this thread's first slot inside the workgroup
+            } else nvalid = -1;
+        } else nvalid = -1;
+        __syncthreads();
+        const int bn = s_n;
+        if (bn == 0) return;
+        if (threadIdx.x == 0) {
+            s_base = (int)atomicAdd(&m.icp_acc[29], (unsigned long long)bn);  // list cursor == correspondence count (group 0)
+            const int g4 = s_sig;
+            if (g4) atomicAdd(&m.icp_acc[(size_t)(blk % kGroups) * 32 + 30], (unsigned long long)(long long)g4);
+        }
+        __syncthreads();
+        if (nvalid >= 0) {
+            uint2* __restrict__ out = m.recs + s_base + nvalid;
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                if (g[p] >= 0) { *out++ = make_uint2((unsigned)(k0 + p), (unsigned)g[p] | ((unsigned)(dq[p] + 256) << 22)); }
+        }
     }
 }
 
-__global__ void __launch_bounds__(1024) rgb_residual_kernel(const RgbArgs ra) { rgb_residual_body(ra, blockIdx.y, blockIdx.x); }
+__global__ void __launch_bounds__(1024) rgb_residual_kernel(const RgbArgs ra) { rgb_residual_body<false>(ra, blockIdx.y, blockIdx.x); }
 
 // sum of word `w` over the groups (wave 0 only; result valid in all lanes of wave 0)
 __device__ __forceinline__ unsigned long long group_sum(const unsigned long long* acc, int w, int lane)
@@ -328,6 +450,28 @@ __device__ __forceinline__ float sigma_val_from(int count, int sigma, int rgbOnl
 // ================================================================================================
 // RGB step: RGBReduction::getProducts, reduce.cu:521-604
 // ================================================================================================
+// Jacobian row of one valid correspondence (o = flat index in the next image, g = in the last image / point cloud)
+__device__ __forceinline__ void rgb_step_row(const RgbArgs& ra, const RgbModelArgs& m, float sigma, float diff, int o, int g, float (&row)[7])
+{
+    const cf_cam il = ra.il;
+    float w = sigma + fabsf(diff);
+    w = w > 1.19209290E-07F ? 1.0f / w : 1.0f;
+    if (sigma == -1) w = 1;
+    row[6] = -w * diff;
+    const float* cp = m.cloud + (size_t)g * 3;
+    const float px = cp[0], py = cp[1], pz = cp[2];
+    const float invz = 1.0f / pz;
+    const float dI_dx_val = w * ra.sobelScale * (float)m.dIdx[o];
+    const float dI_dy_val = w * ra.sobelScale * (float)m.dIdy[o];
+    const float v0 = dI_dx_val * il.fx * invz;
+    const float v1 = dI_dy_val * il.fy * invz;
+    const float v2 = -(v0 * px + v1 * py) * invz;
+    row[0] = v0; row[1] = v1; row[2] = v2;
+    row[3] = -pz * v1 + py * v2;
+    row[4] = pz * v0 - px * v2;
+    row[5] = -py * v0 + px * v1;
+}
+
 __global__ void __launch_bounds__(256) rgb_step_kernel(const RgbArgs ra)
 {
     const RgbModelArgs& m = ra.m[blockIdx.y];
@@ -345,7 +489,6 @@ __global__ void __launch_bounds__(256) rgb_step_kernel(const RgbArgs ra)
         if (i < N) raw = *reinterpret_cast<const int4*>(&m.corres[i]);
         __syncthreads();
         const float sigma = s_sigma;
-        const cf_cam il = ra.il;
         unsigned long long acc[32];
 #pragma unroll
         for (int k = 0; k < 28; k++) acc[k] = 0ull - kMagicBits;
@@ -356,23 +499,7 @@ __global__ void __launch_bounds__(256) rgb_step_kernel(const RgbArgs ra)
             const cf_dataterm c = *reinterpret_cast<const cf_dataterm*>(&raw);
             if (c.valid) {
                 found = 1;
-                float w = sigma + fabsf(c.diff);
-                w = w > 1.19209290E-07F ? 1.0f / w : 1.0f;
-                if (sigma == -1) w = 1;
-                row[6] = -w * c.diff;
-                const float* cp = m.cloud + (size_t)(c.zero_y * cols + c.zero_x) * 3;
-                const float px = cp[0], py = cp[1], pz = cp[2];
-                const float invz = 1.0f / pz;
-                const int o = c.one_y * cols + c.one_x;
-                const float dI_dx_val = w * ra.sobelScale * (float)m.dIdx[o];
-                const float dI_dy_val = w * ra.sobelScale * (float)m.dIdy[o];
-                const float v0 = dI_dx_val * il.fx * invz;
-                const float v1 = dI_dy_val * il.fy * invz;
-                const float v2 = -(v0 * px + v1 * py) * invz;
-                row[0] = v0; row[1] = v1; row[2] = v2;
-                row[3] = -pz * v1 + py * v2;
-                row[4] = pz * v0 - px * v2;
-                row[5] = -py * v0 + px * v1;
+                rgb_step_row(ra, m, sigma, c.diff, c.one_y * cols + c.one_x, c.zero_y * cols + c.zero_x, row);
             }
         }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -560,7 +687,7 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
                         const unsigned target = (unsigned)(it + 1) * G;
                         unsigned spins = 0;
                         while (__hip_atomic_load(&sync->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                            if (++spins > (1u << 22)) break;  // never hang the GPU if the workgroups are not co-resident
+                            if (++spins > (1u << 22)) { od->stats.fault = 1; break; }  // never hang the GPU; the host reports CF_ESTATE
                             __builtin_amdgcn_s_sleep(1);
                         }
                     }
@@ -655,19 +782,15 @@ __device__ __forceinline__ void se3_unpack_word(const unsigned long long* sums, 
 }
 
 // The solve is latency-bound serial work (f64 LDL^T, Rodrigues, SE3 products) on a nearly idle GPU, so:
-//  * every pointer arrives in the kernarg segment and the whole device-resident state is staged through LDS
-//    (no dependent global round trips),
-//  * the embarrassingly parallel pieces (group totals, fixed-point -> f32 unpack, f64 combine, 4x4 / 3x3
-//    products) are spread over lanes with exactly the element expressions of the serial helpers, and K^-1
-//    of the next level is formed by another wave while lane 0 factorises,
-//  * only the pivoted LDL^T + Rodrigues and the 3x3 pose composition stay on one lane.
-// The solve is latency-bound serial work (f64 LDL^T, Rodrigues, SE3 products) on a nearly idle GPU, so:
 //  * the whole device-resident state is staged through LDS (no dependent global round trips),
 //  * the parallel pieces (group totals, fixed-point -> f32 unpack, f64 combine, 4x4 / 3x3 products) are spread
 //    over lanes with exactly the element expressions of the serial helpers, the 6x6 pivoted LDL^T runs across
 //    one wave (ldlt_solve6_wave), and K^-1 of the next level is formed by another wave meanwhile,
 //  * only Rodrigues and the 3x3 pose composition stay on one lane.
 // Must be called by all 256 threads of a workgroup.
+// COHERENT: the RGB accumulators were written by other workgroups of the SAME launch (gn_rgb_solve_kernel): read them with
+// device-scope atomic loads instead of plain (L2-cached) loads.
+template <bool COHERENT>
 __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* icp_acc, unsigned long long* rgb_acc, int next_level,
                                               int last_of_level)
 {
@@ -688,7 +811,8 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
         unsigned long long a = 0, b = 0;
         for (int g = sl * (kGroups / 8); g < (sl + 1) * (kGroups / 8); g++) {
             a += icp_acc[(size_t)g * 32 + w];
-            b += rgb_acc[(size_t)g * 32 + w];
+            if constexpr (COHERENT) b += __hip_atomic_load(&rgb_acc[(size_t)g * 32 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else b += rgb_acc[(size_t)g * 32 + w];
         }
         s_part[0][sl][w] = a; s_part[1][sl][w] = b;
     }
@@ -815,7 +939,79 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
 
 __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int next_level, int last_of_level)
 {
-    gn_solve_body(args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level);
+    gn_solve_body<false>(args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level);
+}
+
+// RGB step over the compact correspondence list + the solve, in ONE launch (grid: G workgroups x models).
+// Every workgroup reduces its stride of the list into the model's RGB accumulators (integer atomics) and arrives at a
+// counter; workgroup 0 waits for the G arrivals -- the others simply leave -- and then runs the solve.  Compared with
+// rgb_step_kernel + gn_solve_kernel this saves a launch boundary per Gauss-Newton iteration, and the list is < 10 % of
+// the DataTerm image the reference re-reads.  The wait is bounded: if the workgroups of a model are not scheduled
+// within the bound (they always are: G x models <= 256 small workgroups), the fault word is set and the host call
+// that fetches the result reports CF_ESTATE instead of returning a pose computed from partial sums.
+__global__ void __launch_bounds__(256) gn_rgb_solve_kernel(const RgbArgs ra, const GnArgs args, GnSync* __restrict__ syncs, int do_rgb,
+                                                           int next_level, int last_of_level)
+{
+    const int model = blockIdx.y;
+    const RgbModelArgs& m = ra.m[model];
+    OdomDev* const god = args.od[model];
+    const unsigned G = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (do_rgb) {
+        if (god->rgb && !god->level_done) {  // uniform over the grid row
+            __shared__ float s_sigma;
+            if (tid < 64) {
+                const long long sg = (long long)group_sum(m.icp_acc, 30, tid);
+                if (tid == 0) s_sigma = sigma_val_from((int)(long long)m.icp_acc[29], (int)sg, god->rgbOnly);
+            }
+            const int count = (int)(long long)m.icp_acc[29];  // list cursor == number of correspondences
+            __syncthreads();
+            const float sigma = s_sigma;
+            const int F = rgb_fix_bits(sigma);
+            const float lim = ldexpf(1.0f, (50 - F) / 2), scale = ldexpf(1.0f, F);
+            unsigned long long acc[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) acc[k] = 0;
+            unsigned long long terms = 0;
+            const uint2* __restrict__ recs = m.recs;
+            for (int r = blockIdx.x * 256 + tid; r < count; r += (int)G * 256) {
+                const uint2 rc = recs[r];
+                float row[7];
+                rgb_step_row(ra, m, sigma, (float)((int)(rc.y >> 22) - 256), (int)rc.x, (int)(rc.y & 0x3fffffu), row);
+                se3_accumulate_dyn(row, acc, lim, scale);
+                terms++;
+            }
+            unsigned long long v = 0;
+            if (__any(terms != 0)) {
+#pragma unroll
+                for (int k = 0; k < 28; k++) acc[k] -= terms * kMagicBits;
+                acc[28] = terms;
+                v = wave_reduce32_u64(acc, lane);
+            }
+            block_commit32<4>(v, lane, wave, 4, m.rgb_acc + (size_t)(blockIdx.x % kGroups) * 32);
+        }
+        if (G > 1) {
+            GnSync* sync = syncs + model;
+            __threadfence();  // this thread's accumulator atomics are performed before the arrival below
+            __syncthreads();
+            if (tid == 0) {
+                atomicAdd(&sync->arrive, 1u);
+                if (blockIdx.x == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(&sync->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+                        if (++spins > (1u << 24)) { god->stats.fault = 1; break; }  // surfaces as CF_ESTATE (cf_odom_fetch_result)
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    __hip_atomic_store(&sync->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (blockIdx.x != 0) return;
+            __threadfence();
+            __syncthreads();
+        }
+    }
+    if (blockIdx.x != 0) return;
+    gn_solve_body<true>(god, args.icp_acc[model], args.rgb_acc[model], next_level, last_of_level);
 }
 
 
@@ -851,7 +1047,8 @@ static void launch_icp_rgbres(hipStream_t s, IcpLaunch cfg, const IcpArgs& args,
                               hipEvent_t ev0, hipEvent_t ev1)
 {
     const int N = (icp ? args.cols * args.rows : ra.cols * ra.rows);
-    const int n_res_blocks = rgb ? (N + cfg.threads - 1) / cfg.threads : 0;
+    const int res_per_block = cfg.threads * (ra.compact ? 4 : 1);  // compact list pass: four pixels per thread
+    const int n_res_blocks = rgb ? (N + res_per_block - 1) / res_per_block : 0;
     // distinct symbols per pyramid level so that rocprofv3 --stats separates them
     // (tag = level for one model, level + 4 for lock-step batches of several models)
     if (n > 1) {
@@ -879,8 +1076,9 @@ void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, 
 // grid barrier, a chain of about five device-scope memory round trips of ~1.5 us each across the XCDs, whereas a dependent
 // launch costs ~2.5 us (tools/microbench/launch_floor.hip).  On this part the kernel boundary IS the cheapest grid barrier.
 // Kept as separate launches.
-void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const IcpArgs icp_args[3],
-                     const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, ProfSink* prof)
+void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, GnSync* gn_syncs, const IcpArgs icp_args[3],
+                     const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, int mode,
+                     ProfSink* prof)
 {
     int iterations[3];
     iterations[0] = fast_odom ? 3 : 10;
@@ -895,6 +1093,7 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
         gn.icp_acc[m] = icp_args[0].m[m].acc;
         gn.rgb_acc[m] = icp_args[0].m[m].rgb_acc;
     }
+    const bool fused = mode != 0;
     for (int i = 2; i >= 0; i--) {
         const int N = (width >> i) * (height >> i);
         for (int j = 0; j < iterations[i]; j++) {
@@ -904,12 +1103,14 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
                 next_level = i - 1;
                 while (next_level >= 0 && iterations[next_level] == 0) next_level--;
             }
+            RgbArgs ra = rgb_args[i];
+            ra.compact = fused ? 1 : 0;
             {
                 // the roofline figure is quoted on the dominant kernel: the level-0 instantiation
                 const bool timed = prof && prof->enabled && i == 0 && prof->used + 4 <= prof->capacity;
                 IcpArgs a = icp_args[i];
                 a.flags = (i == 0 && last_of_level) ? 1 : 0;
-                launch_icp_rgbres(s, cfg, a, rgb_args[i], icp, rgb, n, i, timed ? prof->events[prof->used] : nullptr,
+                launch_icp_rgbres(s, cfg, a, ra, icp, rgb, n, i, timed ? prof->events[prof->used] : nullptr,
                                   timed ? prof->events[prof->used + 1] : nullptr);
                 if (timed) {
                     prof->used += 2;
@@ -917,8 +1118,15 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
                     prof->launches += 1;
                 }
             }
-            if (rgb) rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(rgb_args[i]);
-            gn_solve_kernel<<<n, 256, 0, s>>>(gn, next_level, last_of_level ? 1 : 0);
+            if (fused) {
+                // workgroups per model for the list pass: the list holds at most N/3 records in practice (gradient + depth gates)
+                int G = rgb ? (N >= 640 * 480 ? 32 : (N >= 320 * 240 ? 16 : 8)) : 1;
+                if (G * n > 256) G = 256 / n;
+                gn_rgb_solve_kernel<<<dim3(G, n), 256, 0, s>>>(ra, gn, gn_syncs, rgb ? 1 : 0, next_level, last_of_level ? 1 : 0);
+            } else {
+                if (rgb) rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(ra);
+                gn_solve_kernel<<<n, 256, 0, s>>>(gn, next_level, last_of_level ? 1 : 0);
+            }
         }
     }
 }
@@ -927,7 +1135,8 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
 void launch_rgb_residual(hipStream_t s, const RgbArgs& ra, int n)
 {
     const int N = ra.cols * ra.rows;
-    rgb_residual_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(ra);
+    RgbArgs a = ra; a.compact = 0;
+    rgb_residual_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(a);
 }
 void launch_rgb_step(hipStream_t s, const RgbArgs& ra, int n)
 {

@@ -26,7 +26,7 @@ SYMBOLS = [
     "cf_model_fuse", "cf_model_clean", "cf_model_download_map", "cf_model_upload_map", "cf_model_buffer",
     "cf_fusion_weight", "cf_seg_create", "cf_seg_destroy", "cf_seg_slic", "cf_seg_accumulate", "cf_seg_crf", "cf_seg_upsample",
     "cf_seg_labels",
-    "cf_depth_pyramid", "cf_set_icp_launch", "cf_profile_enable", "cf_profile_read", "cf_odom_bench_icp",
+    "cf_depth_pyramid", "cf_set_icp_launch", "cf_set_gn_mode", "cf_profile_enable", "cf_profile_read", "cf_odom_bench_icp",
 ]
 
 

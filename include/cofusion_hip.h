@@ -158,6 +158,7 @@ typedef struct {
     float last_icp_error, last_icp_count, last_rgb_error, last_rgb_count, last_so3_error, last_so3_count;
     double lastA[36], lastb[6];
     int so3_iterations;
+    int fault;              /* non-zero: a bounded device-side wait expired (cf_odom_fetch_result returns CF_ESTATE) */
 } cf_track_stats;
 
 int cf_odom_create(cf_ctx *ctx, cf_odom **out);
@@ -269,6 +270,10 @@ int cf_seg_upsample(cf_segmenter *s, const uint8_t *low_map_host, uint8_t *full_
 /* device view of the SLIC labels, int32 [H*W] */
 int cf_seg_labels(cf_segmenter *s, void **dptr, uint64_t *bytes);
 
+/* schedule of the device-resident Gauss-Newton loop.  1 (default): two launches per iteration -- {ICP reduction || RGB
+ * residual -> compact correspondence list} and {list pass + solve}; 0: three launches with the reference's DataTerm
+ * image between them (diagnostic / comparison).  Results are bit-identical. */
+int cf_set_gn_mode(cf_ctx *ctx, int mode);
 /* launch-shape tuning of the ICP reduction (GPUConfig.h:51-58 in the reference) */
 int cf_set_icp_launch(cf_ctx *ctx, int threads, int pixels_per_thread);
 
