@@ -145,6 +145,13 @@ int cf_mark(cf_ctx* ctx, int slot)
     ctx->mark_set[slot] = true;
     return CF_OK;
 }
+// host wait for a mark (e.g. before re-using a pinned staging buffer whose transfer was enqueued before the mark)
+int cf_event_wait_host(cf_ctx* ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= cf_ctx::kMarks) return CF_EINVAL;
+    if (ctx->mark_set[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->marks[slot]));
+    return CF_OK;
+}
 int cf_fork_after(cf_ctx* ctx, int lane, int slot)
 {
     if (!ctx || lane < 0 || slot >= cf_ctx::kMarks || ctx->forked) return CF_EINVAL;
@@ -201,6 +208,35 @@ int cf_memcpy_d2h(cf_ctx* ctx, void* dst, const void* src, uint64_t bytes)
     if (!ctx) return CF_EINVAL;
     HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
+}
+
+// pinned host staging + asynchronous upload: the host-input path of the facade copies a frame into pinned memory and
+// enqueues the transfer without waiting for it
+int cf_malloc_host(cf_ctx* ctx, uint64_t bytes, void** hptr)
+{
+    if (!ctx || !hptr) return CF_EINVAL;
+    HIPCHK(ctx, hipHostMalloc(hptr, bytes));
+    return CF_OK;
+}
+int cf_free_host(cf_ctx* ctx, void* hptr) { if (!ctx) return CF_EINVAL; HIPCHK(ctx, hipHostFree(hptr)); return CF_OK; }
+int cf_memcpy_h2d_async(cf_ctx* ctx, void* dst, const void* src_pinned, uint64_t bytes)
+{
+    if (!ctx) return CF_EINVAL;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return CF_OK;
+}
+int cf_memcpy_d2h_async(cf_ctx* ctx, void* dst_pinned, const void* src, uint64_t bytes)
+{
+    if (!ctx) return CF_EINVAL;
+    HIPCHK(ctx, hipMemcpyAsync(dst_pinned, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return CF_OK;
+}
+int cf_rgb_to_rgba(cf_ctx* ctx, const uint8_t* rgb_dev, int cols, int rows, uint8_t* rgba_dev)
+{
+    if (!ctx || !rgb_dev || !rgba_dev || cols <= 0 || rows <= 0) return CF_EINVAL;
+    launch_rgb_expand(ctx->stream, rgb_dev, cols * rows, rgba_dev);
+    LAUNCHCHK(ctx);
     return CF_OK;
 }
 

@@ -61,6 +61,7 @@ void launch_vertices_to_depth(hipStream_t s, const float* v4, int cols, int rows
 void launch_pyrdown_f32(hipStream_t s, const float* src, int scols, int srows, float* dst);
 void launch_pyrdown_u8(hipStream_t s, const uint8_t* src, int scols, int srows, uint8_t* dst);
 void launch_intensity(hipStream_t s, const uint8_t* rgba, int cols, int rows, uint8_t* dst);
+void launch_rgb_expand(hipStream_t s, const uint8_t* rgb, int n, uint8_t* rgba);
 void launch_sobel(hipStream_t s, const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy);
 void launch_cloud(hipStream_t s, const float* depth, int cols, int rows, cf_cam il, float* cloud3);
 
@@ -155,6 +156,8 @@ void launch_rgb_step(hipStream_t s, const RgbArgs& ra, int n);
 // algorithmic bytes per pixel and model of the RGB residual pass: candidate mask 1 + next depth 4 + next
 // intensity 1 + gathered last depth 4 + last intensity 1 + DataTerm record 16
 constexpr uint64_t kRgbResidualBytes = 27;
+// the compact-list flavour writes 8 B per VALID correspondence instead of 16 B per pixel; only its reads are counted
+constexpr uint64_t kRgbResidualBytesCompact = 11;
 void launch_acc_total(hipStream_t s, const unsigned long long* acc, unsigned long long* out);
 void launch_rgb_cand(hipStream_t s, const int16_t* dIdx, const int16_t* dIdy, const float* next_depth,
                      const uint8_t* next_image, float min_scale, int cols, int rows, uint8_t* cand);

@@ -251,6 +251,14 @@ __global__ void __launch_bounds__(kBlock) rgbd_pyrdown_kernel(const RgbdBatch b,
 }
 
 // bgr2IntensityKernel, cudafuncs.cu:626-639 (texel is R,G,B: .114 R + .299 G + .587 B)
+// 3-byte RGB (FrameData.rgb, the host image of CoFusion.cpp:179) -> RGBA8 with alpha 255 (the GL_RGBA texture upload)
+__global__ void __launch_bounds__(kBlock) rgb_expand_kernel(const uint8_t* __restrict__ rgb, int N, uchar4* __restrict__ rgba)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    rgba[i] = make_uchar4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 255);
+}
+
 __global__ void __launch_bounds__(kBlock) intensity_kernel(const uchar4* __restrict__ rgba, int N, uint8_t* __restrict__ dst)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -570,6 +578,10 @@ void launch_pyrdown_u8(hipStream_t s, const uint8_t* src, int scols, int srows, 
 void launch_intensity(hipStream_t s, const uint8_t* rgba, int cols, int rows, uint8_t* dst)
 {
     intensity_kernel<<<grid_for(cols * rows), kBlock, 0, s>>>(reinterpret_cast<const uchar4*>(rgba), cols * rows, dst);
+}
+void launch_rgb_expand(hipStream_t s, const uint8_t* rgb, int n, uint8_t* rgba)
+{
+    rgb_expand_kernel<<<grid_for(n), kBlock, 0, s>>>(rgb, n, reinterpret_cast<uchar4*>(rgba));
 }
 void launch_sobel(hipStream_t s, const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy)
 {

@@ -1114,7 +1114,7 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
                                   timed ? prof->events[prof->used + 1] : nullptr);
                 if (timed) {
                     prof->used += 2;
-                    prof->bytes += (uint64_t)N * ((icp ? 24 + 24 * (uint64_t)n : 0) + (rgb ? kRgbResidualBytes * (uint64_t)n : 0));
+                    prof->bytes += (uint64_t)N * ((icp ? 24 + 24 * (uint64_t)n : 0) + (rgb ? (fused ? kRgbResidualBytesCompact : kRgbResidualBytes) * (uint64_t)n : 0));
                     prof->launches += 1;
                 }
             }

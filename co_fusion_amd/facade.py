@@ -153,6 +153,17 @@ class CoFusion:
         self._check(self.lib.cofusion_model_icp_stats(self.h, index, C.byref(e), C.byref(c)))
         return e.value, c.value
 
+    def model_tracking_inputs(self, index):
+        """host copies of the prediction the next frame's tracking of this model reads: vertex4, normal4 (f32 [H,W,4]), image (u8 [H,W,4])"""
+        H, W = self.height, self.width
+        v = np.empty((H, W, 4), np.float32); n = np.empty((H, W, 4), np.float32); img = np.empty((H, W, 4), np.uint8)
+        self._check(self.lib.cofusion_model_tracking_inputs(self.h, index, v.ctypes.data_as(C.c_void_p), n.ctypes.data_as(C.c_void_p),
+                                                            img.ctypes.data_as(C.c_void_p)))
+        return v, n, img
+
+    def set_gn_mode(self, mode):
+        assert self.abi.cf_set_gn_mode(self._ctx(), int(mode)) == 0
+
     def model_download(self, index):
         n = self.model_info(index)["count"]
         out = np.zeros((max(n, 1), 12), np.float32)

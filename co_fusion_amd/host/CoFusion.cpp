@@ -3,6 +3,7 @@
 // Compiled with -ffp-contract=off: the host arithmetic here is mirrored by the CPU oracle.
 #include "CoFusion.h"
 
+#include <algorithm>
 #include <chrono>
 
 #include <cmath>
@@ -558,8 +559,13 @@ CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
     }
     depthFiltered_dev = depthFilteredBuf[0]; depthPyr1 = depthPyr1Buf[0]; depthPyr2 = depthPyr2Buf[0];
     check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); rgba_dev = static_cast<uint8_t*>(p);
-    check(ctx, cf_malloc(ctx, N, &p), "cf_malloc"); mask_dev = static_cast<uint8_t*>(p);
-    rgbaHost.resize(N * 4);
+    check(ctx, cf_malloc(ctx, N * 3, &p), "cf_malloc"); rgb_dev = static_cast<uint8_t*>(p);
+    check(ctx, cf_malloc(ctx, N, &p), "cf_malloc"); mask_dev = static_cast<uint8_t*>(p);  // zero-filled: the -static mask
+    // host-input path: two pinned staging sets (depth f32 + rgb u8x3), so that copying frame t+1 into one does not wait
+    // for the transfer of frame t out of the other
+    for (int b = 0; b < 2; b++) {
+        check(ctx, cf_malloc_host(ctx, N * 4 + N * 3, &p), "cf_malloc_host"); stage[b] = static_cast<uint8_t*>(p);
+    }
     globalModel = std::make_shared<Model>(ctx, getNextModelID(true), cfg.confGlobalInit, true, cfg.maxSurfels, 3.402823466e+38f,
                                           dist.owner(0) == dist.rank);
     globalModel->loggingPoses = cfg.enablePoseLogging;
@@ -571,7 +577,8 @@ CoFusion::~CoFusion()
     models.clear(); inactiveModels.clear(); newModel.reset(); globalModel.reset();
     cf_free(ctx, depth_dev);
     for (int b = 0; b < 2; b++) { cf_free(ctx, depthFilteredBuf[b]); cf_free(ctx, depthPyr1Buf[b]); cf_free(ctx, depthPyr2Buf[b]); }
-    cf_free(ctx, rgba_dev); cf_free(ctx, mask_dev);
+    cf_free(ctx, rgba_dev); cf_free(ctx, rgb_dev); cf_free(ctx, mask_dev);
+    for (int b = 0; b < 2; b++) if (stage[b]) cf_free_host(ctx, stage[b]);
     labelGenerator.reset();
     cf_destroy(ctx);
 }
@@ -694,12 +701,22 @@ void CoFusion::exchangeTracking()
 bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float weightMultiplier, bool bootstrap)
 {
     const size_t N = (size_t)cfg.width * cfg.height;
+    check(ctx, cf_join(ctx), "cf_join");  // a previous call that threw inside a forked region must not leave the context on a lane
     // upload (CoFusion.cpp:179-184); RGB -> RGBA like the GL_RGBA texture upload
     if (frame.rgba_dev && frame.depth_dev) { curRgba = frame.rgba_dev; curDepth = frame.depth_dev; }
     else {
-        for (size_t i = 0; i < N; i++) { rgbaHost[i * 4] = frame.rgb[i * 3]; rgbaHost[i * 4 + 1] = frame.rgb[i * 3 + 1]; rgbaHost[i * 4 + 2] = frame.rgb[i * 3 + 2]; rgbaHost[i * 4 + 3] = 255; }
-        check(ctx, cf_memcpy_h2d(ctx, rgba_dev, rgbaHost.data(), N * 4), "rgb upload");
-        check(ctx, cf_memcpy_h2d(ctx, depth_dev, frame.depth, N * 4), "depth upload");
+        // one memcpy into pinned staging, transfers only enqueued (no host wait), RGB -> RGBA on the device.  The staging set
+        // used two frames ago is free again once the stream has passed that frame's transfer (stageMark).
+        const unsigned sb = uploads & 1u;
+        if (uploads >= 2) check(ctx, cf_event_wait_host(ctx, 2 + (int)sb), "staging wait");
+        uint8_t* st = stage[sb];
+        memcpy(st, frame.depth, N * 4);
+        memcpy(st + N * 4, frame.rgb, N * 3);
+        check(ctx, cf_memcpy_h2d_async(ctx, depth_dev, st, N * 4), "depth upload");
+        check(ctx, cf_memcpy_h2d_async(ctx, rgb_dev, st + N * 4, N * 3), "rgb upload");
+        check(ctx, cf_mark(ctx, 2 + (int)sb), "cf_mark");
+        check(ctx, cf_rgb_to_rgba(ctx, rgb_dev, cfg.width, cfg.height, rgba_dev), "rgb expand");
+        uploads++;
         curRgba = rgba_dev; curDepth = depth_dev;
     }
     // filterDepth + the depth pyramid only read the new frame.  With a device-resident frame they go to an auxiliary stream that
@@ -714,10 +731,6 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
     check(ctx, cf_bilateral(ctx, curDepth, cfg.width, cfg.height, cfg.depthCutoff, depthFiltered_dev), "filterDepth");
     if (willTrack) check(ctx, cf_depth_pyramid(ctx, depthFiltered_dev, cfg.width, cfg.height, depthPyr1, depthPyr2), "generateCUDATextures");
     if (headAside) check(ctx, cf_join(ctx), "cf_join");
-    if (!cfg.enableMultipleModels) {
-        std::vector<uint8_t> zeros(N, 0);
-        if (tick == 1) check(ctx, cf_memcpy_h2d(ctx, mask_dev, zeros.data(), N), "mask upload");  // stays all-zero afterwards
-    }
 
     if (tick == 1) {
         globalModel->initialise(curRgba, curDepth, depthFiltered_dev, tick, maxDepthProcessed);
@@ -745,9 +758,13 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
                 const int K = (cfg.width / 16) * (cfg.height / 16);
                 std::vector<uint8_t> firstRows((size_t)K * 4);
                 if (frame.rgba_dev) check(ctx, cf_memcpy_d2h(ctx, firstRows.data(), curRgba, (size_t)K * 4), "rgb readback");
-                else memcpy(firstRows.data(), rgbaHost.data(), (size_t)K * 4);
+                else for (int i = 0; i < K; i++) { firstRows[i * 4] = frame.rgb[i * 3]; firstRows[i * 4 + 1] = frame.rgb[i * 3 + 1]; firstRows[i * 4 + 2] = frame.rgb[i * 3 + 2]; firstRows[i * 4 + 3] = 255; }
+                // a new label needs a free model slot: the segmenter holds at most 16 labels and the context was sized for
+                // cfg.maxModels trackers (the reference allows 256 ids, CoFusion.cpp:631-634; its GUI never gets there)
+                const size_t modelCap = (size_t)std::min(cfg.maxModels, 16);
+                const bool allowNew = spawnOffset >= cfg.modelSpawnOffset && models.size() < modelCap;
                 SegmentationResult seg = labelGenerator->performSegmentation(models, frame, curDepth, curRgba, firstRows.data(), getNextModelID(),
-                                                                            spawnOffset >= cfg.modelSpawnOffset, mask_dev);
+                                                                            allowNew, mask_dev);
                 if (!exportSegmentationPrefix.empty()) {  // CoFusion.cpp:235-240: labels > 254 (rejected) are written as 0
                     std::vector<uint8_t> labels(N);
                     check(ctx, cf_memcpy_d2h(ctx, labels.data(), mask_dev, N), "mask readback");

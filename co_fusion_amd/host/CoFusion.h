@@ -248,8 +248,9 @@ class CoFusion {
     float *depth_dev = nullptr, *depthFiltered_dev = nullptr, *depthPyr1 = nullptr, *depthPyr2 = nullptr;
     float *depthFilteredBuf[2] = {nullptr, nullptr}, *depthPyr1Buf[2] = {nullptr, nullptr}, *depthPyr2Buf[2] = {nullptr, nullptr};
     unsigned frameParity = 0;
-    uint8_t *rgba_dev = nullptr, *mask_dev = nullptr;
-    std::vector<uint8_t> rgbaHost;
+    uint8_t *rgba_dev = nullptr, *rgb_dev = nullptr, *mask_dev = nullptr;
+    uint8_t* stage[2] = {nullptr, nullptr};   // pinned staging of the host-input path (depth f32 | rgb u8x3)
+    unsigned uploads = 0;
     const float* curDepth = nullptr;   // device pointers of the frame being processed
     const uint8_t* curRgba = nullptr;
     unsigned modelKeepMinSurfels = 4000;

@@ -108,6 +108,20 @@ int cofusion_model_icp_stats(cofusion_handle* h, int index, float* err, float* c
     if (cnt) *cnt = m->lastStats.last_icp_count;
     return 0;
 }
+int cofusion_model_tracking_inputs(cofusion_handle* h, int index, float* vertex4, float* normal4, uint8_t* image_rgba)
+{
+    Model* m = model_at(h, index);
+    if (!m) { g_err = "model index out of range"; return -1; }
+    if (!m->isOwned()) { g_err = "model is a shadow on this rank"; return -1; }
+    const float* v; const float* n; const uint8_t* img;
+    GUARD(m->trackingInputs(m->requiresFillIn(), h->cf->cfg.frameToFrameRGB, v, n, img));
+    cf_ctx* ctx = h->cf->context();
+    const uint64_t N = (uint64_t)h->cf->cfg.width * h->cf->cfg.height;
+    if (vertex4 && cf_memcpy_d2h(ctx, vertex4, v, N * 16)) { g_err = cf_last_error(ctx); return -1; }
+    if (normal4 && cf_memcpy_d2h(ctx, normal4, n, N * 16)) { g_err = cf_last_error(ctx); return -1; }
+    if (image_rgba && cf_memcpy_d2h(ctx, image_rgba, img, N * 4)) { g_err = cf_last_error(ctx); return -1; }
+    return 0;
+}
 const uint8_t* cofusion_mask_device(cofusion_handle* h) { return h->cf->maskDevice(); }
 void* cofusion_context(cofusion_handle* h) { return h->cf->context(); }
 int cofusion_set_crf(cofusion_handle* h, float uwe, float uke, float thn, float wa, float ws, float srgb, float sdepth, float spos, float minr,

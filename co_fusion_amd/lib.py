@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcofusion_hip.so")
 
 # every symbol include/cofusion_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "cf_create", "cf_destroy", "cf_last_error", "cf_set_stream", "cf_use_own_stream", "cf_get_stream", "cf_synchronize", "cf_fork", "cf_main", "cf_join", "cf_mark", "cf_fork_after", "cf_malloc",
-    "cf_free", "cf_memcpy_h2d", "cf_memcpy_d2h", "cf_create_vmap", "cf_create_nmap", "cf_copy_maps", "cf_resize_map",
+    "cf_create", "cf_destroy", "cf_last_error", "cf_set_stream", "cf_use_own_stream", "cf_get_stream", "cf_synchronize", "cf_fork", "cf_main", "cf_join", "cf_mark", "cf_event_wait_host", "cf_fork_after", "cf_malloc",
+    "cf_free", "cf_memcpy_h2d", "cf_memcpy_d2h", "cf_malloc_host", "cf_free_host", "cf_memcpy_h2d_async", "cf_memcpy_d2h_async", "cf_rgb_to_rgba", "cf_create_vmap", "cf_create_nmap", "cf_copy_maps", "cf_resize_map",
     "cf_transform_maps", "cf_vertices_to_depth", "cf_pyrdown_gauss_f32", "cf_pyrdown_gauss_u8",
     "cf_rgba_to_intensity", "cf_sobel", "cf_project_cloud", "cf_icp_step", "cf_icp_step_band", "cf_rgb_residual", "cf_rgb_step",
     "cf_so3_step", "cf_odom_create", "cf_odom_destroy", "cf_odom_init_icp_model", "cf_odom_init_rgb_model",
@@ -48,7 +48,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "lib", "libcofusion.so")
 HOST_SYMBOLS = [
     "cofusion_default_config", "cofusion_create", "cofusion_destroy", "cofusion_last_error", "cofusion_set_stream",
     "cofusion_process_frame", "cofusion_process_frame_device", "cofusion_num_models", "cofusion_tick", "cofusion_model_info",
-    "cofusion_model_download", "cofusion_model_icp_stats", "cofusion_mask_device", "cofusion_context", "cofusion_set_crf",
+    "cofusion_model_download", "cofusion_model_icp_stats", "cofusion_model_tracking_inputs", "cofusion_mask_device", "cofusion_context", "cofusion_set_crf",
     "cofusion_save_ply", "cofusion_export_poses", "cofusion_set_export_segmentation", "cofusion_klg_open", "cofusion_klg_next", "cofusion_klg_close",
     "cofusion_klg_create", "cofusion_klg_write", "cofusion_klg_finish", "cofusion_debug_phase_ms", "cofusion_set_allreduce", "cofusion_model_owned",
 ]

@@ -46,6 +46,9 @@ int cofusion_tick(cofusion_handle *h);
 int cofusion_model_info(cofusion_handle *h, int index, unsigned *id, unsigned *count, float pose[16], float *conf_threshold);
 int cofusion_model_download(cofusion_handle *h, int index, float *surfels, uint32_t capacity, uint32_t *count);
 int cofusion_model_icp_stats(cofusion_handle *h, int index, float *icp_error, float *icp_count);
+/* host copies of what the NEXT frame's tracking of this model reads (Model::initICP, Model.cpp:350-367): the predicted
+ * vertex+conf / normal+radius maps (f32x4 [H*W]) and the predicted image (rgba8 [H*W]); any pointer may be NULL */
+int cofusion_model_tracking_inputs(cofusion_handle *h, int index, float *vertex4, float *normal4, uint8_t *image_rgba);
 /* device pointer of the full-resolution label mask (u8 [H*W]) */
 const uint8_t *cofusion_mask_device(cofusion_handle *h);
 /* the underlying C-ABI context (profiling hooks etc.) */

@@ -17,7 +17,7 @@
  *   pose            f32[16] ROW-major T(model <- camera)      (Eigen::Matrix4f in the reference)
  *   SE3 sums        int64[32]: 27 upper-triangular products row_i*row_j (i<6, i<=j<7) in
  *                   Q31.32 fixed point, [27] = sum r^2 (Q31.32), [28] = inlier count.  The RGB step's sums use
- *                   CF_FIX_RGB fraction bits, which follow its sigma argument (see the define below)
+ *                   CF_FIX_RGB_BITS(sigma) fraction bits (see below)
  *   surfel          12 f32 (48 B): [x y z conf][colour24 0 initTime lastTime][nx ny nz radius]
  *                   (Core/Shaders/Vertex.cpp:21-43)
  */
@@ -40,7 +40,19 @@ extern "C" {
 #define CF_SE3_WORDS 32
 #define CF_SO3_WORDS 16
 #define CF_FIX_ICP 32
-#define CF_FIX_RGB 32       /* sigma >= 4096; in general 8 + 2*floor(log2 sigma) capped at 32, 8 for sigma in {-1, <2} */
+/* Fraction bits of the RGB step's sums are NOT a constant: they follow the sigma handed to rgbStep --
+ * 8 + 2*floor(log2 sigma) capped at 32, and 8 for sigma in {-1, < 2}.  Readers of cf_rgb_step's sums_host must use
+ * CF_FIX_RGB_BITS(sigma); CF_FIX_RGB_MAX is only the cap (reached for sigma >= 4096). */
+#define CF_FIX_RGB_MAX 32
+static inline int CF_FIX_RGB_BITS(float sigma)
+{
+    union { float f; uint32_t u; } v;
+    int F;
+    if (sigma == -1.0f || !(sigma >= 2.0f)) return 8;
+    v.f = sigma;
+    F = 8 + 2 * ((int)((v.u >> 23) & 255u) - 127);
+    return F > CF_FIX_RGB_MAX ? CF_FIX_RGB_MAX : F;
+}
 #define CF_FIX_SO3 12
 
 typedef struct cf_ctx cf_ctx;
@@ -48,6 +60,19 @@ typedef struct cf_odom cf_odom;
 typedef struct cf_model cf_model;
 
 typedef struct { float fx, fy, cx, cy; } cf_cam; /* CameraModel, Core/Cuda/types.cuh:83-99 */
+
+/* one surfel of a model map, byte-compatible with the reference's VBO vertex (Core/Shaders/Vertex.cpp:21-43):
+ * what cf_model_download_map / cf_model_upload_map move */
+typedef struct {
+    float x, y, z, conf;
+    float colour24, unused, init_time, last_time; /* colour: r<<16 | g<<8 | b stored as a float (color_encoding.glsl) */
+    float nx, ny, nz, radius;
+} cf_surfel;
+#ifdef __cplusplus
+static_assert(sizeof(cf_surfel) == 48, "surfel record is 3 x float4");
+#else
+_Static_assert(sizeof(cf_surfel) == 48, "surfel record is 3 x float4");
+#endif
 
 /* DataTerm, Core/Cuda/types.cuh:75-81 */
 typedef struct {
@@ -86,12 +111,21 @@ int cf_join(cf_ctx *ctx);
  * ordered after that point only (slot < 0: after nothing): for work that does not depend on what the stream still has queued,
  * e.g. filtering the next frame while the previous frame's fusion passes run.  cf_join orders the stream after the lane. */
 int cf_mark(cf_ctx *ctx, int slot);
+int cf_event_wait_host(cf_ctx *ctx, int slot); /* block the host until the stream has passed cf_mark(slot) */
 int cf_fork_after(cf_ctx *ctx, int lane, int slot);
 /* device memory helpers for hosts that do not link HIP themselves */
 int cf_malloc(cf_ctx *ctx, uint64_t bytes, void **dptr);
 int cf_free(cf_ctx *ctx, void *dptr);
 int cf_memcpy_h2d(cf_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int cf_memcpy_d2h(cf_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+/* pinned host memory + copies that are only ENQUEUED on the context's stream (the host side of the buffer must stay
+ * untouched until the stream has passed the copy: cf_mark / cf_synchronize) */
+int cf_malloc_host(cf_ctx *ctx, uint64_t bytes, void **hptr);
+int cf_free_host(cf_ctx *ctx, void *hptr);
+int cf_memcpy_h2d_async(cf_ctx *ctx, void *dst, const void *src_pinned, uint64_t bytes);
+int cf_memcpy_d2h_async(cf_ctx *ctx, void *dst_pinned, const void *src, uint64_t bytes);
+/* FrameData.rgb (3 B/pixel, device copy) -> RGBA8 with alpha 255: the GL_RGBA upload of CoFusion.cpp:179 */
+int cf_rgb_to_rgba(cf_ctx *ctx, const uint8_t *rgb_dev, int cols, int rows, uint8_t *rgba_dev);
 
 /* --------------------------------------------- map preparation (cudafuncs.cuh) ---- */
 /* createVMap  cudafuncs.cuh:125-130 */
@@ -284,7 +318,9 @@ int cf_odom_bench_icp(cf_odom *od, int level, int iters, float *avg_us);
 typedef struct {
     double icp_ms_total;   /* accumulated GPU time of ICP-reduce launches since last reset */
     uint64_t icp_launches;
-    uint64_t icp_bytes;    /* algorithmic bytes: 48 B/pixel/launch */
+    uint64_t icp_bytes;    /* algorithmic bytes of those launches: per level-0 pixel (24 + 24*M) for the ICP reduction of the M
+                            * lock-step models + 11*M for the residual passes that share the launch (27*M with
+                            * cf_set_gn_mode 0, which writes the 16 B DataTerm records) */
 } cf_profile;
 int cf_profile_enable(cf_ctx *ctx, int on);
 int cf_profile_read(cf_ctx *ctx, cf_profile *out, int reset);

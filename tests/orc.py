@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_LIB = os.path.join(_ROOT, "oracle", "_build", "liborc.so")
+# ORC_LIB: another build of the same sources (bench.py times oracle/_build/liborc_native.so, -O3 -march=native)
+_LIB = os.environ.get("ORC_LIB") or os.path.join(_ROOT, "oracle", "_build", "liborc.so")
 
 
 def build():

@@ -116,12 +116,13 @@ class OModel:
 
 class MultiPipeline:
     def __init__(self, cam, depth_cutoff=5.0, icp_weight=10.0, conf_global=10.0, conf_object=0.01, outlier_coeff=3.0, so3=True,
-                 spawn_offset=22, seg_params=None):
+                 spawn_offset=22, seg_params=None, max_models=16):
         self.ocam = orc.Cam(cam.fx, cam.fy, cam.cx, cam.cy)
         self.w, self.h = cam.width, cam.height
         self.depth_cutoff, self.icp_weight, self.outlier, self.so3 = depth_cutoff, icp_weight, outlier_coeff, so3
         self.conf_object = conf_object
         self.model_spawn_offset = spawn_offset
+        self.max_models = min(max_models, 16)  # host/CoFusion.cpp: a new label needs a free model slot
         self.spawn_offset = 0
         self.seg_params = seg_params or SegParams.defaults()
         self.tick = 1
@@ -175,7 +176,7 @@ class MultiPipeline:
             self._track(depth_filt, rgba)
             if self.spawn_offset < self.model_spawn_offset:
                 self.spawn_offset += 1
-            allow_new = self.spawn_offset >= self.model_spawn_offset
+            allow_new = self.spawn_offset >= self.model_spawn_offset and len(self.models) < self.max_models
             ids = [m.id for m in self.models]
             if gt_mask is not None:
                 seg = segment_gt(gt_mask, depth, ids, self._next_model_id(), allow_new, self.gt_mapping)

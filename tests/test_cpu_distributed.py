@@ -95,3 +95,20 @@ def test_assign_models_and_bands_single_process():
     assert pl[0] == [0] and all(len(v) >= 1 for v in pl.values())
     bands = parallel.row_bands(480, 8)
     assert bands[0].start == 0 and bands[-1].stop == 480 and sum(len(b) for b in bands) == 480
+
+
+def test_bench_gpus_2_respawns_and_reports_two_ranks():
+    """`python bench.py --gpus 2` from a plain shell re-executes itself under torch.distributed.run (one process per rank),
+    runs the timing contract over the process group and prints ONE JSON line with n_gpus == 2 (round 1 silently ran one rank).
+    --dry-run replaces processFrame by a stub step: there is no GPU here."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2
+    assert out["scaling"] == "strong" and out["config"]["parallel"] == "models"   # default partition of N > 1: models over ranks
+    assert out["ms_per_step"] >= 2.0 * 0.9        # MAX over ranks: rank 1 sleeps 2 ms per step
