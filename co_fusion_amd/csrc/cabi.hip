@@ -60,6 +60,10 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     if (int r = dmalloc(ctx, &ctx->d_so3_sync, (size_t)ctx->cfg.max_models + 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_gn_sync, (size_t)ctx->cfg.max_models + 1)) return r;
     if (const char* e = getenv("CF_GN_MODE")) ctx->gn_mode = atoi(e);  // diagnostic: 0 = three launches per iteration
+    if (const char* e = getenv("CF_ICP_LAUNCH")) {  // diagnostic: "threads,pixels_per_thread"
+        int t = 0, p = 0;
+        if (sscanf(e, "%d,%d", &t, &p) == 2 && cf_set_icp_launch(ctx, t, p) != CF_OK) { ctx->set_error("CF_ICP_LAUNCH: bad value"); return CF_EINVAL; }
+    }
     if (int r = dmalloc(ctx, &ctx->d_cand_scratch, (size_t)cfg->width * cfg->height)) return r;
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scratch_state), sizeof(OdomDev)));
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_model_ptrs), sizeof(OdomDev*) * (ctx->cfg.max_models + 1)));

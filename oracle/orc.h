@@ -158,6 +158,9 @@ typedef struct {
 } orc_seg_model;
 int orc_connected_labels(const uint8_t *in, int cols, int rows, int *comp, int *stats6, int max_stats);
 void orc_slic(const uint8_t *rgba, int cols, int rows, int32_t *labels);
+void orc_crf_kernel(const float *feat, int D, int n, float *Kn);
+void orc_crf_exp_and_normalize(const float *in, float *out, int L, int n);
+void orc_crf_apply(const float *Kn, int n, int L, float w, const float *Q, float *out);
 void orc_crf_meanfield(const float *unary, int L, int n, const float *feat_smooth, const float *feat_app, float w_smooth,
                        float w_app, int iterations, float *Q);
 int orc_segment_crf(const orc_seg_params *P, int cols, int rows, const uint8_t *rgba, const float *depth, int n_models,

@@ -220,6 +220,26 @@ static void crf_kernel(const float *feat, int D, int n, float *Kn)
     free(norm);
 }
 
+/* The three operations of the mean-field loop as separate entry points: the reference pin (oracle/ref_shim/include/densecrf.h)
+ * lets the reference's OWN inference loop (Segmentation.cpp:452-470) call them in place of the absent densecrf library. */
+void orc_crf_kernel(const float *feat, int D, int n, float *Kn) { crf_kernel(feat, D, n, Kn); }
+void orc_crf_exp_and_normalize(const float *in, float *out, int L, int n) { exp_and_normalize(in, out, L, n); }
+/* out[i][l] = -w * sum_j Kn[i][j] Q[j][l]  (PottsCompatibility applied to the filtered marginals), blocked summation order */
+void orc_crf_apply(const float *Kn, int n, int L, float w, const float *Q, float *out)
+{
+    const int len = (n + CRF_CHUNKS - 1) / CRF_CHUNKS;
+    for (int i = 0; i < n; i++)
+        for (int l = 0; l < L; l++) {
+            float a = 0;
+            for (int c = 0; c < CRF_CHUNKS; c++) {
+                float pa = 0;
+                for (int j = c * len; j < n && j < (c + 1) * len; j++) pa += Kn[(size_t)i * n + j] * Q[(size_t)j * L + l];
+                a += pa;
+            }
+            out[(size_t)i * L + l] = -w * a;
+        }
+}
+
 void orc_crf_meanfield(const float *unary /* [n][L] */, int L, int n, const float *feat_smooth /* [n][2] */,
                        const float *feat_app /* [n][6] */, float w_smooth, float w_app, int iterations, float *Q /* [n][L] */)
 {

@@ -95,9 +95,24 @@ def main() -> int:
         obj = os.path.join(tmp, "gl_all.o")
         subprocess.check_call(["g++", *flags, "-I", os.path.dirname(HERE), "-c", gen, "-o", obj])
         objs.append(obj)
-        # the header-only connected-components pass of the segmentation stage (cv::Mat stand-in: include/opencv2/)
-        obj = os.path.join(tmp, "ref_cc.o")
-        subprocess.check_call(["g++", *flags, "-I", os.path.join(REF, "Core"), "-c", os.path.join(HERE, "ref_cc.cpp"), "-o", obj])
+        # the segmentation stage: Slic.cpp as it lies; Segmentation.cpp's text goes into a generated file under <tmp>/Segmentation/
+        # so that its `#include "../Model/Model.h"` (OpenGL-backed class) resolves to the three-method stand-in copied to
+        # <tmp>/Model/Model.h; gSLICr / densecrf / Eigen / OpenCV stand-ins come from include/.  The harness is appended.
+        seg_dir = os.path.join(REF, "Core", "Segmentation")
+        seg_flags = [f for f in flags if f != "-std=c++14"] + ["-std=c++17", "-I", seg_dir, "-I", os.path.join(REF, "Core"), "-I", os.path.join(os.path.dirname(HERE))]
+        obj = os.path.join(tmp, "Slic.o")
+        subprocess.check_call(["g++", *seg_flags, "-c", os.path.join(seg_dir, "Slic.cpp"), "-o", obj])
+        objs.append(obj)
+        os.makedirs(os.path.join(tmp, "Segmentation")); os.makedirs(os.path.join(tmp, "Model"))
+        with open(os.path.join(tmp, "Model", "Model.h"), "w") as f:
+            f.write(open(os.path.join(HERE, "stub", "Model", "Model.h")).read())
+        gen = os.path.join(tmp, "Segmentation", "Segmentation_gen.cpp")
+        with open(gen, "w") as f:
+            f.write(f'#line 1 "{os.path.join(seg_dir, "Segmentation.cpp")}"\n' + open(os.path.join(seg_dir, "Segmentation.cpp")).read() +
+                    f'\n#include "{os.path.join(HERE, "ref_seg.cpp")}"\n#include "{os.path.join(HERE, "ref_cc.cpp")}"\n')  # ref_cc: the
+            # header-only connected-components pass on its own (ConnectedLabels.hpp defines non-inline functions: one TU only)
+        obj = os.path.join(tmp, "Segmentation.o")
+        subprocess.check_call(["g++", *seg_flags, "-c", gen, "-o", obj])
         objs.append(obj)
         orc_dir = os.path.join(os.path.dirname(HERE), "_build")  # orc_inverse_pose (host-side pose inverse) comes from the oracle
         subprocess.check_call(["g++", "-shared", "-o", os.path.join(OUT, "libcofusion_ref.so"), *objs, "-L", orc_dir, "-lorc",
