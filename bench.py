@@ -225,7 +225,10 @@ def main(argv=None):
     for si in range(S):
         cam, frames = make_stream(W, H, args.frames, n_obj=n_obj, seed=1234 + (0 if model_parallel else rank * 64) + si)
         cfi = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels,
-                              enable_multiple_models=int(n_obj > 0), device_frames_complete=1,  # the ring of frames is resident before timing starts
+                              enable_multiple_models=int(n_obj > 0),
+                              # single GPU / independent streams: the ring of frames is resident before timing starts; model-parallel:
+                              # ranks > 0 receive every frame by broadcast just before the call, so frames are consumed in stream order
+                              device_frames_complete=0 if model_parallel else 1,
                               **(dict(rank=rank, world=world) if model_parallel else {}))
         if model_parallel:
             cfi.set_allreduce()
@@ -237,7 +240,12 @@ def main(argv=None):
         if S > 1:  # every stream of work on its own HIP stream (the default is torch's current stream)
             hip_stream = torch.cuda.Stream(device=dev)
             cfi.set_stream(hip_stream)
-        resident = [dict(depth=torch.from_numpy(f["depth"]).to(dev), rgba=torch.from_numpy(f["rgba"]).to(dev)) for f in frames]
+        if model_parallel and rank != 0:
+            # the ingest GPU is rank 0: the other ranks own no frames, only a two-deep landing buffer for the broadcast
+            resident = [dict(depth=torch.empty((H, W), dtype=torch.float32, device=dev), rgba=torch.empty((H, W, 4), dtype=torch.uint8, device=dev))
+                        for _ in range(2)]
+        else:
+            resident = [dict(depth=torch.from_numpy(f["depth"]).to(dev), rgba=torch.from_numpy(f["rgba"]).to(dev)) for f in frames]
         streams.append(dict(cf=cfi, frames=frames, resident=resident, hip_stream=hip_stream))
     cf, frames = streams[0]["cf"], streams[0]["frames"]
     torch.cuda.synchronize()
@@ -251,6 +259,12 @@ def main(argv=None):
             # GT masks are a host-side input of the reference (FrameData.mask); depth/rgb stay host too in this mode
             f = st["frames"][k]
             st["cf"].process_frame(f["depth"], f["rgb"], mask=gt_mask(f), timestamp=i)
+        elif model_parallel:
+            # frame from the ingest GPU (rank 0) to every rank: two broadcasts over xGMI (depth 1.2 MB + colour 1.2 MB at 640x480)
+            buf = st["resident"][k] if rank == 0 else st["resident"][i & 1]
+            dist.broadcast(buf["depth"], src=0)
+            dist.broadcast(buf["rgba"], src=0)
+            st["cf"].process_frame_device(buf["depth"], buf["rgba"], timestamp=i)
         else:
             st["cf"].process_frame_device(st["resident"][k]["depth"], st["resident"][k]["rgba"], timestamp=i)
 
@@ -496,7 +510,7 @@ def cpu_baseline(cf, cam, frames, i0, step_stream, st, budget_s):
     import orc
     import orc_pipeline as op
     n = len(frames)
-    ncpu = os.cpu_count() or 1
+    ncpu = orc.usable_cpus()   # affinity mask and cgroup quota, not the number of CPUs the box shows
     omp = ctypes.CDLL("libgomp.so.1")
     # sample: a few consecutive frames of the running sequence; inputs are what the GPU tracker of each model is about to read
     samples = []
@@ -538,7 +552,7 @@ def cpu_baseline(cf, cam, frames, i0, step_stream, st, budget_s):
         return dict(value=round(1.0 / med, 3), unit="frames/s", ms_per_frame=round(1e3 * med, 2), cores=threads, kind="port",
                     sample=f"median of {len(times)} frame trackings ({sum(times):.1f} s) over {len(samples)} frames sampled from this run x "
                            f"{len(samples[0]['models'])} active models each; oracle odometry path (map preparation + SO3 + 4/5/10 ICP+RGB GN "
-                           f"iterations per model), gcc -O3 -march=native -fopenmp, {threads} of {ncpu} host threads")
+                           f"iterations per model), gcc -O3 -march=native -fopenmp, {threads} of {ncpu} usable host threads ({os.cpu_count()} visible)")
 
     return leg(1, 100), leg(ncpu, 100)
 

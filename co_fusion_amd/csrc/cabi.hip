@@ -236,6 +236,12 @@ int cf_memcpy_d2h_async(cf_ctx* ctx, void* dst_pinned, const void* src, uint64_t
     HIPCHK(ctx, hipMemcpyAsync(dst_pinned, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return CF_OK;
 }
+int cf_memcpy_d2d_async(cf_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+    if (!ctx) return CF_EINVAL;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return CF_OK;
+}
 int cf_rgb_to_rgba(cf_ctx* ctx, const uint8_t* rgb_dev, int cols, int rows, uint8_t* rgba_dev)
 {
     if (!ctx || !rgb_dev || !rgba_dev || cols <= 0 || rows <= 0) return CF_EINVAL;

@@ -314,6 +314,316 @@ __global__ void __launch_bounds__(256) crf_update_kernel(const float* __restrict
     }
 }
 
+
+// --------------------------------------------------- device-side unaries and post-processing ----
+// Everything Segmentation::performSegmentationCRF does around SLIC and the mean field (Segmentation.cpp:160-300, 475-646), on the
+// device: the host no longer reads the sums back to build the unaries, uploads them, reads the marginals back for the component
+// analysis and uploads the label map (four host waits per multi-object frame); only the decisions come back.  Sequential f32 sums of
+// the reference (average confidence, depth statistics) stay sequential -- one lane per model walks the K superpixels in index order --
+// so the results are those of the host code (and of the oracle) bit for bit.
+constexpr float kSegMaxDepth = 100.f;  // Segmentation::MAX_DEPTH
+
+struct SegUnaryArgs {
+    int K, gx, gy, n_models, L, allow_new;
+    float unaryWeightError, unaryKError, unaryThresholdNew, scaleFeaturesRGB, scaleFeaturesDepth, scaleFeaturesPos;
+    unsigned* spix_count; unsigned* depth_count;
+    unsigned long long* depth_sum; unsigned long long* icp_sum; unsigned long long* conf_sum;   // [K], [n][K], [n][K]; zeroed on exit
+    const int* resample;
+    const uchar4* rgba;              // the CRF colour features read the first K pixels of the full-resolution image (sic, :445-447)
+    float* raw;                      // scratch [(1 + 2n)][K]
+    float* low;                      // [(1 + 2n)][K]: lowDepth, lowICP[m], lowConf[m]
+    float* unary; float* feat2;      // [K][L], [K][6]
+    float* avg_conf;                 // [n]
+    float* depth_range;              // [1]
+};
+
+// Slic::downsample<float> normalisation incl. the empty-superpixel fallback (Slic.h:63-76, 192-206) evaluated in place and in index
+// order by the reference: an empty superpixel k reads entry `read`, which has ALREADY been divided when read < k and is still the
+// raw sum when read > k.  Non-empty entries do not depend on anything else (phase 1, parallel); the rare empty ones are replayed in
+// index order by one lane per array (phase 2).
+__global__ void __launch_bounds__(1024) seg_unary_kernel(const SegUnaryArgs a)
+{
+    const int K = a.K, n = a.n_models, A = 1 + 2 * n, L = a.L;
+    const int tid = threadIdx.x, T = blockDim.x;
+    __shared__ float s_min[16], s_max[16];
+    __shared__ float s_range;
+    // A: raw sums as f32, phase 1 of the normalisation
+    for (int idx = tid; idx < A * K; idx += T) {
+        const int arr = idx / K, k = idx - arr * K;
+        const unsigned long long* sums = arr == 0 ? a.depth_sum : (arr <= n ? a.icp_sum + (size_t)(arr - 1) * K : a.conf_sum + (size_t)(arr - 1 - n) * K);
+        const float raw = (float)((double)(long long)sums[k] * 2.3283064365386963e-10 /* 2^-32 */);
+        a.raw[idx] = raw;
+        const int cnt = (int)(arr == 0 ? a.depth_count[k] : a.spix_count[k]);
+        a.low[idx] = cnt != 0 ? raw / (float)cnt : raw;
+    }
+    __syncthreads();
+    // phase 2: empty superpixels in index order, one lane per array
+    if (tid < A) {
+        float* low = a.low + (size_t)tid * K;
+        const float* raw = a.raw + (size_t)tid * K;
+        for (int k = 0; k < K; k++) {
+            const int own = (int)(tid == 0 ? a.depth_count[k] : a.spix_count[k]);
+            if (own != 0) continue;
+            const int read = a.resample[k];
+            const int cnt = (int)a.spix_count[read];
+            const float base = read < k ? low[read] : raw[read];
+            low[k] = base / (float)cnt;
+        }
+    }
+    __syncthreads();
+    // depth range over the valid low-resolution depths (Segmentation.cpp:165-176)
+    {
+        float mn = 3.402823466e+38f, mx = 0.f;
+        for (int k = tid; k < K; k += T) {
+            const float d = a.low[k];
+            if (d > kSegMaxDepth || d < 0 || !is_finite(d)) continue;
+            if (mx < d) mx = d;
+            if (mn > d) mn = d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float omn = __shfl_xor(mn, o, 64), omx = __shfl_xor(mx, o, 64);
+            if (omn < mn) mn = omn;
+            if (mx < omx) mx = omx;
+        }
+        if ((tid & 63) == 0) { s_min[tid >> 6] = mn; s_max[tid >> 6] = mx; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < (T >> 6); w++) { if (s_min[w] < mn) mn = s_min[w]; if (mx < s_max[w]) mx = s_max[w]; }
+            s_range = mx - mn;
+            a.depth_range[0] = s_range;
+        }
+    }
+    // average confidence per model: a sequential f32 sum in index order (:193-203); non-finite entries are zeroed in place
+    if (tid >= 64 && tid < 64 + n) {
+        float* conf = a.low + (size_t)(1 + n + (tid - 64)) * K;
+        float avg = 0;
+        for (int j = 0; j < K; j++) {
+            const float c = conf[j];
+            if (!is_finite(c)) { conf[j] = 0; continue; }
+            avg += c;
+        }
+        a.avg_conf[tid - 64] = avg / (float)K;
+    }
+    __syncthreads();
+    const float depthRange = s_range;
+    // unaries (:237-298, 458-460) and the appearance features (:441-450), one lane per superpixel
+    for (int k = tid; k < K; k += T) {
+        float* icp = a.low + (size_t)K;           // [n][K]
+        const float* conf = a.low + (size_t)(1 + n) * K;
+        if ((double)conf[k] < 0.3) icp[k] = (float)((double)depthRange * 0.01);
+        for (int i = 1; i < n; i++)
+            if ((double)conf[(size_t)i * K + k] <= 0.4) icp[(size_t)i * K + k] = depthRange * a.unaryKError;
+        float lowestError = icp[k] / depthRange;
+        for (int i = 0; i < n; i++) {
+            float error = icp[(size_t)i * K + k];
+            error /= depthRange;
+            if (error < lowestError) lowestError = error;
+            float u = a.unaryWeightError * error;
+            if (u <= 1e-5f) u = 1e-5f;
+            a.unary[(size_t)k * L + i] = u;
+        }
+        if (a.allow_new) {
+            float u = fmaxf(a.unaryThresholdNew - a.unaryWeightError * lowestError, 0.01f);
+            if (u <= 1e-5f) u = 1e-5f;
+            a.unary[(size_t)k * L + n] = u;
+        }
+        const int i = k % a.gx, j = k / a.gx;
+        const uchar4 p = a.rgba[k];
+        float* f = a.feat2 + (size_t)k * 6;
+        f[0] = (float)i * a.scaleFeaturesPos; f[1] = (float)j * a.scaleFeaturesPos;
+        f[2] = (float)p.x * a.scaleFeaturesRGB; f[3] = (float)p.y * a.scaleFeaturesRGB; f[4] = (float)p.z * a.scaleFeaturesRGB;
+        f[5] = fminf(a.low[k] * a.scaleFeaturesDepth, 100.0f);
+    }
+    __syncthreads();
+    // leave the accumulators clean for the next frame
+    for (int k = tid; k < K; k += T) { a.spix_count[k] = 0; a.depth_count[k] = 0; a.depth_sum[k] = 0; }
+    for (int idx = tid; idx < n * K; idx += T) { a.icp_sum[idx] = 0; a.conf_sum[idx] = 0; }
+}
+
+// smoothness features of the superpixel grid: addPairwiseGaussian(2, 2) (:437)
+__global__ void seg_feat1_kernel(int gx, int K, float* __restrict__ feat1)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    feat1[k * 2 + 0] = (float)(k % gx) / 2.0f; feat1[k * 2 + 1] = (float)(k / gx) / 2.0f;
+}
+
+struct SegPostArgs {
+    int K, gx, gy, n_models, L, allow_new, width, height;
+    unsigned next_id;
+    float minRelSizeNew, maxRelSizeNew;
+    unsigned ids[kMaxL + 1];         // model ids in list order (+ the new label's id)
+    const float* Q;                  // [K][L] marginals
+    const float* low_depth;          // [K]
+    const float* avg_conf;           // [n]
+    const float* depth_range;
+    int* parent; int* comp;          // scratch [K]
+    int* cc;                         // scratch [6][K]: label, size, top, right, bottom, left per component
+    unsigned char* low_map;          // [K] out
+    cf_seg_result* result;           // device copy of the result
+};
+
+// arg-max labels -> connected components (ConnectedLabels.hpp:50-172: 4-connectivity, components numbered by their first pixel in
+// raster order) -> largest-component / size / border gates -> bounding boxes, depth statistics, super-pixel counts (:475-646).
+// One workgroup: the label image has K = 1200 superpixels (4800 at 1280x960).
+__global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
+{
+    const int K = a.K, gx = a.gx, L = a.L, tid = threadIdx.x, T = blockDim.x;
+    const int n_md = a.n_models + (a.allow_new ? 1 : 0);
+    __shared__ int s_changed, s_ncc, s_min_label;
+    __shared__ int s_scan[1024];
+    __shared__ int s_id2idx[256];
+    __shared__ int s_box[kMaxL + 1][4];   // top, right, bottom, left per model entry (full-resolution pixels after mapToHigh)
+    __shared__ unsigned s_spc[kMaxL + 1];
+    unsigned char* map = a.low_map;
+    int* parent = a.parent; int* comp = a.comp;
+    int *c_label = a.cc, *c_size = a.cc + K, *c_top = a.cc + 2 * K, *c_right = a.cc + 3 * K, *c_bottom = a.cc + 4 * K, *c_left = a.cc + 5 * K;
+    // 1. label with the highest marginal (first maximum), as model id
+    for (int k = tid; k < K; k += T) {
+        int m = 0; float best = a.Q[(size_t)k * L];
+        for (int l = 1; l < L; l++) { const float q = a.Q[(size_t)k * L + l]; if (q > best) { best = q; m = l; } }
+        map[k] = (unsigned char)a.ids[m];
+        parent[k] = k;
+    }
+    if (tid < 256) s_id2idx[tid] = 0;
+    __syncthreads();
+    if (tid < a.n_models) s_id2idx[a.ids[tid] & 255] = tid;
+    __syncthreads();
+    if (tid == 0 && a.allow_new) s_id2idx[a.next_id & 255] = a.n_models;
+    // 2. connected components: min-label propagation over the 4-neighbourhood + pointer jumping until nothing changes; the root of a
+    //    component is its smallest index = its first pixel in raster order
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_changed = 0;
+        __syncthreads();
+        for (int k = tid; k < K; k += T) {
+            const int x = k % gx, y = k / gx;
+            const unsigned char v = map[k];
+            int p = parent[k];
+            if (x > 0 && map[k - 1] == v) p = min(p, parent[k - 1]);
+            if (x + 1 < gx && map[k + 1] == v) p = min(p, parent[k + 1]);
+            if (y > 0 && map[k - gx] == v) p = min(p, parent[k - gx]);
+            if (y + 1 < a.gy && map[k + gx] == v) p = min(p, parent[k + gx]);
+            if (p < parent[k]) { atomicMin(&parent[parent[k]], p); atomicMin(&parent[k], p); s_changed = 1; }
+        }
+        __syncthreads();
+        for (int k = tid; k < K; k += T) {  // pointer jumping
+            int p = parent[k];
+            while (parent[p] != p) p = parent[p];
+            parent[k] = p;
+        }
+        __syncthreads();
+        if (!s_changed) break;
+    }
+    // 3. number the roots in index order (exclusive scan of the root flags)
+    const int per = (K + T - 1) / T;
+    {
+        int cnt = 0;
+        for (int k = tid * per; k < min(K, (tid + 1) * per); k++) cnt += parent[k] == k;
+        s_scan[tid] = cnt;
+        __syncthreads();
+        for (int o = 1; o < T; o <<= 1) {
+            const int v = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        int base = s_scan[tid] - cnt;
+        for (int k = tid * per; k < min(K, (tid + 1) * per); k++)
+            if (parent[k] == k) comp[k] = base++;
+        if (tid == T - 1) s_ncc = s_scan[T - 1];
+        __syncthreads();
+    }
+    const int ncc = s_ncc;
+    for (int k = tid; k < K; k += T) if (parent[k] != k) comp[k] = comp[parent[k]];  // roots wrote their own entry; read-only for them
+    for (int i = tid; i < ncc; i += T) { c_size[i] = 0; c_top[i] = 2147483647; c_right[i] = 0; c_bottom[i] = 0; c_left[i] = 2147483647; }
+    if (tid == 0) s_min_label = 256;
+    __syncthreads();
+    // 4. component statistics
+    for (int k = tid; k < K; k += T) {
+        const int c = comp[k], x = k % gx, y = k / gx;
+        atomicAdd(&c_size[c], 1);
+        atomicMin(&c_top[c], y); atomicMax(&c_bottom[c], y); atomicMin(&c_left[c], x); atomicMax(&c_right[c], x);
+        if (parent[k] == k) { c_label[c] = map[k]; atomicMin(&s_min_label, (int)map[k]); }
+    }
+    __syncthreads();
+    // 5. onlyKeepLargest (:496-517): every label but the smallest keeps its largest component (ties: the earlier one); one lane per label
+    if (tid < 255 && tid != s_min_label) {
+        int keep = -1;
+        for (int i = 0; i < ncc; i++) {
+            if (c_label[i] != tid) continue;
+            if (keep < 0) { keep = i; continue; }
+            if (c_size[keep] < c_size[i]) { c_label[keep] = 255; keep = i; } else c_label[i] = 255;
+        }
+    }
+    __syncthreads();
+    // 6. a new label must have a plausible size (:521-530)
+    if (a.allow_new) {
+        const int minSize = (int)((float)K * a.minRelSizeNew), maxSize = (int)((float)K * a.maxRelSizeNew);
+        for (int i = tid; i < ncc; i += T)
+            if (c_label[i] == (int)a.next_id && (c_size[i] < minSize || c_size[i] > maxSize)) c_label[i] = 255;
+    }
+    __syncthreads();
+    // 7. bounding boxes (:532-547) and 8. labels whose box lies inside the border strip are rejected (:549-563); one lane per model
+    if (tid < n_md) {
+        const int id = (int)(a.ids[tid] & 255u);
+        int left = 65535, top = 65535, right = 0, bottom = 0;
+        for (int i = 0; i < ncc; i++) {
+            if (c_label[i] != id) continue;
+            if (c_left[i] < left) left = c_left[i];
+            if (c_top[i] < top) top = c_top[i];
+            if (c_right[i] > right) right = c_right[i];
+            if (c_bottom[i] > bottom) bottom = c_bottom[i];
+        }
+        left = (int)(unsigned short)(int)(left * kSpix + kSpix * 0.5); top = (int)(unsigned short)(int)(top * kSpix + kSpix * 0.5);
+        right = (int)(unsigned short)(int)(right * kSpix + kSpix * 0.5); bottom = (int)(unsigned short)(int)(bottom * kSpix + kSpix * 0.5);
+        s_box[tid][0] = top; s_box[tid][1] = right; s_box[tid][2] = bottom; s_box[tid][3] = left;
+    }
+    __syncthreads();
+    if (tid < n_md && a.ids[tid] != 0) {
+        const unsigned borderSize = 20, fullHeight = (unsigned)a.height, fullWidth = (unsigned)a.width;
+        const unsigned top = (unsigned)s_box[tid][0], right = (unsigned)s_box[tid][1], bottom = (unsigned)s_box[tid][2], left = (unsigned)s_box[tid][3];
+        if ((top < borderSize && bottom < borderSize) || (left < borderSize && right < borderSize) ||
+            (top > fullHeight - borderSize && bottom > fullHeight - borderSize) || (left > fullWidth - borderSize && right > fullWidth - borderSize)) {
+            const int id = (int)(a.ids[tid] & 255u);
+            for (int i = 0; i < ncc; i++) if (c_label[i] == id) c_label[i] = 255;
+        }
+    }
+    __syncthreads();
+    // 9. final low-resolution label map
+    for (int k = tid; k < K; k += T) map[k] = (unsigned char)c_label[comp[k]];
+    __syncthreads();
+    // 10. depth statistics with one trimming pass (:570-621) and super-pixel counts (:624-627): sequential f32 sums in index order,
+    //     one lane per model entry
+    if (tid < n_md) {
+        const float* lowDepth = a.low_depth;
+        float sumDepth = 0, sumDev = 0; unsigned cnt = 0, spc = 0;
+        for (int i = 0; i < K; i++) { if (map[i] == 255 || s_id2idx[map[i]] != tid) continue; sumDepth += lowDepth[i]; cnt++; spc++; }
+        float mean = cnt ? sumDepth / (float)cnt : 0;
+        for (int i = 0; i < K; i++) { if (map[i] == 255 || s_id2idx[map[i]] != tid) continue; sumDev += fabsf(mean - lowDepth[i]); }
+        float dev = cnt ? sumDev / (float)cnt : 0;
+        if (tid != 0)
+            for (int i = 0; i < K; i++) {
+                if (map[i] == 255 || s_id2idx[map[i]] != tid) continue;
+                const float d = lowDepth[i];
+                if ((double)d > 1.1 * (double)dev + (double)mean) { sumDepth -= d; sumDev -= fabsf(mean - d); cnt--; }
+            }
+        mean = cnt ? sumDepth / (float)cnt : 0;
+        dev = cnt ? sumDev / (float)cnt : 0;
+        cf_seg_model& o = a.result->model[tid];
+        o.id = a.ids[tid]; o.superPixelCount = spc; o.avgConfidence = tid < a.n_models ? a.avg_conf[tid] : 0.f;
+        o.depthMean = mean; o.depthStd = dev;
+        o.top = s_box[tid][0]; o.right = s_box[tid][1]; o.bottom = s_box[tid][2]; o.left = s_box[tid][3];
+        s_spc[tid] = spc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int has_new = 0, n_out = n_md;
+        if (a.allow_new) { if (s_spc[n_md - 1] > 0) has_new = 1; else n_out = n_md - 1; }
+        a.result->has_new_label = has_new; a.result->n_models = n_out; a.result->depth_range = a.depth_range[0];
+    }
+}
 }  // namespace cf
 
 // ===================================================================================== C-ABI ====
@@ -341,6 +651,14 @@ struct cf_segmenter {
     float* partial = nullptr;            // chunk partial sums [kCrfChunks][K][2][kMaxL]
     std::vector<float> smooth_cache;     // host copy of the smoothness features K1t was built from
     float *unary = nullptr, *Q0 = nullptr, *Q1 = nullptr;
+    // device-side unaries / post-processing (cf_seg_sums / cf_seg_infer / cf_seg_fetch)
+    float *raw_mean = nullptr, *low_mean = nullptr;   // [(1 + 2 kMaxL)][K]
+    float *avg_conf = nullptr, *depth_range = nullptr;
+    int *parent = nullptr, *comp = nullptr, *cc = nullptr;
+    cf_seg_result* d_result = nullptr;
+    cf_seg_result* h_result = nullptr;   // pinned
+    unsigned char* h_low_map = nullptr;  // pinned [K]
+    bool grid_kernel_built = false;      // K1t holds the kernel of the grid's own smoothness features (seg_feat1_kernel)
 };
 
 template <typename T>
@@ -367,8 +685,8 @@ int cf_seg_create(cf_ctx* ctx, cf_segmenter** out)
     if (int r = seg_malloc(ctx, &s->spix_count, K)) return r;
     if (int r = seg_malloc(ctx, &s->depth_count, K)) return r;
     if (int r = seg_malloc(ctx, &s->depth_sum, K)) return r;
-    if (int r = seg_malloc(ctx, &s->icp_sum, K * kMaxL)) return r;
-    if (int r = seg_malloc(ctx, &s->conf_sum, K * kMaxL)) return r;
+    if (int r = seg_malloc(ctx, &s->icp_sum, 2 * K * kMaxL)) return r;  // [icp | conf] in one block: one collective covers both
+    s->conf_sum = s->icp_sum + K * kMaxL;
     if (int r = seg_malloc(ctx, &s->resample, K)) return r;
     if (int r = seg_malloc(ctx, &s->low_map, K)) return r;
     if (int r = seg_malloc(ctx, &s->feat1, K * 2)) return r;
@@ -381,6 +699,17 @@ int cf_seg_create(cf_ctx* ctx, cf_segmenter** out)
     if (int r = seg_malloc(ctx, &s->unary, K * kMaxL)) return r;
     if (int r = seg_malloc(ctx, &s->Q0, K * kMaxL)) return r;
     if (int r = seg_malloc(ctx, &s->Q1, K * kMaxL)) return r;
+    if (int r = seg_malloc(ctx, &s->raw_mean, K * (1 + 2 * kMaxL))) return r;
+    if (int r = seg_malloc(ctx, &s->low_mean, K * (1 + 2 * kMaxL))) return r;
+    if (int r = seg_malloc(ctx, &s->avg_conf, (size_t)kMaxL)) return r;
+    if (int r = seg_malloc(ctx, &s->depth_range, (size_t)1)) return r;
+    if (int r = seg_malloc(ctx, &s->parent, K)) return r;
+    if (int r = seg_malloc(ctx, &s->comp, K)) return r;
+    if (int r = seg_malloc(ctx, &s->cc, 6 * K)) return r;
+    if (int r = seg_malloc(ctx, &s->d_result, (size_t)1)) return r;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(cf_seg_result)));
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_low_map), K));
+    memset(s->h_result, 0, sizeof(cf_seg_result));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return CF_OK;
 }
@@ -389,9 +718,12 @@ void cf_seg_destroy(cf_segmenter* s)
 {
     if (!s) return;
     (void)hipStreamSynchronize(s->ctx->stream);
-    void* ptrs[] = {s->labels, s->centres, s->slic_sums, s->spix_count, s->depth_count, s->depth_sum, s->icp_sum, s->conf_sum, s->resample,
-                    s->low_map, s->feat1, s->feat2, s->raw, s->norm, s->K1t, s->K2t, s->partial, s->unary, s->Q0, s->Q1};
+    void* ptrs[] = {s->labels, s->centres, s->slic_sums, s->spix_count, s->depth_count, s->depth_sum, s->icp_sum, s->resample,
+                    s->low_map, s->feat1, s->feat2, s->raw, s->norm, s->K1t, s->K2t, s->partial, s->unary, s->Q0, s->Q1,
+                    s->raw_mean, s->low_mean, s->avg_conf, s->depth_range, s->parent, s->comp, s->cc, s->d_result};
     for (void* p : ptrs) (void)hipFree(p);
+    if (s->h_result) (void)hipHostFree(s->h_result);
+    if (s->h_low_map) (void)hipHostFree(s->h_low_map);
     delete s;
 }
 
@@ -467,6 +799,7 @@ int cf_seg_crf(cf_segmenter* s, const float* unary_host, int L, const float* fea
         crf_norm_kernel<<<g1, 256, 0, st>>>(s->partial, n, s->norm);
         crf_scale_kernel<<<g2, 256, 0, st>>>(s->raw, s->norm, n, s->K1t);
         s->smooth_cache.assign(feat_smooth_host, feat_smooth_host + (size_t)n * 2);
+        s->grid_kernel_built = false;
     }
     crf_raw_kernel<6><<<g2, 256, 0, st>>>(s->feat2, n, s->raw);
     crf_norm_partial_kernel<<<gc, 64, 0, st>>>(s->raw, n, s->partial);
@@ -495,6 +828,104 @@ int cf_seg_upsample(cf_segmenter* s, const uint8_t* low_map_host, uint8_t* full_
     HIPCHK(ctx, hipStreamSynchronize(st));  // low_map_host may be a caller stack/heap buffer
     seg_upsample_kernel<<<(N + 255) / 256, 256, 0, st>>>(s->labels, s->low_map, N, full_dev);
     LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+// ---- device-resident flavour: sums -> [collective] -> unaries -> mean field -> post-processing -> mask, no host wait ----
+static int enqueue_accumulate(cf_segmenter* s, const float* depth, int n_models, const float* const* icp_err, const float* const* vertconf4)
+{
+    cf_ctx* ctx = s->ctx; hipStream_t st = ctx->stream;
+    AccArgs a;
+    memset(&a, 0, sizeof(a));
+    a.labels = s->labels; a.depth = depth; a.n_models = n_models; a.cols = ctx->cfg.width; a.rows = ctx->cfg.height; a.gx = s->gx; a.gy = s->gy;
+    for (int m = 0; m < n_models; m++) { a.icp[m] = icp_err[m]; a.vconf[m] = reinterpret_cast<const float4*>(vertconf4[m]); }
+    a.spix_count = s->spix_count; a.depth_count = s->depth_count; a.depth_sum = s->depth_sum; a.icp_sum = s->icp_sum; a.conf_sum = s->conf_sum;
+    seg_accumulate_kernel<<<dim3(s->gx, s->gy), 256, 0, st>>>(a);
+    seg_resample_kernel<<<(s->K + 255) / 256, 256, 0, st>>>(s->labels, ctx->cfg.width, ctx->cfg.height, s->gx, s->gy, s->resample);
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+// Slic::downsample* sums of the frame and of every model (Slic.h:48-120), left on the device.  *sums_dev (nullable) receives the
+// device address of the per-model sums -- int64 [2][16][K]: ICP-error sums of model m at [0][m][.], confidence sums at [1][m][.] --
+// which a model-parallel caller SUM-all-reduces in place over the ranks before cf_seg_infer (owners contribute, everybody else
+// passes zero images).  The accumulators are expected zero on entry; cf_seg_infer leaves them zero again.
+int cf_seg_sums(cf_segmenter* s, const float* depth, int n_models, const float* const* icp_err, const float* const* vertconf4,
+                int64_t** sums_dev, uint64_t* sums_words)
+{
+    if (!s || !depth || n_models <= 0 || n_models > kMaxL || !icp_err || !vertconf4) return CF_EINVAL;
+    if (int r = enqueue_accumulate(s, depth, n_models, icp_err, vertconf4)) return r;
+    if (sums_dev) *sums_dev = reinterpret_cast<int64_t*>(s->icp_sum);
+    if (sums_words) *sums_words = 2ull * kMaxL * (uint64_t)s->K;
+    return CF_OK;
+}
+
+// Everything after the sums (Segmentation.cpp:160-706): unaries, 10 mean-field steps, arg-max, connected components, gates,
+// statistics, up-sampling of the label map into full_dev.  Only enqueues; the decisions arrive with cf_seg_fetch.
+int cf_seg_infer(cf_segmenter* s, const cf_seg_params* P, const uint8_t* rgba, int n_models, const uint32_t* model_ids, uint32_t next_model_id,
+                 int allow_new, uint8_t* full_dev)
+{
+    if (!s || !P || !rgba || !model_ids || !full_dev || n_models <= 0) return CF_EINVAL;
+    const int L = n_models + (allow_new ? 1 : 0);
+    if (L > kMaxL) { s->ctx->set_error("segmentation: more than 16 labels"); return CF_EINVAL; }
+    cf_ctx* ctx = s->ctx; hipStream_t st = ctx->stream;
+    const int n = s->K;
+    const int g2 = (n * n + 255) / 256, g1 = (n + 255) / 256;
+    const dim3 gc((n + 63) / 64, kCrfChunks);
+    SegUnaryArgs u;
+    memset(&u, 0, sizeof(u));
+    u.K = n; u.gx = s->gx; u.gy = s->gy; u.n_models = n_models; u.L = L; u.allow_new = allow_new ? 1 : 0;
+    u.unaryWeightError = P->unaryWeightError; u.unaryKError = P->unaryKError; u.unaryThresholdNew = P->unaryThresholdNew;
+    u.scaleFeaturesRGB = P->scaleFeaturesRGB; u.scaleFeaturesDepth = P->scaleFeaturesDepth; u.scaleFeaturesPos = P->scaleFeaturesPos;
+    u.spix_count = s->spix_count; u.depth_count = s->depth_count; u.depth_sum = s->depth_sum; u.icp_sum = s->icp_sum; u.conf_sum = s->conf_sum;
+    u.resample = s->resample; u.rgba = reinterpret_cast<const uchar4*>(rgba);
+    u.raw = s->raw_mean; u.low = s->low_mean; u.unary = s->unary; u.feat2 = s->feat2; u.avg_conf = s->avg_conf; u.depth_range = s->depth_range;
+    seg_unary_kernel<<<1, 1024, 0, st>>>(u);
+    if (!s->grid_kernel_built) {  // the smoothness kernel only depends on the superpixel grid: built once
+        seg_feat1_kernel<<<g1, 256, 0, st>>>(s->gx, n, s->feat1);
+        crf_raw_kernel<2><<<g2, 256, 0, st>>>(s->feat1, n, s->raw);
+        crf_norm_partial_kernel<<<gc, 64, 0, st>>>(s->raw, n, s->partial);
+        crf_norm_kernel<<<g1, 256, 0, st>>>(s->partial, n, s->norm);
+        crf_scale_kernel<<<g2, 256, 0, st>>>(s->raw, s->norm, n, s->K1t);
+        s->grid_kernel_built = true;
+        s->smooth_cache.clear();
+    }
+    crf_raw_kernel<6><<<g2, 256, 0, st>>>(s->feat2, n, s->raw);
+    crf_norm_partial_kernel<<<gc, 64, 0, st>>>(s->raw, n, s->partial);
+    crf_norm_kernel<<<g1, 256, 0, st>>>(s->partial, n, s->norm);
+    crf_scale_kernel<<<g2, 256, 0, st>>>(s->raw, s->norm, n, s->K2t);
+    crf_init_kernel<<<g1, 256, 0, st>>>(s->unary, L, n, s->Q0);
+    float *q = s->Q0, *qn = s->Q1;
+    for (int it = 0; it < P->crfIterations; it++) {
+        launch_crf_message(st, gc, L, n, s->K1t, s->K2t, q, s->partial);
+        crf_update_kernel<<<(n + 15) / 16, 256, 0, st>>>(s->unary, L, n, s->partial, P->weightSmoothness, P->weightAppearance, qn);
+        float* t = q; q = qn; qn = t;
+    }
+    SegPostArgs p;
+    memset(&p, 0, sizeof(p));
+    p.K = n; p.gx = s->gx; p.gy = s->gy; p.n_models = n_models; p.L = L; p.allow_new = allow_new ? 1 : 0;
+    p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.next_id = next_model_id;
+    p.minRelSizeNew = P->minRelSizeNew; p.maxRelSizeNew = P->maxRelSizeNew;
+    for (int m = 0; m < n_models; m++) p.ids[m] = model_ids[m];
+    if (allow_new) p.ids[n_models] = next_model_id;
+    p.Q = q; p.low_depth = s->low_mean; p.avg_conf = s->avg_conf; p.depth_range = s->depth_range;
+    p.parent = s->parent; p.comp = s->comp; p.cc = s->cc; p.low_map = s->low_map; p.result = s->d_result;
+    seg_post_kernel<<<1, 1024, 0, st>>>(p);
+    const int N = ctx->cfg.width * ctx->cfg.height;
+    seg_upsample_kernel<<<(N + 255) / 256, 256, 0, st>>>(s->labels, s->low_map, N, full_dev);
+    LAUNCHCHK(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(s->h_result, s->d_result, sizeof(cf_seg_result), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(s->h_low_map, s->low_map, (size_t)n, hipMemcpyDeviceToHost, st));
+    return CF_OK;
+}
+
+// waits for the stream and hands out the decisions of the last cf_seg_infer (low_map_host: nullable [K])
+int cf_seg_fetch(cf_segmenter* s, cf_seg_result* out, uint8_t* low_map_host)
+{
+    if (!s || !out) return CF_EINVAL;
+    HIPCHK(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    *out = *s->h_result;
+    if (low_map_host) memcpy(low_map_host, s->h_low_map, (size_t)s->K);
     return CF_OK;
 }
 

@@ -74,6 +74,36 @@ class CoFusion:
 
         self._allreduce_cb = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int64), C.c_uint64, C.c_void_p)(thunk)  # keep alive
         self._check(self.lib.cofusion_set_allreduce(self.h, self._allreduce_cb, None))
+        if fn is None and dist.get_backend() == "nccl":
+            self.set_allreduce_device()
+
+    def set_allreduce_device(self):
+        """The collective for buffers that live in HBM (per-superpixel segmentation sums): RCCL all-reduce of an int64 torch tensor,
+        enqueued after the library's work on the context's stream -- no host visit.  The library's buffer is copied device-to-device
+        into / out of a torch-owned tensor because torch.distributed takes tensors, not raw addresses."""
+        import torch.distributed as dist
+        self._ar_buf = None
+
+        def thunk(dev_buf, n, hip_stream, _user):
+            try:
+                if self._ar_buf is None or self._ar_buf.numel() < n:
+                    self._ar_buf = torch.empty(int(n), dtype=torch.int64, device=self.device)
+                t = self._ar_buf[:n]
+                ctx = self._ctx()
+                nbytes = C.c_uint64(int(n) * 8)
+                if self.abi.cf_memcpy_d2d_async(ctx, C.c_void_p(t.data_ptr()), C.c_void_p(dev_buf), nbytes) != 0:
+                    return -1
+                # the library enqueues on the torch stream it was handed (set_stream / the current stream at construction)
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(hip_stream), device=self.device)) if hip_stream else torch.cuda.stream(torch.cuda.current_stream(self.device)):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                if self.abi.cf_memcpy_d2d_async(ctx, C.c_void_p(dev_buf), C.c_void_p(t.data_ptr()), nbytes) != 0:
+                    return -1
+                return 0
+            except Exception:  # noqa: BLE001 -- reported through the C return code
+                return -1
+
+        self._allreduce_dev_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p)(thunk)  # keep alive
+        self._check(self.lib.cofusion_set_allreduce_device(self.h, self._allreduce_dev_cb, None))
 
     def model_owned(self, index):
         return self.lib.cofusion_model_owned(self.h, index) == 1

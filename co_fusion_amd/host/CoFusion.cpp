@@ -73,6 +73,21 @@ void Distributed::sum(int64_t* buf, uint64_t n) const
     if (allreduce_i64(buf, n, user) != 0) throw std::runtime_error("model-parallel CoFusion: the all-reduce callback failed");
 }
 
+// in-place SUM all-reduce of a device buffer: through the device collective when one is registered (RCCL on the context's stream,
+// no host visit), otherwise staged through the host callback
+void Distributed::sumDevice(cf_ctx* ctx, int64_t* dev, uint64_t n) const
+{
+    if (!active()) return;
+    if (allreduce_dev) {
+        if (allreduce_dev(dev, n, cf_get_stream(ctx), user_dev) != 0) throw std::runtime_error("model-parallel CoFusion: the device all-reduce callback failed");
+        return;
+    }
+    std::vector<int64_t> h(n);
+    check(ctx, cf_memcpy_d2h(ctx, h.data(), dev, n * 8), "sums read-back");
+    sum(h.data(), n);
+    check(ctx, cf_memcpy_h2d(ctx, dev, h.data(), n * 8), "sums upload");
+}
+
 // ------------------------------------------------------------------------------- Model ----
 Model::Model(cf_ctx* c, unsigned char id_, float confidenceThresh, bool enableFillIn, int maxSurfels, float maxDepth_, bool owned_)
     : ctx(c), pose(Mat4f::identity()), lastPose(Mat4f::identity()), confidenceThreshold(confidenceThresh), maxDepth(maxDepth_), id(id_),
@@ -296,6 +311,62 @@ void finishMean(const int64_t* sumq, const uint32_t* cntOwn, const uint32_t* spi
 }
 }  // namespace
 
+// Device-resident flavour (default): sums, unaries, mean field, component analysis and up-sampling are enqueued without a host wait;
+// finishCRF() collects the decisions after the frame's one synchronisation.
+void Segmentation::enqueueCRF(ModelList& models, const float* depth_dev, const uint8_t* rgba_dev, unsigned char nextModelID, bool allowNew,
+                              uint8_t* full_dev)
+{
+    PhaseTimer pt(PhaseTimes::SegSlicAccumulate);
+    const int n_models = (int)models.size();
+    if (!slicStarted) check(ctx, cf_seg_slic(seg, rgba_dev), "cf_seg_slic");  // otherwise enqueued by startSlic() beside the tracking
+    slicStarted = false;
+    std::vector<const float*> icpPtr(n_models), vcPtr(n_models);
+    std::vector<uint32_t> ids(n_models);
+    {
+        int m = 0;
+        for (auto& mdl : models) {
+            // a shadow contributes zeros here; its owner's sums arrive through the all-reduce below
+            icpPtr[m] = mdl->isOwned() ? mdl->icpErrorSurface() : zeroImage;
+            vcPtr[m] = mdl->isOwned() ? mdl->vertexConfProjection() : zeroImage;
+            ids[m] = mdl->getID();
+            m++;
+        }
+    }
+    int64_t* sums_dev = nullptr; uint64_t words = 0;
+    check(ctx, cf_seg_sums(seg, depth_dev, n_models, icpPtr.data(), vcPtr.data(), &sums_dev, &words), "cf_seg_sums");
+    if (dist && dist->active()) dist->sumDevice(ctx, sums_dev, words);  // exact: integer sums, every model has exactly one owner
+    cf_seg_params P{};
+    P.unaryWeightError = unaryWeightError; P.unaryKError = unaryKError; P.unaryThresholdNew = unaryThresholdNew;
+    P.weightAppearance = weightAppearance; P.weightSmoothness = weightSmoothness;
+    P.scaleFeaturesRGB = scaleFeaturesRGB; P.scaleFeaturesDepth = scaleFeaturesDepth; P.scaleFeaturesPos = scaleFeaturesPos;
+    P.minRelSizeNew = minRelSizeNew; P.maxRelSizeNew = maxRelSizeNew; P.crfIterations = (int)crfIterations;
+    check(ctx, cf_seg_infer(seg, &P, rgba_dev, n_models, ids.data(), nextModelID, allowNew ? 1 : 0, full_dev), "cf_seg_infer");
+    pendingModels = n_models;
+}
+
+SegmentationResult Segmentation::finishCRF()
+{
+    PhaseTimer pt(PhaseTimes::SegPost);
+    SegmentationResult result;
+    cf_seg_result r{};
+    const int K = (width / SPIX) * (height / SPIX);
+    result.lowMap.resize(K);
+    check(ctx, cf_seg_fetch(seg, &r, result.lowMap.data()), "cf_seg_fetch");
+    result.hasNewLabel = r.has_new_label != 0;
+    result.depthRange = r.depth_range;
+    for (int i = 0; i < r.n_models; i++) {
+        SegmentationResult::ModelData md;
+        md.id = r.model[i].id; md.modelIndex = i < pendingModels ? i : -1;
+        md.superPixelCount = r.model[i].superPixelCount; md.avgConfidence = r.model[i].avgConfidence;
+        md.depthMean = r.model[i].depthMean; md.depthStd = r.model[i].depthStd;
+        md.top = r.model[i].top; md.right = r.model[i].right; md.bottom = r.model[i].bottom; md.left = r.model[i].left;
+        result.modelData.push_back(md);
+    }
+    return result;
+}
+
+// Host flavour (CF_SEG_HOST=1, diagnostics): the reference's host logic verbatim around the GPU SLIC / sums / mean field, with a
+// host wait after each of them.  Same results as the device flavour.
 SegmentationResult Segmentation::performSegmentationCRF(ModelList& models, const float* depth_dev, const uint8_t* rgba_dev,
                                                         const uint8_t* rgba_first_rows, unsigned char nextModelID, bool allowNew,
                                                         uint8_t* full_dev)
@@ -656,20 +727,29 @@ void CoFusion::trackModels(const float* const depthPyr[3])
     }
     cf_track_opts opts{};
     opts.rgb_only = cfg.rgbOnly; opts.pyramid = cfg.pyramid; opts.fast_odom = cfg.fastOdom; opts.so3 = cfg.so3; opts.icp_weight = cfg.icpWeight;
+    // lock-step batches of at most kMaxBatch (8) models; the LAST batch is left in flight (fetchTracking collects it after whatever the
+    // caller enqueues behind it), earlier ones are collected here because the next batch re-uses the context's staging
     const int B = 8;
+    trackPending.clear();
     for (size_t base = 0; base < ms.size(); base += B) {
         const int n = (int)std::min<size_t>(B, ms.size() - base);
         cf_odom* ods[B]; const float* poses[B]; float* errs[B];
         for (int k = 0; k < n; k++) { ods[k] = ms[base + k]->odom; poses[k] = ms[base + k]->pose.m; errs[k] = ms[base + k]->icpError; }
+        if (!trackPending.empty()) fetchTracking(false);
         check(ctx, cf_odom_track_batch_async(ctx, ods, n, poses, &opts, errs), "track_batch");
-        for (int k = 0; k < n; k++) {
-            Model* m = ms[base + k];
-            float t[3], R[9];
-            check(ctx, cf_odom_fetch_result(m->odom, t, R, &m->lastStats), "fetch_result");
-            for (int r = 0; r < 3; r++) { m->pose.m[r * 4 + 0] = R[r * 3 + 0]; m->pose.m[r * 4 + 1] = R[r * 3 + 1]; m->pose.m[r * 4 + 2] = R[r * 3 + 2]; m->pose.m[r * 4 + 3] = t[r]; }
-        }
+        for (int k = 0; k < n; k++) trackPending.push_back(ms[base + k]);
     }
-    exchangeTracking();
+}
+
+void CoFusion::fetchTracking(bool exchange)
+{
+    for (Model* m : trackPending) {
+        float t[3], R[9];
+        check(ctx, cf_odom_fetch_result(m->odom, t, R, &m->lastStats), "fetch_result");
+        for (int r = 0; r < 3; r++) { m->pose.m[r * 4 + 0] = R[r * 3 + 0]; m->pose.m[r * 4 + 1] = R[r * 3 + 1]; m->pose.m[r * 4 + 2] = R[r * 3 + 2]; m->pose.m[r * 4 + 3] = t[r]; }
+    }
+    trackPending.clear();
+    if (exchange) exchangeTracking();
 }
 
 void CoFusion::exchangeTracking()
@@ -749,22 +829,33 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
             }
             { PhaseTimer t(PhaseTimes::Track); trackModels(pyr); }
             if (slicAside) check(ctx, cf_join(ctx), "cf_join");
+            // a new label needs a free model slot: the segmenter holds at most 16 labels and the context was sized for
+            // cfg.maxModels trackers (the reference allows 256 ids, CoFusion.cpp:631-634; its GUI never gets there)
+            bool allowNew = false;
+            const bool segOnDevice = cfg.enableMultipleModels && !frame.mask && !segOnHost;
+            if (cfg.enableMultipleModels) {
+                if (spawnOffset < cfg.modelSpawnOffset) spawnOffset++;
+                const size_t modelCap = (size_t)std::min(cfg.maxModels, 16);
+                allowNew = spawnOffset >= cfg.modelSpawnOffset && models.size() < modelCap;
+            }
+            // the motion segmentation reads device data only (ICP error surfaces, predictions): enqueued right behind the tracking
+            // launches, so that poses AND segmentation decisions are collected by ONE host wait
+            if (segOnDevice) labelGenerator->enqueueCRF(models, curDepth, curRgba, getNextModelID(), allowNew, mask_dev);
+            { PhaseTimer t(PhaseTimes::Track); fetchTracking(true); }
             if (bootstrap) globalModel->overridePose(globalModel->getPose() * (*inPose));
 
             if (cfg.enableMultipleModels) {
                 auto getMaxDepth = [](const SegmentationResult::ModelData& d) -> float { return d.depthMean + d.depthStd * 1.2; };
-                if (spawnOffset < cfg.modelSpawnOffset) spawnOffset++;
-                // the colour features of the CRF read the first K pixels of the full-resolution image
-                const int K = (cfg.width / 16) * (cfg.height / 16);
-                std::vector<uint8_t> firstRows((size_t)K * 4);
-                if (frame.rgba_dev) check(ctx, cf_memcpy_d2h(ctx, firstRows.data(), curRgba, (size_t)K * 4), "rgb readback");
-                else for (int i = 0; i < K; i++) { firstRows[i * 4] = frame.rgb[i * 3]; firstRows[i * 4 + 1] = frame.rgb[i * 3 + 1]; firstRows[i * 4 + 2] = frame.rgb[i * 3 + 2]; firstRows[i * 4 + 3] = 255; }
-                // a new label needs a free model slot: the segmenter holds at most 16 labels and the context was sized for
-                // cfg.maxModels trackers (the reference allows 256 ids, CoFusion.cpp:631-634; its GUI never gets there)
-                const size_t modelCap = (size_t)std::min(cfg.maxModels, 16);
-                const bool allowNew = spawnOffset >= cfg.modelSpawnOffset && models.size() < modelCap;
-                SegmentationResult seg = labelGenerator->performSegmentation(models, frame, curDepth, curRgba, firstRows.data(), getNextModelID(),
-                                                                            allowNew, mask_dev);
+                SegmentationResult seg;
+                if (segOnDevice) seg = labelGenerator->finishCRF();
+                else {
+                    // the colour features of the CRF read the first K pixels of the full-resolution image
+                    const int K = (cfg.width / 16) * (cfg.height / 16);
+                    std::vector<uint8_t> firstRows((size_t)K * 4);
+                    if (frame.rgba_dev) check(ctx, cf_memcpy_d2h(ctx, firstRows.data(), curRgba, (size_t)K * 4), "rgb readback");
+                    else for (int i = 0; i < K; i++) { firstRows[i * 4] = frame.rgb[i * 3]; firstRows[i * 4 + 1] = frame.rgb[i * 3 + 1]; firstRows[i * 4 + 2] = frame.rgb[i * 3 + 2]; firstRows[i * 4 + 3] = 255; }
+                    seg = labelGenerator->performSegmentation(models, frame, curDepth, curRgba, firstRows.data(), getNextModelID(), allowNew, mask_dev);
+                }
                 if (!exportSegmentationPrefix.empty()) {  // CoFusion.cpp:235-240: labels > 254 (rejected) are written as 0
                     std::vector<uint8_t> labels(N);
                     check(ctx, cf_memcpy_d2h(ctx, labels.data(), mask_dev, N), "mask readback");

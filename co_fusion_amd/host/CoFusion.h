@@ -76,6 +76,11 @@ struct Distributed {
     // the background map (by far the largest) alone on rank 0, objects round-robin over the other ranks
     int owner(unsigned id) const { return (world <= 1 || id == 0) ? 0 : 1 + (int)((id - 1) % (unsigned)(world - 1)); }
     void sum(int64_t* buf, uint64_t n) const;  // throws if the collective is missing or fails
+    // the same collective on a DEVICE buffer, enqueued on `stream` (RCCL): no host visit.  Optional: without it device buffers are
+    // staged through the host callback.
+    int (*allreduce_dev)(int64_t* dev_buf, uint64_t n, void* hip_stream, void* user) = nullptr;
+    void* user_dev = nullptr;
+    void sumDevice(cf_ctx* ctx, int64_t* dev_buf, uint64_t n) const;
 };
 
 class Model {
@@ -157,6 +162,11 @@ class Segmentation {
                                            uint8_t* fullSegmentation_dev);
     // enqueue SLIC for this frame's image ahead of performSegmentation (on whatever stream the context currently uses)
     void startSlic(const uint8_t* rgba_dev);
+    // performSegmentationCRF in two halves without a host wait in between: everything is enqueued (sums, unaries, mean field,
+    // component analysis, up-sampling into fullSegmentation_dev), the decisions are collected later
+    void enqueueCRF(ModelList& models, const float* depth_dev, const uint8_t* rgba_dev, unsigned char nextModelID, bool allowNew,
+                    uint8_t* fullSegmentation_dev);
+    SegmentationResult finishCRF();
     // setters (Segmentation.h:100-120); defaults are the GUI values the reference applies every frame (GUI.h:206-227)
     float unaryWeightError = 75.f, unaryKError = 0.0375f, unaryThresholdNew = 5.5f;
     float weightAppearance = 7.f, weightSmoothness = 2.f;
@@ -175,6 +185,7 @@ class Segmentation {
     uint8_t gtMapping[256];
     const Distributed* dist = nullptr;
     bool slicStarted = false;
+    int pendingModels = 0;        // models of the segmentation enqueueCRF left in flight
     float* zeroImage = nullptr;   // device zeros [H*W*4] standing in for the ICP error / confidence maps of shadow models
 };
 
@@ -214,6 +225,7 @@ class CoFusion {
     void setExportSegmentation(const std::string& prefix) { exportSegmentationPrefix = prefix; }
     // the collective of the model-parallel mode (cfg.world > 1); must be set before the first frame
     void setAllreduce(int (*fn)(int64_t*, uint64_t, void*), void* user) { dist.allreduce_i64 = fn; dist.user = user; }
+    void setAllreduceDevice(int (*fn)(int64_t*, uint64_t, void*, void*), void* user) { dist.allreduce_dev = fn; dist.user_dev = user; }
     const Distributed& distributed() const { return dist; }
     ModelList& getModels() { return models; }
     ModelPointer getBackgroundModel() { return globalModel; }
@@ -229,8 +241,11 @@ class CoFusion {
     void moveNewModelToList();
     ModelList::iterator inactivateModel(ModelList::iterator it);
     unsigned char getNextModelID(bool assign = false);
-    void trackModels(const float* const depthPyr[3]);
+    void trackModels(const float* const depthPyr[3]);   // enqueues; poses arrive with fetchTracking
+    void fetchTracking(bool exchange);
     void exchangeTracking();
+    std::vector<Model*> trackPending;
+    bool segOnHost = std::getenv("CF_SEG_HOST") != nullptr;  // diagnostic: host-side unaries / component analysis
     Distributed dist;
 
     cf_ctx* ctx = nullptr;

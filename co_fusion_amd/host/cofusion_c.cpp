@@ -139,6 +139,11 @@ int cofusion_set_allreduce(cofusion_handle* h, cofusion_allreduce_i64_fn fn, voi
     h->cf->setAllreduce(fn, user);
     return 0;
 }
+int cofusion_set_allreduce_device(cofusion_handle* h, cofusion_allreduce_dev_fn fn, void* user)
+{
+    h->cf->setAllreduceDevice(fn, user);
+    return 0;
+}
 int cofusion_model_owned(cofusion_handle* h, int index)
 {
     Model* m = model_at(h, index);

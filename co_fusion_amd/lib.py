@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcofusion_hip.so")
 # every symbol include/cofusion_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "cf_create", "cf_destroy", "cf_last_error", "cf_set_stream", "cf_use_own_stream", "cf_get_stream", "cf_synchronize", "cf_fork", "cf_main", "cf_join", "cf_mark", "cf_event_wait_host", "cf_fork_after", "cf_malloc",
-    "cf_free", "cf_memcpy_h2d", "cf_memcpy_d2h", "cf_malloc_host", "cf_free_host", "cf_memcpy_h2d_async", "cf_memcpy_d2h_async", "cf_rgb_to_rgba", "cf_create_vmap", "cf_create_nmap", "cf_copy_maps", "cf_resize_map",
+    "cf_free", "cf_memcpy_h2d", "cf_memcpy_d2h", "cf_malloc_host", "cf_free_host", "cf_memcpy_h2d_async", "cf_memcpy_d2h_async", "cf_memcpy_d2d_async", "cf_rgb_to_rgba", "cf_create_vmap", "cf_create_nmap", "cf_copy_maps", "cf_resize_map",
     "cf_transform_maps", "cf_vertices_to_depth", "cf_pyrdown_gauss_f32", "cf_pyrdown_gauss_u8",
     "cf_rgba_to_intensity", "cf_sobel", "cf_project_cloud", "cf_icp_step", "cf_icp_step_band", "cf_rgb_residual", "cf_rgb_step",
     "cf_so3_step", "cf_odom_create", "cf_odom_destroy", "cf_odom_init_icp_model", "cf_odom_init_rgb_model",
@@ -24,7 +24,7 @@ SYMBOLS = [
     "cf_bilateral", "cf_model_create", "cf_model_destroy", "cf_model_initialise", "cf_model_count",
     "cf_model_predict_indices", "cf_model_index_keys", "cf_model_index_resolve", "cf_model_combined_predict", "cf_model_prefetch_fill_ratio", "cf_model_perform_fill_in", "cf_model_requires_fill_in",
     "cf_model_fuse", "cf_model_clean", "cf_model_download_map", "cf_model_upload_map", "cf_model_buffer",
-    "cf_fusion_weight", "cf_seg_create", "cf_seg_destroy", "cf_seg_slic", "cf_seg_accumulate", "cf_seg_crf", "cf_seg_upsample",
+    "cf_fusion_weight", "cf_seg_create", "cf_seg_destroy", "cf_seg_slic", "cf_seg_accumulate", "cf_seg_crf", "cf_seg_upsample", "cf_seg_sums", "cf_seg_infer", "cf_seg_fetch",
     "cf_seg_labels",
     "cf_depth_pyramid", "cf_set_icp_launch", "cf_set_gn_mode", "cf_profile_enable", "cf_profile_read", "cf_odom_bench_icp",
 ]
@@ -50,7 +50,7 @@ HOST_SYMBOLS = [
     "cofusion_process_frame", "cofusion_process_frame_device", "cofusion_num_models", "cofusion_tick", "cofusion_model_info",
     "cofusion_model_download", "cofusion_model_icp_stats", "cofusion_model_tracking_inputs", "cofusion_mask_device", "cofusion_context", "cofusion_set_crf",
     "cofusion_save_ply", "cofusion_export_poses", "cofusion_set_export_segmentation", "cofusion_klg_open", "cofusion_klg_next", "cofusion_klg_close",
-    "cofusion_klg_create", "cofusion_klg_write", "cofusion_klg_finish", "cofusion_debug_phase_ms", "cofusion_set_allreduce", "cofusion_model_owned",
+    "cofusion_klg_create", "cofusion_klg_write", "cofusion_klg_finish", "cofusion_debug_phase_ms", "cofusion_set_allreduce", "cofusion_set_allreduce_device", "cofusion_model_owned",
 ]
 _host = None
 

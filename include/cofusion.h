@@ -65,6 +65,12 @@ int cofusion_set_crf(cofusion_handle *h, float unary_weight_error, float unary_k
  * over all ranks (e.g. ncclAllReduce / torch.distributed.all_reduce); return 0 on success.  Register before frame 1. */
 typedef int (*cofusion_allreduce_i64_fn)(int64_t *buf, uint64_t n, void *user);
 int cofusion_set_allreduce(cofusion_handle *h, cofusion_allreduce_i64_fn fn, void *user);
+/* Optional second form of the same collective for buffers that live in HBM (the per-superpixel segmentation sums, 2*16*K
+ * int64): an in-place SUM all-reduce of `n` int64 values at device address `dev_buf`, ENQUEUED on `hip_stream` (ncclAllReduce on
+ * that stream, or on a stream ordered after it and before whatever is enqueued next) -- no host visit.  Without it such
+ * buffers are staged through the host callback. */
+typedef int (*cofusion_allreduce_dev_fn)(int64_t *dev_buf, uint64_t n, void *hip_stream, void *user);
+int cofusion_set_allreduce_device(cofusion_handle *h, cofusion_allreduce_dev_fn fn, void *user);
 /* 1 if the model at `index` lives on this rank, 0 if it is a shadow (count reads 0, download is empty) */
 int cofusion_model_owned(cofusion_handle *h, int index);
 /* diagnostics: accumulated host wall-clock (ms) per processFrame phase on the calling thread -- prepare, track, slic+sums,

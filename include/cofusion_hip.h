@@ -124,6 +124,7 @@ int cf_malloc_host(cf_ctx *ctx, uint64_t bytes, void **hptr);
 int cf_free_host(cf_ctx *ctx, void *hptr);
 int cf_memcpy_h2d_async(cf_ctx *ctx, void *dst, const void *src_pinned, uint64_t bytes);
 int cf_memcpy_d2h_async(cf_ctx *ctx, void *dst_pinned, const void *src, uint64_t bytes);
+int cf_memcpy_d2d_async(cf_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* FrameData.rgb (3 B/pixel, device copy) -> RGBA8 with alpha 255: the GL_RGBA upload of CoFusion.cpp:179 */
 int cf_rgb_to_rgba(cf_ctx *ctx, const uint8_t *rgb_dev, int cols, int rows, uint8_t *rgba_dev);
 
@@ -301,6 +302,32 @@ int cf_seg_crf(cf_segmenter *s, const float *unary_host, int L, const float *fea
                float w_smooth, float w_app, int iterations, float *Q_host);
 /* Slic::upsample<unsigned char> (Slic.h:127-139): low_map [K] host -> full-resolution mask on the device */
 int cf_seg_upsample(cf_segmenter *s, const uint8_t *low_map_host, uint8_t *full_dev);
+/* Device-resident flavour of the three calls above (what the facade uses): per-superpixel sums stay on the device
+ * (cf_seg_sums), unary construction, the mean field, arg-max, connected components (ConnectedLabels.hpp:50-172), the
+ * largest-component / size / border gates, bounding boxes, depth statistics and the up-sampling into full_dev all run as
+ * kernels (cf_seg_infer, Segmentation.cpp:160-706); only the decisions come back (cf_seg_fetch, the one host wait). */
+typedef struct {
+    float unaryWeightError, unaryKError, unaryThresholdNew;        /* GUI defaults 75, 0.0375, 5.5 (GUI.h:222-224) */
+    float weightAppearance, weightSmoothness;                      /* 7, 2 */
+    float scaleFeaturesRGB, scaleFeaturesDepth, scaleFeaturesPos;  /* 1/10, 1/0.9, 1/1.8 */
+    float minRelSizeNew, maxRelSizeNew;                            /* 0.015, 0.4 */
+    int crfIterations;                                             /* 10 */
+} cf_seg_params;
+typedef struct {  /* SegmentationResult::ModelData (Segmentation.h:45-71) */
+    uint32_t id, superPixelCount;
+    float avgConfidence, depthMean, depthStd;
+    int32_t top, right, bottom, left;
+} cf_seg_model;
+typedef struct {
+    int32_t has_new_label, n_models;   /* n_models: rows of model[] (the new label's row is dropped when it got no superpixel) */
+    float depth_range;
+    cf_seg_model model[17];
+} cf_seg_result;
+int cf_seg_sums(cf_segmenter *s, const float *depth, int n_models, const float *const *icp_err, const float *const *vertconf4,
+                int64_t **sums_dev, uint64_t *sums_words);
+int cf_seg_infer(cf_segmenter *s, const cf_seg_params *params, const uint8_t *rgba, int n_models, const uint32_t *model_ids,
+                 uint32_t next_model_id, int allow_new, uint8_t *full_dev);
+int cf_seg_fetch(cf_segmenter *s, cf_seg_result *out, uint8_t *low_map_host);
 /* device view of the SLIC labels, int32 [H*W] */
 int cf_seg_labels(cf_segmenter *s, void **dptr, uint64_t *bytes);
 

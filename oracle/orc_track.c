@@ -21,6 +21,10 @@
 #include <float.h>
 #include <stdlib.h>
 
+/* OpenMP only where a loop covers a full-size image: on the small pyramid levels (and in the small-image tests) a parallel region
+ * costs more than the loop, and on a box whose cgroup grants fewer cores than it shows it costs a lot more */
+#define ORC_OMP_MIN_PIXELS 65536
+
 static inline orc_cam cam_level(orc_cam c, int level)
 { /* CameraModel::operator(), types.cuh:94-98 */
     int div = 1 << level;
@@ -37,7 +41,7 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 void orc_create_vmap(const float *depth, int cols, int rows, orc_cam intr, float depth_cutoff, float *vmap)
 {
     const float fx_inv = 1.f / intr.fx, fy_inv = 1.f / intr.fy;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int v = 0; v < rows; v++)
         for (int u = 0; u < cols; u++) {
             float z = depth[v * cols + u];
@@ -54,7 +58,7 @@ void orc_create_vmap(const float *depth, int cols, int rows, orc_cam intr, float
 /* computeNmapKernel, cudafuncs.cu:152-189 */
 void orc_create_nmap(const float *vmap, int cols, int rows, float *nmap)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int v = 0; v < rows; v++)
         for (int u = 0; u < cols; u++) {
             if (u == cols - 1 || v == rows - 1) { nmap[v * cols + u] = orc_qnan(); continue; }
@@ -75,7 +79,7 @@ void orc_create_nmap(const float *vmap, int cols, int rows, float *nmap)
 /* copyMapsKernel, cudafuncs.cu:271-311: RGBA32F -> planar, z==0 -> NaN (all 3 planes) */
 void orc_copy_maps(const float *v4, const float *n4, int cols, int rows, float *vmap, float *nmap)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) {
             const float *vs = v4 + (y * cols + x) * 4, *ns = n4 + (y * cols + x) * 4;
@@ -91,7 +95,7 @@ void orc_copy_maps(const float *v4, const float *n4, int cols, int rows, float *
 void orc_resize_map(const float *in, int in_cols, int in_rows, float *out, int normalize)
 {
     const int dcols = in_cols / 2, drows = in_rows / 2, srows = in_rows;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (dcols * drows >= ORC_OMP_MIN_PIXELS)
     for (int y = 0; y < drows; y++)
         for (int x = 0; x < dcols; x++) {
             int xs = x * 2, ys = y * 2;
@@ -114,7 +118,7 @@ void orc_transform_maps(float *vmap, float *nmap, int cols, int rows, const floa
 {
     orc_m33 Rm; memcpy(Rm.m, R, sizeof(Rm.m));
     const orc_f3 tv = {t[0], t[1], t[2]};
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) {
             float vx = vmap[y * cols + x];
@@ -139,7 +143,7 @@ void orc_transform_maps(float *vmap, float *nmap, int cols, int rows, const floa
 /* verticesToDepthKernel, cudafuncs.cu:602-613 */
 void orc_vertices_to_depth(const float *v4, int cols, int rows, float cutoff, float *depth)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int i = 0; i < cols * rows; i++) {
         float z = v4[i * 4 + 2];
         depth[i] = (z > cutoff || z <= 0) ? orc_qnan() : z;
@@ -154,7 +158,7 @@ static const float kGauss25[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 2
 void orc_pyrdown_gauss_f32(const float *src, int src_cols, int src_rows, float *dst)
 {
     const int dcols = src_cols / 2, drows = src_rows / 2, D = 5;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (dcols * drows >= ORC_OMP_MIN_PIXELS)
     for (int y = 0; y < drows; y++)
         for (int x = 0; x < dcols; x++) {
             int tx = imin(2 * x - D / 2 + D, src_cols - 1);
@@ -177,7 +181,7 @@ void orc_pyrdown_gauss_f32(const float *src, int src_cols, int src_rows, float *
 void orc_pyrdown_gauss_u8(const uint8_t *src, int src_cols, int src_rows, uint8_t *dst)
 {
     const int dcols = src_cols / 2, drows = src_rows / 2, D = 5;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (dcols * drows >= ORC_OMP_MIN_PIXELS)
     for (int y = 0; y < drows; y++)
         for (int x = 0; x < dcols; x++) {
             int tx = imin(2 * x - D / 2 + D, src_cols - 1);
@@ -202,7 +206,7 @@ void orc_pyrdown_gauss_u8(const uint8_t *src, int src_cols, int src_rows, uint8_
  * CoFusion.cpp:179), so the weights land as .114 R + .299 G + .587 B. */
 void orc_rgba_to_intensity(const uint8_t *rgba, int cols, int rows, uint8_t *dst)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int i = 0; i < cols * rows; i++) {
         int value = (int)((float)rgba[i * 4 + 0] * 0.114f + (float)rgba[i * 4 + 1] * 0.299f + (float)rgba[i * 4 + 2] * 0.587f);
         dst[i] = (uint8_t)value;
@@ -215,7 +219,7 @@ void orc_sobel(const uint8_t *src, int cols, int rows, int16_t *dx, int16_t *dy)
 {
     static const float gsx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
     static const float gsy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) {
             float dxv = 0, dyv = 0; int k = 8;
@@ -234,7 +238,7 @@ void orc_sobel(const uint8_t *src, int cols, int rows, int16_t *dx, int16_t *dy)
 void orc_project_cloud(const float *depth, int cols, int rows, orc_cam il, float *cloud3)
 {
     const float invFx = 1.0f / il.fx, invFy = 1.0f / il.fy;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) {
             float z = depth[y * cols + x];
@@ -322,7 +326,7 @@ void orc_icp_step(const float Rcurr[9], const float tcurr[3], const float *vmap_
                  dist_thres, angle_thres, cols, rows);
     memset(sums, 0, sizeof(int64_t) * ORC_SE3_WORDS);
     /* integer sums: the OpenMP reduction is exact and order independent */
-#pragma omp parallel for schedule(static) reduction(+ : sums[:ORC_SE3_WORDS])
+#pragma omp parallel for schedule(static) reduction(+ : sums[:ORC_SE3_WORDS]) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) {
             float row[7], err;
@@ -443,7 +447,7 @@ void orc_rgb_residual(float min_scale, const int16_t *dIdx, const int16_t *dIdy,
                       int cols, int rows, int *sigma_sum, int *count)
 {
     int cnt = 0, sig = 0;
-#pragma omp parallel for schedule(static) reduction(+ : cnt, sig)
+#pragma omp parallel for schedule(static) reduction(+ : cnt, sig) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int k = 0; k < cols * rows; k++) {
         int i = k / cols, j0 = k - i * cols;
         orc_dataterm c; memset(&c, 0, sizeof(c));
@@ -514,7 +518,7 @@ void orc_rgb_step(const orc_dataterm *corres, float sigma, const float *cloud3, 
 {
     const rgb_ctx r = {corres, sigma, cloud3, fx, fy, dIdx, dIdy, sobel_scale, cols};
     memset(sums, 0, sizeof(int64_t) * ORC_SE3_WORDS);
-#pragma omp parallel for schedule(static) reduction(+ : sums[:ORC_SE3_WORDS])
+#pragma omp parallel for schedule(static) reduction(+ : sums[:ORC_SE3_WORDS]) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int i = 0; i < cols * rows; i++) {
         float row[7];
         if (rgb_row(&r, i, row)) se3_accumulate(row, 1, orc_rgb_fix_bits(sigma), sums);
@@ -582,7 +586,7 @@ void orc_so3_step(const uint8_t *last_image, const uint8_t *next_image, const fl
     so3_ctx c = {last_image, next_image, {{0}}, {{0}}, krlr, cols, rows};
     memcpy(c.B.m, image_basis, 36); memcpy(c.Ki.m, kinv, 36);
     memset(sums, 0, sizeof(int64_t) * ORC_SO3_WORDS);
-#pragma omp parallel for schedule(static) reduction(+ : sums[:ORC_SO3_WORDS])
+#pragma omp parallel for schedule(static) reduction(+ : sums[:ORC_SO3_WORDS]) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int k = 0; k < cols * rows; k++) {
         float row[4];
         if (!so3_row(&c, k, row)) continue;

@@ -34,7 +34,7 @@ SHADERS = os.path.join(REF, "Core", "Shaders")
 # the surfel passes of the hot path; geometry shaders are pass-through filters restated in ref_gl.cpp
 SHADER_FILES = ["data.vert", "update.vert", "copy_unstable.vert", "index_map.vert", "index_map.frag", "splat.vert",
                 "combo_splat.frag", "vertex_feedback.vert", "init_unstable.vert", "fill_vertex.frag", "fill_normal.frag",
-                "fill_rgb.frag", "depth_bilateral_metric.frag", "data.frag"]
+                "fill_rgb.frag", "depth_bilateral_metric.frag", "data.frag", "resize.frag"]
 FLOAT_LIT = re.compile(r"(?<![\w.])((?:\d+\.\d*|\.\d+)(?:[eE][-+]?\d+)?|\d+[eE][-+]?\d+)(?![\w.])")
 
 

@@ -182,6 +182,24 @@ void ref_fill_in(const float* pred_vertex4, const float* pred_normal4, const uin
         }
 }
 
+// resize.frag through GPUResize (Shaders/Resize.cpp: a full-target quad into a cols/20 x rows/20 RGB8 renderbuffer), then the count of
+// CoFusion::requiresFillIn (CoFusion.cpp:547-565).  The source is ModelProjection's splatColorTexture (draw = false: NEAREST).
+int ref_requires_fill_in(const uint8_t* pred_image, int cols, int rows, float ratio)
+{
+    namespace R = sh_resize_frag;
+    const int dw = cols / 20, dh = rows / 20;
+    R::eSampler = tex_u8(pred_image, cols, rows);
+    int sum = 0;
+    for (int j = 0; j < dh; j++)
+        for (int i = 0; i < dw; i++) {
+            R::texcoord = vec2(((float)i + 0.5f) / (float)dw, ((float)j + 0.5f) / (float)dh);
+            R::shader_main();
+            const uint8_t r = unorm8(R::FragColor.d[0]), g = unorm8(R::FragColor.d[1]), b = unorm8(R::FragColor.d[2]);
+            sum += r > 0 && g > 0 && b > 0;
+        }
+    return float(sum) / float(dh * dw) < ratio;
+}
+
 // data.vert + data.geom + data.frag, then update.vert (Model::fuse)
 void ref_fuse(const float* surfels_in, int count, const uint32_t* index, const float* vertConf4, const float* normRad4, const uint8_t* rgba,
               const float* depth_raw, const float* depth_filt, const uint8_t* mask, const float pose[16], orc_cam cam, int cols, int rows,

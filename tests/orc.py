@@ -25,6 +25,27 @@ def _load():
 lib = _load()
 
 
+def usable_cpus() -> int:
+    """cores this process may really use: affinity mask AND the cgroup quota (a container can show 256 CPUs and grant 8)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def set_threads(n: int) -> None:
+    C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+
+
+# the oracle's OpenMP loops (bilateral filter, full-size tracking passes): never more threads than cores really granted, and a small
+# team by default -- the tests run many short calls
+set_threads(min(8, usable_cpus()))
+
+
 class Cam(C.Structure):
     _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
 

@@ -267,3 +267,26 @@ def test_ground_truth_mask_branch_matches_reference_sources():
         if o["hasNewLabel"]:
             ids.append(next_id); next_id += 1
     assert len(ids) >= 3
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_requires_fill_in_matches_resize_shader():
+    """CoFusion::requiresFillIn (CoFusion.cpp:547-565): resize.frag into the 20x smaller buffer + the count, reference shader vs oracle,
+    on predictions with holes of every size (incl. the decision flipping around the 0.75 ratio)."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    L = ref.lib()
+    flips = set()
+    for (w, h) in ((640, 480), (320, 240), (160, 120)):
+        for fill in (0.2, 0.6, 0.74, 0.76, 0.9, 1.0):
+            img = rng.integers(1, 256, size=(h, w, 4), dtype=np.uint8)
+            coarse = rng.random((h // 10, w // 10)) > fill
+            hole = np.kron(coarse, np.ones((10, 10), bool))
+            img[hole] = 0
+            img[rng.random((h, w)) < 0.02, 1] = 0   # single zero channels count as holes too
+            img = np.ascontiguousarray(img)
+            a = orc.lib.orc_requires_fill_in(orc.P(img), w, h, C.c_float(0.75))
+            b = L.ref_requires_fill_in(orc.P(img), w, h, C.c_float(0.75))
+            assert a == b, f"{w}x{h} fill {fill}: oracle {a} vs reference shader {b}"
+            flips.add(int(a))
+    assert flips == {0, 1}
