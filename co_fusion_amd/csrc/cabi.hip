@@ -58,7 +58,6 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     memset(ctx->h_state_pool, 0, sizeof(OdomDev) * cf_ctx::kStateSlots);
     if (int r = dmalloc(ctx, &ctx->d_model_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_so3_sync, (size_t)ctx->cfg.max_models + 1)) return r;
-    if (int r = dmalloc(ctx, &ctx->d_gn_sync, (size_t)ctx->cfg.max_models + 1)) return r;
     if (const char* e = getenv("CF_GN_MODE")) ctx->gn_mode = atoi(e);  // diagnostic: 0 = three launches per iteration
     if (const char* e = getenv("CF_ICP_LAUNCH")) {  // diagnostic: "threads,pixels_per_thread"
         int t = 0, p = 0;
@@ -81,7 +80,7 @@ void cf_destroy(cf_ctx* ctx)
     if (!ctx) return;
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_acc_a); (void)hipFree(ctx->d_acc_b); (void)hipFree(ctx->d_out);
-    (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_gn_sync); (void)hipFree(ctx->d_cand_scratch);
+    (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_cand_scratch);
     (void)hipFree(ctx->d_state_pool); (void)hipHostFree(ctx->h_state_pool);
     (void)hipHostFree(ctx->h_scratch_state); (void)hipHostFree(ctx->h_model_ptrs); (void)hipHostFree(ctx->h_out);
     if (ctx->prof.events) {
@@ -802,7 +801,7 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     fill_icp_args(ctx, ods, n, icp_args);
     RgbArgs rgb_args[3];
     fill_rgb_args(ctx, ods, n, rgb_args);
-    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, ctx->d_gn_sync, icp_args, rgb_args, n, ctx->cfg.width,
+    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, icp_args, rgb_args, n, ctx->cfg.width,
                     ctx->cfg.height, opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, &ctx->prof);
     LAUNCHCHK(ctx);
     if (lo >= 0) {

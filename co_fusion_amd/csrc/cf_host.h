@@ -22,8 +22,7 @@ struct cf_ctx {
     cf::OdomDev** h_model_ptrs = nullptr;  // pinned
     uint8_t* d_cand_scratch = nullptr;
     cf::So3Sync* d_so3_sync = nullptr;  // [max_models]
-    cf::GnSync* d_gn_sync = nullptr;    // [max_models]
-    int gn_mode = 1;                    // launch_gn_track mode (1: two launches per Gauss-Newton iteration)
+    int gn_mode = 1;                    // launch_gn_track mode (1: record slots between the residual pass and the RGB step)
     // device / pinned-host pools of the trackers' state structs: a batch of trackers is uploaded / read back with ONE
     // copy over its slot range instead of one copy per tracker
     static constexpr int kStateSlots = 64;

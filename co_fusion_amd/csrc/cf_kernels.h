@@ -126,20 +126,23 @@ struct RgbModelArgs {
     const uint8_t* lastImage; const uint8_t* nextImage;
     cf_dataterm* corres; const float* cloud; const int16_t* dIdx; const int16_t* dIdy;
     unsigned long long* icp_acc; unsigned long long* rgb_acc;
-    uint2* recs;                        // compact correspondence list of the device-resident loop (aliases corres)
+    uint2* recs;                        // record slots of the device-resident loop (aliases corres: N x 8 B)
+    unsigned* slot_counts;              // records per slot (behind the records in the same buffer)
 };
 struct RgbArgs {
     RgbModelArgs m[kMaxBatch];
     int cols, rows;
     cf_cam il;                          // intrinsics of this level
     float sobelScale, maxDepthDelta;
-    int compact;                        // residual pass writes the compact list (recs) instead of the DataTerm image
+    int compact;                        // residual pass writes record slots (recs) instead of the DataTerm image
+    int slot_px;                        // pixels (= record capacity) per slot: 4 x the producer's workgroup size
 };
 inline RgbModelArgs rgb_model_args(const OdomDev* h /* host mirror */, OdomDev* d_state, int level)
 {
     return RgbModelArgs{d_state, h->cand[level], h->nextDepth[level], h->lastDepth[level], h->lastImage[level], h->nextImage[level],
                         h->corres[level], h->cloud[level], h->dIdx[level], h->dIdy[level], h->icp_acc, h->rgb_acc,
-                        reinterpret_cast<uint2*>(h->corres[level])};
+                        reinterpret_cast<uint2*>(h->corres[level]),
+                        reinterpret_cast<unsigned*>(reinterpret_cast<uint2*>(h->corres[level]) + (size_t)(h->width >> level) * (h->height >> level))};
 }
 struct IcpArgs {
     IcpModelArgs m[kMaxBatch];
@@ -172,11 +175,10 @@ struct ProfSink {  // hipEvent pairs recorded around every ICP-reduce launch whe
 // cross-workgroup state of the SO3 pre-alignment (zero between launches): per-iteration totals + arrival counters
 constexpr int kSo3Blocks = 16;
 struct So3Sync { unsigned long long acc[10][16]; unsigned arrive, depart; };
-struct GnSync { unsigned arrive; unsigned pad[15]; };  // arrival counter of gn_rgb_solve_kernel (zero between launches), one 64 B line per model
-// mode 0: {ICP || residual (DataTerm image)} + rgb_step + solve, 3 launches per iteration;
-// mode 1: {ICP || residual (compact list)} + {list pass + solve}, 2 launches per iteration
+// mode 0: {ICP || residual -> DataTerm image} + rgb_step over the image + solve;
+// mode 1: {ICP || residual -> per-workgroup record slots} + rgb step over the slots + solve
 void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */, So3Sync* so3_syncs /* [n] */,
-                     GnSync* gn_syncs /* [n] */, const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3,
+                     const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3,
                      bool pyramid, bool fast_odom, bool rgb, bool icp, int mode, ProfSink* prof);
 float sqrt_gate_lt(float T);  // smallest x with sqrtf(x) >= T
 float sqrt_gate_le(float T);  // largest x with sqrtf(x) <= T

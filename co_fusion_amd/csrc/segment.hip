@@ -337,16 +337,43 @@ struct SegUnaryArgs {
     float* depth_range;              // [1]
 };
 
+// Sequential f32 sum init + t[0] + t[1] + ... + t[n-1] (this order) by ONE wave: the lanes fetch 64 consecutive terms per step (one
+// coalesced request; the next step's terms are already in flight), lane-uniform code then feeds the chain of additions from
+// registers through v_readlane.  term(j) -> the j-th term, 0.0f for "skip" (x + 0.0f == x for every x these sums can reach, so
+// skipping an element and adding zero agree).  Returns the sum in every lane.
+template <class F>
+__device__ __forceinline__ float wave_sequential_sum(float init, int n, int lane, F term)
+{
+    float sum = init;
+    float cur = lane < n ? term(lane) : 0.f;
+    for (int base = 0; base < n; base += 64) {
+        const int nj = base + 64 + lane;
+        const float nxt = nj < n ? term(nj) : 0.f;
+        const int m = min(64, n - base);
+        if (m == 64) {
+#pragma unroll
+            for (int j = 0; j < 64; j++) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), j));
+        } else {
+            for (int j = 0; j < m; j++) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), j));
+        }
+        cur = nxt;
+    }
+    return sum;
+}
+
 // Slic::downsample<float> normalisation incl. the empty-superpixel fallback (Slic.h:63-76, 192-206) evaluated in place and in index
 // order by the reference: an empty superpixel k reads entry `read`, which has ALREADY been divided when read < k and is still the
 // raw sum when read > k.  Non-empty entries do not depend on anything else (phase 1, parallel); the rare empty ones are replayed in
-// index order by one lane per array (phase 2).
+// index order by one lane per array (phase 2) from a list built with an ordered scan.
 __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegUnaryArgs a)
 {
     const int K = a.K, n = a.n_models, A = 1 + 2 * n, L = a.L;
-    const int tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float s_min[16], s_max[16];
     __shared__ float s_range;
+    __shared__ int s_scan[1024];
+    __shared__ int s_nempty[2];
+    int* empties = reinterpret_cast<int*>(a.raw + (size_t)A * K);  // scratch behind the raw sums: [2][K] (depth-empty, pixel-empty)
     // A: raw sums as f32, phase 1 of the normalisation
     for (int idx = tid; idx < A * K; idx += T) {
         const int arr = idx / K, k = idx - arr * K;
@@ -356,14 +383,32 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegUnaryArgs a)
         const int cnt = (int)(arr == 0 ? a.depth_count[k] : a.spix_count[k]);
         a.low[idx] = cnt != 0 ? raw / (float)cnt : raw;
     }
-    __syncthreads();
+    // ordered lists of the empty superpixels (which == 0: no depth sample, which == 1: no pixel at all)
+    const int per = (K + T - 1) / T;
+    for (int which = 0; which < 2; which++) {
+        const unsigned* cnts = which == 0 ? a.depth_count : a.spix_count;
+        int c = 0;
+        for (int k = tid * per; k < min(K, (tid + 1) * per); k++) c += cnts[k] == 0;
+        s_scan[tid] = c;
+        __syncthreads();
+        for (int o = 1; o < T; o <<= 1) {
+            const int v = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        int pos = s_scan[tid] - c;
+        for (int k = tid * per; k < min(K, (tid + 1) * per); k++) if (cnts[k] == 0) empties[which * K + pos++] = k;
+        if (tid == T - 1) s_nempty[which] = s_scan[tid];
+        __syncthreads();
+    }
     // phase 2: empty superpixels in index order, one lane per array
     if (tid < A) {
         float* low = a.low + (size_t)tid * K;
         const float* raw = a.raw + (size_t)tid * K;
-        for (int k = 0; k < K; k++) {
-            const int own = (int)(tid == 0 ? a.depth_count[k] : a.spix_count[k]);
-            if (own != 0) continue;
+        const int which = tid == 0 ? 0 : 1, ne = s_nempty[which];
+        for (int e = 0; e < ne; e++) {
+            const int k = empties[which * K + e];
             const int read = a.resample[k];
             const int cnt = (int)a.spix_count[read];
             const float base = read < k ? low[read] : raw[read];
@@ -386,7 +431,7 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegUnaryArgs a)
             if (omn < mn) mn = omn;
             if (mx < omx) mx = omx;
         }
-        if ((tid & 63) == 0) { s_min[tid >> 6] = mn; s_max[tid >> 6] = mx; }
+        if (lane == 0) { s_min[wave] = mn; s_max[wave] = mx; }
         __syncthreads();
         if (tid == 0) {
             for (int w = 1; w < (T >> 6); w++) { if (s_min[w] < mn) mn = s_min[w]; if (mx < s_max[w]) mx = s_max[w]; }
@@ -394,16 +439,13 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegUnaryArgs a)
             a.depth_range[0] = s_range;
         }
     }
-    // average confidence per model: a sequential f32 sum in index order (:193-203); non-finite entries are zeroed in place
-    if (tid >= 64 && tid < 64 + n) {
-        float* conf = a.low + (size_t)(1 + n + (tid - 64)) * K;
-        float avg = 0;
-        for (int j = 0; j < K; j++) {
-            const float c = conf[j];
-            if (!is_finite(c)) { conf[j] = 0; continue; }
-            avg += c;
-        }
-        a.avg_conf[tid - 64] = avg / (float)K;
+    // average confidence per model: a sequential f32 sum in index order (:193-203), one WAVE per model; non-finite entries count as
+    // zero and are zeroed in place afterwards
+    for (int m = wave; m < n; m += (T >> 6)) {
+        float* conf = a.low + (size_t)(1 + n + m) * K;
+        const float avg = wave_sequential_sum(0.f, K, lane, [&](int j) { const float c = conf[j]; return is_finite(c) ? c : 0.f; });
+        for (int j = lane; j < K; j += 64) if (!is_finite(conf[j])) conf[j] = 0;
+        if (lane == 0) a.avg_conf[m] = avg / (float)K;
     }
     __syncthreads();
     const float depthRange = s_range;
@@ -466,18 +508,21 @@ struct SegPostArgs {
 
 // arg-max labels -> connected components (ConnectedLabels.hpp:50-172: 4-connectivity, components numbered by their first pixel in
 // raster order) -> largest-component / size / border gates -> bounding boxes, depth statistics, super-pixel counts (:475-646).
-// One workgroup: the label image has K = 1200 superpixels (4800 at 1280x960).
+// One workgroup: the label image has K = 1200 superpixels (4800 at 1280x960, the largest supported); labels, union-find parents and
+// component numbers live in LDS, the sequential sums of the statistics run one wave per model (wave_sequential_sum).
+constexpr int kSegMaxK = 4800;
 __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
 {
-    const int K = a.K, gx = a.gx, L = a.L, tid = threadIdx.x, T = blockDim.x;
+    const int K = a.K, gx = a.gx, L = a.L, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int n_md = a.n_models + (a.allow_new ? 1 : 0);
     __shared__ int s_changed, s_ncc, s_min_label;
     __shared__ int s_scan[1024];
     __shared__ int s_id2idx[256];
     __shared__ int s_box[kMaxL + 1][4];   // top, right, bottom, left per model entry (full-resolution pixels after mapToHigh)
     __shared__ unsigned s_spc[kMaxL + 1];
-    unsigned char* map = a.low_map;
-    int* parent = a.parent; int* comp = a.comp;
+    __shared__ unsigned char map[kSegMaxK];
+    __shared__ int parent[kSegMaxK];
+    __shared__ int comp[kSegMaxK];
     int *c_label = a.cc, *c_size = a.cc + K, *c_top = a.cc + 2 * K, *c_right = a.cc + 3 * K, *c_bottom = a.cc + 4 * K, *c_left = a.cc + 5 * K;
     // 1. label with the highest marginal (first maximum), as model id
     for (int k = tid; k < K; k += T) {
@@ -500,12 +545,13 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
         for (int k = tid; k < K; k += T) {
             const int x = k % gx, y = k / gx;
             const unsigned char v = map[k];
-            int p = parent[k];
+            const int own = parent[k];
+            int p = own;
             if (x > 0 && map[k - 1] == v) p = min(p, parent[k - 1]);
             if (x + 1 < gx && map[k + 1] == v) p = min(p, parent[k + 1]);
             if (y > 0 && map[k - gx] == v) p = min(p, parent[k - gx]);
             if (y + 1 < a.gy && map[k + gx] == v) p = min(p, parent[k + gx]);
-            if (p < parent[k]) { atomicMin(&parent[parent[k]], p); atomicMin(&parent[k], p); s_changed = 1; }
+            if (p < own) { atomicMin(&parent[own], p); atomicMin(&parent[k], p); s_changed = 1; }
         }
         __syncthreads();
         for (int k = tid; k < K; k += T) {  // pointer jumping
@@ -547,6 +593,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
         atomicMin(&c_top[c], y); atomicMax(&c_bottom[c], y); atomicMin(&c_left[c], x); atomicMax(&c_right[c], x);
         if (parent[k] == k) { c_label[c] = map[k]; atomicMin(&s_min_label, (int)map[k]); }
     }
+    __threadfence_block();
     __syncthreads();
     // 5. onlyKeepLargest (:496-517): every label but the smallest keeps its largest component (ties: the earlier one); one lane per label
     if (tid < 255 && tid != s_min_label) {
@@ -557,6 +604,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
             if (c_size[keep] < c_size[i]) { c_label[keep] = 255; keep = i; } else c_label[i] = 255;
         }
     }
+    __threadfence_block();
     __syncthreads();
     // 6. a new label must have a plausible size (:521-530)
     if (a.allow_new) {
@@ -564,6 +612,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
         for (int i = tid; i < ncc; i += T)
             if (c_label[i] == (int)a.next_id && (c_size[i] < minSize || c_size[i] > maxSize)) c_label[i] = 255;
     }
+    __threadfence_block();
     __syncthreads();
     // 7. bounding boxes (:532-547) and 8. labels whose box lies inside the border strip are rejected (:549-563); one lane per model
     if (tid < n_md) {
@@ -590,32 +639,45 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
             for (int i = 0; i < ncc; i++) if (c_label[i] == id) c_label[i] = 255;
         }
     }
+    __threadfence_block();
     __syncthreads();
     // 9. final low-resolution label map
-    for (int k = tid; k < K; k += T) map[k] = (unsigned char)c_label[comp[k]];
+    for (int k = tid; k < K; k += T) { const unsigned char v = (unsigned char)c_label[comp[k]]; map[k] = v; a.low_map[k] = v; }
     __syncthreads();
     // 10. depth statistics with one trimming pass (:570-621) and super-pixel counts (:624-627): sequential f32 sums in index order,
-    //     one lane per model entry
-    if (tid < n_md) {
+    //     one wave per model entry
+    for (int ix = wave; ix < n_md; ix += (T >> 6)) {
         const float* lowDepth = a.low_depth;
-        float sumDepth = 0, sumDev = 0; unsigned cnt = 0, spc = 0;
-        for (int i = 0; i < K; i++) { if (map[i] == 255 || s_id2idx[map[i]] != tid) continue; sumDepth += lowDepth[i]; cnt++; spc++; }
+        auto mine = [&](int i) { const unsigned char v = map[i]; return v != 255 && s_id2idx[v] == ix; };
+        unsigned cnt = 0;
+        for (int i = lane; i < K; i += 64) cnt += mine(i) ? 1u : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        const unsigned spc = cnt;
+        float sumDepth = wave_sequential_sum(0.f, K, lane, [&](int i) { return mine(i) ? lowDepth[i] : 0.f; });
         float mean = cnt ? sumDepth / (float)cnt : 0;
-        for (int i = 0; i < K; i++) { if (map[i] == 255 || s_id2idx[map[i]] != tid) continue; sumDev += fabsf(mean - lowDepth[i]); }
+        float sumDev = wave_sequential_sum(0.f, K, lane, [&](int i) { return mine(i) ? fabsf(mean - lowDepth[i]) : 0.f; });
         float dev = cnt ? sumDev / (float)cnt : 0;
-        if (tid != 0)
-            for (int i = 0; i < K; i++) {
-                if (map[i] == 255 || s_id2idx[map[i]] != tid) continue;
-                const float d = lowDepth[i];
-                if ((double)d > 1.1 * (double)dev + (double)mean) { sumDepth -= d; sumDev -= fabsf(mean - d); cnt--; }
-            }
+        if (ix != 0) {
+            // trimming pass: elements beyond mean + 1.1 dev are taken out of the running sums, in index order (x - d == x + (-d))
+            auto trimmed = [&](int i) { return mine(i) && (double)lowDepth[i] > 1.1 * (double)dev + (double)mean; };
+            unsigned out = 0;
+            for (int i = lane; i < K; i += 64) out += trimmed(i) ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) out += __shfl_xor(out, o, 64);
+            sumDepth = wave_sequential_sum(sumDepth, K, lane, [&](int i) { return trimmed(i) ? -lowDepth[i] : 0.f; });
+            sumDev = wave_sequential_sum(sumDev, K, lane, [&](int i) { return trimmed(i) ? -fabsf(mean - lowDepth[i]) : 0.f; });
+            cnt -= out;
+        }
         mean = cnt ? sumDepth / (float)cnt : 0;
         dev = cnt ? sumDev / (float)cnt : 0;
-        cf_seg_model& o = a.result->model[tid];
-        o.id = a.ids[tid]; o.superPixelCount = spc; o.avgConfidence = tid < a.n_models ? a.avg_conf[tid] : 0.f;
-        o.depthMean = mean; o.depthStd = dev;
-        o.top = s_box[tid][0]; o.right = s_box[tid][1]; o.bottom = s_box[tid][2]; o.left = s_box[tid][3];
-        s_spc[tid] = spc;
+        if (lane == 0) {
+            cf_seg_model& o = a.result->model[ix];
+            o.id = a.ids[ix]; o.superPixelCount = spc; o.avgConfidence = ix < a.n_models ? a.avg_conf[ix] : 0.f;
+            o.depthMean = mean; o.depthStd = dev;
+            o.top = s_box[ix][0]; o.right = s_box[ix][1]; o.bottom = s_box[ix][2]; o.left = s_box[ix][3];
+            s_spc[ix] = spc;
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -624,6 +686,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
         a.result->has_new_label = has_new; a.result->n_models = n_out; a.result->depth_range = a.depth_range[0];
     }
 }
+
 }  // namespace cf
 
 // ===================================================================================== C-ABI ====
@@ -675,6 +738,7 @@ int cf_seg_create(cf_ctx* ctx, cf_segmenter** out)
 {
     if (!ctx || !out) return CF_EINVAL;
     if ((ctx->cfg.width % kSpix) || (ctx->cfg.height % kSpix)) { ctx->set_error("segmentation needs width/height multiples of 16"); return CF_EINVAL; }
+    if ((ctx->cfg.width / kSpix) * (ctx->cfg.height / kSpix) > kSegMaxK) { ctx->set_error("segmentation supports at most 4800 superpixels (1280x960)"); return CF_EINVAL; }
     cf_segmenter* s = new cf_segmenter();
     s->ctx = ctx; s->gx = ctx->cfg.width / kSpix; s->gy = ctx->cfg.height / kSpix; s->K = s->gx * s->gy;
     *out = s;
@@ -699,7 +763,7 @@ int cf_seg_create(cf_ctx* ctx, cf_segmenter** out)
     if (int r = seg_malloc(ctx, &s->unary, K * kMaxL)) return r;
     if (int r = seg_malloc(ctx, &s->Q0, K * kMaxL)) return r;
     if (int r = seg_malloc(ctx, &s->Q1, K * kMaxL)) return r;
-    if (int r = seg_malloc(ctx, &s->raw_mean, K * (1 + 2 * kMaxL))) return r;
+    if (int r = seg_malloc(ctx, &s->raw_mean, K * (3 + 2 * kMaxL))) return r;  // raw sums + the two lists of empty superpixels
     if (int r = seg_malloc(ctx, &s->low_mean, K * (1 + 2 * kMaxL))) return r;
     if (int r = seg_malloc(ctx, &s->avg_conf, (size_t)kMaxL)) return r;
     if (int r = seg_malloc(ctx, &s->depth_range, (size_t)1)) return r;

@@ -326,9 +326,9 @@ __device__ __forceinline__ bool rgb_residual_pixel(const RgbArgs& ra, const RgbM
 // COMPACT == false: the reference's output format, one DataTerm record per pixel (valid or not), read back by
 // rgb_step_kernel -- 16 B/pixel written and re-read although < 10 % of the records are valid.
 // COMPACT == true (the device-resident Gauss-Newton loop): four pixels per thread, and the valid correspondences of a
-// workgroup are appended to ONE list per model (8 B records; a returning atomic on the list cursor per workgroup).  The
-// order of the list depends on the schedule, the sums taken over it do not (integer accumulation).  The cursor is word 29
-// of accumulator group 0 -- the same word that counts correspondences -- so the solve sees the count where it always was.
+// workgroup are packed into that workgroup's own slot of the record buffer (8 B records, slot = 4 x workgroup size; places
+// inside the slot come from LDS atomics, the count goes to slot_counts[workgroup]) -- no global atomic and no extra memory
+// round trip on the producer side.  The order inside a slot depends on the schedule, the sums taken over it do not.
 template <bool COMPACT>
 __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
 {
@@ -368,7 +368,7 @@ __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
             if (g4) atomicAdd(&dst[30], (unsigned long long)(long long)g4);
         }
     } else {
-        __shared__ int s_n, s_sig, s_base;
+        __shared__ int s_n, s_sig;
         const int k0 = (blk * T + threadIdx.x) * 4;  // cols % 4 == 0: the four pixels share a row
         unsigned cw = 0;
         if (k0 < N) cw = *reinterpret_cast<const unsigned*>(m.cand + k0);
@@ -376,8 +376,8 @@ __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
         const bool on = od->rgb && !od->level_done;  // uniform
         if (!on) return;
         __syncthreads();
-        int g[4], dq[4], nvalid = 0, sig = 0;
         if (__any(cw != 0)) {
+            int g[4], dq[4], nvalid = 0, sig = 0;
             float d1[4] = {0, 0, 0, 0}; unsigned iw = 0;
             if (cw) {
                 const float4 dv = *reinterpret_cast<const float4*>(m.nextDepth + k0);
@@ -395,35 +395,29 @@ __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
                     }
                 }
             }
-            // wave totals, one LDS atomic per wave for the slot offset
             int wn = nvalid, ws = sig;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { wn += __shfl_xor(wn, o, 64); ws += __shfl_xor(ws, o, 64); }
             if (wn) {
-                // exclusive prefix of nvalid inside the wave
-                int incl = nvalid;
+                int incl = nvalid;  // inclusive prefix of nvalid inside the wave
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
                 int wbase = 0;
-                if (lane == 0) { wbase = atomicAdd(&s_n, wn); atomicAdd(&s_sig, ws); }
+                if (lane == 0) { wbase = atomicAdd(&s_n, wn); atomicAdd(&s_sig, ws); }  // LDS: the wave's place inside the slot
                 wbase = __shfl(wbase, 0, 64);
-                nvalid = wbase + incl - nvalid;  // from here on: this thread's first slot inside the workgroup
-            } else nvalid = -1;
-        } else nvalid = -1;
-        __syncthreads();
-        const int bn = s_n;
-        if (bn == 0) return;
-        if (threadIdx.x == 0) {
-            s_base = (int)atomicAdd(&m.icp_acc[29], (unsigned long long)bn);  // list cursor == correspondence count (group 0)
-            const int g4 = s_sig;
-            if (g4) atomicAdd(&m.icp_acc[(size_t)(blk % kGroups) * 32 + 30], (unsigned long long)(long long)g4);
+                uint2* __restrict__ out = m.recs + (size_t)blk * T * 4 + wbase + incl - nvalid;
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+                    if (g[p] >= 0) { *out++ = make_uint2((unsigned)(k0 + p), (unsigned)g[p] | ((unsigned)(dq[p] + 256) << 22)); }
+            }
         }
         __syncthreads();
-        if (nvalid >= 0) {
-            uint2* __restrict__ out = m.recs + s_base + nvalid;
-#pragma unroll
-            for (int p = 0; p < 4; p++)
-                if (g[p] >= 0) { *out++ = make_uint2((unsigned)(k0 + p), (unsigned)g[p] | ((unsigned)(dq[p] + 256) << 22)); }
+        if (threadIdx.x == 0) {
+            const int bn = s_n, g4 = s_sig;
+            m.slot_counts[blk] = (unsigned)bn;  // every workgroup publishes its count: the list pass reads it unconditionally
+            unsigned long long* dst = m.icp_acc + (size_t)(blk % kGroups) * 32;
+            if (bn) atomicAdd(&dst[29], (unsigned long long)bn);
+            if (g4) atomicAdd(&dst[30], (unsigned long long)(long long)g4);
         }
     }
 }
@@ -788,9 +782,6 @@ __device__ __forceinline__ void se3_unpack_word(const unsigned long long* sums, 
 //    one wave (ldlt_solve6_wave), and K^-1 of the next level is formed by another wave meanwhile,
 //  * only Rodrigues and the 3x3 pose composition stay on one lane.
 // Must be called by all 256 threads of a workgroup.
-// COHERENT: the RGB accumulators were written by other workgroups of the SAME launch (gn_rgb_solve_kernel): read them with
-// device-scope atomic loads instead of plain (L2-cached) loads.
-template <bool COHERENT>
 __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* icp_acc, unsigned long long* rgb_acc, int next_level,
                                               int last_of_level)
 {
@@ -811,8 +802,7 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
         unsigned long long a = 0, b = 0;
         for (int g = sl * (kGroups / 8); g < (sl + 1) * (kGroups / 8); g++) {
             a += icp_acc[(size_t)g * 32 + w];
-            if constexpr (COHERENT) b += __hip_atomic_load(&rgb_acc[(size_t)g * 32 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else b += rgb_acc[(size_t)g * 32 + w];
+            b += rgb_acc[(size_t)g * 32 + w];
         }
         s_part[0][sl][w] = a; s_part[1][sl][w] = b;
     }
@@ -939,81 +929,56 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
 
 __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int next_level, int last_of_level)
 {
-    gn_solve_body<false>(args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level);
+    gn_solve_body(args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level);
 }
 
-// RGB step over the compact correspondence list + the solve, in ONE launch (grid: G workgroups x models).
-// Every workgroup reduces its stride of the list into the model's RGB accumulators (integer atomics) and arrives at a
-// counter; workgroup 0 waits for the G arrivals -- the others simply leave -- and then runs the solve.  Compared with
-// rgb_step_kernel + gn_solve_kernel this saves a launch boundary per Gauss-Newton iteration, and the list is < 10 % of
-// the DataTerm image the reference re-reads.  The wait is bounded: if the workgroups of a model are not scheduled
-// within the bound (they always are: G x models <= 256 small workgroups), the fault word is set and the host call
-// that fetches the result reports CF_ESTATE instead of returning a pose computed from partial sums.
-__global__ void __launch_bounds__(256) gn_rgb_solve_kernel(const RgbArgs ra, const GnArgs args, GnSync* __restrict__ syncs, int do_rgb,
-                                                           int next_level, int last_of_level)
+// RGB step over the per-workgroup record slots the residual pass left (grid: one workgroup per slot x models).  A slot holds at
+// most 4 x producer-workgroup-size records and typically < 10 % of that; thread r reads record r of its slot speculatively together
+// with the slot's count, so the pass has the same two dependent memory round trips as rgb_step_kernel on a tenth of the bytes.
+//
+// Measured and dropped (round 2, profiles/r02b): running this pass and the solve in ONE launch -- 32 workgroups per model reduce a
+// global list, fence, arrive at a counter, workgroup 0 waits and solves.  22.6 us per launch against 6.3 + 8.4 us for the two
+// separate kernels plus one boundary: the device-scope release fence and the arrival wait cost more than a kernel boundary does.
+__global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra)
 {
-    const int model = blockIdx.y;
-    const RgbModelArgs& m = ra.m[model];
-    OdomDev* const god = args.od[model];
-    const unsigned G = gridDim.x;
+    const RgbModelArgs& m = ra.m[blockIdx.y];
+    const OdomDev* __restrict__ od = m.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (do_rgb) {
-        if (god->rgb && !god->level_done) {  // uniform over the grid row
-            __shared__ float s_sigma;
-            if (tid < 64) {
-                const long long sg = (long long)group_sum(m.icp_acc, 30, tid);
-                if (tid == 0) s_sigma = sigma_val_from((int)(long long)m.icp_acc[29], (int)sg, god->rgbOnly);
-            }
-            const int count = (int)(long long)m.icp_acc[29];  // list cursor == number of correspondences
-            __syncthreads();
-            const float sigma = s_sigma;
-            const int F = rgb_fix_bits(sigma);
-            const float lim = ldexpf(1.0f, (50 - F) / 2), scale = ldexpf(1.0f, F);
-            unsigned long long acc[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) acc[k] = 0;
-            unsigned long long terms = 0;
-            const uint2* __restrict__ recs = m.recs;
-            for (int r = blockIdx.x * 256 + tid; r < count; r += (int)G * 256) {
-                const uint2 rc = recs[r];
-                float row[7];
-                rgb_step_row(ra, m, sigma, (float)((int)(rc.y >> 22) - 256), (int)rc.x, (int)(rc.y & 0x3fffffu), row);
-                se3_accumulate_dyn(row, acc, lim, scale);
-                terms++;
-            }
-            unsigned long long v = 0;
-            if (__any(terms != 0)) {
-#pragma unroll
-                for (int k = 0; k < 28; k++) acc[k] -= terms * kMagicBits;
-                acc[28] = terms;
-                v = wave_reduce32_u64(acc, lane);
-            }
-            block_commit32<4>(v, lane, wave, 4, m.rgb_acc + (size_t)(blockIdx.x % kGroups) * 32);
-        }
-        if (G > 1) {
-            GnSync* sync = syncs + model;
-            __threadfence();  // this thread's accumulator atomics are performed before the arrival below
-            __syncthreads();
-            if (tid == 0) {
-                atomicAdd(&sync->arrive, 1u);
-                if (blockIdx.x == 0) {
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(&sync->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
-                        if (++spins > (1u << 24)) { god->stats.fault = 1; break; }  // surfaces as CF_ESTATE (cf_odom_fetch_result)
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    __hip_atomic_store(&sync->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            if (blockIdx.x != 0) return;
-            __threadfence();
-            __syncthreads();
-        }
+    const size_t slot0 = (size_t)blockIdx.x * ra.slot_px;
+    const unsigned n = m.slot_counts[blockIdx.x];
+    uint2 rc = make_uint2(0, 0);
+    if (tid < ra.slot_px && slot0 + tid < (size_t)ra.cols * ra.rows) rc = m.recs[slot0 + tid];   // speculative: valid if tid < n
+    if (!(od->rgb && !od->level_done) || n == 0) return;  // uniform
+    __shared__ float s_sigma;
+    if (tid < 64) {
+        const long long cnt = (long long)group_sum(m.icp_acc, 29, tid);
+        const long long sg = (long long)group_sum(m.icp_acc, 30, tid);
+        if (tid == 0) s_sigma = sigma_val_from((int)cnt, (int)sg, od->rgbOnly);
     }
-    if (blockIdx.x != 0) return;
-    gn_solve_body<true>(god, args.icp_acc[model], args.rgb_acc[model], next_level, last_of_level);
+    __syncthreads();
+    const float sigma = s_sigma;
+    const int F = rgb_fix_bits(sigma);
+    const float lim = ldexpf(1.0f, (50 - F) / 2), scale = ldexpf(1.0f, F);
+    unsigned long long acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) acc[k] = 0;
+    unsigned long long terms = 0;
+    for (unsigned r = tid; r < n; r += 256) {
+        if (r >= 256) rc = m.recs[slot0 + r];
+        float row[7];
+        rgb_step_row(ra, m, sigma, (float)((int)(rc.y >> 22) - 256), (int)rc.x, (int)(rc.y & 0x3fffffu), row);
+        se3_accumulate_dyn(row, acc, lim, scale);
+        terms++;
+    }
+    unsigned long long v = 0;
+    if (__any(terms != 0)) {
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc[k] -= terms * kMagicBits;
+        acc[28] = terms;
+        v = wave_reduce32_u64(acc, lane);
+    }
+    block_commit32<4>(v, lane, wave, 4, m.rgb_acc + (size_t)(blockIdx.x % kGroups) * 32);
 }
-
 
 // total of the grouped accumulator -> out[32] (stand-alone steps)
 __global__ void __launch_bounds__(64) acc_total_kernel(const unsigned long long* __restrict__ acc, unsigned long long* __restrict__ out)
@@ -1076,7 +1041,7 @@ void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, 
 // grid barrier, a chain of about five device-scope memory round trips of ~1.5 us each across the XCDs, whereas a dependent
 // launch costs ~2.5 us (tools/microbench/launch_floor.hip).  On this part the kernel boundary IS the cheapest grid barrier.
 // Kept as separate launches.
-void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, GnSync* gn_syncs, const IcpArgs icp_args[3],
+void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const IcpArgs icp_args[3],
                      const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, int mode,
                      ProfSink* prof)
 {
@@ -1093,7 +1058,7 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
         gn.icp_acc[m] = icp_args[0].m[m].acc;
         gn.rgb_acc[m] = icp_args[0].m[m].rgb_acc;
     }
-    const bool fused = mode != 0;
+    const bool slots = mode != 0;
     for (int i = 2; i >= 0; i--) {
         const int N = (width >> i) * (height >> i);
         for (int j = 0; j < iterations[i]; j++) {
@@ -1104,7 +1069,8 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
                 while (next_level >= 0 && iterations[next_level] == 0) next_level--;
             }
             RgbArgs ra = rgb_args[i];
-            ra.compact = fused ? 1 : 0;
+            ra.compact = slots ? 1 : 0;
+            ra.slot_px = cfg.threads * 4;
             {
                 // the roofline figure is quoted on the dominant kernel: the level-0 instantiation
                 const bool timed = prof && prof->enabled && i == 0 && prof->used + 4 <= prof->capacity;
@@ -1114,19 +1080,15 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
                                   timed ? prof->events[prof->used + 1] : nullptr);
                 if (timed) {
                     prof->used += 2;
-                    prof->bytes += (uint64_t)N * ((icp ? 24 + 24 * (uint64_t)n : 0) + (rgb ? (fused ? kRgbResidualBytesCompact : kRgbResidualBytes) * (uint64_t)n : 0));
+                    prof->bytes += (uint64_t)N * ((icp ? 24 + 24 * (uint64_t)n : 0) + (rgb ? (slots ? kRgbResidualBytesCompact : kRgbResidualBytes) * (uint64_t)n : 0));
                     prof->launches += 1;
                 }
             }
-            if (fused) {
-                // workgroups per model for the list pass: the list holds at most N/3 records in practice (gradient + depth gates)
-                int G = rgb ? (N >= 640 * 480 ? 32 : (N >= 320 * 240 ? 16 : 8)) : 1;
-                if (G * n > 256) G = 256 / n;
-                gn_rgb_solve_kernel<<<dim3(G, n), 256, 0, s>>>(ra, gn, gn_syncs, rgb ? 1 : 0, next_level, last_of_level ? 1 : 0);
-            } else {
-                if (rgb) rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(ra);
-                gn_solve_kernel<<<n, 256, 0, s>>>(gn, next_level, last_of_level ? 1 : 0);
+            if (rgb) {
+                if (slots) rgb_slot_step_kernel<<<dim3((N + ra.slot_px - 1) / ra.slot_px, n), 256, 0, s>>>(ra);
+                else rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(ra);
             }
+            gn_solve_kernel<<<n, 256, 0, s>>>(gn, next_level, last_of_level ? 1 : 0);
         }
     }
 }

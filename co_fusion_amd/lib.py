@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcofusion_hip.so")
+# CF_HIP_LIB: another build of the C-ABI library (A/B micro-benchmarks against an earlier build; diagnostics only)
+LIB_PATH = os.environ.get("CF_HIP_LIB") or os.path.join(_HERE, "lib", "libcofusion_hip.so")
 
 # every symbol include/cofusion_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

@@ -331,9 +331,9 @@ int cf_seg_fetch(cf_segmenter *s, cf_seg_result *out, uint8_t *low_map_host);
 /* device view of the SLIC labels, int32 [H*W] */
 int cf_seg_labels(cf_segmenter *s, void **dptr, uint64_t *bytes);
 
-/* schedule of the device-resident Gauss-Newton loop.  1 (default): two launches per iteration -- {ICP reduction || RGB
- * residual -> compact correspondence list} and {list pass + solve}; 0: three launches with the reference's DataTerm
- * image between them (diagnostic / comparison).  Results are bit-identical. */
+/* data path between the RGB residual pass and the RGB step inside the device-resident Gauss-Newton loop.  1 (default): the
+ * residual pass packs the valid correspondences of each workgroup into 8 B records; 0: the reference's 16 B DataTerm record
+ * per pixel (diagnostic / comparison).  Results are bit-identical. */
 int cf_set_gn_mode(cf_ctx *ctx, int mode);
 /* launch-shape tuning of the ICP reduction (GPUConfig.h:51-58 in the reference) */
 int cf_set_icp_launch(cf_ctx *ctx, int threads, int pixels_per_thread);
