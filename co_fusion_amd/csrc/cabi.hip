@@ -373,7 +373,7 @@ int cf_icp_step_band(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], co
     h->nmap_g_prev[0] = nmap_g_prev; h->distThres = dist_thres; h->angleThres = angle_thres; h->err_surface = err_surface;
     if (int r = scratch_commit(ctx)) return r;
     IcpArgs a{};
-    a.m[0] = IcpModelArgs{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, ctx->d_scratch_state, ctx->d_acc_a, err_surface, ctx->d_acc_b};
+    a.m[0] = IcpModelArgs{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, ctx->d_scratch_state, ctx->d_acc_a, err_surface, ctx->d_acc_b, nullptr};
     a.cols = cols; a.rows = rows; a.intr = intr; a.distThres = dist_thres; a.angleThres = angle_thres;
     a.angleSqLt = sqrt_gate_lt(angle_thres); a.distSqLe = sqrt_gate_le(dist_thres);
     a.flags = err_surface ? 1 : 0;
@@ -504,6 +504,7 @@ int cf_odom_create(cf_ctx* ctx, cf_odom** out)
     }
     if (int r = dmalloc(ctx, &od->icp_acc, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &od->rgb_acc, (size_t)kGroups * 32)) return r;
+    if (int r = dmalloc(ctx, &od->occ, ((size_t)(W >> 2) * (H >> 2) + 63) / 64 * 2)) return r;
     for (int k = 0; k < cf_ctx::kStateSlots && od->slot < 0; k++)
         if (!ctx->slot_used[k]) { ctx->slot_used[k] = true; od->slot = k; }
     if (od->slot >= 0) {
@@ -538,7 +539,7 @@ void cf_odom_destroy(cf_odom* od)
         (void)hipFree(od->dIdx[i]); (void)hipFree(od->dIdy[i]); (void)hipFree(od->cloud[i]); (void)hipFree(od->corres[i]);
         (void)hipFree(od->cand[i]);
     }
-    (void)hipFree(od->icp_acc); (void)hipFree(od->rgb_acc);
+    (void)hipFree(od->icp_acc); (void)hipFree(od->rgb_acc); (void)hipFree(od->occ);
     if (od->slot >= 0) od->ctx->slot_used[od->slot] = false;
     else { (void)hipFree(od->d_state); (void)hipHostFree(od->h_state); }
     delete od;
@@ -555,6 +556,7 @@ static ModelMapsArgs model_maps_args(cf_odom* od, const float* pred_v4, const fl
     const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
     const float t[3] = {pose[3], pose[7], pose[11]};
     memcpy(a.R, R, sizeof(R)); memcpy(a.t, t, sizeof(t));
+    a.occ = od->occ; od->occ_valid = true;
     return a;
 }
 static RgbdChain rgbd_chain(cf_odom* od, const uint8_t* rgba, float* const* depths, uint8_t* const* images)
@@ -577,6 +579,7 @@ int cf_odom_init_icp_model(cf_odom* od, const float* pred_v4, const float* pred_
     } else {
         const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
         const float t[3] = {pose[3], pose[7], pose[11]};
+        od->occ_valid = false;
         HIPCHK(ctx, hipMemcpyAsync(od->vmaps_tmp, pred_v4, (size_t)W * H * 16, hipMemcpyDeviceToDevice, s));
         launch_copy_maps(s, od->vmaps_tmp, pred_n4, W, H, od->vmap_g_prev[0], od->nmap_g_prev[0]);
         for (int i = 1; i < CF_NUM_PYRS; ++i) {
@@ -665,6 +668,13 @@ int cf_odom_init_icp(cf_odom* od, const float* const depth_pyr[CF_NUM_PYRS], flo
     }
     launch_frame_maps(s, a, W, H);  // createVMap + createNMap of the three levels in one launch
     LAUNCHCHK(ctx);
+    return CF_OK;
+}
+
+int cf_odom_set_culling(cf_odom* od, int on)
+{
+    if (!od) return CF_EINVAL;
+    od->use_occ = on != 0;
     return CF_OK;
 }
 
@@ -759,12 +769,13 @@ static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3
         a.intr = cf_cam{intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
         a.distThres = ods[0]->distThres; a.angleThres = ods[0]->angleThres;
         a.angleSqLt = ods[0]->angleSqLt; a.distSqLe = ods[0]->distSqLe;
+        a.occ_w = ctx->cfg.width >> 2; a.occ_shift = 2 - l;
         for (int m = 0; m < n; m++) {
             cf_odom* od = ods[m];
             a.m[m] = IcpModelArgs{od->ext_vmap_curr[l] ? od->ext_vmap_curr[l] : od->vmap_curr[l],
                                   od->ext_nmap_curr[l] ? od->ext_nmap_curr[l] : od->nmap_curr[l],
                                   od->vmap_g_prev[l], od->nmap_g_prev[l], od->d_state, od->icp_acc,
-                                  od->h_state->err_surface, od->rgb_acc};
+                                  od->h_state->err_surface, od->rgb_acc, (od->use_occ && od->occ_valid) ? od->occ : nullptr};
         }
     }
 }

@@ -67,6 +67,9 @@ struct cf_odom {
     float* cloud[3]{};
     cf_dataterm* corres[3]{};
     uint8_t* cand[3]{};
+    unsigned* occ = nullptr;         // occupancy bitmap of the model maps (written by model_maps_kernel)
+    bool occ_valid = false;          // the bitmap describes the current model maps
+    bool use_occ = false;            // cf_odom_set_culling: worth it for models that cover a small part of the image
     unsigned long long* icp_acc = nullptr;
     unsigned long long* rgb_acc = nullptr;
     cf::OdomDev* d_state = nullptr;

@@ -471,6 +471,7 @@ __global__ void __launch_bounds__(64) model_maps_kernel(const ModelMapsBatch b)
     const int c2 = a.cols >> 2, r2 = a.rows >> 2;
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t >= c2 * r2) return;
+    bool any_valid = false;  // does this thread's 4x4 block hold any predicted surface?
     const int Y2 = t / c2, X2 = t - Y2 * c2;
     const int cols = a.cols, rows = a.rows, N0 = cols * rows, c1 = cols >> 1, N1 = N0 >> 2, N2 = N0 >> 4;
     const float4* __restrict__ v4 = reinterpret_cast<const float4*>(a.pred_v4);
@@ -490,7 +491,7 @@ __global__ void __launch_bounds__(64) model_maps_kernel(const ModelMapsBatch b)
             const float4 vs = v4[i0], ns = n4[i0];
             snap[i0] = vs;
             v0[s].have = true; n0[s].have = true;
-            if (!(vs.z == 0)) { v0[s].p = f3{vs.x, vs.y, vs.z}; n0[s].p = f3{ns.x, ns.y, ns.z}; }
+            if (!(vs.z == 0)) { v0[s].p = f3{vs.x, vs.y, vs.z}; n0[s].p = f3{ns.x, ns.y, ns.z}; any_valid = true; }
             else { v0[s].p = f3{qnan(), qnan(), qnan()}; n0[s].p = v0[s].p; }
             emit_map(a.vmap[0], i0, N0, v0[s], R, tr, true);
             emit_map(a.nmap[0], i0, N0, n0[s], R, tr, false);
@@ -506,6 +507,12 @@ __global__ void __launch_bounds__(64) model_maps_kernel(const ModelMapsBatch b)
     const int i2 = Y2 * c2 + X2;
     emit_map(a.vmap[2], i2, N2, v2, R, tr, true);
     emit_map(a.nmap[2], i2, N2, n2, R, tr, false);
+    // occupancy bitmap of the prediction, one bit per 4x4 block (bit t of word t/32): the ICP reduction skips the gathers of
+    // pixels that project into an empty block (every level's model-map pixel inside such a block is invalid)
+    if (a.occ) {
+        const unsigned long long bits = __ballot(any_valid);
+        if (threadIdx.x == 0) { a.occ[2 * blockIdx.x] = (unsigned)bits; a.occ[2 * blockIdx.x + 1] = (unsigned)(bits >> 32); }
+    }
 }
 
 // ------------------------------------------------------------------ launchers ----

@@ -192,7 +192,13 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
         pr[p] = icp_project(Rcurr, tcurr, Rprev_inv, tprev, args.intr, cols, rows, f3{vx[p], vy[p], vz[p]});
         if (!in_range) pr[p].inb = 0;
         vprev[p] = f3{qnan(), qnan(), qnan()}; nprev[p] = f3{qnan(), qnan(), qnan()};
-        if (pr[p].inb) {
+        bool occupied = pr[p].inb != 0;
+        if (occupied && ma.occ) {  // the model map is invalid (NaN) everywhere inside an empty 4x4 block: no gather needed
+            const int gy = pr[p].g / cols, gxp = pr[p].g - gy * cols;
+            const int tile = (gy >> args.occ_shift) * args.occ_w + (gxp >> args.occ_shift);
+            occupied = (ma.occ[tile >> 5] >> (tile & 31)) & 1u;
+        }
+        if (occupied) {
             const int g = pr[p].g;
             vprev[p] = f3{vp[g], vp[g + N], vp[g + 2 * N]};
             nprev[p] = f3{np[g], np[g + N], np[g + 2 * N]};

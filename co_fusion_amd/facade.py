@@ -74,8 +74,8 @@ class CoFusion:
 
         self._allreduce_cb = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int64), C.c_uint64, C.c_void_p)(thunk)  # keep alive
         self._check(self.lib.cofusion_set_allreduce(self.h, self._allreduce_cb, None))
-        if fn is None and dist.get_backend() == "nccl":
-            self.set_allreduce_device()
+        if fn is None:
+            self.set_allreduce_device()   # nccl: RCCL on the stream; gloo (dry runs): the same path, staged by gloo itself
 
     def set_allreduce_device(self):
         """The collective for buffers that live in HBM (per-superpixel segmentation sums): RCCL all-reduce of an int64 torch tensor,

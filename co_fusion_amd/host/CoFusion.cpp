@@ -96,6 +96,8 @@ Model::Model(cf_ctx* c, unsigned char id_, float confidenceThresh, bool enableFi
     if (!owned) return;  // shadow of a model owned by another rank: replicated state only
     check(ctx, cf_model_create(ctx, maxSurfels, &model), "cf_model_create");
     check(ctx, cf_odom_create(ctx, &odom), "cf_odom_create");
+    // object models cover a small part of the image: their ICP launches skip the gathers into empty blocks of the prediction
+    if (!enableFillIn && !std::getenv("CF_NO_CULLING")) check(ctx, cf_odom_set_culling(odom, 1), "cf_odom_set_culling");
     // icpError texture (Model.cpp:112-117), f32 [H*W]; zero-initialised like the reference's upload (GPUTexture.cpp:48-53)
     void* p = nullptr;
     uint64_t bytes = 0;

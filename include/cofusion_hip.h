@@ -227,6 +227,10 @@ int cf_odom_fetch_result(cf_odom *od, float trans[3], float rot[9], cf_track_sta
 /* test access to internal device pyramids (same `which` numbering as the oracle's orc_odom_buffer) */
 /* share the frame-wide current vertex/normal pyramids between models (all models track the same frame,
  * cudafuncs.cu:119); pass NULL arrays to return to the odom-private maps written by cf_odom_init_icp */
+/* Skip the model-map gathers of pixels that project into empty 4x4 blocks of the prediction (an occupancy bitmap written by
+ * initICPModel).  Results are unchanged; it pays for models that cover a small part of the image (object models) and costs a
+ * dependent look-up for one that covers all of it (background).  Default off. */
+int cf_odom_set_culling(cf_odom *od, int on);
 int cf_odom_bind_frame_maps(cf_odom *od, const float *const vmaps[CF_NUM_PYRS], const float *const nmaps[CF_NUM_PYRS]);
 int cf_odom_buffer(cf_odom *od, int which, int level, void **dptr, uint64_t *bytes);
 /* Model::generateCUDATextures depth half (Model.cpp:341-343): l1/l2 device outputs */
