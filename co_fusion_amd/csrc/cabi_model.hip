@@ -232,14 +232,12 @@ int cf_model_initialise(cf_model* m, const uint8_t* rgba, const float* depth_raw
     const cf_cam cam = ctx_cam(ctx);
     // raw feedback
     launch_feedback(s, rgba, depth_raw, W, H, cam, m->inv_fx, m->inv_fy, m->tcx, m->tcy, time, maxDepth, m->fb_rec, m->new_flags);
-    launch_exclusive_scan(s, m->new_flags, N, m->new_offsets, m->block_sums, m->d_count, 0);
     HIPCHK(ctx, hipMemsetAsync(m->fb_raw, 0, sizeof(float) * 12 * N, s));
-    launch_scatter_records(s, m->fb_rec, m->new_flags, m->new_offsets, N, m->fb_raw, 0);
+    launch_scan_scatter(s, m->fb_rec, m->new_flags, N, m->block_sums, m->d_count, 0, m->fb_raw);
     // filtered feedback (zero-filled past its own count, like the reference's zero-initialised VBO)
     launch_feedback(s, rgba, depth_filt, W, H, cam, m->inv_fx, m->inv_fy, m->tcx, m->tcy, time, maxDepth, m->fb_rec, m->new_flags);
-    launch_exclusive_scan(s, m->new_flags, N, m->new_offsets, m->block_sums, m->d_tmp2, 0);
     HIPCHK(ctx, hipMemsetAsync(m->fb_filt, 0, sizeof(float) * 12 * N, s));
-    launch_scatter_records(s, m->fb_rec, m->new_flags, m->new_offsets, N, m->fb_filt, 0);
+    launch_scan_scatter(s, m->fb_rec, m->new_flags, N, m->block_sums, m->d_tmp2, 0, m->fb_filt);
     launch_init(s, m->fb_raw, m->fb_filt, m->d_count, N, m->buf[m->target]);
     LAUNCHCHK(ctx);
     return sync_count(m);
@@ -366,8 +364,7 @@ int cf_model_fuse(cf_model* m, const float pose[16], int time, const uint8_t* rg
     a.records = m->records; a.new_flags = m->new_flags; a.owner = m->owner;
     launch_associate(s, a);
     // append the new unstable vertices in column-major draw order (transform feedback of data.geom)
-    launch_exclusive_scan(s, m->new_flags, N, m->new_offsets, m->block_sums, m->d_nfresh, 0);
-    launch_scatter_records(s, m->records, m->new_flags, m->new_offsets, N, m->fresh, 0);
+    launch_scan_scatter(s, m->records, m->new_flags, N, m->block_sums, m->d_nfresh, 0, m->fresh);
     // update.vert over all surfels into the other buffer, then swap (Model.cpp:559)
     uint32_t nb = 0;
     if (int r = count_bound(m, &nb)) return r;
@@ -393,8 +390,7 @@ int cf_model_clean(cf_model* m, const float pose[16], int time, float confThresh
     inv44f(pose, a.t_inv); a.cam = ctx_cam(ctx); a.cols = W; a.rows = H; a.time = time; a.confThreshold = confThreshold;
     a.outlierCoeff = outlierCoeff; a.timeDelta = timeDelta; a.maskID = maskID;
     launch_clean(s, m->buf[m->target], m->d_count, m->fresh, m->d_nfresh, bound, a, m->staged, m->flags);
-    launch_exclusive_scan(s, m->flags, bound, m->offsets, m->block_sums, m->d_count, 0);  // the kept total IS the new count
-    launch_scatter_records(s, m->staged, m->flags, m->offsets, bound, m->buf[1 - m->target], 0);
+    launch_scan_scatter(s, m->staged, m->flags, bound, m->block_sums, m->d_count, 0, m->buf[1 - m->target]);  // the kept total IS the new count
     m->target = 1 - m->target;
     LAUNCHCHK(ctx);
     const uint32_t upper = bound < m->max_surfels ? bound : m->max_surfels;

@@ -203,6 +203,8 @@ struct SurfelCleanArgs {
 void launch_bilateral(hipStream_t s, const float* depth, int cols, int rows, float maxD, float* out);
 void launch_exclusive_scan(hipStream_t s, const unsigned* flags, long long n, unsigned* offsets, unsigned* block_sums, unsigned* total,
                            unsigned add_to_total);
+void launch_scan_scatter(hipStream_t s, const float* rec, const unsigned* flags, long long n, unsigned* block_sums, unsigned* total,
+                         unsigned add_to_total, float* out);
 void launch_feedback(hipStream_t s, const uint8_t* rgba, const float* depth, int cols, int rows, cf_cam cam, float inv_fx, float inv_fy,
                      const float* tcx, const float* tcy, int time, float maxDepth, float* rec, unsigned* flags);
 void launch_scatter_records(hipStream_t s, const float* rec, const unsigned* flags, const unsigned* offsets, long long n, float* out,

@@ -223,63 +223,37 @@ __global__ void __launch_bounds__(256) crf_init_kernel(const float* __restrict__
     for (int l = 0; l < L; l++) { e[l] = det_expf(-unary[i * L + l] - mx); s += e[l]; }
     for (int l = 0; l < L; l++) Q[i * L + l] = e[l] / s;
 }
-// one mean-field step, part 1: chunk partials of K1*Q and K2*Q for every label; partial[((c*n + i)*2 + which)*kMaxL + l].
-// LT > 0: the label count as a compile-time constant (no predication); the chunk is walked five nodes at a time so
-// that the 10 kernel-matrix loads of a group are in flight together (the sums stay in node order).
-template <int LT>
+// one mean-field step, part 1: chunk partials of K1*Q and K2*Q; partial[((c*n + i)*2 + which)*kMaxL + l].
+// One lane per (node i, chunk c, label l) -- grid (n/64, chunks, labels): the sums inside a chunk are sequential by definition, so
+// the only parallelism is across nodes, chunks and labels, and with one lane per (node, chunk) only ~300 waves existed for 1024
+// SIMDs.  The chunk is walked five nodes at a time so that the kernel-matrix loads of a group are in flight together (the sums
+// stay in node order).
 __global__ void __launch_bounds__(64) crf_message_kernel(int L, int n, const float* __restrict__ K1t, const float* __restrict__ K2t,
                                                          const float* __restrict__ Q, float* __restrict__ partial)
 {
-    constexpr int LL = LT > 0 ? LT : kMaxL;
-    const int i = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
+    const int i = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y, l = blockIdx.z;
     if (i >= n) return;
     const int len = (n + kCrfChunks - 1) / kCrfChunks, j0 = c * len, j1 = min(n, j0 + len);
-    float a[LL], b[LL];
-#pragma unroll
-    for (int l = 0; l < LL; l++) { a[l] = 0; b[l] = 0; }
+    float a = 0, b = 0;
     int j = j0;
     for (; j + 5 <= j1; j += 5) {
-        float k1[5], k2[5];
+        float k1[5], k2[5], q[5];
 #pragma unroll
-        for (int u = 0; u < 5; u++) { k1[u] = K1t[(j + u) * n + i]; k2[u] = K2t[(j + u) * n + i]; }
+        for (int u = 0; u < 5; u++) { k1[u] = K1t[(j + u) * n + i]; k2[u] = K2t[(j + u) * n + i]; q[u] = Q[(j + u) * L + l]; }
 #pragma unroll
-        for (int u = 0; u < 5; u++)
-#pragma unroll
-            for (int l = 0; l < LL; l++)
-                if (LT > 0 || l < L) {
-                    const float q = Q[(j + u) * L + l];
-                    a[l] += k1[u] * q;
-                    b[l] += k2[u] * q;
-                }
+        for (int u = 0; u < 5; u++) { a += k1[u] * q[u]; b += k2[u] * q[u]; }
     }
     for (; j < j1; j++) {
-        const float k1 = K1t[j * n + i], k2 = K2t[j * n + i];
-#pragma unroll
-        for (int l = 0; l < LL; l++)
-            if (LT > 0 || l < L) {
-                const float q = Q[j * L + l];
-                a[l] += k1 * q;
-                b[l] += k2 * q;
-            }
+        const float q = Q[j * L + l];
+        a += K1t[j * n + i] * q;
+        b += K2t[j * n + i] * q;
     }
     float* out = partial + ((size_t)(c * n + i) * 2) * kMaxL;
-#pragma unroll
-    for (int l = 0; l < LL; l++)
-        if (LT > 0 || l < L) { out[l] = a[l]; out[kMaxL + l] = b[l]; }
+    out[l] = a; out[kMaxL + l] = b;
 }
 static void launch_crf_message(hipStream_t st, dim3 grid, int L, int n, const float* K1t, const float* K2t, const float* Q, float* partial)
 {
-    switch (L) {
-        case 1: crf_message_kernel<1><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
-        case 2: crf_message_kernel<2><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
-        case 3: crf_message_kernel<3><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
-        case 4: crf_message_kernel<4><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
-        case 5: crf_message_kernel<5><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
-        case 6: crf_message_kernel<6><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
-        case 7: crf_message_kernel<7><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
-        case 8: crf_message_kernel<8><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
-        default: crf_message_kernel<0><<<grid, 64, 0, st>>>(L, n, K1t, K2t, Q, partial); break;
-    }
+    crf_message_kernel<<<dim3(grid.x, grid.y, L), 64, 0, st>>>(L, n, K1t, K2t, Q, partial);
 }
 // part 2: chunk totals in chunk order, unary, softmax over the labels.  Thread (node g, label l): 16 nodes x 16 label
 // slots per workgroup; the 32 chunk partials of a (node, label) are loaded independently and summed in chunk order,
@@ -359,6 +333,31 @@ __device__ __forceinline__ float wave_sequential_sum(float init, int n, int lane
         cur = nxt;
     }
     return sum;
+}
+
+// two independent chains in one pass (their additions interleave in the pipeline)
+template <class F, class G>
+__device__ __forceinline__ void wave_sequential_sum2(float& sa, float& sb, int n, int lane, F term_a, G term_b)
+{
+    float ca = lane < n ? term_a(lane) : 0.f, cb = lane < n ? term_b(lane) : 0.f;
+    for (int base = 0; base < n; base += 64) {
+        const int nj = base + 64 + lane;
+        const float na = nj < n ? term_a(nj) : 0.f, nb = nj < n ? term_b(nj) : 0.f;
+        const int m = min(64, n - base);
+        if (m == 64) {
+#pragma unroll
+            for (int j = 0; j < 64; j++) {
+                sa += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca), j));
+                sb += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb), j));
+            }
+        } else {
+            for (int j = 0; j < m; j++) {
+                sa += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca), j));
+                sb += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb), j));
+            }
+        }
+        ca = na; cb = nb;
+    }
 }
 
 // Slic::downsample<float> normalisation incl. the empty-superpixel fallback (Slic.h:63-76, 192-206) evaluated in place and in index
@@ -520,6 +519,8 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
     __shared__ int s_id2idx[256];
     __shared__ int s_box[kMaxL + 1][4];   // top, right, bottom, left per model entry (full-resolution pixels after mapToHigh)
     __shared__ unsigned s_spc[kMaxL + 1];
+    __shared__ unsigned s_best[256];
+    __shared__ int s_reject[kMaxL + 1];
     __shared__ unsigned char map[kSegMaxK];
     __shared__ int parent[kSegMaxK];
     __shared__ int comp[kSegMaxK];
@@ -595,49 +596,54 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
     }
     __threadfence_block();
     __syncthreads();
-    // 5. onlyKeepLargest (:496-517): every label but the smallest keeps its largest component (ties: the earlier one); one lane per label
-    if (tid < 255 && tid != s_min_label) {
-        int keep = -1;
-        for (int i = 0; i < ncc; i++) {
-            if (c_label[i] != tid) continue;
-            if (keep < 0) { keep = i; continue; }
-            if (c_size[keep] < c_size[i]) { c_label[keep] = 255; keep = i; } else c_label[i] = 255;
-        }
-    }
-    __threadfence_block();
+    // 5. onlyKeepLargest (:496-517): every label but the smallest keeps its largest component, the earlier one on ties -- the
+    //    sequential rule "replace the kept component only by a strictly larger one" picks exactly the maximum of (size, -index)
+    if (tid < 256) s_best[tid] = 0;
+    if (tid < kMaxL + 1) { s_box[tid][0] = 65535; s_box[tid][1] = 0; s_box[tid][2] = 0; s_box[tid][3] = 65535; s_reject[tid] = 0; }
     __syncthreads();
-    // 6. a new label must have a plausible size (:521-530)
-    if (a.allow_new) {
+    const int minLabel = s_min_label;
+    for (int i = tid; i < ncc; i += T) {
+        const int lab = c_label[i];
+        if (lab != minLabel && lab != 255) atomicMax(&s_best[lab], ((unsigned)c_size[i] << 16) | (unsigned)(65535 - i));
+    }
+    __syncthreads();
+    // 6. ... and a new label must have a plausible size (:521-530)
+    {
         const int minSize = (int)((float)K * a.minRelSizeNew), maxSize = (int)((float)K * a.maxRelSizeNew);
-        for (int i = tid; i < ncc; i += T)
-            if (c_label[i] == (int)a.next_id && (c_size[i] < minSize || c_size[i] > maxSize)) c_label[i] = 255;
+        for (int i = tid; i < ncc; i += T) {
+            int lab = c_label[i];
+            if (lab != minLabel && lab != 255 && (int)(65535u - (s_best[lab] & 0xffffu)) != i) lab = 255;
+            if (a.allow_new && lab == (int)a.next_id && (c_size[i] < minSize || c_size[i] > maxSize)) lab = 255;
+            c_label[i] = lab;
+            // 7. bounding boxes over the surviving components of every model entry (:532-547)
+            if (lab != 255) {
+                const int e = s_id2idx[lab];
+                if ((int)(a.ids[e] & 255u) == lab) {
+                    atomicMin(&s_box[e][0], c_top[i]); atomicMax(&s_box[e][1], c_right[i]); atomicMax(&s_box[e][2], c_bottom[i]); atomicMin(&s_box[e][3], c_left[i]);
+                }
+            }
+        }
     }
-    __threadfence_block();
     __syncthreads();
-    // 7. bounding boxes (:532-547) and 8. labels whose box lies inside the border strip are rejected (:549-563); one lane per model
+    // Slic::mapToHigh, then 8. labels whose box lies inside the border strip are rejected (:549-563)
     if (tid < n_md) {
-        const int id = (int)(a.ids[tid] & 255u);
-        int left = 65535, top = 65535, right = 0, bottom = 0;
-        for (int i = 0; i < ncc; i++) {
-            if (c_label[i] != id) continue;
-            if (c_left[i] < left) left = c_left[i];
-            if (c_top[i] < top) top = c_top[i];
-            if (c_right[i] > right) right = c_right[i];
-            if (c_bottom[i] > bottom) bottom = c_bottom[i];
-        }
-        left = (int)(unsigned short)(int)(left * kSpix + kSpix * 0.5); top = (int)(unsigned short)(int)(top * kSpix + kSpix * 0.5);
-        right = (int)(unsigned short)(int)(right * kSpix + kSpix * 0.5); bottom = (int)(unsigned short)(int)(bottom * kSpix + kSpix * 0.5);
+        const int top = (int)(unsigned short)(int)(s_box[tid][0] * kSpix + kSpix * 0.5), right = (int)(unsigned short)(int)(s_box[tid][1] * kSpix + kSpix * 0.5);
+        const int bottom = (int)(unsigned short)(int)(s_box[tid][2] * kSpix + kSpix * 0.5), left = (int)(unsigned short)(int)(s_box[tid][3] * kSpix + kSpix * 0.5);
         s_box[tid][0] = top; s_box[tid][1] = right; s_box[tid][2] = bottom; s_box[tid][3] = left;
+        if (a.ids[tid] != 0) {
+            const unsigned borderSize = 20, fullHeight = (unsigned)a.height, fullWidth = (unsigned)a.width;
+            const unsigned t = (unsigned)top, r = (unsigned)right, bo = (unsigned)bottom, l = (unsigned)left;
+            if ((t < borderSize && bo < borderSize) || (l < borderSize && r < borderSize) ||
+                (t > fullHeight - borderSize && bo > fullHeight - borderSize) || (l > fullWidth - borderSize && r > fullWidth - borderSize))
+                s_reject[tid] = 1;
+        }
     }
     __syncthreads();
-    if (tid < n_md && a.ids[tid] != 0) {
-        const unsigned borderSize = 20, fullHeight = (unsigned)a.height, fullWidth = (unsigned)a.width;
-        const unsigned top = (unsigned)s_box[tid][0], right = (unsigned)s_box[tid][1], bottom = (unsigned)s_box[tid][2], left = (unsigned)s_box[tid][3];
-        if ((top < borderSize && bottom < borderSize) || (left < borderSize && right < borderSize) ||
-            (top > fullHeight - borderSize && bottom > fullHeight - borderSize) || (left > fullWidth - borderSize && right > fullWidth - borderSize)) {
-            const int id = (int)(a.ids[tid] & 255u);
-            for (int i = 0; i < ncc; i++) if (c_label[i] == id) c_label[i] = 255;
-        }
+    for (int i = tid; i < ncc; i += T) {
+        const int lab = c_label[i];
+        if (lab == 255) continue;
+        const int e = s_id2idx[lab];
+        if ((int)(a.ids[e] & 255u) == lab && s_reject[e]) c_label[i] = 255;
     }
     __threadfence_block();
     __syncthreads();
@@ -665,8 +671,9 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
             for (int i = lane; i < K; i += 64) out += trimmed(i) ? 1u : 0u;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) out += __shfl_xor(out, o, 64);
-            sumDepth = wave_sequential_sum(sumDepth, K, lane, [&](int i) { return trimmed(i) ? -lowDepth[i] : 0.f; });
-            sumDev = wave_sequential_sum(sumDev, K, lane, [&](int i) { return trimmed(i) ? -fabsf(mean - lowDepth[i]) : 0.f; });
+            if (out)
+                wave_sequential_sum2(sumDepth, sumDev, K, lane, [&](int i) { return trimmed(i) ? -lowDepth[i] : 0.f; },
+                                     [&](int i) { return trimmed(i) ? -fabsf(mean - lowDepth[i]) : 0.f; });
             cnt -= out;
         }
         mean = cnt ? sumDepth / (float)cnt : 0;

@@ -134,6 +134,62 @@ __global__ void __launch_bounds__(256) scan_offsets_kernel(const unsigned* __res
     }
 }
 
+__global__ void set_count_kernel(unsigned* out, unsigned v);
+// Ordered compaction in TWO launches (scan_block_sums_kernel, then this): every workgroup derives its own base from the block
+// sums of the workgroups before it (at most a few hundred values), scans its 2048 flags -- eight consecutive flags per thread, so
+// one pass and two barriers -- and moves the flagged 48 B records straight to their place; the last workgroup publishes the total.
+// Replaces {spine scan, per-element offsets, scatter} = three launches and an offsets array.
+__global__ void __launch_bounds__(256) scan_scatter_kernel(const float4* __restrict__ rec, const unsigned* __restrict__ flags, long long n,
+                                                           const unsigned* __restrict__ block_sums, unsigned* __restrict__ total,
+                                                           unsigned add_to_total, float4* __restrict__ out)
+{
+    __shared__ unsigned wsum[4], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned b = 0;
+    for (int k = tid; k < (int)blockIdx.x; k += 256) b += block_sums[k];
+    for (int o = 32; o > 0; o >>= 1) b += __shfl_xor((int)b, o, 64);
+    if (lane == 0) wsum[wave] = b;
+    __syncthreads();
+    if (tid == 0) s_base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const long long i0 = (long long)blockIdx.x * kScanItems + (long long)tid * 8;
+    unsigned f[8];
+    if (i0 + 8 <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(flags + i0), c = *reinterpret_cast<const uint4*>(flags + i0 + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) f[e] = (i0 + e < n) ? flags[i0 + e] : 0u;
+    }
+    unsigned mine = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) mine += f[e];
+    unsigned incl = mine;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+    __syncthreads();  // s_base written, wsum free again
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned off = s_base + incl - mine;
+    for (int w = 0; w < wave; w++) off += wsum[w];
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        if (f[e]) {
+            const size_t o = (size_t)off * 3, r = (size_t)(i0 + e) * 3;
+            out[o] = rec[r]; out[o + 1] = rec[r + 1]; out[o + 2] = rec[r + 2];
+            off++;
+        }
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) *total = off + add_to_total;  // the last thread's running offset is the total
+}
+
+void launch_scan_scatter(hipStream_t s, const float* rec, const unsigned* flags, long long n, unsigned* block_sums, unsigned* total,
+                         unsigned add_to_total, float* out)
+{
+    const int nb = (int)((n + kScanItems - 1) / kScanItems);
+    if (nb == 0) { set_count_kernel<<<1, 1, 0, s>>>(total, add_to_total); return; }
+    scan_block_sums_kernel<<<nb, 256, 0, s>>>(flags, n, block_sums);
+    scan_scatter_kernel<<<nb, 256, 0, s>>>(reinterpret_cast<const float4*>(rec), flags, n, block_sums, total, add_to_total,
+                                           reinterpret_cast<float4*>(out));
+}
+
 void launch_exclusive_scan(hipStream_t s, const unsigned* flags, long long n, unsigned* offsets, unsigned* block_sums, unsigned* total,
                            unsigned add_to_total)
 {

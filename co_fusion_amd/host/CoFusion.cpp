@@ -901,7 +901,10 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
         } else {
             globalModel->overridePose(*inPose);
         }
-        { PhaseTimer t(PhaseTimes::Predict); predict(); }
+        // CoFusion.cpp:346 predicts every model here, between tracking and fusion.  Nothing in the frame loop reads that prediction: fuse
+        // and clean work on the index maps, the segmentation read the PREVIOUS prediction before this point, and the prediction at the
+        // end of the frame overwrites all of it -- in the reference it only feeds the GUI.  Off by default (Config::midFramePredict).
+        if (cfg.midFramePredict) { PhaseTimer t(PhaseTimes::Predict); predict(); }
         if (!cfg.rgbOnly && trackingOk && !lost) {
             PhaseTimer t(PhaseTimes::Fuse);
             // CoFusion.cpp:316-330 runs the four passes model by model in four loops; the passes of different models touch

@@ -211,6 +211,10 @@ class CoFusion {
         // the work still queued on the context's stream, i.e. beside the previous frame's fusion passes.  false (default) = they
         // may be produced by work queued on that stream just before the call, and are consumed in stream order.
         bool deviceFramesComplete = false;
+        // run CoFusion::predict() between tracking and fusion as the reference does (CoFusion.cpp:346).  Its outputs are overwritten by
+        // the end-of-frame prediction before anything in the frame loop reads them (they are what the reference's GUI shows), so the
+        // default skips the pass; results are identical either way.
+        bool midFramePredict = false;
     };
     explicit CoFusion(const Config& cfg);
     ~CoFusion();

@@ -33,6 +33,7 @@ void cofusion_default_config(cofusion_config* c)
     c->enable_pose_logging = d.enablePoseLogging;
     c->rank = d.rank; c->world = d.world;
     c->device_frames_complete = d.deviceFramesComplete;
+    c->mid_frame_predict = d.midFramePredict;
 }
 
 int cofusion_create(const cofusion_config* c, cofusion_handle** out)
@@ -48,6 +49,7 @@ int cofusion_create(const cofusion_config* c, cofusion_handle** out)
     d.enablePoseLogging = c->enable_pose_logging != 0;
     d.rank = c->rank; d.world = c->world < 1 ? 1 : c->world;
     d.deviceFramesComplete = c->device_frames_complete != 0;
+    d.midFramePredict = c->mid_frame_predict != 0;
     GUARD(*out = new cofusion_handle{new CoFusion(d)});
     return 0;
 }

@@ -26,6 +26,8 @@ typedef struct {
     int device_frames_complete; /* 1: buffers given to cofusion_process_frame_device are complete at call time (uploaded ahead), so the
                                  * new frame's depth filter may run beside the previous frame's fusion passes; 0 (default): they may be
                                  * produced by work queued on the context's stream and are consumed in stream order */
+    int mid_frame_predict;      /* 1: also run the reference's prediction between tracking and fusion (CoFusion.cpp:346); its outputs are
+                                 * overwritten by the end-of-frame prediction before the frame loop reads them (GUI only).  Default 0. */
 } cofusion_config;
 
 void cofusion_default_config(cofusion_config *cfg);
