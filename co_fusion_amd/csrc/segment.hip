@@ -191,7 +191,15 @@ __global__ void __launch_bounds__(64) crf_norm_partial_kernel(const float* __res
     if (i >= n) return;
     const int len = (n + kCrfChunks - 1) / kCrfChunks, j0 = c * len, j1 = min(n, j0 + len);
     float s = 0;
-    for (int j = j0; j < j1; j++) s += raw[j * n + i];
+    int j = j0;
+    for (; j + 25 <= j1; j += 25) {  // independent loads in flight together, additions in node order
+        float v[25];
+#pragma unroll
+        for (int u = 0; u < 25; u++) v[u] = raw[(j + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 25; u++) s += v[u];
+    }
+    for (; j < j1; j++) s += raw[j * n + i];
     partial[c * n + i] = s;
 }
 // norm_i = 1/sqrt(sum_c partial[c][i] + 1e-20)
@@ -236,6 +244,15 @@ __global__ void __launch_bounds__(64) crf_message_kernel(int L, int n, const flo
     const int len = (n + kCrfChunks - 1) / kCrfChunks, j0 = c * len, j1 = min(n, j0 + len);
     float a = 0, b = 0;
     int j = j0;
+    // the chunk is a chain of dependent additions but its loads are independent: 25 nodes' worth in flight at a time (a 75-node chunk
+    // is three memory round trips instead of fifteen)
+    for (; j + 25 <= j1; j += 25) {
+        float k1[25], k2[25], q[25];
+#pragma unroll
+        for (int u = 0; u < 25; u++) { k1[u] = K1t[(j + u) * n + i]; k2[u] = K2t[(j + u) * n + i]; q[u] = Q[(j + u) * L + l]; }
+#pragma unroll
+        for (int u = 0; u < 25; u++) { a += k1[u] * q[u]; b += k2[u] * q[u]; }
+    }
     for (; j + 5 <= j1; j += 5) {
         float k1[5], k2[5], q[5];
 #pragma unroll
@@ -694,6 +711,83 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
     }
 }
 
+
+// One whole mean-field step in one launch: a workgroup owns 16 nodes x all 16 chunks (thread = (node, chunk)), walks its chunk for all
+// labels, parks the chunk partials in LDS, and the first 16 x L threads add them in chunk order, apply the unary and the softmax --
+// exactly crf_message_kernel + crf_update_kernel, minus one launch boundary and the round trip of the partials through memory.
+template <int LT>
+__global__ void __launch_bounds__(256) crf_step_kernel(int L, int n, const float* __restrict__ unary, const float* __restrict__ K1t,
+                                                       const float* __restrict__ K2t, const float* __restrict__ Q, float w_smooth, float w_app,
+                                                       float* __restrict__ Qn)
+{
+    constexpr int LL = LT > 0 ? LT : kMaxL;
+    __shared__ float s_a[kCrfChunks][16][LL], s_b[kCrfChunks][16][LL];
+    __shared__ float s_t[16][LL];
+    const int ii = threadIdx.x & 15, c = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + ii;
+    const int len = (n + kCrfChunks - 1) / kCrfChunks, j0 = c * len, j1 = min(n, j0 + len);
+    float a[LL], b[LL];
+#pragma unroll
+    for (int l = 0; l < LL; l++) { a[l] = 0; b[l] = 0; }
+    if (i < n) {
+        int j = j0;
+        for (; j + 5 <= j1; j += 5) {
+            float k1[5], k2[5];
+#pragma unroll
+            for (int u = 0; u < 5; u++) { k1[u] = K1t[(j + u) * n + i]; k2[u] = K2t[(j + u) * n + i]; }
+#pragma unroll
+            for (int u = 0; u < 5; u++)
+#pragma unroll
+                for (int l = 0; l < LL; l++)
+                    if (LT > 0 || l < L) { const float q = Q[(j + u) * L + l]; a[l] += k1[u] * q; b[l] += k2[u] * q; }
+        }
+        for (; j < j1; j++) {
+            const float k1 = K1t[j * n + i], k2 = K2t[j * n + i];
+#pragma unroll
+            for (int l = 0; l < LL; l++)
+                if (LT > 0 || l < L) { const float q = Q[j * L + l]; a[l] += k1 * q; b[l] += k2 * q; }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < LL; l++) { s_a[c][ii][l] = a[l]; s_b[c][ii][l] = b[l]; }
+    __syncthreads();
+    const int g = threadIdx.x / LL, l = threadIdx.x - g * LL;   // (node of the tile, label) for the first 16 x LL threads
+    const int gi = blockIdx.x * 16 + g;
+    const bool act = g < 16 && gi < n && l < L;
+    float tmp = 0;
+    if (act) {
+        float sa = 0, sb = 0;
+#pragma unroll
+        for (int cc = 0; cc < kCrfChunks; cc++) { sa += s_a[cc][g][l]; sb += s_b[cc][g][l]; }
+        tmp = (-unary[gi * L + l] - (-w_smooth * sa)) - (-w_app * sb);
+        s_t[g][l] = tmp;
+    }
+    __syncthreads();
+    if (act) {
+        float mx = s_t[g][0];
+        for (int k = 1; k < L; k++) if (s_t[g][k] > mx) mx = s_t[g][k];
+        float sum = 0;
+        for (int k = 0; k < L; k++) sum += det_expf(s_t[g][k] - mx);
+        Qn[gi * L + l] = det_expf(tmp - mx) / sum;
+    }
+}
+static void launch_crf_step(hipStream_t st, int L, int n, const float* unary, const float* K1t, const float* K2t, const float* Q, float ws,
+                            float wa, float* Qn)
+{
+    const int grid = (n + 15) / 16;
+    switch (L) {
+        case 1: crf_step_kernel<1><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
+        case 2: crf_step_kernel<2><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
+        case 3: crf_step_kernel<3><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
+        case 4: crf_step_kernel<4><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
+        case 5: crf_step_kernel<5><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
+        case 6: crf_step_kernel<6><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
+        case 7: crf_step_kernel<7><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
+        case 8: crf_step_kernel<8><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
+        default: crf_step_kernel<0><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
+    }
+}
+
 }  // namespace cf
 
 // ===================================================================================== C-ABI ====
@@ -968,6 +1062,7 @@ int cf_seg_infer(cf_segmenter* s, const cf_seg_params* P, const uint8_t* rgba, i
     crf_init_kernel<<<g1, 256, 0, st>>>(s->unary, L, n, s->Q0);
     float *q = s->Q0, *qn = s->Q1;
     for (int it = 0; it < P->crfIterations; it++) {
+        // (one fused launch per step -- crf_step_kernel -- measured 17.6 us against 9.4 + 4.9 us for the pair: kept for reference only)
         launch_crf_message(st, gc, L, n, s->K1t, s->K2t, q, s->partial);
         crf_update_kernel<<<(n + 15) / 16, 256, 0, st>>>(s->unary, L, n, s->partial, P->weightSmoothness, P->weightAppearance, qn);
         float* t = q; q = qn; qn = t;
