@@ -94,6 +94,10 @@ def parse(argv=None):
     ap.add_argument("--parallel", default=None, choices=["streams", "models"],
                     help="N > 1: 'models' (default for object workloads) = ONE sequence, its object models placed on the GPUs (strong "
                          "scaling); 'streams' = one independent sequence per GPU (weak scaling)")
+    ap.add_argument("--shard-background", action="store_true",
+                    help="N > 1, --parallel models: every rank keeps a replica of the background map and takes a share of its index-map "
+                         "rasterisation (surfel range, MIN all-reduce of the z-keys) and of its ICP reduction (image rows, SUM all-reduce of the "
+                         "6x6 accumulators after every launch of the Gauss-Newton loop) -- the split BASELINE.json's configs[4] names")
     ap.add_argument("--dry-run", action="store_true", help="plumbing test without a GPU (tests/test_cpu_distributed.py): the process-group "
                     "set-up, the timing contract and the JSON line with a stub step instead of processFrame")
     ap.add_argument("--streams", type=int, default=1, help="independent RGB-D streams per GPU (own context + HIP stream + host thread each); "
@@ -229,7 +233,7 @@ def main(argv=None):
                               # single GPU / independent streams: the ring of frames is resident before timing starts; model-parallel:
                               # ranks > 0 receive every frame by broadcast just before the call, so frames are consumed in stream order
                               device_frames_complete=0 if model_parallel else 1,
-                              **(dict(rank=rank, world=world) if model_parallel else {}))
+                              **(dict(rank=rank, world=world, shard_background=int(args.shard_background)) if model_parallel else {}))
         if model_parallel:
             cfi.set_allreduce()
         if args.icp_ppt:
@@ -339,6 +343,7 @@ def main(argv=None):
                                              "the reference tree: parity of this stage is against the oracle only)"),
                                icp_launch=[args.icp_threads, args.icp_ppt], gn_mode=args.gn_mode,
                                streams_per_gpu=S, parallel=args.parallel if world > 1 else "single",
+                               background="split over the ranks (replicated map; surfel-range index map + row-band ICP with all-reduce)" if (model_parallel and args.shard_background) else "one rank",
                                frames="ring of device-resident frames, complete before each call (device_frames_complete=1)"),
                    roofline=roofline)
         if world == 1 and S == 1 and not args.no_extras:

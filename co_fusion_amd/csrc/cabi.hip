@@ -373,7 +373,7 @@ int cf_icp_step_band(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], co
     h->nmap_g_prev[0] = nmap_g_prev; h->distThres = dist_thres; h->angleThres = angle_thres; h->err_surface = err_surface;
     if (int r = scratch_commit(ctx)) return r;
     IcpArgs a{};
-    a.m[0] = IcpModelArgs{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, ctx->d_scratch_state, ctx->d_acc_a, err_surface, ctx->d_acc_b, nullptr};
+    a.m[0] = IcpModelArgs{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, ctx->d_scratch_state, ctx->d_acc_a, err_surface, ctx->d_acc_b, nullptr, 0, 0};
     a.cols = cols; a.rows = rows; a.intr = intr; a.distThres = dist_thres; a.angleThres = angle_thres;
     a.angleSqLt = sqrt_gate_lt(angle_thres); a.distSqLe = sqrt_gate_le(dist_thres);
     a.flags = err_surface ? 1 : 0;
@@ -678,6 +678,23 @@ int cf_odom_set_culling(cf_odom* od, int on)
     return CF_OK;
 }
 
+// One model's reductions split over GPUs: this rank reduces the image rows [row_begin, row_end) (level-0 rows, multiples of 4) inside the
+// device-resident Gauss-Newton loop; after every {ICP || residual} launch the registered collective (cf_set_collective, op 0) sums
+// the model's accumulators over the ranks, so every rank solves the same system and holds the same pose.  add_counts: exactly one
+// rank of the split passes 1 (the RGB residual pass, which every rank runs in full, adds its count / sigma only there).
+int cf_odom_set_band(cf_odom* od, int row_begin, int row_end, int add_counts)
+{
+    if (!od || row_begin < 0 || row_end < row_begin || row_end > od->ctx->cfg.height || (row_begin & 3) || (row_end & 3)) return CF_EINVAL;
+    od->band_begin = row_begin; od->band_end = row_end; od->band_counts = add_counts != 0;
+    return CF_OK;
+}
+int cf_set_collective(cf_ctx* ctx, int (*fn)(void*, int, void*, uint64_t, void*), void* user)
+{
+    if (!ctx) return CF_EINVAL;
+    ctx->collective = fn; ctx->collective_user = user;
+    return CF_OK;
+}
+
 int cf_odom_bind_frame_maps(cf_odom* od, const float* const vmaps[CF_NUM_PYRS], const float* const nmaps[CF_NUM_PYRS])
 {
     if (!od) return CF_EINVAL;
@@ -754,7 +771,10 @@ static void fill_rgb_args(cf_ctx* ctx, cf_odom* const* ods, int n, RgbArgs out[3
         a.cols = ctx->cfg.width >> l; a.rows = ctx->cfg.height >> l;
         a.il = cf_cam{intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
         a.sobelScale = ods[0]->sobelScale; a.maxDepthDelta = ods[0]->maxDepthDeltaRGB;
-        for (int m = 0; m < n; m++) a.m[m] = rgb_model_args(ods[m]->h_state, ods[m]->d_state, l);
+        for (int m = 0; m < n; m++) {
+            a.m[m] = rgb_model_args(ods[m]->h_state, ods[m]->d_state, l);
+            a.m[m].no_counts = (ods[m]->band_end > 0 && !ods[m]->band_counts) ? 1 : 0;
+        }
     }
 }
 
@@ -775,7 +795,8 @@ static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3
             a.m[m] = IcpModelArgs{od->ext_vmap_curr[l] ? od->ext_vmap_curr[l] : od->vmap_curr[l],
                                   od->ext_nmap_curr[l] ? od->ext_nmap_curr[l] : od->nmap_curr[l],
                                   od->vmap_g_prev[l], od->nmap_g_prev[l], od->d_state, od->icp_acc,
-                                  od->h_state->err_surface, od->rgb_acc, (od->use_occ && od->occ_valid) ? od->occ : nullptr};
+                                  od->h_state->err_surface, od->rgb_acc, (od->use_occ && od->occ_valid) ? od->occ : nullptr,
+                                  od->band_end > 0 ? (od->band_begin >> l) : 0, od->band_end > 0 ? (od->band_end >> l) : 0};
         }
     }
 }
@@ -812,8 +833,17 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     fill_icp_args(ctx, ods, n, icp_args);
     RgbArgs rgb_args[3];
     fill_rgb_args(ctx, ods, n, rgb_args);
-    launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, icp_args, rgb_args, n, ctx->cfg.width,
-                    ctx->cfg.height, opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, &ctx->prof);
+    GnHook hook{};
+    hook.fn = ctx->collective; hook.user = ctx->collective_user;
+    bool any_split = false;
+    for (int m = 0; m < n; m++) { hook.split[m] = ods[m]->band_end > 0 ? 1 : 0; any_split = any_split || hook.split[m]; }
+    if (any_split && !ctx->collective) { ctx->set_error("a tracker has a row band (cf_odom_set_band) but no collective is registered (cf_set_collective)"); return CF_ESTATE; }
+    if (any_split && ctx->gn_mode == 0) { ctx->set_error("split reductions need the record-slot data path (cf_set_gn_mode 1)"); return CF_ESTATE; }
+    if (!launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, any_split ? &hook : nullptr, icp_args, rgb_args, n,
+                         ctx->cfg.width, ctx->cfg.height, opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, &ctx->prof)) {
+        ctx->set_error("tracking: the registered collective failed inside the Gauss-Newton loop");
+        return CF_ESTATE;
+    }
     LAUNCHCHK(ctx);
     if (lo >= 0) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_state_pool + lo, ctx->d_state_pool + lo, sizeof(OdomDev) * (hi - lo + 1), hipMemcpyDeviceToHost, ctx->stream));

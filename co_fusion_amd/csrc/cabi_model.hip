@@ -291,6 +291,26 @@ int cf_model_index_resolve(cf_model* m, const float pose[16], uint64_t* keys_dev
     return CF_OK;
 }
 
+// Model::predictIndices with the rasterisation split over `nshards` ranks by surfel range (the model map is replicated): this rank
+// rasterises its range of the EXACT surfel count into the 64-bit z-keys, the registered collective (cf_set_collective, op 1: MIN of
+// unsigned 64-bit words) composites the key maps of all ranks, and every rank resolves the same winners -- the index map of
+// cf_model_predict_indices bit for bit (the z-test is a minimum over surfels).
+int cf_model_predict_indices_sharded(cf_model* m, const float pose[16], int time, float maxDepth, int timeDelta, int shard, int nshards)
+{
+    if (!m || !pose || nshards < 1 || shard < 0 || shard >= nshards) return CF_EINVAL;
+    cf_ctx* ctx = m->ctx;
+    if (!ctx->collective) { ctx->set_error("cf_model_predict_indices_sharded: no collective registered (cf_set_collective)"); return CF_ESTATE; }
+    uint32_t n = 0;
+    if (int r = exact_count(m, &n)) return r;   // identical on every replica, unlike the asynchronous upper bound
+    const uint32_t b = (uint32_t)(((uint64_t)n * (uint64_t)shard) / (uint64_t)nshards), e = (uint32_t)(((uint64_t)n * (uint64_t)(shard + 1)) / (uint64_t)nshards);
+    if (int r = cf_model_index_keys(m, pose, time, maxDepth, timeDelta, b, e, reinterpret_cast<uint64_t*>(m->keys))) return r;
+    if (ctx->collective(ctx->collective_user, 1, m->keys, (uint64_t)ctx->cfg.width * ctx->cfg.height, (void*)ctx->stream) != 0) {
+        ctx->set_error("cf_model_predict_indices_sharded: the collective failed");
+        return CF_ESTATE;
+    }
+    return cf_model_index_resolve(m, pose, reinterpret_cast<uint64_t*>(m->keys));
+}
+
 int cf_model_combined_predict(cf_model* m, const float pose[16], float maxDepth, float confThreshold, int time, int maxTime, int timeDelta)
 {
     if (!m || !pose) return CF_EINVAL;

@@ -41,6 +41,10 @@ struct cf_ctx {
     hipStream_t forked_from = nullptr;
     bool forked = false;
     unsigned lanes_used = 0;
+    // collective of a multi-GPU caller (cf_set_collective): op 0 = in-place SUM all-reduce of int64 words, op 1 = in-place MIN
+    // all-reduce of unsigned 64-bit words; enqueued on the given stream
+    int (*collective)(void* user, int op, void* dev_buf, uint64_t words, void* stream) = nullptr;
+    void* collective_user = nullptr;
     cf::ProfSink prof{};
     double prof_ms_accum = 0;
     void set_error(const std::string& m);
@@ -69,7 +73,9 @@ struct cf_odom {
     uint8_t* cand[3]{};
     unsigned* occ = nullptr;         // occupancy bitmap of the model maps (written by model_maps_kernel)
     bool occ_valid = false;          // the bitmap describes the current model maps
-    bool use_occ = false;            // cf_odom_set_culling: worth it for models that cover a small part of the image
+    bool use_occ = false;
+    int band_begin = 0, band_end = 0;  // cf_odom_set_band: this rank's rows of the model's reductions (0, 0: all rows)
+    bool band_counts = true;           // this rank adds the residual pass's count / sigma (exactly one rank of a split does)            // cf_odom_set_culling: worth it for models that cover a small part of the image
     unsigned long long* icp_acc = nullptr;
     unsigned long long* rgb_acc = nullptr;
     cf::OdomDev* d_state = nullptr;

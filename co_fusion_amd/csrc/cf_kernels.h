@@ -114,6 +114,8 @@ struct IcpModelArgs {
     float* err;                         // nullable ICP error surface [rows*cols]
     unsigned long long* rgb_acc;        // the model's RGB accumulators (used by the solve kernel's arguments)
     const unsigned* occ;                // nullable: occupancy bitmap of the model maps (model_maps_kernel), 1 bit per 4x4 level-0 block
+    int row_begin, row_end;             // row band of THIS model's reduction (row_end == 0: all rows): its share when the model's
+                                        // reduction is split over GPUs
 };
 // solve-kernel arguments (by value)
 struct GnArgs {
@@ -128,6 +130,8 @@ struct RgbModelArgs {
     const uint8_t* lastImage; const uint8_t* nextImage;
     cf_dataterm* corres; const float* cloud; const int16_t* dIdx; const int16_t* dIdy;
     unsigned long long* icp_acc; unsigned long long* rgb_acc;
+    int no_counts;                      // the residual pass does not add its correspondence count / sigma to the accumulator: another
+                                        // rank does, and the accumulators are summed over the ranks (split reduction)
     uint2* recs;                        // record slots of the device-resident loop (aliases corres: N x 8 B)
     unsigned* slot_counts;              // records per slot (behind the records in the same buffer)
 };
@@ -142,7 +146,7 @@ struct RgbArgs {
 inline RgbModelArgs rgb_model_args(const OdomDev* h /* host mirror */, OdomDev* d_state, int level)
 {
     return RgbModelArgs{d_state, h->cand[level], h->nextDepth[level], h->lastDepth[level], h->lastImage[level], h->nextImage[level],
-                        h->corres[level], h->cloud[level], h->dIdx[level], h->dIdy[level], h->icp_acc, h->rgb_acc,
+                        h->corres[level], h->cloud[level], h->dIdx[level], h->dIdy[level], h->icp_acc, h->rgb_acc, 0,
                         reinterpret_cast<uint2*>(h->corres[level]),
                         reinterpret_cast<unsigned*>(reinterpret_cast<uint2*>(h->corres[level]) + (size_t)(h->width >> level) * (h->height >> level))};
 }
@@ -180,8 +184,11 @@ constexpr int kSo3Blocks = 16;
 struct So3Sync { unsigned long long acc[10][16]; unsigned arrive, depart; };
 // mode 0: {ICP || residual -> DataTerm image} + rgb_step over the image + solve;
 // mode 1: {ICP || residual -> per-workgroup record slots} + rgb step over the slots + solve
-void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */, So3Sync* so3_syncs /* [n] */,
-                     const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3,
+// hook: called after every {ICP || residual} launch for each model whose reduction is split over GPUs (split[m] != 0) with that
+// model's grouped ICP accumulators (kGroups * 32 words): the caller's in-place SUM all-reduce over the ranks, enqueued on `s`
+struct GnHook { int (*fn)(void* user, int op, void* dev_buf, uint64_t words, void* stream); void* user; int split[kMaxBatch]; };
+bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */, So3Sync* so3_syncs /* [n] */,
+                     const GnHook* hook, const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3,
                      bool pyramid, bool fast_odom, bool rgb, bool icp, int mode, ProfSink* prof);
 float sqrt_gate_lt(float T);  // smallest x with sqrtf(x) >= T
 float sqrt_gate_le(float T);  // largest x with sqrtf(x) <= T

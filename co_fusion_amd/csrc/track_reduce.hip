@@ -154,9 +154,18 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     const OdomDev* __restrict__ st = ma.st;
     const int cols = args.cols, rows = args.rows, N = cols * rows;
     const int T = blockDim.x;
-    // optional row band [row_begin, row_end) (a rank's share when one model's reduction is split over GPUs)
-    const int pix0 = args.row_begin * cols, pix1 = (args.row_end > 0 ? args.row_end : rows) * cols;
+    // optional row band [row_begin, row_end) (a rank's share when one model's reduction is split over GPUs): of the whole launch
+    // (stand-alone band step) or of this model (split background inside the lock-step loop)
+    const int rb = ma.row_end > 0 ? ma.row_begin : args.row_begin, re = ma.row_end > 0 ? ma.row_end : args.row_end;
+    const int band0 = rb * cols, band1 = (re > 0 ? re : rows) * cols;
+    // the error surface (last level-0 iteration) is written for the WHOLE image on every rank of a split model -- the segmentation
+    // reads all of it -- while only the band's pixels enter the sums
+    const bool whole = (args.flags & 1) && ma.err != nullptr && ma.row_end > 0;
+    const int pix0 = whole ? 0 : band0, pix1 = whole ? N : band1;
     const int nlog = (pix1 - pix0 + T * PPT - 1) / (T * PPT);
+    // (the grid is sized for the whole image; a model with a row band has fewer logical blocks, and the XCD interleave below is a
+    // bijection only on the first 8 * ceil(nlog / 8) hardware blocks)
+    if ((int)(blockIdx.x >> 3) >= ((nlog + 7) >> 3)) return;
     const int lb = xcd_logical_block(blockIdx.x, nlog);
     if (lb >= nlog) return;
 
@@ -204,6 +213,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
             nprev[p] = f3{np[g], np[g + N], np[g + 2 * N]};
         }
         // necessary for a correspondence: in view, both normals valid, a finite model vertex
+        if (whole && (i0 + p < band0 || i0 + p >= band1)) continue;  // outside this rank's band: error surface only
         cand |= (pr[p].inb && !is_nan(nx[p]) && !is_nan(nprev[p].x) && !is_nan(vprev[p].x)) ? 1 : 0;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -233,6 +243,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
             const f3 cr0 = cross(ncurr_g, nprev[p]);
             const float sine2 = dot(cr0, cr0);
             fnd[p] = (pr[p].inb && sine2 < args.angleSqLt && dist2 <= args.distSqLe && !is_nan(nx[p]) && !is_nan(nprev[p].x)) ? 1 : 0;
+            if (whole && (i0 + p < band0 || i0 + p >= band1)) fnd[p] = 0;
             any_found |= fnd[p];
             if (fnd[p]) {
                 const f3 s_cp = mul(Rprev_inv, pr[p].vcurr_g - tprev);
@@ -422,8 +433,8 @@ __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
             const int bn = s_n, g4 = s_sig;
             m.slot_counts[blk] = (unsigned)bn;  // every workgroup publishes its count: the list pass reads it unconditionally
             unsigned long long* dst = m.icp_acc + (size_t)(blk % kGroups) * 32;
-            if (bn) atomicAdd(&dst[29], (unsigned long long)bn);
-            if (g4) atomicAdd(&dst[30], (unsigned long long)(long long)g4);
+            if (bn && !m.no_counts) atomicAdd(&dst[29], (unsigned long long)bn);
+            if (g4 && !m.no_counts) atomicAdd(&dst[30], (unsigned long long)(long long)g4);
         }
     }
 }
@@ -1047,7 +1058,7 @@ void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, 
 // grid barrier, a chain of about five device-scope memory round trips of ~1.5 us each across the XCDs, whereas a dependent
 // launch costs ~2.5 us (tools/microbench/launch_floor.hip).  On this part the kernel boundary IS the cheapest grid barrier.
 // Kept as separate launches.
-void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const IcpArgs icp_args[3],
+bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const GnHook* hook, const IcpArgs icp_args[3],
                      const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, int mode,
                      ProfSink* prof)
 {
@@ -1065,6 +1076,7 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
         gn.rgb_acc[m] = icp_args[0].m[m].rgb_acc;
     }
     const bool slots = mode != 0;
+    bool hook_failed = false;
     for (int i = 2; i >= 0; i--) {
         const int N = (width >> i) * (height >> i);
         for (int j = 0; j < iterations[i]; j++) {
@@ -1090,6 +1102,9 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
                     prof->launches += 1;
                 }
             }
+            if (hook && hook->fn)  // split reductions: the partial sums of this rank's row band become the totals on every rank
+                for (int m = 0; m < n; m++)
+                    if (hook->split[m] && hook->fn(hook->user, 0, gn.icp_acc[m], (uint64_t)kGroups * 32, (void*)s) != 0) hook_failed = true;
             if (rgb) {
                 if (slots) rgb_slot_step_kernel<<<dim3((N + ra.slot_px - 1) / ra.slot_px, n), 256, 0, s>>>(ra);
                 else rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(ra);
@@ -1097,6 +1112,7 @@ void launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
             gn_solve_kernel<<<n, 256, 0, s>>>(gn, next_level, last_of_level ? 1 : 0);
         }
     }
+    return !hook_failed;
 }
 
 // ---- stand-alone steps (C-ABI parity with computeRgbResidual / rgbStep) -------------------

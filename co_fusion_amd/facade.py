@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -18,7 +19,7 @@ class Config(C.Structure):
                 ("outlier_coefficient", C.c_float), ("fast_odom", C.c_int), ("so3", C.c_int), ("frame_to_frame_rgb", C.c_int),
                 ("pyramid", C.c_int), ("rgb_only", C.c_int), ("model_spawn_offset", C.c_uint), ("enable_multiple_models", C.c_int),
                 ("enable_pose_logging", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("device_frames_complete", C.c_int),
-                ("mid_frame_predict", C.c_int)]
+                ("mid_frame_predict", C.c_int), ("shard_background", C.c_int)]
 
 
 class CoFusionError(RuntimeError):
@@ -77,6 +78,53 @@ class CoFusion:
         self._check(self.lib.cofusion_set_allreduce(self.h, self._allreduce_cb, None))
         if fn is None:
             self.set_allreduce_device()   # nccl: RCCL on the stream; gloo (dry runs): the same path, staged by gloo itself
+            if self.cfg.shard_background:
+                self.set_collective()
+
+    def set_collective(self):
+        """C-ABI level collective (cf_set_collective) for a background split over the ranks (shard_background=1): op 0 = SUM of int64 words
+        (the normal-equation accumulators, after every launch of the Gauss-Newton loop), op 1 = MIN of unsigned 64-bit words (the z-keys
+        of the index map).  torch.distributed on a torch-owned staging tensor, enqueued on the library's stream."""
+        import torch.distributed as dist
+        self._co_buf = None
+        self._co_calls = 0
+        sign = torch.tensor(-2 ** 63, dtype=torch.int64, device=self.device)
+
+        def thunk(_user, op, dev_buf, words, hip_stream):
+            try:
+                n = int(words)
+                if self._co_buf is None or self._co_buf.numel() < n:
+                    self._co_buf = torch.empty(n, dtype=torch.int64, device=self.device)
+                t = self._co_buf[:n]
+                ctx = self._ctx()
+                nbytes = C.c_uint64(n * 8)
+                if self.abi.cf_memcpy_d2d_async(ctx, C.c_void_p(t.data_ptr()), C.c_void_p(dev_buf), nbytes) != 0:
+                    return -1
+                stream = torch.cuda.ExternalStream(int(hip_stream), device=self.device) if hip_stream else torch.cuda.current_stream(self.device)
+                with torch.cuda.stream(stream):
+                    if op == 0:
+                        dbg = os.environ.get("CF_DEBUG_COLLECTIVE") and self._co_calls < 6
+                        if dbg:
+                            before = t.view(-1, 32).sum(0).cpu().numpy()
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                        if dbg:
+                            after = t.view(-1, 32).sum(0).cpu().numpy()
+                            print(f"[collective rank {dist.get_rank()} call {self._co_calls}] inliers {before[28]} -> {after[28]}  rgb count {before[29]} -> {after[29]}  w0 {before[0]} -> {after[0]}", flush=True)
+                        self._co_calls += 1
+                    else:  # unsigned order through the signed collective: flip the sign bit, MIN, flip back
+                        t.bitwise_xor_(sign)
+                        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                        t.bitwise_xor_(sign)
+                if self.abi.cf_memcpy_d2d_async(ctx, C.c_void_p(dev_buf), C.c_void_p(t.data_ptr()), nbytes) != 0:
+                    return -1
+                return 0
+            except Exception:  # noqa: BLE001 -- reported through the C return code
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        self._collective_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p)(thunk)  # keep alive
+        assert self.abi.cf_set_collective(self._ctx(), self._collective_cb, None) == 0
 
     def set_allreduce_device(self):
         """The collective for buffers that live in HBM (per-superpixel segmentation sums): RCCL all-reduce of an int64 torch tensor,

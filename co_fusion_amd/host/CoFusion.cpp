@@ -187,7 +187,8 @@ void Model::clean(int time, int timeDelta, float /*depthCutoff*/, const float* d
 void Model::predictIndices(int time, float depthCutoff, int timeDelta)
 {
     if (!owned) return;
-    check(ctx, cf_model_predict_indices(model, pose.m, time, depthCutoff, timeDelta), "predictIndices");
+    if (shards > 1) check(ctx, cf_model_predict_indices_sharded(model, pose.m, time, depthCutoff, timeDelta, shard, shards), "predictIndices (sharded)");
+    else check(ctx, cf_model_predict_indices(model, pose.m, time, depthCutoff, timeDelta), "predictIndices");
 }
 void Model::combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta)
 {
@@ -328,8 +329,9 @@ void Segmentation::enqueueCRF(ModelList& models, const float* depth_dev, const u
         int m = 0;
         for (auto& mdl : models) {
             // a shadow contributes zeros here; its owner's sums arrive through the all-reduce below
-            icpPtr[m] = mdl->isOwned() ? mdl->icpErrorSurface() : zeroImage;
-            vcPtr[m] = mdl->isOwned() ? mdl->vertexConfProjection() : zeroImage;
+            const bool mine = mdl->isOwned() && (!dist || dist->contributes(mdl->getID()));
+            icpPtr[m] = mine ? mdl->icpErrorSurface() : zeroImage;
+            vcPtr[m] = mine ? mdl->vertexConfProjection() : zeroImage;
             ids[m] = mdl->getID();
             m++;
         }
@@ -390,8 +392,9 @@ SegmentationResult Segmentation::performSegmentationCRF(ModelList& models, const
         int m = 0;
         for (auto& mdl : models) {
             // a shadow contributes zeros here; its owner's sums arrive through the all-reduce below
-            icpPtr[m] = mdl->isOwned() ? mdl->icpErrorSurface() : zeroImage;
-            vcPtr[m] = mdl->isOwned() ? mdl->vertexConfProjection() : zeroImage;
+            const bool mine = mdl->isOwned() && (!dist || dist->contributes(mdl->getID()));
+            icpPtr[m] = mine ? mdl->icpErrorSurface() : zeroImage;
+            vcPtr[m] = mine ? mdl->vertexConfProjection() : zeroImage;
             m++;
         }
     }
@@ -621,6 +624,7 @@ static cf_ctx* make_ctx(const CoFusion::Config& c)
 CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
 {
     dist.rank = cfg.rank; dist.world = cfg.world < 1 ? 1 : cfg.world;
+    dist.shardBackground = cfg.shardBackground && dist.world > 1;
     labelGenerator.reset(new Segmentation(ctx, cfg.width, cfg.height, &dist));
     const size_t N = (size_t)cfg.width * cfg.height;
     void* p = nullptr;
@@ -640,7 +644,13 @@ CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
         check(ctx, cf_malloc_host(ctx, N * 4 + N * 3, &p), "cf_malloc_host"); stage[b] = static_cast<uint8_t*>(p);
     }
     globalModel = std::make_shared<Model>(ctx, getNextModelID(true), cfg.confGlobalInit, true, cfg.maxSurfels, 3.402823466e+38f,
-                                          dist.owner(0) == dist.rank);
+                                          dist.ownsHere(0));
+    if (dist.shardBackground) {
+        globalModel->shard = dist.rank; globalModel->shards = dist.world;
+        // image rows of the ICP reduction: multiples of 4 (three pyramid levels)
+        const int rows4 = cfg.height / 4, b = (rows4 * dist.rank / dist.world) * 4, e = (rows4 * (dist.rank + 1) / dist.world) * 4;
+        if (globalModel->isOwned()) check(ctx, cf_odom_set_band(globalModel->getFrameOdometry(), b, e, dist.rank == 0 ? 1 : 0), "cf_odom_set_band");
+    }
     globalModel->loggingPoses = cfg.enablePoseLogging;
     models.push_back(globalModel);
 }
@@ -761,7 +771,7 @@ void CoFusion::exchangeTracking()
     std::vector<int64_t> buf(models.size() * R, 0);
     size_t k = 0;
     for (auto& m : models) {
-        if (m->isOwned()) {
+        if (m->isOwned() && dist.contributes(m->getID())) {
             for (int i = 0; i < 16; i++) { uint32_t b; memcpy(&b, &m->pose.m[i], 4); buf[k * R + i] = (int64_t)b; }
             uint32_t b; memcpy(&b, &m->lastStats.last_icp_error, 4); buf[k * R + 16] = (int64_t)b;
             memcpy(&b, &m->lastStats.last_icp_count, 4); buf[k * R + 17] = (int64_t)b;

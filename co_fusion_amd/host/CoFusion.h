@@ -75,6 +75,13 @@ struct Distributed {
     bool active() const { return world > 1; }
     // the background map (by far the largest) alone on rank 0, objects round-robin over the other ranks
     int owner(unsigned id) const { return (world <= 1 || id == 0) ? 0 : 1 + (int)((id - 1) % (unsigned)(world - 1)); }
+    // Background split over the ranks (Config::shardBackground): every rank keeps a replica of the background map and takes a share of
+    // its two reductions -- the surfel range it rasterises into the index map (MIN all-reduce of the z-keys) and the image rows it
+    // reduces in the ICP step (SUM all-reduce of the normal-equation accumulators after every launch of the Gauss-Newton loop).
+    bool shardBackground = false;
+    bool ownsHere(unsigned id) const { return (id == 0 && shardBackground && active()) ? true : owner(id) == rank; }
+    // for the one-owner exchanges (poses, segmentation sums): does THIS rank contribute model `id`?
+    bool contributes(unsigned id) const { return (id == 0 && shardBackground && active()) ? rank == 0 : owner(id) == rank; }
     void sum(int64_t* buf, uint64_t n) const;  // throws if the collective is missing or fails
     // the same collective on a DEVICE buffer, enqueued on `stream` (RCCL): no host visit.  Optional: without it device buffers are
     // staged through the host callback.
@@ -127,6 +134,8 @@ class Model {
     const float* vertexConfProjection() const;
     cf_track_stats lastStats{};
     bool isOwned() const { return owned; }
+    // split over the ranks (background replica): shard index / count, 0 / 1 when the model lives on one rank
+    int shard = 0, shards = 1;
 
     struct PoseLogItem { int64_t ts; float p[7]; };  // x,y,z, qx,qy,qz,qw (Model.h:230-233)
     std::vector<PoseLogItem> poseLog;
@@ -215,6 +224,9 @@ class CoFusion {
         // the end-of-frame prediction before anything in the frame loop reads them (they are what the reference's GUI shows), so the
         // default skips the pass; results are identical either way.
         bool midFramePredict = false;
+        // model-parallel operation only: split the background's index-map rasterisation (by surfel range) and ICP reduction (by image
+        // rows) over all ranks, each holding a replica of the background map (see Distributed::shardBackground)
+        bool shardBackground = false;
     };
     explicit CoFusion(const Config& cfg);
     ~CoFusion();

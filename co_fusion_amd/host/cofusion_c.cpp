@@ -34,6 +34,7 @@ void cofusion_default_config(cofusion_config* c)
     c->rank = d.rank; c->world = d.world;
     c->device_frames_complete = d.deviceFramesComplete;
     c->mid_frame_predict = d.midFramePredict;
+    c->shard_background = d.shardBackground;
 }
 
 int cofusion_create(const cofusion_config* c, cofusion_handle** out)
@@ -50,6 +51,7 @@ int cofusion_create(const cofusion_config* c, cofusion_handle** out)
     d.rank = c->rank; d.world = c->world < 1 ? 1 : c->world;
     d.deviceFramesComplete = c->device_frames_complete != 0;
     d.midFramePredict = c->mid_frame_predict != 0;
+    d.shardBackground = c->shard_background != 0;
     GUARD(*out = new cofusion_handle{new CoFusion(d)});
     return 0;
 }

@@ -28,6 +28,10 @@ typedef struct {
                                  * produced by work queued on the context's stream and are consumed in stream order */
     int mid_frame_predict;      /* 1: also run the reference's prediction between tracking and fusion (CoFusion.cpp:346); its outputs are
                                  * overwritten by the end-of-frame prediction before the frame loop reads them (GUI only).  Default 0. */
+    int shard_background;       /* model-parallel operation (world > 1): 1 = every rank keeps a replica of the background map and takes a
+                                 * share of its index-map rasterisation (surfel range, MIN all-reduce of the z-keys) and of its ICP
+                                 * reduction (image rows, SUM all-reduce of the accumulators after every launch of the Gauss-Newton
+                                 * loop); needs cf_set_collective on the context (cofusion_context).  Default 0. */
 } cofusion_config;
 
 void cofusion_default_config(cofusion_config *cfg);

@@ -231,6 +231,14 @@ int cf_odom_fetch_result(cf_odom *od, float trans[3], float rot[9], cf_track_sta
  * initICPModel).  Results are unchanged; it pays for models that cover a small part of the image (object models) and costs a
  * dependent look-up for one that covers all of it (background).  Default off. */
 int cf_odom_set_culling(cf_odom *od, int on);
+/* Multi-GPU hooks.  cf_set_collective registers the caller's in-place all-reduce over its ranks (RCCL): op 0 = SUM of int64 words,
+ * op 1 = MIN of unsigned 64-bit words; dev_buf is a device address, the call must only ENQUEUE on `hip_stream` (or order itself
+ * after it and before later work on it); 0 = success.  cf_odom_set_band splits one model's reductions over the ranks by image
+ * rows (level-0 rows, multiples of 4; add_counts = 1 on exactly one rank of the split): inside the device-resident loop the
+ * collective sums that model's accumulators after every {ICP || residual} launch, so all ranks solve the same system. */
+typedef int (*cf_collective_fn)(void *user, int op, void *dev_buf, uint64_t words, void *hip_stream);
+int cf_set_collective(cf_ctx *ctx, cf_collective_fn fn, void *user);
+int cf_odom_set_band(cf_odom *od, int row_begin, int row_end, int add_counts);
 int cf_odom_bind_frame_maps(cf_odom *od, const float *const vmaps[CF_NUM_PYRS], const float *const nmaps[CF_NUM_PYRS]);
 int cf_odom_buffer(cf_odom *od, int which, int level, void **dptr, uint64_t *bytes);
 /* Model::generateCUDATextures depth half (Model.cpp:341-343): l1/l2 device outputs */
@@ -257,6 +265,9 @@ int cf_model_predict_indices(cf_model *m, const float pose[16], int time, float 
 int cf_model_index_keys(cf_model *m, const float pose[16], int time, float maxDepth, int timeDelta, uint32_t surfel_begin,
                         uint32_t surfel_end, uint64_t *keys_dev);
 int cf_model_index_resolve(cf_model *m, const float pose[16], uint64_t *keys_dev);
+/* the three steps in one call for a REPLICATED map whose rasterisation is split over `nshards` ranks: this rank's range of the exact
+ * surfel count, the registered collective (cf_set_collective, op 1) on the key map, resolve */
+int cf_model_predict_indices_sharded(cf_model *m, const float pose[16], int time, float maxDepth, int timeDelta, int shard, int nshards);
 /* Model::combinedPredict -> ModelProjection::combinedPredict (ModelProjection.cpp:192-273), ACTIVE prediction */
 int cf_model_combined_predict(cf_model *m, const float pose[16], float maxDepth, float confThreshold, int time, int maxTime,
                               int timeDelta);

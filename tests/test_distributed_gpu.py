@@ -104,7 +104,7 @@ def test_surfel_range_sharded_index_map_min_allreduce_is_exact(tmp_path):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
 
 
-def _mp_worker(rank, world, port, out_dir, use_gt):
+def _mp_worker(rank, world, port, out_dir, use_gt, shard_bg=False, size=(320, 240), n_frames=9, n_obj=2):
     import sys
     import warnings
     here = os.path.dirname(os.path.abspath(__file__))
@@ -114,15 +114,15 @@ def _mp_worker(rank, world, port, out_dir, use_gt):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        W, H = 320, 240
+        W, H = size
         cam = synth.Camera.scaled(W, H)
-        sc = synth.Scene(n_obj=2)
-        kw = dict(max_surfels=1 << 19, conf_global_init=0.5, model_spawn_offset=2, enable_multiple_models=1)
+        sc = synth.Scene(n_obj=n_obj)
+        kw = dict(max_surfels=1 << (21 if W > 320 else 19), conf_global_init=0.5, model_spawn_offset=2, enable_multiple_models=1)
         single = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, **kw)                  # the whole job on one GPU
-        par = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, rank=rank, world=world, **kw)   # this rank's share
+        par = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, rank=rank, world=world, shard_background=int(shard_bg), **kw)   # this rank's share
         par.set_allreduce()
         msgs, owned_any, shadow_any = [], False, False
-        for t in range(9):
+        for t in range(n_frames):
             d, rgb, lab, _ = sc.render(cam, t, noise=True)
             gt = (lab * 40).astype(np.uint8) if use_gt else None
             single.process_frame(d, rgb, mask=gt, timestamp=t)
@@ -143,7 +143,12 @@ def _mp_worker(rank, world, port, out_dir, use_gt):
                     shadow_any = True
         if single.num_models < 2:
             msgs.append("no object model was spawned")
-        if not (owned_any and shadow_any) and rank < 2:   # (with 3 ranks and 2 objects every rank still owns something)
+        if shard_bg and not par.model_owned(0):
+            msgs.append("the background replica is missing on this rank")
+        if shard_bg:   # rank 0: background replica + object shadows; rank 1: background replica + the objects
+            if not owned_any or (rank == 0 and not shadow_any):
+                msgs.append("ownership pattern of the split-background run not seen")
+        elif not (owned_any and shadow_any) and rank < 2:   # (with 3 ranks and 2 objects every rank still owns something)
             msgs.append("this rank did not see both an owned model and a shadow")
         par.close(); single.close()
         open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if not msgs else "; ".join(msgs[:4]))
@@ -159,4 +164,16 @@ def test_model_parallel_frame_loop_matches_single_gpu(tmp_path, use_gt, world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_mp_worker, args=(world, port, str(tmp_path), use_gt), nprocs=world, join=True)
     for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+def test_background_split_over_ranks_matches_single_gpu(tmp_path):
+    """north_star: "for the background, surfel-range shards of the index-map reduction ... with RCCL all-reduce of the 6x6 system".
+    640x480, two ranks, shard_background=1: each rank holds a replica of the background map, rasterises half of its surfels into the
+    index map (MIN all-reduce of the z-keys) and reduces half of the image rows in the ICP step (SUM all-reduce of the accumulators
+    after every launch of the Gauss-Newton loop); objects live on rank 1.  Poses, masks and BOTH background replicas equal the
+    single-GPU run bit for bit over 8 frames (one object spawns on the way)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_mp_worker, args=(2, port, str(tmp_path), False, True, (640, 480), 8, 4), nprocs=2, join=True)
+    for r in range(2):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
