@@ -344,7 +344,7 @@ def main(argv=None):
                                icp_launch=[args.icp_threads, args.icp_ppt], gn_mode=args.gn_mode,
                                streams_per_gpu=S, parallel=args.parallel if world > 1 else "single",
                                background="split over the ranks (replicated map; surfel-range index map + row-band ICP with all-reduce)" if (model_parallel and args.shard_background) else "one rank",
-                               frames="ring of device-resident frames, complete before each call (device_frames_complete=1)"),
+                               frames=("broadcast from rank 0 every step, consumed in stream order" if model_parallel else "ring of device-resident frames, complete before each call (device_frames_complete=1)")),
                    roofline=roofline)
         if world == 1 and S == 1 and not args.no_extras:
             extras(out, args, cf, cam, frames, base + args.steps, use_gt, torch, facade, local_rank)

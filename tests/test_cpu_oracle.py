@@ -154,3 +154,23 @@ def test_rgb_only_tracking_moves_towards_the_known_motion():
     assert np.isfinite(tr).all() and np.isfinite(rot).all() and st.last_rgb_count > 5000
     assert np.linalg.norm(tr - T1[:3, 3]) < np.linalg.norm(T1[:3, 3])
     assert np.abs(rot - T1[:3, :3]).max() < np.abs(np.eye(3) - T1[:3, :3]).max()
+
+
+def test_config_golden_head_is_what_the_oracle_produces():
+    """tests/golden/configs_v1.npz (the oracle's free runs at BASELINE.json's sizes, consumed by tests/test_configs_gpu.py on the GPU box)
+    is reproducible: the first frames of the 640x480 static scenario and of the 4-object scenario, re-derived here."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_config_golden as mcg
+    g = np.load(os.path.join(here, "golden", "configs_v1.npz"))
+    for name, frames in (("static_640", 2), ("objects4_640", 2)):
+        for t, rec in enumerate(mcg.run_oracle(name, n_frames=frames)):
+            n = int(g[f"{name}/nm"][t])
+            assert n == len(rec["ids"])
+            assert list(g[f"{name}/ids"][t, :n]) == rec["ids"] and list(g[f"{name}/counts"][t, :n]) == rec["counts"]
+            for i in range(n):
+                assert g[f"{name}/poses"][t, i].tobytes() == np.asarray(rec["poses"][i], np.float32).tobytes(), f"{name} frame {t}: pose"
+                assert str(g[f"{name}/surf_sha"][t, i]) == rec["surf_sha"][i], f"{name} frame {t}: surfel buffer"
+            assert str(g[f"{name}/mask_sha"][t]) == rec["mask_sha"]
