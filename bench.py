@@ -98,6 +98,8 @@ def parse(argv=None):
                     help="N > 1, --parallel models: every rank keeps a replica of the background map and takes a share of its index-map "
                          "rasterisation (surfel range, MIN all-reduce of the z-keys) and of its ICP reduction (image rows, SUM all-reduce of the "
                          "6x6 accumulators after every launch of the Gauss-Newton loop) -- the split BASELINE.json's configs[4] names")
+    ap.add_argument("--event-sampling", type=int, default=4, help="timing events on the level-0 launches of every N-th timed step (1: every step)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not attach timing events to the level-0 launches (no roofline figure)")
     ap.add_argument("--dry-run", action="store_true", help="plumbing test without a GPU (tests/test_cpu_distributed.py): the process-group "
                     "set-up, the timing contract and the JSON line with a stub step instead of processFrame")
     ap.add_argument("--streams", type=int, default=1, help="independent RGB-D streams per GPU (own context + HIP stream + host thread each); "
@@ -307,7 +309,7 @@ def main(argv=None):
     run_range(0, P, pre_masks)
     run_range(P, P + args.warmup)
     base = P + args.warmup
-    cf.profile_enable(True)
+    cf.profile_enable(0 if args.no_kernel_events else args.event_sampling)
     cf.profile_read(reset=True)
     dt = timed_region(None, args.steps, 0, barrier, all_reduce_max, run_range=lambda lo, hi: run_range(lo + base, hi + base))
     prof = cf.profile_read(reset=True)
@@ -327,6 +329,7 @@ def main(argv=None):
                         kernel="cf::icp_reduce_kernel<PPT,%d>: ICP reduction of all lock-step models || their RGB residual passes, pyramid level 0"
                                % (4 if n_models > 1 else 0),
                         launches=int(prof.icp_launches), avg_us=round(avg_us, 3), bytes_per_launch=bpl,
+                        sampled="level-0 launches of every %d-th timed step carry begin/end events" % args.event_sampling,
                         bytes_per_pixel="24 + 24*M (ICP) + 11*M (residual), M = models in the launch",
                         frac_icp_bytes_only=round(icp_only / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4))
         out = dict(metric="frames/sec at 640x480 (N active models) + ICP-reduce achieved HBM GB/s vs peak", value=round(fps, 2),
@@ -459,7 +462,7 @@ def secondary_static(args, torch, facade, local_rank, warmup=30, steps=120):
         for i in range(warmup):
             k = frame_index(i, args.frames)
             cf.process_frame_device(res[k]["depth"], res[k]["rgba"], timestamp=i)
-        cf.profile_enable(True)
+        cf.profile_enable(args.event_sampling)
         cf.profile_read(reset=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

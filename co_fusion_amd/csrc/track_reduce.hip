@@ -1018,6 +1018,14 @@ static void launch_icp_kernel(hipStream_t s, IcpLaunch cfg, const IcpArgs& args,
     const int nlog = (N + per_block - 1) / per_block;
     const int n_icp_blocks = icp ? ((nlog + 7) / 8) * 8 : 0;
     const dim3 grid(n_icp_blocks + n_res_blocks, n);
+    if (!ev0 && !ev1) {  // plain launches (also what a stream capture records)
+        switch (cfg.ppt) {
+            case 4: icp_reduce_kernel<4, TAG><<<grid, dim3(cfg.threads), 0, s>>>(args, ra, n_icp_blocks); break;
+            case 2: icp_reduce_kernel<2, TAG><<<grid, dim3(cfg.threads), 0, s>>>(args, ra, n_icp_blocks); break;
+            default: icp_reduce_kernel<1, TAG><<<grid, dim3(cfg.threads), 0, s>>>(args, ra, n_icp_blocks); break;
+        }
+        return;
+    }
     switch (cfg.ppt) {
         case 4: hipExtLaunchKernelGGL((icp_reduce_kernel<4, TAG>), grid, dim3(cfg.threads), 0, s, ev0, ev1, 0, args, ra, n_icp_blocks); break;
         case 2: hipExtLaunchKernelGGL((icp_reduce_kernel<2, TAG>), grid, dim3(cfg.threads), 0, s, ev0, ev1, 0, args, ra, n_icp_blocks); break;

@@ -267,6 +267,7 @@ class CoFusion:
         assert self.abi.cf_set_icp_launch(self._ctx(), threads, ppt) == 0
 
     def profile_enable(self, on=True):
+        """on: False / True, or N > 1 = events on the level-0 launches of every N-th tracking call"""
         assert self.abi.cf_profile_enable(self._ctx(), int(on)) == 0
 
     def profile_read(self, reset=True):

@@ -364,6 +364,8 @@ typedef struct {
                             * lock-step models + 11*M for the residual passes that share the launch (27*M with
                             * cf_set_gn_mode 0, which writes the 16 B DataTerm records) */
 } cf_profile;
+/* on = 0: off; on = N >= 1: attach begin/end events to the level-0 launches of every N-th tracking call (sampling keeps the host cost
+ * of the event pairs out of the measured frame rate) */
 int cf_profile_enable(cf_ctx *ctx, int on);
 int cf_profile_read(cf_ctx *ctx, cf_profile *out, int reset);
 
