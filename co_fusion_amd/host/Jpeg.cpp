@@ -155,6 +155,7 @@ std::string decodeJpegRGB(const uint8_t* data, size_t size, int width, int heigh
             while (p < segend) {
                 const int pq = data[p] >> 4, tq = data[p] & 15; p++;
                 if (tq > 3) return "bad quantisation table id";
+                if (p + (pq ? 128 : 64) > segend) return "truncated quantisation table";
                 for (int i = 0; i < 64; i++) { qt[tq][kZigzag[i]] = pq ? (uint16_t)be16(p) : data[p]; p += pq ? 2 : 1; }
             }
         } else if (m == 0xC4) {  // DHT
@@ -164,16 +165,19 @@ std::string decodeJpegRGB(const uint8_t* data, size_t size, int width, int heigh
                 if (th > 3 || tc > 1) return "bad Huffman table id";
                 Huff& h = tc ? ac[th] : dc[th];
                 int total = 0;
+                if (p + 16 > segend) return "truncated Huffman table";
                 for (int l = 1; l <= 16; l++) { h.bits[l] = data[p++]; total += h.bits[l]; }
                 if (total > 256 || p + total > segend) return "bad Huffman table";
                 memcpy(h.vals, data + p, (size_t)total); p += total;
                 h.build();
             }
         } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1
+            if (len < 8) return "truncated frame header";
             if (data[seg] != 8) return "only 8-bit JPEG is supported";
             H = be16(seg + 1); W = be16(seg + 3);
             const int nc = data[seg + 5];
             if (nc != 1 && nc != 3) return "only 1- or 3-component JPEG is supported";
+            if (len < 8 + 3 * nc) return "truncated frame header";
             comps.resize(nc);
             for (int i = 0; i < nc; i++) {
                 comps[i].id = data[seg + 6 + i * 3]; comps[i].h = data[seg + 7 + i * 3] >> 4; comps[i].v = data[seg + 7 + i * 3] & 15;
@@ -185,12 +189,15 @@ std::string decodeJpegRGB(const uint8_t* data, size_t size, int width, int heigh
         } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8)) {
             return "progressive / lossless / arithmetic JPEG is not supported";
         } else if (m == 0xDD) {
+            if (len < 4) return "truncated restart interval";
             restart = be16(seg);
         } else if (m == 0xDA) {  // SOS: decode the (single, interleaved) scan
             if (comps.empty()) return "scan before frame header";
             if (W != width || H != height) return "JPEG size differs from the log's resolution";
+            if (len < 3) return "truncated scan header";
             const int ns = data[seg];
             if (ns != (int)comps.size()) return "non-interleaved scans are not supported";
+            if (len < 6 + 2 * ns) return "truncated scan header";
             for (int i = 0; i < ns; i++) {
                 const int cid = data[seg + 1 + i * 2], t = data[seg + 2 + i * 2];
                 bool found = false;

@@ -23,7 +23,10 @@ class KlgLogReader {
     const std::string& error() const { return err; }
     int getNumFrames() const { return numFrames; }
     int currentFrameIndex() const { return currentFrame; }
-    bool hasMore() const { return currentFrame < numFrames; }
+    // Every frame of the log is played.  The reference's KlgLogReader::hasMore() is `currentFrame + 1 < numFrames` (GUI/Tools/
+    // KlgLogReader.cpp), i.e. it never plays the last frame: set referenceCompatible for frame-count parity with a reference run.
+    bool referenceCompatible = false;
+    bool hasMore() const { return referenceCompatible ? currentFrame + 1 < numFrames : currentFrame < numFrames; }
     // KlgLogReader::getNext/getCore: decodes the next frame into the members below; false on error
     bool getNext();
     void rewind();

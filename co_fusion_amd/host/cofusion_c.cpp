@@ -200,6 +200,7 @@ int cofusion_klg_next(cofusion_klg_reader* r, int64_t* ts, float* depth_m, uint8
     if (rgb) memcpy(rgb, r->r.rgb.data(), r->r.rgb.size());
     return 0;
 }
+int cofusion_klg_set_reference_compatible(cofusion_klg_reader* r, int on) { if (!r) return -1; r->r.referenceCompatible = on != 0; return 0; }
 void cofusion_klg_close(cofusion_klg_reader* r) { delete r; }
 int cofusion_klg_create(const char* file, int width, int height, int compress_depth, cofusion_klg_writer** out)
 {

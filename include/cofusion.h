@@ -95,6 +95,8 @@ typedef struct cofusion_klg_reader cofusion_klg_reader;
 typedef struct cofusion_klg_writer cofusion_klg_writer;
 int cofusion_klg_open(const char *file, int width, int height, int flip_colors, cofusion_klg_reader **out, int *num_frames);
 int cofusion_klg_next(cofusion_klg_reader *r, int64_t *timestamp, float *depth_m, uint8_t *rgb);
+/* 1: stop one frame early like the reference's KlgLogReader::hasMore() (`currentFrame + 1 < numFrames`); default 0 = play every frame */
+int cofusion_klg_set_reference_compatible(cofusion_klg_reader *r, int on);
 void cofusion_klg_close(cofusion_klg_reader *r);
 int cofusion_klg_create(const char *file, int width, int height, int compress_depth, cofusion_klg_writer **out);
 int cofusion_klg_write(cofusion_klg_writer *w, int64_t timestamp, const float *depth_m, const uint8_t *rgb);

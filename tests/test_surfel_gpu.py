@@ -59,7 +59,8 @@ def test_static_pipeline_lockstep(ctx, conf_global, n_frames, n_obj):
     cam = synth.Camera.scaled(W, H)
     sc = synth.Scene(n_obj=n_obj)
     ref = op.StaticPipeline(cam, conf_global=conf_global)
-    gpu = M.StaticPipeline(ctx, max_surfels=1 << 19, conf_global=conf_global)
+    import hip_pipeline
+    gpu = hip_pipeline.StaticPipeline(ctx, max_surfels=1 << 19, conf_global=conf_global)
     ref_pose = {}
     own_pose = {}
 
