@@ -91,6 +91,7 @@ def parse(argv=None):
     ap.add_argument("--icp-ppt", type=int, default=0, help="pixels per lane of the ICP reduction (0: library default)")
     ap.add_argument("--gn-mode", type=int, default=-1, help="-1: library default; 0: three launches per GN iteration; 1: two")
     ap.add_argument("--max-surfels", type=int, default=None)
+    ap.add_argument("--enqueue-threads", type=int, default=None, help="host threads enqueueing the per-model surfel passes (library default: 0)")
     ap.add_argument("--parallel", default=None, choices=["streams", "models"],
                     help="N > 1: 'models' (default for object workloads) = ONE sequence, its object models placed on the GPUs (strong "
                          "scaling); 'streams' = one independent sequence per GPU (weak scaling)")
@@ -235,6 +236,7 @@ def main(argv=None):
                               # single GPU / independent streams: the ring of frames is resident before timing starts; model-parallel:
                               # ranks > 0 receive every frame by broadcast just before the call, so frames are consumed in stream order
                               device_frames_complete=0 if model_parallel else 1,
+                              **(dict(enqueue_threads=args.enqueue_threads) if args.enqueue_threads is not None else {}),
                               **(dict(rank=rank, world=world, shard_background=int(args.shard_background)) if model_parallel else {}))
         if model_parallel:
             cfi.set_allreduce()

@@ -120,6 +120,8 @@ int cf_use_own_stream(cf_ctx* ctx)
 // Independent pieces of one frame (the surfel passes of different models) may overlap on the GPU: cf_fork(lane) routes
 // the following calls to auxiliary stream `lane`, ordered after everything enqueued on the context's stream at the first
 // fork; cf_join returns to that stream and orders it after all lanes used since.
+extern "C++" { thread_local cf_thread_binding cf_tls_binding; }
+
 int cf_fork(cf_ctx* ctx, int lane)
 {
     if (!ctx || lane < 0) return CF_EINVAL;
@@ -189,6 +191,20 @@ int cf_join(cf_ctx* ctx)
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_done[lane], 0));
         }
     ctx->lanes_used = 0;
+    return CF_OK;
+}
+// Bind the calling thread to lane `lane` of the context (lane < 0: unbind).  The owning thread forks the lane first (cf_fork, then
+// cf_main), which orders the lane after the stream and books it for the next cf_join; the bound thread's model calls then go to
+// the lane without touching the context's current stream.
+int cf_thread_lane(cf_ctx* ctx, int lane)
+{
+    if (!ctx) return CF_EINVAL;
+    if (lane < 0) { cf_tls_binding = cf_thread_binding{}; return CF_OK; }
+    lane %= cf_ctx::kLanes;
+    if (!ctx->lanes[lane] || !(ctx->lanes_used & (1u << lane))) { ctx->set_error("cf_thread_lane: lane was not forked"); return CF_ESTATE; }
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    cf_tls_binding.ctx = ctx;
+    cf_tls_binding.stream = ctx->lanes[lane];
     return CF_OK;
 }
 void* cf_get_stream(cf_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }

@@ -71,7 +71,7 @@ template <typename T>
 static int dmalloc(cf_ctx* ctx, T** p, size_t count)
 {
     HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
-    HIPCHK(ctx, hipMemsetAsync(*p, 0, count * sizeof(T), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(*p, 0, count * sizeof(T), ctx->cur()));
     return CF_OK;
 }
 
@@ -101,7 +101,7 @@ extern "C" {
 int cf_bilateral(cf_ctx* ctx, const float* depth, int cols, int rows, float maxD, float* out)
 {
     if (!ctx || !depth || !out) return CF_EINVAL;
-    launch_bilateral(ctx->stream, depth, cols, rows, maxD, out);
+    launch_bilateral(ctx->cur(), depth, cols, rows, maxD, out);
     LAUNCHCHK(ctx);
     return CF_OK;
 }
@@ -128,12 +128,12 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     if (int r = dmalloc(ctx, &m->new_flags, N)) return r;
     if (int r = dmalloc(ctx, &m->new_offsets, N)) return r;
     if (int r = dmalloc(ctx, &m->owner, M)) return r;
-    HIPCHK(ctx, hipMemsetAsync(m->owner, 0xFF, M * sizeof(unsigned), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(m->owner, 0xFF, M * sizeof(unsigned), ctx->cur()));
     if (int r = dmalloc(ctx, &m->fb_rec, N * 12)) return r;
     if (int r = dmalloc(ctx, &m->fb_raw, N * 12)) return r;
     if (int r = dmalloc(ctx, &m->fb_filt, N * 12)) return r;
     if (int r = dmalloc(ctx, &m->keys, N)) return r;
-    HIPCHK(ctx, hipMemsetAsync(m->keys, 0xFF, N * sizeof(unsigned long long), ctx->stream));  // empty z-buffer; every resolve pass re-clears it
+    HIPCHK(ctx, hipMemsetAsync(m->keys, 0xFF, N * sizeof(unsigned long long), ctx->cur()));  // empty z-buffer; every resolve pass re-clears it
     if (int r = dmalloc(ctx, &m->index, N)) return r;
     if (int r = dmalloc(ctx, &m->vertConf, N * 4)) return r;
     if (int r = dmalloc(ctx, &m->colorTime, N * 4)) return r;
@@ -148,7 +148,7 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     if (int r = dmalloc(ctx, &m->tcx, (size_t)W)) return r;
     if (int r = dmalloc(ctx, &m->tcy, (size_t)H)) return r;
     if (int r = dmalloc(ctx, &m->rays, N * 4)) return r;
-    launch_splat_rays(ctx->stream, ctx_cam(ctx), W, H, m->rays);
+    launch_splat_rays(ctx->cur(), ctx_cam(ctx), W, H, m->rays);
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->h_counts), sizeof(unsigned) * 4));
     HIPCHK(ctx, hipEventCreateWithFlags(&m->count_event, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&m->ratio_event, hipEventDisableTiming));
@@ -156,17 +156,17 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     std::vector<float> tx(W), ty(H);
     for (int i = 0; i < W; i++) tx[i] = (float)((double)((float)i / (float)W) + 1.0 / (2.0 * (double)(float)W));
     for (int j = 0; j < H; j++) ty[j] = (float)((double)((float)j / (float)H) + 1.0 / (2.0 * (double)(float)H));
-    HIPCHK(ctx, hipMemcpyAsync(m->tcx, tx.data(), sizeof(float) * W, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(m->tcy, ty.data(), sizeof(float) * H, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(m->tcx, tx.data(), sizeof(float) * W, hipMemcpyHostToDevice, ctx->cur()));
+    HIPCHK(ctx, hipMemcpyAsync(m->tcy, ty.data(), sizeof(float) * H, hipMemcpyHostToDevice, ctx->cur()));
     m->inv_fx = (float)(1.0 / (double)ctx->cfg.fx); m->inv_fy = (float)(1.0 / (double)ctx->cfg.fy);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->cur()));
     return CF_OK;
 }
 
 void cf_model_destroy(cf_model* m)
 {
     if (!m) return;
-    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipStreamSynchronize(m->ctx->cur());
     void* ptrs[] = {m->buf[0], m->buf[1], m->staged, m->flags, m->offsets, m->block_sums, m->d_count, m->d_nfresh, m->d_tmp2, m->records,
                     m->fresh, m->new_flags, m->new_offsets, m->owner, m->fb_rec, m->fb_raw, m->fb_filt, m->keys, m->index, m->vertConf,
                     m->colorTime, m->normRad, m->splat_image, m->splat_vertex, m->splat_normal, m->splat_time, m->fill_vertex,
@@ -188,16 +188,16 @@ static int adopt_count(cf_model* m)
 static int sync_count(cf_model* m)
 {
     cf_ctx* ctx = m->ctx;
-    HIPCHK(ctx, hipMemcpyAsync(m->h_counts, m->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(m->h_counts, m->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->cur()));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->cur()));
     return adopt_count(m);
 }
 // enqueue the read-back of the device count; until it lands count_host holds `upper_bound`
 static int post_count(cf_model* m, uint32_t upper_bound)
 {
     cf_ctx* ctx = m->ctx;
-    HIPCHK(ctx, hipMemcpyAsync(m->h_counts, m->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(m->count_event, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(m->h_counts, m->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->cur()));
+    HIPCHK(ctx, hipEventRecord(m->count_event, ctx->cur()));
     m->count_host = upper_bound;
     m->count_pending = true;
     return CF_OK;
@@ -226,7 +226,7 @@ static int exact_count(cf_model* m, uint32_t* out)
 int cf_model_initialise(cf_model* m, const uint8_t* rgba, const float* depth_raw, const float* depth_filt, int time, float maxDepth)
 {
     if (!m || !rgba || !depth_raw || !depth_filt) return CF_EINVAL;
-    cf_ctx* ctx = m->ctx; hipStream_t s = ctx->stream;
+    cf_ctx* ctx = m->ctx; hipStream_t s = ctx->cur();
     const int W = ctx->cfg.width, H = ctx->cfg.height; const long long N = (long long)W * H;
     if ((uint32_t)N > m->max_surfels) return CF_ENOMEM;
     const cf_cam cam = ctx_cam(ctx);
@@ -253,7 +253,7 @@ int cf_model_predict_indices(cf_model* m, const float pose[16], int time, float 
     inv44f(pose, t_inv);
     uint32_t nb = 0;
     if (int r = count_bound(m, &nb)) return r;
-    launch_predict_indices(ctx->stream, m->buf[m->target], m->d_count, nb, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
+    launch_predict_indices(ctx->cur(), m->buf[m->target], m->d_count, nb, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
                            maxDepth, time, timeDelta, m->keys, m->index, m->vertConf, m->colorTime, m->normRad);
     LAUNCHCHK(ctx);
     return CF_OK;
@@ -273,8 +273,8 @@ int cf_model_index_keys(cf_model* m, const float pose[16], int time, float maxDe
     inv44f(pose, t_inv);
     uint32_t nb = 0;
     if (int r = count_bound(m, &nb)) return r;
-    HIPCHK(ctx, hipMemsetAsync(keys_dev, 0xFF, sizeof(uint64_t) * (size_t)W * H, ctx->stream));
-    launch_index_keys(ctx->stream, m->buf[m->target], m->d_count, surfel_begin, surfel_end < nb ? surfel_end : nb, t_inv, ctx_cam(ctx), W, H, maxDepth,
+    HIPCHK(ctx, hipMemsetAsync(keys_dev, 0xFF, sizeof(uint64_t) * (size_t)W * H, ctx->cur()));
+    launch_index_keys(ctx->cur(), m->buf[m->target], m->d_count, surfel_begin, surfel_end < nb ? surfel_end : nb, t_inv, ctx_cam(ctx), W, H, maxDepth,
                       time, timeDelta, reinterpret_cast<unsigned long long*>(keys_dev));
     LAUNCHCHK(ctx);
     return CF_OK;
@@ -285,7 +285,7 @@ int cf_model_index_resolve(cf_model* m, const float pose[16], uint64_t* keys_dev
     cf_ctx* ctx = m->ctx;
     float t_inv[16];
     inv44f(pose, t_inv);
-    launch_index_resolve(ctx->stream, m->buf[m->target], t_inv, ctx->cfg.width, ctx->cfg.height, reinterpret_cast<unsigned long long*>(keys_dev),
+    launch_index_resolve(ctx->cur(), m->buf[m->target], t_inv, ctx->cfg.width, ctx->cfg.height, reinterpret_cast<unsigned long long*>(keys_dev),
                          m->index, m->vertConf, m->colorTime, m->normRad);
     LAUNCHCHK(ctx);
     return CF_OK;
@@ -304,7 +304,7 @@ int cf_model_predict_indices_sharded(cf_model* m, const float pose[16], int time
     if (int r = exact_count(m, &n)) return r;   // identical on every replica, unlike the asynchronous upper bound
     const uint32_t b = (uint32_t)(((uint64_t)n * (uint64_t)shard) / (uint64_t)nshards), e = (uint32_t)(((uint64_t)n * (uint64_t)(shard + 1)) / (uint64_t)nshards);
     if (int r = cf_model_index_keys(m, pose, time, maxDepth, timeDelta, b, e, reinterpret_cast<uint64_t*>(m->keys))) return r;
-    if (ctx->collective(ctx->collective_user, 1, m->keys, (uint64_t)ctx->cfg.width * ctx->cfg.height, (void*)ctx->stream) != 0) {
+    if (ctx->collective(ctx->collective_user, 1, m->keys, (uint64_t)ctx->cfg.width * ctx->cfg.height, (void*)ctx->cur()) != 0) {
         ctx->set_error("cf_model_predict_indices_sharded: the collective failed");
         return CF_ESTATE;
     }
@@ -319,7 +319,7 @@ int cf_model_combined_predict(cf_model* m, const float pose[16], float maxDepth,
     inv44f(pose, t_inv);
     uint32_t nb = 0;
     if (int r = count_bound(m, &nb)) return r;
-    launch_combined_predict(ctx->stream, m->buf[m->target], m->d_count, nb, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
+    launch_combined_predict(ctx->cur(), m->buf[m->target], m->d_count, nb, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
                             maxDepth, confThreshold, time, maxTime, timeDelta, m->rays, m->keys, m->splat_image, m->splat_vertex, m->splat_normal,
                             m->splat_time);
     LAUNCHCHK(ctx);
@@ -334,10 +334,10 @@ int cf_model_prefetch_fill_ratio(cf_model* m)
 {
     if (!m) return CF_EINVAL;
     cf_ctx* ctx = m->ctx;
-    launch_fill_ratio(ctx->stream, m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2);
+    launch_fill_ratio(ctx->cur(), m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2);
     LAUNCHCHK(ctx);
-    HIPCHK(ctx, hipMemcpyAsync(m->h_counts + 2, m->d_tmp2 + 2, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(m->ratio_event, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(m->h_counts + 2, m->d_tmp2 + 2, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->cur()));
+    HIPCHK(ctx, hipEventRecord(m->ratio_event, ctx->cur()));
     m->ratio_valid = true;
     return CF_OK;
 }
@@ -347,7 +347,7 @@ int cf_model_perform_fill_in(cf_model* m, const uint8_t* rgba, const float* dept
 {
     if (!m || !rgba || !depth_filt) return CF_EINVAL;
     cf_ctx* ctx = m->ctx;
-    launch_fill_in(ctx->stream, m->splat_vertex, m->splat_normal, m->splat_image, depth_filt, rgba, ctx->cfg.width, ctx->cfg.height, ctx_cam(ctx),
+    launch_fill_in(ctx->cur(), m->splat_vertex, m->splat_normal, m->splat_image, depth_filt, rgba, ctx->cfg.width, ctx->cfg.height, ctx_cam(ctx),
                    m->inv_fx, m->inv_fy, passthrough_geom, passthrough_rgb, m->fill_vertex, m->fill_normal, m->fill_image);
     LAUNCHCHK(ctx);
     return CF_OK;
@@ -361,10 +361,10 @@ int cf_model_requires_fill_in(cf_model* m, float ratio, int* out)
     if (m->ratio_valid) {
         HIPCHK(ctx, hipEventSynchronize(m->ratio_event));
     } else {
-        launch_fill_ratio(ctx->stream, m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2);
+        launch_fill_ratio(ctx->cur(), m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2);
         LAUNCHCHK(ctx);
-        HIPCHK(ctx, hipMemcpyAsync(m->h_counts + 2, m->d_tmp2 + 2, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(m->h_counts + 2, m->d_tmp2 + 2, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->cur()));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->cur()));
     }
     *out = ((float)m->h_counts[2] / (float)m->h_counts[3] < ratio) ? 1 : 0;
     return CF_OK;
@@ -375,7 +375,7 @@ int cf_model_fuse(cf_model* m, const float pose[16], int time, const uint8_t* rg
                   const float* depth_filt, float maxDepth, float weighting, int maskID)
 {
     if (!m || !pose || !rgba || !mask || !depth_raw || !depth_filt) return CF_EINVAL;
-    cf_ctx* ctx = m->ctx; hipStream_t s = ctx->stream;
+    cf_ctx* ctx = m->ctx; hipStream_t s = ctx->cur();
     const int W = ctx->cfg.width, H = ctx->cfg.height; const long long N = (long long)W * H;
     SurfelFuseArgs a;
     a.index = m->index; a.vertConf = m->vertConf; a.normRad = m->normRad; a.rgba = rgba; a.depth_raw = depth_raw; a.depth_filt = depth_filt;
@@ -399,7 +399,7 @@ int cf_model_clean(cf_model* m, const float pose[16], int time, float confThresh
                    const uint8_t* mask, int maskID, uint32_t* count_out)
 {
     if (!m || !pose || !depth_filt || !mask) return CF_EINVAL;
-    cf_ctx* ctx = m->ctx; hipStream_t s = ctx->stream;
+    cf_ctx* ctx = m->ctx; hipStream_t s = ctx->cur();
     const int W = ctx->cfg.width, H = ctx->cfg.height;
     uint32_t nb = 0;
     if (int r = count_bound(m, &nb)) return r;
@@ -427,8 +427,8 @@ int cf_model_download_map(cf_model* m, float* host_surfels, uint32_t capacity, u
     if (int r = exact_count(m, count)) return r;
     if (host_surfels) {
         const uint32_t n = m->count_host < capacity ? m->count_host : capacity;
-        HIPCHK(ctx, hipMemcpyAsync(host_surfels, m->buf[m->target], (size_t)n * 48, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(host_surfels, m->buf[m->target], (size_t)n * 48, hipMemcpyDeviceToHost, ctx->cur()));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->cur()));
     }
     return CF_OK;
 }
@@ -437,9 +437,9 @@ int cf_model_upload_map(cf_model* m, const float* host_surfels, uint32_t count)
 {
     if (!m || (!host_surfels && count) || count > m->max_surfels) return CF_EINVAL;
     cf_ctx* ctx = m->ctx;
-    if (count) HIPCHK(ctx, hipMemcpyAsync(m->buf[m->target], host_surfels, (size_t)count * 48, hipMemcpyHostToDevice, ctx->stream));
-    launch_set_count(ctx->stream, m->d_count, count);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (count) HIPCHK(ctx, hipMemcpyAsync(m->buf[m->target], host_surfels, (size_t)count * 48, hipMemcpyHostToDevice, ctx->cur()));
+    launch_set_count(ctx->cur(), m->d_count, count);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->cur()));
     m->count_host = count; m->count_pending = false;
     return CF_OK;
 }

@@ -5,9 +5,16 @@
 
 #include "cf_kernels.h"
 
+struct cf_ctx;
+// cf_thread_lane: a helper thread of the host enqueues one model's passes on a lane while the owning thread does the same for
+// another model; the binding is per thread, so the context's own `stream` field is never written from two threads
+struct cf_thread_binding { const cf_ctx* ctx = nullptr; hipStream_t stream = nullptr; };
+extern thread_local cf_thread_binding cf_tls_binding;
+
 struct cf_ctx {
     cf_config cfg{};
     hipStream_t stream = nullptr;
+    hipStream_t cur() const { return cf_tls_binding.ctx == this ? cf_tls_binding.stream : stream; }  // stream of the calling thread
     hipStream_t own_stream = nullptr;
     std::string last_error;
     cf::IcpLaunch icp_launch{256, 1};

@@ -9,7 +9,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <exception>
+#include <functional>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 namespace cofusion {
 
@@ -621,6 +626,77 @@ static cf_ctx* make_ctx(const CoFusion::Config& c)
     return ctx;
 }
 
+// Helper threads for the per-model launch chains.  run(n, fn) calls fn(0..n-1), each index once, from the helpers and from the
+// calling thread, and returns when all are done; the first exception is re-thrown on the caller.
+class EnqueuePool {
+public:
+    explicit EnqueuePool(int helpers)
+    {
+        for (int i = 0; i < helpers; i++) workers.emplace_back([this] { loop(); });
+    }
+    ~EnqueuePool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        wake.notify_all();
+        for (auto& w : workers) w.join();
+    }
+    int helpers() const { return (int)workers.size(); }
+    void run(int count, const std::function<void(int)>& fn)
+    {
+        uint64_t g;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = &fn; total = count; next = 0; done = 0; error = nullptr; g = ++generation;
+        }
+        wake.notify_all();
+        work(g);
+        std::unique_lock<std::mutex> lk(mu);
+        finished.wait(lk, [&] { return done == total; });
+        job = nullptr;
+        if (error) { std::exception_ptr e = error; error = nullptr; lk.unlock(); std::rethrow_exception(e); }
+    }
+
+private:
+    void work(uint64_t g)
+    {
+        for (;;) {
+            int i;
+            const std::function<void(int)>* fn;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (g != generation || next >= total) return;
+                i = next++; fn = job;
+            }
+            std::exception_ptr e;
+            try { (*fn)(i); } catch (...) { e = std::current_exception(); }
+            std::lock_guard<std::mutex> lk(mu);
+            if (e && !error) error = e;
+            if (++done == total) finished.notify_all();
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                wake.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+            }
+            work(seen);
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable wake, finished;
+    const std::function<void(int)>* job = nullptr;
+    std::exception_ptr error;
+    uint64_t generation = 0;
+    int total = 0, next = 0, done = 0;
+    bool stop = false;
+};
+
 CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
 {
     dist.rank = cfg.rank; dist.world = cfg.world < 1 ? 1 : cfg.world;
@@ -653,10 +729,14 @@ CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
     }
     globalModel->loggingPoses = cfg.enablePoseLogging;
     models.push_back(globalModel);
+    int helpers = cfg.enqueueThreads;
+    if (const char* e = std::getenv("CF_ENQUEUE_THREADS")) helpers = std::atoi(e);
+    if (helpers > 0 && useLanes) pool = std::make_shared<EnqueuePool>(helpers > 7 ? 7 : helpers);
 }
 
 CoFusion::~CoFusion()
 {
+    pool.reset();
     models.clear(); inactiveModels.clear(); newModel.reset(); globalModel.reset();
     cf_free(ctx, depth_dev);
     for (int b = 0; b < 2; b++) { cf_free(ctx, depthFilteredBuf[b]); cf_free(ctx, depthPyr1Buf[b]); cf_free(ctx, depthPyr2Buf[b]); }
@@ -714,6 +794,60 @@ void CoFusion::predict(bool lastOfFrame)
         model->performFillIn(curRgba, depthFiltered_dev, cfg.frameToFrameRGB, lost);
     }
     if (overlap) check(ctx, cf_join(ctx), "cf_join");
+}
+
+// One model's share of the frame's second half: CoFusion.cpp:316-330 (index map, fuse, index map, clean) and :350 + :533-545
+// (end-of-frame prediction and fill-in).  Nothing here reads another model's buffers.
+void CoFusion::modelPasses(Model& model, bool fuse, float weightMultiplier, bool lost)
+{
+    if (fuse) {
+        model.predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
+        model.fuse(tick, curRgba, mask_dev, curDepth, depthFiltered_dev, maxDepthProcessed, weightMultiplier);
+        model.predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
+        model.clean(tick, cfg.timeDelta, maxDepthProcessed, depthFiltered_dev, mask_dev, cfg.outlierCoefficient);
+    }
+    model.combinedPredict(maxDepthProcessed, tick, tick, cfg.timeDelta);
+    model.prefetchFillRatio();  // requiresFillIn() of the next frame asks about THIS prediction
+    model.performFillIn(curRgba, depthFiltered_dev, cfg.frameToFrameRGB, lost);
+}
+// The reference runs these passes in six loops over the models (CoFusion.cpp:316-330, :533-545).  The passes of different models
+// touch disjoint buffers (shared inputs: frame, mask), so each model's whole chain goes to its own stream, without a barrier
+// between fusion and prediction; with Config::enqueueThreads the chains are also ENQUEUED by different host threads (~19 launches
+// per model: worth it when the host's launch rate is the limit).
+void CoFusion::fuseAndPredict(bool fuse, float weightMultiplier, bool lost)
+{
+    const bool overlap = models.size() > 1 && useLanes;
+    if (!overlap) {
+        for (auto& model : models) modelPasses(*model, fuse, weightMultiplier, lost);
+        return;
+    }
+    std::vector<Model*> list;
+    for (auto& model : models) if (model->isOwned()) list.push_back(model.get());
+    const int n = (int)list.size();
+    // a split background talks to the other ranks from inside its passes (the caller's collective): keep that on this thread
+    const bool threaded = pool && n > 1 && !dist.shardBackground;
+    const int lanes = 6;  // lanes 6 and 7 belong to the frame head and the superpixel pass
+    if (!threaded) {
+        for (int i = 0; i < n; i++) {
+            check(ctx, cf_fork(ctx, i % lanes), "cf_fork");
+            modelPasses(*list[i], fuse, weightMultiplier, lost);
+        }
+        check(ctx, cf_join(ctx), "cf_join");
+        return;
+    }
+    for (int i = 0; i < n && i < lanes; i++) check(ctx, cf_fork(ctx, i), "cf_fork");
+    check(ctx, cf_main(ctx), "cf_main");
+    struct Unbind { cf_ctx* c; ~Unbind() { cf_thread_lane(c, -1); } };
+    std::exception_ptr failed;
+    try {
+        pool->run(n, [&](int i) {
+            Unbind u{ctx};
+            check(ctx, cf_thread_lane(ctx, i % lanes), "cf_thread_lane");
+            modelPasses(*list[i], fuse, weightMultiplier, lost);
+        });
+    } catch (...) { failed = std::current_exception(); }
+    check(ctx, cf_join(ctx), "cf_join");
+    if (failed) std::rethrow_exception(failed);
 }
 
 void CoFusion::trackModels(const float* const depthPyr[3])
@@ -824,6 +958,7 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
     if (willTrack) check(ctx, cf_depth_pyramid(ctx, depthFiltered_dev, cfg.width, cfg.height, depthPyr1, depthPyr2), "generateCUDATextures");
     if (headAside) check(ctx, cf_join(ctx), "cf_join");
 
+    bool fuseNow = false;
     if (tick == 1) {
         globalModel->initialise(curRgba, curDepth, depthFiltered_dev, tick, maxDepthProcessed);
         if (globalModel->isOwned()) check(ctx, cf_odom_init_first_rgb(globalModel->getFrameOdometry(), curRgba), "initFirstRGB");
@@ -915,23 +1050,12 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
         // and clean work on the index maps, the segmentation read the PREVIOUS prediction before this point, and the prediction at the
         // end of the frame overwrites all of it -- in the reference it only feeds the GUI.  Off by default (Config::midFramePredict).
         if (cfg.midFramePredict) { PhaseTimer t(PhaseTimes::Predict); predict(); }
-        if (!cfg.rgbOnly && trackingOk && !lost) {
-            PhaseTimer t(PhaseTimes::Fuse);
-            // CoFusion.cpp:316-330 runs the four passes model by model in four loops; the passes of different models touch
-            // disjoint buffers (shared inputs: frame, mask), so each model's chain goes to its own stream and the chains overlap
-            const bool overlap = models.size() > 1 && useLanes;
-            int lane = 0;
-            for (auto& model : models) {
-                if (overlap) check(ctx, cf_fork(ctx, lane++), "cf_fork");
-                model->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
-                model->fuse(tick, curRgba, mask_dev, curDepth, depthFiltered_dev, maxDepthProcessed, weightMultiplier);
-                model->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
-                model->clean(tick, cfg.timeDelta, maxDepthProcessed, depthFiltered_dev, mask_dev, cfg.outlierCoefficient);
-            }
-            if (overlap) check(ctx, cf_join(ctx), "cf_join");
-        }
+        fuseNow = !cfg.rgbOnly && trackingOk && !lost;
     }
-    { PhaseTimer t(PhaseTimes::Predict); predict(true); }
+    {
+        PhaseTimer t(fuseNow ? PhaseTimes::Fuse : PhaseTimes::Predict);
+        fuseAndPredict(fuseNow, weightMultiplier, lost);
+    }
     check(ctx, cf_mark(ctx, (int)b), "cf_mark");  // everything that reads this frame's filtered depth is enqueued
     phaseTimes().frames++;
     if (!lost) tick++;

@@ -35,6 +35,7 @@ void cofusion_default_config(cofusion_config* c)
     c->device_frames_complete = d.deviceFramesComplete;
     c->mid_frame_predict = d.midFramePredict;
     c->shard_background = d.shardBackground;
+    c->enqueue_threads = d.enqueueThreads;
 }
 
 int cofusion_create(const cofusion_config* c, cofusion_handle** out)
@@ -52,6 +53,7 @@ int cofusion_create(const cofusion_config* c, cofusion_handle** out)
     d.deviceFramesComplete = c->device_frames_complete != 0;
     d.midFramePredict = c->mid_frame_predict != 0;
     d.shardBackground = c->shard_background != 0;
+    d.enqueueThreads = c->enqueue_threads < 0 ? 0 : c->enqueue_threads;
     GUARD(*out = new cofusion_handle{new CoFusion(d)});
     return 0;
 }

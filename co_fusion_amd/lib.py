@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CF_HIP_LIB") or os.path.join(_HERE, "lib", "libcofusi
 
 # every symbol include/cofusion_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "cf_create", "cf_destroy", "cf_last_error", "cf_set_stream", "cf_use_own_stream", "cf_get_stream", "cf_synchronize", "cf_fork", "cf_main", "cf_join", "cf_mark", "cf_event_wait_host", "cf_fork_after", "cf_malloc",
+    "cf_create", "cf_destroy", "cf_last_error", "cf_set_stream", "cf_use_own_stream", "cf_get_stream", "cf_synchronize", "cf_fork", "cf_main", "cf_join", "cf_thread_lane", "cf_mark", "cf_event_wait_host", "cf_fork_after", "cf_malloc",
     "cf_free", "cf_memcpy_h2d", "cf_memcpy_d2h", "cf_malloc_host", "cf_free_host", "cf_memcpy_h2d_async", "cf_memcpy_d2h_async", "cf_memcpy_d2d_async", "cf_rgb_to_rgba", "cf_create_vmap", "cf_create_nmap", "cf_copy_maps", "cf_resize_map",
     "cf_transform_maps", "cf_vertices_to_depth", "cf_pyrdown_gauss_f32", "cf_pyrdown_gauss_u8",
     "cf_rgba_to_intensity", "cf_sobel", "cf_project_cloud", "cf_icp_step", "cf_icp_step_band", "cf_rgb_residual", "cf_rgb_step",

@@ -32,6 +32,8 @@ typedef struct {
                                  * share of its index-map rasterisation (surfel range, MIN all-reduce of the z-keys) and of its ICP
                                  * reduction (image rows, SUM all-reduce of the accumulators after every launch of the Gauss-Newton
                                  * loop); needs cf_set_collective on the context (cofusion_context).  Default 0. */
+    int enqueue_threads;        /* helper threads that enqueue the per-model surfel passes (one model's launch chain each) beside the calling
+                                 * thread; 0 = none (default).  Results do not depend on it. */
 } cofusion_config;
 
 void cofusion_default_config(cofusion_config *cfg);

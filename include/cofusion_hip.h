@@ -107,6 +107,11 @@ int cf_synchronize(cf_ctx *ctx);
 int cf_fork(cf_ctx *ctx, int lane);
 int cf_main(cf_ctx *ctx);
 int cf_join(cf_ctx *ctx);
+/* Enqueue from several host threads: the owning thread forks the lanes (cf_fork(lane) for each, then cf_main), helper threads
+ * call cf_thread_lane(ctx, lane) and then issue the cf_model_* calls of ONE model each -- those go to the lane, the context's
+ * current stream is untouched -- and unbind with lane < 0; the owning thread waits for the helpers and calls cf_join.  Only the
+ * cf_model_* entry points honour the binding. */
+int cf_thread_lane(cf_ctx *ctx, int lane);
 /* cf_mark(slot 0..3) remembers the current point of the stream; cf_fork_after(lane, slot) routes the following calls to `lane`
  * ordered after that point only (slot < 0: after nothing): for work that does not depend on what the stream still has queued,
  * e.g. filtering the next frame while the previous frame's fusion passes run.  cf_join orders the stream after the lane. */
