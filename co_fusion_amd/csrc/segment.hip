@@ -340,12 +340,20 @@ __device__ __forceinline__ float wave_sequential_sum(float init, int n, int lane
     for (int base = 0; base < n; base += 64) {
         const int nj = base + 64 + lane;
         const float nxt = nj < n ? term(nj) : 0.f;
-        const int m = min(64, n - base);
-        if (m == 64) {
+        // lanes past n hold 0.0f, and a step whose 64 terms are all zero changes nothing
+        if (__ballot(cur != 0.f) != 0ull) {
 #pragma unroll
-            for (int j = 0; j < 64; j++) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), j));
-        } else {
-            for (int j = 0; j < m; j++) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), j));
+            for (int g = 0; g < 64; g += 16) {
+                // sixteen independent lane reads into scalar registers first, THEN the dependent chain of additions: interleaved, every
+                // addition waits for its own v_readlane (a VALU-writes-SGPR hazard per term)
+                float t[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) t[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), g + j));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 16; j++) sum += t[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         cur = nxt;
     }
@@ -360,17 +368,19 @@ __device__ __forceinline__ void wave_sequential_sum2(float& sa, float& sb, int n
     for (int base = 0; base < n; base += 64) {
         const int nj = base + 64 + lane;
         const float na = nj < n ? term_a(nj) : 0.f, nb = nj < n ? term_b(nj) : 0.f;
-        const int m = min(64, n - base);
-        if (m == 64) {
+        if (__ballot(ca != 0.f || cb != 0.f) != 0ull) {
 #pragma unroll
-            for (int j = 0; j < 64; j++) {
-                sa += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca), j));
-                sb += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb), j));
-            }
-        } else {
-            for (int j = 0; j < m; j++) {
-                sa += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca), j));
-                sb += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb), j));
+            for (int g = 0; g < 64; g += 8) {
+                float ta[8], tb[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    ta[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca), g + j));
+                    tb[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb), g + j));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; j++) { sa += ta[j]; sb += tb[j]; }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         ca = na; cb = nb;
@@ -527,11 +537,12 @@ struct SegPostArgs {
 // One workgroup: the label image has K = 1200 superpixels (4800 at 1280x960, the largest supported); labels, union-find parents and
 // component numbers live in LDS, the sequential sums of the statistics run one wave per model (wave_sequential_sum).
 constexpr int kSegMaxK = 4800;
+constexpr int kCcLds = 512;   // components whose statistics fit in LDS (a frame has tens)
 __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
 {
     const int K = a.K, gx = a.gx, L = a.L, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int n_md = a.n_models + (a.allow_new ? 1 : 0);
-    __shared__ int s_changed, s_ncc, s_min_label;
+    __shared__ int s_changed, s_min_label;
     __shared__ int s_scan[1024];
     __shared__ int s_id2idx[256];
     __shared__ int s_box[kMaxL + 1][4];   // top, right, bottom, left per model entry (full-resolution pixels after mapToHigh)
@@ -541,7 +552,8 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
     __shared__ unsigned char map[kSegMaxK];
     __shared__ int parent[kSegMaxK];
     __shared__ int comp[kSegMaxK];
-    int *c_label = a.cc, *c_size = a.cc + K, *c_top = a.cc + 2 * K, *c_right = a.cc + 3 * K, *c_bottom = a.cc + 4 * K, *c_left = a.cc + 5 * K;
+    __shared__ int s_cc[6 * kCcLds];
+    if (tid == 0) s_min_label = 256;
     // 1. label with the highest marginal (first maximum), as model id
     for (int k = tid; k < K; k += T) {
         int m = 0; float best = a.Q[(size_t)k * L];
@@ -580,36 +592,57 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
         __syncthreads();
         if (!s_changed) break;
     }
-    // 3. number the roots in index order (exclusive scan of the root flags)
+    // 3. number the roots in index order (exclusive scan of the root flags); a root also files its label under its number
     const int per = (K + T - 1) / T;
-    {
-        int cnt = 0;
-        for (int k = tid * per; k < min(K, (tid + 1) * per); k++) cnt += parent[k] == k;
-        s_scan[tid] = cnt;
+    int cnt3 = 0;
+    for (int k = tid * per; k < min(K, (tid + 1) * per); k++) cnt3 += parent[k] == k;
+    s_scan[tid] = cnt3;
+    __syncthreads();
+    for (int o = 1; o < T; o <<= 1) {
+        const int v = tid >= o ? s_scan[tid - o] : 0;
         __syncthreads();
-        for (int o = 1; o < T; o <<= 1) {
-            const int v = tid >= o ? s_scan[tid - o] : 0;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
-        }
-        int base = s_scan[tid] - cnt;
-        for (int k = tid * per; k < min(K, (tid + 1) * per); k++)
-            if (parent[k] == k) comp[k] = base++;
-        if (tid == T - 1) s_ncc = s_scan[T - 1];
+        s_scan[tid] += v;
         __syncthreads();
     }
-    const int ncc = s_ncc;
-    for (int k = tid; k < K; k += T) if (parent[k] != k) comp[k] = comp[parent[k]];  // roots wrote their own entry; read-only for them
+    const int ncc = s_scan[T - 1];
+    // per-component label, size, top, right, bottom, left: in LDS unless the label image is unusually fragmented
+    int* const ccb = ncc <= kCcLds ? s_cc : a.cc;
+    const int ccs = ncc <= kCcLds ? kCcLds : K;
+    int *c_label = ccb, *c_size = ccb + ccs, *c_top = ccb + 2 * ccs, *c_right = ccb + 3 * ccs, *c_bottom = ccb + 4 * ccs, *c_left = ccb + 5 * ccs;
+    {
+        int base = s_scan[tid] - cnt3;
+        for (int k = tid * per; k < min(K, (tid + 1) * per); k++)
+            if (parent[k] == k) { comp[k] = base; c_label[base] = map[k]; atomicMin(&s_min_label, (int)map[k]); base++; }
+    }
     for (int i = tid; i < ncc; i += T) { c_size[i] = 0; c_top[i] = 2147483647; c_right[i] = 0; c_bottom[i] = 0; c_left[i] = 2147483647; }
-    if (tid == 0) s_min_label = 256;
     __syncthreads();
-    // 4. component statistics
-    for (int k = tid; k < K; k += T) {
-        const int c = comp[k], x = k % gx, y = k / gx;
-        atomicAdd(&c_size[c], 1);
-        atomicMin(&c_top[c], y); atomicMax(&c_bottom[c], y); atomicMin(&c_left[c], x); atomicMax(&c_right[c], x);
-        if (parent[k] == k) { c_label[c] = map[k]; atomicMin(&s_min_label, (int)map[k]); }
+    for (int k = tid; k < K; k += T) if (parent[k] != k) comp[k] = comp[parent[k]];  // roots wrote their own entry; read-only for them
+    __syncthreads();
+    // 4. component statistics.  A wave first combines the lanes that belong to the same component (usually one or two per wave), so
+    //    that one lane per (wave, component) touches the shared counters: a thousand atomics on the background's five words otherwise
+    //    queue up behind each other
+    for (int kb = 0; kb < K; kb += T) {
+        const int k = kb + tid;
+        const bool in = k < K;
+        const int c = in ? comp[k] : -1, x = in ? k % gx : 0, y = in ? k / gx : 0;
+        unsigned long long todo = __ballot(in);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const int c0 = __builtin_amdgcn_readlane(c, leader);
+            const bool member = in && c == c0;
+            const unsigned long long grp = __ballot(member);
+            int ymin = member ? y : 2147483647, ymax = member ? y : 0, xmin = member ? x : 2147483647, xmax = member ? x : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                ymin = min(ymin, __shfl_xor(ymin, o, 64)); ymax = max(ymax, __shfl_xor(ymax, o, 64));
+                xmin = min(xmin, __shfl_xor(xmin, o, 64)); xmax = max(xmax, __shfl_xor(xmax, o, 64));
+            }
+            if (lane == leader) {
+                atomicAdd(&c_size[c0], (int)__popcll(grp));
+                atomicMin(&c_top[c0], ymin); atomicMax(&c_bottom[c0], ymax); atomicMin(&c_left[c0], xmin); atomicMax(&c_right[c0], xmax);
+            }
+            todo &= ~grp;
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -665,12 +698,13 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
     __threadfence_block();
     __syncthreads();
     // 9. final low-resolution label map
-    for (int k = tid; k < K; k += T) { const unsigned char v = (unsigned char)c_label[comp[k]]; map[k] = v; a.low_map[k] = v; }
+    float* const s_depth = reinterpret_cast<float*>(parent);   // the union-find parents are dead: their storage holds the low-resolution depths
+    for (int k = tid; k < K; k += T) { const unsigned char v = (unsigned char)c_label[comp[k]]; map[k] = v; a.low_map[k] = v; s_depth[k] = a.low_depth[k]; }
     __syncthreads();
     // 10. depth statistics with one trimming pass (:570-621) and super-pixel counts (:624-627): sequential f32 sums in index order,
     //     one wave per model entry
     for (int ix = wave; ix < n_md; ix += (T >> 6)) {
-        const float* lowDepth = a.low_depth;
+        const float* lowDepth = s_depth;
         auto mine = [&](int i) { const unsigned char v = map[i]; return v != 255 && s_id2idx[v] == ix; };
         unsigned cnt = 0;
         for (int i = lane; i < K; i += 64) cnt += mine(i) ? 1u : 0u;
