@@ -522,7 +522,7 @@ int cf_odom_create(cf_ctx* ctx, cf_odom** out)
     }
     if (int r = dmalloc(ctx, &od->icp_acc, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &od->rgb_acc, (size_t)kGroups * 32)) return r;
-    if (int r = dmalloc(ctx, &od->occ, ((size_t)(W >> 2) * (H >> 2) + 63) / 64 * 2)) return r;
+    if (int r = dmalloc(ctx, &od->occ, ((size_t)(W >> 2) * (H >> 2) + 3) / 4 * 4)) return r;
     for (int k = 0; k < cf_ctx::kStateSlots && od->slot < 0; k++)
         if (!ctx->slot_used[k]) { ctx->slot_used[k] = true; od->slot = k; }
     if (od->slot >= 0) {
@@ -622,7 +622,7 @@ static int populate_rgbd(cf_odom* od, const uint8_t* rgba, float* const* depths,
     return CF_OK;
 }
 int cf_odom_init_rgb_model(cf_odom* od, const uint8_t* pred_rgba) { if (!od || !pred_rgba) return CF_EINVAL; return populate_rgbd(od, pred_rgba, od->lastDepth, od->lastImage); }
-int cf_odom_init_rgb(cf_odom* od, const uint8_t* rgba) { if (!od || !rgba) return CF_EINVAL; return populate_rgbd(od, rgba, od->nextDepth, od->nextImage); }
+int cf_odom_init_rgb(cf_odom* od, const uint8_t* rgba) { if (!od || !rgba) return CF_EINVAL; od->next_depth_is_last = false; return populate_rgbd(od, rgba, od->nextDepth, od->nextImage); }
 
 // initICPModel + initRGBModel + initRGB of `n` trackers in four launches (one grid row per tracker / chain) instead of
 // seven per tracker: what CoFusion::trackModels issues for every active model of a frame.
@@ -650,6 +650,9 @@ int cf_odom_init_models_batch(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
             mb.m[k] = model_maps_args(od, pred_v4[base + k], pred_n4[base + k], poses[base + k]);
             rb.c[2 * k] = rgbd_chain(od, pred_rgba[base + k], od->lastDepth, od->lastImage);   // initRGBModel
             rb.c[2 * k + 1] = rgbd_chain(od, frame_rgba, od->nextDepth, od->nextImage);        // initRGB
+            // ... whose depth pyramid would be a second copy of the first chain's (same source, same cutoff): intensity only
+            for (int i = 0; i < CF_NUM_PYRS; ++i) rb.c[2 * k + 1].depth[i] = nullptr;
+            od->next_depth_is_last = true;
         }
         launch_model_maps(s, mb, nb);
         launch_rgbd_pyramids(s, rb, 2 * nb, W, H, ods[base]->maxDepthRGB);
@@ -745,7 +748,7 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
         for (int i = 0; i < CF_NUM_PYRS; i++) {
             const int div = 1 << i;
             const cf_cam il = {intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
-            a.nextImage[i] = od->nextImage[i]; a.nextDepth[i] = od->nextDepth[i]; a.lastDepth[i] = od->lastDepth[i];
+            a.nextImage[i] = od->nextImage[i]; a.nextDepth[i] = od->next_depth(i); a.lastDepth[i] = od->lastDepth[i];
             a.dIdx[i] = od->dIdx[i]; a.dIdy[i] = od->dIdy[i]; a.cand[i] = od->cand[i]; a.cloud[i] = od->cloud[i];
             a.minScale[i] = (float)(pow((double)od->minGrad[i], 2.0) / pow((double)od->sobelScale, 2.0));
             a.fx_inv[i] = 1.0f / il.fx; a.fy_inv[i] = 1.0f / il.fy; a.cx[i] = il.cx; a.cy[i] = il.cy;
@@ -757,7 +760,7 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
         h->vmap_curr[i] = od->ext_vmap_curr[i] ? od->ext_vmap_curr[i] : od->vmap_curr[i];
         h->nmap_curr[i] = od->ext_nmap_curr[i] ? od->ext_nmap_curr[i] : od->nmap_curr[i];
         h->vmap_g_prev[i] = od->vmap_g_prev[i]; h->nmap_g_prev[i] = od->nmap_g_prev[i];
-        h->lastDepth[i] = od->lastDepth[i]; h->nextDepth[i] = od->nextDepth[i];
+        h->lastDepth[i] = od->lastDepth[i]; h->nextDepth[i] = od->next_depth(i);
         h->lastImage[i] = od->lastImage[i]; h->nextImage[i] = od->nextImage[i]; h->lastNextImage[i] = od->lastNextImage[i];
         h->dIdx[i] = od->dIdx[i]; h->dIdy[i] = od->dIdy[i]; h->cloud[i] = od->cloud[i]; h->corres[i] = od->corres[i];
         h->cand[i] = od->cand[i];
@@ -984,7 +987,7 @@ int cf_odom_buffer(cf_odom* od, int which, int level, void** dptr, uint64_t* byt
         case 2: p = od->vmap_g_prev[level]; b = n * 12; break;
         case 3: p = od->nmap_g_prev[level]; b = n * 12; break;
         case 4: p = od->lastDepth[level]; b = n * 4; break;
-        case 5: p = od->nextDepth[level]; b = n * 4; break;
+        case 5: p = od->next_depth(level); b = n * 4; break;
         case 6: p = od->lastImage[level]; b = n; break;
         case 7: p = od->nextImage[level]; b = n; break;
         case 8: p = od->lastNextImage[level]; b = n; break;

@@ -76,6 +76,10 @@ struct cf_odom {
     const float* ext_nmap_curr[3]{};
     float* lastDepth[3]{};
     float* nextDepth[3]{};
+    // cf_odom_init_models_batch: initRGB takes its depth from the same snapshot of the predicted vertex map as initRGBModel
+    // (RGBDOdometry.cpp:179), so the "next" depth pyramid IS the "last" one; the batch path builds it once and reads lastDepth for both
+    bool next_depth_is_last = false;
+    float* next_depth(int i) const { return next_depth_is_last ? lastDepth[i] : nextDepth[i]; }
     uint8_t* lastImage[3]{};
     uint8_t* nextImage[3]{};
     uint8_t* lastNextImage[3]{};
@@ -84,8 +88,8 @@ struct cf_odom {
     float* cloud[3]{};
     cf_dataterm* corres[3]{};
     uint8_t* cand[3]{};
-    unsigned* occ = nullptr;         // occupancy bitmap of the model maps (written by model_maps_kernel)
-    bool occ_valid = false;          // the bitmap describes the current model maps
+    unsigned char* occ = nullptr;    // occupancy map of the model maps (written by model_maps_kernel)
+    bool occ_valid = false;          // the map describes the current model maps
     bool use_occ = false;
     int band_begin = 0, band_end = 0;  // cf_odom_set_band: this rank's rows of the model's reductions (0, 0: all rows)
     bool band_counts = true;           // this rank adds the residual pass's count / sigma (exactly one rank of a split does)            // cf_odom_set_culling: worth it for models that cover a small part of the image

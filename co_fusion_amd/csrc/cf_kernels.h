@@ -85,7 +85,7 @@ struct ModelMapsArgs {
     float* vmap[3]; float* nmap[3];
     int cols, rows;
     float R[9], t[3];
-    unsigned* occ;                               // nullable: occupancy bitmap of the prediction (1 bit per 4x4 block)
+    unsigned char* occ;                          // nullable: occupancy map of the prediction (1 byte per 4x4 block)
 };
 // batches: one grid row per tracked model (<= kPrepBatch), so that a frame with several models still issues each
 // preparation kernel once
@@ -113,7 +113,7 @@ struct IcpModelArgs {
     unsigned long long* acc;            // [kGroups][32] grouped accumulators
     float* err;                         // nullable ICP error surface [rows*cols]
     unsigned long long* rgb_acc;        // the model's RGB accumulators (used by the solve kernel's arguments)
-    const unsigned* occ;                // nullable: occupancy bitmap of the model maps (model_maps_kernel), 1 bit per 4x4 level-0 block
+    const unsigned char* occ;           // nullable: occupancy map of the model maps (model_maps_kernel), 1 byte per 4x4 level-0 block
     int row_begin, row_end;             // row band of THIS model's reduction (row_end == 0: all rows): its share when the model's
                                         // reduction is split over GPUs
 };
@@ -156,7 +156,7 @@ struct IcpArgs {
     cf_cam intr;                        // already divided by 2^level
     float distThres, angleThres;
     float angleSqLt, distSqLe;          // exact radicand bounds of the two gates (sqrt_gate_lt / sqrt_gate_le)
-    int occ_w, occ_shift;               // bitmap row length (level-0 cols / 4) and 2 - level
+    int occ_w, occ_shift;               // occupancy row length (level-0 cols / 4) and 2 - level
     int flags;                          // bit0: write the error surface
     int row_begin, row_end;             // row band to reduce; row_end == 0: all rows
 };

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(kBlock) rgbd_base_kernel(const RgbdBatch b, in
     const int nb = (N + kBlock - 1) / kBlock;
     if ((int)blockIdx.x < nb) {  // verticesToDepthKernel, cudafuncs.cu:602-613
         const int i = blockIdx.x * kBlock + threadIdx.x;
-        if (i >= N) return;
+        if (i >= N || !c.depth[0]) return;  // (a chain without a depth pyramid: the intensity half only)
         const float z = v4[i].z;
         c.depth[0][i] = (z > cutoff || z <= 0) ? qnan() : z;
     } else {                     // bgr2IntensityKernel, cudafuncs.cu:626-639
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(kBlock) rgbd_pyrdown_kernel(const RgbdBatch b,
     const int n = (scols / 2) * (srows / 2), nb = (n + kBlock - 1) / kBlock;
     if ((int)blockIdx.x < nb) {
         const int i = blockIdx.x * kBlock + threadIdx.x;
-        if (i < n) pyrdown_f32_px(c.depth[level], scols, srows, c.depth[level + 1], i);
+        if (i < n && c.depth[level]) pyrdown_f32_px(c.depth[level], scols, srows, c.depth[level + 1], i);
     } else {
         const int i = (blockIdx.x - nb) * kBlock + threadIdx.x;
         if (i < n) pyrdown_u8_px(c.image[level], scols, srows, c.image[level + 1], i);
@@ -507,11 +507,70 @@ __global__ void __launch_bounds__(64) model_maps_kernel(const ModelMapsBatch b)
     const int i2 = Y2 * c2 + X2;
     emit_map(a.vmap[2], i2, N2, v2, R, tr, true);
     emit_map(a.nmap[2], i2, N2, n2, R, tr, false);
-    // occupancy bitmap of the prediction, one bit per 4x4 block (bit t of word t/32): the ICP reduction skips the gathers of
-    // pixels that project into an empty block (every level's model-map pixel inside such a block is invalid)
-    if (a.occ) {
-        const unsigned long long bits = __ballot(any_valid);
-        if (threadIdx.x == 0) { a.occ[2 * blockIdx.x] = (unsigned)bits; a.occ[2 * blockIdx.x + 1] = (unsigned)(bits >> 32); }
+    // occupancy map of the prediction, one byte per 4x4 block: the ICP reduction skips the gathers of pixels that project into an
+    // empty block (every level's model-map pixel inside such a block is invalid)
+    if (a.occ) a.occ[t] = any_valid ? 1 : 0;
+}
+
+// The same pass with one lane per level-0 pixel: a wave owns a 16 x 4 tile (rows of 16 float4 = 256 contiguous bytes per load, 64
+// contiguous bytes per planar store), the 2x2 averages of levels 1 and 2 take their four sources from the neighbouring lanes in
+// the order the reference adds them (resize4 is the same function).  16x the parallelism of model_maps_kernel, whose lanes walk
+// a 4x4 block each.  Needs cols % 16 == 0 and rows % 4 == 0.
+__device__ __forceinline__ MapVal lane_mapval(const MapVal& m, int src_lane)
+{
+    MapVal o;
+    o.p.x = __shfl(m.p.x, src_lane, 64); o.p.y = __shfl(m.p.y, src_lane, 64); o.p.z = __shfl(m.p.z, src_lane, 64);
+    o.have = __shfl((int)m.have, src_lane, 64) != 0;
+    return o;
+}
+__global__ void __launch_bounds__(256) model_maps_tiled_kernel(const ModelMapsBatch b)
+{
+    const ModelMapsArgs& a = b.m[blockIdx.y];  // one tracked model per grid row
+    const int cols = a.cols, rows = a.rows, N0 = cols * rows, c1 = cols >> 1, c2 = cols >> 2, N1 = N0 >> 2, N2 = N0 >> 4;
+    const int lane = threadIdx.x & 63, lx = lane & 15, ly = lane >> 4;
+    const int tiles_x = cols >> 4;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= tiles_x * (rows >> 2)) return;  // whole waves leave
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x = tx * 16 + lx, y = ty * 4 + ly, i0 = y * cols + x;
+    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(a.pred_v4);
+    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(a.pred_n4);
+    float4* __restrict__ snap = reinterpret_cast<float4*>(a.snapshot);
+    m33 R; for (int k = 0; k < 9; k++) R.m[k] = a.R[k];
+    const f3 tr = {a.t[0], a.t[1], a.t[2]};
+    const float4 vs = v4[i0], ns = n4[i0];
+    snap[i0] = vs;
+    MapVal v0, n0;
+    v0.have = true; n0.have = true;
+    const bool valid = !(vs.z == 0);
+    if (valid) { v0.p = f3{vs.x, vs.y, vs.z}; n0.p = f3{ns.x, ns.y, ns.z}; }
+    else { v0.p = f3{qnan(), qnan(), qnan()}; n0.p = v0.p; }
+    emit_map(a.vmap[0], i0, N0, v0, R, tr, true);
+    emit_map(a.nmap[0], i0, N0, n0, R, tr, false);
+    // level 1: the lane at the even corner of a 2x2 block combines (y, x), (y, x+1), (y+1, x), (y+1, x+1)
+    const MapVal v01 = lane_mapval(v0, lane + 1), v10 = lane_mapval(v0, lane + 16), v11 = lane_mapval(v0, lane + 17);
+    const MapVal n01 = lane_mapval(n0, lane + 1), n10 = lane_mapval(n0, lane + 16), n11 = lane_mapval(n0, lane + 17);
+    MapVal v1, n1;
+    v1.have = false; n1.have = false; v1.p = f3{qnan(), qnan(), qnan()}; n1.p = v1.p;
+    if (((lx | ly) & 1) == 0) {
+        v1 = resize4(v0, v01, v10, v11, false);
+        n1 = resize4(n0, n01, n10, n11, true);
+        const int i1 = (y >> 1) * c1 + (x >> 1);
+        emit_map(a.vmap[1], i1, N1, v1, R, tr, true);
+        emit_map(a.nmap[1], i1, N1, n1, R, tr, false);
+    }
+    // level 2: the lane at the corner of a 4x4 block combines the four level-1 values of the block
+    const MapVal w01 = lane_mapval(v1, lane + 2), w10 = lane_mapval(v1, lane + 32), w11 = lane_mapval(v1, lane + 34);
+    const MapVal m01 = lane_mapval(n1, lane + 2), m10 = lane_mapval(n1, lane + 32), m11 = lane_mapval(n1, lane + 34);
+    const unsigned long long valid_bits = __ballot(valid);
+    if ((lx & 3) == 0 && ly == 0) {
+        const MapVal v2 = resize4(v1, w01, w10, w11, false);
+        const MapVal n2 = resize4(n1, m01, m10, m11, true);
+        const int i2 = (y >> 2) * c2 + (x >> 2);
+        emit_map(a.vmap[2], i2, N2, v2, R, tr, true);
+        emit_map(a.nmap[2], i2, N2, n2, R, tr, false);
+        // occupancy of this 4x4 block: lanes lx..lx+3 of the four tile rows
+        if (a.occ) a.occ[i2] = ((valid_bits >> lx) & 0x000F000F000F000Full) != 0 ? 1 : 0;
     }
 }
 
@@ -535,7 +594,13 @@ void launch_rgb_prep(hipStream_t s, RgbPrepBatch b, int n, int W, int H)
 }
 void launch_model_maps(hipStream_t s, const ModelMapsBatch& b, int n)
 {
-    const int t = (b.m[0].cols >> 2) * (b.m[0].rows >> 2);
+    const int cols = b.m[0].cols, rows = b.m[0].rows;
+    if (cols % 16 == 0 && rows % 4 == 0) {
+        const int tiles = (cols >> 4) * (rows >> 2);
+        model_maps_tiled_kernel<<<dim3((tiles + 3) / 4, n), 256, 0, s>>>(b);
+        return;
+    }
+    const int t = (cols >> 2) * (rows >> 2);
     model_maps_kernel<<<dim3((t + 63) / 64, n), 64, 0, s>>>(b);
 }
 void launch_rgbd_pyramids(hipStream_t s, const RgbdBatch& b, int n_chains, int W, int H, float cutoff)

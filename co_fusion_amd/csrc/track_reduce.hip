@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
         if (occupied && ma.occ) {  // the model map is invalid (NaN) everywhere inside an empty 4x4 block: no gather needed
             const int gy = pr[p].g / cols, gxp = pr[p].g - gy * cols;
             const int tile = (gy >> args.occ_shift) * args.occ_w + (gxp >> args.occ_shift);
-            occupied = (ma.occ[tile >> 5] >> (tile & 31)) & 1u;
+            occupied = ma.occ[tile] != 0;
         }
         if (occupied) {
             const int g = pr[p].g;
