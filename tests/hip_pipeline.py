@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from co_fusion_amd.api import Context, Odometry, _f, _p
-from co_fusion_amd.model import SURFEL, TIME_DELTA, Model, bilateral, fusion_weight
+from co_fusion_amd.model import SURFEL, TIME_DELTA, Model, _DevView, bilateral, fusion_weight
 
 
 class StaticPipeline:
