@@ -1,0 +1,131 @@
+"""GPU parity of the device-resident segmentation stage (cf_seg_slic -> cf_seg_sums -> cf_seg_infer -> cf_seg_fetch) against the
+oracle's Segmentation::performSegmentationCRF on label images the frame loop never produces: checkerboards (one component per
+superpixel: more components than the LDS statistics hold, up to 64 components per wave), one-superpixel stripes, random labels,
+empty models, invalid depth -- the connected-components / gate / statistics code paths behind the smooth masks of the real run."""
+import ctypes as C
+import warnings
+
+import numpy as np
+import pytest
+
+import orc_multi as om
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore", category=RuntimeWarning)
+
+W, H = 640, 480
+GX, GY = W // 16, H // 16
+
+
+class SegModel(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("superPixelCount", C.c_uint32), ("avgConfidence", C.c_float), ("depthMean", C.c_float),
+                ("depthStd", C.c_float), ("top", C.c_int32), ("right", C.c_int32), ("bottom", C.c_int32), ("left", C.c_int32)]
+
+
+class SegResult(C.Structure):
+    _fields_ = [("has_new_label", C.c_int32), ("n_models", C.c_int32), ("depth_range", C.c_float), ("model", SegModel * 17)]
+
+
+def _bits(x):
+    return np.float32(x).view(np.uint32)
+
+
+def _run_hip(ctx, seg, params, rgba, depth, ids, icp, vc, next_id, allow_new):
+    n = len(ids)
+    keep = [ctx.to_device(rgba), ctx.to_device(depth)] + [ctx.to_device(a) for a in icp] + [ctx.to_device(a) for a in vc]
+    t_rgba, t_depth = keep[0], keep[1]
+    icp_arr = (C.c_void_p * n)(*[t.data_ptr() for t in keep[2:2 + n]])
+    vc_arr = (C.c_void_p * n)(*[t.data_ptr() for t in keep[2 + n:]])
+    full = ctx.to_device(np.zeros((H, W), np.uint8))
+    ctx._check(ctx.lib.cf_seg_slic(seg, C.c_void_p(t_rgba.data_ptr())))
+    sums = C.c_void_p(); words = C.c_uint64()
+    ctx._check(ctx.lib.cf_seg_sums(seg, C.c_void_p(t_depth.data_ptr()), n, icp_arr, vc_arr, C.byref(sums), C.byref(words)))
+    id_arr = (C.c_uint32 * n)(*ids)
+    ctx._check(ctx.lib.cf_seg_infer(seg, C.byref(params), C.c_void_p(t_rgba.data_ptr()), n, id_arr, C.c_uint32(next_id), int(allow_new),
+                                    C.c_void_p(full.data_ptr())))
+    res = SegResult()
+    low = np.zeros(GX * GY, np.uint8)
+    ctx._check(ctx.lib.cf_seg_fetch(seg, C.byref(res), low.ctypes.data_as(C.c_void_p)))
+    return res, low.reshape(GY, GX), full.cpu().numpy()
+
+
+def _compare(name, res, low, full, ref):
+    assert np.array_equal(low, ref["low"]), f"{name}: low-resolution labels differ in {np.count_nonzero(low != ref['low'])} superpixels"
+    assert np.array_equal(full, ref["full"]), f"{name}: full-resolution mask"
+    assert bool(res.has_new_label) == ref["hasNewLabel"], f"{name}: hasNewLabel"
+    assert _bits(res.depth_range) == _bits(ref["depthRange"]), f"{name}: depth range"
+    assert res.n_models == len(ref["modelData"]), f"{name}: rows {res.n_models} vs {len(ref['modelData'])}"
+    for i, r in enumerate(ref["modelData"]):
+        g = res.model[i]
+        assert (g.id, g.superPixelCount) == (r["id"], r["superPixelCount"]), f"{name} row {i}: id / count"
+        assert (g.top, g.right, g.bottom, g.left) == (r["top"], r["right"], r["bottom"], r["left"]), f"{name} row {i}: box"
+        for k in ("avgConfidence", "depthMean", "depthStd"):
+            a, b = getattr(g, k), r[k]
+            assert _bits(a) == _bits(b) or (a != a and b != b), f"{name} row {i}: {k} {a} vs {b}"
+
+
+def _block_image(values):
+    """[GY, GX] per-superpixel values -> [H, W] image constant over each 16x16 block"""
+    return np.repeat(np.repeat(np.asarray(values, np.float32), 16, 0), 16, 1)
+
+
+def _scenarios():
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:GY, 0:GX]
+    rgba_flat = np.zeros((H, W, 4), np.uint8); rgba_flat[..., :3] = 120; rgba_flat[..., 3] = 255
+    rgba_noise = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8); rgba_noise[..., 3] = 255
+    depth_ramp = (1.0 + 2.0 * np.arange(W, dtype=np.float32)[None, :] / W + 0.5 * np.arange(H, dtype=np.float32)[:, None] / H).astype(np.float32)
+
+    def vc(conf, depth):
+        v = np.zeros((H, W, 4), np.float32)
+        v[..., 2] = depth; v[..., 3] = conf
+        return v
+
+    def errs_from_labels(lab, n, lo=0.0005, hi=0.2):
+        return [_block_image(np.where(lab == m, lo, hi)) for m in range(n)]
+
+    unary_only = om.SegParams.defaults()
+    unary_only.weightAppearance = 0.0; unary_only.weightSmoothness = 0.0
+    out = []
+    # one component per superpixel: 1200 components (beyond the LDS statistics), 64 different components in every wave
+    lab = (yy + xx) % 2
+    out.append(("checkerboard of two models", unary_only, rgba_flat, depth_ramp, [0, 3], errs_from_labels(lab, 2), [vc(1.0, depth_ramp)] * 2, 4, False))
+    # one-superpixel-wide stripes of three models: tall thin components, 13-14 per label
+    lab = xx % 3
+    out.append(("vertical stripes of three models", unary_only, rgba_noise, depth_ramp, [0, 1, 2], errs_from_labels(lab, 3), [vc(1.0, depth_ramp)] * 3, 3, False))
+    # random labels of five models, a new label allowed: hundreds of components, keep-largest ties, size gates of the new label
+    lab = rng.integers(0, 5, size=(GY, GX))
+    e = errs_from_labels(lab, 5, hi=0.08)
+    e[0][:] = np.where(_block_image(rng.random((GY, GX)) < 0.15) > 0, 0.3, e[0])  # some superpixels nobody explains -> new label
+    for m in range(1, 5):
+        e[m][:] = np.where(e[0] == 0.3, 0.3, e[m])
+    out.append(("random labels of five models + new label", unary_only, rgba_noise, depth_ramp, [0, 2, 5, 7, 9], e, [vc(1.0, depth_ramp)] * 5, 10, True))
+    # the default CRF on the same inputs (smoothing merges the noise), a model that gets nothing, low-confidence regions
+    conf = _block_image(np.where(xx < GX // 3, 0.2, 1.0))
+    out.append(("default CRF, starved model, low confidence", om.SegParams.defaults(), rgba_noise, depth_ramp, [0, 2, 5, 7, 9], e,
+                [vc(conf, depth_ramp)] * 4 + [vc(0.0, depth_ramp)], 10, True))
+    # superpixels without valid depth (holes) and an object hugging the border (border gate)
+    d = depth_ramp.copy()
+    d[:64, :] = 0.0; d[200:264, 300:364] = 0.0
+    lab = np.zeros((GY, GX), np.int64); lab[:, :1] = 1; lab[10:20, 15:25] = 2
+    out.append(("depth holes + border object", om.SegParams.defaults(), rgba_noise, d, [0, 1, 2], errs_from_labels(lab, 3), [vc(1.0, d)] * 3, 3, True))
+    return out
+
+
+def test_segmentation_stage_on_adversarial_label_images():
+    from co_fusion_amd import api, synth
+    cam = synth.Camera.scaled(W, H)
+    ctx = api.Context(W, H, cam.fx, cam.fy, cam.cx, cam.cy)
+    seg = C.c_void_p()
+    ctx._check(ctx.lib.cf_seg_create(ctx.h, C.byref(seg)))
+    components = []
+    for name, params, rgba, depth, ids, icp, vcs, next_id, allow_new in _scenarios():
+        ref = om.segment_crf(params, rgba, depth, ids, icp, vcs, next_id, allow_new)
+        p = params.__class__.from_buffer_copy(params)
+        for rep in range(2):  # twice: the kernels leave their accumulators clean for the next frame
+            res, low, full = _run_hip(ctx, seg, p, rgba, depth, ids, icp, vcs, next_id, allow_new)
+            _compare(f"{name} (pass {rep})", res, low, full, ref)
+        components.append(len(np.unique(ref["low"])))
+    assert max(components) >= 2
+    ctx.lib.cf_seg_destroy(seg)
+    ctx.close()
