@@ -435,6 +435,11 @@ __device__ __forceinline__ void ldlt_solve6_wave(double a, const double* b, doub
     }
 }
 
+// Measured and dropped (round 2): the same factorisation with LDS as the exchange medium (matrix mirrored in LDS once per step, pivot
+// search and column values as broadcast loads, each trailing lane dividing its own two column entries): 2.84 us against 2.60 us for
+// this version inside the 7 us solve kernel (in-kernel clocks).  The time is the chain of dependent f64 operations -- six steps of
+// {pivot compare, IEEE division, multiply, multiply, subtract} and the two substitutions --, not the data movement.
+
 // exact conversion of a fixed-point sum to the reference's f32 host value
 __device__ __forceinline__ float fix_to_f32(long long q, int F) { return (float)ldexp((double)q, -F); }
 

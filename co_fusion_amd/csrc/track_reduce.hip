@@ -835,14 +835,17 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
     for (int k = tid; k < kGroups * 32; k += 256) { icp_acc[k] = 0; rgb_acc[k] = 0; }
     __syncthreads();
 
-    // uniform decisions (RGBDOdometry.cpp:371-392), evaluated redundantly by every lane
+    // uniform decisions (RGBDOdometry.cpp:371-392), evaluated redundantly by every lane.  The RGB error (an f64 square root and division)
+    // only decides anything in the RGB-only mode; otherwise it is a statistic, and an idle wave computes it beside the combine / solve
     bool active = od->level_done == 0, stop = false;
+    const bool rgbOnly = od->rgbOnly != 0;
     float tmpError = 0.f; int rgbCount = 0;
     if (active) {
-        const long long rgbSize = (long long)s_icp[29], sigma = (long long)s_icp[30];
-        rgbCount = (int)rgbSize;
-        tmpError = (float)(sqrt((double)(int)sigma) / (double)(int)rgbSize);
-        if (od->rgbOnly && tmpError > od->lastRGBError) { stop = true; active = false; }
+        rgbCount = (int)(long long)s_icp[29];
+        if (rgbOnly) {
+            tmpError = (float)(sqrt((double)(int)(long long)s_icp[30]) / (double)rgbCount);
+            if (tmpError > od->lastRGBError) { stop = true; active = false; }
+        }
     }
     const bool useIcp = od->icp != 0, useRgb = od->rgb != 0;
     if (active) {
@@ -850,14 +853,13 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
         if (tid >= 32 && tid < 59 && useRgb) se3_unpack_word(s_rgb, tid - 32, rgb_fix_bits(sigma_val_from(rgbCount, (int)(long long)s_icp[30], od->rgbOnly)), s_Af[1], s_bf[1], nullptr);
     }
     __syncthreads();
-    if (tid == 0) {
-        if (stop) od->level_done = 1;
-        if (active) {
-            od->lastRGBError = tmpError;
-            od->stats.last_rgb_error = tmpError; od->stats.last_rgb_count = (float)rgbCount;
-            od->stats.last_icp_error = sqrtf(od->residual[0]) / od->residual[1];
-            od->stats.last_icp_count = od->residual[1];
-        }
+    if (tid == 0 && stop) od->level_done = 1;
+    if (tid == 128 && active) {
+        if (!rgbOnly) tmpError = (float)(sqrt((double)(int)(long long)s_icp[30]) / (double)rgbCount);
+        od->lastRGBError = tmpError;
+        od->stats.last_rgb_error = tmpError; od->stats.last_rgb_count = (float)rgbCount;
+        od->stats.last_icp_error = sqrtf(od->residual[0]) / od->residual[1];
+        od->stats.last_icp_count = od->residual[1];
     }
     if (active && tid < 42) {
         const bool isA = tid < 36;
