@@ -248,10 +248,18 @@ def main(argv=None):
         if S > 1:  # every stream of work on its own HIP stream (the default is torch's current stream)
             hip_stream = torch.cuda.Stream(device=dev)
             cfi.set_stream(hip_stream)
+        def packed(f=None):
+            # depth (f32) and colour (RGBA8) of one frame in ONE allocation: the frame crosses the ranks as a single broadcast
+            buf = torch.empty(H * W * 8, dtype=torch.uint8, device=dev)
+            d = dict(pack=buf, depth=buf[:H * W * 4].view(torch.float32).view(H, W), rgba=buf[H * W * 4:].view(H, W, 4))
+            if f is not None:
+                d["depth"].copy_(torch.from_numpy(f["depth"])); d["rgba"].copy_(torch.from_numpy(f["rgba"]))
+            return d
         if model_parallel and rank != 0:
             # the ingest GPU is rank 0: the other ranks own no frames, only a two-deep landing buffer for the broadcast
-            resident = [dict(depth=torch.empty((H, W), dtype=torch.float32, device=dev), rgba=torch.empty((H, W, 4), dtype=torch.uint8, device=dev))
-                        for _ in range(2)]
+            resident = [packed() for _ in range(2)]
+        elif model_parallel:
+            resident = [packed(f) for f in frames]
         else:
             resident = [dict(depth=torch.from_numpy(f["depth"]).to(dev), rgba=torch.from_numpy(f["rgba"]).to(dev)) for f in frames]
         streams.append(dict(cf=cfi, frames=frames, resident=resident, hip_stream=hip_stream))
@@ -268,10 +276,9 @@ def main(argv=None):
             f = st["frames"][k]
             st["cf"].process_frame(f["depth"], f["rgb"], mask=gt_mask(f), timestamp=i)
         elif model_parallel:
-            # frame from the ingest GPU (rank 0) to every rank: two broadcasts over xGMI (depth 1.2 MB + colour 1.2 MB at 640x480)
+            # frame from the ingest GPU (rank 0) to every rank: one broadcast over xGMI (depth 1.2 MB + colour 1.2 MB at 640x480)
             buf = st["resident"][k] if rank == 0 else st["resident"][i & 1]
-            dist.broadcast(buf["depth"], src=0)
-            dist.broadcast(buf["rgba"], src=0)
+            dist.broadcast(buf["pack"], src=0)
             st["cf"].process_frame_device(buf["depth"], buf["rgba"], timestamp=i)
         else:
             st["cf"].process_frame_device(st["resident"][k]["depth"], st["resident"][k]["rgba"], timestamp=i)

@@ -24,7 +24,11 @@ using namespace cf;
 
 #define LAUNCHCHK(ctx) HIPCHK(ctx, hipGetLastError())
 
-void cf_ctx::set_error(const std::string& m) { last_error = m; }
+void cf_ctx::set_error(const std::string& m)
+{
+    std::lock_guard<std::mutex> lk(error_mutex);
+    last_error = m;
+}
 
 template <typename T>
 static int dmalloc(cf_ctx* ctx, T** p, size_t count)

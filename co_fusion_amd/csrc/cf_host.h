@@ -1,6 +1,7 @@
 // cf_host.h -- host-side object definitions behind the opaque C-ABI handles.
 #pragma once
 
+#include <mutex>
 #include <string>
 
 #include "cf_kernels.h"
@@ -17,6 +18,7 @@ struct cf_ctx {
     hipStream_t cur() const { return cf_tls_binding.ctx == this ? cf_tls_binding.stream : stream; }  // stream of the calling thread
     hipStream_t own_stream = nullptr;
     std::string last_error;
+    std::mutex error_mutex;            // helper threads bound with cf_thread_lane may fail at the same time
     cf::IcpLaunch icp_launch{256, 1};
     // scratch for the stand-alone reduction steps
     unsigned long long* d_acc_a = nullptr;

@@ -537,6 +537,7 @@ struct SegPostArgs {
 // One workgroup: the label image has K = 1200 superpixels (4800 at 1280x960, the largest supported); labels, union-find parents and
 // component numbers live in LDS, the sequential sums of the statistics run one wave per model (wave_sequential_sum).
 constexpr int kSegMaxK = 4800;
+constexpr int kPoseWords = 18;   // cf_seg_publish_poses: 16 pose words + ICP error + ICP inlier count, one 64-bit slot per f32 bit pattern
 constexpr int kCcLds = 512;   // components whose statistics fit in LDS (a frame has tens)
 __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
 {
@@ -835,6 +836,26 @@ static void launch_crf_step(hipStream_t st, int L, int n, const float* unary, co
     } while (0)
 #define LAUNCHCHK(ctx) HIPCHK(ctx, hipGetLastError())
 
+// cf_seg_publish_poses: model m's tracked pose (T = [Rcurr | tcurr], row-major 4x4) and ICP statistics as f32 bit patterns, one 64-bit
+// slot each, behind the segmentation sums -- zeros for models this process does not own, so that the caller's SUM all-reduce of the
+// block leaves every model's pose on every rank (exact: one contributor per word)
+struct PosePublishArgs { const OdomDev* st[kMaxL]; int n; };
+__global__ void __launch_bounds__(64) pose_publish_kernel(const PosePublishArgs a, long long* __restrict__ tail)
+{
+    const int m = blockIdx.x, w = threadIdx.x;
+    if (w >= kPoseWords) return;
+    long long v = 0;
+    const OdomDev* st = m < a.n ? a.st[m] : nullptr;
+    if (st) {
+        float f;
+        if (w < 12) { const int r = w >> 2, c = w & 3; f = c < 3 ? st->Rcurr[r * 3 + c] : st->tcurr[r]; }
+        else if (w < 16) f = w == 15 ? 1.f : 0.f;
+        else f = w == 16 ? st->stats.last_icp_error : st->stats.last_icp_count;
+        v = (long long)__float_as_uint(f);
+    }
+    tail[m * kPoseWords + w] = v;
+}
+
 struct cf_segmenter {
     cf_ctx* ctx = nullptr;
     int gx = 0, gy = 0, K = 0;
@@ -856,6 +877,8 @@ struct cf_segmenter {
     cf_seg_result* d_result = nullptr;
     cf_seg_result* h_result = nullptr;   // pinned
     unsigned char* h_low_map = nullptr;  // pinned [K]
+    long long* h_pose_tail = nullptr;    // pinned [kMaxL][kPoseWords]: the tail of the sums block after the caller's all-reduce
+    bool poses_published = false;
     bool grid_kernel_built = false;      // K1t holds the kernel of the grid's own smoothness features (seg_feat1_kernel)
 };
 
@@ -884,7 +907,9 @@ int cf_seg_create(cf_ctx* ctx, cf_segmenter** out)
     if (int r = seg_malloc(ctx, &s->spix_count, K)) return r;
     if (int r = seg_malloc(ctx, &s->depth_count, K)) return r;
     if (int r = seg_malloc(ctx, &s->depth_sum, K)) return r;
-    if (int r = seg_malloc(ctx, &s->icp_sum, 2 * K * kMaxL)) return r;  // [icp | conf] in one block: one collective covers both
+    // [icp | conf | pose tail] in one block: one collective of a model-parallel caller covers all of it (cf_seg_publish_poses)
+    if (int r = seg_malloc(ctx, &s->icp_sum, 2 * K * kMaxL + kMaxL * kPoseWords)) return r;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_pose_tail), sizeof(long long) * kMaxL * kPoseWords));
     s->conf_sum = s->icp_sum + K * kMaxL;
     if (int r = seg_malloc(ctx, &s->resample, K)) return r;
     if (int r = seg_malloc(ctx, &s->low_map, K)) return r;
@@ -923,6 +948,7 @@ void cf_seg_destroy(cf_segmenter* s)
     for (void* p : ptrs) (void)hipFree(p);
     if (s->h_result) (void)hipHostFree(s->h_result);
     if (s->h_low_map) (void)hipHostFree(s->h_low_map);
+    if (s->h_pose_tail) (void)hipHostFree(s->h_pose_tail);
     delete s;
 }
 
@@ -1055,7 +1081,32 @@ int cf_seg_sums(cf_segmenter* s, const float* depth, int n_models, const float* 
     if (!s || !depth || n_models <= 0 || n_models > kMaxL || !icp_err || !vertconf4) return CF_EINVAL;
     if (int r = enqueue_accumulate(s, depth, n_models, icp_err, vertconf4)) return r;
     if (sums_dev) *sums_dev = reinterpret_cast<int64_t*>(s->icp_sum);
-    if (sums_words) *sums_words = 2ull * kMaxL * (uint64_t)s->K;
+    if (sums_words) *sums_words = 2ull * kMaxL * (uint64_t)s->K + (uint64_t)kMaxL * kPoseWords;  // the pose tail rides along (zeros unless published)
+    return CF_OK;
+}
+
+// Model-parallel callers: put the poses the trackers hold on THIS process behind the sums (trackers[m] == NULL: model m is tracked
+// elsewhere), between cf_seg_sums and the all-reduce; after cf_seg_infer + cf_seg_fetch, cf_seg_fetch_poses hands out all of them.
+// Replaces a separate (blocking) pose exchange per frame.
+int cf_seg_publish_poses(cf_segmenter* s, int n_models, cf_odom* const* trackers)
+{
+    if (!s || n_models <= 0 || n_models > kMaxL || !trackers) return CF_EINVAL;
+    PosePublishArgs a{};
+    a.n = n_models;
+    for (int m = 0; m < n_models; m++) a.st[m] = trackers[m] ? trackers[m]->d_state : nullptr;
+    pose_publish_kernel<<<kMaxL, 64, 0, s->ctx->stream>>>(a, reinterpret_cast<long long*>(s->icp_sum) + 2 * (size_t)kMaxL * s->K);
+    LAUNCHCHK(s->ctx);
+    s->poses_published = true;
+    return CF_OK;
+}
+// words: [n_models][18] (16 pose words row-major, ICP error, ICP inlier count) as written by the owners; valid after cf_seg_fetch
+int cf_seg_fetch_poses(cf_segmenter* s, int n_models, int64_t* words_host)
+{
+    if (!s || n_models <= 0 || n_models > kMaxL || !words_host) return CF_EINVAL;
+    if (!s->poses_published) { s->ctx->set_error("cf_seg_fetch_poses: no poses were published for this inference"); return CF_ESTATE; }
+    HIPCHK(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    memcpy(words_host, s->h_pose_tail, sizeof(int64_t) * (size_t)n_models * kPoseWords);
+    s->poses_published = false;
     return CF_OK;
 }
 
@@ -1116,6 +1167,10 @@ int cf_seg_infer(cf_segmenter* s, const cf_seg_params* P, const uint8_t* rgba, i
     LAUNCHCHK(ctx);
     HIPCHK(ctx, hipMemcpyAsync(s->h_result, s->d_result, sizeof(cf_seg_result), hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(s->h_low_map, s->low_map, (size_t)n, hipMemcpyDeviceToHost, st));
+    if (s->poses_published) {  // the tail now holds what the caller's all-reduce made of it; the next frame starts from zeros again
+        long long* tail = reinterpret_cast<long long*>(s->icp_sum) + 2 * (size_t)kMaxL * s->K;
+        HIPCHK(ctx, hipMemcpyAsync(s->h_pose_tail, tail, sizeof(long long) * kMaxL * kPoseWords, hipMemcpyDeviceToHost, st));
+    }
     return CF_OK;
 }
 

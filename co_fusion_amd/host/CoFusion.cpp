@@ -343,7 +343,17 @@ void Segmentation::enqueueCRF(ModelList& models, const float* depth_dev, const u
     }
     int64_t* sums_dev = nullptr; uint64_t words = 0;
     check(ctx, cf_seg_sums(seg, depth_dev, n_models, icpPtr.data(), vcPtr.data(), &sums_dev, &words), "cf_seg_sums");
-    if (dist && dist->active()) dist->sumDevice(ctx, sums_dev, words);  // exact: integer sums, every model has exactly one owner
+    posesPublished = false;
+    if (dist && dist->active()) {
+        // the tracking launches are queued ahead of this point: the poses they leave in the trackers' device state travel in the tail of
+        // the same block, so the frame needs ONE collective and no separate (blocking) pose exchange
+        std::vector<cf_odom*> trackers(n_models, nullptr);
+        int m = 0;
+        for (auto& mdl : models) { if (mdl->isOwned() && dist->contributes(mdl->getID())) trackers[m] = mdl->getFrameOdometry(); m++; }
+        check(ctx, cf_seg_publish_poses(seg, n_models, trackers.data()), "cf_seg_publish_poses");
+        posesPublished = true;
+        dist->sumDevice(ctx, sums_dev, words);  // exact: integer sums, every word has exactly one contributor
+    }
     cf_seg_params P{};
     P.unaryWeightError = unaryWeightError; P.unaryKError = unaryKError; P.unaryThresholdNew = unaryThresholdNew;
     P.weightAppearance = weightAppearance; P.weightSmoothness = weightSmoothness;
@@ -351,6 +361,15 @@ void Segmentation::enqueueCRF(ModelList& models, const float* depth_dev, const u
     P.minRelSizeNew = minRelSizeNew; P.maxRelSizeNew = maxRelSizeNew; P.crfIterations = (int)crfIterations;
     check(ctx, cf_seg_infer(seg, &P, rgba_dev, n_models, ids.data(), nextModelID, allowNew ? 1 : 0, full_dev), "cf_seg_infer");
     pendingModels = n_models;
+}
+
+bool Segmentation::fetchPublishedPoses(size_t nModels, std::vector<int64_t>& words)
+{
+    if (!posesPublished || (int)nModels != pendingModels) return false;
+    words.resize(nModels * 18);
+    check(ctx, cf_seg_fetch_poses(seg, (int)nModels, words.data()), "cf_seg_fetch_poses");
+    posesPublished = false;
+    return true;
 }
 
 SegmentationResult Segmentation::finishCRF()
@@ -902,17 +921,22 @@ void CoFusion::exchangeTracking()
 {   // owners publish pose + ICP statistics as bit patterns (one 64-bit slot per float), shadows contribute zeros
     if (!dist.active()) return;
     const int R = 16 + 2;
-    std::vector<int64_t> buf(models.size() * R, 0);
+    std::vector<int64_t> buf;
     size_t k = 0;
-    for (auto& m : models) {
-        if (m->isOwned() && dist.contributes(m->getID())) {
-            for (int i = 0; i < 16; i++) { uint32_t b; memcpy(&b, &m->pose.m[i], 4); buf[k * R + i] = (int64_t)b; }
-            uint32_t b; memcpy(&b, &m->lastStats.last_icp_error, 4); buf[k * R + 16] = (int64_t)b;
-            memcpy(&b, &m->lastStats.last_icp_count, 4); buf[k * R + 17] = (int64_t)b;
+    // with the device segmentation in flight the poses came along with its sums (Segmentation::enqueueCRF); otherwise (ground-truth
+    // masks, single-model mode, host segmentation) a collective of its own
+    if (!labelGenerator->fetchPublishedPoses(models.size(), buf)) {
+        buf.assign(models.size() * R, 0);
+        for (auto& m : models) {
+            if (m->isOwned() && dist.contributes(m->getID())) {
+                for (int i = 0; i < 16; i++) { uint32_t b; memcpy(&b, &m->pose.m[i], 4); buf[k * R + i] = (int64_t)b; }
+                uint32_t b; memcpy(&b, &m->lastStats.last_icp_error, 4); buf[k * R + 16] = (int64_t)b;
+                memcpy(&b, &m->lastStats.last_icp_count, 4); buf[k * R + 17] = (int64_t)b;
+            }
+            k++;
         }
-        k++;
+        dist.sum(buf.data(), buf.size());
     }
-    dist.sum(buf.data(), buf.size());
     k = 0;
     for (auto& m : models) {
         if (!m->isOwned()) {

@@ -177,6 +177,9 @@ class Segmentation {
     void enqueueCRF(ModelList& models, const float* depth_dev, const uint8_t* rgba_dev, unsigned char nextModelID, bool allowNew,
                     uint8_t* fullSegmentation_dev);
     SegmentationResult finishCRF();
+    // model-parallel operation: enqueueCRF put every owner's tracked pose behind the sums it all-reduces; after the frame's host wait
+    // this hands out [models][18] words (pose row-major, ICP error, ICP inlier count as f32 bit patterns).  false: nothing was published
+    bool fetchPublishedPoses(size_t nModels, std::vector<int64_t>& words);
     // setters (Segmentation.h:100-120); defaults are the GUI values the reference applies every frame (GUI.h:206-227)
     float unaryWeightError = 75.f, unaryKError = 0.0375f, unaryThresholdNew = 5.5f;
     float weightAppearance = 7.f, weightSmoothness = 2.f;
@@ -196,6 +199,7 @@ class Segmentation {
     const Distributed* dist = nullptr;
     bool slicStarted = false;
     int pendingModels = 0;        // models of the segmentation enqueueCRF left in flight
+    bool posesPublished = false;  // ... which carries the owners' poses in its all-reduce
     float* zeroImage = nullptr;   // device zeros [H*W*4] standing in for the ICP error / confidence maps of shadow models
 };
 

@@ -348,6 +348,13 @@ int cf_seg_sums(cf_segmenter *s, const float *depth, int n_models, const float *
 int cf_seg_infer(cf_segmenter *s, const cf_seg_params *params, const uint8_t *rgba, int n_models, const uint32_t *model_ids,
                  uint32_t next_model_id, int allow_new, uint8_t *full_dev);
 int cf_seg_fetch(cf_segmenter *s, cf_seg_result *out, uint8_t *low_map_host);
+/* Model-parallel callers (one process per GPU, each tracking some of the models): the block cf_seg_sums hands out ends in a tail of
+ * 16 x 18 words.  cf_seg_publish_poses (between cf_seg_sums and the caller's in-place SUM all-reduce of the block) writes there, for
+ * every model tracked by THIS process (trackers[m] != NULL), the tracked pose (row-major 4x4) + ICP error + ICP inlier count as f32
+ * bit patterns, zeros for the others; the all-reduce then leaves every model's pose on every rank, and cf_seg_fetch_poses hands
+ * them out after cf_seg_infer / cf_seg_fetch ([n_models][18] words) -- no separate pose exchange, no extra host wait. */
+int cf_seg_publish_poses(cf_segmenter *s, int n_models, cf_odom *const *trackers);
+int cf_seg_fetch_poses(cf_segmenter *s, int n_models, int64_t *words_host);
 /* device view of the SLIC labels, int32 [H*W] */
 int cf_seg_labels(cf_segmenter *s, void **dptr, uint64_t *bytes);
 
