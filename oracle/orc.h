@@ -14,9 +14,11 @@
  *            CUDA kernels / GLSL shaders compiled for the CPU (oracle/ref_shim ->
  *            oracle/_ref; fixtures tests/golden/ref_v1.npz, ref_surfel_v1.npz;
  *            tests/test_cpu_refpin.py).
- *   UNPINNED orc_segment.c (gSLICr / densecrf are not in the tree) and the host
- *            Gauss-Newton loop of orc_track.c (RGBDOdometry.cpp needs Eigen):
- *            tests/golden/oracle_v1.npz pins those against themselves only.
+ *            The host Gauss-Newton loop of orc_track.c: against the reference's own RGBDOdometry class compiled
+ *            with a fixed-size Eigen stand-in (Eigen is absent; its rounding conventions are stated in
+ *            oracle/ref_shim/eigen_fixed/Eigen/Core): counts identical, poses within 5e-6 (ref_odo_v1.npz).
+ *            orc_segment.c's host logic: against Segmentation.cpp / Slic.* / ConnectedLabels.hpp (ref_seg_v1.npz).
+ *   UNPINNED the two third-party algorithms that are not in the tree (gSLICr, densecrf): stated in orc_segment.c.
  *
  * Data layouts (identical to the HIP C-ABI in include/cofusion_hip.h):
  *   depth            f32  [H*W] metres, 0 = invalid

@@ -1,7 +1,8 @@
 /*
  * orc_track.c -- CPU ORACLE for the dense tracking half of the hot path.
  * TEST INFRASTRUCTURE ONLY (see orc.h).  Kernels PINNED against the reference's own reduce.cu / cudafuncs.cu run on the CPU
- * (oracle/ref_shim, tests/test_cpu_refpin.py); the host Gauss-Newton loop is UNPINNED (RGBDOdometry.cpp needs Eigen).
+ * (oracle/ref_shim, tests/test_cpu_refpin.py); the host Gauss-Newton loop PINNED against the reference's own RGBDOdometry class compiled
+ * with a stand-in for Eigen whose rounding conventions are stated, not verified (poses within 5e-6, counts identical; ref_odo_v1.npz).
  *
  * Restates, function by function:
  *   Core/Cuda/cudafuncs.cu   map preparation kernels

@@ -114,6 +114,27 @@ def main() -> int:
         obj = os.path.join(tmp, "Segmentation.o")
         subprocess.check_call(["g++", *seg_flags, "-c", gen, "-o", obj])
         objs.append(obj)
+        # the odometry host code: RGBDOdometry.{h,cpp} as generated copies under <tmp>/Utils/ so that their `#include "../GPUTexture.h"`
+        # (a Pangolin OpenGL texture) and "Stopwatch.h" resolve to the stand-ins copied beside them; OdometryProvider.h, GPUConfig.h
+        # and the CUDA headers are read where they lie.  Eigen: the fixed-size stand-in of eigen_fixed/ (FIRST on the include path, the
+        # dynamic-matrix stand-in of include/Eigen is for the segmentation sources).  The harness is appended.
+        utils_dir = os.path.join(REF, "Core", "Utils")
+        os.makedirs(os.path.join(tmp, "Utils"))
+        for src_name, dst_name in (("GPUTexture.h", "GPUTexture.h"), (os.path.join("Utils", "Stopwatch.h"), os.path.join("Utils", "Stopwatch.h"))):
+            with open(os.path.join(tmp, dst_name), "w") as f:
+                f.write(open(os.path.join(HERE, "stub", src_name)).read())
+        with open(os.path.join(tmp, "Utils", "RGBDOdometry.h"), "w") as f:
+            f.write(f'#line 1 "{os.path.join(utils_dir, "RGBDOdometry.h")}"\n' + open(os.path.join(utils_dir, "RGBDOdometry.h")).read())
+        gen = os.path.join(tmp, "Utils", "RGBDOdometry_gen.cpp")
+        with open(gen, "w") as f:
+            f.write(f'#line 1 "{os.path.join(utils_dir, "RGBDOdometry.cpp")}"\n' + open(os.path.join(utils_dir, "RGBDOdometry.cpp")).read() +
+                    f'\n#include "{os.path.join(HERE, "ref_odo.cpp")}"\n')
+        odo_flags = ["-O2", "-g0", "-std=c++14", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w", "-DCUSIM_HOST_TU", "-I", os.path.join(HERE, "eigen_fixed"),
+                     "-I", os.path.join(HERE, "include"), "-I", utils_dir, "-I", CUDA, "-include", "cusim.h", "-include", "string", "-include", "sstream",
+                     "-include", "iostream", "-include", "limits"]
+        obj = os.path.join(tmp, "RGBDOdometry.o")
+        subprocess.check_call(["g++", *odo_flags, "-c", gen, "-o", obj])
+        objs.append(obj)
         orc_dir = os.path.join(os.path.dirname(HERE), "_build")  # orc_inverse_pose (host-side pose inverse) comes from the oracle
         subprocess.check_call(["g++", "-shared", "-o", os.path.join(OUT, "libcofusion_ref.so"), *objs, "-L", orc_dir, "-lorc",
                                "-Wl,-rpath,$ORIGIN/../_build"])

@@ -22,7 +22,9 @@
 #include <limits>
 #include <cmath>
 
-#ifndef __CUDACC__
+// device translation units (.cu) see __CUDACC__ as under nvcc; a HOST translation unit of the reference (RGBDOdometry.cpp, compiled
+// with -DCUSIM_HOST_TU) must not: Core/Cuda/types.cuh gives mat33 its Eigen constructor only to the host compiler
+#if !defined(__CUDACC__) && !defined(CUSIM_HOST_TU)
 #define __CUDACC__ 1
 #endif
 #define __global__
@@ -101,11 +103,16 @@ static inline cudaError cudaMemcpy2D(void* d, size_t dp, const void* s, size_t s
     for (size_t y = 0; y < h; y++) memcpy((char*)d + y * dp, (const char*)s + y * sp, wbytes);
     return cudaSuccess;
 }
+struct cudaArray;
+static inline cudaError cudaMemcpyFromArray(void* d, const cudaArray* a, size_t, size_t, size_t n, cudaMemcpyKind);  // defined below the type
+struct cudaDeviceProp { char name[256]; };
+static inline cudaError cudaGetDeviceProperties(cudaDeviceProp* p, int) { memset(p, 0, sizeof(*p)); strcpy(p->name, "cusim (CPU SIMT emulator)"); return cudaSuccess; }
 template <class T> static inline cudaError cudaMemcpyToSymbol(T& sym, const void* s, size_t n) { memcpy((void*)&sym, s, n); return cudaSuccess; }
 
 // ---- surfaces / textures ---------------------------------------------------------------------------------------------
 typedef unsigned long long cudaSurfaceObject_t;  // 0 = none, else a cusim::Surface*
 struct cudaArray { void* data; int width, height; };
+static inline cudaError cudaMemcpyFromArray(void* d, const cudaArray* a, size_t, size_t, size_t n, cudaMemcpyKind) { memcpy(d, a->data, n); return cudaSuccess; }
 enum cudaTextureReadMode { cudaReadModeElementType = 0 };
 template <class T, int D, cudaTextureReadMode M> struct texture { const cudaArray* arr = nullptr; };
 namespace cusim {

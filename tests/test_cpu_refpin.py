@@ -290,3 +290,76 @@ def test_requires_fill_in_matches_resize_shader():
             assert a == b, f"{w}x{h} fill {fill}: oracle {a} vs reference shader {b}"
             flips.add(int(a))
     assert flips == {0, 1}
+
+
+# ---- the Gauss-Newton loop: oracle vs the reference's own RGBDOdometry class -------------------------------------------------------
+ODO_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_odo_v1.npz")
+# getIncrementalTransformation runs 57 f32 tree reductions whose order the oracle does not follow (it sums exactly), and the stand-in
+# Eigen states its own rounding conventions (oracle/ref_shim/eigen_fixed/Eigen/Core): poses agree to a few f32 ulps of the motion, not bits
+ODO_POSE_TOL = 5e-6
+
+
+def _odo_inputs():
+    import hashlib
+    import refodo
+    z = np.load(ODO_GOLDEN)
+    W, H, n_frames = (int(v) for v in z["meta"])
+    cam, frames = refodo.record_tracking_inputs(W, H, n_frames)
+    for fi in z["frames"]:
+        fr = frames[int(fi)]
+        h = hashlib.sha256()
+        for k in ("prev_rgba", "v4", "n4", "pose", "img", "rgba"):
+            h.update(np.ascontiguousarray(fr[k]).tobytes())
+        for d in fr["depth_pyr"]:
+            h.update(np.ascontiguousarray(d).tobytes())
+        assert h.hexdigest() == str(z[f"f{int(fi)}/digest"]), "the recorded tracking inputs changed: regenerate tests/golden/ref_odo_v1.npz"
+    return z, cam, frames, W, H
+
+
+def test_gn_loop_matches_reference_odometry_class():
+    """SURVEY 8 row a7: orc_odom_get_incremental_transformation against RGBDOdometry::getIncrementalTransformation compiled from
+    /root/reference (schedule, SO(3) pre-alignment loop, ICP/RGB weighting, LDL^T solve, computeUpdateSE3, pose composition,
+    divergence guard), six option sets x two frames: identical inlier / correspondence counts, poses within ODO_POSE_TOL."""
+    import refodo
+    z, cam, frames, W, H = _odo_inputs()
+    moved = 0.0
+    for fi in z["frames"]:
+        fr = frames[int(fi)]
+        for opts in refodo.OPTION_SETS:
+            key = f"f{int(fi)}/{opts[0]}"
+            tr, rot, st, err = refodo.track_once(orc.Odometry, cam, W, H, fr, opts)
+            rt, rr, rs = z[key + "/trans"], z[key + "/rot"], z[key + "/stats"]
+            assert np.abs(tr - rt).max() <= ODO_POSE_TOL, f"{key}: translation {tr} vs reference {rt}"
+            assert np.abs(rot - rr).max() <= ODO_POSE_TOL, f"{key}: rotation differs by {np.abs(rot - rr).max()}"
+            icp, rgb, so3 = not opts[1] and opts[2] > 0, opts[1] or opts[2] < 100, opts[5]
+            if icp:
+                assert st["last_icp_count"] == rs[1], f"{key}: ICP inliers {st['last_icp_count']} vs {rs[1]}"
+                assert abs(st["last_icp_error"] - rs[0]) <= 1e-4 * rs[0], f"{key}: ICP error"
+            if rgb:
+                assert st["last_rgb_count"] == rs[3], f"{key}: RGB correspondences {st['last_rgb_count']} vs {rs[3]}"
+                assert abs(st["last_rgb_error"] - rs[2]) <= 1e-4 * max(rs[2], 1e-6), f"{key}: RGB error"
+            if so3:  # (with so3 off the reference's members keep their constructor values, the oracle reports zeros)
+                assert st["last_so3_count"] == rs[5] and abs(st["last_so3_error"] - rs[4]) <= 1e-4 * rs[4], f"{key}: SO3 statistics"
+            A, b = z[key + "/lastA"], z[key + "/lastb"]
+            assert np.abs(st["lastA"] - A).max() <= 2e-4 * np.abs(A).max(), f"{key}: last normal matrix"
+            assert np.abs(st["lastb"] - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-3 * np.abs(A).max()), f"{key}: last right-hand side"
+            if icp:
+                es = z[key + "/err_sum_max"]
+                assert abs(err.astype(np.float64).sum() - es[0]) <= 1e-4 * es[0] and abs(err.max() - es[1]) <= 1e-4, f"{key}: ICP error surface"
+            moved = max(moved, float(np.abs(tr - fr["pose"][:3, 3]).max()))
+    assert moved > 5e-3, "degenerate pin: the tracker did not move"
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_gn_loop_fixture_is_what_the_reference_class_produces():
+    """the committed fixture is reproducible from the reference sources (spot check: the RGB-only option set, ~25 s on the emulator;
+    tests/golden/make_ref_odo_golden.py regenerates all of it)"""
+    import refodo
+    z, cam, frames, W, H = _odo_inputs()
+    fi = int(z["frames"][0])
+    opts = [o for o in refodo.OPTION_SETS if o[0] == "rgb_only"][0]
+    tr, rot, st, _ = refodo.track_once(refodo.RefOdometry, cam, W, H, frames[fi], opts)
+    key = f"f{fi}/rgb_only"
+    assert refpin.bits_equal(tr, z[key + "/trans"]) and refpin.bits_equal(rot, z[key + "/rot"])
+    assert st["last_rgb_count"] == z[key + "/stats"][3] and st["last_so3_count"] == z[key + "/stats"][5]
+    assert np.array_equal(st["lastA"], z[key + "/lastA"]) and np.array_equal(st["lastb"], z[key + "/lastb"])
