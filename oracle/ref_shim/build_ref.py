@@ -71,7 +71,8 @@ def main() -> int:
         return 0
     os.makedirs(OUT, exist_ok=True)
     subprocess.check_call(["make", "-s", "-C", os.path.dirname(HERE)])  # liborc.so: the harness takes the host-side pose inverse from it
-    flags = ["-O2", "-g0", "-std=c++14", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w",
+    san = ["-fsanitize=address", "-g"] if os.environ.get("COFUSION_REF_SANITIZE") else []   # debugging aid: LD_PRELOAD libasan.so
+    flags = san + ["-O2", "-g0" if not san else "-g", "-std=c++14", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w",
              "-I", os.path.join(HERE, "include"), "-I", CUDA]
     objs = []
     with tempfile.TemporaryDirectory() as tmp:
@@ -99,7 +100,7 @@ def main() -> int:
         # so that its `#include "../Model/Model.h"` (OpenGL-backed class) resolves to the three-method stand-in copied to
         # <tmp>/Model/Model.h; gSLICr / densecrf / Eigen / OpenCV stand-ins come from include/.  The harness is appended.
         seg_dir = os.path.join(REF, "Core", "Segmentation")
-        seg_flags = [f for f in flags if f != "-std=c++14"] + ["-std=c++17", "-I", seg_dir, "-I", os.path.join(REF, "Core"), "-I", os.path.join(os.path.dirname(HERE))]
+        seg_flags = ["-I", os.path.join(HERE, "eigen_fixed")] + [f for f in flags if f != "-std=c++14"] + ["-std=c++17", "-I", seg_dir, "-I", os.path.join(REF, "Core"), "-I", os.path.join(os.path.dirname(HERE))]
         obj = os.path.join(tmp, "Slic.o")
         subprocess.check_call(["g++", *seg_flags, "-c", os.path.join(seg_dir, "Slic.cpp"), "-o", obj])
         objs.append(obj)
@@ -129,14 +130,34 @@ def main() -> int:
         with open(gen, "w") as f:
             f.write(f'#line 1 "{os.path.join(utils_dir, "RGBDOdometry.cpp")}"\n' + open(os.path.join(utils_dir, "RGBDOdometry.cpp")).read() +
                     f'\n#include "{os.path.join(HERE, "ref_odo.cpp")}"\n')
-        odo_flags = ["-O2", "-g0", "-std=c++14", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w", "-DCUSIM_HOST_TU", "-I", os.path.join(HERE, "eigen_fixed"),
+        odo_flags = san + ["-O2", "-g0" if not san else "-g", "-std=c++14", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w", "-DCUSIM_HOST_TU", "-I", os.path.join(HERE, "eigen_fixed"),
                      "-I", os.path.join(HERE, "include"), "-I", utils_dir, "-I", CUDA, "-include", "cusim.h", "-include", "string", "-include", "sstream",
                      "-include", "iostream", "-include", "limits"]
         obj = os.path.join(tmp, "RGBDOdometry.o")
         subprocess.check_call(["g++", *odo_flags, "-c", gen, "-o", obj])
         objs.append(obj)
+        # the frame loop: the reference's own function bodies out of Core/CoFusion.cpp (cut at build time, never stored) behind
+        # stub/CoFusionPin.h, followed by the harness; every pass runs on the oracle (stub/Model/Model.h)
+        cofusion_cpp = open(os.path.join(REF, "Core", "CoFusion.cpp")).read().split("\n")
+        wanted = ["SegmentationResult CoFusion::performSegmentation(", "bool CoFusion::processFrame(", "void CoFusion::predict(",
+                  "bool CoFusion::requiresFillIn(", "void CoFusion::spawnObjectModel(", "void CoFusion::moveNewModelToList(",
+                  "ModelListIterator CoFusion::inactivateModel(", "unsigned char CoFusion::getNextModelID("]
+        pieces = []
+        for sig in wanted:
+            start = next(i for i, l in enumerate(cofusion_cpp) if l.startswith(sig))
+            end = next(i for i in range(start, len(cofusion_cpp)) if cofusion_cpp[i] == "}")
+            pieces.append(f'#line {start + 1} "{os.path.join(REF, "Core", "CoFusion.cpp")}"\n' + "\n".join(cofusion_cpp[start:end + 1]))
+        gen = os.path.join(tmp, "CoFusion_gen.cpp")
+        with open(gen, "w") as f:
+            f.write('#include "CoFusionPin.h"\n' + "\n".join(pieces) + f'\n#include "{os.path.join(HERE, "ref_cofusion.cpp")}"\n')
+        cf_flags = (["-fsanitize=address", "-g", "-O1", "-fno-inline"] if os.environ.get("COFUSION_REF_SANITIZE") else ["-O2", "-g0"]) + [ "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w", "-DCUSIM_HOST_TU", "-DRGBDOdometry=PinOdometry",
+                    "-I", os.path.join(HERE, "stub"), "-I", os.path.join(HERE, "eigen_fixed"), "-I", os.path.join(HERE, "include"),
+                    "-I", os.path.join(REF, "Core"), "-I", os.path.join(REF, "Core", "Segmentation"), "-I", os.path.dirname(HERE), "-include", "cusim.h"]
+        obj = os.path.join(tmp, "CoFusion.o")
+        subprocess.check_call(["g++", *cf_flags, "-c", gen, "-o", obj])
+        objs.append(obj)
         orc_dir = os.path.join(os.path.dirname(HERE), "_build")  # orc_inverse_pose (host-side pose inverse) comes from the oracle
-        subprocess.check_call(["g++", "-shared", "-o", os.path.join(OUT, "libcofusion_ref.so"), *objs, "-L", orc_dir, "-lorc",
+        subprocess.check_call(["g++", "-shared", *(["-fsanitize=address"] if os.environ.get("COFUSION_REF_SANITIZE") else []), "-o", os.path.join(OUT, "libcofusion_ref.so"), *objs, "-L", orc_dir, "-lorc",
                                "-Wl,-rpath,$ORIGIN/../_build"])
     print(os.path.join(OUT, "libcofusion_ref.so"))
     return 0

@@ -1,0 +1,109 @@
+"""Scenarios of the frame-loop pin: the reference's own CoFusion::processFrame text (tests/refcofusion.py) and the
+oracle's restatement of it (tests/orc_multi.MultiPipeline) play the same synthetic stream; everything the frame loop decides -- model
+list, ids, poses, surfel buffers, confidence thresholds, unseen counters, label masks -- is digested per frame.  Test infrastructure."""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+W, H = 160, 128
+# name -> (objects in the scene, frames, conf_global, spawn offset, ground-truth masks, multiple models)
+SCENARIOS = {
+    "crf_two_objects": (2, 14, 0.5, 3, False, True),
+    "crf_four_objects": (4, 18, 0.5, 1, False, True),
+    "gt_masks_three_objects": (3, 10, 0.5, 2, True, True),
+    "gt_masks_fill_in_tracking": (3, 8, 10.0, 2, True, True),
+    "static": (2, 5, 10.0, 20, False, False),
+}
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:24]
+
+
+def frames_of(name):
+    from co_fusion_amd import synth
+    n_obj, n_frames, _, _, use_gt, _ = SCENARIOS[name]
+    cam = synth.Camera.scaled(W, H)
+    sc = synth.Scene(n_obj=n_obj)
+    out = []
+    for t in range(n_frames):
+        d, rgb, label, _ = sc.render(cam, t, noise=True)
+        out.append((d, rgb, synth.rgb_to_rgba(rgb), (label * 40).astype(np.uint8) if use_gt else None))
+    return cam, out
+
+
+def run_reference(name):
+    import refcofusion
+    _, _, conf_global, spawn, _, multi = SCENARIOS[name]
+    cam, frames = frames_of(name)
+    cf = refcofusion.RefCoFusion(cam, conf_global=conf_global, spawn_offset=spawn, multi=multi)
+    rows = []
+    for t, (d, rgb, _, gt) in enumerate(frames):
+        cf.process_frame(d, rgb, gt_mask=gt, timestamp=t)
+        ms = [cf.model(i) for i in range(cf.num_models)]
+        rows.append(dict(ids=[m["id"] for m in ms], counts=[m["count"] for m in ms], poses=[_sha(m["pose"]) for m in ms],
+                         surfels=[_sha(m["surfels"]) for m in ms], conf=[float(m["conf_threshold"]) for m in ms],
+                         unseen=[m["unseen"] for m in ms], mask=_sha(cf.mask()), tick=cf.tick,
+                         pose_log=[m["last_pose_log"].copy() for m in ms]))
+    return rows
+
+
+def run_oracle(name):
+    import orc_multi as om
+    _, _, conf_global, spawn, _, multi = SCENARIOS[name]
+    cam, frames = frames_of(name)
+    rows = []
+    if multi:
+        cf = om.MultiPipeline(cam, conf_global=conf_global, spawn_offset=spawn)
+        for d, _, rgba, gt in frames:
+            cf.process_frame(d, rgba, gt_mask=gt)
+            ms = cf.models
+            rows.append(dict(ids=[m.id for m in ms], counts=[m.surfels.shape[0] for m in ms], poses=[_sha(m.pose) for m in ms],
+                             surfels=[_sha(m.surfels) for m in ms], conf=[float(np.float32(m.conf_threshold)) for m in ms],
+                             unseen=[m.unseen for m in ms], mask=_sha(cf.mask), tick=cf.tick))
+    else:
+        import orc_pipeline as op
+        cf = op.StaticPipeline(cam, conf_global=conf_global)
+        for d, _, rgba, _ in frames:
+            cf.process_frame(d, rgba)
+            rows.append(dict(ids=[0], counts=[cf.surfels.shape[0]], poses=[_sha(cf.pose)], surfels=[_sha(cf.surfels)],
+                             conf=[float(np.float32(conf_global))], unseen=[0], mask=_sha(cf.mask), tick=cf.tick))
+    return rows
+
+
+# The confidence threshold of an object model follows SegmentationResult::avgConfidence, which the reference's Segmentation computes from f32
+# running sums per superpixel and the oracle from exact sums (pinned to 2e-5 on its own, ref_seg_v1.npz): a tolerance, everything else bits
+CONF_RTOL = 1e-4
+
+
+def run_reference_isolated(name):
+    """run_reference in a process of its own.  Core/Segmentation/Segmentation.cpp:64 keeps the ground-truth label -> model id table
+    in a FUNCTION-STATIC vector and indexes an uninitialised `modelIdToIndex[256]` with whatever it finds there: a second CoFusion
+    instance in the same process inherits the first one's table, writes labels of models it does not have and then runs off the
+    end of `modelData` (found by AddressSanitizer while building this pin).  The reference program has one instance per process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import cfpin; rows = cfpin.run_reference(%r); "
+            "[r.__setitem__('pose_log', [list(map(float, p)) for p in r['pose_log']]) for r in rows]; print('CFPIN_JSON' + json.dumps(rows))"
+            % (here, os.path.dirname(here), name))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+    line = [l for l in out.split("\n") if l.startswith("CFPIN_JSON")][-1]
+    return json.loads(line[len("CFPIN_JSON"):])
+
+
+def differences(ref_rows, orc_rows, keys=("ids", "counts", "poses", "surfels", "unseen", "mask", "tick")):
+    out = []
+    for t, (a, b) in enumerate(zip(ref_rows, orc_rows)):
+        for k in keys:
+            if a[k] != b[k]:
+                out.append(f"frame {t}: {k}: reference {a[k]} vs oracle {b[k]}")
+        if len(a["conf"]) != len(b["conf"]) or any(abs(x - y) > CONF_RTOL * max(abs(x), 1e-3) for x, y in zip(a["conf"], b["conf"])):
+            out.append(f"frame {t}: conf: reference {a['conf']} vs oracle {b['conf']}")
+    if len(ref_rows) != len(orc_rows):
+        out.append("different number of frames")
+    return out

@@ -1,0 +1,55 @@
+"""ctypes binding of the reference's OWN frame loop -- CoFusion::processFrame and its helpers, cut out of Core/CoFusion.cpp at build
+time and compiled into oracle/_ref/libcofusion_ref.so behind oracle/ref_shim/stub/CoFusionPin.h (every pass of a frame runs on the
+CPU oracle; Core/Segmentation is the reference's own as well).  Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+import ref
+from orc import P, f32, u8
+
+
+class RefCoFusion:
+    def __init__(self, cam, conf_global=10.0, conf_object=0.01, depth_cutoff=5.0, icp_weight=10.0, so3=True, spawn_offset=20, multi=True):
+        self.lib = ref.lib()
+        self.lib.ref_cf_create.restype = C.c_void_p
+        self.w, self.h = cam.width, cam.height
+        self.h_ = self.lib.ref_cf_create(self.w, self.h, C.c_float(cam.fx), C.c_float(cam.fy), C.c_float(cam.cx), C.c_float(cam.cy),
+                                         C.c_float(conf_global), C.c_float(conf_object), C.c_float(depth_cutoff), C.c_float(icp_weight),
+                                         int(so3), C.c_uint(spawn_offset), int(multi))
+
+    def __del__(self):
+        if getattr(self, "h_", None):
+            self.lib.ref_cf_destroy(C.c_void_p(self.h_))
+            self.h_ = None
+
+    def process_frame(self, depth, rgb, gt_mask=None, timestamp=0):
+        self.lib.ref_cf_process_frame(C.c_void_p(self.h_), P(f32(depth)), P(u8(rgb)), P(u8(gt_mask)) if gt_mask is not None else None,
+                                      C.c_longlong(timestamp))
+
+    @property
+    def num_models(self):
+        return self.lib.ref_cf_num_models(C.c_void_p(self.h_))
+
+    @property
+    def tick(self):
+        return self.lib.ref_cf_tick(C.c_void_p(self.h_))
+
+    def model(self, i):
+        mid = C.c_uint(); conf = C.c_float(); unseen = C.c_uint(); nlog = C.c_int()
+        pose = np.zeros(16, np.float32)
+        n = self.lib.ref_cf_model_info(C.c_void_p(self.h_), i, C.byref(mid), P(pose), C.byref(conf), C.byref(unseen), C.byref(nlog))
+        s = np.zeros((n, 12), np.float32)
+        if n:
+            self.lib.ref_cf_model_surfels(C.c_void_p(self.h_), i, P(s))
+        log = np.zeros(7, np.float32)
+        self.lib.ref_cf_model_last_pose_log(C.c_void_p(self.h_), i, P(log))
+        return dict(id=mid.value, pose=pose.reshape(4, 4), conf_threshold=np.float32(conf.value), unseen=unseen.value, count=n, surfels=s,
+                    pose_log_items=nlog.value, last_pose_log=log)
+
+    def mask(self):
+        m = np.zeros((self.h, self.w), np.uint8)
+        self.lib.ref_cf_mask(C.c_void_p(self.h_), P(m))
+        return m

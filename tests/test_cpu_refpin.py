@@ -363,3 +363,42 @@ def test_gn_loop_fixture_is_what_the_reference_class_produces():
     assert refpin.bits_equal(tr, z[key + "/trans"]) and refpin.bits_equal(rot, z[key + "/rot"])
     assert st["last_rgb_count"] == z[key + "/stats"][3] and st["last_so3_count"] == z[key + "/stats"][5]
     assert np.array_equal(st["lastA"], z[key + "/lastA"]) and np.array_equal(st["lastb"], z[key + "/lastb"])
+
+
+# ---- the frame loop: oracle vs the reference's own CoFusion::processFrame text ----------------------------------------------------
+CF_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_cofusion_v1.json")
+
+
+def _cf_golden():
+    import json
+    with open(CF_GOLDEN) as f:
+        return json.load(f)["scenarios"]
+
+
+def test_frame_loop_matches_reference_process_frame():
+    """the oracle's restatement of the frame loop (orc_multi.MultiPipeline / orc_pipeline.StaticPipeline, which the
+    C++ facade is tested against bit for bit) against CoFusion::processFrame + performSegmentation / predict / requiresFillIn /
+    spawnObjectModel / moveNewModelToList / inactivateModel / getNextModelID as they stand in /root/reference/Core/CoFusion.cpp, with
+    the reference's own Core/Segmentation: model list, ids, poses, surfel buffers, unseen counters, label masks and the clock identical
+    in every frame (3 + 7 spawns, 2 + 5 deactivations, id re-use, ground-truth masks, fill-in tracking, single-model mode)."""
+    import cfpin
+    gold = _cf_golden()
+    assert set(gold) == set(cfpin.SCENARIOS)
+    spawns = drops = 0
+    for name, ref_rows in gold.items():
+        orc_rows = cfpin.run_oracle(name)
+        diffs = cfpin.differences(ref_rows, orc_rows)
+        assert not diffs, f"{name}: " + "; ".join(diffs[:4])
+        n = [len(r["ids"]) for r in ref_rows]
+        spawns += sum(1 for a, b in zip(n, n[1:]) if b > a); drops += sum(1 for a, b in zip(n, n[1:]) if b < a)
+    assert spawns >= 10 and drops >= 5, "the scenarios no longer exercise spawning / deactivation"
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_frame_loop_fixture_is_what_the_reference_text_produces():
+    """the committed fixture is reproducible from the reference sources (two scenarios, each in a process of its own)"""
+    import cfpin
+    gold = _cf_golden()
+    for name in ("crf_two_objects", "gt_masks_three_objects"):
+        rows = cfpin.run_reference_isolated(name)
+        assert rows == gold[name], f"{name}: the reference frame loop no longer produces the committed fixture"
