@@ -18,6 +18,8 @@
  *            with a fixed-size Eigen stand-in (Eigen is absent; its rounding conventions are stated in
  *            oracle/ref_shim/eigen_fixed/Eigen/Core): counts identical, poses within 5e-6 (ref_odo_v1.npz).
  *            orc_segment.c's host logic: against Segmentation.cpp / Slic.* / ConnectedLabels.hpp (ref_seg_v1.npz).
+ *            The frame loop (tests/orc_multi.py, tests/orc_pipeline.py): against the text of CoFusion::processFrame and its
+ *            helpers (ref_cofusion_v1.json): identical bits.
  *   UNPINNED the two third-party algorithms that are not in the tree (gSLICr, densecrf): stated in orc_segment.c.
  *
  * Data layouts (identical to the HIP C-ABI in include/cofusion_hip.h):
