@@ -858,6 +858,8 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     fill_icp_args(ctx, ods, n, icp_args);
     RgbArgs rgb_args[3];
     fill_rgb_args(ctx, ods, n, rgb_args);
+    OdomDev* h_states[kMaxBatch];
+    for (int m = 0; m < n; m++) h_states[m] = ods[m]->h_state;
     GnHook hook{};
     hook.fn = ctx->collective; hook.user = ctx->collective_user;
     bool any_split = false;
@@ -884,7 +886,7 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
             bool ok = hipStreamBeginCapture(ctx->own_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 launch_gn_track(ctx->own_stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, nullptr, icp_args, rgb_args, n, ctx->cfg.width,
-                                ctx->cfg.height, opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, nullptr);
+                                ctx->cfg.height, opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, nullptr, h_states);
                 ok = hipStreamEndCapture(ctx->own_stream, &g) == hipSuccess && g != nullptr;
             }
             if (ok) ok = hipGraphInstantiate(&ctx->gn_graph, g, nullptr, nullptr, 0) == hipSuccess;
@@ -899,17 +901,12 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     }
     if (!launched &&
         !launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, any_split ? &hook : nullptr, icp_args, rgb_args, n,
-                         ctx->cfg.width, ctx->cfg.height, opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, prof)) {
+                         ctx->cfg.width, ctx->cfg.height, opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, prof, h_states)) {
         ctx->set_error("tracking: the registered collective failed inside the Gauss-Newton loop");
         return CF_ESTATE;
     }
     LAUNCHCHK(ctx);
-    if (lo >= 0) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_state_pool + lo, ctx->d_state_pool + lo, sizeof(OdomDev) * (hi - lo + 1), hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-        for (int m = 0; m < n; m++)
-            HIPCHK(ctx, hipMemcpyAsync(ods[m]->h_state, ods[m]->d_state, sizeof(OdomDev), hipMemcpyDeviceToHost, ctx->stream));
-    }
+    // no read-back copy: the last solve of the schedule wrote every tracker's result into its pinned host state (h_states)
     ctx->state_readback_pending = true;
     return CF_OK;
 }

@@ -192,11 +192,11 @@ static int sync_count(cf_model* m)
     HIPCHK(ctx, hipStreamSynchronize(ctx->cur()));
     return adopt_count(m);
 }
-// enqueue the read-back of the device count; until it lands count_host holds `upper_bound`
+// the compaction that was just enqueued writes the new count into pinned host memory itself (h_counts[0]); the event marks when
+// it has landed.  Until then count_host holds `upper_bound`
 static int post_count(cf_model* m, uint32_t upper_bound)
 {
     cf_ctx* ctx = m->ctx;
-    HIPCHK(ctx, hipMemcpyAsync(m->h_counts, m->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->cur()));
     HIPCHK(ctx, hipEventRecord(m->count_event, ctx->cur()));
     m->count_host = upper_bound;
     m->count_pending = true;
@@ -334,9 +334,8 @@ int cf_model_prefetch_fill_ratio(cf_model* m)
 {
     if (!m) return CF_EINVAL;
     cf_ctx* ctx = m->ctx;
-    launch_fill_ratio(ctx->cur(), m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2);
+    launch_fill_ratio(ctx->cur(), m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2, m->h_counts + 2);  // the kernel publishes to pinned memory
     LAUNCHCHK(ctx);
-    HIPCHK(ctx, hipMemcpyAsync(m->h_counts + 2, m->d_tmp2 + 2, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->cur()));
     HIPCHK(ctx, hipEventRecord(m->ratio_event, ctx->cur()));
     m->ratio_valid = true;
     return CF_OK;
@@ -361,9 +360,8 @@ int cf_model_requires_fill_in(cf_model* m, float ratio, int* out)
     if (m->ratio_valid) {
         HIPCHK(ctx, hipEventSynchronize(m->ratio_event));
     } else {
-        launch_fill_ratio(ctx->cur(), m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2);
+        launch_fill_ratio(ctx->cur(), m->splat_image, ctx->cfg.width, ctx->cfg.height, m->d_tmp2 + 2, m->h_counts + 2);
         LAUNCHCHK(ctx);
-        HIPCHK(ctx, hipMemcpyAsync(m->h_counts + 2, m->d_tmp2 + 2, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->cur()));
         HIPCHK(ctx, hipStreamSynchronize(ctx->cur()));
     }
     *out = ((float)m->h_counts[2] / (float)m->h_counts[3] < ratio) ? 1 : 0;
@@ -410,7 +408,7 @@ int cf_model_clean(cf_model* m, const float pose[16], int time, float confThresh
     inv44f(pose, a.t_inv); a.cam = ctx_cam(ctx); a.cols = W; a.rows = H; a.time = time; a.confThreshold = confThreshold;
     a.outlierCoeff = outlierCoeff; a.timeDelta = timeDelta; a.maskID = maskID;
     launch_clean(s, m->buf[m->target], m->d_count, m->fresh, m->d_nfresh, bound, a, m->staged, m->flags);
-    launch_scan_scatter(s, m->staged, m->flags, bound, m->block_sums, m->d_count, 0, m->buf[1 - m->target]);  // the kept total IS the new count
+    launch_scan_scatter(s, m->staged, m->flags, bound, m->block_sums, m->d_count, 0, m->buf[1 - m->target], m->h_counts);  // the kept total IS the new count
     m->target = 1 - m->target;
     LAUNCHCHK(ctx);
     const uint32_t upper = bound < m->max_surfels ? bound : m->max_surfels;

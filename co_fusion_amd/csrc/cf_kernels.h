@@ -122,6 +122,7 @@ struct GnArgs {
     OdomDev* od[kMaxBatch];
     unsigned long long* icp_acc[kMaxBatch];
     unsigned long long* rgb_acc[kMaxBatch];
+    OdomDev* od_host[kMaxBatch];   // nullable: pinned host copies of the states; the LAST solve of a schedule publishes its result there
 };
 // RGB residual / RGB step arguments (by value): everything but the pose-dependent state arrives in the kernarg
 struct RgbModelArgs {
@@ -189,7 +190,8 @@ struct So3Sync { unsigned long long acc[10][16]; unsigned arrive, depart; };
 struct GnHook { int (*fn)(void* user, int op, void* dev_buf, uint64_t words, void* stream); void* user; int split[kMaxBatch]; };
 bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */, So3Sync* so3_syncs /* [n] */,
                      const GnHook* hook, const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3,
-                     bool pyramid, bool fast_odom, bool rgb, bool icp, int mode, ProfSink* prof);
+                     bool pyramid, bool fast_odom, bool rgb, bool icp, int mode, ProfSink* prof,
+                     OdomDev* const* h_states = nullptr /* [n] pinned host copies the last solve publishes to */);
 float sqrt_gate_lt(float T);  // smallest x with sqrtf(x) >= T
 float sqrt_gate_le(float T);  // largest x with sqrtf(x) <= T
 
@@ -211,7 +213,7 @@ void launch_bilateral(hipStream_t s, const float* depth, int cols, int rows, flo
 void launch_exclusive_scan(hipStream_t s, const unsigned* flags, long long n, unsigned* offsets, unsigned* block_sums, unsigned* total,
                            unsigned add_to_total);
 void launch_scan_scatter(hipStream_t s, const float* rec, const unsigned* flags, long long n, unsigned* block_sums, unsigned* total,
-                         unsigned add_to_total, float* out);
+                         unsigned add_to_total, float* out, unsigned* total_host = nullptr /* pinned mirror of *total */);
 void launch_feedback(hipStream_t s, const uint8_t* rgba, const float* depth, int cols, int rows, cf_cam cam, float inv_fx, float inv_fy,
                      const float* tcx, const float* tcy, int time, float maxDepth, float* rec, unsigned* flags);
 void launch_scatter_records(hipStream_t s, const float* rec, const unsigned* flags, const unsigned* offsets, long long n, float* out,
@@ -230,7 +232,7 @@ void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned
                              const float* rays, unsigned long long* keys, uint8_t* image, float* vertexConf, float* normalRad, uint16_t* time16);
 void launch_fill_in(hipStream_t s, const float* pv, const float* pn, const uint8_t* pimg, const float* depth, const uint8_t* rgba, int cols,
                     int rows, cf_cam cam, float inv_fx, float inv_fy, int pass_geom, int pass_rgb, float* ov, float* on, uint8_t* oi);
-void launch_fill_ratio(hipStream_t s, const uint8_t* pimg, int cols, int rows, unsigned* out2);
+void launch_fill_ratio(hipStream_t s, const uint8_t* pimg, int cols, int rows, unsigned* out2, unsigned* out2_host = nullptr /* pinned */);
 void launch_associate(hipStream_t s, const SurfelFuseArgs& h);
 void launch_update(hipStream_t s, const float* in, const unsigned* count, unsigned count_bound, unsigned* owner, const float* records, int time,
                    float* out);

@@ -530,6 +530,8 @@ struct SegPostArgs {
     int* cc;                         // scratch [6][K]: label, size, top, right, bottom, left per component
     unsigned char* low_map;          // [K] out
     cf_seg_result* result;           // device copy of the result
+    cf_seg_result* result_host;      // pinned: the kernel publishes the decisions itself (no copy command behind it on the stream)
+    unsigned* low_map_host;          // pinned, [ceil(K / 4)] words
 };
 
 // arg-max labels -> connected components (ConnectedLabels.hpp:50-172: 4-connectivity, components numbered by their first pixel in
@@ -550,7 +552,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
     __shared__ unsigned s_spc[kMaxL + 1];
     __shared__ unsigned s_best[256];
     __shared__ int s_reject[kMaxL + 1];
-    __shared__ unsigned char map[kSegMaxK];
+    __shared__ __attribute__((aligned(4))) unsigned char map[kSegMaxK];
     __shared__ int parent[kSegMaxK];
     __shared__ int comp[kSegMaxK];
     __shared__ int s_cc[6 * kCcLds];
@@ -744,6 +746,16 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
         if (a.allow_new) { if (s_spc[n_md - 1] > 0) has_new = 1; else n_out = n_md - 1; }
         a.result->has_new_label = has_new; a.result->n_models = n_out; a.result->depth_range = a.depth_range[0];
     }
+    // publish: decisions and the low-resolution map into pinned host memory (what the frame's one host wait collects)
+    __threadfence_block();
+    __syncthreads();
+    if (a.result_host) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(a.result);
+        unsigned* dst = reinterpret_cast<unsigned*>(a.result_host);
+        for (int k = tid; k < (int)(sizeof(cf_seg_result) / 4); k += T) dst[k] = src[k];
+    }
+    if (a.low_map_host)
+        for (int k = tid; k < (K + 3) / 4; k += T) a.low_map_host[k] = reinterpret_cast<const unsigned*>(map)[k];
 }
 
 
@@ -932,7 +944,7 @@ int cf_seg_create(cf_ctx* ctx, cf_segmenter** out)
     if (int r = seg_malloc(ctx, &s->cc, 6 * K)) return r;
     if (int r = seg_malloc(ctx, &s->d_result, (size_t)1)) return r;
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(cf_seg_result)));
-    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_low_map), K));
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_low_map), ((size_t)K + 3) / 4 * 4));  // written as 32-bit words by seg_post_kernel
     memset(s->h_result, 0, sizeof(cf_seg_result));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return CF_OK;
@@ -1161,12 +1173,11 @@ int cf_seg_infer(cf_segmenter* s, const cf_seg_params* P, const uint8_t* rgba, i
     if (allow_new) p.ids[n_models] = next_model_id;
     p.Q = q; p.low_depth = s->low_mean; p.avg_conf = s->avg_conf; p.depth_range = s->depth_range;
     p.parent = s->parent; p.comp = s->comp; p.cc = s->cc; p.low_map = s->low_map; p.result = s->d_result;
+    p.result_host = s->h_result; p.low_map_host = reinterpret_cast<unsigned*>(s->h_low_map);
     seg_post_kernel<<<1, 1024, 0, st>>>(p);
     const int N = ctx->cfg.width * ctx->cfg.height;
     seg_upsample_kernel<<<(N + 255) / 256, 256, 0, st>>>(s->labels, s->low_map, N, full_dev);
     LAUNCHCHK(ctx);
-    HIPCHK(ctx, hipMemcpyAsync(s->h_result, s->d_result, sizeof(cf_seg_result), hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(s->h_low_map, s->low_map, (size_t)n, hipMemcpyDeviceToHost, st));
     if (s->poses_published) {  // the tail now holds what the caller's all-reduce made of it; the next frame starts from zeros again
         long long* tail = reinterpret_cast<long long*>(s->icp_sum) + 2 * (size_t)kMaxL * s->K;
         HIPCHK(ctx, hipMemcpyAsync(s->h_pose_tail, tail, sizeof(long long) * kMaxL * kPoseWords, hipMemcpyDeviceToHost, st));

@@ -135,13 +135,14 @@ __global__ void __launch_bounds__(256) scan_offsets_kernel(const unsigned* __res
 }
 
 __global__ void set_count_kernel(unsigned* out, unsigned v);
+__global__ void set_count2_kernel(unsigned* out, unsigned* out_host, unsigned v);
 // Ordered compaction in TWO launches (scan_block_sums_kernel, then this): every workgroup derives its own base from the block
 // sums of the workgroups before it (at most a few hundred values), scans its 2048 flags -- eight consecutive flags per thread, so
 // one pass and two barriers -- and moves the flagged 48 B records straight to their place; the last workgroup publishes the total.
 // Replaces {spine scan, per-element offsets, scatter} = three launches and an offsets array.
 __global__ void __launch_bounds__(256) scan_scatter_kernel(const float4* __restrict__ rec, const unsigned* __restrict__ flags, long long n,
                                                            const unsigned* __restrict__ block_sums, unsigned* __restrict__ total,
-                                                           unsigned add_to_total, float4* __restrict__ out)
+                                                           unsigned add_to_total, float4* __restrict__ out, unsigned* __restrict__ total_host)
 {
     __shared__ unsigned wsum[4], s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -177,17 +178,20 @@ __global__ void __launch_bounds__(256) scan_scatter_kernel(const float4* __restr
             out[o] = rec[r]; out[o + 1] = rec[r + 1]; out[o + 2] = rec[r + 2];
             off++;
         }
-    if (blockIdx.x == gridDim.x - 1 && tid == 255) *total = off + add_to_total;  // the last thread's running offset is the total
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) {  // the last thread's running offset is the total
+        *total = off + add_to_total;
+        if (total_host) *total_host = off + add_to_total;  // pinned host memory: the read-back needs no copy command on the stream
+    }
 }
 
 void launch_scan_scatter(hipStream_t s, const float* rec, const unsigned* flags, long long n, unsigned* block_sums, unsigned* total,
-                         unsigned add_to_total, float* out)
+                         unsigned add_to_total, float* out, unsigned* total_host)
 {
     const int nb = (int)((n + kScanItems - 1) / kScanItems);
-    if (nb == 0) { set_count_kernel<<<1, 1, 0, s>>>(total, add_to_total); return; }
+    if (nb == 0) { set_count2_kernel<<<1, 1, 0, s>>>(total, total_host, add_to_total); return; }
     scan_block_sums_kernel<<<nb, 256, 0, s>>>(flags, n, block_sums);
     scan_scatter_kernel<<<nb, 256, 0, s>>>(reinterpret_cast<const float4*>(rec), flags, n, block_sums, total, add_to_total,
-                                           reinterpret_cast<float4*>(out));
+                                           reinterpret_cast<float4*>(out), total_host);
 }
 
 void launch_exclusive_scan(hipStream_t s, const unsigned* flags, long long n, unsigned* offsets, unsigned* block_sums, unsigned* total,
@@ -443,7 +447,8 @@ __global__ void __launch_bounds__(kB) fill_in_kernel(const float4* __restrict__ 
 }
 
 // CoFusion::requiresFillIn (CoFusion.cpp:547-565): one workgroup counts the 20x down-sampled image
-__global__ void __launch_bounds__(1024) fill_ratio_kernel(const uchar4* __restrict__ pimg, int cols, int rows, unsigned* __restrict__ out2)
+__global__ void __launch_bounds__(1024) fill_ratio_kernel(const uchar4* __restrict__ pimg, int cols, int rows, unsigned* __restrict__ out2,
+                                                          unsigned* __restrict__ out2_host)
 {
     const int dw = cols / 20, dh = rows / 20;
     unsigned s = 0;
@@ -461,6 +466,7 @@ __global__ void __launch_bounds__(1024) fill_ratio_kernel(const uchar4* __restri
         unsigned t = 0;
         for (int k = 0; k < 16; k++) t += w[k];
         out2[0] = t; out2[1] = (unsigned)(dw * dh);
+        if (out2_host) { out2_host[0] = t; out2_host[1] = (unsigned)(dw * dh); }
     }
 }
 
@@ -794,6 +800,7 @@ __global__ void __launch_bounds__(kB) clean_kernel(const float4* __restrict__ su
 
 __global__ void add_counts_kernel(const unsigned* a, const unsigned* b, unsigned* out) { *out = *a + *b; }
 __global__ void set_count_kernel(unsigned* out, unsigned v) { *out = v; }
+__global__ void set_count2_kernel(unsigned* out, unsigned* out_host, unsigned v) { *out = v; if (out_host) *out_host = v; }
 
 // ------------------------------------------------------------------------------- launchers ----
 void launch_bilateral(hipStream_t s, const float* depth, int cols, int rows, float maxD, float* out)
@@ -868,9 +875,9 @@ void launch_fill_in(hipStream_t s, const float* pv, const float* pn, const uint8
         reinterpret_cast<const uchar4*>(rgba), cols, rows, cam.cx, cam.cy, inv_fx, inv_fy, pass_geom, pass_rgb, reinterpret_cast<float4*>(ov),
         reinterpret_cast<float4*>(on), reinterpret_cast<uchar4*>(oi));
 }
-void launch_fill_ratio(hipStream_t s, const uint8_t* pimg, int cols, int rows, unsigned* out2)
+void launch_fill_ratio(hipStream_t s, const uint8_t* pimg, int cols, int rows, unsigned* out2, unsigned* out2_host)
 {
-    fill_ratio_kernel<<<1, 1024, 0, s>>>(reinterpret_cast<const uchar4*>(pimg), cols, rows, out2);
+    fill_ratio_kernel<<<1, 1024, 0, s>>>(reinterpret_cast<const uchar4*>(pimg), cols, rows, out2, out2_host);
 }
 void launch_associate(hipStream_t s, const SurfelFuseArgs& h)
 {

@@ -800,7 +800,7 @@ __device__ __forceinline__ void se3_unpack_word(const unsigned long long* sums, 
 //  * only Rodrigues and the 3x3 pose composition stay on one lane.
 // Must be called by all 256 threads of a workgroup.
 __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* icp_acc, unsigned long long* rgb_acc, int next_level,
-                                              int last_of_level)
+                                              int last_of_level, OdomDev* god_host)
 {
     __shared__ OdomDev s_od;
     __shared__ unsigned long long s_icp[32], s_rgb[32];
@@ -944,11 +944,15 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
     }
     __syncthreads();
     for (int k = kMutableFrom + tid; k < kWords; k += 256) reinterpret_cast<unsigned*>(god)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
+    // end of the schedule: the result (pose, statistics, fault word) goes to the tracker's pinned host copy as well -- the frame's host
+    // wait finds it there without a copy command behind the loop on the stream
+    if (god_host && next_level < 0)
+        for (int k = kMutableFrom + tid; k < kWords; k += 256) reinterpret_cast<unsigned*>(god_host)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
 }
 
 __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int next_level, int last_of_level)
 {
-    gn_solve_body(args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level);
+    gn_solve_body(args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level, args.od_host[blockIdx.x]);
 }
 
 // RGB step over the per-workgroup record slots the residual pass left (grid: one workgroup per slot x models).  A slot holds at
@@ -1070,7 +1074,7 @@ void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, 
 // Kept as separate launches.
 bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const GnHook* hook, const IcpArgs icp_args[3],
                      const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, int mode,
-                     ProfSink* prof)
+                     ProfSink* prof, OdomDev* const* h_states)
 {
     int iterations[3];
     iterations[0] = fast_odom ? 3 : 10;
@@ -1084,6 +1088,7 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
         gn.od[m] = const_cast<OdomDev*>(icp_args[0].m[m].st);
         gn.icp_acc[m] = icp_args[0].m[m].acc;
         gn.rgb_acc[m] = icp_args[0].m[m].rgb_acc;
+        gn.od_host[m] = h_states ? h_states[m] : nullptr;
     }
     const bool slots = mode != 0;
     bool hook_failed = false;
