@@ -58,7 +58,7 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     if (int r = dmalloc(ctx, &ctx->d_out, 64)) return r;
     if (int r = dmalloc(ctx, &ctx->d_scratch_state, 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_state_pool, (size_t)cf_ctx::kStateSlots)) return r;
-    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state_pool), sizeof(OdomDev) * cf_ctx::kStateSlots));
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state_pool), sizeof(OdomDev) * cf_ctx::kStateSlots, hipHostMallocCoherent));  // the last solve stores into it
     memset(ctx->h_state_pool, 0, sizeof(OdomDev) * cf_ctx::kStateSlots);
     if (int r = dmalloc(ctx, &ctx->d_model_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_so3_sync, (size_t)ctx->cfg.max_models + 1)) return r;
@@ -534,7 +534,7 @@ int cf_odom_create(cf_ctx* ctx, cf_odom** out)
         HIPCHK(ctx, hipMemsetAsync(od->d_state, 0, sizeof(OdomDev), ctx->stream));
     } else {
         if (int r = dmalloc(ctx, &od->d_state, 1)) return r;
-        HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&od->h_state), sizeof(OdomDev)));
+        HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&od->h_state), sizeof(OdomDev), hipHostMallocCoherent));
     }
     memset(od->h_state, 0, sizeof(OdomDev));
     // RGBDOdometry ctor defaults: RGBDOdometry.h:45-46, RGBDOdometry.cpp:31-36,103-105

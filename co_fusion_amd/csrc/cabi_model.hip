@@ -149,7 +149,7 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     if (int r = dmalloc(ctx, &m->tcy, (size_t)H)) return r;
     if (int r = dmalloc(ctx, &m->rays, N * 4)) return r;
     launch_splat_rays(ctx->cur(), ctx_cam(ctx), W, H, m->rays);
-    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->h_counts), sizeof(unsigned) * 4));
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->h_counts), sizeof(unsigned) * 4, hipHostMallocCoherent));  // kernels store the counts here
     HIPCHK(ctx, hipEventCreateWithFlags(&m->count_event, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&m->ratio_event, hipEventDisableTiming));
     // texcoords exactly as the reference builds its uv buffer (Model.cpp:166-170)

@@ -943,8 +943,8 @@ int cf_seg_create(cf_ctx* ctx, cf_segmenter** out)
     if (int r = seg_malloc(ctx, &s->comp, K)) return r;
     if (int r = seg_malloc(ctx, &s->cc, 6 * K)) return r;
     if (int r = seg_malloc(ctx, &s->d_result, (size_t)1)) return r;
-    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(cf_seg_result)));
-    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_low_map), ((size_t)K + 3) / 4 * 4));  // written as 32-bit words by seg_post_kernel
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_result), sizeof(cf_seg_result), hipHostMallocCoherent));  // seg_post_kernel stores into it
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_low_map), ((size_t)K + 3) / 4 * 4, hipHostMallocCoherent));  // written as 32-bit words by seg_post_kernel
     memset(s->h_result, 0, sizeof(cf_seg_result));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return CF_OK;
