@@ -107,7 +107,7 @@ int CoFusion::exportPoses(const std::string& exportDir)
             if (!f) { written = -1; return; }
             for (const auto& p : m->poseLog) {
                 fprintf(f, "%lld", (long long)p.ts);
-                for (int i = 0; i < 7; i++) fprintf(f, " %.9g", (double)p.p[i]);
+                for (int i = 0; i < 7; i++) fprintf(f, " %g", (double)p.p[i]);  // == `fs << p.p(i)` (CoFusion.cpp:773): six significant digits
                 fprintf(f, "\n");
             }
             fclose(f);
