@@ -32,6 +32,9 @@ SCENARIOS = {
     "objects4_640": dict(W=640, H=480, n_obj=4, frames=64, multi=True, conf_global=0.5, spawn_offset=2),
     # configs[1] at its own size, long free run
     "static_640": dict(W=640, H=480, n_obj=0, frames=100, multi=False, conf_global=10.0),
+    # "C2 / C3 at 300 frames" -- the same two streams played for 300 frames
+    "static_640_300": dict(W=640, H=480, n_obj=0, frames=300, multi=False, conf_global=10.0),
+    "objects4_640_300": dict(W=640, H=480, n_obj=4, frames=300, multi=True, conf_global=0.5, spawn_offset=2),
     # configs[4]'s frame size (static part: one 1280x960 model)
     "static_1280": dict(W=1280, H=960, n_obj=0, frames=3, multi=False, conf_global=10.0),
 }
