@@ -35,6 +35,8 @@ SCENARIOS = {
     # "C2 / C3 at 300 frames" -- the same two streams played for 300 frames
     "static_640_300": dict(W=640, H=480, n_obj=0, frames=300, multi=False, conf_global=10.0),
     "objects4_640_300": dict(W=640, H=480, n_obj=4, frames=300, multi=True, conf_global=0.5, spawn_offset=2),
+    # configs[0] / SURVEY's C1: `-static` on a scene whose 4 objects move unsegmented (one model, all-zero mask), 300 frames
+    "static_moving4_640_300": dict(W=640, H=480, n_obj=4, frames=300, multi=False, conf_global=10.0),
     # configs[4]'s frame size (static part: one 1280x960 model)
     "static_1280": dict(W=1280, H=960, n_obj=0, frames=3, multi=False, conf_global=10.0),
 }
