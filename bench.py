@@ -64,6 +64,8 @@ WORKLOADS = {
     "objects4-gt": dict(n_obj=4, size=(640, 480), config="configs[2] with ground-truth masks",
                         desc="4 moving objects + background, ground-truth label masks"),
     "objects8": dict(n_obj=8, size=(640, 480), config="configs[3]", desc="8 moving objects + background, motion-CRF segmentation on"),
+    "big-static": dict(n_obj=0, size=(1280, 960), config="configs[4]'s frame size, one model", desc="1280x960, single static background model",
+                       max_surfels=1 << 23),
     "big": dict(n_obj=4, size=(1280, 960), config="configs[4]", desc="1280x960, 4 moving objects + background, 32 M surfels per model",
                 max_surfels=1 << 25),
 }
