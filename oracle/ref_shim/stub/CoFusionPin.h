@@ -101,65 +101,32 @@ class CoFusion {
     void filterDepth();              // ref_cofusion.cpp (bilateral filter on the oracle)
     bool requiresFillIn(ModelPointer model, float ratio = 0.75f);
 
-    // CoFusion.h:266-391
-    ModelList models;
-    ModelList inactiveModels;
-    ModelList preallocatedModels;
-    ModelPointer newModel;
-    std::shared_ptr<Model> globalModel;
+    // state the frame loop reads and writes (what CoFusion.h:266-391 declares for it), grouped by type; defaults as in that header
+    ModelList models, inactiveModels, preallocatedModels;   // models.front() is the static environment
+    ModelPointer newModel, globalModel;
     unsigned char nextID = 0;
     Segmentation labelGenerator;
     Model::MatchingType modelMatchingType;
-    CallbackBuffer<std::shared_ptr<Model>> newModelListeners;
-    CallbackBuffer<std::shared_ptr<Model>> inactiveModelListeners;
+    CallbackBuffer<std::shared_ptr<Model>> newModelListeners, inactiveModelListeners;
     PinOdometry modelToModel;
     Ferns ferns;
-    Deformation localDeformation;
-    Deformation globalDeformation;
+    Deformation localDeformation, globalDeformation;
     std::map<std::string, GPUTexture*> textures;
     std::map<std::string, FeedbackBuffer*> feedbackBuffers;
-    int tick;
-    const int timeDelta;
-    const int icpCountThresh;
-    const float icpErrThresh;
-    const float covThresh;
-    int deforms;
-    int fernDeforms;
-    const int consSample;
     GPUResize resize;
     std::vector<PoseMatch> poseMatches;
     std::vector<Deformation::Constraint> relativeCons;
     Img<Eigen::Matrix<unsigned char, 3, 1>> imageBuff;
     Img<Eigen::Vector4f> consBuff;
     Img<unsigned short> timesBuff;
-    const bool closeLoops;
-    const bool iclnuim;
-    const bool reloc;
-    bool lost;
-    bool lastFrameRecovery;
-    int trackingCount;
-    const float maxDepthProcessed;
-    bool enableMultipleModels = true;
-    bool enableSmartModelDelete = true;
-    bool enableRedetection = false;
-    bool enableModelMerging = false;
-    bool enableSpawnSubtraction = true;
-    bool enablePoseLogging = true;
-    bool rgbOnly;
-    float icpWeight;
-    bool pyramid;
-    bool fastOdom;
-    float initConfThresGlobal;
-    float initConfThresObject;
-    float fernThresh;
-    bool so3;
-    bool frameToFrameRGB;
-    float depthCutoff;
-    unsigned modelDeactivateCount = 10;
-    unsigned modelKeepMinSurfels = 4000;
-    float modelKeepConfThreshold = 0.3;
-    unsigned modelSpawnOffset;
-    unsigned spawnOffset = 0;
-    bool exportSegmentation;
     std::string exportDir;
+    int tick, deforms, fernDeforms, trackingCount;
+    const int timeDelta, icpCountThresh, consSample;
+    const float icpErrThresh, covThresh, maxDepthProcessed;
+    const bool closeLoops, iclnuim, reloc;
+    bool lost, lastFrameRecovery, rgbOnly, pyramid, fastOdom, so3, frameToFrameRGB, exportSegmentation;
+    bool enableMultipleModels = true, enableSmartModelDelete = true, enableRedetection = false, enableModelMerging = false,
+         enableSpawnSubtraction = true, enablePoseLogging = true;
+    float icpWeight, initConfThresGlobal, initConfThresObject, fernThresh, depthCutoff, modelKeepConfThreshold = 0.3;
+    unsigned modelDeactivateCount = 10, modelKeepMinSurfels = 4000, modelSpawnOffset, spawnOffset = 0;
 };
