@@ -215,7 +215,21 @@ void* ref_cf_create(int w, int h, float fx, float fy, float cx, float cy, float 
     return new CoFusion(w, h, fx, fy, cx, cy, conf_global, conf_object, depth_cut, icp_weight, so3 != 0, model_spawn_offset, enable_multiple_models != 0);
 }
 void ref_cf_destroy(void* p) { delete (CoFusion*)p; }
-// depth f32 [H*W] metres, rgb u8 [H*W*3]; gt_mask nullable u8 [H*W] (FrameData::mask)
+// depth f32 [H*W] metres, rgb u8 [H*W*3]; gt_mask nullable u8 [H*W] (FrameData::mask); in_pose nullable row-major 4x4 (the ground-truth
+// odometry of GUI/Tools/GroundTruthOdometry.cpp hands processFrame a pose instead of letting it track)
+int ref_cf_process_frame_pose(void* p, const float* depth, const unsigned char* rgb3, const unsigned char* gt_mask, long long timestamp,
+                              const float* in_pose_row_major)
+{
+    CoFusion* cf = (CoFusion*)p;
+    FrameData frame;
+    frame.timestamp = timestamp;
+    frame.rgb = cv::Mat(g_h, g_w, CV_8UC3, (void*)rgb3);
+    frame.depth = cv::Mat(g_h, g_w, CV_32FC1, (void*)depth);
+    if (gt_mask) frame.mask = cv::Mat(g_h, g_w, CV_8UC1, (void*)gt_mask);
+    Eigen::Matrix4f pose;
+    if (in_pose_row_major) for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) pose(i, j) = in_pose_row_major[i * 4 + j];
+    return cf->processFrame(frame, in_pose_row_major ? &pose : nullptr) ? 1 : 0;
+}
 int ref_cf_process_frame(void* p, const float* depth, const unsigned char* rgb3, const unsigned char* gt_mask, long long timestamp)
 {
     CoFusion* cf = (CoFusion*)p;

@@ -15,7 +15,10 @@ SCENARIOS = {
     "gt_masks_three_objects": (3, 10, 0.5, 2, True, True),
     "gt_masks_fill_in_tracking": (3, 8, 10.0, 2, True, True),
     "static": (2, 5, 10.0, 20, False, False),
+    # ground-truth odometry (processFrame's inPose, CoFusion.cpp:341-343) on frames 2-4 and 7, tracking on the others
+    "static_injected_poses": (0, 9, 0.5, 20, False, False),
 }
+INJECTED = {"static_injected_poses": (2, 3, 4, 7)}
 
 
 def _sha(a):
@@ -34,6 +37,14 @@ def frames_of(name):
     return cam, out
 
 
+def injected_pose(name, t):
+    """the generator's camera pose for the frames a scenario hands to processFrame as inPose, else None"""
+    if t not in INJECTED.get(name, ()):
+        return None
+    from co_fusion_amd import synth
+    return synth.Scene(n_obj=SCENARIOS[name][0]).camera_pose(t).astype(np.float32)
+
+
 def run_reference(name):
     import refcofusion
     _, _, conf_global, spawn, _, multi = SCENARIOS[name]
@@ -41,7 +52,7 @@ def run_reference(name):
     cf = refcofusion.RefCoFusion(cam, conf_global=conf_global, spawn_offset=spawn, multi=multi)
     rows = []
     for t, (d, rgb, _, gt) in enumerate(frames):
-        cf.process_frame(d, rgb, gt_mask=gt, timestamp=t)
+        cf.process_frame(d, rgb, gt_mask=gt, timestamp=t, in_pose=injected_pose(name, t))
         ms = [cf.model(i) for i in range(cf.num_models)]
         rows.append(dict(ids=[m["id"] for m in ms], counts=[m["count"] for m in ms], poses=[_sha(m["pose"]) for m in ms],
                          surfels=[_sha(m["surfels"]) for m in ms], conf=[float(m["conf_threshold"]) for m in ms],
@@ -66,8 +77,8 @@ def run_oracle(name):
     else:
         import orc_pipeline as op
         cf = op.StaticPipeline(cam, conf_global=conf_global)
-        for d, _, rgba, _ in frames:
-            cf.process_frame(d, rgba)
+        for t, (d, _, rgba, _) in enumerate(frames):
+            cf.process_frame(d, rgba, in_pose=injected_pose(name, t))
             rows.append(dict(ids=[0], counts=[cf.surfels.shape[0]], poses=[_sha(cf.pose)], surfels=[_sha(cf.surfels)],
                              conf=[float(np.float32(conf_global))], unseen=[0], mask=_sha(cf.mask), tick=cf.tick))
     return rows

@@ -25,9 +25,9 @@ class RefCoFusion:
             self.lib.ref_cf_destroy(C.c_void_p(self.h_))
             self.h_ = None
 
-    def process_frame(self, depth, rgb, gt_mask=None, timestamp=0):
-        self.lib.ref_cf_process_frame(C.c_void_p(self.h_), P(f32(depth)), P(u8(rgb)), P(u8(gt_mask)) if gt_mask is not None else None,
-                                      C.c_longlong(timestamp))
+    def process_frame(self, depth, rgb, gt_mask=None, timestamp=0, in_pose=None):
+        self.lib.ref_cf_process_frame_pose(C.c_void_p(self.h_), P(f32(depth)), P(u8(rgb)), P(u8(gt_mask)) if gt_mask is not None else None,
+                                           C.c_longlong(timestamp), P(f32(in_pose).reshape(16)) if in_pose is not None else None)
 
     @property
     def num_models(self):
