@@ -215,6 +215,10 @@ void* ref_cf_create(int w, int h, float fx, float fy, float cx, float cy, float 
     return new CoFusion(w, h, fx, fy, cx, cy, conf_global, conf_object, depth_cut, icp_weight, so3 != 0, model_spawn_offset, enable_multiple_models != 0);
 }
 void ref_cf_destroy(void* p) { delete (CoFusion*)p; }
+void ref_cf_set_tracking_options(void* p, int rgb_only, int pyramid, int fast_odom, int frame_to_frame_rgb)
+{
+    ((CoFusion*)p)->setTrackingOptions(rgb_only != 0, pyramid != 0, fast_odom != 0, frame_to_frame_rgb != 0);
+}
 // depth f32 [H*W] metres, rgb u8 [H*W*3]; gt_mask nullable u8 [H*W] (FrameData::mask); in_pose nullable row-major 4x4 (the ground-truth
 // odometry of GUI/Tools/GroundTruthOdometry.cpp hands processFrame a pose instead of letting it track)
 int ref_cf_process_frame_pose(void* p, const float* depth, const unsigned char* rgb3, const unsigned char* gt_mask, long long timestamp,

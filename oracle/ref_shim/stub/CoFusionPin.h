@@ -91,6 +91,8 @@ class CoFusion {
     GPUTexture* maskTexture() { return textures[GPUTexture::MASK]; }
     int getTick() const { return tick; }
     Segmentation& segmentation() { return labelGenerator; }
+    void setTrackingOptions(bool rgbOnly_, bool pyramid_, bool fastOdom_, bool frameToFrameRGB_)   // CoFusion::setRgbOnly / setPyramid / setFastOdom / setFrameToFrameRGB
+    { rgbOnly = rgbOnly_; pyramid = pyramid_; fastOdom = fastOdom_; frameToFrameRGB = frameToFrameRGB_; }
 
   private:
     void spawnObjectModel();

@@ -19,6 +19,19 @@ SCENARIOS = {
     "static_injected_poses": (0, 9, 0.5, 20, False, False),
 }
 INJECTED = {"static_injected_poses": (2, 3, 4, 7)}
+# tracking switches of the frame loop (CoFusion::setFrameToFrameRGB / setFastOdom / setSo3 / setPyramid / setIcpWeight): these scenarios
+# compare the reference's loop with the C++ FACADE (tests/test_configs_gpu.py); the oracle's Python loop does not have the switches
+SCENARIOS.update({
+    "frame_to_frame_rgb": (2, 10, 10.0, 3, False, True),
+    "fast_odom_no_so3_no_pyramid": (2, 10, 0.5, 3, False, True),
+    "icp_only": (1, 8, 0.5, 3, False, True),
+})
+OPTIONS = {
+    "frame_to_frame_rgb": dict(frame_to_frame_rgb=True),
+    "fast_odom_no_so3_no_pyramid": dict(fast_odom=True, so3=False, pyramid=False),
+    "icp_only": dict(icp_weight=100.0),
+}
+FACADE_ONLY = set(OPTIONS)
 
 
 def _sha(a):
@@ -49,7 +62,7 @@ def run_reference(name):
     import refcofusion
     _, _, conf_global, spawn, _, multi = SCENARIOS[name]
     cam, frames = frames_of(name)
-    cf = refcofusion.RefCoFusion(cam, conf_global=conf_global, spawn_offset=spawn, multi=multi)
+    cf = refcofusion.RefCoFusion(cam, conf_global=conf_global, spawn_offset=spawn, multi=multi, **OPTIONS.get(name, {}))
     rows = []
     for t, (d, rgb, _, gt) in enumerate(frames):
         cf.process_frame(d, rgb, gt_mask=gt, timestamp=t, in_pose=injected_pose(name, t))

@@ -12,13 +12,15 @@ from orc import P, f32, u8
 
 
 class RefCoFusion:
-    def __init__(self, cam, conf_global=10.0, conf_object=0.01, depth_cutoff=5.0, icp_weight=10.0, so3=True, spawn_offset=20, multi=True):
+    def __init__(self, cam, conf_global=10.0, conf_object=0.01, depth_cutoff=5.0, icp_weight=10.0, so3=True, spawn_offset=20, multi=True,
+                 rgb_only=False, pyramid=True, fast_odom=False, frame_to_frame_rgb=False):
         self.lib = ref.lib()
         self.lib.ref_cf_create.restype = C.c_void_p
         self.w, self.h = cam.width, cam.height
         self.h_ = self.lib.ref_cf_create(self.w, self.h, C.c_float(cam.fx), C.c_float(cam.fy), C.c_float(cam.cx), C.c_float(cam.cy),
                                          C.c_float(conf_global), C.c_float(conf_object), C.c_float(depth_cutoff), C.c_float(icp_weight),
                                          int(so3), C.c_uint(spawn_offset), int(multi))
+        self.lib.ref_cf_set_tracking_options(C.c_void_p(self.h_), int(rgb_only), int(pyramid), int(fast_odom), int(frame_to_frame_rgb))
 
     def __del__(self):
         if getattr(self, "h_", None):

@@ -386,6 +386,8 @@ def test_frame_loop_matches_reference_process_frame():
     assert set(gold) == set(cfpin.SCENARIOS)
     spawns = drops = 0
     for name, ref_rows in gold.items():
+        if name in cfpin.FACADE_ONLY:  # tracking switches the oracle's Python loop does not have: checked against the facade on the GPU
+            continue
         orc_rows = cfpin.run_oracle(name)
         diffs = cfpin.differences(ref_rows, orc_rows)
         assert not diffs, f"{name}: " + "; ".join(diffs[:4])
