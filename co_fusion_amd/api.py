@@ -39,7 +39,7 @@ class TrackOpts(C.Structure):
 class TrackStats(C.Structure):
     _fields_ = [("last_icp_error", C.c_float), ("last_icp_count", C.c_float), ("last_rgb_error", C.c_float),
                 ("last_rgb_count", C.c_float), ("last_so3_error", C.c_float), ("last_so3_count", C.c_float),
-                ("lastA", C.c_double * 36), ("lastb", C.c_double * 6), ("so3_iterations", C.c_int), ("fault", C.c_int)]
+                ("lastA", C.c_double * 36), ("lastb", C.c_double * 6), ("so3_iterations", C.c_int), ("fault", C.c_int), ("cull_box", C.c_int * 4)]
 
 
 class Profile(C.Structure):

@@ -103,7 +103,18 @@ void cf_destroy(cf_ctx* ctx)
     delete ctx;
 }
 
-const char* cf_last_error(const cf_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+const char* cf_last_error(const cf_ctx* ctx)
+{
+    if (!ctx) return "null ctx";
+    // helper threads bound with cf_thread_lane may fail (and rewrite last_error) at the same time: hand out a per-thread copy taken
+    // under the lock, valid until the calling thread's next cf_last_error
+    static thread_local std::string copy;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<cf_ctx*>(ctx)->error_mutex);
+        copy = ctx->last_error;
+    }
+    return copy.c_str();
+}
 // Switching streams drains the old one first: allocations zero-fill asynchronously on the stream that was current when they
 // were made, and nothing else would order that before the first use on the new stream.
 int cf_set_stream(cf_ctx* ctx, void* s)  // NULL = the legacy default stream
@@ -527,6 +538,7 @@ int cf_odom_create(cf_ctx* ctx, cf_odom** out)
     if (int r = dmalloc(ctx, &od->icp_acc, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &od->rgb_acc, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &od->occ, ((size_t)(W >> 2) * (H >> 2) + 3) / 4 * 4)) return r;
+    if (int r = dmalloc(ctx, &od->aabb, 8)) return r;
     for (int k = 0; k < cf_ctx::kStateSlots && od->slot < 0; k++)
         if (!ctx->slot_used[k]) { ctx->slot_used[k] = true; od->slot = k; }
     if (od->slot >= 0) {
@@ -561,7 +573,7 @@ void cf_odom_destroy(cf_odom* od)
         (void)hipFree(od->dIdx[i]); (void)hipFree(od->dIdy[i]); (void)hipFree(od->cloud[i]); (void)hipFree(od->corres[i]);
         (void)hipFree(od->cand[i]);
     }
-    (void)hipFree(od->icp_acc); (void)hipFree(od->rgb_acc); (void)hipFree(od->occ);
+    (void)hipFree(od->icp_acc); (void)hipFree(od->rgb_acc); (void)hipFree(od->occ); (void)hipFree(od->aabb);
     if (od->slot >= 0) od->ctx->slot_used[od->slot] = false;
     else { (void)hipFree(od->d_state); (void)hipHostFree(od->h_state); }
     delete od;
@@ -579,6 +591,9 @@ static ModelMapsArgs model_maps_args(cf_odom* od, const float* pred_v4, const fl
     const float t[3] = {pose[3], pose[7], pose[11]};
     memcpy(a.R, R, sizeof(R)); memcpy(a.t, t, sizeof(t));
     a.occ = od->occ; od->occ_valid = true;
+    // the bounding box only pays for models that are culled (a model that fills the image would add atomics for nothing)
+    const bool tiled = a.cols % 16 == 0 && a.rows % 4 == 0;  // launch_model_maps: the pass that reduces the box
+    a.aabb = (od->use_occ && tiled) ? od->aabb : nullptr; od->box_valid = a.aabb != nullptr;
     return a;
 }
 static RgbdChain rgbd_chain(cf_odom* od, const uint8_t* rgba, float* const* depths, uint8_t* const* images)
@@ -601,7 +616,7 @@ int cf_odom_init_icp_model(cf_odom* od, const float* pred_v4, const float* pred_
     } else {
         const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
         const float t[3] = {pose[3], pose[7], pose[11]};
-        od->occ_valid = false;
+        od->occ_valid = false; od->box_valid = false;
         HIPCHK(ctx, hipMemcpyAsync(od->vmaps_tmp, pred_v4, (size_t)W * H * 16, hipMemcpyDeviceToDevice, s));
         launch_copy_maps(s, od->vmaps_tmp, pred_n4, W, H, od->vmap_g_prev[0], od->nmap_g_prev[0]);
         for (int i = 1; i < CF_NUM_PYRS; ++i) {
@@ -775,6 +790,8 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
     h->distThres = od->distThres; h->angleThres = od->angleThres; h->sobelScale = od->sobelScale;
     h->maxDepthDeltaRGB = od->maxDepthDeltaRGB; h->icpWeight = opts->icp_weight;
     h->icp = icp; h->rgb = rgb; h->rgbOnly = opts->rgb_only;
+    static const bool no_box = getenv("CF_NO_SCREEN_BOX") != nullptr;  // diagnostics: A/B of the screen-box culling on one box
+    h->aabb_acc = od->aabb; h->cull = (od->use_occ && od->box_valid && od->band_end == 0 && !no_box) ? 1 : 0;
     const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
     const float t[3] = {pose[3], pose[7], pose[11]};
     memcpy(h->Rprev, R, 36); memcpy(h->tprev, t, 12); memcpy(h->Rcurr, R, 36); memcpy(h->tcurr, t, 12);
@@ -821,7 +838,8 @@ static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3
                                   od->ext_nmap_curr[l] ? od->ext_nmap_curr[l] : od->nmap_curr[l],
                                   od->vmap_g_prev[l], od->nmap_g_prev[l], od->d_state, od->icp_acc,
                                   od->h_state->err_surface, od->rgb_acc, (od->use_occ && od->occ_valid) ? od->occ : nullptr,
-                                  od->band_end > 0 ? (od->band_begin >> l) : 0, od->band_end > 0 ? (od->band_end >> l) : 0};
+                                  od->band_end > 0 ? (od->band_begin >> l) : 0, od->band_end > 0 ? (od->band_end >> l) : 0,
+                                  od->h_state->cull};
         }
     }
 }

@@ -62,6 +62,18 @@ __device__ __forceinline__ float qnan() { return __int_as_float(0x7fffffff); }
 __device__ __forceinline__ bool is_nan(float v) { return v != v; }
 __device__ __forceinline__ bool is_finite(float v) { return fabsf(v) < __int_as_float(0x7f800000); }
 
+// order-preserving 32-bit key of a float (a < b  <=>  fkey(a) < fkey(b) for non-NaN values) and its inverse; the
+// bounding boxes the culling tests use are reduced with integer atomicMax on these keys
+__device__ __forceinline__ unsigned fkey(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k)
+{
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
 // __float2int_rn semantics: round-half-even, saturating, NaN -> 0
 __device__ __forceinline__ int f2i_rn(float v)
 {

@@ -92,7 +92,9 @@ struct cf_odom {
     uint8_t* cand[3]{};
     unsigned char* occ = nullptr;    // occupancy map of the model maps (written by model_maps_kernel)
     bool occ_valid = false;          // the map describes the current model maps
-    bool use_occ = false;
+    bool use_occ = false;            // cf_odom_set_culling: occupancy look-up + screen-box culling of the ICP reduction
+    unsigned* aabb = nullptr;        // 8 words: bounding-box accumulator of the model maps (OdomDev::aabb_acc)
+    bool box_valid = false;          // the model-map pass of this frame fed the accumulator
     int band_begin = 0, band_end = 0;  // cf_odom_set_band: this rank's rows of the model's reductions (0, 0: all rows)
     bool band_counts = true;           // this rank adds the residual pass's count / sigma (exactly one rank of a split does)            // cf_odom_set_culling: worth it for models that cover a small part of the image
     unsigned long long* icp_acc = nullptr;

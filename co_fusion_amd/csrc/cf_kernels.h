@@ -40,6 +40,11 @@ struct OdomDev {
     float minGrad[3];
     float icpWeight;
     int icp, rgb, rgbOnly;
+    // screen-box culling of the ICP reduction (cf_odom_set_culling): the global-frame bounding box of the model's predicted vertices is
+    // accumulated by the model-map pass into aabb_acc (6 order-preserving keys, zero = empty), latched into box_lo / box_hi by the first
+    // kernel of the Gauss-Newton loop and re-projected into the current camera after every pose update (ibox)
+    unsigned* aabb_acc;
+    int cull;
     // Gauss-Newton state
     float Rprev[9], tprev[3], Rprev_inv[9], Rcurr[9], tcurr[3];
     double resultRt[16];
@@ -47,6 +52,9 @@ struct OdomDev {
     float lastRGBError;
     int level_done;
     float residual[2];
+    float box_lo[3], box_hi[3];  // bounding box of the model's predicted vertices, global frame (box_lo[0] > box_hi[0]: no valid vertex)
+    // (the screen box itself -- the level-0 pixel rectangle outside of which no pixel of the current frame can find a correspondence
+    // under Rcurr / tcurr -- is stats.cull_box)
     // outputs
     cf_track_stats stats;
 };
@@ -86,6 +94,7 @@ struct ModelMapsArgs {
     int cols, rows;
     float R[9], t[3];
     unsigned char* occ;                          // nullable: occupancy map of the prediction (1 byte per 4x4 block)
+    unsigned* aabb;                              // nullable: bounding box of the transformed level-0 vertices (OdomDev::aabb_acc)
 };
 // batches: one grid row per tracked model (<= kPrepBatch), so that a frame with several models still issues each
 // preparation kernel once
@@ -116,6 +125,7 @@ struct IcpModelArgs {
     const unsigned char* occ;           // nullable: occupancy map of the model maps (model_maps_kernel), 1 byte per 4x4 level-0 block
     int row_begin, row_end;             // row band of THIS model's reduction (row_end == 0: all rows): its share when the model's
                                         // reduction is split over GPUs
+    int cull;                           // workgroups / waves outside st->ibox leave before they load anything
 };
 // solve-kernel arguments (by value)
 struct GnArgs {

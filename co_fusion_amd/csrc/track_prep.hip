@@ -572,6 +572,24 @@ __global__ void __launch_bounds__(256) model_maps_tiled_kernel(const ModelMapsBa
         // occupancy of this 4x4 block: lanes lx..lx+3 of the four tile rows
         if (a.occ) a.occ[i2] = ((valid_bits >> lx) & 0x000F000F000F000Full) != 0 ? 1 : 0;
     }
+    // bounding box of the transformed level-0 vertices (what the ICP reduction gathers as vprev; the coarser levels are averages
+    // of these): the Gauss-Newton loop projects it into the current camera to cull workgroups that cannot find a correspondence.
+    // Six order-preserving keys, atomicMax each (the lower bounds as complemented keys), zero = empty.
+    if (a.aabb && valid_bits != 0) {
+        const float inf = __int_as_float(0x7f800000);
+        float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+        if (valid && !is_nan(v0.p.x)) {
+            const f3 d = mul(R, v0.p) + tr;
+            lo[0] = hi[0] = d.x; lo[1] = hi[1] = d.y; lo[2] = hi[2] = d.z;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64)); }
+        if (lane == 0 && lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])
+#pragma unroll
+            for (int k = 0; k < 3; k++) { atomicMax(&a.aabb[k], ~fkey(lo[k])); atomicMax(&a.aabb[3 + k], fkey(hi[k])); }
+    }
 }
 
 // ------------------------------------------------------------------ launchers ----

@@ -104,6 +104,41 @@ __device__ __forceinline__ IcpProj icp_project(const m33& Rcurr, const f3& tcurr
     return o;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Screen-box culling.  A pixel of the current frame finds a correspondence only if its vertex, moved into the global frame
+// (vcurr_g = Rcurr * vcurr + tcurr), lies within distThres of a predicted model vertex (reduce.cu:321-325), i.e. inside the
+// bounding box of the model's predicted vertices dilated by distThres.  Taken back into the current camera and projected, that
+// box bounds the pixels that can contribute: everything outside adds exact zeros and is skipped before it loads anything.
+// Object models cover a few percent of the image, so most of their workgroups leave after one scalar load.
+// The rectangle is conservative: the box is dilated by 1 % + 1 mm on top of distThres (f32 rounding of the per-pixel
+// arithmetic is ~1e-6 relative), the projection by 3 pixels, and any corner that is not clearly in front of the camera (or not
+// finite) gives the whole image.  Called by a whole wave; the result is valid in every lane.
+__device__ __forceinline__ void screen_box(const float* lo, const float* hi, const float* Rcurr, const float* tcurr, cf_cam intr,
+                                           float distThres, int W, int H, int lane, int (&out)[4])
+{
+    if (!(lo[0] <= hi[0])) { out[0] = 1; out[1] = 1; out[2] = 0; out[3] = 0; return; }  // no predicted vertex: nothing can match
+    const float m = distThres * 1.01f + 1e-3f;
+    const float dx = ((lane & 1) ? hi[0] + m : lo[0] - m) - tcurr[0];
+    const float dy = ((lane & 2) ? hi[1] + m : lo[1] - m) - tcurr[1];
+    const float dz = ((lane & 4) ? hi[2] + m : lo[2] - m) - tcurr[2];
+    // Rcurr^T (Rcurr is a rotation up to f32 rounding)
+    const float xc = Rcurr[0] * dx + Rcurr[3] * dy + Rcurr[6] * dz;
+    const float yc = Rcurr[1] * dx + Rcurr[4] * dy + Rcurr[7] * dz;
+    const float zc = Rcurr[2] * dx + Rcurr[5] * dy + Rcurr[8] * dz;
+    const float u = intr.fx * xc / zc + intr.cx, v = intr.fy * yc / zc + intr.cy;
+    const bool bad = !(zc > 0.05f) || !is_finite(u) || !is_finite(v);
+    float u0 = u, u1 = u, v0 = v, v1 = v;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        u0 = fminf(u0, __shfl_xor(u0, o, 64)); u1 = fmaxf(u1, __shfl_xor(u1, o, 64));
+        v0 = fminf(v0, __shfl_xor(v0, o, 64)); v1 = fmaxf(v1, __shfl_xor(v1, o, 64));
+    }
+    if (__any(bad)) { out[0] = 0; out[1] = 0; out[2] = W - 1; out[3] = H - 1; return; }
+    const float fw = (float)(W + 16), fh = (float)(H + 16);
+    out[0] = (int)floorf(fminf(fmaxf(u0, -16.f), fw)) - 3; out[1] = (int)floorf(fminf(fmaxf(v0, -16.f), fh)) - 3;
+    out[2] = (int)ceilf(fminf(fmaxf(u1, -16.f), fw)) + 3; out[3] = (int)ceilf(fminf(fmaxf(v1, -16.f), fh)) + 3;
+}
+
 template <int PPT> struct VecF;
 template <> struct VecF<1> { using T = float; };
 template <> struct VecF<2> { using T = float2; };
@@ -145,12 +180,16 @@ template <bool COMPACT> __device__ void rgb_residual_body(const RgbArgs& ra, int
 template <int PPT, int LEVEL_TAG>
 __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, const RgbArgs ra, int n_icp_blocks)
 {
-    if ((int)blockIdx.x >= n_icp_blocks) {
-        if (ra.compact) rgb_residual_body<true>(ra, blockIdx.y, blockIdx.x - n_icp_blocks);
-        else rgb_residual_body<false>(ra, blockIdx.y, blockIdx.x - n_icp_blocks);
+    // (Measured and dropped, round 3: dispatching the residual workgroups of all models before the mostly culled ICP workgroups of
+    // the object models, so that the launch would end on short work -- 22.2 against 21.4 us in grid order, profiles/r03e.)
+    const int model = blockIdx.y, bx = blockIdx.x;
+    if (bx >= n_icp_blocks) {
+        if (((args.flags >> 8) & 32) || (((args.flags >> 8) & 16) && model > 0)) return;  // timing ablations (CF_ICP_ABLATE)
+        if (ra.compact) rgb_residual_body<true>(ra, model, bx - n_icp_blocks);
+        else rgb_residual_body<false>(ra, model, bx - n_icp_blocks);
         return;
     }
-    const IcpModelArgs& ma = args.m[blockIdx.y];
+    const IcpModelArgs& ma = args.m[model];
     const OdomDev* __restrict__ st = ma.st;
     const int cols = args.cols, rows = args.rows, N = cols * rows;
     const int T = blockDim.x;
@@ -165,8 +204,11 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     const int nlog = (pix1 - pix0 + T * PPT - 1) / (T * PPT);
     // (the grid is sized for the whole image; a model with a row band has fewer logical blocks, and the XCD interleave below is a
     // bijection only on the first 8 * ceil(nlog / 8) hardware blocks)
-    if ((int)(blockIdx.x >> 3) >= ((nlog + 7) >> 3)) return;
-    const int lb = xcd_logical_block(blockIdx.x, nlog);
+    if ((bx >> 3) >= ((nlog + 7) >> 3)) return;
+    // A culled model keeps the workgroups of a few image rows only: giving every XCD a horizontal band would leave that work on
+    // the XCDs whose bands the rectangle crosses.  Its workgroups are dealt round-robin instead (neighbouring pixel runs on
+    // different XCDs), so what survives the culling is spread over the whole chip.
+    const int lb = ma.cull ? bx : xcd_logical_block(bx, nlog);
     if (lb >= nlog) return;
 
     const float* __restrict__ vc = ma.vc;
@@ -174,10 +216,25 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     const float* __restrict__ vp = ma.vp;
     const float* __restrict__ np = ma.np;
     float* __restrict__ errs = (args.flags & 1) ? ma.err : nullptr;
-    const int abl = args.flags >> 8;  // micro-benchmark ablation bits (0 in production)
+    const int abl = (args.flags >> 8) & 7;  // micro-benchmark ablation bits (0 in production)
 
     const int i0 = pix0 + (lb * T + threadIdx.x) * PPT;
-    const bool in_range = i0 < pix1;  // cols is a multiple of PPT, so the whole vector is in range
+    bool in_range = i0 < pix1;  // cols is a multiple of PPT, so the whole vector is in range
+    // Screen-box culling (screen_box above): pixels outside the model's rectangle add exact zeros.  A workgroup whose pixel run
+    // misses the rectangle leaves after this one scalar load; inside a workgroup that straddles it, the waves outside load nothing
+    // and go straight to the commit.  Not on the error-surface iteration, which writes every pixel.
+    if (ma.cull && !(args.flags & 1)) {
+        if ((args.flags >> 8) & 8) return;  // timing ablation: culled models do nothing
+        const int L = 2 - args.occ_shift;
+        const int bx0 = (st->stats.cull_box[0] >> L) - 1, by0 = (st->stats.cull_box[1] >> L) - 1, bx1 = (st->stats.cull_box[2] >> L) + 1, by1 = (st->stats.cull_box[3] >> L) + 1;
+        const int p0 = pix0 + lb * T * PPT, p1 = min(p0 + T * PPT, pix1) - 1;  // first / last pixel of this workgroup
+        const int r0 = p0 / cols, r1 = p1 / cols;
+        if (r1 < by0 || r0 > by1) return;
+        if (r0 == r1 && (p1 - r0 * cols < bx0 || p0 - r0 * cols > bx1)) return;
+        const int w0 = p0 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * 64 * PPT, w1 = min(w0 + 64 * PPT, pix1) - 1;
+        const int q0 = w0 / cols, q1 = w1 / cols;
+        if (w0 > w1 || q1 < by0 || q0 > by1 || (q0 == q1 && (w1 - q0 * cols < bx0 || w0 - q0 * cols > bx1))) in_range = false;
+    }
     float vx[PPT], vy[PPT], vz[PPT], nx[PPT], ny[PPT], nz[PPT];
 #pragma unroll
     for (int p = 0; p < PPT; p++) { vx[p] = vy[p] = vz[p] = nx[p] = ny[p] = nz[p] = qnan(); }
@@ -197,10 +254,12 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     f3 vprev[PPT], nprev[PPT];
     int cand = 0;
 #pragma unroll
+    for (int p = 0; p < PPT; p++) { pr[p].vcurr_g = f3{qnan(), qnan(), qnan()}; pr[p].g = 0; pr[p].inb = 0; vprev[p] = pr[p].vcurr_g; nprev[p] = pr[p].vcurr_g; }
+    if (__any(in_range))  // (a wave culled by the screen box skips the projection as well)
+#pragma unroll
     for (int p = 0; p < PPT; p++) {
         pr[p] = icp_project(Rcurr, tcurr, Rprev_inv, tprev, args.intr, cols, rows, f3{vx[p], vy[p], vz[p]});
         if (!in_range) pr[p].inb = 0;
-        vprev[p] = f3{qnan(), qnan(), qnan()}; nprev[p] = f3{qnan(), qnan(), qnan()};
         bool occupied = pr[p].inb != 0;
         if (occupied && ma.occ) {  // the model map is invalid (NaN) everywhere inside an empty 4x4 block: no gather needed
             const int gy = pr[p].g / cols, gxp = pr[p].g - gy * cols;
@@ -286,8 +345,9 @@ float sqrt_gate_lt(float T)
 float sqrt_gate_le(float T)
 {   // largest x with sqrtf(x) <= T  =>  sqrtf(x) <= T  <=>  x <= bound
     if (!(T >= 0.f)) return -1.f;
+    if (std::isinf(T)) return INFINITY;  // gate disabled: every radicand passes (x <= inf)
     float x = T * T;
-    while (sqrtf(x) <= T) x = nextafterf(x, INFINITY);
+    while (sqrtf(x) <= T && std::isfinite(x)) x = nextafterf(x, INFINITY);
     while (sqrtf(x) > T) x = nextafterf(x, 0.f);
     return x;
 }
@@ -747,6 +807,23 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
             }
         }
     }
+    if (lead && threadIdx.x < 64) {
+        // latch the bounding box the model-map pass accumulated (and clear the accumulator for the next frame); first screen box
+        const int lane = threadIdx.x;
+        unsigned key = 0;
+        if (od->cull && lane < 6) { key = od->aabb_acc[lane]; od->aabb_acc[lane] = 0; }
+        const float val = lane < 3 ? fkey_inv(~key) : fkey_inv(key);
+        float lo[3], hi[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lo[k] = __shfl(val, k, 64); hi[k] = __shfl(val, 3 + k, 64); }
+        if (__shfl((int)key, 3, 64) == 0) { lo[0] = 1.f; hi[0] = 0.f; }  // never written: empty
+        int ib[4] = {0, 0, od->width - 1, od->height - 1};
+        if (od->cull) screen_box(lo, hi, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, lane, ib);
+        if (lane == 0) {
+            for (int k = 0; k < 3; k++) { od->box_lo[k] = lo[k]; od->box_hi[k] = hi[k]; }
+            for (int k = 0; k < 4; k++) od->stats.cull_box[k] = ib[k];
+        }
+    }
     if (lead && threadIdx.x == 0) {
         for (int k = 0; k < 16; k++) od->resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
         if (do_so3)
@@ -920,6 +997,11 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
     }
     if (tid == 0 && last_of_level) { od->level_done = 0; od->lastRGBError = 3.402823466e+38F; }
     __syncthreads();
+    if (next_level >= 0 && od->cull && tid >= 128 && tid < 192) {  // an idle wave: the screen box under the new pose
+        int ib[4];
+        screen_box(od->box_lo, od->box_hi, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, tid - 128, ib);
+        if (tid == 128) { od->stats.cull_box[0] = ib[0]; od->stats.cull_box[1] = ib[1]; od->stats.cull_box[2] = ib[2]; od->stats.cull_box[3] = ib[3]; }
+    }
     if (next_level >= 0) {  // prepare_iteration(od, next_level), spread over lanes
         if (tid == 0) inv44_affine(od->resultRt, s_Rt);
         __syncthreads();
@@ -1108,7 +1190,8 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
                 // the roofline figure is quoted on the dominant kernel: the level-0 instantiation
                 const bool timed = prof && prof->enabled && i == 0 && prof->used + 4 <= prof->capacity;
                 IcpArgs a = icp_args[i];
-                a.flags = (i == 0 && last_of_level) ? 1 : 0;
+                static const int ablate = getenv("CF_ICP_ABLATE") ? atoi(getenv("CF_ICP_ABLATE")) : 0;  // diagnostics: timing ablations (results change)
+                a.flags = ((i == 0 && last_of_level) ? 1 : 0) | (ablate << 8);
                 launch_icp_rgbres(s, cfg, a, ra, icp, rgb, n, i, timed ? prof->events[prof->used] : nullptr,
                                   timed ? prof->events[prof->used + 1] : nullptr);
                 if (timed) {

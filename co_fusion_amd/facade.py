@@ -227,6 +227,11 @@ class CoFusion:
         self._check(self.lib.cofusion_model_info(self.h, index, C.byref(mid), C.byref(cnt), pose, C.byref(conf)))
         return dict(id=mid.value, count=cnt.value, pose=np.array(pose, np.float32).reshape(4, 4), conf_threshold=conf.value)
 
+    def model_cull_box(self, index):
+        b = (C.c_int * 4)()
+        self._check(self.lib.cofusion_model_cull_box(self.h, index, b))
+        return list(b)
+
     def model_icp_stats(self, index):
         e = C.c_float(); c = C.c_float()
         self._check(self.lib.cofusion_model_icp_stats(self.h, index, C.byref(e), C.byref(c)))

@@ -1008,6 +1008,10 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
                 if (spawnOffset < cfg.modelSpawnOffset) spawnOffset++;
                 const size_t modelCap = (size_t)std::min(cfg.maxModels, 16);
                 allowNew = spawnOffset >= cfg.modelSpawnOffset && models.size() < modelCap;
+                if (spawnOffset >= cfg.modelSpawnOffset && !allowNew && !capReported) {  // say so once: the reference would go on to 256 ids
+                    fprintf(stderr, "[cofusion] %zu active models: the model cap (min(max_models, 16)) suppresses further spawns\n", models.size());
+                    capReported = true;
+                }
             }
             // the motion segmentation reads device data only (ICP error surfaces, predictions): enqueued right behind the tracking
             // launches, so that poses AND segmentation decisions are collected by ONE host wait

@@ -282,6 +282,7 @@ class CoFusion {
     int tick = 1;
     float maxDepthProcessed = 20.0f;
     unsigned spawnOffset = 0;
+    bool capReported = false;  // the model cap suppressed a spawn and said so
     bool lost = false;
     // device frame buffers (CoFusion::textures)
     // filtered depth + its pyramid are double buffered: the filter of frame t+1 runs on an auxiliary stream while the fusion

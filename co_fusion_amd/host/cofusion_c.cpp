@@ -114,6 +114,13 @@ int cofusion_model_icp_stats(cofusion_handle* h, int index, float* err, float* c
     if (cnt) *cnt = m->lastStats.last_icp_count;
     return 0;
 }
+int cofusion_model_cull_box(cofusion_handle* h, int index, int box[4])
+{
+    Model* m = model_at(h, index);
+    if (!m || !box) { g_err = "model index out of range"; return -1; }
+    for (int k = 0; k < 4; k++) box[k] = m->lastStats.cull_box[k];
+    return 0;
+}
 int cofusion_model_tracking_inputs(cofusion_handle* h, int index, float* vertex4, float* normal4, uint8_t* image_rgba)
 {
     Model* m = model_at(h, index);

@@ -49,7 +49,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "lib", "libcofusion.so")
 HOST_SYMBOLS = [
     "cofusion_default_config", "cofusion_create", "cofusion_destroy", "cofusion_last_error", "cofusion_set_stream",
     "cofusion_process_frame", "cofusion_process_frame_device", "cofusion_num_models", "cofusion_tick", "cofusion_model_info",
-    "cofusion_model_download", "cofusion_model_icp_stats", "cofusion_model_tracking_inputs", "cofusion_mask_device", "cofusion_context", "cofusion_set_crf",
+    "cofusion_model_download", "cofusion_model_icp_stats", "cofusion_model_cull_box", "cofusion_model_tracking_inputs", "cofusion_mask_device", "cofusion_context", "cofusion_set_crf",
     "cofusion_save_ply", "cofusion_export_poses", "cofusion_set_export_segmentation", "cofusion_klg_open", "cofusion_klg_next", "cofusion_klg_set_reference_compatible", "cofusion_klg_close",
     "cofusion_klg_create", "cofusion_klg_write", "cofusion_klg_finish", "cofusion_debug_phase_ms", "cofusion_set_allreduce", "cofusion_set_allreduce_device", "cofusion_model_owned",
 ]

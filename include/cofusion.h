@@ -16,7 +16,9 @@ typedef struct cofusion_handle cofusion_handle;
 typedef struct {
     int width, height;
     float fx, fy, cx, cy;
-    int device, max_surfels, max_models;
+    int device, max_surfels, max_models; /* at most min(max_models, 16) models are active at a time: the device segmentation holds 16
+                                          * labels (15 models + the "new model" label).  The reference allows 256 ids (CoFusion.cpp:631-634);
+                                          * beyond the cap new objects are not spawned (reported once on stderr) */
     float conf_global_init, conf_object_init, depth_cutoff, icp_weight, outlier_coefficient;
     int fast_odom, so3, frame_to_frame_rgb, pyramid, rgb_only;
     unsigned model_spawn_offset;
@@ -54,6 +56,8 @@ int cofusion_tick(cofusion_handle *h);
 int cofusion_model_info(cofusion_handle *h, int index, unsigned *id, unsigned *count, float pose[16], float *conf_threshold);
 int cofusion_model_download(cofusion_handle *h, int index, float *surfels, uint32_t capacity, uint32_t *count);
 int cofusion_model_icp_stats(cofusion_handle *h, int index, float *icp_error, float *icp_count);
+/* the level-0 pixel rectangle [x0, y0, x1, y1] the model's last ICP iteration was restricted to (cf_track_stats::cull_box) */
+int cofusion_model_cull_box(cofusion_handle *h, int index, int box[4]);
 /* host copies of what the NEXT frame's tracking of this model reads (Model::initICP, Model.cpp:350-367): the predicted
  * vertex+conf / normal+radius maps (f32x4 [H*W]) and the predicted image (rgba8 [H*W]); any pointer may be NULL */
 int cofusion_model_tracking_inputs(cofusion_handle *h, int index, float *vertex4, float *normal4, uint8_t *image_rgba);

@@ -199,6 +199,9 @@ typedef struct {
     double lastA[36], lastb[6];
     int so3_iterations;
     int fault;              /* non-zero: a bounded device-side wait expired (cf_odom_fetch_result returns CF_ESTATE) */
+    int cull_box[4];        /* cf_odom_set_culling: level-0 pixel rectangle [x0, y0, x1, y1] (inclusive, may exceed the image) the last ICP
+                             * iteration was restricted to -- pixels outside cannot find a correspondence; x0 > x1: empty; the whole
+                             * image when culling is off */
 } cf_track_stats;
 
 int cf_odom_create(cf_ctx *ctx, cf_odom **out);

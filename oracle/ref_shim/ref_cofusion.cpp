@@ -9,7 +9,22 @@ extern "C" {
 #include <math.h>
 #include <string.h>
 
+// the reference's own RGBDOdometry class (ref_odo.cpp, another translation unit of this library: CUDA kernels under the emulator, f32 tree
+// reductions): optional tracker of the frame loop, for the trajectory-level comparison with the exact-integer arithmetic of the oracle
+extern "C" {
+void* ref_odo_create(int w, int h, float cx, float cy, float fx, float fy);
+void ref_odo_destroy(void* p);
+void ref_odo_init_first_rgb(void* p, const unsigned char* rgba);
+void ref_odo_init_icp_model(void* p, const float* v4, const float* n4, float cutoff, const float* pose_row_major);
+void ref_odo_init_rgb_model(void* p, const unsigned char* rgba);
+void ref_odo_init_icp(void* p, const float* const* depth_pyr, float cutoff);
+void ref_odo_init_rgb(void* p, const unsigned char* rgba);
+void ref_odo_track(void* p, float* trans, float* rot_row_major, int rgb_only, float icp_weight, int pyramid, int fast_odom, int so3,
+                   float* icp_err_surface, float* stats6, double* lastA36, double* lastb6);
+}
+
 namespace {
+bool g_reference_tracker = false;             // ref_cf_use_reference_tracker
 orc_cam g_cam;
 int g_w = 0, g_h = 0;
 float g_outlier = 3.0f;                       // GUI default of the outlier coefficient (GUI.h:213), set through Model::GPUSetup
@@ -45,9 +60,17 @@ struct ModelImpl {
     }
 };
 
-PinOdometry::PinOdometry(int width, int height, float cx, float cy, float fx, float fy) { orc = orc_odom_create(width, height, cx, cy, fx, fy); }
-PinOdometry::~PinOdometry() { orc_odom_destroy((orc_odometry*)orc); }
-void PinOdometry::initFirstRGB(GPUTexture* rgb) { orc_odom_init_first_rgb((orc_odometry*)orc, rgb->data<uint8_t>()); }
+PinOdometry::PinOdometry(int width, int height, float cx, float cy, float fx, float fy)
+{
+    orc = orc_odom_create(width, height, cx, cy, fx, fy);
+    if (g_reference_tracker) ref = ref_odo_create(width, height, cx, cy, fx, fy);
+}
+PinOdometry::~PinOdometry() { orc_odom_destroy((orc_odometry*)orc); if (ref) ref_odo_destroy(ref); }
+void PinOdometry::initFirstRGB(GPUTexture* rgb)
+{
+    orc_odom_init_first_rgb((orc_odometry*)orc, rgb->data<uint8_t>());
+    if (ref) ref_odo_init_first_rgb(ref, rgb->data<uint8_t>());
+}
 
 Model::Model(unsigned char id, float confidenceThresh, bool enableFillIn, bool, bool enablePoseLogging, MatchingType, float maxDepth_)
     : impl(new ModelImpl()), pose(Eigen::Matrix4f::Identity()), lastPose(Eigen::Matrix4f::Identity()), confidenceThreshold(confidenceThresh),
@@ -90,6 +113,22 @@ void Model::performTracking(bool frameToFrameRGB, bool rgbOnly, float icpWeight,
         orc_odom_init_rgb_model(od, (frameToFrameRGB && allowsFillIn()) ? impl->fi.data() : impl->img.data());
     }
     const float* pyr[3] = {g_depth_pyr[0].data(), g_depth_pyr[1].data(), g_depth_pyr[2].data()};
+    if (impl->odom->ref) {  // the same five initialisers and the same arguments on the reference's class (Model.cpp:352-378)
+        void* r = impl->odom->ref;
+        if (doFillIn) { ref_odo_init_icp_model(r, impl->fv.data(), impl->fn.data(), maxDepthProcessed, p); ref_odo_init_rgb_model(r, impl->fi.data()); }
+        else {
+            ref_odo_init_icp_model(r, impl->vc.data(), impl->nr.data(), maxDepthProcessed, p);
+            ref_odo_init_rgb_model(r, (frameToFrameRGB && allowsFillIn()) ? impl->fi.data() : impl->img.data());
+        }
+        ref_odo_init_icp(r, pyr, maxDepthProcessed);
+        ref_odo_init_rgb(r, rgb->data<uint8_t>());
+        float trans[3] = {pose(0, 3), pose(1, 3), pose(2, 3)}, rot[9], stats[6];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rot[i * 3 + j] = pose(i, j);
+        ref_odo_track(r, trans, rot, rgbOnly ? 1 : 0, icpWeight, pyramid ? 1 : 0, fastOdom ? 1 : 0, so3 ? 1 : 0, impl->icp_error.data(), stats, nullptr, nullptr);
+        impl->odom->lastICPError = stats[0]; impl->odom->lastICPCount = stats[1];
+        for (int i = 0; i < 3; i++) { pose(i, 3) = trans[i]; for (int j = 0; j < 3; j++) pose(i, j) = rot[i * 3 + j]; }
+        return;
+    }
     orc_odom_init_icp(od, pyr, maxDepthProcessed);
     orc_odom_init_rgb(od, rgb->data<uint8_t>());
     float trans[3] = {pose(0, 3), pose(1, 3), pose(2, 3)}, rot[9];
@@ -215,6 +254,8 @@ void* ref_cf_create(int w, int h, float fx, float fy, float cx, float cy, float 
     return new CoFusion(w, h, fx, fy, cx, cy, conf_global, conf_object, depth_cut, icp_weight, so3 != 0, model_spawn_offset, enable_multiple_models != 0);
 }
 void ref_cf_destroy(void* p) { delete (CoFusion*)p; }
+// 1: models created from now on track with the reference's own RGBDOdometry class instead of the oracle's restatement of it
+void ref_cf_use_reference_tracker(int on) { g_reference_tracker = on != 0; }
 void ref_cf_set_tracking_options(void* p, int rgb_only, int pyramid, int fast_odom, int frame_to_frame_rgb)
 {
     ((CoFusion*)p)->setTrackingOptions(rgb_only != 0, pyramid != 0, fast_odom != 0, frame_to_frame_rgb != 0);

@@ -48,6 +48,7 @@ class PinOdometry {
     template <class... A> void getIncrementalTransformation(A&&...) {}
     float lastICPError = 0, lastICPCount = 0;
     void* orc = nullptr;  // orc_odometry*
+    void* ref = nullptr;  // the reference's own RGBDOdometry behind ref_odo.cpp's C entry points (ref_cf_use_reference_tracker)
 };
 
 class Model {

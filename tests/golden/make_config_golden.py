@@ -39,6 +39,12 @@ SCENARIOS = {
     "static_moving4_640_300": dict(W=640, H=480, n_obj=4, frames=300, multi=False, conf_global=10.0),
     # configs[4]'s frame size (static part: one 1280x960 model)
     "static_1280": dict(W=1280, H=960, n_obj=0, frames=3, multi=False, conf_global=10.0),
+    # configs[3] at its own size: 8 moving objects + background, motion CRF on (no ground-truth masks), 64 frames
+    "objects8_640": dict(W=640, H=480, n_obj=8, frames=64, multi=True, conf_global=0.5, spawn_offset=2),
+    # ... and for 200 frames, long enough for the CRF to have found most of the eight objects
+    "objects8_640_200": dict(W=640, H=480, n_obj=8, frames=200, multi=True, conf_global=0.5, spawn_offset=2),
+    # configs[4] at its own size: 1280x960, 4 moving objects + background, motion CRF on (the facade runs it with 32 M surfels per model)
+    "objects4_1280": dict(W=1280, H=960, n_obj=4, frames=48, multi=True, conf_global=0.5, spawn_offset=2),
 }
 
 

@@ -74,3 +74,27 @@ def test_no_product_code_touches_the_oracle():
                 # comments may cite the oracle's spec; code must not include, import, load or call it
                 bad = re.search(r'#include\s*"[^"]*orc[^"]*"|^\s*(import|from)\s+orc|liborc|\borc_[a-z0-9_]+\s*\(', txt, flags=re.M)
                 assert not bad, f"{f} uses the oracle: {bad.group(0)}"
+
+
+def test_sqrt_gate_bounds_terminate_and_decide_exactly(libs):
+    """The radicand bounds of the two ICP gates (sqrtf(x) < T, sqrtf(x) <= T decided on x; csrc/track_reduce.hip) for thresholds a
+    C-ABI caller may pass to cf_icp_step: 0, a denormal, FLT_MAX and +inf (gate disabled) must not hang and must decide exactly."""
+    import numpy as np
+    lib = libs.load()
+    lt = getattr(lib, "_ZN2cf12sqrt_gate_ltEf"); le = getattr(lib, "_ZN2cf12sqrt_gate_leEf")
+    for f in (lt, le):
+        f.restype = C.c_float; f.argtypes = [C.c_float]
+    f32 = np.float32
+    fmax = float(np.finfo(f32).max)
+    for T in (0.0, 1e-42, 1e-20, 0.1, float(f32(np.sin(f32(20.0) * f32(3.14159254) / f32(180.0)))), 1.0, 1e19, fmax, float("inf")):
+        bl, be = f32(lt(T)), f32(le(T))
+        Tf = f32(T)
+        # probe the neighbourhood of the bounds
+        for b, strict in ((bl, True), (be, False)):
+            xs = [b, np.nextafter(b, f32(np.inf)), np.nextafter(b, f32(0))] if np.isfinite(b) else [f32(fmax), f32(np.inf)]
+            for x in xs:
+                if not (x >= 0):
+                    continue
+                want = (np.sqrt(f32(x)) < Tf) if strict else (np.sqrt(f32(x)) <= Tf)
+                got = (f32(x) < bl) if strict else (f32(x) <= be)
+                assert bool(want) == bool(got), (T, float(x), strict)

@@ -117,7 +117,7 @@ def _mp_worker(rank, world, port, out_dir, use_gt, shard_bg=False, size=(320, 24
         W, H = size
         cam = synth.Camera.scaled(W, H)
         sc = synth.Scene(n_obj=n_obj)
-        kw = dict(max_surfels=1 << (21 if W > 320 else 19), conf_global_init=0.5, model_spawn_offset=2, enable_multiple_models=1)
+        kw = dict(max_surfels=1 << (22 if W > 640 else 21 if W > 320 else 19), conf_global_init=0.5, model_spawn_offset=2, enable_multiple_models=1)
         single = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, **kw)                  # the whole job on one GPU
         par = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, rank=rank, world=world, shard_background=int(shard_bg), **kw)   # this rank's share
         par.set_allreduce()
@@ -176,4 +176,15 @@ def test_background_split_over_ranks_matches_single_gpu(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_mp_worker, args=(2, port, str(tmp_path), False, True, (640, 480), 8, 4), nprocs=2, join=True)
     for r in range(2):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_background_split_at_1280x960_matches_single_gpu(tmp_path, world):
+    """configs[4]'s split at configs[4]'s frame size: 1280x960, 4 moving objects, the background's index-map rasterisation
+    and ICP reduction split over 2 and over 4 ranks (gloo on the one GPU of the box; 4 ranks = the split BASELINE.json names), 18 frames
+    with the motion CRF -- the first object spawns at frame 15 -- equal to the single-GPU run bit for bit on every rank."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_mp_worker, args=(world, port, str(tmp_path), False, True, (1280, 960), 18, 4), nprocs=world, join=True)
+    for r in range(world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"

@@ -9,9 +9,9 @@ shift 2
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-timeout 700 python -m pytest ${@:-tests/test_configs_gpu.py tests/test_facade_gpu.py tests/test_track_gpu.py} -m gpu -x -q > $O/pytest.log 2>&1; echo "tests rc=$?"; tail -3 $O/pytest.log
+timeout ${TEST_TIMEOUT:-700} python -m pytest ${@:-tests/test_configs_gpu.py tests/test_facade_gpu.py tests/test_track_gpu.py} -m gpu -x -q > $O/pytest.log 2>&1; echo "tests rc=$?"; tail -3 $O/pytest.log
 : > $O/sweep.jsonl
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for W in objects4 static; do
     timeout 150 python bench.py --workload $W --steps 100 --warmup 20 --no-cpu-baseline --no-extras >> $O/sweep.jsonl 2>> $O/sweep.err
     env $V=1 timeout 150 python bench.py --workload $W --steps 100 --warmup 20 --no-cpu-baseline --no-extras >> $O/sweep.jsonl 2>> $O/sweep.err
