@@ -11,7 +11,7 @@ Workloads (BASELINE.json configs):
   objects4     configs[2]: 4 moving objects + background, motion-CRF segmentation on, 640x480     <- default / headline
   static       configs[1]: single static background model (`-static`), 640x480                      (reported as "secondary")
   objects4-gt  as objects4 but with ground-truth label masks (the reference's Mask####.png input mode)
-  objects8     configs[3]: 8 moving objects + background (the default of `--gpus N > 1`: models placed on the GPUs)
+  objects8     configs[3]: 8 moving objects + background
   big          configs[4]: 1280x960, 4 objects, 32 M surfels per model
 
 Phases of one run (only the third is timed for `value`):
@@ -23,10 +23,14 @@ Phases of one run (only the third is timed for `value`):
   extras     (rank 0, N = 1) the same stream through the host-input entry point (`input: host` rate, PCIe inclusive),
              trajectory error (ATE) against the synthetic ground truth and against the CPU oracle, the CPU baseline.
 
-N > 1: one process per GPU.  `--gpus N` without RANK in the environment re-executes itself under
+N > 1: one process per GPU, the SAME workload as N = 1 (configs[2] unless --workload says otherwise; the same pre-roll with
+ground-truth masks, so the same models exist at every N).  `--gpus N` without RANK in the environment re-executes itself under
 torch.distributed.run.  Default partition (`--parallel models`): ONE RGB-D stream, the object models placed on the ranks
-(background on rank 0), poses / segmentation sums exchanged with an exact integer all-reduce over RCCL ("scaling":
-"strong").  `--parallel streams`: one independent sequence per GPU, no data-path collective ("weak").
+(background on rank 0), frames broadcast from the ingest GPU, poses / segmentation sums exchanged with an exact integer
+all-reduce ("scaling": "strong") -- through the library's OWN RCCL communicator (cofusion_init_rccl: ncclBroadcast / ncclAllReduce
+in place on the context's stream, no Python in the frame loop) when the process group is RCCL; `--collectives torch` keeps the
+torch.distributed callbacks (the gloo dry runs).  `--parallel streams`: one independent sequence per GPU, no data-path
+collective ("weak").
 
 The JSON line also carries
   roofline      achieved algorithmic bytes/s of the dominant kernel -- the level-0 launch that carries the ICP reduction of
@@ -105,11 +109,14 @@ def parse(argv=None):
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not attach timing events to the level-0 launches (no roofline figure)")
     ap.add_argument("--dry-run", action="store_true", help="plumbing test without a GPU (tests/test_cpu_distributed.py): the process-group "
                     "set-up, the timing contract and the JSON line with a stub step instead of processFrame")
+    ap.add_argument("--collectives", default="auto", choices=["auto", "rccl", "torch"],
+                    help="N > 1, --parallel models: 'rccl' = the library's own RCCL communicator (cofusion_init_rccl), 'torch' = "
+                         "torch.distributed callbacks, 'auto' = rccl when the process group's backend is nccl")
     ap.add_argument("--streams", type=int, default=1, help="independent RGB-D streams per GPU (own context + HIP stream + host thread each); "
                     "1 = the headline single-sequence figure, >1 = throughput mode")
     a = ap.parse_args(argv)
     if a.workload is None:
-        a.workload = "objects8" if a.gpus > 1 else "objects4"
+        a.workload = "objects4"   # the metric's configuration at EVERY number of GPUs: the per-N values form one curve
     wl = WORKLOADS[a.workload]
     if a.width is None:
         a.width = wl["size"][0]
@@ -230,6 +237,7 @@ def main(argv=None):
     use_gt = args.workload == "objects4-gt"
     dev = torch.device("cuda", local_rank)
     model_parallel = args.parallel == "models" and world > 1 and n_obj > 0
+    use_rccl = model_parallel and (args.collectives == "rccl" or (args.collectives == "auto" and backend == "nccl"))
     streams = []
     for si in range(S):
         cam, frames = make_stream(W, H, args.frames, n_obj=n_obj, seed=1234 + (0 if model_parallel else rank * 64) + si)
@@ -241,7 +249,10 @@ def main(argv=None):
                               **(dict(enqueue_threads=args.enqueue_threads) if args.enqueue_threads is not None else {}),
                               **(dict(rank=rank, world=world, shard_background=int(args.shard_background)) if model_parallel else {}))
         if model_parallel:
-            cfi.set_allreduce()
+            if use_rccl:
+                cfi.init_rccl()       # the library's own ncclComm_t: every collective of the frame loop runs inside the library
+            else:
+                cfi.set_allreduce()   # torch.distributed callbacks (process groups that are not RCCL)
         if args.icp_ppt:
             cfi.set_icp_launch(args.icp_threads, args.icp_ppt)
         if args.gn_mode >= 0:
@@ -280,7 +291,10 @@ def main(argv=None):
         elif model_parallel:
             # frame from the ingest GPU (rank 0) to every rank: one broadcast over xGMI (depth 1.2 MB + colour 1.2 MB at 640x480)
             buf = st["resident"][k] if rank == 0 else st["resident"][i & 1]
-            dist.broadcast(buf["pack"], src=0)
+            if use_rccl:
+                st["cf"].broadcast(buf["pack"], 0)   # ncclBroadcast on the context's stream, consumed in stream order
+            else:
+                dist.broadcast(buf["pack"], src=0)
             st["cf"].process_frame_device(buf["depth"], buf["rgba"], timestamp=i)
         else:
             st["cf"].process_frame_device(st["resident"][k]["depth"], st["resident"][k]["rgba"], timestamp=i)
@@ -316,7 +330,9 @@ def main(argv=None):
 
     # pre-roll (state the metric is quoted on: the object models exist), then W warm-up steps; all untimed
     P = args.preroll
-    pre_masks = "gt" if (n_obj > 0 and args.preroll_masks == "gt" and not model_parallel) else None
+    # (model-parallel too: every rank holds the host copy of the stream, ground-truth-mask frames take the host-input path on every
+    # rank, so all N see the same models as N = 1)
+    pre_masks = "gt" if (n_obj > 0 and args.preroll_masks == "gt") else None
     run_range(0, P, pre_masks)
     run_range(P, P + args.warmup)
     base = P + args.warmup
@@ -357,6 +373,9 @@ def main(argv=None):
                                              "the reference tree: parity of this stage is against the oracle only)"),
                                icp_launch=[args.icp_threads, args.icp_ppt], gn_mode=args.gn_mode,
                                streams_per_gpu=S, parallel=args.parallel if world > 1 else "single",
+                               collectives=("library RCCL communicator (ncclBroadcast + ncclAllReduce in place on the context's stream)" if use_rccl
+                                            else "torch.distributed callbacks" if model_parallel else "none"),
+                               metric_definition="r03: configs[2] at every N; pre-roll with ground-truth masks, warm-up and timed steps with the motion CRF",
                                background="split over the ranks (replicated map; surfel-range index map + row-band ICP with all-reduce)" if (model_parallel and args.shard_background) else "one rank",
                                frames=("broadcast from rank 0 every step, consumed in stream order" if model_parallel else "ring of device-resident frames, complete before each call (device_frames_complete=1)")),
                    roofline=roofline)
@@ -439,22 +458,41 @@ def extras(out, args, cf, cam, frames, i0, use_gt, torch, facade, local_rank):
         out["secondary"] = secondary_static(args, torch, facade, local_rank)
 
 
-def oracle_trajectory_check(cam, frames, torch, facade, local_rank, args, n_frames=5):
-    """Free run of the first frames on the GPU and on the CPU oracle: the trajectories must be identical (ATE 0)."""
-    import orc_pipeline as op
+def oracle_trajectory_check(cam, frames, torch, facade, local_rank, args, n_frames=8):
+    """Free run of the first frames of the HEADLINE workload's pipeline on the GPU and on the CPU oracle (multi-model frame loop with the
+    motion CRF for the object workloads, -static otherwise; fast spawning so that object models exist within the checked frames): the
+    trajectories of the camera and of every model must be identical (ATE 0, same bits)."""
     W, H = args.width, args.height
-    ref = op.StaticPipeline(cam)
-    g = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels, enable_multiple_models=0)
-    errs, same = [], True
+    multi = WORKLOADS[args.workload]["n_obj"] > 0
+    if multi:
+        import orc_multi as om
+        ref = om.MultiPipeline(cam, conf_global=0.5, spawn_offset=2)
+        g = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels, enable_multiple_models=1,
+                            conf_global_init=0.5, model_spawn_offset=2)
+    else:
+        import orc_pipeline as op
+        ref = op.StaticPipeline(cam)
+        g = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels, enable_multiple_models=0)
+    errs, same, most = [], True, 1
     for t in range(n_frames):
         f = frames[t]
-        rp, rn = ref.process_frame(f["depth"], f["rgba"])
+        if multi:
+            ref.process_frame(f["depth"], f["rgba"])
+            rposes = [m.pose for m in ref.models]; rcounts = [m.surfels.shape[0] for m in ref.models]
+        else:
+            rp, rn = ref.process_frame(f["depth"], f["rgba"])
+            rposes, rcounts = [rp], [rn]
         g.process_frame(f["depth"], f["rgb"], timestamp=t)
-        info = g.model_info(0)
-        errs.append(float(np.linalg.norm(info["pose"][:3, 3].astype(np.float64) - rp[:3, 3].astype(np.float64))))
-        same = same and bool((info["pose"].view(np.uint32) == rp.view(np.uint32)).all()) and info["count"] == rn
+        same = same and g.num_models == len(rposes)
+        most = max(most, len(rposes))
+        for i in range(min(g.num_models, len(rposes))):
+            info = g.model_info(i)
+            same = same and bool((info["pose"].view(np.uint32) == np.asarray(rposes[i], np.float32).view(np.uint32)).all()) and info["count"] == rcounts[i]
+        errs.append(float(np.linalg.norm(g.model_info(0)["pose"][:3, 3].astype(np.float64) - np.asarray(rposes[0])[:3, 3].astype(np.float64))))
     g.close()
-    return dict(vs_oracle=round(float(np.sqrt(np.mean(np.square(errs)))), 9), vs_oracle_frames=n_frames, vs_oracle_bit_identical=same)
+    return dict(vs_oracle=round(float(np.sqrt(np.mean(np.square(errs)))), 9), vs_oracle_frames=n_frames, vs_oracle_bit_identical=same,
+                vs_oracle_pipeline=("multi-model frame loop, motion CRF (the headline workload's pipeline), up to %d models" % most) if multi else "-static",
+                vs_reference="tests/golden/ref_traj_v1.npz (CPU suite): the same frame loop tracked by the reference's own RGBDOdometry class")
 
 
 def secondary_static(args, torch, facade, local_rank, warmup=30, steps=120):

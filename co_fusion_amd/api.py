@@ -103,6 +103,30 @@ class Context:
     def synchronize(self):
         self._check(self.lib.cf_synchronize(self.h))
 
+    # ---- the library's own RCCL communicator (csrc/rccl_comm.hip) ----
+    @staticmethod
+    def rccl_unique_id():
+        buf = (C.c_ubyte * 128)()
+        if _libmod.load().cf_rccl_unique_id(buf) != 0:
+            raise CofusionError("cf_rccl_unique_id failed")
+        return bytes(buf)
+
+    def rccl_init(self, unique_id, rank, world):
+        self._check(self.lib.cf_rccl_init(self.h, C.c_char_p(unique_id), int(rank), int(world)))
+
+    def rccl_allreduce(self, tensor, op=0):
+        """in place on the context's stream: op 0 = SUM of int64 words, op 1 = MIN of unsigned 64-bit words"""
+        assert tensor.element_size() == 8 and tensor.is_contiguous()
+        self._check(self.lib.cf_rccl_allreduce(self.h, C.c_void_p(tensor.data_ptr()), C.c_uint64(tensor.numel()), int(op), None))
+
+    def rccl_broadcast(self, tensor, root=0):
+        self._check(self.lib.cf_rccl_broadcast(self.h, C.c_void_p(tensor.data_ptr()), C.c_uint64(tensor.numel() * tensor.element_size()), int(root), None))
+
+    def rccl_info(self):
+        r, w, v = C.c_int(), C.c_int(), C.c_int()
+        rc = self.lib.cf_rccl_info(self.h, C.byref(r), C.byref(w), C.byref(v))
+        return dict(active=rc == 0, rank=r.value, world=w.value, version=v.value)
+
     def empty(self, shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
@@ -275,6 +299,13 @@ class Odometry:
 
     def init_rgb_model(self, rgba):
         self.ctx._check(self.ctx.lib.cf_odom_init_rgb_model(self.h, _p(rgba)))
+
+    def set_band(self, row_begin, row_end, add_counts=1):
+        """this rank's rows of the model's reductions (cf_odom_set_band); (0, 0): all rows, no collective"""
+        self.ctx._check(self.ctx.lib.cf_odom_set_band(self.h, int(row_begin), int(row_end), int(add_counts)))
+
+    def set_culling(self, on=True):
+        self.ctx._check(self.ctx.lib.cf_odom_set_culling(self.h, int(bool(on))))
 
     def init_rgb(self, rgba):
         self.ctx._check(self.ctx.lib.cf_odom_init_rgb(self.h, _p(rgba)))

@@ -84,6 +84,7 @@ void cf_destroy(cf_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipStreamSynchronize(ctx->stream);
+    (void)cf_rccl_destroy(ctx);
     (void)hipFree(ctx->d_acc_a); (void)hipFree(ctx->d_acc_b); (void)hipFree(ctx->d_out);
     (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_cand_scratch);
     (void)hipFree(ctx->d_state_pool); (void)hipHostFree(ctx->h_state_pool);

@@ -54,6 +54,7 @@ struct cf_ctx {
     // all-reduce of unsigned 64-bit words; enqueued on the given stream
     int (*collective)(void* user, int op, void* dev_buf, uint64_t words, void* stream) = nullptr;
     void* collective_user = nullptr;
+    void* rccl = nullptr;              // the library's own RCCL communicator (cf_rccl_init, rccl_comm.hip); its collective replaces the caller's
     // the launch schedule of the device-resident Gauss-Newton loop as a hipGraph: captured once per set of kernel arguments (which
     // models, which buffers, which options), replayed every frame -- ~1 us less per launch boundary than 58 stream launches
     hipGraphExec_t gn_graph = nullptr;

@@ -26,6 +26,23 @@ class CoFusionError(RuntimeError):
     pass
 
 
+class _DevWords:
+    """a device address as an int64 array (the __cuda_array_interface__ protocol): torch.as_tensor turns it into a tensor VIEW of the
+    library's buffer, so that torch.distributed reduces it in place -- no staging copies"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<i8", data=(int(ptr), False), version=2)
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId through the facade (128 bytes): rank 0 creates it, every rank passes it to CoFusion.init_rccl"""
+    lib = _libmod.load_host()
+    buf = (C.c_ubyte * 128)()
+    if lib.cofusion_rccl_unique_id(buf) != 0:
+        raise CoFusionError(f"cofusion_rccl_unique_id: {lib.cofusion_last_error().decode()}")
+    return bytes(buf)
+
+
 class CoFusion:
     def __init__(self, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, device=0, **kw):
         if not torch.cuda.is_available():
@@ -50,6 +67,28 @@ class CoFusion:
     def _check(self, rc):
         if rc != 0:
             raise CoFusionError(f"cofusion error {rc}: {self.lib.cofusion_last_error().decode()}")
+
+    def init_rccl(self, unique_id=None):
+        """The library's own RCCL communicator as this instance's collective (cofusion_init_rccl): ncclAllReduce / ncclBroadcast in
+        place on the context's stream, no Python in the frame loop.  unique_id: the 128 bytes rank 0 got from rccl_unique_id(); None:
+        created on rank 0 and distributed through the default torch.distributed process group.  Collective call (every rank)."""
+        if unique_id is None:
+            import torch.distributed as dist
+            cuda = dist.get_backend() == "nccl"
+            t = torch.zeros(128, dtype=torch.uint8)
+            if self.cfg.rank == 0:
+                t = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).clone()
+            if cuda:
+                t = t.to(self.device)
+            dist.broadcast(t, src=0)
+            unique_id = bytes(t.cpu().numpy().tobytes())
+        assert len(unique_id) == 128
+        self._check(self.lib.cofusion_init_rccl(self.h, C.c_char_p(unique_id)))
+        self.rccl = True
+
+    def broadcast(self, tensor, root=0):
+        """a device tensor (a frame: depth + colour in one buffer) from rank `root` to every rank: ncclBroadcast on the context's stream"""
+        self._check(self.lib.cofusion_broadcast(self.h, C.c_void_p(tensor.data_ptr()), C.c_uint64(tensor.numel() * tensor.element_size()), int(root)))
 
     def set_allreduce(self, fn=None):
         """model-parallel mode (rank / world given at construction): register the SUM all-reduce of int64 buffers.
@@ -84,39 +123,21 @@ class CoFusion:
     def set_collective(self):
         """C-ABI level collective (cf_set_collective) for a background split over the ranks (shard_background=1): op 0 = SUM of int64 words
         (the normal-equation accumulators, after every launch of the Gauss-Newton loop), op 1 = MIN of unsigned 64-bit words (the z-keys
-        of the index map).  torch.distributed on a torch-owned staging tensor, enqueued on the library's stream."""
+        of the index map).  torch.distributed in place on a tensor view of the library's buffer, on the stream the library hands over."""
         import torch.distributed as dist
-        self._co_buf = None
-        self._co_calls = 0
         sign = torch.tensor(-2 ** 63, dtype=torch.int64, device=self.device)
 
         def thunk(_user, op, dev_buf, words, hip_stream):
             try:
-                n = int(words)
-                if self._co_buf is None or self._co_buf.numel() < n:
-                    self._co_buf = torch.empty(n, dtype=torch.int64, device=self.device)
-                t = self._co_buf[:n]
-                ctx = self._ctx()
-                nbytes = C.c_uint64(n * 8)
-                if self.abi.cf_memcpy_d2d_async(ctx, C.c_void_p(t.data_ptr()), C.c_void_p(dev_buf), nbytes) != 0:
-                    return -1
+                t = torch.as_tensor(_DevWords(dev_buf, words), device=self.device)   # a view of the library's buffer: reduced in place
                 stream = torch.cuda.ExternalStream(int(hip_stream), device=self.device) if hip_stream else torch.cuda.current_stream(self.device)
-                with torch.cuda.stream(stream):
+                with torch.cuda.stream(stream):   # everything on the stream the library enqueues this model's work on
                     if op == 0:
-                        dbg = os.environ.get("CF_DEBUG_COLLECTIVE") and self._co_calls < 6
-                        if dbg:
-                            before = t.view(-1, 32).sum(0).cpu().numpy()
                         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                        if dbg:
-                            after = t.view(-1, 32).sum(0).cpu().numpy()
-                            print(f"[collective rank {dist.get_rank()} call {self._co_calls}] inliers {before[28]} -> {after[28]}  rgb count {before[29]} -> {after[29]}  w0 {before[0]} -> {after[0]}", flush=True)
-                        self._co_calls += 1
                     else:  # unsigned order through the signed collective: flip the sign bit, MIN, flip back
                         t.bitwise_xor_(sign)
                         dist.all_reduce(t, op=dist.ReduceOp.MIN)
                         t.bitwise_xor_(sign)
-                if self.abi.cf_memcpy_d2d_async(ctx, C.c_void_p(dev_buf), C.c_void_p(t.data_ptr()), nbytes) != 0:
-                    return -1
                 return 0
             except Exception:  # noqa: BLE001 -- reported through the C return code
                 import traceback
@@ -128,27 +149,22 @@ class CoFusion:
 
     def set_allreduce_device(self):
         """The collective for buffers that live in HBM (per-superpixel segmentation sums): RCCL all-reduce of an int64 torch tensor,
-        enqueued after the library's work on the context's stream -- no host visit.  The library's buffer is copied device-to-device
-        into / out of a torch-owned tensor because torch.distributed takes tensors, not raw addresses."""
+        enqueued after the library's work on the context's stream -- no host visit.  torch.distributed takes tensors, not raw
+        addresses: the library's buffer is wrapped as a tensor VIEW (_DevWords) and reduced in place.  This is the path of process groups
+        that are not RCCL (the gloo tests on a one-GPU box); with RCCL use init_rccl (the library's own communicator)."""
         import torch.distributed as dist
-        self._ar_buf = None
 
         def thunk(dev_buf, n, hip_stream, _user):
             try:
-                if self._ar_buf is None or self._ar_buf.numel() < n:
-                    self._ar_buf = torch.empty(int(n), dtype=torch.int64, device=self.device)
-                t = self._ar_buf[:n]
-                ctx = self._ctx()
-                nbytes = C.c_uint64(int(n) * 8)
-                if self.abi.cf_memcpy_d2d_async(ctx, C.c_void_p(t.data_ptr()), C.c_void_p(dev_buf), nbytes) != 0:
-                    return -1
+                t = torch.as_tensor(_DevWords(dev_buf, n), device=self.device)   # a view of the library's buffer: reduced in place
                 # the library enqueues on the torch stream it was handed (set_stream / the current stream at construction)
-                with torch.cuda.stream(torch.cuda.ExternalStream(int(hip_stream), device=self.device)) if hip_stream else torch.cuda.stream(torch.cuda.current_stream(self.device)):
+                stream = torch.cuda.ExternalStream(int(hip_stream), device=self.device) if hip_stream else torch.cuda.current_stream(self.device)
+                with torch.cuda.stream(stream):
                     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                if self.abi.cf_memcpy_d2d_async(ctx, C.c_void_p(dev_buf), C.c_void_p(t.data_ptr()), nbytes) != 0:
-                    return -1
                 return 0
             except Exception:  # noqa: BLE001 -- reported through the C return code
+                import traceback
+                traceback.print_exc()
                 return -1
 
         self._allreduce_dev_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p)(thunk)  # keep alive

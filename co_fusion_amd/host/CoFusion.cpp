@@ -93,6 +93,46 @@ void Distributed::sumDevice(cf_ctx* ctx, int64_t* dev, uint64_t n) const
     check(ctx, cf_memcpy_h2d(ctx, dev, h.data(), n * 8), "sums upload");
 }
 
+// ---- RCCL inside the library (csrc/rccl_comm.hip) as this instance's collective ----
+namespace {
+int rccl_sum_device(int64_t* dev, uint64_t n, void* stream, void* user)
+{
+    return cf_rccl_allreduce(static_cast<cf_ctx*>(user), dev, n, 0, stream) == CF_OK ? 0 : -1;
+}
+int rccl_sum_host(int64_t* buf, uint64_t n, void* user)
+{   // the few host-side exchanges (surfel counts at retirement, the pose exchange of frames without the device segmentation)
+    CoFusion* cf = static_cast<CoFusion*>(user);
+    return cf->rcclSumHost(buf, n);
+}
+}  // namespace
+
+int CoFusion::rcclSumHost(int64_t* buf, uint64_t n)
+{
+    if (n > rcclStageWords) {
+        if (rcclStage) cf_free(ctx, rcclStage);
+        rcclStage = nullptr; rcclStageWords = 0;
+        void* p = nullptr;
+        const uint64_t words = n < 4096 ? 4096 : n;
+        if (cf_malloc(ctx, words * 8, &p) != CF_OK) return -1;
+        rcclStage = static_cast<int64_t*>(p); rcclStageWords = words;
+    }
+    if (cf_memcpy_h2d(ctx, rcclStage, buf, n * 8) != CF_OK) return -1;
+    if (cf_rccl_allreduce(ctx, rcclStage, n, 0, cf_get_stream(ctx)) != CF_OK) return -1;
+    return cf_memcpy_d2h(ctx, buf, rcclStage, n * 8) == CF_OK ? 0 : -1;
+}
+
+void CoFusion::initRccl(const void* id128)
+{
+    check(ctx, cf_rccl_init(ctx, id128, dist.rank, dist.world), "cf_rccl_init");
+    dist.allreduce_dev = rccl_sum_device; dist.user_dev = ctx;
+    dist.allreduce_i64 = rccl_sum_host; dist.user = this;
+}
+
+void CoFusion::broadcast(void* dev_buf, uint64_t bytes, int root)
+{
+    check(ctx, cf_rccl_broadcast(ctx, dev_buf, bytes, root, cf_get_stream(ctx)), "cf_rccl_broadcast");
+}
+
 // ------------------------------------------------------------------------------- Model ----
 Model::Model(cf_ctx* c, unsigned char id_, float confidenceThresh, bool enableFillIn, int maxSurfels, float maxDepth_, bool owned_)
     : ctx(c), pose(Mat4f::identity()), lastPose(Mat4f::identity()), confidenceThreshold(confidenceThresh), maxDepth(maxDepth_), id(id_),
@@ -762,6 +802,7 @@ CoFusion::~CoFusion()
     cf_free(ctx, rgba_dev); cf_free(ctx, rgb_dev); cf_free(ctx, mask_dev);
     for (int b = 0; b < 2; b++) if (stage[b]) cf_free_host(ctx, stage[b]);
     labelGenerator.reset();
+    if (rcclStage) cf_free(ctx, rcclStage);
     cf_destroy(ctx);
 }
 

@@ -252,6 +252,13 @@ class CoFusion {
     // the collective of the model-parallel mode (cfg.world > 1); must be set before the first frame
     void setAllreduce(int (*fn)(int64_t*, uint64_t, void*), void* user) { dist.allreduce_i64 = fn; dist.user = user; }
     void setAllreduceDevice(int (*fn)(int64_t*, uint64_t, void*, void*), void* user) { dist.allreduce_dev = fn; dist.user_dev = user; }
+    // the library's own RCCL communicator (cf_rccl_init) as the collective of this instance: device buffers are all-reduced in place by
+    // ncclAllReduce on the context's stream, host buffers through a small device staging buffer; also registers the collective of a
+    // split background.  `id128` is the ncclUniqueId rank 0 created (cofusion_rccl_unique_id).  Collective call: every rank of cfg.world.
+    void initRccl(const void* id128);
+    // depth + colour of a frame (any device buffer) from rank `root` to every rank: ncclBroadcast on the context's stream
+    void broadcast(void* dev_buf, uint64_t bytes, int root);
+    int rcclSumHost(int64_t* buf, uint64_t n);  // (the host-buffer flavour of the collective; 0 on success)
     const Distributed& distributed() const { return dist; }
     ModelList& getModels() { return models; }
     ModelPointer getBackgroundModel() { return globalModel; }
@@ -282,6 +289,8 @@ class CoFusion {
     int tick = 1;
     float maxDepthProcessed = 20.0f;
     unsigned spawnOffset = 0;
+    int64_t* rcclStage = nullptr;      // device staging buffer of the host-buffer all-reduce (initRccl)
+    uint64_t rcclStageWords = 0;
     bool capReported = false;  // the model cap suppressed a spawn and said so
     bool lost = false;
     // device frame buffers (CoFusion::textures)

@@ -6,6 +6,8 @@
 #include <iterator>
 #include <string>
 
+#include <rccl/rccl.h>
+
 #include "CoFusion.h"
 #include "KlgIO.h"
 
@@ -155,6 +157,27 @@ int cofusion_set_allreduce(cofusion_handle* h, cofusion_allreduce_i64_fn fn, voi
 int cofusion_set_allreduce_device(cofusion_handle* h, cofusion_allreduce_dev_fn fn, void* user)
 {
     h->cf->setAllreduceDevice(fn, user);
+    return 0;
+}
+int cofusion_rccl_unique_id(void* id128)
+{
+    // (ncclGetUniqueId directly: creating the id needs no context, and rank 0 calls this before any instance exists)
+    static_assert(sizeof(ncclUniqueId) == CF_RCCL_ID_BYTES, "ncclUniqueId is 128 bytes");
+    if (!id128) { g_err = "null id buffer"; return -1; }
+    const ncclResult_t r = ncclGetUniqueId(static_cast<ncclUniqueId*>(id128));
+    if (r != ncclSuccess) { g_err = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r); return -1; }
+    return 0;
+}
+int cofusion_init_rccl(cofusion_handle* h, const void* id128)
+{
+    if (!h || !id128) { g_err = "null argument"; return -1; }
+    GUARD(h->cf->initRccl(id128));
+    return 0;
+}
+int cofusion_broadcast(cofusion_handle* h, void* dev_buf, uint64_t bytes, int root)
+{
+    if (!h || !dev_buf) { g_err = "null argument"; return -1; }
+    GUARD(h->cf->broadcast(dev_buf, bytes, root));
     return 0;
 }
 int cofusion_model_owned(cofusion_handle* h, int index)

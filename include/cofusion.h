@@ -83,6 +83,16 @@ int cofusion_set_allreduce(cofusion_handle *h, cofusion_allreduce_i64_fn fn, voi
  * buffers are staged through the host callback. */
 typedef int (*cofusion_allreduce_dev_fn)(int64_t *dev_buf, uint64_t n, void *hip_stream, void *user);
 int cofusion_set_allreduce_device(cofusion_handle *h, cofusion_allreduce_dev_fn fn, void *user);
+/* RCCL inside the library: instead of the two callbacks above, give the instance its own ncclComm_t (created on the instance's
+ * device, one process per GPU).  Rank 0 creates the 128-byte ncclUniqueId (cofusion_rccl_unique_id) and hands it to the other
+ * ranks over any side channel (a file, MPI, a torch.distributed broadcast); then EVERY rank of cfg.world calls cofusion_init_rccl
+ * (collective).  From then on the segmentation sums / tracked poses, the split reductions of a sharded background and the host-side
+ * exchanges run ncclAllReduce in place on the context's stream -- no staging copies, no callback into the host language.
+ * cofusion_broadcast sends a device buffer (a frame: depth + colour) from rank `root` to every rank with ncclBroadcast on the same
+ * stream, so a following cofusion_process_frame_device consumes it in stream order (device_frames_complete = 0). */
+int cofusion_rccl_unique_id(void *id128 /* 128 bytes */);
+int cofusion_init_rccl(cofusion_handle *h, const void *id128);
+int cofusion_broadcast(cofusion_handle *h, void *dev_buf, uint64_t bytes, int root);
 /* 1 if the model at `index` lives on this rank, 0 if it is a shadow (count reads 0, download is empty) */
 int cofusion_model_owned(cofusion_handle *h, int index);
 /* diagnostics: accumulated host wall-clock (ms) per processFrame phase on the calling thread -- prepare, track, slic+sums,

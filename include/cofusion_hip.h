@@ -247,6 +247,20 @@ int cf_odom_set_culling(cf_odom *od, int on);
 typedef int (*cf_collective_fn)(void *user, int op, void *dev_buf, uint64_t words, void *hip_stream);
 int cf_set_collective(cf_ctx *ctx, cf_collective_fn fn, void *user);
 int cf_odom_set_band(cf_odom *od, int row_begin, int row_end, int add_counts);
+/* RCCL inside the library (one process per GPU; north_star: "RCCL all-reduce of the 6x6 system over xGMI").  cf_rccl_unique_id
+ * wraps ncclGetUniqueId (rank 0 creates the 128-byte id, the caller hands it to the other ranks over any side channel);
+ * cf_rccl_init creates the context's own ncclComm_t on the context's device (collective call: every rank of `world`) and registers
+ * the library's own collective in place of cf_set_collective: the split reductions then run ncclAllReduce in place on the stream
+ * their kernels are enqueued on -- no staging copy, no callback.  cf_rccl_allreduce: op 0 = SUM of int64 words, op 1 = MIN of
+ * unsigned 64-bit words, in place, enqueued on hip_stream (NULL: the context's stream); cf_rccl_broadcast: `bytes` bytes from
+ * rank `root` (a frame from the ingest GPU).  cf_destroy releases the communicator. */
+#define CF_RCCL_ID_BYTES 128
+int cf_rccl_unique_id(void *id128);
+int cf_rccl_init(cf_ctx *ctx, const void *id128, int rank, int world);
+int cf_rccl_allreduce(cf_ctx *ctx, void *dev_buf, uint64_t words, int op, void *hip_stream);
+int cf_rccl_broadcast(cf_ctx *ctx, void *dev_buf, uint64_t bytes, int root, void *hip_stream);
+int cf_rccl_info(const cf_ctx *ctx, int *rank, int *world, int *rccl_version);
+int cf_rccl_destroy(cf_ctx *ctx);
 int cf_odom_bind_frame_maps(cf_odom *od, const float *const vmaps[CF_NUM_PYRS], const float *const nmaps[CF_NUM_PYRS]);
 int cf_odom_buffer(cf_odom *od, int which, int level, void **dptr, uint64_t *bytes);
 /* Model::generateCUDATextures depth half (Model.cpp:341-343): l1/l2 device outputs */

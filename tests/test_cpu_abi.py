@@ -98,3 +98,19 @@ def test_sqrt_gate_bounds_terminate_and_decide_exactly(libs):
                 want = (np.sqrt(f32(x)) < Tf) if strict else (np.sqrt(f32(x)) <= Tf)
                 got = (f32(x) < bl) if strict else (f32(x) <= be)
                 assert bool(want) == bool(got), (T, float(x), strict)
+
+
+def test_library_links_rccl_and_resolves_it(libs):
+    """RCCL is called from inside the library (csrc/rccl_comm.hip, host/cofusion_c.cpp): both shared objects import the nccl* entry
+    points, and they resolve when the libraries are loaded (no GPU needed to create a unique id is NOT assumed: only symbol resolution
+    and the argument checks are exercised here)."""
+    for path, needed in ((libs.LIB_PATH, {"ncclAllReduce", "ncclBroadcast", "ncclCommInitRank", "ncclCommDestroy", "ncclGetUniqueId"}),
+                         (libs.HOST_LIB_PATH, {"ncclGetUniqueId"})):
+        out = subprocess.check_output(["nm", "-D", "--undefined-only", path]).decode()
+        imported = set(re.findall(r" U (nccl\w+)", out))
+        assert needed <= imported, f"{os.path.basename(path)} imports {sorted(imported)}"
+    lib = libs.load()          # dlopen succeeded: librccl.so.1 was found and every nccl symbol bound
+    host = libs.load_host()
+    assert lib.cf_rccl_init(None, None, 0, 1) != 0 and lib.cf_rccl_allreduce(None, None, 0, 0, None) != 0
+    assert lib.cf_rccl_destroy(None) != 0
+    assert host.cofusion_init_rccl(None, None) != 0 and host.cofusion_broadcast(None, None, 0, 0) != 0

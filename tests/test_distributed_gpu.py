@@ -188,3 +188,45 @@ def test_background_split_at_1280x960_matches_single_gpu(tmp_path, world):
     mp.spawn(_mp_worker, args=(world, port, str(tmp_path), False, True, (1280, 960), 18, 4), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+def test_library_rccl_communicator_executes_on_the_gpu():
+    """The library's own RCCL communicator (csrc/rccl_comm.hip: cf_rccl_init / cf_rccl_allreduce / cf_rccl_broadcast).  The box has ONE
+    GPU and RCCL refuses two ranks on one device, so this is a one-rank communicator: ncclCommInitRank, ncclAllReduce (SUM of int64,
+    MIN of uint64) and ncclBroadcast really run on the MI355X on the context's stream, in place; with one rank they must leave the
+    buffers unchanged.  Then the split background's hook: a tracker with a row band covering the whole image reduces through the
+    registered RCCL collective inside the device-resident Gauss-Newton loop and must equal the plain run bit for bit."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import common
+    from co_fusion_amd import api
+    W, H = 320, 240
+    fp = common.frame_pair(W, H, noise=True)
+    cam = fp["cam"]
+    ctx = api.Context(W, H, cam.fx, cam.fy, cam.cx, cam.cy)
+    ctx.rccl_init(api.Context.rccl_unique_id(), 0, 1)
+    info = ctx.rccl_info()
+    assert info["active"] and info["world"] == 1 and info["version"] >= 20000
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-2 ** 62, 2 ** 62, (64 * 32,), dtype=torch.int64, generator=g)
+    d = a.cuda()
+    ctx.rccl_allreduce(d, 0); ctx.rccl_allreduce(d, 1); ctx.rccl_broadcast(d, 0)
+    ctx.synchronize()
+    assert torch.equal(d.cpu(), a)
+
+    def track(band):
+        od = api.Odometry(ctx)
+        dv = ctx.to_device
+        pose = common.perturbed_pose(2)
+        od.init_first_rgb(dv(fp["rgba0"])); od.init_icp_model(dv(fp["v4"]), dv(fp["n4"]), pose); od.init_rgb_model(dv(fp["img"]))
+        od.init_icp(ctx.depth_pyramid(dv(fp["d1"])), 20.0); od.init_rgb(dv(fp["rgba1"]))
+        if band:
+            od.set_band(0, H, 1)   # the whole image as "this rank's band": every launch goes through the collective
+        tr, rot, st = od.track(pose[:3, 3], pose[:3, :3])
+        od.close()
+        return tr, rot, st
+    t0, r0, s0 = track(False)
+    t1, r1, s1 = track(True)
+    assert t0.tobytes() == t1.tobytes() and r0.tobytes() == r1.tobytes() and s0.last_icp_count == s1.last_icp_count > 1000
+    ctx.close()

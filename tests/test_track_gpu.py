@@ -196,3 +196,56 @@ def test_get_incremental_transformation(ctx, opts):
     exact = np.array_equal(tr, otr) and np.array_equal(rot, orot)
     print("pose bit-exact:", exact)
     g.close()
+
+
+def test_screen_box_culling_leaves_the_gauss_newton_loop_bit_identical():
+    """cf_odom_set_culling: an object-sized model (the prediction cut down to a rectangle) tracked with the occupancy look-up and the
+    screen-box culling of the ICP reduction -- workgroups outside the re-projected bounding box of the predicted vertices leave before
+    they load anything -- must give the bits of the unculled run and of the oracle; the box must be a proper part of the image,
+    contain the model's rectangle, and an empty prediction must cull everything (exact zeros, pose unchanged)."""
+    from co_fusion_amd import api
+    W, H = 320, 240
+    fp = common.frame_pair(W, H, noise=True)
+    cam = fp["cam"]
+    pose = common.perturbed_pose(2)
+    x0, x1, y0, y1 = 120, 200, 60, 150
+    v4 = fp["v4"].copy(); n4 = fp["n4"].copy()
+    keep = np.zeros((H, W), bool); keep[y0:y1, x0:x1] = True
+    v4[~keep] = 0; n4[~keep] = 0
+    ctx = api.Context(W, H, cam.fx, cam.fy, cam.cx, cam.cy)
+    d = ctx.to_device
+
+    def run(vv, nn, cull):
+        g = api.Odometry(ctx)
+        g.set_culling(cull)
+        g.init_first_rgb(d(fp["rgba0"])); g.init_icp_model(d(vv), d(nn), pose); g.init_rgb_model(d(fp["img"]))
+        g.init_icp(ctx.depth_pyramid(d(fp["d1"])), 20.0); g.init_rgb(d(fp["rgba1"]))
+        err = ctx.empty((H, W))
+        tr, rot, st = g.track(pose[:3, 3], pose[:3, :3], err_surface=err)
+        e = err.cpu().numpy()
+        g.close()
+        return tr, rot, st, e
+
+    t0, r0, s0, e0 = run(v4, n4, False)
+    t1, r1, s1, e1 = run(v4, n4, True)
+    assert t0.tobytes() == t1.tobytes() and r0.tobytes() == r1.tobytes() and e0.tobytes() == e1.tobytes()
+    assert s0.last_icp_count == s1.last_icp_count > 500 and s0.last_rgb_count == s1.last_rgb_count
+    assert np.array_equal(np.array(s0.lastA), np.array(s1.lastA)) and np.array_equal(np.array(s0.lastb), np.array(s1.lastb))
+    b = list(s1.cull_box)
+    assert list(s0.cull_box) == [0, 0, W - 1, H - 1]
+    assert b[0] <= x0 and b[1] <= y0 and b[2] >= x1 - 1 and b[3] >= y1 - 1, b
+    assert (min(b[2], W - 1) - max(b[0], 0) + 1) * (min(b[3], H - 1) - max(b[1], 0) + 1) < 0.8 * W * H, f"the box {b} culls nothing"
+    # the oracle on the same cut-down prediction
+    od = orc.Odometry(W, H, cam.cx, cam.cy, cam.fx, cam.fy)
+    od.init_first_rgb(fp["rgba0"]); od.init_icp_model(v4, n4, pose); od.init_rgb_model(fp["img"])
+    od.init_icp(orc.depth_pyramid(fp["d1"]), 20.0); od.init_rgb(fp["rgba1"])
+    otr, orot, ost = od.track(pose[:3, 3], pose[:3, :3])
+    assert t1.tobytes() == np.asarray(otr, np.float32).tobytes() and r1.tobytes() == np.asarray(orot, np.float32).tobytes()
+    assert s1.last_icp_count == ost.last_icp_count
+    # an empty prediction: everything culled
+    z4 = np.zeros_like(v4)
+    t2, r2, s2, _ = run(z4, z4, True)
+    t3, r3, s3, _ = run(z4, z4, False)
+    assert t2.tobytes() == t3.tobytes() and r2.tobytes() == r3.tobytes() and s2.last_icp_count == s3.last_icp_count == 0
+    assert s2.cull_box[0] > s2.cull_box[2], list(s2.cull_box)
+    ctx.close()
