@@ -209,6 +209,19 @@ int cf_join(cf_ctx* ctx)
     ctx->lanes_used = 0;
     return CF_OK;
 }
+// ... for one lane only: the main stream waits for what that lane holds, the other lanes keep running beside it
+int cf_join_lane(cf_ctx* ctx, int lane)
+{
+    if (!ctx || lane < 0) return CF_EINVAL;
+    lane %= cf_ctx::kLanes;
+    if (ctx->forked) { ctx->stream = ctx->forked_from; ctx->forked = false; }
+    if (ctx->lanes_used & (1u << lane)) {
+        HIPCHK(ctx, hipEventRecord(ctx->lane_done[lane], ctx->lanes[lane]));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_done[lane], 0));
+        ctx->lanes_used &= ~(1u << lane);
+    }
+    return CF_OK;
+}
 // Bind the calling thread to lane `lane` of the context (lane < 0: unbind).  The owning thread forks the lane first (cf_fork, then
 // cf_main), which orders the lane after the stream and books it for the next cf_join; the bound thread's model calls then go to
 // the lane without touching the context's current stream.
@@ -649,13 +662,22 @@ int cf_odom_init_rgb(cf_odom* od, const uint8_t* rgba) { if (!od || !rgba) retur
 int cf_odom_init_models_batch(cf_ctx* ctx, cf_odom* const* ods, int n, const float* const* pred_v4, const float* const* pred_n4,
                               const uint8_t* const* pred_rgba, const float* const* poses, const uint8_t* frame_rgba)
 {
+    if (!ctx || n <= 0 || !frame_rgba) return CF_EINVAL;
+    std::vector<const uint8_t*> frames((size_t)n, frame_rgba);
+    return cf_odom_init_models_batch_frames(ctx, ods, n, pred_v4, pred_n4, pred_rgba, poses, frames.data());
+}
+
+// ... with one frame image per tracker: the trackers of SEVERAL sequences (each tracking its own frame) prepared by the same launches
+int cf_odom_init_models_batch_frames(cf_ctx* ctx, cf_odom* const* ods, int n, const float* const* pred_v4, const float* const* pred_n4,
+                                     const uint8_t* const* pred_rgba, const float* const* poses, const uint8_t* const* frame_rgba)
+{
     if (!ctx || !ods || n <= 0 || !pred_v4 || !pred_n4 || !pred_rgba || !poses || !frame_rgba) return CF_EINVAL;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
     if (W % 4 || H % 4) {
         for (int k = 0; k < n; k++) {
             if (int r = cf_odom_init_icp_model(ods[k], pred_v4[k], pred_n4[k], poses[k])) return r;
             if (int r = cf_odom_init_rgb_model(ods[k], pred_rgba[k])) return r;
-            if (int r = cf_odom_init_rgb(ods[k], frame_rgba)) return r;
+            if (int r = cf_odom_init_rgb(ods[k], frame_rgba[k])) return r;
         }
         return CF_OK;
     }
@@ -666,10 +688,10 @@ int cf_odom_init_models_batch(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
         RgbdBatch rb{};
         for (int k = 0; k < nb; k++) {
             cf_odom* od = ods[base + k];
-            if (!od || !pred_v4[base + k] || !pred_n4[base + k] || !pred_rgba[base + k] || !poses[base + k]) return CF_EINVAL;
+            if (!od || !pred_v4[base + k] || !pred_n4[base + k] || !pred_rgba[base + k] || !poses[base + k] || !frame_rgba[base + k]) return CF_EINVAL;
             mb.m[k] = model_maps_args(od, pred_v4[base + k], pred_n4[base + k], poses[base + k]);
             rb.c[2 * k] = rgbd_chain(od, pred_rgba[base + k], od->lastDepth, od->lastImage);   // initRGBModel
-            rb.c[2 * k + 1] = rgbd_chain(od, frame_rgba, od->nextDepth, od->nextImage);        // initRGB
+            rb.c[2 * k + 1] = rgbd_chain(od, frame_rgba[base + k], od->nextDepth, od->nextImage);        // initRGB
             // ... whose depth pyramid would be a second copy of the first chain's (same source, same cutoff): intensity only
             for (int i = 0; i < CF_NUM_PYRS; ++i) rb.c[2 * k + 1].depth[i] = nullptr;
             od->next_depth_is_last = true;
@@ -851,12 +873,15 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     if (!ctx || !ods || n <= 0 || n > ctx->cfg.max_models || n > kMaxBatch || !poses_in || !opts) return CF_EINVAL;
     const bool want_rgb = opts->rgb_only || opts->icp_weight < 100;
     if (ctx->state_readback_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ctx->state_readback_pending = false; }
-    RgbPrepBatch prep{};
-    for (int m = 0; m < n; m++) {
-        if (int r = odom_prepare(ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr, &prep.m[m])) return r;
-        ctx->h_model_ptrs[m] = ods[m]->d_state;
+    for (int base = 0; base < n; base += kPrepBatch) {  // the preparation launches hold kPrepBatch trackers each
+        const int nb = n - base < kPrepBatch ? n - base : kPrepBatch;
+        RgbPrepBatch prep{};
+        for (int m = base; m < base + nb; m++) {
+            if (int r = odom_prepare(ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr, &prep.m[m - base])) return r;
+            ctx->h_model_ptrs[m] = ods[m]->d_state;
+        }
+        if (want_rgb) launch_rgb_prep(ctx->stream, prep, nb, ctx->cfg.width, ctx->cfg.height);
     }
-    if (want_rgb) launch_rgb_prep(ctx->stream, prep, n, ctx->cfg.width, ctx->cfg.height);
     // state upload: one copy over the slot range when every tracker of the batch lives in the pool (the host copies of
     // other trackers in the range equal their device copies: both are only written by a tracking call + its read-back)
     int lo = cf_ctx::kStateSlots, hi = -1;

@@ -44,7 +44,7 @@ struct cf_ctx {
     hipStream_t lanes[kLanes]{};
     hipEvent_t lane_done[kLanes]{};
     hipEvent_t fork_point = nullptr;
-    static constexpr int kMarks = 4;
+    static constexpr int kMarks = 64;  // (a group of sequences sharing the context uses four per sequence)
     hipEvent_t marks[kMarks]{};       // cf_mark / cf_fork_after: points of the main stream a detached lane waits for
     bool mark_set[kMarks]{};
     hipStream_t forked_from = nullptr;

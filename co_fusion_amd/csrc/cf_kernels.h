@@ -114,7 +114,8 @@ struct IcpLaunch { int threads; int ppt; };  // threads per workgroup, pixels pe
 // stand-alone steps (C-ABI parity with icpStep / computeRgbResidual / rgbStep / so3Step) run the same
 // kernels on a scratch OdomDev prepared by cabi.cpp.
 // ICP kernel arguments (by value, in the kernarg segment): per-model pointers + shared geometry
-constexpr int kMaxBatch = 8;
+constexpr int kMaxBatch = 16;  // trackers per lock-step launch (grid.y): the models of one frame, or of several sequences' frames.
+                               // Bounded by the 4 KB kernel-argument segment (IcpArgs + RgbArgs by value: 3.4 KB at 16)
 struct IcpModelArgs {
     const float* vc; const float* nc;   // current-frame vertex / normal planes of this level
     const float* vp; const float* np;   // model prediction planes (global frame)
@@ -229,13 +230,15 @@ void launch_feedback(hipStream_t s, const uint8_t* rgba, const float* depth, int
 void launch_scatter_records(hipStream_t s, const float* rec, const unsigned* flags, const unsigned* offsets, long long n, float* out,
                             unsigned out_base);
 void launch_init(hipStream_t s, const float* raw, const float* filt, const unsigned* raw_count, long long max_n, float* out);
+// t_inv_dev (nullable): the transform as 16 floats in device memory (launch_pose_tinv) instead of the host array t_inv (then nullable)
 void launch_index_keys(hipStream_t s, const float* surfels, const unsigned* count, unsigned id_begin, unsigned id_end, const float t_inv[16],
-                       cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys);
+                       cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, const float* t_inv_dev = nullptr);
 void launch_index_resolve(hipStream_t s, const float* surfels, const float t_inv[16], int cols, int rows, unsigned long long* keys,
-                          unsigned* index, float* vertConf, float* colorTime, float* normRad);
+                          unsigned* index, float* vertConf, float* colorTime, float* normRad, const float* t_inv_dev = nullptr);
 void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                             int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, unsigned* index,
-                            float* vertConf, float* colorTime, float* normRad);
+                            float* vertConf, float* colorTime, float* normRad, const float* t_inv_dev = nullptr);
+void launch_pose_tinv(hipStream_t s, const OdomDev* state, float* t_inv_dev /* [16] */);
 void launch_splat_rays(hipStream_t s, cf_cam cam, int cols, int rows, float* rays /* [rows*cols*4] */);
 void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                              int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,

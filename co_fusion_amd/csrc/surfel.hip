@@ -23,6 +23,23 @@ namespace cf {
 
 static constexpr int kB = 256;
 static inline int gridFor(long long n) { return (int)((n + kB - 1) / kB); }
+// XCD-aware workgroup order for passes that gather from the index-map images: the hardware deals consecutive workgroups round-robin
+// over the 8 XCDs, each with its own L2, so neighbouring workgroups -- neighbouring surfels / pixels, which read the same image
+// lines -- would pull every line into all eight L2s.  With a grid that is a multiple of 8, XCD x is given the x-th contiguous range
+// of logical workgroups (a band of the image / a run of the surfel buffer) instead.
+static inline int gridXcd(long long n, int chunk = 1) { const int q = 8 * (chunk > 1 ? chunk : 1); return (gridFor(n) + q - 1) / q * q; }  // xcd_block is a bijection on it
+// chunk > 0: the XCDs take turns on runs of `chunk` consecutive logical workgroups (locality inside a run, balance between the XCDs
+// when the cost per workgroup drifts along the buffer); chunk < 0: one band per XCD; 0: plain round-robin (the hardware's order).
+static int xcd_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+__device__ __forceinline__ int xcd_block(int chunk)
+{
+    const int b = blockIdx.x;
+    if (chunk == 0) return b;
+    const int per = (int)gridDim.x >> 3, x = b & 7, r = b >> 3;  // XCD, rank inside the XCD
+    if (chunk < 0) return x * per + r;
+    const int lb = ((r / chunk) * 8 + x) * chunk + (r % chunk);
+    return lb;  // (the grid is a multiple of 8 * chunk: a bijection)
+}
 
 __device__ __forceinline__ unsigned sortable_bits(float z)
 {  // order-preserving float -> uint
@@ -262,25 +279,29 @@ __device__ __forceinline__ bool index_project(const float4 pc, const float4 ct, 
     return true;
 }
 
-__global__ void __launch_bounds__(kB) index_splat_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count, Mat4 t_inv,
-                                                         cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta,
-                                                         unsigned id_begin, unsigned id_end, unsigned long long* __restrict__ keys)
+// t_dev (nullable): the transform in device memory instead of the kernel argument -- the inverse of a pose the tracker has just left
+// in HBM (pose_tinv_kernel), for passes that are enqueued before the host has seen that pose
+__global__ void __launch_bounds__(kB) index_splat_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count, Mat4 t_arg,
+                                                         const Mat4* __restrict__ t_dev, cf_cam cam, int cols, int rows, float maxDepth, int time,
+                                                         int timeDelta, unsigned id_begin, unsigned id_end, unsigned long long* __restrict__ keys)
 {
     // [id_begin, id_end): the surfel range of this launch (the whole map, or a rank's shard of it)
     const unsigned id = id_begin + blockIdx.x * kB + threadIdx.x;
     if (id >= *count || id >= id_end) return;
+    const Mat4 t_inv = t_dev ? *t_dev : t_arg;
     f3 ph; int q;
     if (!index_project(surfels[id * 3], surfels[id * 3 + 1], t_inv, cam, cols, rows, maxDepth, time, timeDelta, ph, q)) return;
     atomicMin(&keys[q], zkey(ph.z, id));
 }
 
-__global__ void __launch_bounds__(kB) index_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_inv, int N,
+__global__ void __launch_bounds__(kB) index_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_arg, const Mat4* __restrict__ t_dev, int N,
                                                            unsigned long long* __restrict__ keys, unsigned* __restrict__ index,
                                                            float4* __restrict__ vertConf, float4* __restrict__ colorTime,
                                                            float4* __restrict__ normRad)
 {
     const int q = blockIdx.x * kB + threadIdx.x;
     if (q >= N) return;
+    const Mat4 t_inv = t_dev ? *t_dev : t_arg;
     const unsigned long long k = keys[q];
     keys[q] = kEmptyKey;  // leave the z-buffer cleared for the next pass (no memset launch per projection)
     if (k == kEmptyKey) {
@@ -502,7 +523,7 @@ __device__ __forceinline__ float bilerp(float a, float b, float c, float d, floa
 static constexpr int kAssocItems = kB / 4;   // pixels per workgroup
 static constexpr int kPatchStride = 7 * 16 + 1;  // words per staged neighbourhood (+1: odd stride, no bank conflicts)
 
-__global__ void __launch_bounds__(kB) associate_kernel(const FuseArgs a)
+__global__ void __launch_bounds__(kB) associate_kernel(const FuseArgs a, int xcd)
 {
     __shared__ float s_patch[kAssocItems * kPatchStride];
     const int cols = a.cols, rows = a.rows;
@@ -511,7 +532,7 @@ __global__ void __launch_bounds__(kB) associate_kernel(const FuseArgs a)
     // the image; new_flags is cleared by a memset beforehand.
     const int par = a.time % 2;
     const int n_i = (cols - par + 1) / 2, n_j = (rows - par + 1) / 2;
-    const int gt = blockIdx.x * kB + threadIdx.x;
+    const int gt = xcd_block(xcd) * kB + threadIdx.x;
     const int t = gt >> 2, sub = gt & 3;
     float* const P = s_patch + (threadIdx.x >> 2) * kPatchStride;  // word c of texel k: P[c * 16 + k]
     bool alive = t < n_i * n_j;
@@ -685,11 +706,11 @@ static constexpr int kCleanItems = kB / 4;
 
 __global__ void __launch_bounds__(kB) clean_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count,
                                                    const float4* __restrict__ fresh, const unsigned* __restrict__ n_fresh, const CleanArgs a,
-                                                   unsigned total_bound, float4* __restrict__ staged, unsigned* __restrict__ flags)
+                                                   unsigned total_bound, float4* __restrict__ staged, unsigned* __restrict__ flags, int xcd)
 {
     __shared__ float s_patch[kCleanItems * kPatchStride];
     float* const P = s_patch + (threadIdx.x >> 2) * kPatchStride;  // word c of texel t: P[c * 16 + t]
-    const unsigned gt = blockIdx.x * kB + threadIdx.x;
+    const unsigned gt = (unsigned)xcd_block(xcd) * kB + threadIdx.x;
     const unsigned k = gt >> 2;
     const int sub = (int)(gt & 3u);
     const unsigned n_old = *count, n_all = n_old + *n_fresh;
@@ -827,27 +848,55 @@ void launch_init(hipStream_t s, const float* raw, const float* filt, const unsig
                                               reinterpret_cast<float4*>(out));
 }
 void launch_index_keys(hipStream_t s, const float* surfels, const unsigned* count, unsigned id_begin, unsigned id_end, const float t_inv[16],
-                       cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys)
+                       cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, const float* t_inv_dev)
 {
-    const Mat4 T = mat4_from(t_inv);
+    const Mat4 T = t_inv ? mat4_from(t_inv) : Mat4{};
     if (id_end > id_begin)
-        index_splat_kernel<<<gridFor(id_end - id_begin), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, cam, cols, rows, maxDepth,
-                                                                     time, timeDelta, id_begin, id_end, keys);
+        index_splat_kernel<<<gridFor(id_end - id_begin), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, reinterpret_cast<const Mat4*>(t_inv_dev),
+                                                                     cam, cols, rows, maxDepth, time, timeDelta, id_begin, id_end, keys);
 }
 void launch_index_resolve(hipStream_t s, const float* surfels, const float t_inv[16], int cols, int rows, unsigned long long* keys,
-                          unsigned* index, float* vertConf, float* colorTime, float* normRad)
+                          unsigned* index, float* vertConf, float* colorTime, float* normRad, const float* t_inv_dev)
 {
     const int N = cols * rows;
-    index_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), mat4_from(t_inv), N, keys, index,
+    index_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), t_inv ? mat4_from(t_inv) : Mat4{},
+                                                   reinterpret_cast<const Mat4*>(t_inv_dev), N, keys, index,
                                                    reinterpret_cast<float4*>(vertConf), reinterpret_cast<float4*>(colorTime),
                                                    reinterpret_cast<float4*>(normRad));
 }
+// inverse of the pose a tracker left in its device state (Rcurr | tcurr after the last solve of the schedule): the statement of
+// inv44f (cabi_model.hip) / Mat4f::inverse (host/CoFusion.cpp), so the bits equal what the host computes from the fetched pose
+__global__ void pose_tinv_kernel(const OdomDev* __restrict__ st, Mat4* __restrict__ out)
+{
+    float a[16];
+    for (int r = 0; r < 3; r++) { a[r * 4 + 0] = st->Rcurr[r * 3 + 0]; a[r * 4 + 1] = st->Rcurr[r * 3 + 1]; a[r * 4 + 2] = st->Rcurr[r * 3 + 2]; a[r * 4 + 3] = st->tcurr[r]; }
+    const float c00 = a[5] * a[10] - a[6] * a[9];
+    const float c01 = a[6] * a[8] - a[4] * a[10];
+    const float c02 = a[4] * a[9] - a[5] * a[8];
+    const float det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    const float id = 1.0f / det;
+    float Li[9];
+    Li[0] = c00 * id; Li[1] = (a[2] * a[9] - a[1] * a[10]) * id; Li[2] = (a[1] * a[6] - a[2] * a[5]) * id;
+    Li[3] = c01 * id; Li[4] = (a[0] * a[10] - a[2] * a[8]) * id; Li[5] = (a[2] * a[4] - a[0] * a[6]) * id;
+    Li[6] = c02 * id; Li[7] = (a[1] * a[8] - a[0] * a[9]) * id; Li[8] = (a[0] * a[5] - a[1] * a[4]) * id;
+    Mat4 o;
+    for (int i = 0; i < 3; i++) {
+        o.m[i * 4 + 0] = Li[i * 3 + 0]; o.m[i * 4 + 1] = Li[i * 3 + 1]; o.m[i * 4 + 2] = Li[i * 3 + 2];
+        o.m[i * 4 + 3] = -(Li[i * 3 + 0] * a[3] + Li[i * 3 + 1] * a[7] + Li[i * 3 + 2] * a[11]);
+    }
+    o.m[12] = 0; o.m[13] = 0; o.m[14] = 0; o.m[15] = 1;
+    *out = o;
+}
+void launch_pose_tinv(hipStream_t s, const OdomDev* state, float* t_inv_dev)
+{
+    pose_tinv_kernel<<<1, 1, 0, s>>>(state, reinterpret_cast<Mat4*>(t_inv_dev));
+}
 void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                             int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, unsigned* index,
-                            float* vertConf, float* colorTime, float* normRad)
+                            float* vertConf, float* colorTime, float* normRad, const float* t_inv_dev)
 {
-    launch_index_keys(s, surfels, count, 0, count_bound, t_inv, cam, cols, rows, maxDepth, time, timeDelta, keys);
-    launch_index_resolve(s, surfels, t_inv, cols, rows, keys, index, vertConf, colorTime, normRad);
+    launch_index_keys(s, surfels, count, 0, count_bound, t_inv, cam, cols, rows, maxDepth, time, timeDelta, keys, t_inv_dev);
+    launch_index_resolve(s, surfels, t_inv, cols, rows, keys, index, vertConf, colorTime, normRad, t_inv_dev);
 }
 void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                              int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
@@ -890,7 +939,8 @@ void launch_associate(hipStream_t s, const SurfelFuseArgs& h)
     (void)hipMemsetAsync(h.new_flags, 0, sizeof(unsigned) * (size_t)h.cols * h.rows, s);
     const int par = h.time % 2;
     const long long n = (long long)((h.cols - par + 1) / 2) * ((h.rows - par + 1) / 2);
-    associate_kernel<<<gridFor(4 * n), kB, 0, s>>>(a);
+    static const int chunk = xcd_env("CF_XCD_ASSOC", 0);
+    associate_kernel<<<gridXcd(4 * n, chunk), kB, 0, s>>>(a, chunk);
 }
 void launch_update(hipStream_t s, const float* in, const unsigned* count, unsigned count_bound, unsigned* owner, const float* records, int time,
                    float* out)
@@ -906,9 +956,10 @@ void launch_clean(hipStream_t s, const float* surfels, const unsigned* count, co
     a.index = h.index; a.vertConf = reinterpret_cast<const float4*>(h.vertConf); a.colorTime = reinterpret_cast<const float4*>(h.colorTime);
     a.depth_filt = h.depth_filt; a.mask = h.mask; a.t_inv = mat4_from(h.t_inv); a.cam = h.cam; a.cols = h.cols; a.rows = h.rows; a.time = h.time;
     a.confThreshold = h.confThreshold; a.outlierCoeff = h.outlierCoeff; a.timeDelta = h.timeDelta; a.maskID = h.maskID;
+    static const int chunk = xcd_env("CF_XCD_CLEAN", 64);
     if (total_bound > 0)
-        clean_kernel<<<gridFor(4ll * total_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, reinterpret_cast<const float4*>(fresh), n_fresh,
-                                                         a, total_bound, reinterpret_cast<float4*>(staged), flags);
+        clean_kernel<<<gridXcd(4ll * total_bound, chunk), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, reinterpret_cast<const float4*>(fresh), n_fresh,
+                                                         a, total_bound, reinterpret_cast<float4*>(staged), flags, chunk);
 }
 void launch_add_counts(hipStream_t s, const unsigned* a, const unsigned* b, unsigned* out) { add_counts_kernel<<<1, 1, 0, s>>>(a, b, out); }
 void launch_set_count(hipStream_t s, unsigned* out, unsigned v) { set_count_kernel<<<1, 1, 0, s>>>(out, v); }

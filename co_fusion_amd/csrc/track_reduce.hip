@@ -177,6 +177,7 @@ template <bool COMPACT> __device__ void rgb_residual_body(const RgbArgs& ra, int
 // VALU budget (the kernel is VALU-bound once several models share a launch): PPT pixels per lane feed ONE
 // 32 x u64 butterfly; a wave whose pixels cannot produce a correspondence (projection out of view, model map empty
 // there -- the common case for object models, which cover a small part of the image) leaves after the projection.
+static_assert(sizeof(IcpArgs) + sizeof(RgbArgs) + 16 <= 4096, "the kernel-argument segment holds 4 KB: lower kMaxBatch");
 template <int PPT, int LEVEL_TAG>
 __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, const RgbArgs ra, int n_icp_blocks)
 {

@@ -43,23 +43,32 @@ def rccl_unique_id():
     return bytes(buf)
 
 
+def _make_config(lib, width, height, fx, fy, cx, cy, device, kw):
+    cfg = Config()
+    lib.cofusion_default_config(C.byref(cfg))
+    cfg.width, cfg.height, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.device = width, height, fx, fy, cx, cy, device
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown CoFusion option {k}")
+        setattr(cfg, k, v)
+    return cfg
+
+
 class CoFusion:
-    def __init__(self, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, device=0, **kw):
+    def __init__(self, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, device=0, _borrowed=None, **kw):
         if not torch.cuda.is_available():
             raise CoFusionError("no GPU visible: the Co-Fusion hot path has no CPU fallback")
         self.lib = _libmod.load_host()
         self.abi = _libmod.load()
-        cfg = Config()
-        self.lib.cofusion_default_config(C.byref(cfg))
-        cfg.width, cfg.height, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.device = width, height, fx, fy, cx, cy, device
-        for k, v in kw.items():
-            if not hasattr(cfg, k):
-                raise TypeError(f"unknown CoFusion option {k}")
-            setattr(cfg, k, v)
+        cfg = _make_config(self.lib, width, height, fx, fy, cx, cy, device, kw)
         self.cfg = cfg
         self.width, self.height = width, height
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
+        self._owned = _borrowed is None
+        if _borrowed is not None:   # a sequence of a CoFusionGroup: the handle belongs to the group
+            self.h = C.c_void_p(_borrowed)
+            return
         self.h = C.c_void_p()
         self._check(self.lib.cofusion_create(C.byref(cfg), C.byref(self.h)))
         self._check(self.lib.cofusion_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
@@ -198,7 +207,8 @@ class CoFusion:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.cofusion_destroy(self.h)
+            if getattr(self, "_owned", True):
+                self.lib.cofusion_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -295,3 +305,62 @@ class CoFusion:
         p = Profile()
         assert self.abi.cf_profile_read(self._ctx(), C.byref(p), int(reset)) == 0
         return p
+
+
+class CoFusionGroup:
+    """Several independent RGB-D sequences on ONE GPU in lock-step (include/cofusion.h: cofusion_group_*): one context, one set of
+    tracking launches for the trackers of all sequences.  `sequences[s]` is a CoFusion view of sequence s for the getters (model_info,
+    model_download, mask, ...); frames are fed to all sequences at once with process_frames / process_frames_device."""
+
+    def __init__(self, n_sequences, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, device=0, **kw):
+        if not torch.cuda.is_available():
+            raise CoFusionError("no GPU visible: the Co-Fusion hot path has no CPU fallback")
+        self.lib = _libmod.load_host()
+        cfg = _make_config(self.lib, width, height, fx, fy, cx, cy, device, kw)
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.n = int(n_sequences)
+        self.g = C.c_void_p()
+        if self.lib.cofusion_group_create(C.byref(cfg), self.n, C.byref(self.g)) != 0:
+            raise CoFusionError(f"cofusion_group_create: {self.lib.cofusion_last_error().decode()}")
+        self._check(self.lib.cofusion_group_set_stream(self.g, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        self.sequences = [CoFusion(width, height, fx, fy, cx, cy, device, _borrowed=self.lib.cofusion_group_sequence(self.g, s), **kw)
+                          for s in range(self.n)]
+
+    def _check(self, rc):
+        if rc != 0:
+            raise CoFusionError(f"cofusion error {rc}: {self.lib.cofusion_last_error().decode()}")
+
+    def set_stream(self, stream):
+        ptr = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+        self._check(self.lib.cofusion_group_set_stream(self.g, C.c_void_p(ptr)))
+
+    def process_frames(self, depths, rgbs, masks=None, timestamp=0):
+        """one frame per sequence from host arrays: depths[s] f32 [H,W] metres, rgbs[s] u8 [H,W,3], masks[s] u8 [H,W] or None"""
+        keep = [np.ascontiguousarray(d, np.float32) for d in depths] + [np.ascontiguousarray(r, np.uint8) for r in rgbs]
+        mk = [None if (masks is None or m is None) else np.ascontiguousarray(m, np.uint8) for m in (masks or [None] * self.n)]
+        P = C.c_void_p * self.n
+        ts = (C.c_int64 * self.n)(*([timestamp] * self.n))
+        self._check(self.lib.cofusion_group_process_frames(
+            self.g, ts, P(*[r.ctypes.data for r in keep[self.n:]]), P(*[d.ctypes.data for d in keep[:self.n]]),
+            P(*[None if m is None else m.ctypes.data for m in mk]) if masks is not None else None))
+
+    def process_frames_device(self, depth_ts, rgba_ts, timestamp=0):
+        """one frame per sequence already resident in HBM: torch CUDA tensors depth f32 [H,W], rgba u8 [H,W,4]"""
+        P = C.c_void_p * self.n
+        ts = (C.c_int64 * self.n)(*([timestamp] * self.n))
+        self._check(self.lib.cofusion_group_process_frames_device(self.g, ts, P(*[t.data_ptr() for t in depth_ts]),
+                                                                  P(*[t.data_ptr() for t in rgba_ts])))
+
+    def close(self):
+        if getattr(self, "g", None):
+            for s in self.sequences:
+                s.h = None
+            self.lib.cofusion_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -235,6 +235,12 @@ void Model::predictIndices(int time, float depthCutoff, int timeDelta)
     if (shards > 1) check(ctx, cf_model_predict_indices_sharded(model, pose.m, time, depthCutoff, timeDelta, shard, shards), "predictIndices (sharded)");
     else check(ctx, cf_model_predict_indices(model, pose.m, time, depthCutoff, timeDelta), "predictIndices");
 }
+void Model::predictIndicesTracked(int time, float depthCutoff, int timeDelta, int lane)
+{
+    if (!owned) return;
+    check(ctx, cf_model_predict_indices_tracked(model, odom, time, depthCutoff, timeDelta), "predictIndices (tracked pose)");
+    preIndexedTick = time; preIndexedLane = lane;
+}
 void Model::combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta)
 {
     if (!owned) return;
@@ -756,7 +762,10 @@ private:
     bool stop = false;
 };
 
-CoFusion::CoFusion(const Config& c) : cfg(c), ctx(make_ctx(c))
+CoFusion::CoFusion(const Config& c) : CoFusion(c, nullptr, 0) {}
+
+CoFusion::CoFusion(const Config& c, cf_ctx* shared, int sequenceIndex)
+    : cfg(c), ownsCtx(shared == nullptr), markBase(4 * sequenceIndex), ctx(shared ? shared : make_ctx(c))
 {
     dist.rank = cfg.rank; dist.world = cfg.world < 1 ? 1 : cfg.world;
     dist.shardBackground = cfg.shardBackground && dist.world > 1;
@@ -803,7 +812,7 @@ CoFusion::~CoFusion()
     for (int b = 0; b < 2; b++) if (stage[b]) cf_free_host(ctx, stage[b]);
     labelGenerator.reset();
     if (rcclStage) cf_free(ctx, rcclStage);
-    cf_destroy(ctx);
+    if (ownsCtx) cf_destroy(ctx);
 }
 
 unsigned char CoFusion::getNextModelID(bool assign)
@@ -861,7 +870,8 @@ void CoFusion::predict(bool lastOfFrame)
 void CoFusion::modelPasses(Model& model, bool fuse, float weightMultiplier, bool lost)
 {
     if (fuse) {
-        model.predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
+        // (the first index map of a tracked model was enqueued right behind its tracking, beside the segmentation: processFrame)
+        if (model.preIndexedTick != tick) model.predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
         model.fuse(tick, curRgba, mask_dev, curDepth, depthFiltered_dev, maxDepthProcessed, weightMultiplier);
         model.predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
         model.clean(tick, cfg.timeDelta, maxDepthProcessed, depthFiltered_dev, mask_dev, cfg.outlierCoefficient);
@@ -874,10 +884,13 @@ void CoFusion::modelPasses(Model& model, bool fuse, float weightMultiplier, bool
 // touch disjoint buffers (shared inputs: frame, mask), so each model's whole chain goes to its own stream, without a barrier
 // between fusion and prediction; with Config::enqueueThreads the chains are also ENQUEUED by different host threads (~19 launches
 // per model: worth it when the host's launch rate is the limit).
-void CoFusion::fuseAndPredict(bool fuse, float weightMultiplier, bool lost)
+void CoFusion::fuseAndPredict(bool fuse, float weightMultiplier, bool lost, bool join, int laneOffset)
 {
-    const bool overlap = models.size() > 1 && useLanes;
+    // (a sequence of a lock-step group puts even a single model's chain on a lane -- the chains of the OTHER sequences run beside it --
+    // and leaves the join to the group)
+    const bool overlap = (models.size() > 1 || !join) && useLanes;
     if (!overlap) {
+        check(ctx, cf_join(ctx), "cf_join");  // (an index map enqueued on a lane before a deactivation left one model: order the stream after it)
         for (auto& model : models) modelPasses(*model, fuse, weightMultiplier, lost);
         return;
     }
@@ -885,14 +898,16 @@ void CoFusion::fuseAndPredict(bool fuse, float weightMultiplier, bool lost)
     for (auto& model : models) if (model->isOwned()) list.push_back(model.get());
     const int n = (int)list.size();
     // a split background talks to the other ranks from inside its passes (the caller's collective): keep that on this thread
-    const bool threaded = pool && n > 1 && !dist.shardBackground;
+    const bool threaded = pool && n > 1 && !dist.shardBackground && join;
     const int lanes = 6;  // lanes 6 and 7 belong to the frame head and the superpixel pass
     if (!threaded) {
         for (int i = 0; i < n; i++) {
-            check(ctx, cf_fork(ctx, i % lanes), "cf_fork");
+            // a model whose first index map is already queued on a lane continues on that lane (stream order is the dependency)
+            check(ctx, cf_fork(ctx, (fuse && list[i]->preIndexedTick == tick) ? list[i]->preIndexedLane : (laneOffset + i) % lanes), "cf_fork");
             modelPasses(*list[i], fuse, weightMultiplier, lost);
         }
-        check(ctx, cf_join(ctx), "cf_join");
+        if (join) check(ctx, cf_join(ctx), "cf_join");
+        else check(ctx, cf_main(ctx), "cf_main");
         return;
     }
     for (int i = 0; i < n && i < lanes; i++) check(ctx, cf_fork(ctx, i), "cf_fork");
@@ -910,41 +925,58 @@ void CoFusion::fuseAndPredict(bool fuse, float weightMultiplier, bool lost)
     if (failed) std::rethrow_exception(failed);
 }
 
-void CoFusion::trackModels(const float* const depthPyr[3])
-{  // CoFusion.cpp:213-217 + Model::performTracking (Model.cpp:369-389); all models advance in lock-step on the GPU
-    std::vector<Model*> ms;
+// CoFusion.cpp:213-217 + Model::performTracking (Model.cpp:369-389), in two halves so that the trackers of SEVERAL sequences (a lock-step
+// group, CoFusionGroup) can advance through the same launches: every sequence adds its owned models to a batch (trackCollect), the batch
+// is prepared and tracked at once (trackLaunch), each sequence collects its own poses later (fetchTracking).
+void CoFusion::trackCollect(TrackBatch& batch, const float* const depthPyr[3])
+{
+    Model* owner = nullptr;  // computes the frame-wide vertex / normal pyramids the other models of this sequence (and rank) share
+    trackPending.clear();
     for (auto& m : models) {
         m->lastPose = m->pose;
-        if (m->isOwned()) ms.push_back(m.get());
+        if (!m->isOwned()) continue;
+        if (!owner) owner = m.get();
+        TrackBatch::Item it;
+        it.model = m.get(); it.owner = owner; it.frameRgba = curRgba; it.maxDepth = maxDepthProcessed;
+        for (int l = 0; l < 3; l++) it.depthPyr[l] = depthPyr[l];
+        m->trackingInputs(m->requiresFillIn(), cfg.frameToFrameRGB, it.predV, it.predN, it.predImg);
+        batch.items.push_back(it);
+        trackPending.push_back(m.get());
     }
-    if (!ms.empty()) {
-        // Model::initICP of every model (initICPModel + initRGBModel + initICP + initRGB), batched: one launch per
-        // preparation kernel for all models of the frame
-        Model* owner = ms[0];  // computes the frame-wide vertex / normal pyramids the other models of this rank share
-        std::vector<cf_odom*> ods; std::vector<const float*> pv, pn, pp; std::vector<const uint8_t*> pi;
-        for (Model* m : ms) {
-            const float* v; const float* n; const uint8_t* img;
-            m->trackingInputs(m->requiresFillIn(), cfg.frameToFrameRGB, v, n, img);
-            ods.push_back(m->odom); pv.push_back(v); pn.push_back(n); pi.push_back(img); pp.push_back(m->pose.m);
-        }
-        check(ctx, cf_odom_init_models_batch(ctx, ods.data(), (int)ods.size(), pv.data(), pn.data(), pi.data(), pp.data(), curRgba),
-              "init_models_batch");
-        for (Model* m : ms) m->bindFrameMaps(depthPyr, maxDepthProcessed, owner);
+}
+
+void CoFusion::trackLaunch(cf_ctx* ctx, TrackBatch& batch, const Config& cfg)
+{
+    const size_t n = batch.items.size();
+    if (n == 0) return;
+    // Model::initICP of every model (initICPModel + initRGBModel + initICP + initRGB), batched: one launch per preparation kernel for
+    // all models of the batch
+    std::vector<cf_odom*> ods; std::vector<const float*> pv, pn, pp; std::vector<const uint8_t*> pi, fr;
+    for (auto& it : batch.items) {
+        ods.push_back(it.model->odom); pv.push_back(it.predV); pn.push_back(it.predN); pi.push_back(it.predImg); pp.push_back(it.model->pose.m);
+        fr.push_back(it.frameRgba);
     }
+    check(ctx, cf_odom_init_models_batch_frames(ctx, ods.data(), (int)n, pv.data(), pn.data(), pi.data(), pp.data(), fr.data()), "init_models_batch");
+    for (auto& it : batch.items) it.model->bindFrameMaps(it.depthPyr, it.maxDepth, it.owner);
     cf_track_opts opts{};
     opts.rgb_only = cfg.rgbOnly; opts.pyramid = cfg.pyramid; opts.fast_odom = cfg.fastOdom; opts.so3 = cfg.so3; opts.icp_weight = cfg.icpWeight;
-    // lock-step batches of at most kMaxBatch (8) models; the LAST batch is left in flight (fetchTracking collects it after whatever the
-    // caller enqueues behind it), earlier ones are collected here because the next batch re-uses the context's staging
-    const int B = 8;
-    trackPending.clear();
-    for (size_t base = 0; base < ms.size(); base += B) {
-        const int n = (int)std::min<size_t>(B, ms.size() - base);
-        cf_odom* ods[B]; const float* poses[B]; float* errs[B];
-        for (int k = 0; k < n; k++) { ods[k] = ms[base + k]->odom; poses[k] = ms[base + k]->pose.m; errs[k] = ms[base + k]->icpError; }
-        if (!trackPending.empty()) fetchTracking(false);
-        check(ctx, cf_odom_track_batch_async(ctx, ods, n, poses, &opts, errs), "track_batch");
-        for (int k = 0; k < n; k++) trackPending.push_back(ms[base + k]);
+    // lock-step launches of at most 16 trackers (kMaxBatch, csrc/cf_kernels.h); a further chunk starts when the previous one has
+    // finished (cf_odom_track_batch_async waits for it: the chunks share the context's staging), the LAST one is left in flight --
+    // fetchTracking collects it after whatever the caller enqueues behind it
+    const size_t B = 16;
+    for (size_t base = 0; base < n; base += B) {
+        const int k_n = (int)std::min(B, n - base);
+        cf_odom* o[B]; const float* poses[B]; float* errs[B];
+        for (int k = 0; k < k_n; k++) { Model* m = batch.items[base + k].model; o[k] = m->odom; poses[k] = m->pose.m; errs[k] = m->icpError; }
+        check(ctx, cf_odom_track_batch_async(ctx, o, k_n, poses, &opts, errs), "track_batch");
     }
+}
+
+void CoFusion::trackModels(const float* const depthPyr[3])
+{
+    TrackBatch batch;
+    trackCollect(batch, depthPyr);
+    trackLaunch(ctx, batch, cfg);
 }
 
 void CoFusion::fetchTracking(bool exchange)
@@ -989,23 +1021,33 @@ void CoFusion::exchangeTracking()
     }
 }
 
-bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float weightMultiplier, bool bootstrap)
+// CoFusion::processFrame (Core/CoFusion.cpp:171-524) as a sequence of stages.  One sequence runs them back to back (processFrame);
+// a lock-step group of sequences (CoFusionGroup) runs each stage for all its sequences before the next, with ONE set of tracking
+// launches for the trackers of all of them.
+//   frameBegin   upload, depth filter + pyramid, first-frame initialisation, superpixels started aside
+//   trackCollect / trackLaunch   (above)
+//   frameMiddle  segmentation enqueued, the frame's host wait (poses + segmentation decisions), model bookkeeping
+//   frameFuse    per-model fusion / clean-up / prediction chains
+//   frameEnd     clock, pose log
+void CoFusion::frameBegin(const FrameData& frame, const Mat4f* inPose, float weightMultiplier, bool bootstrap)
 {
+    st = FrameStage{};
+    st.frame = &frame; st.inPose = inPose; st.weightMultiplier = weightMultiplier; st.bootstrap = bootstrap;
     const size_t N = (size_t)cfg.width * cfg.height;
-    check(ctx, cf_join(ctx), "cf_join");  // a previous call that threw inside a forked region must not leave the context on a lane
+    if (ownsCtx) check(ctx, cf_join(ctx), "cf_join");  // a previous call that threw inside a forked region must not leave the context on a lane
     // upload (CoFusion.cpp:179-184); RGB -> RGBA like the GL_RGBA texture upload
     if (frame.rgba_dev && frame.depth_dev) { curRgba = frame.rgba_dev; curDepth = frame.depth_dev; }
     else {
         // one memcpy into pinned staging, transfers only enqueued (no host wait), RGB -> RGBA on the device.  The staging set
         // used two frames ago is free again once the stream has passed that frame's transfer (stageMark).
         const unsigned sb = uploads & 1u;
-        if (uploads >= 2) check(ctx, cf_event_wait_host(ctx, 2 + (int)sb), "staging wait");
-        uint8_t* st = stage[sb];
-        memcpy(st, frame.depth, N * 4);
-        memcpy(st + N * 4, frame.rgb, N * 3);
-        check(ctx, cf_memcpy_h2d_async(ctx, depth_dev, st, N * 4), "depth upload");
-        check(ctx, cf_memcpy_h2d_async(ctx, rgb_dev, st + N * 4, N * 3), "rgb upload");
-        check(ctx, cf_mark(ctx, 2 + (int)sb), "cf_mark");
+        if (uploads >= 2) check(ctx, cf_event_wait_host(ctx, markBase + 2 + (int)sb), "staging wait");
+        uint8_t* sp = stage[sb];
+        memcpy(sp, frame.depth, N * 4);
+        memcpy(sp + N * 4, frame.rgb, N * 3);
+        check(ctx, cf_memcpy_h2d_async(ctx, depth_dev, sp, N * 4), "depth upload");
+        check(ctx, cf_memcpy_h2d_async(ctx, rgb_dev, sp + N * 4, N * 3), "rgb upload");
+        check(ctx, cf_mark(ctx, markBase + 2 + (int)sb), "cf_mark");
         check(ctx, cf_rgb_to_rgba(ctx, rgb_dev, cfg.width, cfg.height, rgba_dev), "rgb expand");
         uploads++;
         curRgba = rgba_dev; curDepth = depth_dev;
@@ -1015,117 +1057,147 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
     // mark[b] = end of the last frame that used buffer set b, which is all this lane has to wait for.
     const bool willTrack = tick > 1 && (bootstrap || !inPose);
     const unsigned b = frameParity & 1u;
+    st.willTrack = willTrack; st.b = b;
     frameParity++;
     depthFiltered_dev = depthFilteredBuf[b]; depthPyr1 = depthPyr1Buf[b]; depthPyr2 = depthPyr2Buf[b];
     const bool headAside = useLanes && cfg.deviceFramesComplete && frame.depth_dev != nullptr;
-    if (headAside) check(ctx, cf_fork_after(ctx, 6, (int)b), "cf_fork_after");
+    if (headAside) check(ctx, cf_fork_after(ctx, 6, markBase + (int)b), "cf_fork_after");
     check(ctx, cf_bilateral(ctx, curDepth, cfg.width, cfg.height, cfg.depthCutoff, depthFiltered_dev), "filterDepth");
     if (willTrack) check(ctx, cf_depth_pyramid(ctx, depthFiltered_dev, cfg.width, cfg.height, depthPyr1, depthPyr2), "generateCUDATextures");
-    if (headAside) check(ctx, cf_join(ctx), "cf_join");
+    if (headAside) check(ctx, cf_join_lane(ctx, 6), "cf_join_lane");
 
-    bool fuseNow = false;
+    st.pyr[0] = depthFiltered_dev; st.pyr[1] = depthPyr1; st.pyr[2] = depthPyr2;
     if (tick == 1) {
         globalModel->initialise(curRgba, curDepth, depthFiltered_dev, tick, maxDepthProcessed);
         if (globalModel->isOwned()) check(ctx, cf_odom_init_first_rgb(globalModel->getFrameOdometry(), curRgba), "initFirstRGB");
-    } else {
-        bool trackingOk = true;
-        if (bootstrap || !inPose) {
-            const float* pyr[3] = {depthFiltered_dev, depthPyr1, depthPyr2};
-            // the superpixels only depend on the colour image: SLIC runs on an auxiliary stream beside the (latency-bound)
-            // tracking launches and is joined before the segmentation needs it
-            const bool slicAside = cfg.enableMultipleModels && !frame.mask && useLanes;
-            if (slicAside) {
-                check(ctx, cf_fork(ctx, 7), "cf_fork");
-                labelGenerator->startSlic(curRgba);
-                check(ctx, cf_main(ctx), "cf_main");
-            }
-            { PhaseTimer t(PhaseTimes::Track); trackModels(pyr); }
-            if (slicAside) check(ctx, cf_join(ctx), "cf_join");
-            // a new label needs a free model slot: the segmenter holds at most 16 labels and the context was sized for
-            // cfg.maxModels trackers (the reference allows 256 ids, CoFusion.cpp:631-634; its GUI never gets there)
-            bool allowNew = false;
-            const bool segOnDevice = cfg.enableMultipleModels && !frame.mask && !segOnHost;
-            if (cfg.enableMultipleModels) {
-                if (spawnOffset < cfg.modelSpawnOffset) spawnOffset++;
-                const size_t modelCap = (size_t)std::min(cfg.maxModels, 16);
-                allowNew = spawnOffset >= cfg.modelSpawnOffset && models.size() < modelCap;
-                if (spawnOffset >= cfg.modelSpawnOffset && !allowNew && !capReported) {  // say so once: the reference would go on to 256 ids
-                    fprintf(stderr, "[cofusion] %zu active models: the model cap (min(max_models, 16)) suppresses further spawns\n", models.size());
-                    capReported = true;
-                }
-            }
-            // the motion segmentation reads device data only (ICP error surfaces, predictions): enqueued right behind the tracking
-            // launches, so that poses AND segmentation decisions are collected by ONE host wait
-            if (segOnDevice) labelGenerator->enqueueCRF(models, curDepth, curRgba, getNextModelID(), allowNew, mask_dev);
-            { PhaseTimer t(PhaseTimes::Track); fetchTracking(true); }
-            if (bootstrap) globalModel->overridePose(globalModel->getPose() * (*inPose));
-
-            if (cfg.enableMultipleModels) {
-                auto getMaxDepth = [](const SegmentationResult::ModelData& d) -> float { return d.depthMean + d.depthStd * 1.2; };
-                SegmentationResult seg;
-                if (segOnDevice) seg = labelGenerator->finishCRF();
-                else {
-                    // the colour features of the CRF read the first K pixels of the full-resolution image
-                    const int K = (cfg.width / 16) * (cfg.height / 16);
-                    std::vector<uint8_t> firstRows((size_t)K * 4);
-                    if (frame.rgba_dev) check(ctx, cf_memcpy_d2h(ctx, firstRows.data(), curRgba, (size_t)K * 4), "rgb readback");
-                    else for (int i = 0; i < K; i++) { firstRows[i * 4] = frame.rgb[i * 3]; firstRows[i * 4 + 1] = frame.rgb[i * 3 + 1]; firstRows[i * 4 + 2] = frame.rgb[i * 3 + 2]; firstRows[i * 4 + 3] = 255; }
-                    seg = labelGenerator->performSegmentation(models, frame, curDepth, curRgba, firstRows.data(), getNextModelID(), allowNew, mask_dev);
-                }
-                if (!exportSegmentationPrefix.empty()) {  // CoFusion.cpp:235-240: labels > 254 (rejected) are written as 0
-                    std::vector<uint8_t> labels(N);
-                    check(ctx, cf_memcpy_d2h(ctx, labels.data(), mask_dev, N), "mask readback");
-                    for (auto& v : labels) if (v > 254) v = 0;
-                    writePngGray8(exportSegmentationPrefix + "Segmentation" + std::to_string(tick) + ".png", labels.data(), cfg.width, cfg.height);
-                }
-                if (seg.hasNewLabel) {
-                    spawnObjectModel();
-                    spawnOffset = 0;
-                    newModel->setMaxDepth(getMaxDepth(seg.modelData.back()));
-                }
-                {
-                    auto it = models.begin();
-                    for (unsigned i = 1; i < models.size(); i++) (*++it)->setMaxDepth(getMaxDepth(seg.modelData[i]));
-                }
-                if (seg.hasNewLabel) {
-                    newModel->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
-                    newModel->fuse(tick, curRgba, mask_dev, curDepth, depthFiltered_dev, maxDepthProcessed, 100);
-                    newModel->clean(tick, cfg.timeDelta, maxDepthProcessed, depthFiltered_dev, mask_dev, cfg.outlierCoefficient);
-                    moveNewModelToList();
-                }
-                for (auto& md : seg.modelData) {  // CoFusion.cpp:284-291
-                    if (md.superPixelCount <= 0) {
-                        auto it = models.begin();
-                        std::advance(it, md.modelIndex);
-                        if ((*it)->incrementUnseenCount() > 0 && md.id != 0) {
-                            inactivateModel(it);
-                            // later entries referred to list positions that have now shifted by one
-                            for (auto& o : seg.modelData) if (o.modelIndex > md.modelIndex) o.modelIndex--;
-                        }
-                    }
-                }
-                {
-                    auto it = models.begin();
-                    for (unsigned i = 1; i < models.size(); i++) {  // :294-298 (indices into modelData are NOT re-aligned, as in the reference)
-                        const float oldConf = (*++it)->getConfidenceThreshold();
-                        (*it)->setConfidenceThreshold(std::fmin(std::fmax(oldConf, seg.modelData[i].avgConfidence), 9.0f));
-                    }
-                }
-            }
-        } else {
-            globalModel->overridePose(*inPose);
+    } else if (willTrack) {
+        // the superpixels only depend on the colour image: SLIC runs on an auxiliary stream beside the (latency-bound)
+        // tracking launches and is joined before the segmentation needs it
+        st.slicAside = cfg.enableMultipleModels && !frame.mask && useLanes;
+        if (st.slicAside) {
+            check(ctx, cf_fork(ctx, 7), "cf_fork");
+            labelGenerator->startSlic(curRgba);
+            check(ctx, cf_main(ctx), "cf_main");
         }
-        // CoFusion.cpp:346 predicts every model here, between tracking and fusion.  Nothing in the frame loop reads that prediction: fuse
-        // and clean work on the index maps, the segmentation read the PREVIOUS prediction before this point, and the prediction at the
-        // end of the frame overwrites all of it -- in the reference it only feeds the GUI.  Off by default (Config::midFramePredict).
-        if (cfg.midFramePredict) { PhaseTimer t(PhaseTimes::Predict); predict(); }
-        fuseNow = !cfg.rgbOnly && trackingOk && !lost;
     }
-    {
-        PhaseTimer t(fuseNow ? PhaseTimes::Fuse : PhaseTimes::Predict);
-        fuseAndPredict(fuseNow, weightMultiplier, lost);
+}
+
+void CoFusion::frameMiddle()
+{
+    const FrameData& frame = *st.frame;
+    const Mat4f* inPose = st.inPose;
+    const bool bootstrap = st.bootstrap;
+    const size_t N = (size_t)cfg.width * cfg.height;
+    st.fuseNow = false;
+    if (tick == 1) return;
+    bool trackingOk = true;
+    if (bootstrap || !inPose) {
+        if (st.slicAside) check(ctx, cf_join_lane(ctx, 7), "cf_join_lane");
+        // Every tracked model's first index map (CoFusion.cpp:316-318) depends on its new pose only, and the pose is in device
+        // memory when the Gauss-Newton loop ends: enqueued here, on the models' lanes, it runs beside the segmentation instead
+        // of behind the frame's host wait.  Not when the pose is overridden afterwards (bootstrap), not for shadows / shards.
+        if (preIndex && !bootstrap && !cfg.rgbOnly && !lost && !dist.active() && !pool) {
+            int i = 0;
+            const bool lanes = models.size() > 1 && useLanes;
+            for (auto& m : models) {
+                if (!m->isOwned() || m->shards > 1) continue;
+                if (lanes) check(ctx, cf_fork(ctx, i % 6), "cf_fork");
+                m->predictIndicesTracked(tick, maxDepthProcessed, cfg.timeDelta, i % 6);
+                i++;
+            }
+            if (lanes) check(ctx, cf_main(ctx), "cf_main");
+        }
+        // a new label needs a free model slot: the segmenter holds at most 16 labels and the context was sized for
+        // cfg.maxModels trackers (the reference allows 256 ids, CoFusion.cpp:631-634; its GUI never gets there)
+        bool allowNew = false;
+        const bool segOnDevice = cfg.enableMultipleModels && !frame.mask && !segOnHost;
+        if (cfg.enableMultipleModels) {
+            if (spawnOffset < cfg.modelSpawnOffset) spawnOffset++;
+            const size_t modelCap = (size_t)std::min(cfg.maxModels, 16);
+            allowNew = spawnOffset >= cfg.modelSpawnOffset && models.size() < modelCap;
+            if (spawnOffset >= cfg.modelSpawnOffset && !allowNew && !capReported) {  // say so once: the reference would go on to 256 ids
+                fprintf(stderr, "[cofusion] %zu active models: the model cap (min(max_models, 16)) suppresses further spawns\n", models.size());
+                capReported = true;
+            }
+        }
+        // the motion segmentation reads device data only (ICP error surfaces, predictions): enqueued right behind the tracking
+        // launches, so that poses AND segmentation decisions are collected by ONE host wait
+        if (segOnDevice) labelGenerator->enqueueCRF(models, curDepth, curRgba, getNextModelID(), allowNew, mask_dev);
+        { PhaseTimer t(PhaseTimes::Track); fetchTracking(true); }
+        if (bootstrap) globalModel->overridePose(globalModel->getPose() * (*inPose));
+
+        if (cfg.enableMultipleModels) {
+            auto getMaxDepth = [](const SegmentationResult::ModelData& d) -> float { return d.depthMean + d.depthStd * 1.2; };
+            SegmentationResult seg;
+            if (segOnDevice) seg = labelGenerator->finishCRF();
+            else {
+                // the colour features of the CRF read the first K pixels of the full-resolution image
+                const int K = (cfg.width / 16) * (cfg.height / 16);
+                std::vector<uint8_t> firstRows((size_t)K * 4);
+                if (frame.rgba_dev) check(ctx, cf_memcpy_d2h(ctx, firstRows.data(), curRgba, (size_t)K * 4), "rgb readback");
+                else for (int i = 0; i < K; i++) { firstRows[i * 4] = frame.rgb[i * 3]; firstRows[i * 4 + 1] = frame.rgb[i * 3 + 1]; firstRows[i * 4 + 2] = frame.rgb[i * 3 + 2]; firstRows[i * 4 + 3] = 255; }
+                seg = labelGenerator->performSegmentation(models, frame, curDepth, curRgba, firstRows.data(), getNextModelID(), allowNew, mask_dev);
+            }
+            if (!exportSegmentationPrefix.empty()) {  // CoFusion.cpp:235-240: labels > 254 (rejected) are written as 0
+                std::vector<uint8_t> labels(N);
+                check(ctx, cf_memcpy_d2h(ctx, labels.data(), mask_dev, N), "mask readback");
+                for (auto& v : labels) if (v > 254) v = 0;
+                writePngGray8(exportSegmentationPrefix + "Segmentation" + std::to_string(tick) + ".png", labels.data(), cfg.width, cfg.height);
+            }
+            if (seg.hasNewLabel) {
+                spawnObjectModel();
+                spawnOffset = 0;
+                newModel->setMaxDepth(getMaxDepth(seg.modelData.back()));
+            }
+            {
+                auto it = models.begin();
+                for (unsigned i = 1; i < models.size(); i++) (*++it)->setMaxDepth(getMaxDepth(seg.modelData[i]));
+            }
+            if (seg.hasNewLabel) {
+                newModel->predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
+                newModel->fuse(tick, curRgba, mask_dev, curDepth, depthFiltered_dev, maxDepthProcessed, 100);
+                newModel->clean(tick, cfg.timeDelta, maxDepthProcessed, depthFiltered_dev, mask_dev, cfg.outlierCoefficient);
+                moveNewModelToList();
+            }
+            for (auto& md : seg.modelData) {  // CoFusion.cpp:284-291
+                if (md.superPixelCount <= 0) {
+                    auto it = models.begin();
+                    std::advance(it, md.modelIndex);
+                    if ((*it)->incrementUnseenCount() > 0 && md.id != 0) {
+                        inactivateModel(it);
+                        // later entries referred to list positions that have now shifted by one
+                        for (auto& o : seg.modelData) if (o.modelIndex > md.modelIndex) o.modelIndex--;
+                    }
+                }
+            }
+            {
+                auto it = models.begin();
+                for (unsigned i = 1; i < models.size(); i++) {  // :294-298 (indices into modelData are NOT re-aligned, as in the reference)
+                    const float oldConf = (*++it)->getConfidenceThreshold();
+                    (*it)->setConfidenceThreshold(std::fmin(std::fmax(oldConf, seg.modelData[i].avgConfidence), 9.0f));
+                }
+            }
+        }
+    } else {
+        globalModel->overridePose(*inPose);
     }
-    check(ctx, cf_mark(ctx, (int)b), "cf_mark");  // everything that reads this frame's filtered depth is enqueued
+    // CoFusion.cpp:346 predicts every model here, between tracking and fusion.  Nothing in the frame loop reads that prediction: fuse
+    // and clean work on the index maps, the segmentation read the PREVIOUS prediction before this point, and the prediction at the
+    // end of the frame overwrites all of it -- in the reference it only feeds the GUI.  Off by default (Config::midFramePredict).
+    if (cfg.midFramePredict) { PhaseTimer t(PhaseTimes::Predict); predict(); }
+    st.fuseNow = !cfg.rgbOnly && trackingOk && !lost;
+}
+
+void CoFusion::frameFuse(bool join, int laneOffset)
+{
+    PhaseTimer t(st.fuseNow ? PhaseTimes::Fuse : PhaseTimes::Predict);
+    fuseAndPredict(st.fuseNow, st.weightMultiplier, lost, join, laneOffset);
+}
+
+void CoFusion::frameEnd()
+{
+    const FrameData& frame = *st.frame;
+    check(ctx, cf_mark(ctx, markBase + (int)st.b), "cf_mark");  // everything that reads this frame's filtered depth is enqueued
     phaseTimes().frames++;
     if (!lost) tick++;
     moveNewModelToList();
@@ -1158,7 +1230,63 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
         model->poseLog.push_back(item);
         first = false;
     }
+}
+
+bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float weightMultiplier, bool bootstrap)
+{
+    frameBegin(frame, inPose, weightMultiplier, bootstrap);
+    if (st.willTrack) { PhaseTimer t(PhaseTimes::Track); trackModels(st.pyr); }
+    frameMiddle();
+    frameFuse(true, 0);
+    frameEnd();
     return false;
+}
+
+// ------------------------------------------------------------------------ CoFusionGroup ----
+// Several independent RGB-D sequences on ONE GPU, advancing in lock-step.  Most kernels of the hot path run at their launch floor
+// (a 640x480 frame is a few MB: ~5 us of launch latency per pass against 1-2 us of streaming), so a second sequence in a context of
+// its own buys little (the contexts compete for the hardware queues: 1.45x with 2-4 contexts).  Here the sequences share
+// ONE context and every set of tracking launches -- map preparation, SO(3) pre-alignment, the 57 launches of the Gauss-Newton loop
+// -- carries the trackers of ALL sequences (grid.y = tracker, as for the models of one frame), the per-model surfel chains of all
+// sequences share the context's lanes, and each sequence keeps its own maps, segmentation and clock.  Results per sequence are those
+// of a CoFusion of its own, bit for bit (the reductions are exact integer sums, independent of what else is in the launch).
+CoFusionGroup::CoFusionGroup(const CoFusion::Config& c, int sequences) : cfg(c)
+{
+    if (sequences < 1 || sequences > 16) throw std::runtime_error("CoFusionGroup: 1..16 sequences");
+    if (c.world > 1) throw std::runtime_error("CoFusionGroup: a group lives on one GPU (world == 1)");
+    CoFusion::Config shared = c;
+    shared.maxModels = c.maxModels * sequences;  // trackers of all sequences in the context's staging
+    ctx = make_ctx(shared);
+    try {
+        for (int s = 0; s < sequences; s++) seqs.emplace_back(new CoFusion(c, ctx, s));
+    } catch (...) { seqs.clear(); cf_destroy(ctx); throw; }
+}
+
+CoFusionGroup::~CoFusionGroup()
+{
+    seqs.clear();
+    cf_destroy(ctx);
+}
+
+void CoFusionGroup::processFrames(const FrameData* frames, const Mat4f* const* inPoses)
+{
+    const int S = (int)seqs.size();
+    check(ctx, cf_join(ctx), "cf_join");  // (a previous call that threw inside a forked region)
+    for (int s = 0; s < S; s++) seqs[s]->frameBegin(frames[s], inPoses ? inPoses[s] : nullptr, 1.f, false);
+    {   // ONE set of tracking launches for the trackers of every sequence that tracks this frame
+        PhaseTimer t(PhaseTimes::Track);
+        CoFusion::TrackBatch batch;
+        for (int s = 0; s < S; s++) if (seqs[s]->frameTracks()) seqs[s]->trackCollect(batch);
+        CoFusion::trackLaunch(ctx, batch, cfg);
+    }
+    for (int s = 0; s < S; s++) seqs[s]->frameMiddle();
+    int lane = 0;
+    for (int s = 0; s < S; s++) {  // the chains of all sequences side by side on the lanes, one join
+        seqs[s]->frameFuse(false, lane);
+        lane += (int)seqs[s]->getModels().size();
+    }
+    check(ctx, cf_join(ctx), "cf_join");
+    for (int s = 0; s < S; s++) seqs[s]->frameEnd();
 }
 
 }  // namespace cofusion

@@ -112,6 +112,10 @@ class Model {
               float weightMultiplier);
     void clean(int time, int timeDelta, float depthCutoff, const float* depthFiltered, const uint8_t* mask, float outlierCoeff);
     void predictIndices(int time, float depthCutoff, int timeDelta);
+    // the same pass under the pose the model's tracker has just left on the device (cf_model_predict_indices_tracked): enqueued behind
+    // the tracking launches, before the host has fetched the pose.  Remembers the tick and the lane it was issued on.
+    void predictIndicesTracked(int time, float depthCutoff, int timeDelta, int lane);
+    int preIndexedTick = -1, preIndexedLane = 0;
     void combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta);
     void performFillIn(const uint8_t* rgba, const float* depthFiltered, bool frameToFrameRGB, bool lost);
     bool requiresFillIn(float ratio = 0.75f);
@@ -239,6 +243,8 @@ class CoFusion {
         int enqueueThreads = 0;
     };
     explicit CoFusion(const Config& cfg);
+    // a sequence of a lock-step group (CoFusionGroup): the context is the group's, shared with the other sequences
+    CoFusion(const Config& cfg, cf_ctx* sharedContext, int sequenceIndex);
     ~CoFusion();
 
     // CoFusion::processFrame (Core/CoFusion.cpp:171-524)
@@ -269,7 +275,29 @@ class CoFusion {
     cf_ctx* context() { return ctx; }
     Config cfg;
 
+    // ---- the stages of processFrame (see CoFusion.cpp); CoFusionGroup runs them stage by stage over its sequences ----
+    struct TrackBatch {   // the trackers of one set of lock-step launches: the owned models of one frame, or of several sequences' frames
+        struct Item { Model* model; Model* owner; const float* depthPyr[3]; const uint8_t* frameRgba; float maxDepth;
+                      const float* predV; const float* predN; const uint8_t* predImg; };
+        std::vector<Item> items;
+    };
+    void frameBegin(const FrameData& frame, const Mat4f* inPose, float weightMultiplier, bool bootstrap);
+    bool frameTracks() const { return st.willTrack; }
+    void trackCollect(TrackBatch& batch) { trackCollect(batch, st.pyr); }
+    static void trackLaunch(cf_ctx* ctx, TrackBatch& batch, const Config& cfg);
+    void frameMiddle();
+    void frameFuse(bool join, int laneOffset);
+    void frameEnd();
+
   private:
+    struct FrameStage {   // what the stages of one frame hand to each other
+        const FrameData* frame = nullptr; const Mat4f* inPose = nullptr; float weightMultiplier = 1.f; bool bootstrap = false;
+        unsigned b = 0; bool willTrack = false, slicAside = false, fuseNow = false;
+        const float* pyr[3] = {nullptr, nullptr, nullptr};
+    } st;
+    bool ownsCtx = true;
+    int markBase = 0;   // this sequence's four event slots of the context (cf_mark)
+    void trackCollect(TrackBatch& batch, const float* const depthPyr[3]);
     void spawnObjectModel();
     void moveNewModelToList();
     ModelList::iterator inactivateModel(ModelList::iterator it);
@@ -309,9 +337,30 @@ class CoFusion {
     bool enableSmartModelDelete = true;
     std::string exportSegmentationPrefix;
     bool useLanes = std::getenv("CF_NO_LANES") == nullptr;  // per-model auxiliary streams (diagnostic switch)
+    bool preIndex = std::getenv("CF_PREINDEX") != nullptr;  // experiment, off: first index maps enqueued behind the tracking, beside the segmentation (measured slower)
     std::shared_ptr<EnqueuePool> pool;                      // Config::enqueueThreads helpers
     void modelPasses(Model& model, bool fuse, float weightMultiplier, bool lost);
-    void fuseAndPredict(bool fuse, float weightMultiplier, bool lost);
+    void fuseAndPredict(bool fuse, float weightMultiplier, bool lost, bool join = true, int laneOffset = 0);
+};
+
+// Several independent sequences on one GPU in lock-step: one context, one set of tracking launches for the trackers of all of them
+// (CoFusion.cpp, "CoFusionGroup").  Same configuration (image size, intrinsics, options) for every sequence.
+class CoFusionGroup {
+  public:
+    CoFusionGroup(const CoFusion::Config& cfg, int sequences);
+    ~CoFusionGroup();
+    CoFusionGroup(const CoFusionGroup&) = delete;
+    CoFusionGroup& operator=(const CoFusionGroup&) = delete;
+    int size() const { return (int)seqs.size(); }
+    CoFusion& sequence(int s) { return *seqs.at((size_t)s); }
+    // one frame of EVERY sequence: frames[s] goes to sequence s (inPoses: nullable, entries nullable)
+    void processFrames(const FrameData* frames, const Mat4f* const* inPoses = nullptr);
+    cf_ctx* context() { return ctx; }
+
+  private:
+    CoFusion::Config cfg;
+    cf_ctx* ctx = nullptr;
+    std::vector<std::unique_ptr<CoFusion>> seqs;
 };
 
 }  // namespace cofusion

@@ -5,6 +5,7 @@
 #include <exception>
 #include <iterator>
 #include <string>
+#include <vector>
 
 #include <rccl/rccl.h>
 
@@ -14,6 +15,7 @@
 using namespace cofusion;
 
 struct cofusion_handle { CoFusion* cf; };
+struct cofusion_group { CoFusionGroup* g; std::vector<cofusion_handle> handles; };  // handles: borrowed views of the sequences
 static thread_local std::string g_err;
 
 #define GUARD(expr)                                  \
@@ -40,9 +42,8 @@ void cofusion_default_config(cofusion_config* c)
     c->enqueue_threads = d.enqueueThreads;
 }
 
-int cofusion_create(const cofusion_config* c, cofusion_handle** out)
+static CoFusion::Config to_config(const cofusion_config* c)
 {
-    if (!c || !out) { g_err = "null argument"; return -1; }
     CoFusion::Config d;
     d.width = c->width; d.height = c->height; d.fx = c->fx; d.fy = c->fy; d.cx = c->cx; d.cy = c->cy; d.device = c->device;
     d.maxSurfels = c->max_surfels; d.maxModels = c->max_models; d.confGlobalInit = c->conf_global_init;
@@ -56,6 +57,13 @@ int cofusion_create(const cofusion_config* c, cofusion_handle** out)
     d.midFramePredict = c->mid_frame_predict != 0;
     d.shardBackground = c->shard_background != 0;
     d.enqueueThreads = c->enqueue_threads < 0 ? 0 : c->enqueue_threads;
+    return d;
+}
+
+int cofusion_create(const cofusion_config* c, cofusion_handle** out)
+{
+    if (!c || !out) { g_err = "null argument"; return -1; }
+    const CoFusion::Config d = to_config(c);
     GUARD(*out = new cofusion_handle{new CoFusion(d)});
     return 0;
 }
@@ -159,6 +167,45 @@ int cofusion_set_allreduce_device(cofusion_handle* h, cofusion_allreduce_dev_fn 
     h->cf->setAllreduceDevice(fn, user);
     return 0;
 }
+// ---- lock-step group of sequences on one GPU (CoFusionGroup) ----
+int cofusion_group_create(const cofusion_config* c, int sequences, cofusion_group** out)
+{
+    if (!c || !out) { g_err = "null argument"; return -1; }
+    const CoFusion::Config d = to_config(c);
+    try {
+        cofusion_group* g = new cofusion_group{new CoFusionGroup(d, sequences), std::vector<cofusion_handle>()};
+        for (int s = 0; s < sequences; s++) g->handles.push_back(cofusion_handle{&g->g->sequence(s)});
+        *out = g;
+    }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+    catch (...) { g_err = "unknown exception"; return -1; }
+    return 0;
+}
+void cofusion_group_destroy(cofusion_group* g) { if (g) { delete g->g; delete g; } }
+int cofusion_group_size(cofusion_group* g) { return g ? g->g->size() : 0; }
+cofusion_handle* cofusion_group_sequence(cofusion_group* g, int s)
+{
+    if (!g || s < 0 || s >= g->g->size()) { g_err = "sequence index out of range"; return nullptr; }
+    return &g->handles[(size_t)s];
+}
+int cofusion_group_set_stream(cofusion_group* g, void* s) { return g ? cf_set_stream(g->g->context(), s) : -1; }
+int cofusion_group_process_frames(cofusion_group* g, const int64_t* ts, const uint8_t* const* rgb, const float* const* depth, const uint8_t* const* mask)
+{
+    if (!g || !rgb || !depth) { g_err = "null argument"; return -1; }
+    std::vector<FrameData> f((size_t)g->g->size());
+    for (size_t s = 0; s < f.size(); s++) { f[s].timestamp = ts ? ts[s] : 0; f[s].rgb = rgb[s]; f[s].depth = depth[s]; f[s].mask = mask ? mask[s] : nullptr; }
+    GUARD(g->g->processFrames(f.data()));
+    return 0;
+}
+int cofusion_group_process_frames_device(cofusion_group* g, const int64_t* ts, const float* const* depth_dev, const uint8_t* const* rgba_dev)
+{
+    if (!g || !rgba_dev || !depth_dev) { g_err = "null argument"; return -1; }
+    std::vector<FrameData> f((size_t)g->g->size());
+    for (size_t s = 0; s < f.size(); s++) { f[s].timestamp = ts ? ts[s] : 0; f[s].depth_dev = depth_dev[s]; f[s].rgba_dev = rgba_dev[s]; }
+    GUARD(g->g->processFrames(f.data()));
+    return 0;
+}
+
 int cofusion_rccl_unique_id(void* id128)
 {
     // (ncclGetUniqueId directly: creating the id needs no context, and rank 0 calls this before any instance exists)

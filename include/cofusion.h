@@ -70,6 +70,24 @@ int cofusion_set_crf(cofusion_handle *h, float unary_weight_error, float unary_k
                      float weight_smoothness, float sigma_rgb, float sigma_depth, float sigma_pos, float min_rel_size_new,
                      float max_rel_size_new, unsigned iterations);
 
+/* Several independent RGB-D sequences on ONE GPU in lock-step (throughput mode): the sequences share one context, and every set of
+ * tracking launches (map preparation, SO(3) pre-alignment, the Gauss-Newton loop) carries the trackers of all of them, up to 16 per
+ * launch -- the kernels of a 640x480 frame run at their launch floor, more trackers per launch is what fills the GPU.  Each sequence
+ * keeps its own maps, models, segmentation and clock; its results are those of a cofusion_handle of its own, bit for bit.  One
+ * configuration for all sequences (cfg->max_models is per sequence).  cofusion_group_sequence returns a BORROWED handle for the
+ * per-sequence getters (model info, download, mask, export ...): do not pass it to cofusion_destroy / cofusion_process_frame*. */
+typedef struct cofusion_group cofusion_group;
+int cofusion_group_create(const cofusion_config *cfg, int sequences /* 1..16 */, cofusion_group **out);
+void cofusion_group_destroy(cofusion_group *g);
+int cofusion_group_size(cofusion_group *g);
+cofusion_handle *cofusion_group_sequence(cofusion_group *g, int s);
+int cofusion_group_set_stream(cofusion_group *g, void *hip_stream);
+/* one frame of EVERY sequence: entry s of each array belongs to sequence s (timestamps / mask: nullable, mask entries nullable) */
+int cofusion_group_process_frames(cofusion_group *g, const int64_t *timestamps, const uint8_t *const *rgb, const float *const *depth_m,
+                                  const uint8_t *const *mask);
+int cofusion_group_process_frames_device(cofusion_group *g, const int64_t *timestamps, const float *const *depth_dev,
+                                         const uint8_t *const *rgba_dev);
+
 /* Model-parallel mode (cfg.world > 1, one process per GPU, every rank fed the same frames): the object models are placed
  * round-robin on ranks 1.., the background on rank 0; every rank runs the same frame loop and keeps data-less shadows of
  * the models it does not own.  All inter-rank traffic (poses after tracking, per-superpixel ICP / confidence sums for

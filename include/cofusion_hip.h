@@ -107,6 +107,8 @@ int cf_synchronize(cf_ctx *ctx);
 int cf_fork(cf_ctx *ctx, int lane);
 int cf_main(cf_ctx *ctx);
 int cf_join(cf_ctx *ctx);
+/* the same for ONE lane: the stream waits for that lane only (the other lanes keep running beside what follows) */
+int cf_join_lane(cf_ctx *ctx, int lane);
 /* Enqueue from several host threads: the owning thread forks the lanes (cf_fork(lane) for each, then cf_main), helper threads
  * call cf_thread_lane(ctx, lane) and then issue the cf_model_* calls of ONE model each -- those go to the lane, the context's
  * current stream is untouched -- and unbind with lane < 0; the owning thread waits for the helpers and calls cf_join.  Only the
@@ -218,6 +220,10 @@ int cf_odom_init_first_rgb(cf_odom *od, const uint8_t *rgba);
 int cf_odom_init_models_batch(cf_ctx *ctx, cf_odom *const *ods, int n, const float *const *pred_vertex4,
                               const float *const *pred_normal4, const uint8_t *const *pred_rgba, const float *const *poses /* n x [16] */,
                               const uint8_t *frame_rgba);
+/* ... with one frame image per tracker (frame_rgba[k] for ods[k]): the trackers of several sequences prepared by the same launches */
+int cf_odom_init_models_batch_frames(cf_ctx *ctx, cf_odom *const *ods, int n, const float *const *pred_vertex4,
+                                     const float *const *pred_normal4, const uint8_t *const *pred_rgba, const float *const *poses /* n x [16] */,
+                                     const uint8_t *const *frame_rgba /* n */);
 /* initICP(depthPyramid, maskPyramid, depthCutoff) :48-49 (frame -> model); the mask pyramid is dead in the
  * reference (cudafuncs.cu:119) and therefore not part of the ABI */
 int cf_odom_init_icp(cf_odom *od, const float *const depth_pyr[CF_NUM_PYRS], float depth_cutoff);
@@ -281,6 +287,10 @@ int cf_model_initialise(cf_model *m, const uint8_t *rgba, const float *depth_raw
 int cf_model_count(cf_model *m, uint32_t *count);
 /* Model::predictIndices -> ModelProjection::predictIndices (ModelProjection.cpp:105-157) */
 int cf_model_predict_indices(cf_model *m, const float pose[16], int time, float maxDepth, int timeDelta);
+/* the same pass under the pose the tracker `od` has just computed and left in its device state -- without the host having fetched that
+ * pose (cf_odom_fetch_result): the inverse is formed on the device with the statement the host uses, so the index map has the same bits.
+ * Lets a frame loop enqueue every model's first index map right behind the tracking launches instead of behind its host wait. */
+int cf_model_predict_indices_tracked(cf_model *m, cf_odom *od, int time, float maxDepth, int timeDelta);
 /* predictIndices in two halves for a surfel map sharded over GPUs: rasterise the surfels [surfel_begin, surfel_end) into
  * keys_dev (u64 [H*W], filled by the call; smaller key = nearer surfel, ties -> lower id, empty = all ones), MIN-all-reduce
  * the key maps over the ranks as unsigned 64-bit integers, then resolve the reduced map into the model's index textures. */
