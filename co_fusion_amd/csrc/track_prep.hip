@@ -586,9 +586,13 @@ __global__ void __launch_bounds__(256) model_maps_tiled_kernel(const ModelMapsBa
         for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
             for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64)); }
-        if (lane == 0 && lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])
-#pragma unroll
-            for (int k = 0; k < 3; k++) { atomicMax(&a.aabb[k], ~fkey(lo[k])); atomicMax(&a.aabb[3 + k], fkey(hi[k])); }
+        // lanes 0..5 own one key each; a wave that does not extend the box (nearly all of them, after the first few) only READS the
+        // current keys -- six same-address atomics per wave had doubled the duration of this kernel
+        if (lane < 6 && lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
+            const float val = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lane == 2 ? lo[2] : lane == 3 ? hi[0] : lane == 4 ? hi[1] : hi[2];
+            const unsigned key = lane < 3 ? ~fkey(val) : fkey(val);
+            if (key > __hip_atomic_load(&a.aabb[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.aabb[lane], key);
+        }
     }
 }
 

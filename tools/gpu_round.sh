@@ -1,6 +1,7 @@
 #!/bin/bash
-# One GPU-box pass: parity tests, the three bench workloads, rocprofv3 kernel stats of the default bench
-# command, and the two PMC passes (FETCH_SIZE / WRITE_SIZE each in its own run).  Outputs under gpurun_out/.
+# One verification pass on a GPU box: the whole GPU suite, the default bench line (what the driver runs), bench lines of the other
+# configurations, rocprofv3 kernel stats of the default command.  Outputs under gpurun_out/<tag>/.
+#   SKIP_TESTS=1 / SKIP_LINES=1 / SKIP_PROF=1 skip a part; LONG=1 adds the COFUSION_LONG_TESTS replays
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-round}
@@ -8,25 +9,29 @@ mkdir -p $O
 cd $R
 export TMPDIR=/tmp
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
-  tail -3 $O/pytest.log
+  [ "${LONG:-0}" = "1" ] && export COFUSION_LONG_TESTS=1
+  timeout ${TEST_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q --durations=12 > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
+  tail -4 $O/pytest.log
 fi
-timeout 600 python bench.py > $O/bench_static.json 2> $O/bench_static.err; tail -1 $O/bench_static.json
-if [ "${SKIP_MULTI:-0}" != "1" ]; then
-  timeout 600 python bench.py --workload objects4 --warmup 150 --steps 100 --cpu-frames 4 > $O/bench_objects4.json 2> $O/bench_objects4.err; tail -1 $O/bench_objects4.json
-  timeout 600 python bench.py --workload objects4-gt --warmup 60 --steps 100 --no-cpu-baseline > $O/bench_objects4gt.json 2> $O/bench_objects4gt.err; tail -1 $O/bench_objects4gt.json
+timeout 600 python bench.py > $O/bench_default_line.json 2> $O/bench_default.err; tail -c 600 $O/bench_default_line.json; echo
+if [ "${SKIP_LINES:-0}" != "1" ]; then
+  : > $O/bench_lines_all_configs.jsonl
+  for A in "--workload objects4" "--workload static" "--workload objects8" "--workload big" "--workload big-static" "--workload static --streams 4 --lockstep" "--workload objects4 --streams 3 --lockstep"; do
+    timeout 400 python bench.py $A --no-cpu-baseline --no-extras >> $O/bench_lines_all_configs.jsonl 2>> $O/bench_lines.err
+  done
+  python - <<PY
+import json
+for l in open("$O/bench_lines_all_configs.jsonl"):
+    try: d = json.loads(l)
+    except Exception: continue
+    r = d["roofline"]; c = d["config"]
+    print(c["workload"][:60].ljust(60), "fps", d["value"], "ms", d["ms_per_step"], "models", c["active_models"], "icp us", r["avg_us"], "frac", r["frac"])
+PY
 fi
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python $R/bench.py --no-cpu-baseline --no-secondary > $O/prof.log 2>&1
-python $R/tools/prof_summary.py $O/prof > $O/kernel_stats.txt 2>&1; head -30 $O/kernel_stats.txt
-if [ "${SKIP_PMC:-0}" != "1" ]; then
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $O/pmc_fetch.log 2>&1
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $O/pmc_write.log 2>&1
-  python $R/tools/pmc_summary.py $O/pmc_fetch icp_reduce > $O/pmc_icp.txt 2>&1
-  python $R/tools/pmc_summary.py $O/pmc_write icp_reduce >> $O/pmc_icp.txt 2>&1
-  cat $O/pmc_icp.txt
-  python $R/tools/pmc_summary.py $O/pmc_fetch > $O/pmc_all_fetch.txt 2>&1
-  python $R/tools/pmc_summary.py $O/pmc_write > $O/pmc_all_write.txt 2>&1
-  rm -rf $O/pmc_fetch/*counter_collection.csv $O/pmc_write/*counter_collection.csv $O/pmc_fetch/*kernel_trace.csv $O/pmc_write/*kernel_trace.csv
+if [ "${SKIP_PROF:-0}" != "1" ]; then
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python $R/bench.py --no-cpu-baseline --no-extras > $O/prof.log 2>&1
+  python $R/tools/prof_summary.py $O/prof > $O/kernel_stats_objects4.txt 2>&1; head -24 $O/kernel_stats_objects4.txt
+  f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/rocprofv3_kernel_stats.csv
+  rm -rf $O/prof
 fi
-rm -f $O/prof/*kernel_trace.csv
