@@ -1082,15 +1082,13 @@ void CoFusion::frameBegin(const FrameData& frame, const Mat4f* inPose, float wei
     }
 }
 
-void CoFusion::frameMiddle()
+void CoFusion::frameSegment(int lane)
 {
     const FrameData& frame = *st.frame;
     const Mat4f* inPose = st.inPose;
     const bool bootstrap = st.bootstrap;
-    const size_t N = (size_t)cfg.width * cfg.height;
     st.fuseNow = false;
     if (tick == 1) return;
-    bool trackingOk = true;
     if (bootstrap || !inPose) {
         if (st.slicAside) check(ctx, cf_join_lane(ctx, 7), "cf_join_lane");
         // Every tracked model's first index map (CoFusion.cpp:316-318) depends on its new pose only, and the pose is in device
@@ -1111,6 +1109,8 @@ void CoFusion::frameMiddle()
         // cfg.maxModels trackers (the reference allows 256 ids, CoFusion.cpp:631-634; its GUI never gets there)
         bool allowNew = false;
         const bool segOnDevice = cfg.enableMultipleModels && !frame.mask && !segOnHost;
+        // (a sequence of a lock-step group puts its segmentation chain on a lane: the chains of the other sequences run beside it)
+        if (lane >= 0 && segOnDevice) check(ctx, cf_fork(ctx, lane), "cf_fork");
         if (cfg.enableMultipleModels) {
             if (spawnOffset < cfg.modelSpawnOffset) spawnOffset++;
             const size_t modelCap = (size_t)std::min(cfg.maxModels, 16);
@@ -1123,6 +1123,22 @@ void CoFusion::frameMiddle()
         // the motion segmentation reads device data only (ICP error surfaces, predictions): enqueued right behind the tracking
         // launches, so that poses AND segmentation decisions are collected by ONE host wait
         if (segOnDevice) labelGenerator->enqueueCRF(models, curDepth, curRgba, getNextModelID(), allowNew, mask_dev);
+        if (lane >= 0 && segOnDevice) check(ctx, cf_main(ctx), "cf_main");
+        st.allowNew = allowNew; st.segOnDevice = segOnDevice;
+    }
+}
+
+void CoFusion::frameCollect()
+{
+    const FrameData& frame = *st.frame;
+    const Mat4f* inPose = st.inPose;
+    const bool bootstrap = st.bootstrap;
+    const size_t N = (size_t)cfg.width * cfg.height;
+    st.fuseNow = false;
+    if (tick == 1) return;
+    bool trackingOk = true;
+    if (bootstrap || !inPose) {
+        const bool allowNew = st.allowNew, segOnDevice = st.segOnDevice;
         { PhaseTimer t(PhaseTimes::Track); fetchTracking(true); }
         if (bootstrap) globalModel->overridePose(globalModel->getPose() * (*inPose));
 
@@ -1236,7 +1252,8 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
 {
     frameBegin(frame, inPose, weightMultiplier, bootstrap);
     if (st.willTrack) { PhaseTimer t(PhaseTimes::Track); trackModels(st.pyr); }
-    frameMiddle();
+    frameSegment(-1);
+    frameCollect();
     frameFuse(true, 0);
     frameEnd();
     return false;
@@ -1279,7 +1296,11 @@ void CoFusionGroup::processFrames(const FrameData* frames, const Mat4f* const* i
         for (int s = 0; s < S; s++) if (seqs[s]->frameTracks()) seqs[s]->trackCollect(batch);
         CoFusion::trackLaunch(ctx, batch, cfg);
     }
-    for (int s = 0; s < S; s++) seqs[s]->frameMiddle();
+    // the segmentation chains of the multi-object sequences side by side on the lanes (each is ~35 launch-floor kernels: alone it
+    // leaves the GPU idle), one join, then ONE host wait for the poses and the decisions of all sequences
+    for (int s = 0; s < S; s++) seqs[s]->frameSegment(s % 6);
+    check(ctx, cf_join(ctx), "cf_join");
+    for (int s = 0; s < S; s++) seqs[s]->frameCollect();
     int lane = 0;
     for (int s = 0; s < S; s++) {  // the chains of all sequences side by side on the lanes, one join
         seqs[s]->frameFuse(false, lane);

@@ -285,14 +285,15 @@ class CoFusion {
     bool frameTracks() const { return st.willTrack; }
     void trackCollect(TrackBatch& batch) { trackCollect(batch, st.pyr); }
     static void trackLaunch(cf_ctx* ctx, TrackBatch& batch, const Config& cfg);
-    void frameMiddle();
+    void frameSegment(int lane);   // segmentation enqueued (lane >= 0: on that lane of the context, beside other sequences' chains)
+    void frameCollect();           // the frame's host wait (poses + segmentation decisions), model bookkeeping
     void frameFuse(bool join, int laneOffset);
     void frameEnd();
 
   private:
     struct FrameStage {   // what the stages of one frame hand to each other
         const FrameData* frame = nullptr; const Mat4f* inPose = nullptr; float weightMultiplier = 1.f; bool bootstrap = false;
-        unsigned b = 0; bool willTrack = false, slicAside = false, fuseNow = false;
+        unsigned b = 0; bool willTrack = false, slicAside = false, fuseNow = false, allowNew = false, segOnDevice = false;
         const float* pyr[3] = {nullptr, nullptr, nullptr};
     } st;
     bool ownsCtx = true;
