@@ -401,13 +401,30 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegUnaryArgs a)
     __shared__ int s_nempty[2];
     int* empties = reinterpret_cast<int*>(a.raw + (size_t)A * K);  // scratch behind the raw sums: [2][K] (depth-empty, pixel-empty)
     // A: raw sums as f32, phase 1 of the normalisation
-    for (int idx = tid; idx < A * K; idx += T) {
-        const int arr = idx / K, k = idx - arr * K;
-        const unsigned long long* sums = arr == 0 ? a.depth_sum : (arr <= n ? a.icp_sum + (size_t)(arr - 1) * K : a.conf_sum + (size_t)(arr - 1 - n) * K);
-        const float raw = (float)((double)(long long)sums[k] * 2.3283064365386963e-10 /* 2^-32 */);
-        a.raw[idx] = raw;
-        const int cnt = (int)(arr == 0 ? a.depth_count[k] : a.spix_count[k]);
-        a.low[idx] = cnt != 0 ? raw / (float)cnt : raw;
+    // (eight entries per lane in flight: this workgroup is alone on the GPU, a loop of dependent round trips to HBM -- 13 of them at five
+    // models -- was a third of the kernel)
+    for (int base = 0; base < A * K; base += 8 * T) {
+        unsigned long long sv[8]; int cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * T + tid;
+            sv[u] = 0; cv[u] = 0;
+            if (idx < A * K) {
+                const int arr = idx / K, k = idx - arr * K;
+                const unsigned long long* sums = arr == 0 ? a.depth_sum : (arr <= n ? a.icp_sum + (size_t)(arr - 1) * K : a.conf_sum + (size_t)(arr - 1 - n) * K);
+                sv[u] = sums[k];
+                cv[u] = (int)(arr == 0 ? a.depth_count[k] : a.spix_count[k]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * T + tid;
+            if (idx < A * K) {
+                const float raw = (float)((double)(long long)sv[u] * 2.3283064365386963e-10 /* 2^-32 */);
+                a.raw[idx] = raw;
+                a.low[idx] = cv[u] != 0 ? raw / (float)cv[u] : raw;
+            }
+        }
     }
     // ordered lists of the empty superpixels (which == 0: no depth sample, which == 1: no pixel at all)
     const int per = (K + T - 1) / T;
