@@ -211,7 +211,13 @@ def main(argv=None):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     backend = None
+    out_stream = sys.stdout
     if world > 1:
+        # stdout carries ONE JSON line: RCCL prints a version banner when a communicator is created (torch's and the library's), so for
+        # the rest of the run file descriptor 1 is routed to stderr and the line goes to a duplicate of the original descriptor
+        sys.stdout.flush()
+        out_stream = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("CF_BENCH_BACKEND", "nccl")  # "gloo": dry run of the multi-rank path on a 1-GPU box
@@ -224,7 +230,7 @@ def main(argv=None):
         else:
             dist.init_process_group(backend)
     if args.dry_run:
-        return dry_run(args, rank, world, dist)
+        return dry_run(args, rank, world, dist, out_stream)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if local_rank >= torch.cuda.device_count():
@@ -395,7 +401,7 @@ def main(argv=None):
                 out["cpu_baseline_all_cores"] = call
             except Exception as e:  # noqa: BLE001 -- the headline line must not depend on this leg
                 out["cpu_baseline"] = dict(error=str(e))
-        print(json.dumps(out))
+        print(json.dumps(out), file=out_stream, flush=True)
     for st in streams:
         st["cf"].close()
     if dist is not None:
@@ -466,7 +472,7 @@ def lockstep_run(args, torch, facade, local_rank, wl, S):
     return out
 
 
-def dry_run(args, rank, world, dist):
+def dry_run(args, rank, world, dist, out_stream=None):
     """No GPU: stub steps through the same timing contract and process-group plumbing (CPU test of `--gpus N`)."""
     import torch
 
@@ -488,7 +494,7 @@ def dry_run(args, rank, world, dist):
                    warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 4), higher_is_better=True,
                    scaling="strong" if args.parallel == "models" else "weak", vs_baseline=None, dtype="f32", data="none",
                    config=dict(workload=f"dry run of {args.workload}", parallel=args.parallel if world > 1 else "single"))
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=out_stream or sys.stdout, flush=True)
     if dist is not None:
         dist.destroy_process_group()
     return out

@@ -547,7 +547,8 @@ int cf_odom_create(cf_ctx* ctx, cf_odom** out)
         if (int r = dmalloc(ctx, &od->cloud[i], n * 3)) return r;
         if (int r = dmalloc(ctx, &od->corres[i], n)) return r;
         if (int r = dmalloc(ctx, &od->cand[i], n)) return r;
-        od->ext_vmap_curr[i] = nullptr; od->ext_nmap_curr[i] = nullptr;
+        if (int r = dmalloc(ctx, &od->zrange[i], (n + 63) / 64)) return r;
+        od->ext_vmap_curr[i] = nullptr; od->ext_nmap_curr[i] = nullptr; od->ext_zrange[i] = nullptr;
     }
     if (int r = dmalloc(ctx, &od->icp_acc, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &od->rgb_acc, (size_t)kGroups * 32)) return r;
@@ -585,7 +586,7 @@ void cf_odom_destroy(cf_odom* od)
         (void)hipFree(od->nmap_curr[i]); (void)hipFree(od->lastDepth[i]); (void)hipFree(od->nextDepth[i]);
         (void)hipFree(od->lastImage[i]); (void)hipFree(od->nextImage[i]); (void)hipFree(od->lastNextImage[i]);
         (void)hipFree(od->dIdx[i]); (void)hipFree(od->dIdy[i]); (void)hipFree(od->cloud[i]); (void)hipFree(od->corres[i]);
-        (void)hipFree(od->cand[i]);
+        (void)hipFree(od->cand[i]); (void)hipFree(od->zrange[i]);
     }
     (void)hipFree(od->icp_acc); (void)hipFree(od->rgb_acc); (void)hipFree(od->occ); (void)hipFree(od->aabb);
     if (od->slot >= 0) od->ctx->slot_used[od->slot] = false;
@@ -725,9 +726,9 @@ int cf_odom_init_icp(cf_odom* od, const float* const depth_pyr[CF_NUM_PYRS], flo
     for (int i = 0; i < CF_NUM_PYRS; ++i) {
         const int div = 1 << i;
         const cf_cam il = {intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
-        a.depth[i] = depth_pyr[i]; a.vmap[i] = od->vmap_curr[i]; a.nmap[i] = od->nmap_curr[i];
+        a.depth[i] = depth_pyr[i]; a.vmap[i] = od->vmap_curr[i]; a.nmap[i] = od->nmap_curr[i]; a.zrange[i] = od->zrange[i];
         a.fx_inv[i] = 1.f / il.fx; a.fy_inv[i] = 1.f / il.fy; a.cx[i] = il.cx; a.cy[i] = il.cy;
-        od->ext_vmap_curr[i] = nullptr; od->ext_nmap_curr[i] = nullptr;
+        od->ext_vmap_curr[i] = nullptr; od->ext_nmap_curr[i] = nullptr; od->ext_zrange[i] = nullptr;
     }
     launch_frame_maps(s, a, W, H);  // createVMap + createNMap of the three levels in one launch
     LAUNCHCHK(ctx);
@@ -761,7 +762,19 @@ int cf_set_collective(cf_ctx* ctx, int (*fn)(void*, int, void*, uint64_t, void*)
 int cf_odom_bind_frame_maps(cf_odom* od, const float* const vmaps[CF_NUM_PYRS], const float* const nmaps[CF_NUM_PYRS])
 {
     if (!od) return CF_EINVAL;
-    for (int i = 0; i < CF_NUM_PYRS; i++) { od->ext_vmap_curr[i] = vmaps[i]; od->ext_nmap_curr[i] = nmaps[i]; }
+    for (int i = 0; i < CF_NUM_PYRS; i++) { od->ext_vmap_curr[i] = vmaps ? vmaps[i] : nullptr; od->ext_nmap_curr[i] = nmaps ? nmaps[i] : nullptr; od->ext_zrange[i] = nullptr; }
+    return CF_OK;
+}
+// the frame maps `owner` computed with cf_odom_init_icp (all models of a frame track the same frame), incl. their per-run depth
+// intervals -- what lets the culled ICP reduction of `od` skip runs at other depths
+int cf_odom_share_frame_maps(cf_odom* od, cf_odom* owner)
+{
+    if (!od || !owner || od->ctx != owner->ctx) return CF_EINVAL;
+    for (int i = 0; i < CF_NUM_PYRS; i++) {
+        od->ext_vmap_curr[i] = owner->ext_vmap_curr[i] ? owner->ext_vmap_curr[i] : owner->vmap_curr[i];
+        od->ext_nmap_curr[i] = owner->ext_nmap_curr[i] ? owner->ext_nmap_curr[i] : owner->nmap_curr[i];
+        od->ext_zrange[i] = owner->ext_vmap_curr[i] ? owner->ext_zrange[i] : owner->zrange[i];
+    }
     return CF_OK;
 }
 
@@ -845,6 +858,8 @@ static void fill_rgb_args(cf_ctx* ctx, cf_odom* const* ods, int n, RgbArgs out[3
 
 static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3])
 {
+    static const bool no_zcull = getenv("CF_NO_ZCULL") != nullptr;  // diagnostics: A/B of the depth-interval culling on one box
+    static const bool no_occ = getenv("CF_NO_OCC") != nullptr;      // ... and of the occupancy look-up
     const cf_cam intr = {ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy};
     for (int l = 0; l < CF_NUM_PYRS; l++) {
         IcpArgs& a = out[l];
@@ -860,9 +875,10 @@ static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3
             a.m[m] = IcpModelArgs{od->ext_vmap_curr[l] ? od->ext_vmap_curr[l] : od->vmap_curr[l],
                                   od->ext_nmap_curr[l] ? od->ext_nmap_curr[l] : od->nmap_curr[l],
                                   od->vmap_g_prev[l], od->nmap_g_prev[l], od->d_state, od->icp_acc,
-                                  od->h_state->err_surface, od->rgb_acc, (od->use_occ && od->occ_valid) ? od->occ : nullptr,
+                                  od->h_state->err_surface, od->rgb_acc, (od->use_occ && od->occ_valid && !no_occ) ? od->occ : nullptr,
                                   od->band_end > 0 ? (od->band_begin >> l) : 0, od->band_end > 0 ? (od->band_end >> l) : 0,
-                                  od->h_state->cull};
+                                  od->h_state->cull,
+                                  no_zcull ? nullptr : (od->ext_vmap_curr[l] ? od->ext_zrange[l] : od->zrange[l])};
         }
     }
 }
@@ -950,6 +966,27 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
         return CF_ESTATE;
     }
     LAUNCHCHK(ctx);
+    // diagnostics: CF_ICP_REPLAY=<call> re-launches the level-0 {ICP || residual} launch of that tracking call (its converged state) back
+    // to back under a list of ablation masks and prints the durations -- the decomposition of the launch quoted in DESIGN.md 4.1
+    static const int replay_call = getenv("CF_ICP_REPLAY") ? atoi(getenv("CF_ICP_REPLAY")) : -1;
+    static int calls_seen = 0;
+    if (replay_call >= 0 && calls_seen++ == replay_call) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const int masks[] = {0, 8, 16, 32, 8 | 32, 256, 256 | 32, 256 | 16 | 8, 8 | 256 | 32, 256 | 32 | 512, 256 | 32 | 1024, 1024};
+        const char* names[] = {"full", "culled models: no ICP", "culled models: no residual", "no residual at all", "unculled ICP only",
+                               "unculled models: no ICP", "culled ICP only", "unculled residual + culled nothing", "nothing (empty workgroups)",
+                               "culled ICP: the cull test only", "culled ICP only, XCD bands", "full, XCD bands for culled models"};
+        for (int k = 0; k < 12; k++) {
+            const float us = replay_icp_level0(ctx->stream, ctx->icp_launch, icp_args[0], rgb_args[0], n, ctx->gn_mode, masks[k], 200,
+                                               ctx->prof.events[ctx->prof.capacity - 2], ctx->prof.events[ctx->prof.capacity - 1]);
+            fprintf(stderr, "[icp replay] %d trackers, mask %3d  %-40s %7.2f us\n", n, masks[k], names[k], us);
+        }
+        for (int m = 0; m < n; m++) {
+            HIPCHK(ctx, hipMemsetAsync(ods[m]->icp_acc, 0, sizeof(unsigned long long) * kGroups * 32, ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(ods[m]->rgb_acc, 0, sizeof(unsigned long long) * kGroups * 32, ctx->stream));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     // no read-back copy: the last solve of the schedule wrote every tracker's result into its pinned host state (h_states)
     ctx->state_readback_pending = true;
     return CF_OK;

@@ -77,6 +77,8 @@ struct cf_odom {
     float* nmap_curr[3]{};
     const float* ext_vmap_curr[3]{};  // frame-shared current maps (all models track the same frame)
     const float* ext_nmap_curr[3]{};
+    float2* zrange[3]{};              // depth interval of every 64-pixel run of vmap_curr (written with the frame maps, cf_odom_init_icp)
+    const float2* ext_zrange[3]{};    // ... of the shared frame maps (cf_odom_share_frame_maps), null when bound without them
     float* lastDepth[3]{};
     float* nextDepth[3]{};
     // cf_odom_init_models_batch: initRGB takes its depth from the same snapshot of the predicted vertex map as initRGBModel

@@ -53,6 +53,8 @@ struct OdomDev {
     int level_done;
     float residual[2];
     float box_lo[3], box_hi[3];  // bounding box of the model's predicted vertices, global frame (box_lo[0] > box_hi[0]: no valid vertex)
+    float cull_z[2];             // depth interval (current camera) of that box dilated by distThres: a 64-pixel run of the current frame
+                                 // whose valid depths all lie outside cannot find a correspondence (-inf, +inf: no depth culling)
     // (the screen box itself -- the level-0 pixel rectangle outside of which no pixel of the current frame can find a correspondence
     // under Rcurr / tcurr -- is stats.cull_box)
     // outputs
@@ -80,6 +82,7 @@ struct FrameMapsArgs {
     const float* depth[3]; float* vmap[3]; float* nmap[3];
     float fx_inv[3], fy_inv[3], cx[3], cy[3];
     float cutoff;
+    float2* zrange[3];           // nullable: (min, max) valid depth of every run of 64 consecutive pixels (flat index / 64) of a level
 };
 struct RgbPrepArgs {
     Level3 L;
@@ -126,7 +129,8 @@ struct IcpModelArgs {
     const unsigned char* occ;           // nullable: occupancy map of the model maps (model_maps_kernel), 1 byte per 4x4 level-0 block
     int row_begin, row_end;             // row band of THIS model's reduction (row_end == 0: all rows): its share when the model's
                                         // reduction is split over GPUs
-    int cull;                           // workgroups / waves outside st->ibox leave before they load anything
+    int cull;                           // workgroups / waves outside st->stats.cull_box leave before they load anything
+    const float2* zr;                   // nullable: depth interval of every 64-pixel run of the current frame's level (FrameMapsArgs::zrange)
 };
 // solve-kernel arguments (by value)
 struct GnArgs {
@@ -203,6 +207,7 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* d
                      const GnHook* hook, const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3,
                      bool pyramid, bool fast_odom, bool rgb, bool icp, int mode, ProfSink* prof,
                      OdomDev* const* h_states = nullptr /* [n] pinned host copies the last solve publishes to */);
+float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, int ablate, int reps, hipEvent_t e0, hipEvent_t e1);
 float sqrt_gate_lt(float T);  // smallest x with sqrtf(x) >= T
 float sqrt_gate_le(float T);  // largest x with sqrtf(x) <= T
 

@@ -339,11 +339,23 @@ __global__ void __launch_bounds__(kBlock) frame_maps_kernel(const FrameMapsArgs 
     const int lv = level_of(a.L, blockIdx.x, lb);
     const int cols = a.L.cols[lv], rows = a.L.rows[lv], N = cols * rows;
     const int i = lb * kBlock + threadIdx.x;
-    if (i >= N) return;
     const float* __restrict__ depth = a.depth[lv];
+    const float cutoff = a.cutoff;
+    if (a.zrange[lv]) {
+        // depth interval of this wave's 64 consecutive pixels (valid vertices only): the ICP reduction skips a run whose interval
+        // misses the depth interval a culled model can match in (screen_box)
+        const float inf = __int_as_float(0x7f800000);
+        const float zz = i < N ? depth[i] : 0.f;
+        const bool ok = zz != 0 && zz < cutoff;
+        float lo = ok ? zz : inf, hi = ok ? zz : -inf;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+        if ((threadIdx.x & 63) == 0 && i < N) a.zrange[lv][i >> 6] = make_float2(lo, hi);
+    }
+    if (i >= N) return;
     float* __restrict__ vmap = a.vmap[lv];
     float* __restrict__ nmap = a.nmap[lv];
-    const float fx_inv = a.fx_inv[lv], fy_inv = a.fy_inv[lv], cx = a.cx[lv], cy = a.cy[lv], cutoff = a.cutoff;
+    const float fx_inv = a.fx_inv[lv], fy_inv = a.fy_inv[lv], cx = a.cx[lv], cy = a.cy[lv];
     const int v = i / cols, u = i - v * cols;
     const bool edge = (u == cols - 1 || v == rows - 1);
     const float z = depth[i];

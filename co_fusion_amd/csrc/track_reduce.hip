@@ -114,8 +114,10 @@ __device__ __forceinline__ IcpProj icp_project(const m33& Rcurr, const f3& tcurr
 // arithmetic is ~1e-6 relative), the projection by 3 pixels, and any corner that is not clearly in front of the camera (or not
 // finite) gives the whole image.  Called by a whole wave; the result is valid in every lane.
 __device__ __forceinline__ void screen_box(const float* lo, const float* hi, const float* Rcurr, const float* tcurr, cf_cam intr,
-                                           float distThres, int W, int H, int lane, int (&out)[4])
+                                           float distThres, int W, int H, int lane, int (&out)[4], float (&zout)[2])
 {
+    const float finf = __int_as_float(0x7f800000);
+    zout[0] = -finf; zout[1] = finf;
     if (!(lo[0] <= hi[0])) { out[0] = 1; out[1] = 1; out[2] = 0; out[3] = 0; return; }  // no predicted vertex: nothing can match
     const float m = distThres * 1.01f + 1e-3f;
     const float dx = ((lane & 1) ? hi[0] + m : lo[0] - m) - tcurr[0];
@@ -127,13 +129,16 @@ __device__ __forceinline__ void screen_box(const float* lo, const float* hi, con
     const float zc = Rcurr[2] * dx + Rcurr[5] * dy + Rcurr[8] * dz;
     const float u = intr.fx * xc / zc + intr.cx, v = intr.fy * yc / zc + intr.cy;
     const bool bad = !(zc > 0.05f) || !is_finite(u) || !is_finite(v);
-    float u0 = u, u1 = u, v0 = v, v1 = v;
+    float u0 = u, u1 = u, v0 = v, v1 = v, z0 = zc, z1 = zc;
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) {
         u0 = fminf(u0, __shfl_xor(u0, o, 64)); u1 = fmaxf(u1, __shfl_xor(u1, o, 64));
         v0 = fminf(v0, __shfl_xor(v0, o, 64)); v1 = fmaxf(v1, __shfl_xor(v1, o, 64));
+        z0 = fminf(z0, __shfl_xor(z0, o, 64)); z1 = fmaxf(z1, __shfl_xor(z1, o, 64));
     }
     if (__any(bad)) { out[0] = 0; out[1] = 0; out[2] = W - 1; out[3] = H - 1; return; }
+    // the depth (z in the current camera) of a matching vertex lies between the extreme corners: a linear map of a box
+    zout[0] = z0 - (1e-3f + 1e-3f * fabsf(z0)); zout[1] = z1 + (1e-3f + 1e-3f * fabsf(z1));
     const float fw = (float)(W + 16), fh = (float)(H + 16);
     out[0] = (int)floorf(fminf(fmaxf(u0, -16.f), fw)) - 3; out[1] = (int)floorf(fminf(fmaxf(v0, -16.f), fh)) - 3;
     out[2] = (int)ceilf(fminf(fmaxf(u1, -16.f), fw)) + 3; out[3] = (int)ceilf(fminf(fmaxf(v1, -16.f), fh)) + 3;
@@ -185,12 +190,13 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     // the object models, so that the launch would end on short work -- 22.2 against 21.4 us in grid order, profiles/r03e.)
     const int model = blockIdx.y, bx = blockIdx.x;
     if (bx >= n_icp_blocks) {
-        if (((args.flags >> 8) & 32) || (((args.flags >> 8) & 16) && model > 0)) return;  // timing ablations (CF_ICP_ABLATE)
+        if (((args.flags >> 8) & 32) || (((args.flags >> 8) & 16) && args.m[model].cull)) return;  // timing ablations (CF_ICP_REPLAY)
         if (ra.compact) rgb_residual_body<true>(ra, model, bx - n_icp_blocks);
         else rgb_residual_body<false>(ra, model, bx - n_icp_blocks);
         return;
     }
     const IcpModelArgs& ma = args.m[model];
+    if (((args.flags >> 8) & 256) && !ma.cull) return;  // timing ablation (CF_ICP_REPLAY): unculled models do nothing
     const OdomDev* __restrict__ st = ma.st;
     const int cols = args.cols, rows = args.rows, N = cols * rows;
     const int T = blockDim.x;
@@ -209,7 +215,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     // A culled model keeps the workgroups of a few image rows only: giving every XCD a horizontal band would leave that work on
     // the XCDs whose bands the rectangle crosses.  Its workgroups are dealt round-robin instead (neighbouring pixel runs on
     // different XCDs), so what survives the culling is spread over the whole chip.
-    const int lb = ma.cull ? bx : xcd_logical_block(bx, nlog);
+    const int lb = (ma.cull && !((args.flags >> 8) & 1024)) ? bx : xcd_logical_block(bx, nlog);  // (1024: timing ablation, bands for everybody)
     if (lb >= nlog) return;
 
     const float* __restrict__ vc = ma.vc;
@@ -221,6 +227,8 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
 
     const int i0 = pix0 + (lb * T + threadIdx.x) * PPT;
     bool in_range = i0 < pix1;  // cols is a multiple of PPT, so the whole vector is in range
+    // (Measured and dropped, round 3: issuing the plane loads BEFORE the box test, so that in-box waves would not pay the box's scalar
+    // round trip in front of them: 22.3 against 21.5 us.)
     // Screen-box culling (screen_box above): pixels outside the model's rectangle add exact zeros.  A workgroup whose pixel run
     // misses the rectangle leaves after this one scalar load; inside a workgroup that straddles it, the waves outside load nothing
     // and go straight to the commit.  Not on the error-surface iteration, which writes every pixel.
@@ -234,7 +242,20 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
         if (r0 == r1 && (p1 - r0 * cols < bx0 || p0 - r0 * cols > bx1)) return;
         const int w0 = p0 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * 64 * PPT, w1 = min(w0 + 64 * PPT, pix1) - 1;
         const int q0 = w0 / cols, q1 = w1 / cols;
+        if ((args.flags >> 8) & 512) return;  // timing ablation (CF_ICP_REPLAY): the cull test alone
         if (w0 > w1 || q1 < by0 || q0 > by1 || (q0 == q1 && (w1 - q0 * cols < bx0 || w0 - q0 * cols > bx1))) in_range = false;
+        // ... and by depth: the run of 64 pixels this wave owns (per pixel of a lane) carries the interval of its valid depths
+        // (frame_maps_kernel); if it misses the interval the model's dilated box spans in this camera, no pixel of the run can match
+        if (in_range && ma.zr && w0 <= w1) {
+            const float zlo = st->cull_z[0], zhi = st->cull_z[1];
+            bool any = false;
+#pragma unroll
+            for (int p = 0; p < PPT; p++) {
+                const int c = (w0 >> 6) + p;   // runs are aligned: pix0 == 0 for a culled model, w0 a multiple of 64 * PPT
+                if (c * 64 <= w1) { const float2 r = ma.zr[c]; any = any || (r.x <= zhi && r.y >= zlo); }
+            }
+            if (!any) in_range = false;
+        }
     }
     float vx[PPT], vy[PPT], vz[PPT], nx[PPT], ny[PPT], nz[PPT];
 #pragma unroll
@@ -819,10 +840,12 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
         for (int k = 0; k < 3; k++) { lo[k] = __shfl(val, k, 64); hi[k] = __shfl(val, 3 + k, 64); }
         if (__shfl((int)key, 3, 64) == 0) { lo[0] = 1.f; hi[0] = 0.f; }  // never written: empty
         int ib[4] = {0, 0, od->width - 1, od->height - 1};
-        if (od->cull) screen_box(lo, hi, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, lane, ib);
+        float zb[2] = {-__int_as_float(0x7f800000), __int_as_float(0x7f800000)};
+        if (od->cull) screen_box(lo, hi, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, lane, ib, zb);
         if (lane == 0) {
             for (int k = 0; k < 3; k++) { od->box_lo[k] = lo[k]; od->box_hi[k] = hi[k]; }
             for (int k = 0; k < 4; k++) od->stats.cull_box[k] = ib[k];
+            od->cull_z[0] = zb[0]; od->cull_z[1] = zb[1];
         }
     }
     if (lead && threadIdx.x == 0) {
@@ -999,9 +1022,12 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
     if (tid == 0 && last_of_level) { od->level_done = 0; od->lastRGBError = 3.402823466e+38F; }
     __syncthreads();
     if (next_level >= 0 && od->cull && tid >= 128 && tid < 192) {  // an idle wave: the screen box under the new pose
-        int ib[4];
-        screen_box(od->box_lo, od->box_hi, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, tid - 128, ib);
-        if (tid == 128) { od->stats.cull_box[0] = ib[0]; od->stats.cull_box[1] = ib[1]; od->stats.cull_box[2] = ib[2]; od->stats.cull_box[3] = ib[3]; }
+        int ib[4]; float zb[2];
+        screen_box(od->box_lo, od->box_hi, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, tid - 128, ib, zb);
+        if (tid == 128) {
+            od->stats.cull_box[0] = ib[0]; od->stats.cull_box[1] = ib[1]; od->stats.cull_box[2] = ib[2]; od->stats.cull_box[3] = ib[3];
+            od->cull_z[0] = zb[0]; od->cull_z[1] = zb[1];
+        }
     }
     if (next_level >= 0) {  // prepare_iteration(od, next_level), spread over lanes
         if (tid == 0) inv44_affine(od->resultRt, s_Rt);
@@ -1212,6 +1238,21 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
         }
     }
     return !hook_failed;
+}
+
+// diagnostics (CF_ICP_REPLAY): the level-0 {ICP || residual} launch of a batch, `reps` times back to back with the given ablation mask;
+// returns the average duration in us.  The sums it leaves in the accumulators are garbage: the caller zeroes them.
+float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, int ablate, int reps, hipEvent_t e0, hipEvent_t e1)
+{
+    IcpArgs a = a0; a.flags = ablate << 8;
+    RgbArgs ra = r0; ra.compact = slots ? 1 : 0; ra.slot_px = cfg.threads * 4;
+    for (int i = 0; i < 3; i++) launch_icp_rgbres(s, cfg, a, ra, true, true, n, 0, nullptr, nullptr);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < reps; i++) launch_icp_rgbres(s, cfg, a, ra, true, true, n, 0, nullptr, nullptr);
+    (void)hipEventRecord(e1, s);
+    (void)hipStreamSynchronize(s);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1000.f / reps;
 }
 
 // ---- stand-alone steps (C-ABI parity with computeRgbResidual / rgbStep) -------------------

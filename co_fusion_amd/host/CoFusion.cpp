@@ -193,13 +193,7 @@ void Model::bindFrameMaps(const float* const depthPyr[3], float depthCutoff, Mod
         // in createVMap, cudafuncs.cu:119): computed once, shared with every other model of this frame
         check(ctx, cf_odom_init_icp(odom, depthPyr, depthCutoff), "initICP");
     } else {
-        const float* vm[3]; const float* nm[3];
-        for (int l = 0; l < 3; l++) {
-            void* p = nullptr;
-            check(ctx, cf_odom_buffer(frameOwner->odom, 0, l, &p, nullptr), "cf_odom_buffer"); vm[l] = static_cast<const float*>(p);
-            check(ctx, cf_odom_buffer(frameOwner->odom, 1, l, &p, nullptr), "cf_odom_buffer"); nm[l] = static_cast<const float*>(p);
-        }
-        check(ctx, cf_odom_bind_frame_maps(odom, vm, nm), "bind_frame_maps");
+        check(ctx, cf_odom_share_frame_maps(odom, frameOwner->odom), "share_frame_maps");
     }
 }
 void Model::initICP(bool doFillIn, bool frameToFrameRGB, const float* const depthPyr[3], float depthCutoff, const uint8_t* rgba,

@@ -268,6 +268,9 @@ int cf_rccl_broadcast(cf_ctx *ctx, void *dev_buf, uint64_t bytes, int root, void
 int cf_rccl_info(const cf_ctx *ctx, int *rank, int *world, int *rccl_version);
 int cf_rccl_destroy(cf_ctx *ctx);
 int cf_odom_bind_frame_maps(cf_odom *od, const float *const vmaps[CF_NUM_PYRS], const float *const nmaps[CF_NUM_PYRS]);
+/* ... or, when another tracker of the same context computed them with cf_odom_init_icp: share that tracker's current-frame pyramids
+ * (and the per-run depth intervals the culled reduction uses) */
+int cf_odom_share_frame_maps(cf_odom *od, cf_odom *owner);
 int cf_odom_buffer(cf_odom *od, int which, int level, void **dptr, uint64_t *bytes);
 /* Model::generateCUDATextures depth half (Model.cpp:341-343): l1/l2 device outputs */
 int cf_depth_pyramid(cf_ctx *ctx, const float *depth_filtered, int cols, int rows, float *l1, float *l2);
