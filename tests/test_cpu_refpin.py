@@ -465,3 +465,21 @@ def test_trajectory_within_1mm_ate_of_the_reference_arithmetic():
                 if rids[t, m] >= 0:
                     e = float(np.linalg.norm(op[t, m, :3, 3].astype(np.float64) - rp[t, m, :3, 3].astype(np.float64)))
                     assert e <= 2 * ATE_TOL_M, f"{name} frame {t}: object {rids[t, m]}: pose differs by {e} m"
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_trajectory_fixture_is_what_the_reference_tracker_produces():
+    """the committed trajectory fixture is reproducible from the reference sources: the first TRACKED frame of the static scenario through
+    the reference's own RGBDOdometry class under the emulator (~110 s; tests/golden/make_ref_traj_golden.py regenerates all of it in ~3 h)"""
+    import subprocess
+    import sys
+    z = np.load(TRAJ_GOLDEN)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r); import make_ref_traj_golden as g; "
+            "p, i, c = g.play('static_camera', True, n_frames=2); np.savez(sys.argv[1], poses=p, counts=c)"
+            % (os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__)), os.path.join(os.path.dirname(__file__), "golden")))
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"traj_live_{os.getpid()}.npz")
+    subprocess.run([sys.executable, "-c", code, out], check=True, capture_output=True)
+    o = np.load(out); os.remove(out)
+    assert refpin.bits_equal(o["poses"][1, 0], z["static_camera/poses"][1, 0]), "frame 1: pose of the reference-tracked run"
+    assert int(o["counts"][1, 0]) == int(z["static_camera/counts"][1, 0])
+    assert float(np.abs(o["poses"][1, 0, :3, 3]).max()) > 5e-3, "degenerate: the camera did not move"
