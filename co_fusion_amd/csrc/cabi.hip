@@ -62,6 +62,8 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     memset(ctx->h_state_pool, 0, sizeof(OdomDev) * cf_ctx::kStateSlots);
     if (int r = dmalloc(ctx, &ctx->d_model_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_so3_sync, (size_t)ctx->cfg.max_models + 1)) return r;
+    if (int r = dmalloc(ctx, &ctx->d_pre_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pre_ptrs), sizeof(OdomDev*) * (ctx->cfg.max_models + 1)));
     if (const char* e = getenv("CF_GN_GRAPH")) ctx->gn_use_graph = atoi(e);
     if (const char* e = getenv("CF_GN_MODE")) ctx->gn_mode = atoi(e);  // diagnostic: 0 = three launches per iteration
     if (const char* e = getenv("CF_ICP_LAUNCH")) {  // diagnostic: "threads,pixels_per_thread"
@@ -89,6 +91,7 @@ void cf_destroy(cf_ctx* ctx)
     (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_cand_scratch);
     (void)hipFree(ctx->d_state_pool); (void)hipHostFree(ctx->h_state_pool);
     (void)hipHostFree(ctx->h_scratch_state); (void)hipHostFree(ctx->h_model_ptrs); (void)hipHostFree(ctx->h_out);
+    (void)hipFree(ctx->d_pre_ptrs); (void)hipHostFree(ctx->h_pre_ptrs);
     if (ctx->gn_graph) (void)hipGraphExecDestroy(ctx->gn_graph);
     if (ctx->prof.events) {
         for (int i = 0; i < ctx->prof.capacity; i++) (void)hipEventDestroy(ctx->prof.events[i]);
@@ -715,6 +718,80 @@ int cf_odom_init_first_rgb(cf_odom* od, const uint8_t* rgba)
     return CF_OK;
 }
 
+// ---- SO(3) pre-alignment of a frame (cf_so3) ----
+int cf_so3_create(cf_ctx* ctx, cf_so3** out)
+{
+    if (!ctx || !out) return CF_EINVAL;
+    cf_so3* h = new cf_so3();
+    h->ctx = ctx; *out = h;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    for (int i = 0; i < CF_NUM_PYRS; i++) {
+        const size_t n = (size_t)(W >> i) * (H >> i);
+        if (int r = dmalloc(ctx, &h->last[i], n)) return r;
+        if (int r = dmalloc(ctx, &h->next[i], n)) return r;
+    }
+    if (int r = dmalloc(ctx, &h->d_state, 1)) return r;
+    if (int r = dmalloc(ctx, &h->d_ptr, 1)) return r;
+    if (int r = dmalloc(ctx, &h->d_sync, 1)) return r;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&h->h_state), sizeof(OdomDev), hipHostMallocCoherent));
+    memset(h->h_state, 0, sizeof(OdomDev));
+    HIPCHK(ctx, hipMemcpyAsync(h->d_ptr, &h->d_state, sizeof(OdomDev*), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
+}
+void cf_so3_destroy(cf_so3* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->ctx->stream);
+    for (int i = 0; i < CF_NUM_PYRS; i++) { (void)hipFree(h->last[i]); (void)hipFree(h->next[i]); }
+    (void)hipFree(h->d_state); (void)hipFree(h->d_ptr); (void)hipFree(h->d_sync); (void)hipHostFree(h->h_state);
+    delete h;
+}
+static int so3_pyramid(cf_so3* h, const uint8_t* rgba, uint8_t* const* dst)
+{
+    cf_ctx* ctx = h->ctx; hipStream_t s = ctx->cur();
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    launch_intensity(s, rgba, W, H, dst[0]);   // imageBGRToIntensity + pyrDownUcharGauss x2, as initFirstRGB / populateRGBDData
+    for (int i = 0; i + 1 < CF_NUM_PYRS; i++) launch_pyrdown_u8(s, dst[i], W >> i, H >> i, dst[i + 1]);
+    LAUNCHCHK(ctx);
+    return CF_OK;
+}
+int cf_so3_first_frame(cf_so3* h, const uint8_t* rgba)
+{   // RGBDOdometry::initFirstRGB (RGBDOdometry.cpp:206-215) for every tracker this frame will spawn
+    if (!h || !rgba) return CF_EINVAL;
+    h->have_last = true; h->pending = false;
+    return so3_pyramid(h, rgba, h->last);
+}
+int cf_so3_prealign(cf_so3* h, const uint8_t* rgba)
+{
+    if (!h || !rgba) return CF_EINVAL;
+    cf_ctx* ctx = h->ctx;
+    if (!h->have_last) { ctx->set_error("cf_so3_prealign: no previous frame (cf_so3_first_frame)"); return CF_ESTATE; }
+    if (int r = so3_pyramid(h, rgba, h->next)) return r;
+    OdomDev* st = h->h_state;
+    for (int i = 0; i < CF_NUM_PYRS; i++) { st->lastNextImage[i] = h->last[i]; st->nextImage[i] = h->next[i]; }
+    st->intr = cf_cam{ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy};
+    st->width = ctx->cfg.width; st->height = ctx->cfg.height; st->cull = 0;
+    memset(&st->stats, 0, sizeof(st->stats));
+    HIPCHK(ctx, hipMemcpyAsync(h->d_state, st, sizeof(OdomDev), hipMemcpyHostToDevice, ctx->cur()));
+    launch_so3_frame(ctx->cur(), h->d_ptr, h->d_sync);
+    LAUNCHCHK(ctx);
+    h->pending = true;
+    return CF_OK;
+}
+int cf_so3_commit(cf_so3* h)
+{   // the image swap after getIncrementalTransformation (RGBDOdometry.cpp:469-473): the pre-aligned frame becomes the last one
+    if (!h) return CF_EINVAL;
+    if (h->pending) { for (int i = 0; i < CF_NUM_PYRS; i++) std::swap(h->last[i], h->next[i]); h->pending = false; }
+    return CF_OK;
+}
+int cf_odom_set_prealignment(cf_odom* od, cf_so3* h)
+{
+    if (!od || (h && h->ctx != od->ctx)) return CF_EINVAL;
+    od->pre = h;
+    return CF_OK;
+}
+
 int cf_odom_init_icp(cf_odom* od, const float* const depth_pyr[CF_NUM_PYRS], float depth_cutoff)
 {  // RGBDOdometry.cpp:110-118
     if (!od || !depth_pyr) return CF_EINVAL;
@@ -912,6 +989,14 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
             HIPCHK(ctx, hipMemcpyAsync(ods[m]->d_state, ods[m]->h_state, sizeof(OdomDev), hipMemcpyHostToDevice, ctx->stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_model_ptrs, ctx->h_model_ptrs, sizeof(OdomDev*) * n, hipMemcpyHostToDevice, ctx->stream));
+    // frame pre-alignments (cf_so3): when every tracker of the batch has one enqueued, the SO(3) iterations are not repeated here
+    bool use_pre = opts->so3 != 0;
+    for (int m = 0; m < n; m++) use_pre = use_pre && ods[m]->pre && ods[m]->pre->pending;
+    if (use_pre) {
+        for (int m = 0; m < n; m++) ctx->h_pre_ptrs[m] = ods[m]->pre->d_state;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_pre_ptrs, ctx->h_pre_ptrs, sizeof(OdomDev*) * n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const bool so3_here = opts->so3 != 0 && !use_pre;
     const bool icp = !opts->rgb_only && opts->icp_weight > 0;
     const bool rgb = opts->rgb_only || opts->icp_weight < 100;
     IcpArgs icp_args[3];
@@ -938,7 +1023,7 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
         std::string key;
         key.append(reinterpret_cast<const char*>(icp_args), sizeof(icp_args));
         key.append(reinterpret_cast<const char*>(rgb_args), sizeof(rgb_args));
-        const int misc[10] = {n, opts->so3, opts->pyramid, opts->fast_odom, rgb, icp, ctx->gn_mode, ctx->icp_launch.threads, ctx->icp_launch.ppt, 0};
+        const int misc[10] = {n, opts->so3, opts->pyramid, opts->fast_odom, rgb, icp, ctx->gn_mode, ctx->icp_launch.threads, ctx->icp_launch.ppt, use_pre ? 1 : 0};
         key.append(reinterpret_cast<const char*>(misc), sizeof(misc));
         if (!ctx->gn_graph || key != ctx->gn_graph_key) {
             if (ctx->gn_graph) { (void)hipGraphExecDestroy(ctx->gn_graph); ctx->gn_graph = nullptr; }
@@ -946,7 +1031,8 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
             bool ok = hipStreamBeginCapture(ctx->own_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 launch_gn_track(ctx->own_stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, nullptr, icp_args, rgb_args, n, ctx->cfg.width,
-                                ctx->cfg.height, opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, nullptr, h_states);
+                                ctx->cfg.height, so3_here, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, nullptr, h_states,
+                                use_pre ? ctx->d_pre_ptrs : nullptr);
                 ok = hipStreamEndCapture(ctx->own_stream, &g) == hipSuccess && g != nullptr;
             }
             if (ok) ok = hipGraphInstantiate(&ctx->gn_graph, g, nullptr, nullptr, 0) == hipSuccess;
@@ -961,7 +1047,8 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     }
     if (!launched &&
         !launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, any_split ? &hook : nullptr, icp_args, rgb_args, n,
-                         ctx->cfg.width, ctx->cfg.height, opts->so3 != 0, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, prof, h_states)) {
+                         ctx->cfg.width, ctx->cfg.height, so3_here, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, prof, h_states,
+                         use_pre ? ctx->d_pre_ptrs : nullptr)) {
         ctx->set_error("tracking: the registered collective failed inside the Gauss-Newton loop");
         return CF_ESTATE;
     }
@@ -992,11 +1079,26 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     return CF_OK;
 }
 
+// The frame's host wait.  hipStreamSynchronize may put the thread to sleep and wake it tens of microseconds after the stream has drained;
+// CF_SPIN_WAIT=1 polls an event instead (diagnostics: A/B of the wake-up latency).
+int cf_wait_stream(cf_ctx* ctx)
+{
+    static const bool spin = getenv("CF_SPIN_WAIT") != nullptr;
+    if (!spin) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return CF_OK; }
+    if (!ctx->wait_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->wait_event, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->wait_event, ctx->stream));
+    for (;;) {
+        const hipError_t e = hipEventQuery(ctx->wait_event);
+        if (e == hipSuccess) return CF_OK;
+        if (e != hipErrorNotReady) { ctx->set_error(std::string("hipEventQuery: ") + hipGetErrorString(e)); return CF_EHIP; }
+    }
+}
+
 int cf_odom_fetch_result(cf_odom* od, float trans[3], float rot[9], cf_track_stats* stats)
 {
     if (!od) return CF_EINVAL;
     cf_ctx* ctx = od->ctx;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int r = cf_wait_stream(ctx)) return r;
     ctx->state_readback_pending = false;
     if (trans) memcpy(trans, od->h_state->tcurr, 12);
     if (rot) memcpy(rot, od->h_state->Rcurr, 36);

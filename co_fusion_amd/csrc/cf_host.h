@@ -29,6 +29,8 @@ struct cf_ctx {
     cf::OdomDev* h_scratch_state = nullptr;  // pinned
     cf::OdomDev** d_model_ptrs = nullptr;
     cf::OdomDev** h_model_ptrs = nullptr;  // pinned
+    const cf::OdomDev** d_pre_ptrs = nullptr;   // per tracker of a batch: the frame pre-alignment it adopts
+    const cf::OdomDev** h_pre_ptrs = nullptr;   // pinned
     uint8_t* d_cand_scratch = nullptr;
     cf::So3Sync* d_so3_sync = nullptr;  // [max_models]
     int gn_mode = 1;                    // launch_gn_track mode (1: record slots between the residual pass and the RGB step)
@@ -54,6 +56,7 @@ struct cf_ctx {
     // all-reduce of unsigned 64-bit words; enqueued on the given stream
     int (*collective)(void* user, int op, void* dev_buf, uint64_t words, void* stream) = nullptr;
     void* collective_user = nullptr;
+    hipEvent_t wait_event = nullptr;   // cf_wait_stream (CF_SPIN_WAIT)
     void* rccl = nullptr;              // the library's own RCCL communicator (cf_rccl_init, rccl_comm.hip); its collective replaces the caller's
     // the launch schedule of the device-resident Gauss-Newton loop as a hipGraph: captured once per set of kernel arguments (which
     // models, which buffers, which options), replayed every frame -- ~1 us less per launch boundary than 58 stream launches
@@ -64,6 +67,20 @@ struct cf_ctx {
     cf::ProfSink prof{};
     double prof_ms_accum = 0;
     void set_error(const std::string& m);
+};
+extern "C" int cf_wait_stream(cf_ctx* ctx);   // the frame's host wait (cabi.hip)
+
+// SO(3) pre-alignment of a frame, ahead of (and shared by) the trackers of that frame: RGBDOdometry.cpp:239-310 reads the previous and
+// the new frame's level-2 intensity images only
+struct cf_so3 {
+    cf_ctx* ctx = nullptr;
+    uint8_t* last[3]{};             // intensity pyramid of the last TRACKED frame (every tracker's lastNextImage)
+    uint8_t* next[3]{};             // ... of the frame being pre-aligned
+    cf::OdomDev* d_state = nullptr;   // the kernel's state block: images, intrinsics, size in; rotation + statistics out
+    cf::OdomDev* h_state = nullptr;   // pinned
+    cf::OdomDev** d_ptr = nullptr;    // one-entry model list
+    cf::So3Sync* d_sync = nullptr;
+    bool have_last = false, pending = false;   // pending: a pre-alignment of `next` is enqueued and not yet committed
 };
 
 // Device-resident RGBDOdometry (Core/Utils/RGBDOdometry.h:78-137)
@@ -109,4 +126,5 @@ struct cf_odom {
     float angleSqLt = 0, distSqLe = 0;  // exact radicand bounds of the two ICP gates
     float minGrad[3]{};
     bool pending_so3_swap = false;
+    cf_so3* pre = nullptr;           // cf_odom_set_prealignment: adopt this frame pre-alignment instead of iterating per tracker
 };

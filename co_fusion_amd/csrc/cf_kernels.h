@@ -206,7 +206,9 @@ struct GnHook { int (*fn)(void* user, int op, void* dev_buf, uint64_t words, voi
 bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */, So3Sync* so3_syncs /* [n] */,
                      const GnHook* hook, const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3,
                      bool pyramid, bool fast_odom, bool rgb, bool icp, int mode, ProfSink* prof,
-                     OdomDev* const* h_states = nullptr /* [n] pinned host copies the last solve publishes to */);
+                     OdomDev* const* h_states = nullptr /* [n] pinned host copies the last solve publishes to */,
+                     const OdomDev* const* d_pre = nullptr /* device array [n]: frame pre-alignments to adopt (with so3 == false) */);
+void launch_so3_frame(hipStream_t s, OdomDev* const* d_model, So3Sync* sync);
 float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, int ablate, int reps, hipEvent_t e0, hipEvent_t e1);
 float sqrt_gate_lt(float T);  // smallest x with sqrtf(x) >= T
 float sqrt_gate_le(float T);  // largest x with sqrtf(x) <= T

@@ -1206,7 +1206,7 @@ int cf_seg_infer(cf_segmenter* s, const cf_seg_params* P, const uint8_t* rgba, i
 int cf_seg_fetch(cf_segmenter* s, cf_seg_result* out, uint8_t* low_map_host)
 {
     if (!s || !out) return CF_EINVAL;
-    HIPCHK(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    if (int r = cf_wait_stream(s->ctx)) return r;
     *out = *s->h_result;
     if (low_map_host) memcpy(low_map_host, s->h_low_map, (size_t)s->K);
     return CF_OK;

@@ -728,8 +728,10 @@ __global__ void __launch_bounds__(1024) so3_step_kernel(const uint8_t* __restric
 // loads) and runs the identical 3x3 solve + Rodrigues on its own LDS copy of the state, so nothing but integer
 // atomics crosses workgroups and the data-dependent early exits stay uniform.  The last workgroup to leave
 // re-zeroes the sync block for the next frame.  Also seeds resultRt and the first iteration's krkInv/kt.
+// pre (nullable, with do_so3 == 0): per model, the state of a FRAME pre-alignment (cf_so3: this same kernel run ahead on the frame's two
+// intensity images, which is all the pre-alignment depends on) whose rotation and statistics are adopted instead of iterating here.
 __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __restrict__ models, So3Sync* __restrict__ syncs, int do_so3,
-                                                           int first_level)
+                                                           int first_level, const OdomDev* const* __restrict__ pre)
 {
     OdomDev* od = models[blockIdx.y];
     So3Sync* sync = syncs + blockIdx.y;
@@ -853,6 +855,13 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
         if (do_so3)
             for (int x = 0; x < 3; x++)
                 for (int y = 0; y < 3; y++) od->resultRt[x * 4 + y] = s_resultR[x * 3 + y];
+        else if (pre && pre[blockIdx.y]) {
+            const OdomDev* p = pre[blockIdx.y];
+            for (int x = 0; x < 3; x++)
+                for (int y = 0; y < 3; y++) od->resultRt[x * 4 + y] = p->resultRt[x * 4 + y];
+            od->stats.so3_iterations = p->stats.so3_iterations; od->stats.last_so3_error = p->stats.last_so3_error;
+            od->stats.last_so3_count = p->stats.last_so3_count; od->stats.fault |= p->stats.fault;
+        }
         od->lastRGBError = 3.402823466e+38F;
         od->level_done = 0;
         od->residual[0] = 0; od->residual[1] = 0;
@@ -1183,7 +1192,7 @@ void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, 
 // Kept as separate launches.
 bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const GnHook* hook, const IcpArgs icp_args[3],
                      const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, int mode,
-                     ProfSink* prof, OdomDev* const* h_states)
+                     ProfSink* prof, OdomDev* const* h_states, const OdomDev* const* d_pre)
 {
     int iterations[3];
     iterations[0] = fast_odom ? 3 : 10;
@@ -1191,7 +1200,7 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
     iterations[2] = pyramid ? 4 : 0;
     int first_level = 2;
     while (first_level > 0 && iterations[first_level] == 0) first_level--;
-    so3_prealign_kernel<<<dim3(so3 ? kSo3Blocks : 1, n), 256, 0, s>>>(d_models, so3_syncs, so3 ? 1 : 0, first_level);
+    so3_prealign_kernel<<<dim3(so3 ? kSo3Blocks : 1, n), 256, 0, s>>>(d_models, so3_syncs, so3 ? 1 : 0, first_level, so3 ? nullptr : d_pre);
     GnArgs gn{};
     for (int m = 0; m < n; m++) {
         gn.od[m] = const_cast<OdomDev*>(icp_args[0].m[m].st);
@@ -1253,6 +1262,13 @@ float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const R
     (void)hipStreamSynchronize(s);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     return ms * 1000.f / reps;
+}
+
+// the SO(3) pre-alignment of a FRAME (cf_so3): the kernel above on a one-entry model list whose state only carries the two level-2
+// intensity images, the intrinsics and the image size
+void launch_so3_frame(hipStream_t s, OdomDev* const* d_model /* device array of 1 */, So3Sync* sync)
+{
+    so3_prealign_kernel<<<dim3(kSo3Blocks, 1), 256, 0, s>>>(d_model, sync, 1, 2, nullptr);
 }
 
 // ---- stand-alone steps (C-ABI parity with computeRgbResidual / rgbStep) -------------------

@@ -764,6 +764,10 @@ CoFusion::CoFusion(const Config& c, cf_ctx* shared, int sequenceIndex)
     dist.rank = cfg.rank; dist.world = cfg.world < 1 ? 1 : cfg.world;
     dist.shardBackground = cfg.shardBackground && dist.world > 1;
     labelGenerator.reset(new Segmentation(ctx, cfg.width, cfg.height, &dist));
+    // experiment, off by default (CF_FRAME_SO3=1): the SO(3) pre-alignment once per frame and ahead of the tracking launches (cf_so3).
+    // Bit-identical; measured +0.6 % on configs[2] and -1.9 % on configs[1]: beside the previous frame's fusion passes
+    // the pre-alignment is late as often as it is early
+    if (std::getenv("CF_FRAME_SO3") != nullptr) check(ctx, cf_so3_create(ctx, &frameSo3), "cf_so3_create");
     const size_t N = (size_t)cfg.width * cfg.height;
     void* p = nullptr;
     check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); depth_dev = static_cast<float*>(p);
@@ -805,6 +809,7 @@ CoFusion::~CoFusion()
     cf_free(ctx, rgba_dev); cf_free(ctx, rgb_dev); cf_free(ctx, mask_dev);
     for (int b = 0; b < 2; b++) if (stage[b]) cf_free_host(ctx, stage[b]);
     labelGenerator.reset();
+    if (frameSo3) cf_so3_destroy(frameSo3);
     if (rcclStage) cf_free(ctx, rcclStage);
     if (ownsCtx) cf_destroy(ctx);
 }
@@ -934,6 +939,7 @@ void CoFusion::trackCollect(TrackBatch& batch, const float* const depthPyr[3])
         it.model = m.get(); it.owner = owner; it.frameRgba = curRgba; it.maxDepth = maxDepthProcessed;
         for (int l = 0; l < 3; l++) it.depthPyr[l] = depthPyr[l];
         m->trackingInputs(m->requiresFillIn(), cfg.frameToFrameRGB, it.predV, it.predN, it.predImg);
+        check(ctx, cf_odom_set_prealignment(m->odom, (cfg.so3 && frameSo3) ? frameSo3 : nullptr), "set_prealignment");
         batch.items.push_back(it);
         trackPending.push_back(m.get());
     }
@@ -980,6 +986,9 @@ void CoFusion::fetchTracking(bool exchange)
         check(ctx, cf_odom_fetch_result(m->odom, t, R, &m->lastStats), "fetch_result");
         for (int r = 0; r < 3; r++) { m->pose.m[r * 4 + 0] = R[r * 3 + 0]; m->pose.m[r * 4 + 1] = R[r * 3 + 1]; m->pose.m[r * 4 + 2] = R[r * 3 + 2]; m->pose.m[r * 4 + 3] = t[r]; }
     }
+    // the image swap of a tracked frame (RGBDOdometry.cpp:469-473) -- on every rank, also one that owns no tracker this frame: a model
+    // it is given later starts from the last TRACKED frame's image like everybody else's
+    if (frameSo3) check(ctx, cf_so3_commit(frameSo3), "cf_so3_commit");
     trackPending.clear();
     if (exchange) exchangeTracking();
 }
@@ -1058,12 +1067,17 @@ void CoFusion::frameBegin(const FrameData& frame, const Mat4f* inPose, float wei
     if (headAside) check(ctx, cf_fork_after(ctx, 6, markBase + (int)b), "cf_fork_after");
     check(ctx, cf_bilateral(ctx, curDepth, cfg.width, cfg.height, cfg.depthCutoff, depthFiltered_dev), "filterDepth");
     if (willTrack) check(ctx, cf_depth_pyramid(ctx, depthFiltered_dev, cfg.width, cfg.height, depthPyr1, depthPyr2), "generateCUDATextures");
+    // The SO(3) pre-alignment every tracker starts with (RGBDOdometry.cpp:239-310) reads the previous and the new frame's intensity
+    // images only: done ONCE for the frame and here -- with a device-resident frame on the auxiliary stream, beside the previous
+    // frame's fusion passes -- instead of at the head of the tracking launches (55 us of the critical path)
+    if (willTrack && cfg.so3 && frameSo3) check(ctx, cf_so3_prealign(frameSo3, curRgba), "cf_so3_prealign");
     if (headAside) check(ctx, cf_join_lane(ctx, 6), "cf_join_lane");
 
     st.pyr[0] = depthFiltered_dev; st.pyr[1] = depthPyr1; st.pyr[2] = depthPyr2;
     if (tick == 1) {
         globalModel->initialise(curRgba, curDepth, depthFiltered_dev, tick, maxDepthProcessed);
         if (globalModel->isOwned()) check(ctx, cf_odom_init_first_rgb(globalModel->getFrameOdometry(), curRgba), "initFirstRGB");
+        if (frameSo3) check(ctx, cf_so3_first_frame(frameSo3, curRgba), "cf_so3_first_frame");
     } else if (willTrack) {
         // the superpixels only depend on the colour image: SLIC runs on an auxiliary stream beside the (latency-bound)
         // tracking launches and is joined before the segmentation needs it

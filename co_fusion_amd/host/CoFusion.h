@@ -318,6 +318,7 @@ class CoFusion {
     int tick = 1;
     float maxDepthProcessed = 20.0f;
     unsigned spawnOffset = 0;
+    cf_so3* frameSo3 = nullptr;        // SO(3) pre-alignment of the frame, once and ahead of its trackers (cf_so3)
     int64_t* rcclStage = nullptr;      // device staging buffer of the host-buffer all-reduce (initRccl)
     uint64_t rcclStageWords = 0;
     bool capReported = false;  // the model cap suppressed a spawn and said so

@@ -224,6 +224,20 @@ int cf_odom_init_models_batch(cf_ctx *ctx, cf_odom *const *ods, int n, const flo
 int cf_odom_init_models_batch_frames(cf_ctx *ctx, cf_odom *const *ods, int n, const float *const *pred_vertex4,
                                      const float *const *pred_normal4, const uint8_t *const *pred_rgba, const float *const *poses /* n x [16] */,
                                      const uint8_t *const *frame_rgba /* n */);
+/* SO(3) pre-alignment of a FRAME.  RGBDOdometry::getIncrementalTransformation starts with up to ten SO(3) iterations
+ * (RGBDOdometry.cpp:239-310) that read the previous and the new frame's level-2 intensity images and nothing else -- every tracker of a
+ * frame repeats the same computation, and none of it depends on the maps.  cf_so3 does it once per frame and AHEAD: cf_so3_prealign only
+ * needs the new colour image (e.g. on an auxiliary stream beside the previous frame's fusion passes), trackers that were given the handle
+ * (cf_odom_set_prealignment) adopt its rotation and statistics at the start of cf_odom_track_batch_async instead of iterating -- the
+ * same bits.  cf_so3_first_frame = initFirstRGB; cf_so3_commit = the image swap after a tracked frame (not after frames whose pose was
+ * injected). */
+typedef struct cf_so3 cf_so3;
+int cf_so3_create(cf_ctx *ctx, cf_so3 **out);
+void cf_so3_destroy(cf_so3 *h);
+int cf_so3_first_frame(cf_so3 *h, const uint8_t *rgba);
+int cf_so3_prealign(cf_so3 *h, const uint8_t *rgba);
+int cf_so3_commit(cf_so3 *h);
+int cf_odom_set_prealignment(cf_odom *od, cf_so3 *h /* nullable */);
 /* initICP(depthPyramid, maskPyramid, depthCutoff) :48-49 (frame -> model); the mask pyramid is dead in the
  * reference (cudafuncs.cu:119) and therefore not part of the ABI */
 int cf_odom_init_icp(cf_odom *od, const float *const depth_pyr[CF_NUM_PYRS], float depth_cutoff);
