@@ -1226,8 +1226,7 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
                 // the roofline figure is quoted on the dominant kernel: the level-0 instantiation
                 const bool timed = prof && prof->enabled && i == 0 && prof->used + 4 <= prof->capacity;
                 IcpArgs a = icp_args[i];
-                static const int ablate = getenv("CF_ICP_ABLATE") ? atoi(getenv("CF_ICP_ABLATE")) : 0;  // diagnostics: timing ablations (results change)
-                a.flags = ((i == 0 && last_of_level) ? 1 : 0) | (ablate << 8);
+                a.flags = (i == 0 && last_of_level) ? 1 : 0;
                 launch_icp_rgbres(s, cfg, a, ra, icp, rgb, n, i, timed ? prof->events[prof->used] : nullptr,
                                   timed ? prof->events[prof->used + 1] : nullptr);
                 if (timed) {
