@@ -263,8 +263,19 @@ def main(argv=None):
                               **(dict(rank=rank, world=world, shard_background=int(args.shard_background)) if model_parallel else {}))
         if model_parallel:
             if use_rccl:
-                cfi.init_rccl()       # the library's own ncclComm_t: every collective of the frame loop runs inside the library
-            else:
+                # the library's own ncclComm_t: every collective of the frame loop runs inside the library.  All ranks agree on whether
+                # that worked; if it failed anywhere, every rank falls back to the torch.distributed callbacks
+                ok = 1
+                try:
+                    cfi.init_rccl()
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench rank {rank}] cofusion_init_rccl failed: {e}", file=sys.stderr, flush=True)
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    use_rccl = False
+            if not use_rccl:
                 cfi.set_allreduce()   # torch.distributed callbacks (process groups that are not RCCL)
         if args.icp_ppt:
             cfi.set_icp_launch(args.icp_threads, args.icp_ppt)
