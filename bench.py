@@ -375,6 +375,13 @@ def main(argv=None):
         bpl = int(prof.icp_bytes / max(1, prof.icp_launches))
         avg_us = 1e3 * prof.icp_ms_total / max(1, prof.icp_launches)
         icp_only = (24 + 24 * n_models) * W * H  # the ICP part alone, if nothing is credited to the residual passes
+        # ... and on the pixels the launch actually works on: a culled model only touches the runs inside its screen box (the rectangle the
+        # last iteration of the last timed frame was restricted to; the background's is the whole image)
+        boxed = []
+        for i in range(n_models):
+            b = cf.model_cull_box(i)
+            boxed.append(max(0, min(b[2], W - 1) - max(b[0], 0) + 1) * max(0, min(b[3], H - 1) - max(b[1], 0) + 1))
+        processed = 24 * W * H + 24 * sum(boxed) + 11 * n_models * W * H
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                         traffic=pmc_traffic(args.workload, W * H),
                         kernel="cf::icp_reduce_kernel<PPT,%d>: ICP reduction of all lock-step models || their RGB residual passes, pyramid level 0"
@@ -382,7 +389,9 @@ def main(argv=None):
                         launches=int(prof.icp_launches), avg_us=round(avg_us, 3), bytes_per_launch=bpl,
                         sampled="level-0 launches of every %d-th timed step carry begin/end events" % args.event_sampling,
                         bytes_per_pixel="24 + 24*M (ICP) + 11*M (residual), M = models in the launch",
-                        frac_icp_bytes_only=round(icp_only / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4))
+                        frac_icp_bytes_only=round(icp_only / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4),
+                        bytes_processed_per_launch=int(processed), pixels_in_screen_boxes=[int(v) for v in boxed],
+                        frac_bytes_processed=round(processed / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4))
         out = dict(metric="frames/sec at 640x480 (N active models) + ICP-reduce achieved HBM GB/s vs peak", value=round(fps, 2),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 4),
                    higher_is_better=True, scaling="strong" if model_parallel else "weak", vs_baseline=None, dtype="f32", data="synthetic",
