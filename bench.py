@@ -115,6 +115,9 @@ def parse(argv=None):
     ap.add_argument("--lockstep", action="store_true",
                     help="--streams S > 1: the S sequences form ONE lock-step group (cofusion_group_*: one context, one set of tracking "
                          "launches for the trackers of all sequences) instead of S contexts driven by S host threads")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="--lockstep: split the S sequences into this many lock-step groups, each with its own context, HIP stream and host "
+                         "thread (the latency-bound stretches of one group run beside the throughput-bound ones of another)")
     ap.add_argument("--streams", type=int, default=1, help="independent RGB-D streams per GPU (own context + HIP stream + host thread each); "
                     "1 = the headline single-sequence figure, >1 = throughput mode")
     a = ap.parse_args(argv)
@@ -430,65 +433,89 @@ def main(argv=None):
 
 
 def lockstep_run(args, torch, facade, local_rank, wl, S):
-    """--streams S --lockstep: S independent sequences (different seeds) as ONE lock-step group on one GPU.  A step = one frame of EVERY
-    sequence; value = S * steps / time (aggregate frames/s).  Same phases as the single-sequence run."""
+    """--streams S --lockstep [--groups G]: S independent sequences (different seeds) in G lock-step groups on one GPU (G = 1: ONE group, one
+    context; G > 1: each group has its own context, HIP stream and host thread).  A step = one frame of EVERY sequence; value =
+    S * steps / time (aggregate frames/s).  Same phases as the single-sequence run."""
+    import threading
     W, H = args.width, args.height
     n_obj = wl["n_obj"]
     dev = torch.device("cuda", local_rank)
+    G = max(1, min(args.groups, S))
     seqs = [make_stream(W, H, args.frames, n_obj=n_obj, seed=1234 + si) for si in range(S)]
     cam = seqs[0][0]
-    g = facade.CoFusionGroup(S, W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels,
-                             enable_multiple_models=int(n_obj > 0), device_frames_complete=1)
-    if args.icp_ppt:
-        g.sequences[0].set_icp_launch(args.icp_threads, args.icp_ppt)   # (the launch shape belongs to the shared context)
-    if args.gn_mode >= 0:
-        g.sequences[0].set_gn_mode(args.gn_mode)
+    members = [list(range(g, S, G)) for g in range(G)]
+    groups = []
+    for g in range(G):
+        hs = torch.cuda.Stream(device=dev) if G > 1 else None
+        if hs is not None:
+            torch.cuda.set_stream(hs)   # the group adopts the current stream at construction
+        grp = facade.CoFusionGroup(len(members[g]), W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels,
+                                   enable_multiple_models=int(n_obj > 0), device_frames_complete=1)
+        if args.icp_ppt:
+            grp.sequences[0].set_icp_launch(args.icp_threads, args.icp_ppt)   # (the launch shape belongs to the shared context)
+        if args.gn_mode >= 0:
+            grp.sequences[0].set_gn_mode(args.gn_mode)
+        groups.append(dict(g=grp, stream=hs, members=members[g]))
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))
     res = [[dict(depth=torch.from_numpy(f["depth"]).to(dev), rgba=torch.from_numpy(f["rgba"]).to(dev)) for f in fr] for _, fr in seqs]
     torch.cuda.synchronize()
 
-    def step(i, masks=None):
+    def step(gr, i, masks=None):
         k = frame_index(i, args.frames)
         if masks == "gt":
-            fs = [fr[k] for _, fr in seqs]
-            g.process_frames([f["depth"] for f in fs], [f["rgb"] for f in fs], [(f["label"] * 40).astype(np.uint8) for f in fs], timestamp=i)
+            fs = [seqs[m][1][k] for m in gr["members"]]
+            gr["g"].process_frames([f["depth"] for f in fs], [f["rgb"] for f in fs], [(f["label"] * 40).astype(np.uint8) for f in fs], timestamp=i)
         else:
-            g.process_frames_device([r[k]["depth"] for r in res], [r[k]["rgba"] for r in res], timestamp=i)
+            gr["g"].process_frames_device([res[m][k]["depth"] for m in gr["members"]], [res[m][k]["rgba"] for m in gr["members"]], timestamp=i)
+
+    def run(lo, hi, masks=None):
+        if G == 1:
+            for i in range(lo, hi):
+                step(groups[0], i, masks)
+            return
+        def work(gr):
+            torch.cuda.set_device(local_rank)
+            for i in range(lo, hi):
+                step(gr, i, masks)
+        ths = [threading.Thread(target=work, args=(gr,)) for gr in groups]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
 
     P = args.preroll
     pre_masks = "gt" if (n_obj > 0 and args.preroll_masks == "gt") else None
-    for i in range(P):
-        step(i, pre_masks)
-    for i in range(P, P + args.warmup):
-        step(i)
+    run(0, P, pre_masks)
+    run(P, P + args.warmup)
     base = P + args.warmup
-    cf0 = g.sequences[0]
+    cf0 = groups[0]["g"].sequences[0]
     cf0.profile_enable(0 if args.no_kernel_events else args.event_sampling)
     cf0.profile_read(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(base, base + args.steps):
-        step(i)
+    run(base, base + args.steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = cf0.profile_read(reset=True)
     cf0.profile_enable(False)
-    n_models = [q.num_models for q in g.sequences]
-    trackers = sum(n_models)
+    n_models = [q.num_models for gr in groups for q in gr["g"].sequences]
+    trackers = sum(q.num_models for q in groups[0]["g"].sequences)
     avg_us = 1e3 * prof.icp_ms_total / max(1, prof.icp_launches)
     achieved = (prof.icp_bytes / 1e9) / (prof.icp_ms_total / 1e3) if prof.icp_ms_total > 0 else 0.0
     out = dict(metric="frames/sec at 640x480 (N active models) + ICP-reduce achieved HBM GB/s vs peak", value=round(S * args.steps / dt, 2),
                unit="frames/s (aggregate over the sequences)", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 4),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", input="resident",
-               config=dict(workload=f"{wl['config']}: {wl['desc']}, {W}x{H} synthetic noisy RGB-D -- {S} independent sequences in ONE lock-step group "
-                                    "(one context, one set of tracking launches for the trackers of all sequences)",
-                           sequences=S, active_models=n_models, trackers_per_launch=min(trackers, 16), preroll_frames=P, preroll_masks=pre_masks or "none",
-                           streams_per_gpu=S, parallel="lock-step group"),
+               config=dict(workload=f"{wl['config']}: {wl['desc']}, {W}x{H} synthetic noisy RGB-D -- {S} independent sequences in {G} lock-step group(s) "
+                                    "(per group: one context, one set of tracking launches for the trackers of its sequences)",
+                           sequences=S, groups=G, active_models=n_models, trackers_per_launch=min(trackers, 16), preroll_frames=P, preroll_masks=pre_masks or "none",
+                           streams_per_gpu=S, parallel="lock-step group" if G == 1 else "lock-step groups on their own streams / host threads"),
                roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                             traffic=None, kernel="cf::icp_reduce_kernel<PPT,4>: level-0 launch with the trackers of all sequences",
+                             traffic=None, kernel="cf::icp_reduce_kernel<PPT,4>: level-0 launch with the trackers of all sequences of the first group",
                              launches=int(prof.icp_launches), avg_us=round(avg_us, 3), bytes_per_launch=int(prof.icp_bytes / max(1, prof.icp_launches)),
                              bytes_per_pixel="counted as 24 + (24 + 11) * trackers, i.e. the current-frame planes ONCE although the sequences do not share them (an undercount)"))
     print(json.dumps(out))
-    g.close()
+    for gr in groups:
+        gr["g"].close()
     return out
 
 
