@@ -95,6 +95,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work per CPU-baseline leg")
     ap.add_argument("--icp-threads", type=int, default=256)
     ap.add_argument("--icp-ppt", type=int, default=0, help="pixels per lane of the ICP reduction (0: library default)")
+    ap.add_argument("--icp-arith", default=None, choices=["product", "gram"],
+                    help="rounding specification of the ICP sums (cf_set_icp_arith; default: the library's): products rounded once / row entries "
+                         "rounded once and contracted on the matrix cores; the oracle legs follow")
     ap.add_argument("--gn-mode", type=int, default=-1, help="-1: library default; 0: three launches per GN iteration; 1: two")
     ap.add_argument("--max-surfels", type=int, default=None)
     ap.add_argument("--enqueue-threads", type=int, default=None, help="host threads enqueueing the per-model surfel passes (library default: 0)")
@@ -121,6 +124,10 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=1, help="independent RGB-D streams per GPU (own context + HIP stream + host thread each); "
                     "1 = the headline single-sequence figure, >1 = throughput mode")
     a = ap.parse_args(argv)
+    if a.icp_arith:
+        os.environ["CF_ICP_ARITH"] = a.icp_arith   # read by every context this process creates (cf_create)
+    else:
+        a.icp_arith = {"1": "gram", "gram": "gram"}.get(os.environ.get("CF_ICP_ARITH", ""), "product")
     if a.workload is None:
         a.workload = "objects4"   # the metric's configuration at EVERY number of GPUs: the per-N values form one curve
     wl = WORKLOADS[a.workload]
@@ -407,7 +414,7 @@ def main(argv=None):
                                              "ground-truth masks" if use_gt else
                                              "SLIC + exact O(K^2) dense-CRF mean field as specified by oracle/orc_segment.c (gSLICr / densecrf are not in "
                                              "the reference tree: parity of this stage is against the oracle only)"),
-                               icp_launch=[args.icp_threads, args.icp_ppt], gn_mode=args.gn_mode,
+                               icp_launch=[args.icp_threads, args.icp_ppt], icp_arith=args.icp_arith, gn_mode=args.gn_mode,
                                streams_per_gpu=S, parallel=args.parallel if world > 1 else "single",
                                collectives=("library RCCL communicator (ncclBroadcast + ncclAllReduce in place on the context's stream)" if use_rccl
                                             else "torch.distributed callbacks" if model_parallel else "none"),
@@ -587,6 +594,8 @@ def oracle_trajectory_check(cam, frames, torch, facade, local_rank, args, n_fram
     trajectories of the camera and of every model must be identical (ATE 0, same bits)."""
     W, H = args.width, args.height
     multi = WORKLOADS[args.workload]["n_obj"] > 0
+    import orc
+    orc.set_icp_arith(args.icp_arith)
     if multi:
         import orc_multi as om
         ref = om.MultiPipeline(cam, conf_global=0.5, spawn_offset=2)
@@ -689,6 +698,7 @@ def cpu_baseline(cf, cam, frames, i0, step_stream, st, budget_s):
     os.environ["ORC_LIB"] = native_oracle()
     import orc
     import orc_pipeline as op
+    orc.set_icp_arith("gram" if os.environ.get("CF_ICP_ARITH") in ("gram", "1") else "product")   # (the rounding specification the GPU legs ran with)
     n = len(frames)
     ncpu = orc.usable_cpus()   # affinity mask and cgroup quota, not the number of CPUs the box shows
     omp = ctypes.CDLL("libgomp.so.1")

@@ -261,6 +261,10 @@ class Context:
     def set_icp_launch(self, threads, ppt):
         self._check(self.lib.cf_set_icp_launch(self.h, threads, ppt))
 
+    def set_icp_arith(self, mode):
+        """rounding specification of the ICP sums: 0 / "product" (default) or 1 / "gram" (include/cofusion_hip.h: cf_set_icp_arith)"""
+        self._check(self.lib.cf_set_icp_arith(self.h, {"product": 0, "gram": 1}.get(mode, mode)))
+
     def profile_enable(self, on=True):
         self._check(self.lib.cf_profile_enable(self.h, int(on)))
 

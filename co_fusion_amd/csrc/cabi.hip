@@ -52,7 +52,7 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     HIPCHK(ctx, hipSetDevice(cfg->device));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    ctx->icp_launch = IcpLaunch{256, 1};
+    ctx->icp_launch = IcpLaunch{256, 1, 0};
     if (int r = dmalloc(ctx, &ctx->d_acc_a, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &ctx->d_acc_b, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &ctx->d_out, 64)) return r;
@@ -69,6 +69,11 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     if (const char* e = getenv("CF_ICP_LAUNCH")) {  // diagnostic: "threads,pixels_per_thread"
         int t = 0, p = 0;
         if (sscanf(e, "%d,%d", &t, &p) == 2 && cf_set_icp_launch(ctx, t, p) != CF_OK) { ctx->set_error("CF_ICP_LAUNCH: bad value"); return CF_EINVAL; }
+    }
+    if (const char* e = getenv("CF_ICP_ARITH")) {  // "product" (default) / "gram": rounding specification of the ICP sums (cf_set_icp_arith)
+        if (cf_set_icp_arith(ctx, (!strcmp(e, "gram") || !strcmp(e, "1")) ? CF_ICP_ARITH_GRAM : (!strcmp(e, "product") || !strcmp(e, "0")) ? CF_ICP_ARITH_PRODUCT : -1) != CF_OK) {
+            ctx->set_error("CF_ICP_ARITH: product | gram"); return CF_EINVAL;
+        }
     }
     if (int r = dmalloc(ctx, &ctx->d_cand_scratch, (size_t)cfg->width * cfg->height)) return r;
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scratch_state), sizeof(OdomDev)));
@@ -304,9 +309,17 @@ int cf_set_icp_launch(cf_ctx* ctx, int threads, int ppt)
     if (!ctx || (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024) ||
         (ppt != 1 && ppt != 2 && ppt != 4))
         return CF_EINVAL;
-    ctx->icp_launch = IcpLaunch{threads, ppt};
+    ctx->icp_launch = IcpLaunch{threads, ppt, ctx->icp_launch.gram};
     return CF_OK;
 }
+
+int cf_set_icp_arith(cf_ctx* ctx, int mode)
+{
+    if (!ctx || (mode != CF_ICP_ARITH_PRODUCT && mode != CF_ICP_ARITH_GRAM)) return CF_EINVAL;
+    ctx->icp_launch.gram = mode;
+    return CF_OK;
+}
+int cf_get_icp_arith(cf_ctx* ctx) { return ctx ? ctx->icp_launch.gram : CF_EINVAL; }
 
 int cf_profile_enable(cf_ctx* ctx, int on) { if (!ctx || on < 0) return CF_EINVAL; ctx->prof.enabled = on; ctx->prof_calls = 0; return CF_OK; }
 int cf_profile_read(cf_ctx* ctx, cf_profile* out, int reset)
@@ -361,15 +374,15 @@ int cf_depth_pyramid(cf_ctx* ctx, const float* depth_filtered, int cols, int row
 
 // ------------------------------------------------------------ stand-alone reductions ----
 static void se3_unpack_host(const unsigned long long* t, int F, float* A, float* b, float* residual)
-{  // reduce.cu:481-498
+{  // reduce.cu:481-498;  F < 0: the Gram form of the ICP sums, word (i, j) carries kGramBits[i] + kGramBits[j] fraction bits
     int shift = 0;
     for (int i = 0; i < 6; ++i)
         for (int j = i; j < 7; ++j) {
-            const float value = (float)ldexp((double)(long long)t[shift++], -F);
+            const float value = (float)ldexp((double)(long long)t[shift++], -(F >= 0 ? F : kGramBits[i] + kGramBits[j]));
             if (j == 6) { if (b) b[i] = value; }
             else if (A) A[j * 6 + i] = A[i * 6 + j] = value;
         }
-    if (residual) { residual[0] = (float)ldexp((double)(long long)t[27], -F); residual[1] = (float)(long long)t[28]; }
+    if (residual) { residual[0] = (float)ldexp((double)(long long)t[27], -(F >= 0 ? F : 2 * kGramBits[6])); residual[1] = (float)(long long)t[28]; }
 }
 
 // Runs one kernel family on the ctx scratch state (single model, level 0 geometry = cols x rows).
@@ -431,7 +444,7 @@ int cf_icp_step_band(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], co
     launch_icp_level(ctx->stream, ctx->icp_launch, a, 1, 0);
     LAUNCHCHK(ctx);
     if (int r = fetch_totals(ctx, ctx->d_acc_a, 32)) return r;
-    se3_unpack_host(ctx->h_out, CF_FIX_ICP, A_host, b_host, residual_host);
+    se3_unpack_host(ctx->h_out, ctx->icp_launch.gram ? -1 : CF_FIX_ICP, A_host, b_host, residual_host);
     if (sums_host) memcpy(sums_host, ctx->h_out, sizeof(int64_t) * 32);
     return CF_OK;
 }

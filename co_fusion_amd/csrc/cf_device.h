@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "cf_kernels.h"
+
 namespace cf {
 
 constexpr int kFixICP = 32;
@@ -75,12 +77,14 @@ __device__ __forceinline__ float fkey_inv(unsigned k)
 }
 
 // __float2int_rn semantics: round-half-even, saturating, NaN -> 0
+// (v_cvt_i32_f32 saturates out-of-range inputs and turns NaN into 0 by itself; written as the instruction because the C++ conversion is
+//  undefined out of range and the guarded form compiled to three nested exec-mask branches per call)
 __device__ __forceinline__ int f2i_rn(float v)
 {
-    if (v != v) return 0;
-    if (v >= 2147483648.0f) return 2147483647;
-    if (v <= -2147483648.0f) return (-2147483647 - 1);
-    return (int)rintf(v);
+    int r;
+    const float t = rintf(v);
+    asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(t));
+    return r;
 }
 
 // ---- exact fixed-point accumulation --------------------------------------------
@@ -198,6 +202,111 @@ __device__ __forceinline__ unsigned long long wave_reduce16_u64(const unsigned l
     add64(a, b, dpp_u32<kDppXor2>(lo[0]), dpp_u32<kDppXor2>(hi[0]));
     add64(a, b, dpp_u32<kDppXor1>(a), dpp_u32<kDppXor1>(b));
     return ((unsigned long long)b << 32) | a;
+}
+
+// ---- Gram form of the ICP sums (cf_set_icp_arith 1; oracle: ORC_ICP_ARITH_GRAM) -------------------------------------------
+// Every row ENTRY is rounded once to a fixed-point grid: q_i = RNE(clamp(row_i, +-kGramLim[i]) * 2^kGramBits[i]), |q_i| <= 2^22;
+// entry 7 is 1 for a found correspondence.  The 29 words are entries of the Gram matrix sum_pixels q q^T of that integer matrix,
+// which is a dense contraction over the pixels: each q_i is split into three balanced signed 8-bit limbs (q = d0 + 2^8 d1 + 2^16 d2,
+// -128 <= d <= 127), the 64 pixels of a wave are the K dimension of v_mfma_i32_32x32x32_i8 on the 32 x 64 limb matrix (row 4i + a =
+// limb a of entry i, a = 3 unused) against ITSELF; the int32 tiles of a workgroup's waves are added through LDS and the 9 limb products
+// of an entry pair are recombined with shifts ONCE PER WORKGROUP (gram_block_commit), then 29 64-bit atomics as in the product form.
+// Exact: int8 x int8 products in int32 accumulators (at most 2^14 * 4096 pixels per workgroup), 64-bit recombination.
+// (kGramBits: cf_kernels.h -- the host unpack needs it too)
+constexpr float kGramLim[7] = {4.f, 4.f, 4.f, 32.f, 32.f, 32.f, 1.f};
+constexpr int kGramRowStride = 68;                       // dwords per limb-matrix row in LDS (64 pixels + pad: the 8 rows start in different banks)
+constexpr int kGramWaveDwords = 12 * 64;                 // one wave's staging area: 8 rows of limbs, afterwards its 12 x 64 partial products
+typedef int gram_v4i __attribute__((ext_vector_type(4)));
+typedef int gram_v16i __attribute__((ext_vector_type(16)));
+
+// balanced signed limbs of q (|q| <= 0x7f7f7f): byte k of the result, read as int8, is d_k
+__device__ __forceinline__ unsigned gram_limbs(int q) { return ((unsigned)q + 0x00808080u) ^ 0x00808080u; }
+
+// word of the 32-word accumulator layout (se3_unpack) that lane `lane` of a wave holds after gram_wave_finish, or -1
+__device__ __forceinline__ int gram_word_of_lane(int lane)
+{
+    const int i = 2 * (lane & 3) + (lane >> 5), j = (lane & 31) >> 2;
+    if (i <= 5 && j >= i && j <= 6) return 7 * i - (i * (i - 1)) / 2 + (j - i);
+    if (i == 6 && j == 6) return 27;
+    if (i == 7 && j == 7) return 28;
+    return -1;
+}
+
+// One K = 64 step: the wave's 64 pixels (8 limb dwords each, already in `wl`: wl[i * kGramRowStride + pixel]) times themselves.
+// Lane l feeds limb-matrix row l & 31 (entry (l & 31) >> 2, limb l & 3) for the 16 pixels 32 s + 16 (l >> 5) + t of step s as A AND as B:
+// the order of the pixels inside K does not matter for a Gram matrix, only that A and B agree.
+__device__ __forceinline__ gram_v16i gram_wave_mfma(const int* wl, int lane, gram_v16i acc)
+{
+    const unsigned a = (unsigned)lane & 3u;
+    const unsigned selLo = a | ((4u + a) << 8) | 0x0c0c0000u;          // v_perm_b32: bytes 0-3 = second source, 4-7 = first, 0x0c = zero
+    const unsigned selHi = 0x00000c0cu | (a << 16) | ((4u + a) << 24);
+    const int* src = wl + ((lane & 31) >> 2) * kGramRowStride + 16 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        gram_v4i x[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) x[c] = *reinterpret_cast<const gram_v4i*>(src + 32 * s + 4 * c);
+        gram_v4i f;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            f[c] = (int)(__builtin_amdgcn_perm((unsigned)x[c][1], (unsigned)x[c][0], selLo) | __builtin_amdgcn_perm((unsigned)x[c][3], (unsigned)x[c][2], selHi));
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f, f, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// acc (C/D layout of the 32x32 shapes: column l & 31, row (r & 3) + 8 (r >> 2) + 4 (l >> 5)) -> the 64-bit Gram entries.  Register
+// r = 4 g + a2 of lane l is (entry i = 2 g + (l >> 5), limb a2) x (entry j = (l & 31) >> 2, limb b = l & 3): weight 2^(8 (a2 + b)),
+// summed over a2 in the lane and over b across the quad.  Returns the entry of word gram_word_of_lane(lane).
+__device__ __forceinline__ unsigned long long gram_wave_finish(const gram_v16i& acc, int lane)
+{
+    const int b8 = 8 * (lane & 3);
+    unsigned rlo = 0, rhi = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        long long P = (long long)acc[4 * g] + ((long long)acc[4 * g + 1] << 8) + ((long long)acc[4 * g + 2] << 16);
+        P <<= b8;
+        unsigned lo = (unsigned)P, hi = (unsigned)((unsigned long long)P >> 32);
+        add64(lo, hi, dpp_u32<kDppXor1>(lo), dpp_u32<kDppXor1>(hi));
+        add64(lo, hi, dpp_u32<kDppXor2>(lo), dpp_u32<kDppXor2>(hi));
+        if ((lane & 3) == g) { rlo = lo; rhi = hi; }
+    }
+    return ((unsigned long long)rhi << 32) | rlo;
+}
+
+// Workgroup commit of the Gram form: every wave that found correspondences has left the 12 used registers of its tile in its staging
+// area (gram_wave_store); wave 0 adds the tiles, recombines the limbs and issues the atomics.  Called by all threads of the workgroup.
+__device__ __forceinline__ void gram_wave_store(int* wl, const gram_v16i& acc, int lane)
+{
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) wl[(3 * g + a) * 64 + lane] = acc[4 * g + a];
+}
+__device__ __forceinline__ void gram_block_commit(const int* lds, bool has, int lane, int wave, int nwaves,
+                                                  unsigned long long* __restrict__ dst /* [32] of this group */)
+{
+    __shared__ int s_has[16];
+    if (lane == 0) s_has[wave] = has ? 1 : 0;
+    __syncthreads();
+    if (wave != 0) return;
+    gram_v16i c;
+#pragma unroll
+    for (int r = 0; r < 16; r++) c[r] = 0;
+    bool any = false;
+    for (int w = 0; w < nwaves; w++) {
+        if (!s_has[w]) continue;
+        any = true;
+        const int* src = lds + w * kGramWaveDwords + lane;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) c[4 * g + a] += src[(3 * g + a) * 64];
+    }
+    if (!any) return;
+    const unsigned long long v = gram_wave_finish(c, lane);
+    const int word = gram_word_of_lane(lane);
+    if (word >= 0 && v != 0) atomicAdd(&dst[word], v);
 }
 
 // ---- deterministic f64 sin/cos (same spec as oracle/orc_math.h: orc_sincos) ------

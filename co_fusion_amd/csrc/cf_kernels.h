@@ -112,7 +112,20 @@ void launch_rgbd_pyramids(hipStream_t s, const RgbdBatch& b, int n_chains, int W
 void launch_rgb_prep(hipStream_t s, RgbPrepBatch b, int n, int W, int H);
 
 // ---- reduction launchers (track_reduce.hip) ----
-struct IcpLaunch { int threads; int ppt; };  // threads per workgroup, pixels per thread
+// Division of a pixel index by the image width without the ~25-instruction integer-division sequence: for 0 <= n < 2^31 and d >= 2,
+// n / d == umulhi(n, M) >> s with M = ceil(2^(31 + l) / d), s = l - 1, l = ceil(log2 d) (M * d - 2^(31+l) < d <= 2^l, so the error term
+// n * (M d - 2^(31+l)) stays below 2^(31+l)).  Filled by the launchers from `cols`.
+struct IDiv { unsigned M, s; };
+inline IDiv make_idiv(int d)
+{
+    if (d < 2) return IDiv{0x80000000u, 0u};  // (d == 1 would need n itself; no image is one pixel wide -- gives n / 2, asserted against in the launchers)
+    unsigned l = 0;
+    while ((1u << l) < (unsigned)d) l++;
+    return IDiv{(unsigned)((((unsigned long long)1 << (31 + l)) + (unsigned)d - 1) / (unsigned)d), l - 1};
+}
+// Gram form of the ICP sums (cf_set_icp_arith 1, cf_device.h): fraction bits of the fixed-point grid of row entry i (7 = the inlier flag)
+constexpr int kGramBits[8] = {20, 20, 20, 17, 17, 17, 22, 0};
+struct IcpLaunch { int threads; int ppt; int gram; };  // threads per workgroup, pixels per thread, rounding specification of the sums (cf_set_icp_arith)
 
 // stand-alone steps (C-ABI parity with icpStep / computeRgbResidual / rgbStep / so3Step) run the same
 // kernels on a scratch OdomDev prepared by cabi.cpp.
@@ -138,6 +151,7 @@ struct GnArgs {
     unsigned long long* icp_acc[kMaxBatch];
     unsigned long long* rgb_acc[kMaxBatch];
     OdomDev* od_host[kMaxBatch];   // nullable: pinned host copies of the states; the LAST solve of a schedule publishes its result there
+    int icp_gram;                  // rounding specification of the ICP sums (IcpLaunch::gram): selects the scales of the unpack
 };
 // RGB residual / RGB step arguments (by value): everything but the pose-dependent state arrives in the kernarg
 struct RgbModelArgs {
@@ -158,6 +172,7 @@ struct RgbArgs {
     float sobelScale, maxDepthDelta;
     int compact;                        // residual pass writes record slots (recs) instead of the DataTerm image
     int slot_px;                        // pixels (= record capacity) per slot: 4 x the producer's workgroup size
+    IDiv cdiv;                          // make_idiv(cols), set by the launchers
 };
 inline RgbModelArgs rgb_model_args(const OdomDev* h /* host mirror */, OdomDev* d_state, int level)
 {
@@ -175,6 +190,7 @@ struct IcpArgs {
     int occ_w, occ_shift;               // occupancy row length (level-0 cols / 4) and 2 - level
     int flags;                          // bit0: write the error surface
     int row_begin, row_end;             // row band to reduce; row_end == 0: all rows
+    IDiv cdiv;                          // make_idiv(cols), set by the launchers
 };
 void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void launch_rgb_residual(hipStream_t s, const RgbArgs& ra, int n);

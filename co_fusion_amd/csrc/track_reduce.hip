@@ -27,6 +27,8 @@ __device__ __forceinline__ cf_cam cam_level(cf_cam c, int level)
     return cf_cam{c.fx / div, c.fy / div, c.cx / div, c.cy / div};
 }
 
+__device__ __forceinline__ int idiv(int n, IDiv d) { return (int)(__umulhi((unsigned)n, d.M) >> d.s); }  // n / cols, cf_kernels.h: make_idiv
+
 __device__ __forceinline__ float clamp_row(float v, float lim) { return fminf(fmaxf(v, -lim), lim); }
 
 // acc[k] += RNE(row_i*row_j*2^F) for the 27 upper-triangular SE3 products + residual
@@ -89,7 +91,7 @@ __device__ __forceinline__ void block_commit32(unsigned long long v, int lane, i
 // sine < angleThres, dist <= distThres).  sqrtf is correctly rounded and monotonic, so each gate is decided
 // exactly by comparing the radicand with a precomputed f32 bound (IcpArgs::angleSqLt / distSqLe, sqrt_gate_* below):
 // no square root per pixel unless the error surface (which stores dist itself) is requested.
-struct IcpProj { f3 vcurr_g; int g; int inb; };
+struct IcpProj { f3 vcurr_g; int g; int inb; int ux, uy; };
 
 __device__ __forceinline__ IcpProj icp_project(const m33& Rcurr, const f3& tcurr, const m33& Rprev_inv, const f3& tprev, const cf_cam& intr,
                                                int cols, int rows, f3 vcurr)
@@ -101,6 +103,7 @@ __device__ __forceinline__ IcpProj icp_project(const m33& Rcurr, const f3& tcurr
     const int uy = f2i_rn(vcurr_cp.y * intr.fy / vcurr_cp.z + intr.cy);
     o.inb = !(ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0);
     o.g = o.inb ? uy * cols + ux : 0;
+    o.ux = o.inb ? ux : 0; o.uy = o.inb ? uy : 0;
     return o;
 }
 
@@ -183,7 +186,12 @@ template <bool COMPACT> __device__ void rgb_residual_body(const RgbArgs& ra, int
 // 32 x u64 butterfly; a wave whose pixels cannot produce a correspondence (projection out of view, model map empty
 // there -- the common case for object models, which cover a small part of the image) leaves after the projection.
 static_assert(sizeof(IcpArgs) + sizeof(RgbArgs) + 16 <= 4096, "the kernel-argument segment holds 4 KB: lower kMaxBatch");
-template <int PPT, int LEVEL_TAG>
+//
+// GRAM (cf_set_icp_arith 1): the accumulation and the butterfly are replaced by the matrix cores -- the rows are rounded to integers,
+// staged through LDS as signed 8-bit limbs and contracted over the wave's pixels by v_mfma_i32_32x32x32_i8 (cf_device.h: gram_*);
+// dynamic LDS = kGramWaveDwords * 4 bytes per wave (gram_block_commit adds the waves' tiles and recombines the limbs).  A different rounding specification (ORC_ICP_ARITH_GRAM in the oracle).
+extern __shared__ int gram_lds[];
+template <int PPT, int LEVEL_TAG, bool GRAM>
 __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, const RgbArgs ra, int n_icp_blocks)
 {
     // (Measured and dropped, round 3: dispatching the residual workgroups of all models before the mostly culled ICP workgroups of
@@ -208,7 +216,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     // reads all of it -- while only the band's pixels enter the sums
     const bool whole = (args.flags & 1) && ma.err != nullptr && ma.row_end > 0;
     const int pix0 = whole ? 0 : band0, pix1 = whole ? N : band1;
-    const int nlog = (pix1 - pix0 + T * PPT - 1) / (T * PPT);
+    const int nlog = (pix1 - pix0 + T * PPT - 1) >> __builtin_ctz(T * PPT);  // (workgroup sizes are powers of two: cf_set_icp_launch)
     // (the grid is sized for the whole image; a model with a row band has fewer logical blocks, and the XCD interleave below is a
     // bijection only on the first 8 * ceil(nlog / 8) hardware blocks)
     if ((bx >> 3) >= ((nlog + 7) >> 3)) return;
@@ -237,11 +245,11 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
         const int L = 2 - args.occ_shift;
         const int bx0 = (st->stats.cull_box[0] >> L) - 1, by0 = (st->stats.cull_box[1] >> L) - 1, bx1 = (st->stats.cull_box[2] >> L) + 1, by1 = (st->stats.cull_box[3] >> L) + 1;
         const int p0 = pix0 + lb * T * PPT, p1 = min(p0 + T * PPT, pix1) - 1;  // first / last pixel of this workgroup
-        const int r0 = p0 / cols, r1 = p1 / cols;
+        const int r0 = idiv(p0, args.cdiv), r1 = idiv(p1, args.cdiv);
         if (r1 < by0 || r0 > by1) return;
         if (r0 == r1 && (p1 - r0 * cols < bx0 || p0 - r0 * cols > bx1)) return;
         const int w0 = p0 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * 64 * PPT, w1 = min(w0 + 64 * PPT, pix1) - 1;
-        const int q0 = w0 / cols, q1 = w1 / cols;
+        const int q0 = idiv(w0, args.cdiv), q1 = idiv(max(w1, 0), args.cdiv);
         if ((args.flags >> 8) & 512) return;  // timing ablation (CF_ICP_REPLAY): the cull test alone
         if (w0 > w1 || q1 < by0 || q0 > by1 || (q0 == q1 && (w1 - q0 * cols < bx0 || w0 - q0 * cols > bx1))) in_range = false;
         // ... and by depth: the run of 64 pixels this wave owns (per pixel of a lane) carries the interval of its valid depths
@@ -276,7 +284,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     f3 vprev[PPT], nprev[PPT];
     int cand = 0;
 #pragma unroll
-    for (int p = 0; p < PPT; p++) { pr[p].vcurr_g = f3{qnan(), qnan(), qnan()}; pr[p].g = 0; pr[p].inb = 0; vprev[p] = pr[p].vcurr_g; nprev[p] = pr[p].vcurr_g; }
+    for (int p = 0; p < PPT; p++) { pr[p].vcurr_g = f3{qnan(), qnan(), qnan()}; pr[p].g = 0; pr[p].inb = 0; pr[p].ux = pr[p].uy = 0; vprev[p] = pr[p].vcurr_g; nprev[p] = pr[p].vcurr_g; }
     if (__any(in_range))  // (a wave culled by the screen box skips the projection as well)
 #pragma unroll
     for (int p = 0; p < PPT; p++) {
@@ -284,8 +292,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
         if (!in_range) pr[p].inb = 0;
         bool occupied = pr[p].inb != 0;
         if (occupied && ma.occ) {  // the model map is invalid (NaN) everywhere inside an empty 4x4 block: no gather needed
-            const int gy = pr[p].g / cols, gxp = pr[p].g - gy * cols;
-            const int tile = (gy >> args.occ_shift) * args.occ_w + (gxp >> args.occ_shift);
+            const int tile = (pr[p].uy >> args.occ_shift) * args.occ_w + (pr[p].ux >> args.occ_shift);
             occupied = ma.occ[tile] != 0;
         }
         if (occupied) {
@@ -299,6 +306,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long v = 0;
+    bool gram_has = false;
     const bool wave_cand = __any(cand) != 0;
     if (errs) {  // last level-0 iteration: the error surface stores dist for every pixel (0 if not finite / out of view)
 #pragma unroll
@@ -336,6 +344,26 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
                 row[p][6] = dot(n_cp, s_cp - d_cp);
             }
         }
+        if constexpr (GRAM) {
+            if (__any(any_found) || abl) {
+                int* wl = gram_lds + wave * kGramWaveDwords;
+                gram_v16i macc;
+#pragma unroll
+                for (int r = 0; r < 16; r++) macc[r] = 0;
+#pragma unroll
+                for (int p = 0; p < PPT; p++) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++)
+                        wl[k * kGramRowStride + lane] = (int)gram_limbs((int)rintf(clamp_row(row[p][k], kGramLim[k]) * (float)(1 << kGramBits[k])));
+                    wl[7 * kGramRowStride + lane] = (int)gram_limbs(fnd[p]);
+                    __builtin_amdgcn_wave_barrier();   // (one wave, LDS in program order: the reads below see every lane's dwords)
+                    macc = gram_wave_mfma(wl, lane, macc);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                gram_wave_store(wl, macc, lane);   // (after the last read of the staging area; LDS runs in program order)
+                gram_has = true;
+            }
+        } else
         if (__any(any_found) || abl) {
             unsigned long long acc[32];
 #pragma unroll
@@ -352,7 +380,8 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
             if (abl & 4) { if (v == 0x1234567ull) ma.acc[lane] = v; return; }
         }
     }
-    block_commit32<16>(v, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
+    if constexpr (GRAM) gram_block_commit(gram_lds, gram_has, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
+    else block_commit32<16>(v, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
 }
 
 // host side: the f32 bounds that decide "sqrtf(x) < T" and "sqrtf(x) <= T" exactly (sqrtf is correctly rounded, monotonic)
@@ -407,7 +436,7 @@ __device__ __forceinline__ bool rgb_residual_pixel(const RgbArgs& ra, const RgbM
                                                    const float* __restrict__ kt, int k, float d1, float ni, int& u0, int& v0, float& diff)
 {
     const int cols = ra.cols, rows = ra.rows;
-    const int y = k / cols, x = k - y * cols;
+    const int y = idiv(k, ra.cdiv), x = k - y * cols;
     const float transformed_d1 = (float)(d1 * (krk[6] * x + krk[7] * y + krk[8]) + kt[2]);
     u0 = f2i_rn((d1 * (krk[0] * x + krk[1] * y + krk[2]) + kt[0]) / transformed_d1);
     v0 = f2i_rn((d1 * (krk[3] * x + krk[4] * y + krk[5]) + kt[1]) / transformed_d1);
@@ -445,7 +474,7 @@ __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
             if (m.cand[k]) {
                 int u0, v0; float diff;
                 if (rgb_residual_pixel(ra, m, od->krkInv, od->kt, k, m.nextDepth[k], (float)m.nextImage[k], u0, v0, diff)) {
-                    const int y = k / cols, x = k - y * cols;
+                    const int y = idiv(k, ra.cdiv), x = k - y * cols;
                     c.zero_x = (int16_t)u0; c.zero_y = (int16_t)v0; c.one_x = (int16_t)x; c.one_y = (int16_t)y;
                     c.diff = diff; c.valid = 1;
                     cnt = 1; sig = (int)(diff * diff);
@@ -887,20 +916,23 @@ __device__ inline void se3_unpack(const unsigned long long* t, int F, float A[36
 }
 
 // one word of se3_unpack: t < 27 -> A / b entry, 27 -> sum of squared residuals, 28 -> inlier count
+// F < 0: the Gram form of the ICP sums (cf_device.h: word (i, j) carries kGramBits[i] + kGramBits[j] fraction bits)
 __device__ __forceinline__ void se3_unpack_word(const unsigned long long* sums, int t, int F, float* A, float* b, float* residual)
 {
     if (t < 27) {
         int i = 0, rem = t;
         while (rem >= 7 - i) { rem -= 7 - i; i++; }
         const int j = i + rem;
-        const float value = fix_to_f32((long long)sums[t], F);
+        const int bits = F >= 0 ? F : (i < 3 ? 20 : 17) + (j < 3 ? 20 : j < 6 ? 17 : 22);
+        const float value = fix_to_f32((long long)sums[t], bits);
         if (j == 6) b[i] = value;
         else A[j * 6 + i] = A[i * 6 + j] = value;
     } else if (residual) {
-        if (t == 27) residual[0] = fix_to_f32((long long)sums[27], F);
+        if (t == 27) residual[0] = fix_to_f32((long long)sums[27], F >= 0 ? F : 44);
         else if (t == 28) residual[1] = (float)(long long)sums[28];
     }
 }
+static_assert(kGramBits[0] == 20 && kGramBits[2] == 20 && kGramBits[3] == 17 && kGramBits[5] == 17 && kGramBits[6] == 22, "se3_unpack_word spells the Gram scales out");
 
 // The solve is latency-bound serial work (f64 LDL^T, Rodrigues, SE3 products) on a nearly idle GPU, so:
 //  * the whole device-resident state is staged through LDS (no dependent global round trips),
@@ -909,7 +941,7 @@ __device__ __forceinline__ void se3_unpack_word(const unsigned long long* sums, 
 //    one wave (ldlt_solve6_wave), and K^-1 of the next level is formed by another wave meanwhile,
 //  * only Rodrigues and the 3x3 pose composition stay on one lane.
 // Must be called by all 256 threads of a workgroup.
-__device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* icp_acc, unsigned long long* rgb_acc, int next_level,
+__device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigned long long* icp_acc, unsigned long long* rgb_acc, int next_level,
                                               int last_of_level, OdomDev* god_host)
 {
     __shared__ OdomDev s_od;
@@ -959,7 +991,7 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
     }
     const bool useIcp = od->icp != 0, useRgb = od->rgb != 0;
     if (active) {
-        if (tid < 29 && useIcp) se3_unpack_word(s_icp, tid, kFixICP, s_Af[0], s_bf[0], od->residual);
+        if (tid < 29 && useIcp) se3_unpack_word(s_icp, tid, icp_fix, s_Af[0], s_bf[0], od->residual);
         if (tid >= 32 && tid < 59 && useRgb) se3_unpack_word(s_rgb, tid - 32, rgb_fix_bits(sigma_val_from(rgbCount, (int)(long long)s_icp[30], od->rgbOnly)), s_Af[1], s_bf[1], nullptr);
     }
     __syncthreads();
@@ -1070,7 +1102,7 @@ __device__ __forceinline__ void gn_solve_body(OdomDev* god, unsigned long long* 
 
 __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int next_level, int last_of_level)
 {
-    gn_solve_body(args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level, args.od_host[blockIdx.x]);
+    gn_solve_body(args.icp_gram ? -1 : kFixICP, args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level, args.od_host[blockIdx.x]);
 }
 
 // RGB step over the per-workgroup record slots the residual pass left (grid: one workgroup per slot x models).  A slot holds at
@@ -1133,28 +1165,38 @@ __global__ void __launch_bounds__(64) acc_total_kernel(const unsigned long long*
 // ------------------------------------------------------------------------------ launchers ----
 // ev0/ev1 (nullable) receive the dispatch's own begin/end timestamps (the figures rocprofv3 reports), not the
 // stream time around it.  n_res_blocks > 0 appends the RGB residual workgroups to the same launch.
-template <int TAG>
-static void launch_icp_kernel(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, const RgbArgs& ra, bool icp, int n_res_blocks, int n,
-                              hipEvent_t ev0, hipEvent_t ev1)
+template <int TAG, bool GRAM>
+static void launch_icp_kernel_arith(hipStream_t s, IcpLaunch cfg, const IcpArgs& args_in, const RgbArgs& ra_in, bool icp, int n_res_blocks, int n,
+                                    hipEvent_t ev0, hipEvent_t ev1)
 {
+    IcpArgs args = args_in; args.cdiv = make_idiv(args.cols);
+    RgbArgs ra = ra_in; ra.cdiv = make_idiv(ra.cols);
     const int N = ((args.row_end > 0 ? args.row_end : args.rows) - args.row_begin) * args.cols;
     const int per_block = cfg.threads * cfg.ppt;
     const int nlog = (N + per_block - 1) / per_block;
     const int n_icp_blocks = icp ? ((nlog + 7) / 8) * 8 : 0;
     const dim3 grid(n_icp_blocks + n_res_blocks, n);
+    const unsigned lds = GRAM ? (unsigned)(cfg.threads / 64) * kGramWaveDwords * sizeof(int) : 0u;
     if (!ev0 && !ev1) {  // plain launches (also what a stream capture records)
         switch (cfg.ppt) {
-            case 4: icp_reduce_kernel<4, TAG><<<grid, dim3(cfg.threads), 0, s>>>(args, ra, n_icp_blocks); break;
-            case 2: icp_reduce_kernel<2, TAG><<<grid, dim3(cfg.threads), 0, s>>>(args, ra, n_icp_blocks); break;
-            default: icp_reduce_kernel<1, TAG><<<grid, dim3(cfg.threads), 0, s>>>(args, ra, n_icp_blocks); break;
+            case 4: icp_reduce_kernel<4, TAG, GRAM><<<grid, dim3(cfg.threads), lds, s>>>(args, ra, n_icp_blocks); break;
+            case 2: icp_reduce_kernel<2, TAG, GRAM><<<grid, dim3(cfg.threads), lds, s>>>(args, ra, n_icp_blocks); break;
+            default: icp_reduce_kernel<1, TAG, GRAM><<<grid, dim3(cfg.threads), lds, s>>>(args, ra, n_icp_blocks); break;
         }
         return;
     }
     switch (cfg.ppt) {
-        case 4: hipExtLaunchKernelGGL((icp_reduce_kernel<4, TAG>), grid, dim3(cfg.threads), 0, s, ev0, ev1, 0, args, ra, n_icp_blocks); break;
-        case 2: hipExtLaunchKernelGGL((icp_reduce_kernel<2, TAG>), grid, dim3(cfg.threads), 0, s, ev0, ev1, 0, args, ra, n_icp_blocks); break;
-        default: hipExtLaunchKernelGGL((icp_reduce_kernel<1, TAG>), grid, dim3(cfg.threads), 0, s, ev0, ev1, 0, args, ra, n_icp_blocks); break;
+        case 4: hipExtLaunchKernelGGL((icp_reduce_kernel<4, TAG, GRAM>), grid, dim3(cfg.threads), lds, s, ev0, ev1, 0, args, ra, n_icp_blocks); break;
+        case 2: hipExtLaunchKernelGGL((icp_reduce_kernel<2, TAG, GRAM>), grid, dim3(cfg.threads), lds, s, ev0, ev1, 0, args, ra, n_icp_blocks); break;
+        default: hipExtLaunchKernelGGL((icp_reduce_kernel<1, TAG, GRAM>), grid, dim3(cfg.threads), lds, s, ev0, ev1, 0, args, ra, n_icp_blocks); break;
     }
+}
+template <int TAG>
+static void launch_icp_kernel(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, const RgbArgs& ra, bool icp, int n_res_blocks, int n,
+                              hipEvent_t ev0, hipEvent_t ev1)
+{
+    if (cfg.gram) launch_icp_kernel_arith<TAG, true>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
+    else launch_icp_kernel_arith<TAG, false>(s, cfg, args, ra, icp, n_res_blocks, n, ev0, ev1);
 }
 
 static void launch_icp_rgbres(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, const RgbArgs& ra, bool icp, bool rgb, int n, int level,
@@ -1202,6 +1244,7 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
     while (first_level > 0 && iterations[first_level] == 0) first_level--;
     so3_prealign_kernel<<<dim3(so3 ? kSo3Blocks : 1, n), 256, 0, s>>>(d_models, so3_syncs, so3 ? 1 : 0, first_level, so3 ? nullptr : d_pre);
     GnArgs gn{};
+    gn.icp_gram = cfg.gram;
     for (int m = 0; m < n; m++) {
         gn.od[m] = const_cast<OdomDev*>(icp_args[0].m[m].st);
         gn.icp_acc[m] = icp_args[0].m[m].acc;
@@ -1274,7 +1317,7 @@ void launch_so3_frame(hipStream_t s, OdomDev* const* d_model /* device array of 
 void launch_rgb_residual(hipStream_t s, const RgbArgs& ra, int n)
 {
     const int N = ra.cols * ra.rows;
-    RgbArgs a = ra; a.compact = 0;
+    RgbArgs a = ra; a.compact = 0; a.cdiv = make_idiv(a.cols);
     rgb_residual_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(a);
 }
 void launch_rgb_step(hipStream_t s, const RgbArgs& ra, int n)

@@ -27,7 +27,7 @@ SYMBOLS = [
     "cf_model_fuse", "cf_model_clean", "cf_model_download_map", "cf_model_upload_map", "cf_model_buffer",
     "cf_fusion_weight", "cf_seg_create", "cf_seg_destroy", "cf_seg_slic", "cf_seg_accumulate", "cf_seg_crf", "cf_seg_upsample", "cf_seg_sums", "cf_seg_infer", "cf_seg_fetch", "cf_seg_publish_poses", "cf_seg_fetch_poses",
     "cf_seg_labels",
-    "cf_depth_pyramid", "cf_set_icp_launch", "cf_set_gn_mode", "cf_profile_enable", "cf_profile_read", "cf_odom_bench_icp",
+    "cf_depth_pyramid", "cf_set_icp_launch", "cf_set_icp_arith", "cf_get_icp_arith", "cf_set_gn_mode", "cf_profile_enable", "cf_profile_read", "cf_odom_bench_icp",
     "cf_rccl_unique_id", "cf_rccl_init", "cf_rccl_allreduce", "cf_rccl_broadcast", "cf_rccl_info", "cf_rccl_destroy",
 ]
 

@@ -408,6 +408,17 @@ int cf_seg_labels(cf_segmenter *s, void **dptr, uint64_t *bytes);
 int cf_set_gn_mode(cf_ctx *ctx, int mode);
 /* launch-shape tuning of the ICP reduction (GPUConfig.h:51-58 in the reference) */
 int cf_set_icp_launch(cf_ctx *ctx, int threads, int pixels_per_thread);
+/* Rounding specification of the ICP normal equations (icpStep's 27 products + residual, reduce.cu:334-394), a property of the context:
+ *   CF_ICP_ARITH_PRODUCT (default): each product row_i*row_j is formed exactly in f64 and rounded once to 2^-CF_FIX_ICP;
+ *   CF_ICP_ARITH_GRAM: each row ENTRY is rounded once to a fixed-point grid (2^-20 normal, 2^-17 moment, 2^-22 residual) and the
+ *     integer products are summed exactly -- the Gram matrix of an integer matrix, contracted over the pixels on the matrix cores
+ *     (signed 8-bit limbs, v_mfma_i32_32x32x32_i8).  Fewer vector instructions per pixel; both forms are exact integer sums
+ *     (independent of launch shape and GPU count) and both have an oracle (oracle/orc.h: orc_set_icp_arith).
+ * The 64-bit sums cf_icp_step returns are in the units of the chosen form.  Also: CF_ICP_ARITH=product|gram in the environment. */
+#define CF_ICP_ARITH_PRODUCT 0
+#define CF_ICP_ARITH_GRAM 1
+int cf_set_icp_arith(cf_ctx *ctx, int mode);
+int cf_get_icp_arith(cf_ctx *ctx);
 
 /* micro-benchmark of the ICP reduction on the state of the last tracking call (level 0..2) */
 int cf_odom_bench_icp(cf_odom *od, int level, int iters, float *avg_us);

@@ -46,6 +46,18 @@ extern "C" {
 #define ORC_FIX_RGB 32 /* for sigma >= 4096; in general orc_rgb_fix_bits(sigma), see orc_math.h */
 #define ORC_FIX_SO3 12
 
+/* Rounding specification of the ICP normal equations (the RGB and SO3 sums always use the first):
+ *   ORC_ICP_ARITH_PRODUCT (default): every product row_i*row_j is formed exactly and rounded ONCE to 2^-32 (orc_fix_prod);
+ *   ORC_ICP_ARITH_GRAM: every row ENTRY is rounded once to a fixed-point grid (orc_gram_quant: 2^-20 for the normal,
+ *     2^-17 for the moment, 2^-22 for the residual) and the products of those integers are summed exactly -- the sums are
+ *     the Gram matrix of an integer matrix, which the HIP kernels contract on the matrix cores (signed 8-bit limbs,
+ *     v_mfma_i32_32x32x32_i8; cf_set_icp_arith).
+ * Process-global switch: test infrastructure. */
+#define ORC_ICP_ARITH_PRODUCT 0
+#define ORC_ICP_ARITH_GRAM 1
+void orc_set_icp_arith(int mode);
+int orc_get_icp_arith(void);
+
 typedef struct { float fx, fy, cx, cy; } orc_cam;
 
 /* reference DataTerm, Core/Cuda/types.cuh:75-81 (16 bytes; `valid` is a bool + pad) */
@@ -97,6 +109,8 @@ void orc_rgb_step_f32tree(const orc_dataterm *corres, float sigma, const float *
 void orc_so3_step_f32tree(const uint8_t *last_image, const uint8_t *next_image, const float image_basis[9], const float kinv[9],
                           const float krlr[9], int cols, int rows, int threads, int blocks, float out11[11]);
 void orc_se3_sums_to_host(const int64_t sums[ORC_SE3_WORDS], int F, float A[36], float b[6], float residual[2]);
+/* the ICP sums under the current rounding specification (orc_set_icp_arith): F = ORC_FIX_ICP, or the per-entry scales of the Gram form */
+void orc_icp_sums_to_host(const int64_t sums[ORC_SE3_WORDS], float A[36], float b[6], float residual[2]);
 void orc_so3_sums_to_host(const int64_t sums[ORC_SO3_WORDS], int F, float A[9], float b[3], float residual[2]);
 
 /* ----------------------- RGBDOdometry (Core/Utils/RGBDOdometry.*) ------------- */

@@ -121,6 +121,17 @@ static inline int64_t orc_fix_prod(float a, float b, int F)
 }
 static inline double orc_fix_to_double(int64_t q, int F) { return ldexp((double)q, -F); }
 
+/* Gram form of the ICP sums (ORC_ICP_ARITH_GRAM): row entry i -> integer q_i = RNE(clamp(row_i, +-lim_i) * 2^bits_i), |q_i| <= 2^22
+ * (three signed 8-bit limbs); entry 7 is the constant 1 of a found correspondence, so q_7*q_7 counts the inliers.  Same tables
+ * as cf_device.h (kGramBits / kGramLim). */
+static const int orc_gram_bits[8] = {20, 20, 20, 17, 17, 17, 22, 0};
+static const float orc_gram_lim[7] = {4.0f, 4.0f, 4.0f, 32.0f, 32.0f, 32.0f, 1.0f};
+static inline int32_t orc_gram_quant(float v, int i)
+{
+    const float lim = orc_gram_lim[i];
+    return (int32_t)lrintf(fminf(fmaxf(v, -lim), lim) * ldexpf(1.0f, orc_gram_bits[i]));  /* power-of-two scale: exact; one RNE */
+}
+
 /* Fraction bits of the RGB step's fixed-point sums, chosen from the weight's scale: rgbStep is handed sigma = the
  * correspondence COUNT n (RGBDOdometry.cpp:373-374), so a Jacobian row scales like 1/n; sigma = -1 (rgbOnly, w = 1,
  * reduce.cu:537-540) and sigma = 1 (zero residual) leave the rows unscaled (|row| up to ~2^18).

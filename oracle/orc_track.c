@@ -307,6 +307,37 @@ static void icp_ctx_fill(icp_ctx *c, const float Rcurr[9], const float tcurr[3],
     c->distThres = dist_thres; c->angleThres = angle_thres; c->cols = cols; c->rows = rows;
 }
 
+static int g_icp_arith = ORC_ICP_ARITH_PRODUCT;
+void orc_set_icp_arith(int mode) { g_icp_arith = mode == ORC_ICP_ARITH_GRAM ? ORC_ICP_ARITH_GRAM : ORC_ICP_ARITH_PRODUCT; }
+int orc_get_icp_arith(void) { return g_icp_arith; }
+
+/* ORC_ICP_ARITH_GRAM: the same 29 words as the Gram matrix of the quantised rows (wrapping 64-bit sums like the product form) */
+static void se3_accumulate_gram(const float row[7], int found, int64_t sums[ORC_SE3_WORDS])
+{
+    if (!found) return;
+    int64_t q[7];
+    for (int i = 0; i < 7; i++) q[i] = orc_gram_quant(row[i], i);
+    int k = 0;
+    for (int i = 0; i < 6; i++)
+        for (int j = i; j < 7; j++) sums[k++] += q[i] * q[j];
+    sums[27] += q[6] * q[6];
+    sums[28] += 1;
+}
+
+void orc_icp_sums_to_host(const int64_t sums[ORC_SE3_WORDS], float A[36], float b[6], float residual[2])
+{
+    if (g_icp_arith != ORC_ICP_ARITH_GRAM) { orc_se3_sums_to_host(sums, ORC_FIX_ICP, A, b, residual); return; }
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            float value = (float)orc_fix_to_double(sums[shift++], orc_gram_bits[i] + orc_gram_bits[j]);
+            if (j == 6) b[i] = value;
+            else A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+    residual[0] = (float)orc_fix_to_double(sums[27], 2 * orc_gram_bits[6]);
+    residual[1] = (float)sums[28];
+}
+
 static void se3_accumulate(const float row[7], int found, int F, int64_t sums[ORC_SE3_WORDS])
 {
     if (!found) return; /* row is all zero: contributes nothing */
@@ -326,6 +357,7 @@ void orc_icp_step(const float Rcurr[9], const float tcurr[3], const float *vmap_
     icp_ctx_fill(&c, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev,
                  dist_thres, angle_thres, cols, rows);
     memset(sums, 0, sizeof(int64_t) * ORC_SE3_WORDS);
+    const int gram = g_icp_arith == ORC_ICP_ARITH_GRAM;
     /* integer sums: the OpenMP reduction is exact and order independent */
 #pragma omp parallel for schedule(static) reduction(+ : sums[:ORC_SE3_WORDS]) if (cols * rows >= ORC_OMP_MIN_PIXELS)
     for (int y = 0; y < rows; y++)
@@ -333,7 +365,8 @@ void orc_icp_step(const float Rcurr[9], const float tcurr[3], const float *vmap_
             float row[7], err;
             int found = icp_row(&c, x, y, row, &err);
             if (err_surface) err_surface[y * cols + x] = err;
-            se3_accumulate(row, found, ORC_FIX_ICP, sums);
+            if (gram) se3_accumulate_gram(row, found, sums);
+            else se3_accumulate(row, found, ORC_FIX_ICP, sums);
         }
 }
 
@@ -865,7 +898,7 @@ void orc_odom_get_incremental_transformation(orc_odometry *o, float trans[3], fl
                 orc_icp_step(Rcurr, tcurr, o->vmaps_curr[i], o->nmaps_curr[i], Rprev_inv, tprev, il, o->vmaps_g_prev[i],
                              o->nmaps_g_prev[i], o->distThres, o->angleThres, cols, rows, sums,
                              (i == 0 && j == iterations[i] - 1) ? icp_err_surface : 0);
-                orc_se3_sums_to_host(sums, ORC_FIX_ICP, A_icp, b_icp, residual);
+                orc_icp_sums_to_host(sums, A_icp, b_icp, residual);
             }
             st->last_icp_error = sqrtf(residual[0]) / residual[1];
             st->last_icp_count = residual[1];

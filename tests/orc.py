@@ -249,6 +249,22 @@ def se3_to_host(sums, F=32):
     return A.reshape(6, 6), b, r
 
 
+def set_icp_arith(mode):
+    """rounding specification of the ICP sums, process-global (oracle/orc.h): 0 / "product" (default) or 1 / "gram" """
+    lib.orc_set_icp_arith({"product": 0, "gram": 1}.get(mode, mode))
+
+
+def get_icp_arith():
+    return int(lib.orc_get_icp_arith())
+
+
+def icp_sums_to_host(sums):
+    """the ICP sums under the current rounding specification -> A, b, residual"""
+    A = np.zeros(36, np.float32); b = np.zeros(6, np.float32); r = np.zeros(2, np.float32)
+    lib.orc_icp_sums_to_host(P(np.ascontiguousarray(sums, np.int64)), P(A), P(b), P(r))
+    return A.reshape(6, 6), b, r
+
+
 def so3_to_host(sums, F=12):
     A = np.zeros(9, np.float32); b = np.zeros(3, np.float32); r = np.zeros(2, np.float32)
     lib.orc_so3_sums_to_host(P(np.ascontiguousarray(sums, np.int64)), F, P(A), P(b), P(r))
