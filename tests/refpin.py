@@ -93,7 +93,7 @@ def run(m, inp, cam_cls):
         else:
             sums, err = m.icp_step(T2[:3, :3], T2[:3, 3], vmaps[l], nmaps[l], Rprev_inv, tprev, cl, mv[l], mn[l], DIST_THRES,
                                    ANGLE_THRES, want_err=True)
-            A, b, res = m.se3_to_host(sums)
+            A, b, res = m.icp_sums_to_host(sums) if hasattr(m, "icp_sums_to_host") else m.se3_to_host(sums)  # (follows orc_set_icp_arith)
             tA, tb, tres = m.icp_step_ref_order(T2[:3, :3], T2[:3, 3], vmaps[l], nmaps[l], Rprev_inv, tprev, cl, mv[l], mn[l],
                                                 DIST_THRES, ANGLE_THRES)
             out[f"icp_A{l}_order"], out[f"icp_b{l}_order"], out[f"icp_res{l}_order"] = tA, tb, tres
