@@ -84,6 +84,89 @@ __global__ void __launch_bounds__(kB) bilateral_kernel(const float* __restrict__
     out[i] = sum1 / sum2;
 }
 
+// Packed-f32 flavour (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per lane and instruction) of bilateral_kernel: one pixel per
+// lane as before, but the taps (dx, dx + 1) of a window row are evaluated TOGETHER -- one 8-byte load {row[x+dx], row[x+dx+1]}, the
+// weight arithmetic on both elements at once -- and only the two running sums keep the reference's sequential order
+// (sum += a; sum += b).  Same operations on the same values: identical bits.  det_expf is evaluated without branches (its argument is
+// <= 0 or NaN here: one select after the polynomial), a wave whose pixels all keep their whole window inside the image
+// columns skips the column tests, and in the others a tap outside the image is excluded from the sums by a select.
+// (Measured and dropped: two PIXELS per lane on the same instructions -- half as many waves, each a chain of dependent packed
+// operations with a wait state after every one of them: 90.9 against 57.5 us, profiles/r05e.)
+typedef float bl_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int bl_cvt_i32(float v) { int r; asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(v)); return r; }  // saturating, NaN -> 0
+__device__ __forceinline__ bl_v2f bl_expf_nonpos(bl_v2f x)
+{   // det_expf(x) for x <= 0 or NaN, both elements (the x > 88 exit cannot be taken).  The polynomial runs on every argument: for
+    // x <= -87 (incl. -inf) its result is discarded by the select below, and a NaN argument comes out as NaN by itself, which is
+    // what det_expf returns for it (the conversion saturates / maps NaN to 0, so nothing here is undefined).
+    const bl_v2f t = x * 1.44269504088896341f;
+    const bl_v2f n = {rintf(t.x), rintf(t.y)};
+    bl_v2f r = x - n * 0.693145751953125f;
+    r = r - n * 1.42860682030941723212e-6f;
+    bl_v2f p = {1.0f / 720.0f, 1.0f / 720.0f};
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    bl_v2f e = {ldexpf(p.x, bl_cvt_i32(n.x)), ldexpf(p.y, bl_cvt_i32(n.y))};
+    e.x = (x.x <= -87.0f) ? 0.0f : e.x;
+    e.y = (x.y <= -87.0f) ? 0.0f : e.y;
+    return e;
+}
+template <bool INTERIOR>
+__device__ __forceinline__ void bilateral_rows_tap2(const float* __restrict__ depth, int cols, int rows, int x, int y, float value,
+                                                    float& sum1, float& sum2)
+{
+    const bl_v2f vv = {value, value};
+#pragma unroll
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int cy = y + dy;
+        if (cy < 0 || cy >= rows) continue;
+        const float* __restrict__ rowp = depth + (size_t)cy * cols + x;
+#pragma unroll
+        for (int dx = -6; dx <= 6; dx += 2) {   // taps (dx, dx + 1); the 13th tap of the row is evaluated alone (second element unused)
+            const bool two = dx + 1 <= 6;
+            bool inA = true, inB = two;
+            bl_v2f tmp;
+            if (INTERIOR) {
+                if (two) tmp = *reinterpret_cast<const bl_v2f*>(rowp + dx);   // 4-byte aligned 8-byte load
+                else { tmp.x = rowp[dx]; tmp.y = 0.0f; }
+            } else {
+                const int ca = x + dx, cb = x + dx + 1;
+                inA = ca >= 0 && ca < cols; inB = two && cb >= 0 && cb < cols;
+                tmp.x = inA ? rowp[dx] : 0.0f;
+                tmp.y = inB ? rowp[dx + 1] : 0.0f;
+            }
+            const bl_v2f cs = {(float)(dx * dx + dy * dy) * 0.024691358f, (float)((dx + 1) * (dx + 1) + dy * dy) * 0.024691358f};
+            const bl_v2f d = vv - tmp;
+            const bl_v2f color2 = d * d;
+            const bl_v2f w = bl_expf_nonpos(-(cs + color2 * 555.556f));
+            const bl_v2f tw = tmp * w;
+            if (inA) { sum1 += tw.x; sum2 += w.x; }
+            if (inB) { sum1 += tw.y; sum2 += w.y; }
+        }
+    }
+}
+__global__ void __launch_bounds__(kB) bilateral_tap2_kernel(const float* __restrict__ depth, int cols, int rows, float maxD,
+                                                            float* __restrict__ out)
+{
+    const int i = blockIdx.x * kB + threadIdx.x;
+    const bool alive = i < cols * rows;
+    const int y = alive ? i / cols : 0, x = alive ? i - y * cols : 0;
+    const float value = alive ? depth[i] : 0.0f;
+    const bool ok = alive && !(value > maxD || value < 0.3f);
+    float sum1 = 0, sum2 = 0;
+    if (__any(ok)) {
+        const bool interior = !alive || (x >= 6 && x + 6 < cols);
+        if (__all(interior)) {
+            if (ok) bilateral_rows_tap2<true>(depth, cols, rows, x, y, value, sum1, sum2);
+        } else if (ok)
+            bilateral_rows_tap2<false>(depth, cols, rows, x, y, value, sum1, sum2);
+    }
+    if (alive) out[i] = ok ? sum1 / sum2 : 0.0f;
+}
+
 // ==================================================================== ordered compaction (scan) ====
 // Exclusive scan of u32 flags in three phases; blocks of kScanItems elements.
 static constexpr int kScanItems = 2048;  // 256 threads x 8
@@ -826,7 +909,11 @@ __global__ void set_count2_kernel(unsigned* out, unsigned* out_host, unsigned v)
 // ------------------------------------------------------------------------------- launchers ----
 void launch_bilateral(hipStream_t s, const float* depth, int cols, int rows, float maxD, float* out)
 {
-    bilateral_kernel<<<gridFor((long long)cols * rows), kB, 0, s>>>(depth, cols, rows, maxD, out);
+    // CF_BILATERAL_TAP2=1: the packed-f32 flavour (identical bits; 56 against 57 us, +2 % on a lock-step group of 12 sequences, nothing on
+    // one sequence -- profiles/r05f: the taps are chains of dependent operations, not issue slots; left off)
+    static const int tap2 = xcd_env("CF_BILATERAL_TAP2", 0);
+    if (tap2 && cols >= 16) bilateral_tap2_kernel<<<gridFor((long long)cols * rows), kB, 0, s>>>(depth, cols, rows, maxD, out);
+    else bilateral_kernel<<<gridFor((long long)cols * rows), kB, 0, s>>>(depth, cols, rows, maxD, out);
 }
 
 static Mat4 mat4_from(const float m[16]) { Mat4 r; for (int i = 0; i < 16; i++) r.m[i] = m[i]; return r; }

@@ -49,6 +49,26 @@ def test_bilateral_exact(ctx):
     d[100, 100] = 7.0       # beyond the cutoff
     out = M.bilateral(ctx, ctx.to_device(d), 5.0).cpu().numpy()
     _same(out, op.bilateral(d, 5.0), "bilateral")
+    # the two-pixels-per-lane kernel (even widths) against the one-pixel kernel's cases: holes and non-finite values at the image
+    # borders (a tap outside the image must add exact zeros, a non-finite tap inside must poison its neighbours exactly as the
+    # shader arithmetic does), a window wider than the image, an odd width (one-pixel kernel)
+    e = d.copy()
+    e[0, 5] = np.inf; e[H - 1, W - 3] = np.nan; e[50, 0] = np.inf; e[60, W - 1] = np.nan; e[:, 0:2] = 0.0; e[120:130, W - 7:] = 0.0
+    _same(M.bilateral(ctx, ctx.to_device(e), 5.0).cpu().numpy(), op.bilateral(e, 5.0), "bilateral, borders and non-finite values")
+    for shape in ((9, 16), (33, 18), (40, 161), (5, 320)):
+        f = np.ascontiguousarray(d[:shape[0], :shape[1]])
+        _same(M.bilateral(ctx, ctx.to_device(f), 5.0).cpu().numpy(), op.bilateral(f, 5.0), f"bilateral {shape}")
+
+
+def test_bilateral_packed_flavour_exact():
+    """CF_BILATERAL_TAP2=1 (the packed-f32 flavour of the filter, off by default; the switch is read once per process): the same cases"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CF_BILATERAL_TAP2="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", f"{__file__}::test_bilateral_exact", f"{__file__}::test_static_pipeline_lockstep"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("conf_global,n_frames,n_obj", [(10.0, 6, 0), (0.5, 8, 2)])
