@@ -114,3 +114,19 @@ def test_library_links_rccl_and_resolves_it(libs):
     assert lib.cf_rccl_init(None, None, 0, 1) != 0 and lib.cf_rccl_allreduce(None, None, 0, 0, None) != 0
     assert lib.cf_rccl_destroy(None) != 0
     assert host.cofusion_init_rccl(None, None) != 0 and host.cofusion_broadcast(None, None, 0, 0) != 0
+
+
+def test_division_by_the_image_width_is_exact(tmp_path):
+    """the tracking kernels divide pixel indices by the image width with a multiply-high and a shift (cf_kernels.h: make_idiv, late round
+    3): the host function that makes the magic numbers, compiled from the real header, against the integer division"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "idiv_check")
+    subprocess.check_call([hipcc, "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17", "-w", "-I", os.path.join(root, "co_fusion_amd", "csrc"),
+                           os.path.join(root, "tests", "native", "idiv_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout + r.stderr
