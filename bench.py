@@ -394,6 +394,9 @@ def main(argv=None):
         processed = 24 * W * H + 24 * sum(boxed) + 11 * n_models * W * H
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                         traffic=pmc_traffic(args.workload, W * H),
+                        traffic_source="HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this workload (profiles/r03_icp_traffic.json: "
+                                       "FETCH_SIZE x2 + WRITE_SIZE x1, factors measured by tools/microbench/fetch_calib.hip); counters cannot be read "
+                                       "from inside the benchmark process",
                         kernel="cf::icp_reduce_kernel<PPT,%d>: ICP reduction of all lock-step models || their RGB residual passes, pyramid level 0"
                                % (4 if n_models > 1 else 0),
                         launches=int(prof.icp_launches), avg_us=round(avg_us, 3), bytes_per_launch=bpl,
