@@ -64,6 +64,16 @@ def test_product_path_fails_loudly_without_gpu(libs):
     cfg = api.Config(64, 48, 50, 50, 32, 24, 0, 1, 1024)
     h = C.c_void_p()
     assert lib.cf_create(C.byref(cfg), C.byref(h)) != 0
+    # ... so do the facade's C entry points (one instance, a lock-step group), with a message
+    with pytest.raises(facade.CoFusionError):
+        facade.CoFusionGroup(2, 64, 48, 50, 50, 32, 24)
+    host = libs.load_host()
+    fcfg = facade._make_config(host, 64, 48, 50.0, 50.0, 32.0, 24.0, 0, {})
+    g = C.c_void_p()
+    host.cofusion_last_error.restype = C.c_char_p
+    assert host.cofusion_group_create(C.byref(fcfg), 2, C.byref(g)) != 0 and not g.value
+    assert host.cofusion_last_error(), "an error without a message"
+    assert host.cofusion_group_create(C.byref(fcfg), 0, C.byref(g)) != 0, "a group of zero sequences"
 
 
 def test_no_product_code_touches_the_oracle():
