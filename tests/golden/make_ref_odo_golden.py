@@ -15,6 +15,12 @@ sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.dirname(os
 import refodo  # noqa: E402
 
 W, H, N_FRAMES, FRAMES = 160, 120, 5, (1, 3)   # tracked frames 1 and 3 of a 5-frame run (0-based among the tracked ones)
+# `make_ref_odo_golden.py full`: the same pin at BASELINE.json's own frame size, 640x480 (two frames x {default, fast_odom}; the emulator
+# needs ~20 minutes per call there) -> ref_odo_full_v1.npz
+FULL = len(sys.argv) > 1 and sys.argv[1] == "full"
+if FULL:
+    W, H = 640, 480
+OUT_NAME = "ref_odo_full_v1.npz" if FULL else "ref_odo_v1.npz"
 
 
 def digest(fr):
@@ -29,11 +35,11 @@ def digest(fr):
 def main():
     cam, frames = refodo.record_tracking_inputs(W, H, N_FRAMES)
     out = dict(meta=np.array([W, H, N_FRAMES], np.int32), frames=np.array(FRAMES, np.int32),
-               options=np.array([o[0] for o in refodo.OPTION_SETS]))
+               options=np.array([o[0] for o in refodo.OPTION_SETS if not FULL or o[0] in ("default", "fast_odom")]))
     for fi in FRAMES:
         fr = frames[fi]
         out[f"f{fi}/digest"] = np.array(digest(fr))
-        for opts in refodo.OPTION_SETS:
+        for opts in ([o for o in refodo.OPTION_SETS if o[0] in ("default", "fast_odom")] if FULL else refodo.OPTION_SETS):
             tr, rot, st, err = refodo.track_once(refodo.RefOdometry, cam, W, H, fr, opts)
             key = f"f{fi}/{opts[0]}"
             out[key + "/trans"] = tr; out[key + "/rot"] = rot
@@ -42,7 +48,7 @@ def main():
             out[key + "/lastA"] = st["lastA"]; out[key + "/lastb"] = st["lastb"]
             out[key + "/err_sum_max"] = np.array([err.astype(np.float64).sum(), err.max()], np.float64)
             print(key, tr, st["last_icp_count"], st["last_rgb_count"], flush=True)
-    np.savez_compressed(os.path.join(HERE, "ref_odo_v1.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, OUT_NAME), **out)
 
 
 if __name__ == "__main__":
