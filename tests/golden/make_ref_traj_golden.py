@@ -35,6 +35,15 @@ SCENARIOS = {
 }
 
 
+SCENARIOS["static_camera_640"] = (0, 12, 10.0, 20, False)   # the static scenario at BASELINE.json's own frame size (~5 min per tracked frame)
+SCENARIOS["crf_two_objects_640"] = (2, 24, 0.5, 3, True)    # ... and the motion-CRF scenario: at this size the objects cover ~15 000 pixels each
+SIZES = {"static_camera_640": (640, 480), "crf_two_objects_640": (640, 480)}
+
+
+def size(name):
+    return SIZES.get(name, (W, H))
+
+
 def uses_gt_masks(name):
     return len(SCENARIOS[name]) > 5 and bool(SCENARIOS[name][5])
 
@@ -71,7 +80,7 @@ def play(name, reference_tracker, n_frames=None, log=None):
     n_obj, frames, conf_global, spawn, multi = SCENARIOS[name][:5]
     gt = uses_gt_masks(name)
     F = n_frames or frames
-    cam = synth.Camera.scaled(W, H)
+    cam = synth.Camera.scaled(*size(name))
     sc = synth.Scene(n_obj=n_obj)
     cf = refcofusion.RefCoFusion(cam, conf_global=conf_global, spawn_offset=spawn, multi=multi, reference_tracker=reference_tracker)
     poses = np.zeros((F, MAXM, 4, 4), np.float32); ids = np.full((F, MAXM), -1, np.int32); counts = np.zeros((F, MAXM), np.int64)

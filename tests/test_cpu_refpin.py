@@ -481,8 +481,8 @@ def test_trajectory_within_1mm_ate_of_the_reference_arithmetic():
     """tests/golden/ref_traj_v1.npz holds the poses of the pinned frame loop (the text of CoFusion::processFrame) when every model is
     tracked by the reference's OWN RGBDOdometry class -- its CUDA kernels under the emulator, f32 tree reductions, Eigen-style solve --
     for 40 frames of a static scene, 24 frames of a two-object scene with the motion CRF and 32 frames of the two-object scene with
-    ground-truth masks (identical model lists over the whole run) at 160x128 (~5.5 h of emulator time, generated once by
-    tests/golden/make_ref_traj_golden.py).  Here the same loops run with the oracle's exact-integer tracker (whose bits the HIP
+    ground-truth masks (identical model lists over the whole run) at 160x128, and 12 frames of the static scene at 640x480 (~6 h of
+    emulator time, generated once by tests/golden/make_ref_traj_golden.py).  Here the same loops run with the oracle's exact-integer tracker (whose bits the HIP
     path reproduces: tests/test_configs_gpu.py) and the camera trajectories must agree within BASELINE.json's 1e-3 m ATE over ALL frames;
     the model lists must be identical for the whole static run and for at least the first 10 frames of the two-object run (spawn /
     deactivation are threshold decisions: they shift by a frame under different rounding), object poses within the bound while they are."""
@@ -496,7 +496,7 @@ def test_trajectory_within_1mm_ate_of_the_reference_arithmetic():
     for name in names:
         rp, rids = z[name + "/poses"], z[name + "/ids"]
         F = rp.shape[0]
-        assert F >= 24
+        assert F >= (24 if g.size(name) == (g.W, g.H) else 12)
         # one process per scenario (function-static state in Core/Segmentation, see cfpin.run_reference_isolated)
         code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r); import make_ref_traj_golden as g; "
                 "p, i, c = g.play(%r, False, n_frames=%d); np.savez(sys.argv[1], poses=p, ids=i)"
@@ -508,7 +508,7 @@ def test_trajectory_within_1mm_ate_of_the_reference_arithmetic():
         rmse, worst = _ate(op[:, 0, :3, 3], rp[:, 0, :3, 3])
         length = float(np.linalg.norm(np.diff(rp[:, 0, :3, 3].astype(np.float64), axis=0), axis=1).sum())
         print(f"{name}: camera ATE rmse {rmse:.2e} m, max {worst:.2e} m over {F} frames, path length {length:.3f} m")
-        assert length > 0.15, f"{name}: degenerate trajectory"
+        assert length > (0.15 if F >= 24 else 0.08), f"{name}: degenerate trajectory"
         assert (ATE_TOL_M, 2 * ATE_TOL_M) == g.ate_bounds(name)
         assert rmse <= ATE_TOL_M and worst <= 2 * ATE_TOL_M, f"{name}: camera ATE {rmse} (max {worst}) against the reference's arithmetic"
         rot = np.abs(op[:, 0, :3, :3].astype(np.float64) - rp[:, 0, :3, :3].astype(np.float64)).max()
