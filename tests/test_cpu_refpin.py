@@ -493,16 +493,22 @@ def test_trajectory_within_1mm_ate_of_the_reference_arithmetic():
     z = np.load(TRAJ_GOLDEN)
     names = sorted({k.split("/")[0] for k in z.files})
     assert names, "empty fixture"
+    # one process per scenario (function-static state in Core/Segmentation, see cfpin.run_reference_isolated), all of them side by side
+    procs = {}
     for name in names:
-        rp, rids = z[name + "/poses"], z[name + "/ids"]
-        F = rp.shape[0]
-        assert F >= (24 if g.size(name) == (g.W, g.H) else 12)
-        # one process per scenario (function-static state in Core/Segmentation, see cfpin.run_reference_isolated)
+        F = z[name + "/poses"].shape[0]
         code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r); import make_ref_traj_golden as g; "
                 "p, i, c = g.play(%r, False, n_frames=%d); np.savez(sys.argv[1], poses=p, ids=i)"
                 % (os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__)), os.path.join(os.path.dirname(__file__), "golden"), name, F))
         out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"traj_{name}_{os.getpid()}.npz")
-        subprocess.run([sys.executable, "-c", code, out], check=True, capture_output=True)
+        procs[name] = (subprocess.Popen([sys.executable, "-c", code, out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE), out)
+    for name in names:
+        rp, rids = z[name + "/poses"], z[name + "/ids"]
+        F = rp.shape[0]
+        assert F >= (24 if g.size(name) == (g.W, g.H) else 12)
+        proc, out = procs[name]
+        _, err_text = proc.communicate(timeout=1200)
+        assert proc.returncode == 0, f"{name}: {err_text.decode()[-2000:]}"
         o = np.load(out); os.remove(out)
         op, oids = o["poses"], o["ids"]
         rmse, worst = _ate(op[:, 0, :3, 3], rp[:, 0, :3, 3])
