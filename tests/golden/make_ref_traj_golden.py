@@ -37,7 +37,8 @@ SCENARIOS = {
 
 SCENARIOS["static_camera_640"] = (0, 12, 10.0, 20, False)   # the static scenario at BASELINE.json's own frame size (~5 min per tracked frame)
 SCENARIOS["crf_two_objects_640"] = (2, 24, 0.5, 3, True)    # ... and the motion-CRF scenario: at this size the objects cover ~15 000 pixels each
-SIZES = {"static_camera_640": (640, 480), "crf_two_objects_640": (640, 480)}
+SCENARIOS["gt_masks_two_objects_640"] = (2, 16, 0.5, 3, True, True)   # ... and ground-truth masks: three models in lock-step from frame 6 on
+SIZES = {"static_camera_640": (640, 480), "crf_two_objects_640": (640, 480), "gt_masks_two_objects_640": (640, 480)}
 
 
 def size(name):
@@ -61,6 +62,14 @@ def object_frames_before_loss(poses, ids, slot, jump=0.05):
             break
         out.append(t)
     return out
+
+
+# Object trajectories that ARE comparable: model slot -> bound in metres on every frame of the run.  With ground-truth masks at 640x480
+# the first object (slot 1, ~5 000 surfels, a steady 1 cm per frame) is tracked stably by the reference's own class, and the oracle / the
+# HIP facade stay within 3.5e-4 m of it over all 13 frames of its life; the second object's own track oscillates by +-2 cm per frame in the
+# reference run and the arithmetics differ by up to 2.2 cm on it -- reported by the tests, not asserted.  Scenarios not listed here use
+# object_frames_before_loss.
+OBJECT_BOUNDS = {"gt_masks_two_objects_640": {1: 1e-3}}
 
 
 # camera ATE bounds (rmse, per frame) in metres.  BASELINE.json's bar is 1e-3 m ATE; the per-frame bound is twice that.  The ground-truth
