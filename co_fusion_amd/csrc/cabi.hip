@@ -64,7 +64,6 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     if (int r = dmalloc(ctx, &ctx->d_so3_sync, (size_t)ctx->cfg.max_models + 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_pre_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pre_ptrs), sizeof(OdomDev*) * (ctx->cfg.max_models + 1)));
-    if (const char* e = getenv("CF_GN_GRAPH")) ctx->gn_use_graph = atoi(e);
     if (const char* e = getenv("CF_GN_MODE")) ctx->gn_mode = atoi(e);  // diagnostic: 0 = three launches per iteration
     if (const char* e = getenv("CF_ICP_LAUNCH")) {  // diagnostic: "threads,pixels_per_thread"
         int t = 0, p = 0;
@@ -97,7 +96,6 @@ void cf_destroy(cf_ctx* ctx)
     (void)hipFree(ctx->d_state_pool); (void)hipHostFree(ctx->h_state_pool);
     (void)hipHostFree(ctx->h_scratch_state); (void)hipHostFree(ctx->h_model_ptrs); (void)hipHostFree(ctx->h_out);
     (void)hipFree(ctx->d_pre_ptrs); (void)hipHostFree(ctx->h_pre_ptrs);
-    if (ctx->gn_graph) (void)hipGraphExecDestroy(ctx->gn_graph);
     if (ctx->prof.events) {
         for (int i = 0; i < ctx->prof.capacity; i++) (void)hipEventDestroy(ctx->prof.events[i]);
         delete[] ctx->prof.events;
@@ -821,6 +819,7 @@ int cf_odom_init_icp(cf_odom* od, const float* const depth_pyr[CF_NUM_PYRS], flo
         od->ext_vmap_curr[i] = nullptr; od->ext_nmap_curr[i] = nullptr; od->ext_zrange[i] = nullptr;
     }
     launch_frame_maps(s, a, W, H);  // createVMap + createNMap of the three levels in one launch
+    od->zrange_valid = true;
     LAUNCHCHK(ctx);
     return CF_OK;
 }
@@ -863,7 +862,7 @@ int cf_odom_share_frame_maps(cf_odom* od, cf_odom* owner)
     for (int i = 0; i < CF_NUM_PYRS; i++) {
         od->ext_vmap_curr[i] = owner->ext_vmap_curr[i] ? owner->ext_vmap_curr[i] : owner->vmap_curr[i];
         od->ext_nmap_curr[i] = owner->ext_nmap_curr[i] ? owner->ext_nmap_curr[i] : owner->nmap_curr[i];
-        od->ext_zrange[i] = owner->ext_vmap_curr[i] ? owner->ext_zrange[i] : owner->zrange[i];
+        od->ext_zrange[i] = owner->ext_vmap_curr[i] ? owner->ext_zrange[i] : (owner->zrange_valid ? owner->zrange[i] : nullptr);
     }
     return CF_OK;
 }
@@ -917,7 +916,14 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
     h->maxDepthDeltaRGB = od->maxDepthDeltaRGB; h->icpWeight = opts->icp_weight;
     h->icp = icp; h->rgb = rgb; h->rgbOnly = opts->rgb_only;
     static const bool no_box = getenv("CF_NO_SCREEN_BOX") != nullptr;  // diagnostics: A/B of the screen-box culling on one box
+    // the screen box the previous tracking call ended with sizes this call's launches (launch_icp_kernel_arith); the pinned host state
+    // holds it once that call's results were fetched
+    if (h->cull && !ctx->state_readback_pending) memcpy(od->box_hint, h->stats.cull_box, sizeof(od->box_hint));
+    else od->box_hint[0] = kNoBoxHint;
     h->aabb_acc = od->aabb; h->cull = (od->use_occ && od->box_valid && od->band_end == 0 && !no_box) ? 1 : 0;
+    // the first launch of a tracking call latches the accumulator and zeroes it (so3_prealign_kernel): a second tracking call on the
+    // same preparation would read an empty box and cull every workgroup.  It falls back to the whole image instead.
+    od->box_valid = false;
     const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
     const float t[3] = {pose[3], pose[7], pose[11]};
     memcpy(h->Rprev, R, 36); memcpy(h->tprev, t, 12); memcpy(h->Rcurr, R, 36); memcpy(h->tcurr, t, 12);
@@ -968,7 +974,8 @@ static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3
                                   od->h_state->err_surface, od->rgb_acc, (od->use_occ && od->occ_valid && !no_occ) ? od->occ : nullptr,
                                   od->band_end > 0 ? (od->band_begin >> l) : 0, od->band_end > 0 ? (od->band_end >> l) : 0,
                                   od->h_state->cull,
-                                  no_zcull ? nullptr : (od->ext_vmap_curr[l] ? od->ext_zrange[l] : od->zrange[l])};
+                                  no_zcull ? nullptr : (od->ext_vmap_curr[l] ? od->ext_zrange[l] : (od->zrange_valid ? od->zrange[l] : nullptr)),
+                                  od->h_state->cull ? box_blocks_for(od->box_hint, l, a.cols, a.rows, ctx->icp_launch.threads) : 0};
         }
     }
 }
@@ -1024,48 +1031,18 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     for (int m = 0; m < n; m++) { hook.split[m] = ods[m]->band_end > 0 ? 1 : 0; any_split = any_split || hook.split[m]; }
     if (any_split && !ctx->collective) { ctx->set_error("a tracker has a row band (cf_odom_set_band) but no collective is registered (cf_set_collective)"); return CF_ESTATE; }
     if (any_split && ctx->gn_mode == 0) { ctx->set_error("split reductions need the record-slot data path (cf_set_gn_mode 1)"); return CF_ESTATE; }
-    // hipGraph replay of the schedule.  Not with a collective hook inside the loop (host callbacks) nor while the launches carry
-    // profiling events.  Stream capture is not allowed on the legacy default stream, so the schedule is captured on the context's own
-    // stream (capturing executes nothing) and the graph is launched on whatever stream the context uses.
-    bool launched = false;
     // timing events on the level-0 launches of every prof.enabled-th tracking call (cf_profile_enable(ctx, N)): the event pairs cost
     // host time (static 640x480: 1275 frames/s without, 1210 with events on every call), sampling keeps the figure and the cost apart
     cf::ProfSink* prof = nullptr;
     if (ctx->prof.enabled > 0 && (ctx->prof_calls++ % (unsigned)ctx->prof.enabled) == 0) prof = &ctx->prof;
-    if (ctx->gn_use_graph && !any_split && !prof) {
-        std::string key;
-        key.append(reinterpret_cast<const char*>(icp_args), sizeof(icp_args));
-        key.append(reinterpret_cast<const char*>(rgb_args), sizeof(rgb_args));
-        const int misc[10] = {n, opts->so3, opts->pyramid, opts->fast_odom, rgb, icp, ctx->gn_mode, ctx->icp_launch.threads, ctx->icp_launch.ppt, use_pre ? 1 : 0};
-        key.append(reinterpret_cast<const char*>(misc), sizeof(misc));
-        if (!ctx->gn_graph || key != ctx->gn_graph_key) {
-            if (ctx->gn_graph) { (void)hipGraphExecDestroy(ctx->gn_graph); ctx->gn_graph = nullptr; }
-            hipGraph_t g = nullptr;
-            bool ok = hipStreamBeginCapture(ctx->own_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) {
-                launch_gn_track(ctx->own_stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, nullptr, icp_args, rgb_args, n, ctx->cfg.width,
-                                ctx->cfg.height, so3_here, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, nullptr, h_states,
-                                use_pre ? ctx->d_pre_ptrs : nullptr);
-                ok = hipStreamEndCapture(ctx->own_stream, &g) == hipSuccess && g != nullptr;
-            }
-            if (ok) ok = hipGraphInstantiate(&ctx->gn_graph, g, nullptr, nullptr, 0) == hipSuccess;
-            if (g) (void)hipGraphDestroy(g);
-            if (!ok) { (void)hipGetLastError(); ctx->gn_graph = nullptr; ctx->gn_use_graph = 0; }  // fall back to stream launches for good
-            else ctx->gn_graph_key = key;
-        }
-        if (ctx->gn_graph) {
-            HIPCHK(ctx, hipGraphLaunch(ctx->gn_graph, ctx->stream));
-            launched = true;
-        }
-    }
-    if (!launched &&
-        !launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, any_split ? &hook : nullptr, icp_args, rgb_args, n,
+    if (!launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, any_split ? &hook : nullptr, icp_args, rgb_args, n,
                          ctx->cfg.width, ctx->cfg.height, so3_here, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, prof, h_states,
                          use_pre ? ctx->d_pre_ptrs : nullptr)) {
         ctx->set_error("tracking: the registered collective failed inside the Gauss-Newton loop");
         return CF_ESTATE;
     }
     LAUNCHCHK(ctx);
+#ifdef CF_ABLATE
     // diagnostics: CF_ICP_REPLAY=<call> re-launches the level-0 {ICP || residual} launch of that tracking call (its converged state) back
     // to back under a list of ablation masks and prints the durations -- the decomposition of the launch quoted in DESIGN.md 4.1
     static const int replay_call = getenv("CF_ICP_REPLAY") ? atoi(getenv("CF_ICP_REPLAY")) : -1;
@@ -1087,24 +1064,17 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
         }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+#endif
     // no read-back copy: the last solve of the schedule wrote every tracker's result into its pinned host state (h_states)
     ctx->state_readback_pending = true;
     return CF_OK;
 }
 
-// The frame's host wait.  hipStreamSynchronize may put the thread to sleep and wake it tens of microseconds after the stream has drained;
-// CF_SPIN_WAIT=1 polls an event instead (diagnostics: A/B of the wake-up latency).
+// The frame's host wait (a polling variant on hipEventQuery was measured in round 3 and bought nothing: DESIGN-NOTES.md).
 int cf_wait_stream(cf_ctx* ctx)
 {
-    static const bool spin = getenv("CF_SPIN_WAIT") != nullptr;
-    if (!spin) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return CF_OK; }
-    if (!ctx->wait_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->wait_event, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventRecord(ctx->wait_event, ctx->stream));
-    for (;;) {
-        const hipError_t e = hipEventQuery(ctx->wait_event);
-        if (e == hipSuccess) return CF_OK;
-        if (e != hipErrorNotReady) { ctx->set_error(std::string("hipEventQuery: ") + hipGetErrorString(e)); return CF_EHIP; }
-    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
 }
 
 int cf_odom_fetch_result(cf_odom* od, float trans[3], float rot[9], cf_track_stats* stats)
@@ -1124,6 +1094,44 @@ int cf_odom_fetch_result(cf_odom* od, float trans[3], float rot[9], cf_track_sta
     if (fault) {  // a device-side wait between co-resident workgroups expired: the pose was computed from partial sums
         ctx->set_error("tracking: a bounded device-side wait expired (workgroups of one launch were not co-resident)");
         return CF_ESTATE;
+    }
+    return CF_OK;
+}
+
+// RGBDOdometry::getCovariance, RGBDOdometry.cpp:479.  Eigen's lu() is PartialPivLU: per column the row with the largest |entry| at or
+// below the diagonal is the pivot (first maximum wins), the column below it is divided by the pivot, rank-1 update of the trailing
+// block; inverse() = P e_j through the unit-lower and the upper triangle, column by column.  Host arithmetic in f64, as the reference's.
+int cf_odom_get_covariance(const cf_track_stats* stats, double cov[36])
+{
+    if (!stats || !cov) return CF_EINVAL;
+    constexpr int N = 6;
+    double lu[N * N];
+    int perm[N];
+    memcpy(lu, stats->lastA, sizeof(lu));
+    for (int i = 0; i < N; i++) perm[i] = i;
+    for (int k = 0; k < N; k++) {
+        int piv = k;
+        double big = fabs(lu[k * N + k]);
+        for (int r = k + 1; r < N; r++) { const double a = fabs(lu[r * N + k]); if (a > big) { big = a; piv = r; } }
+        if (piv != k) {
+            for (int c = 0; c < N; c++) std::swap(lu[k * N + c], lu[piv * N + c]);
+            std::swap(perm[k], perm[piv]);
+        }
+        if (big != 0.0)
+            for (int r = k + 1; r < N; r++) lu[r * N + k] /= lu[k * N + k];
+        for (int r = k + 1; r < N; r++)
+            for (int c = k + 1; c < N; c++) lu[r * N + c] -= lu[r * N + k] * lu[k * N + c];
+    }
+    for (int j = 0; j < N; j++) {
+        double x[N];
+        for (int i = 0; i < N; i++) x[i] = (perm[i] == j) ? 1.0 : 0.0;
+        for (int i = 0; i < N; i++)
+            for (int c = 0; c < i; c++) x[i] -= lu[i * N + c] * x[c];
+        for (int i = N - 1; i >= 0; i--) {
+            for (int c = i + 1; c < N; c++) x[i] -= lu[i * N + c] * x[c];
+            x[i] /= lu[i * N + i];
+        }
+        for (int i = 0; i < N; i++) cov[i * N + j] = x[i];
     }
     return CF_OK;
 }
@@ -1178,6 +1186,9 @@ int cf_odom_buffer(cf_odom* od, int which, int level, void** dptr, uint64_t* byt
     if (!od || level < 0 || level >= CF_NUM_PYRS || !dptr) return CF_EINVAL;
     const size_t n = (size_t)(od->ctx->cfg.width >> level) * (od->ctx->cfg.height >> level);
     void* p = nullptr; size_t b = 0;
+    // a caller that takes the pointer of the current vertex map may write it: the depth intervals cf_odom_init_icp stored beside the
+    // map no longer describe it (the culled reduction would skip runs that now hold matching depths)
+    if (which == 0 && !od->ext_vmap_curr[level]) od->zrange_valid = false;
     switch (which) {
         case 0: p = od->ext_vmap_curr[level] ? (void*)od->ext_vmap_curr[level] : od->vmap_curr[level]; b = n * 12; break;
         case 1: p = od->ext_nmap_curr[level] ? (void*)od->ext_nmap_curr[level] : od->nmap_curr[level]; b = n * 12; break;

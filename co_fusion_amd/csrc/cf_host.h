@@ -56,13 +56,7 @@ struct cf_ctx {
     // all-reduce of unsigned 64-bit words; enqueued on the given stream
     int (*collective)(void* user, int op, void* dev_buf, uint64_t words, void* stream) = nullptr;
     void* collective_user = nullptr;
-    hipEvent_t wait_event = nullptr;   // cf_wait_stream (CF_SPIN_WAIT)
     void* rccl = nullptr;              // the library's own RCCL communicator (cf_rccl_init, rccl_comm.hip); its collective replaces the caller's
-    // the launch schedule of the device-resident Gauss-Newton loop as a hipGraph: captured once per set of kernel arguments (which
-    // models, which buffers, which options), replayed every frame -- ~1 us less per launch boundary than 58 stream launches
-    hipGraphExec_t gn_graph = nullptr;
-    std::string gn_graph_key;          // byte image of everything the captured launches depend on
-    int gn_use_graph = 0;              // CF_GN_GRAPH=1 enables (measured: +1 % with 5 models, -11 % with one model)
     unsigned prof_calls = 0;           // tracking calls seen while profiling is on (events are attached to every prof.enabled-th call)
     cf::ProfSink prof{};
     double prof_ms_accum = 0;
@@ -95,6 +89,7 @@ struct cf_odom {
     const float* ext_vmap_curr[3]{};  // frame-shared current maps (all models track the same frame)
     const float* ext_nmap_curr[3]{};
     float2* zrange[3]{};              // depth interval of every 64-pixel run of vmap_curr (written with the frame maps, cf_odom_init_icp)
+    bool zrange_valid = false;        // cf_odom_init_icp wrote zrange for the current contents of vmap_curr (cleared when a caller takes the map's pointer)
     const float2* ext_zrange[3]{};    // ... of the shared frame maps (cf_odom_share_frame_maps), null when bound without them
     float* lastDepth[3]{};
     float* nextDepth[3]{};
@@ -114,6 +109,7 @@ struct cf_odom {
     bool occ_valid = false;          // the map describes the current model maps
     bool use_occ = false;            // cf_odom_set_culling: occupancy look-up + screen-box culling of the ICP reduction
     unsigned* aabb = nullptr;        // 8 words: bounding-box accumulator of the model maps (OdomDev::aabb_acc)
+    int box_hint[4] = {0x7fffffff, 0, 0, 0};  // level-0 screen box at the end of the previous tracking call (kNoBoxHint: none): sizes the culled launches
     bool box_valid = false;          // the model-map pass of this frame fed the accumulator
     int band_begin = 0, band_end = 0;  // cf_odom_set_band: this rank's rows of the model's reductions (0, 0: all rows)
     bool band_counts = true;           // this rank adds the residual pass's count / sigma (exactly one rank of a split does)            // cf_odom_set_culling: worth it for models that cover a small part of the image

@@ -144,7 +144,36 @@ struct IcpModelArgs {
                                         // reduction is split over GPUs
     int cull;                           // workgroups / waves outside st->stats.cull_box leave before they load anything
     const float2* zr;                   // nullable: depth interval of every 64-pixel run of the current frame's level (FrameMapsArgs::zrange)
+    int box_blocks;                     // > 0 (culled models): workgroups of this model in the launch, dealt the runs of its screen box
+                                        // (box_blocks_for; the launcher drops it where the mapping does not apply); 0: one workgroup
+                                        // per run of the whole image
 };
+constexpr int kNoBoxHint = 0x7fffffff;
+// The 64-pixel runs of a level inside a level-0 screen box (OdomDev::stats.cull_box), for the host (sizing the launch) and the kernel
+// (dealing them to waves) alike.  Image width a multiple of 64: the rectangle in units of runs -- run r is row y0 + r / nrx, columns
+// (x0 + r % nrx) * 64 ...; otherwise (nrx == 0) the flat runs y0 + r that hold the rows of the box.
+struct CullRuns { int x0, y0, nrx, total; };
+__host__ __device__ inline CullRuns cull_runs(const int box[4], int L, int cols, int rows)
+{
+    int bx0 = (box[0] >> L) - 1, by0 = (box[1] >> L) - 1, bx1 = (box[2] >> L) + 1, by1 = (box[3] >> L) + 1;  // (as the per-wave test)
+    bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0; bx1 = bx1 > cols - 1 ? cols - 1 : bx1; by1 = by1 > rows - 1 ? rows - 1 : by1;
+    if (bx0 > bx1 || by0 > by1) return CullRuns{0, 0, 0, 0};
+    if ((cols & 63) == 0) { const int nrx = (bx1 >> 6) - (bx0 >> 6) + 1; return CullRuns{bx0 >> 6, by0, nrx, nrx * (by1 - by0 + 1)}; }
+    const int q0 = (by0 * cols) >> 6, q1 = ((by1 + 1) * cols - 1) >> 6;
+    return CullRuns{0, q0, 0, q1 - q0 + 1};
+}
+// Workgroups for a culled model at level L: the runs of the level-0 screen box the model ended its previous tracking call with
+// (box_hint; [0] == kNoBoxHint: none known -> 0 = the whole image's), + 25 % + two rows of runs -- the waves walk on if the box has
+// grown beyond that -- in multiples of 8 (slots start on XCD 0), at least 8.
+inline int box_blocks_for(const int box_hint[4], int L, int cols, int rows, int threads)
+{
+    if (box_hint[0] == kNoBoxHint) return 0;
+    const CullRuns cr = cull_runs(box_hint, L, cols, rows);
+    const int wpb = threads / 64;
+    const int runs = cr.total + cr.total / 4 + 2 * (cr.nrx > 0 ? cr.nrx : (cols + 63) / 64);
+    int want = (((runs + wpb - 1) / wpb + 7) / 8) * 8;
+    return want < 8 ? 8 : want;
+}
 // solve-kernel arguments (by value)
 struct GnArgs {
     OdomDev* od[kMaxBatch];
@@ -191,6 +220,12 @@ struct IcpArgs {
     int flags;                          // bit0: write the error surface
     int row_begin, row_end;             // row band to reduce; row_end == 0: all rows
     IDiv cdiv;                          // make_idiv(cols), set by the launchers
+    // layout of the one-dimensional grid (set by the launchers, icp_reduce_kernel): running totals of the ICP workgroups per slot, the
+    // model of every slot, residual workgroups per model
+    int blk_end[kMaxBatch];
+    int blk_model[kMaxBatch];
+    int n_res_blocks;
+    IDiv res_div;                       // make_idiv(n_res_blocks)
 };
 void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void launch_rgb_residual(hipStream_t s, const RgbArgs& ra, int n);

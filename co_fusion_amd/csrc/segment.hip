@@ -6,7 +6,7 @@
 // gSLICr and densecrf are third-party and not vendored by the reference (Scripts/install.sh:84-85); they are
 // replaced by their published algorithms exactly as stated in oracle/orc_segment.c (same arithmetic, same
 // summation order => bit-identical to the oracle):
-//   * SLIC: one 16x16-pixel workgroup per grid cell; a pixel can only join one of the 3x3 neighbouring
+//   * SLIC (gSLICr's published engine: metric, normalisers, schedule -- see the oracle's header): one 16x16-pixel workgroup per grid cell; a pixel can only join one of the 3x3 neighbouring
 //     clusters, so each workgroup privatises 9 x 6 integer accumulators in LDS and issues 54 global atomics.
 //   * accumulation: same tiling; exact Q32 fixed-point sums (order independent).
 //   * CRF: the two 1200x1200 Gaussian kernels are evaluated exactly (no permutohedral lattice), stored
@@ -59,14 +59,18 @@ __global__ void __launch_bounds__(256) slic_assign_kernel(const uchar4* __restri
     __syncthreads();
     const int x = cx0 * kSpix + (t & 15), y = cy0 * kSpix + (t >> 4);
     const uchar4 p = rgba[y * cols + x];
-    const float inv_color = 1.0f / (20.0f * 20.0f), inv_xy = 0.6f / ((float)kSpix * (float)kSpix);
-    float best = 3.402823466e+38F; int bi = 4;
+    // gSLICr's normalisers (seg_engine_GPU constructor, RGB case) and coherence weight (Slic.cpp:37), as in oracle/orc_segment.c
+    float max_color_dist = 5.0f / (1.7321f * 255), max_xy_dist = 1.0f / (1.4142f * kSpix);
+    max_color_dist *= max_color_dist; max_xy_dist *= max_xy_dist;
+    const float weight = 0.6f;
+    float best = 999999.9999f; int bi = 4;
 #pragma unroll
     for (int n = 0; n < 9; n++) {  // dy-major, dx-minor: same scan order as the oracle
         if (s_lab[n] < 0) continue;
         const float dr = (float)p.x - s_c[n][2], dg = (float)p.y - s_c[n][3], db = (float)p.z - s_c[n][4];
         const float ex = (float)x - s_c[n][0], ey = (float)y - s_c[n][1];
-        const float d = (dr * dr + dg * dg + db * db) * inv_color + (ex * ex + ey * ey) * inv_xy;
+        const float dcolor = dr * dr + dg * dg + db * db, dxy = ex * ex + ey * ey;
+        const float d = sqrtf(dcolor * max_color_dist + weight * dxy * max_xy_dist);  // compute_slic_distance
         if (d < best) { best = d; bi = n; }
     }
     labels[y * cols + x] = s_lab[bi];
@@ -84,8 +88,8 @@ __global__ void slic_update_kernel(unsigned long long* __restrict__ sums, int K,
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     unsigned long long* s = sums + (size_t)k * 6;
-    if (s[5] != 0)
-        for (int q = 0; q < 5; q++) centres[k * 5 + q] = (float)(long long)s[q] / (float)(long long)s[5];
+    // finalize_reduction_result_shared: a cluster without pixels stays at its reset value (centre (0,0), colour 0)
+    for (int q = 0; q < 5; q++) centres[k * 5 + q] = s[5] ? (float)(long long)s[q] / (float)(long long)s[5] : 0.f;
     for (int q = 0; q < 6; q++) s[q] = 0;
 }
 
@@ -990,9 +994,10 @@ int cf_seg_slic(cf_segmenter* s, const uint8_t* rgba)
     const uchar4* img = reinterpret_cast<const uchar4*>(rgba);
     slic_init_kernel<<<(s->K + 255) / 256, 256, 0, st>>>(img, W, s->gx, s->K, s->centres);
     HIPCHK(ctx, hipMemsetAsync(s->slic_sums, 0, sizeof(unsigned long long) * 6 * s->K, st));
-    for (int it = 0; it < 5; it++) {
+    // gSLICr's Perform_Segmentation: assign; no_iters (5, Slic.cpp:38) x {update; assign} -- the labels are the sixth pass's
+    for (int it = 0; it <= 5; it++) {
+        if (it > 0) slic_update_kernel<<<(s->K + 255) / 256, 256, 0, st>>>(s->slic_sums, s->K, s->centres);
         slic_assign_kernel<<<dim3(s->gx, s->gy), 256, 0, st>>>(img, W, H, s->gx, s->gy, s->centres, s->labels, s->slic_sums);
-        slic_update_kernel<<<(s->K + 255) / 256, 256, 0, st>>>(s->slic_sums, s->K, s->centres);
     }
     LAUNCHCHK(ctx);
     return CF_OK;

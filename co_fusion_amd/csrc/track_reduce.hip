@@ -190,81 +190,32 @@ static_assert(sizeof(IcpArgs) + sizeof(RgbArgs) + 16 <= 4096, "the kernel-argume
 // GRAM (cf_set_icp_arith 1): the accumulation and the butterfly are replaced by the matrix cores -- the rows are rounded to integers,
 // staged through LDS as signed 8-bit limbs and contracted over the wave's pixels by v_mfma_i32_32x32x32_i8 (cf_device.h: gram_*);
 // dynamic LDS = kGramWaveDwords * 4 bytes per wave (gram_block_commit adds the waves' tiles and recombines the limbs).  A different rounding specification (ORC_ICP_ARITH_GRAM in the oracle).
+// Timing ablations of the launch (CF_ICP_REPLAY, DESIGN-NOTES): bits 8.. of IcpArgs::flags switch parts of the kernel off.  They exist in
+// a diagnostics build only (make ABLATE=1 -> -DCF_ABLATE); in the production kernel ABL() is the constant 0 and the tests vanish.
+#ifdef CF_ABLATE
+#define ABL(bits) ((args.flags >> 8) & (bits))
+#else
+#define ABL(bits) 0
+#endif
 extern __shared__ int gram_lds[];
-template <int PPT, int LEVEL_TAG, bool GRAM>
-__global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, const RgbArgs ra, int n_icp_blocks)
-{
-    // (Measured and dropped, round 3: dispatching the residual workgroups of all models before the mostly culled ICP workgroups of
-    // the object models, so that the launch would end on short work -- 22.2 against 21.4 us in grid order, profiles/r03e.)
-    const int model = blockIdx.y, bx = blockIdx.x;
-    if (bx >= n_icp_blocks) {
-        if (((args.flags >> 8) & 32) || (((args.flags >> 8) & 16) && args.m[model].cull)) return;  // timing ablations (CF_ICP_REPLAY)
-        if (ra.compact) rgb_residual_body<true>(ra, model, bx - n_icp_blocks);
-        else rgb_residual_body<false>(ra, model, bx - n_icp_blocks);
-        return;
-    }
-    const IcpModelArgs& ma = args.m[model];
-    if (((args.flags >> 8) & 256) && !ma.cull) return;  // timing ablation (CF_ICP_REPLAY): unculled models do nothing
-    const OdomDev* __restrict__ st = ma.st;
-    const int cols = args.cols, rows = args.rows, N = cols * rows;
-    const int T = blockDim.x;
-    // optional row band [row_begin, row_end) (a rank's share when one model's reduction is split over GPUs): of the whole launch
-    // (stand-alone band step) or of this model (split background inside the lock-step loop)
-    const int rb = ma.row_end > 0 ? ma.row_begin : args.row_begin, re = ma.row_end > 0 ? ma.row_end : args.row_end;
-    const int band0 = rb * cols, band1 = (re > 0 ? re : rows) * cols;
-    // the error surface (last level-0 iteration) is written for the WHOLE image on every rank of a split model -- the segmentation
-    // reads all of it -- while only the band's pixels enter the sums
-    const bool whole = (args.flags & 1) && ma.err != nullptr && ma.row_end > 0;
-    const int pix0 = whole ? 0 : band0, pix1 = whole ? N : band1;
-    const int nlog = (pix1 - pix0 + T * PPT - 1) >> __builtin_ctz(T * PPT);  // (workgroup sizes are powers of two: cf_set_icp_launch)
-    // (the grid is sized for the whole image; a model with a row band has fewer logical blocks, and the XCD interleave below is a
-    // bijection only on the first 8 * ceil(nlog / 8) hardware blocks)
-    if ((bx >> 3) >= ((nlog + 7) >> 3)) return;
-    // A culled model keeps the workgroups of a few image rows only: giving every XCD a horizontal band would leave that work on
-    // the XCDs whose bands the rectangle crosses.  Its workgroups are dealt round-robin instead (neighbouring pixel runs on
-    // different XCDs), so what survives the culling is spread over the whole chip.
-    const int lb = (ma.cull && !((args.flags >> 8) & 1024)) ? bx : xcd_logical_block(bx, nlog);  // (1024: timing ablation, bands for everybody)
-    if (lb >= nlog) return;
+// One run of pixels of one model: the 6 plane loads, projection, gather, gates, rows, accumulation and the wave butterfly.
+// i0 = this lane's first pixel, in_range = the lane's pixels take part.  Returns false when the tracker has nothing to do at this level
+// (workgroup-uniform: the caller leaves).  v = this wave's total of word ((lane >> 1) & 31) (product form), gram_has (Gram form).
+// The tracker state is written by the solve kernel of the PREVIOUS launch and only read here: through the constant address space its
+// (wave-uniform) loads are scalar loads whatever the compiler can prove about the stores around them -- with the run loop in the kernel
+// it fell back to per-lane vector loads of the pose, 44 more VGPRs and three waves of occupancy less.
+typedef const __attribute__((address_space(4))) OdomDev* StatePtr;
 
+template <int PPT, bool GRAM>
+__device__ __forceinline__ bool icp_run(const IcpArgs& args, const IcpModelArgs& ma, StatePtr st, int i0, bool in_range,
+                                        bool whole, int band0, int band1, float* __restrict__ errs, int abl, int lane, int wave,
+                                        unsigned long long& v, bool& gram_has, bool& done)
+{
+    const int cols = args.cols, rows = args.rows, N = cols * rows;
     const float* __restrict__ vc = ma.vc;
     const float* __restrict__ nc = ma.nc;
     const float* __restrict__ vp = ma.vp;
     const float* __restrict__ np = ma.np;
-    float* __restrict__ errs = (args.flags & 1) ? ma.err : nullptr;
-    const int abl = (args.flags >> 8) & 7;  // micro-benchmark ablation bits (0 in production)
-
-    const int i0 = pix0 + (lb * T + threadIdx.x) * PPT;
-    bool in_range = i0 < pix1;  // cols is a multiple of PPT, so the whole vector is in range
-    // (Measured and dropped, round 3: issuing the plane loads BEFORE the box test, so that in-box waves would not pay the box's scalar
-    // round trip in front of them: 22.3 against 21.5 us.)
-    // Screen-box culling (screen_box above): pixels outside the model's rectangle add exact zeros.  A workgroup whose pixel run
-    // misses the rectangle leaves after this one scalar load; inside a workgroup that straddles it, the waves outside load nothing
-    // and go straight to the commit.  Not on the error-surface iteration, which writes every pixel.
-    if (ma.cull && !(args.flags & 1)) {
-        if ((args.flags >> 8) & 8) return;  // timing ablation: culled models do nothing
-        const int L = 2 - args.occ_shift;
-        const int bx0 = (st->stats.cull_box[0] >> L) - 1, by0 = (st->stats.cull_box[1] >> L) - 1, bx1 = (st->stats.cull_box[2] >> L) + 1, by1 = (st->stats.cull_box[3] >> L) + 1;
-        const int p0 = pix0 + lb * T * PPT, p1 = min(p0 + T * PPT, pix1) - 1;  // first / last pixel of this workgroup
-        const int r0 = idiv(p0, args.cdiv), r1 = idiv(p1, args.cdiv);
-        if (r1 < by0 || r0 > by1) return;
-        if (r0 == r1 && (p1 - r0 * cols < bx0 || p0 - r0 * cols > bx1)) return;
-        const int w0 = p0 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * 64 * PPT, w1 = min(w0 + 64 * PPT, pix1) - 1;
-        const int q0 = idiv(w0, args.cdiv), q1 = idiv(max(w1, 0), args.cdiv);
-        if ((args.flags >> 8) & 512) return;  // timing ablation (CF_ICP_REPLAY): the cull test alone
-        if (w0 > w1 || q1 < by0 || q0 > by1 || (q0 == q1 && (w1 - q0 * cols < bx0 || w0 - q0 * cols > bx1))) in_range = false;
-        // ... and by depth: the run of 64 pixels this wave owns (per pixel of a lane) carries the interval of its valid depths
-        // (frame_maps_kernel); if it misses the interval the model's dilated box spans in this camera, no pixel of the run can match
-        if (in_range && ma.zr && w0 <= w1) {
-            const float zlo = st->cull_z[0], zhi = st->cull_z[1];
-            bool any = false;
-#pragma unroll
-            for (int p = 0; p < PPT; p++) {
-                const int c = (w0 >> 6) + p;   // runs are aligned: pix0 == 0 for a culled model, w0 a multiple of 64 * PPT
-                if (c * 64 <= w1) { const float2 r = ma.zr[c]; any = any || (r.x <= zhi && r.y >= zlo); }
-            }
-            if (!any) in_range = false;
-        }
-    }
     float vx[PPT], vy[PPT], vz[PPT], nx[PPT], ny[PPT], nz[PPT];
 #pragma unroll
     for (int p = 0; p < PPT; p++) { vx[p] = vy[p] = vz[p] = nx[p] = ny[p] = nz[p] = qnan(); }
@@ -272,7 +223,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
         load_vec<PPT>(vc + i0, vx); load_vec<PPT>(vc + i0 + N, vy); load_vec<PPT>(vc + i0 + 2 * N, vz);
         load_vec<PPT>(nc + i0, nx); load_vec<PPT>(nc + i0 + N, ny); load_vec<PPT>(nc + i0 + 2 * N, nz);
     }
-    if (!st->icp || st->level_done) return;
+    if (!st->icp || st->level_done) return false;
     m33 Rcurr, Rprev_inv;
 #pragma unroll
     for (int i = 0; i < 9; i++) { Rcurr.m[i] = st->Rcurr[i]; Rprev_inv.m[i] = st->Rprev_inv[i]; }
@@ -304,9 +255,6 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
         if (whole && (i0 + p < band0 || i0 + p >= band1)) continue;  // outside this rank's band: error surface only
         cand |= (pr[p].inb && !is_nan(nx[p]) && !is_nan(nprev[p].x) && !is_nan(vprev[p].x)) ? 1 : 0;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long v = 0;
-    bool gram_has = false;
     const bool wave_cand = __any(cand) != 0;
     if (errs) {  // last level-0 iteration: the error surface stores dist for every pixel (0 if not finite / out of view)
 #pragma unroll
@@ -345,7 +293,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
             }
         }
         if constexpr (GRAM) {
-            if (__any(any_found) || abl) {
+            if (__any(any_found) || abl != 0) {
                 int* wl = gram_lds + wave * kGramWaveDwords;
                 gram_v16i macc;
 #pragma unroll
@@ -364,7 +312,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
                 gram_has = true;
             }
         } else
-        if (__any(any_found) || abl) {
+        if (__any(any_found) || abl != 0) {
             unsigned long long acc[32];
 #pragma unroll
             for (int k = 0; k < 28; k++) acc[k] = 0ull - (unsigned long long)PPT * kMagicBits;
@@ -375,11 +323,142 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
                 else acc[0] += __float_as_uint(row[p][6]) + __float_as_uint(row[p][3]);
                 acc[28] += (unsigned long long)fnd[p];
             }
-            if (abl & 2) { if (acc[0] + acc[28] == 0x1234567ull) ma.acc[lane] = acc[5]; return; }
+            if (abl & 2) { if (acc[0] + acc[28] == 0x1234567ull) ma.acc[lane] = acc[5]; done = true; return true; }
             v = wave_reduce32_u64(acc, lane);
-            if (abl & 4) { if (v == 0x1234567ull) ma.acc[lane] = v; return; }
+            if (abl & 4) { if (v == 0x1234567ull) ma.acc[lane] = v; done = true; return true; }
         }
     }
+    return true;
+}
+
+// GRID.  One-dimensional: [ICP workgroups of slot 0 | slot 1 | ... | residual workgroups of model 0 | model 1 | ...], IcpArgs::blk_end
+// holds the running totals of the ICP part, IcpArgs::blk_model the model of every slot (the launcher puts the culled models first:
+// their waves have the longest chain of dependent memory round trips).  Every slot starts at a multiple of 8, so hardware workgroup b
+// and its slot-local index agree on the XCD (b % 8).
+//  * A model that is not culled gets one workgroup per run of T * PPT pixels of its image (or row band), XCD x owning the x-th
+//    horizontal band (xcd_logical_block).
+//  * A CULLED model (IcpModelArgs::box_blocks > 0) gets box_blocks workgroups -- sized by the host from the screen box the model ended
+//    the previous frame with -- whose waves are dealt the 64-pixel runs INSIDE the model's current screen box (cull_runs: the rectangle
+//    in units of runs when the image width is a multiple of 64, the rows of the box otherwise); a wave walks on by the number of waves
+//    when the box has more runs than the host expected.  Until round 4 a culled model had the whole image's workgroups, 80 % of
+//    which read the box and left: 4 800 of the 7 500 workgroups of a five-model level-0 launch, dispatched ahead of the work that the
+//    launch waits for.  Sums are integers: which wave adds which pixel does not change a bit.
+template <int PPT, int LEVEL_TAG, bool GRAM>
+__global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, const RgbArgs ra, int n_icp_blocks)
+{
+    const int b = blockIdx.x;
+    if (b >= n_icp_blocks) {
+        const int rb = b - n_icp_blocks;
+        const int model = args.n_res_blocks > 1 ? idiv(rb, args.res_div) : rb;
+        if (ABL(32) || (ABL(16) && args.m[model].cull)) return;  // timing ablations (CF_ICP_REPLAY)
+        if (ra.compact) rgb_residual_body<true>(ra, model, rb - model * args.n_res_blocks);
+        else rgb_residual_body<false>(ra, model, rb - model * args.n_res_blocks);
+        return;
+    }
+    int slot = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxBatch - 1; k++) slot += (b >= args.blk_end[k]) ? 1 : 0;  // (one wide scalar load of the table, 15 compares; unused slots end at INT_MAX)
+    const int model = args.blk_model[slot], bx = b - (slot ? args.blk_end[slot - 1] : 0);
+    const IcpModelArgs& ma = args.m[model];
+    if (ABL(256) && !ma.cull) return;  // timing ablation (CF_ICP_REPLAY): unculled models do nothing
+    StatePtr st = (StatePtr)ma.st;
+    const int cols = args.cols, rows = args.rows, N = cols * rows;
+    const int T = blockDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int abl = ABL(7);  // micro-benchmark ablation bits (0 in production)
+    unsigned long long v = 0;
+    bool gram_has = false, done = false;
+
+    if (ma.box_blocks > 0) {  // culled model, runs of its screen box (the launcher: PPT == 1, product form, no error surface)
+        if (ABL(8)) return;  // timing ablation: culled models do nothing
+        if (!st->icp || st->level_done) return;
+        const int L = 2 - args.occ_shift;
+        const int box[4] = {st->stats.cull_box[0], st->stats.cull_box[1], st->stats.cull_box[2], st->stats.cull_box[3]};
+        const CullRuns cr = cull_runs(box, L, cols, rows);
+        if (ABL(512)) return;  // timing ablation (CF_ICP_REPLAY): the cull test alone
+        const int wpb = T >> 6, stride = ma.box_blocks * wpb;
+        const float rcp = __builtin_amdgcn_rcpf((float)(cr.nrx > 0 ? cr.nrx : 1));
+        const float zlo = st->cull_z[0], zhi = st->cull_z[1];
+#pragma nounroll
+        for (int r = bx * wpb + __builtin_amdgcn_readfirstlane(wave); r < cr.total; r += stride) {
+            int start;
+            bool in_range = true;
+            if (cr.nrx > 0) {  // rectangle of runs: r / nrx exactly ((r + 0.5) / nrx is at least 0.5 / nrx away from an integer, r < 2^16)
+                const int q = (int)(((float)r + 0.5f) * rcp);
+                start = (cr.y0 + q) * cols + ((cr.x0 + (r - q * cr.nrx)) << 6);
+            } else {           // runs of the box's rows; a run may straddle rows: the rectangle test of the run's first / last pixel
+                start = (cr.y0 + r) << 6;
+                const int bx0 = (box[0] >> L) - 1, by0 = (box[1] >> L) - 1, bx1 = (box[2] >> L) + 1, by1 = (box[3] >> L) + 1;
+                const int w1 = min(start + 63, N - 1);
+                const int q0 = idiv(start, args.cdiv), q1 = idiv(w1, args.cdiv);
+                if (q1 < by0 || q0 > by1 || (q0 == q1 && (w1 - q0 * cols < bx0 || start - q0 * cols > bx1))) in_range = false;
+            }
+            // ... and by depth: the run carries the interval of its valid depths (frame_maps_kernel); if it misses the interval the
+            // model's dilated box spans in this camera, no pixel of the run can match
+            if (in_range && ma.zr) { const float2 zz = ma.zr[start >> 6]; if (!(zz.x <= zhi && zz.y >= zlo)) in_range = false; }
+            const int i0 = start + lane;
+            unsigned long long vr = 0;
+            if (!icp_run<1, false>(args, ma, st, i0, in_range && i0 < N, false, 0, N, nullptr, abl, lane, wave, vr, gram_has, done)) return;
+            if (done) return;
+            v += vr;
+        }
+        if constexpr (!GRAM) block_commit32<16>(v, lane, wave, T >> 6, ma.acc + (size_t)(bx % kGroups) * 32);
+        return;
+    }
+
+    // optional row band [row_begin, row_end) (a rank's share when one model's reduction is split over GPUs): of the whole launch
+    // (stand-alone band step) or of this model (split background inside the lock-step loop)
+    const int rb = ma.row_end > 0 ? ma.row_begin : args.row_begin, re = ma.row_end > 0 ? ma.row_end : args.row_end;
+    const int band0 = rb * cols, band1 = (re > 0 ? re : rows) * cols;
+    // the error surface (last level-0 iteration) is written for the WHOLE image on every rank of a split model -- the segmentation
+    // reads all of it -- while only the band's pixels enter the sums
+    const bool whole = (args.flags & 1) && ma.err != nullptr && ma.row_end > 0;
+    const int pix0 = whole ? 0 : band0, pix1 = whole ? N : band1;
+    const int nlog = (pix1 - pix0 + T * PPT - 1) >> __builtin_ctz(T * PPT);  // (workgroup sizes are powers of two: cf_set_icp_launch)
+    // (the slot is sized for the whole image; a model with a row band has fewer logical blocks, and the XCD interleave below is a
+    // bijection only on the first 8 * ceil(nlog / 8) hardware blocks)
+    if ((bx >> 3) >= ((nlog + 7) >> 3)) return;
+    // A culled model keeps the workgroups of a few image rows only: giving every XCD a horizontal band would leave that work on
+    // the XCDs whose bands the rectangle crosses.  Its workgroups are dealt round-robin instead (neighbouring pixel runs on
+    // different XCDs), so what survives the culling is spread over the whole chip.
+    const int lb = (ma.cull && !ABL(1024)) ? bx : xcd_logical_block(bx, nlog);  // (1024: timing ablation, bands for everybody)
+    if (lb >= nlog) return;
+    float* __restrict__ errs = (args.flags & 1) ? ma.err : nullptr;
+
+    const int i0 = pix0 + (lb * T + threadIdx.x) * PPT;
+    bool in_range = i0 < pix1;  // cols is a multiple of PPT, so the whole vector is in range
+    // (Measured and dropped, round 3: issuing the plane loads BEFORE the box test, so that in-box waves would not pay the box's scalar
+    // round trip in front of them: 22.3 against 21.5 us.)
+    // Screen-box culling on the whole-image mapping (Gram form, several pixels per lane, stand-alone steps): a workgroup whose pixel
+    // run misses the rectangle leaves after one scalar load; inside a workgroup that straddles it, the waves outside load nothing and
+    // go straight to the commit.  Not on the error-surface iteration, which writes every pixel.
+    if (ma.cull && !(args.flags & 1)) {
+        if (ABL(8)) return;  // timing ablation: culled models do nothing
+        const int L = 2 - args.occ_shift;
+        const int bx0 = (st->stats.cull_box[0] >> L) - 1, by0 = (st->stats.cull_box[1] >> L) - 1, bx1 = (st->stats.cull_box[2] >> L) + 1, by1 = (st->stats.cull_box[3] >> L) + 1;
+        const int p0 = pix0 + lb * T * PPT, p1 = min(p0 + T * PPT, pix1) - 1;  // first / last pixel of this workgroup
+        const int r0 = idiv(p0, args.cdiv), r1 = idiv(p1, args.cdiv);
+        if (r1 < by0 || r0 > by1) return;
+        if (r0 == r1 && (p1 - r0 * cols < bx0 || p0 - r0 * cols > bx1)) return;
+        const int w0 = p0 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * 64 * PPT, w1 = min(w0 + 64 * PPT, pix1) - 1;
+        const int q0 = idiv(w0, args.cdiv), q1 = idiv(max(w1, 0), args.cdiv);
+        if (ABL(512)) return;  // timing ablation (CF_ICP_REPLAY): the cull test alone
+        if (w0 > w1 || q1 < by0 || q0 > by1 || (q0 == q1 && (w1 - q0 * cols < bx0 || w0 - q0 * cols > bx1))) in_range = false;
+        // ... and by depth: the run of 64 pixels this wave owns (per pixel of a lane) carries the interval of its valid depths
+        // (frame_maps_kernel); if it misses the interval the model's dilated box spans in this camera, no pixel of the run can match
+        if (in_range && ma.zr && w0 <= w1) {
+            const float zlo = st->cull_z[0], zhi = st->cull_z[1];
+            bool any = false;
+#pragma unroll
+            for (int p = 0; p < PPT; p++) {
+                const int c = (w0 >> 6) + p;   // runs are aligned: pix0 == 0 for a culled model, w0 a multiple of 64 * PPT
+                if (c * 64 <= w1) { const float2 r = ma.zr[c]; any = any || (r.x <= zhi && r.y >= zlo); }
+            }
+            if (!any) in_range = false;
+        }
+    }
+    if (!icp_run<PPT, GRAM>(args, ma, st, i0, in_range, whole, band0, band1, errs, abl, lane, wave, v, gram_has, done)) return;
+    if (done) return;
     if constexpr (GRAM) gram_block_commit(gram_lds, gram_has, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
     else block_commit32<16>(v, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
 }
@@ -1174,8 +1253,25 @@ static void launch_icp_kernel_arith(hipStream_t s, IcpLaunch cfg, const IcpArgs&
     const int N = ((args.row_end > 0 ? args.row_end : args.rows) - args.row_begin) * args.cols;
     const int per_block = cfg.threads * cfg.ppt;
     const int nlog = (N + per_block - 1) / per_block;
-    const int n_icp_blocks = icp ? ((nlog + 7) / 8) * 8 : 0;
-    const dim3 grid(n_icp_blocks + n_res_blocks, n);
+    const int full = icp ? ((nlog + 7) / 8) * 8 : 0;
+    // culled models: the workgroups the caller asked for (IcpModelArgs::box_blocks, box_blocks_for), at most the whole image's.  The
+    // mapping is built for one pixel per lane and the product form, and not used on the error-surface iteration (which writes every
+    // pixel) nor with row bands.
+    int blocks[kMaxBatch];
+    for (int m = 0; m < n; m++) {
+        IcpModelArgs& ma = args.m[m];
+        const bool ok = icp && ma.cull && ma.box_blocks > 0 && !GRAM && cfg.ppt == 1 && !(args.flags & 1) && args.row_end == 0 && ma.row_end == 0;
+        ma.box_blocks = ok ? (ma.box_blocks < full ? ((ma.box_blocks + 7) / 8) * 8 : full) : 0;
+        blocks[m] = ok ? ma.box_blocks : full;
+    }
+    int n_icp_blocks = 0, slot = 0;
+    if (icp)
+        for (int pass = 0; pass < 2; pass++)  // culled models first
+            for (int m = 0; m < n; m++)
+                if ((args.m[m].box_blocks > 0) == (pass == 0)) { n_icp_blocks += blocks[m]; args.blk_end[slot] = n_icp_blocks; args.blk_model[slot] = m; slot++; }
+    for (; slot < kMaxBatch; slot++) { args.blk_end[slot] = 0x7fffffff; args.blk_model[slot] = 0; }
+    args.n_res_blocks = n_res_blocks; args.res_div = make_idiv(n_res_blocks > 1 ? n_res_blocks : 2);
+    const dim3 grid(n_icp_blocks + n_res_blocks * n);
     const unsigned lds = GRAM ? (unsigned)(cfg.threads / 64) * kGramWaveDwords * sizeof(int) : 0u;
     if (!ev0 && !ev1) {  // plain launches (also what a stream capture records)
         switch (cfg.ppt) {

@@ -19,7 +19,8 @@ class Config(C.Structure):
                 ("outlier_coefficient", C.c_float), ("fast_odom", C.c_int), ("so3", C.c_int), ("frame_to_frame_rgb", C.c_int),
                 ("pyramid", C.c_int), ("rgb_only", C.c_int), ("model_spawn_offset", C.c_uint), ("enable_multiple_models", C.c_int),
                 ("enable_pose_logging", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("device_frames_complete", C.c_int),
-                ("mid_frame_predict", C.c_int), ("shard_background", C.c_int), ("enqueue_threads", C.c_int)]
+                ("mid_frame_predict", C.c_int), ("shard_background", C.c_int), ("enqueue_threads", C.c_int),
+                ("colocate_background", C.c_int), ("reloc", C.c_int)]
 
 
 class CoFusionError(RuntimeError):
@@ -247,6 +248,11 @@ class CoFusion:
     @property
     def tick(self):
         return self.lib.cofusion_tick(self.h)
+
+    @property
+    def lost(self):
+        """CoFusion::getLost: the camera is lost (option reloc=1)"""
+        return bool(self.lib.cofusion_is_lost(self.h))
 
     def model_info(self, index):
         mid = C.c_uint(); cnt = C.c_uint(); conf = C.c_float(); pose = (C.c_float * 16)()

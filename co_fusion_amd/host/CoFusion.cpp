@@ -763,6 +763,8 @@ CoFusion::CoFusion(const Config& c, cf_ctx* shared, int sequenceIndex)
 {
     dist.rank = cfg.rank; dist.world = cfg.world < 1 ? 1 : cfg.world;
     dist.shardBackground = cfg.shardBackground && dist.world > 1;
+    dist.colocate = cfg.colocateBackground;
+    if (cfg.reloc && dist.world > 1) throw std::runtime_error("CoFusion: reloc (failure detection) is a single-GPU option (the background's normal matrix is not exchanged between ranks)");
     labelGenerator.reset(new Segmentation(ctx, cfg.width, cfg.height, &dist));
     // experiment, off by default (CF_FRAME_SO3=1): the SO(3) pre-alignment once per frame and ahead of the tracking launches (cf_so3).
     // Bit-identical; measured +0.6 % on configs[2] and -1.9 % on configs[1]: beside the previous frame's fusion passes
@@ -1149,6 +1151,21 @@ void CoFusion::frameCollect()
         const bool allowNew = st.allowNew, segOnDevice = st.segOnDevice;
         { PhaseTimer t(PhaseTimes::Track); fetchTracking(true); }
         if (bootstrap) globalModel->overridePose(globalModel->getPose() * (*inPose));
+        if (cfg.reloc) {  // CoFusion.cpp:225 and 301-338 (nothing in between reads trackingCount / lost: evaluated together)
+            const cf_track_stats& gs = globalModel->lastStats;
+            trackingOk = (double)gs.last_icp_error < 1e-04;
+            if (!lost) {
+                double cov[36];
+                check(ctx, cf_odom_get_covariance(&gs, cov), "cf_odom_get_covariance");
+                for (int i = 0; i < 6; i++)
+                    if (cov[i * 6 + i] > 1e-04) { trackingOk = false; break; }
+                if (!trackingOk) {
+                    if (++trackingCount > 10) lost = true;
+                } else trackingCount = 0;
+            }
+            // (lastFrameRecovery, :321-337, is only ever set by the fern database, :365-367 -- closeLoops is off in Co-Fusion and the
+            // database out of scope: a lost camera stays lost)
+        }
 
         if (cfg.enableMultipleModels) {
             auto getMaxDepth = [](const SegmentationResult::ModelData& d) -> float { return d.depthMean + d.depthStd * 1.2; };
@@ -1295,8 +1312,21 @@ CoFusionGroup::~CoFusionGroup()
 
 void CoFusionGroup::processFrames(const FrameData* frames, const Mat4f* const* inPoses)
 {
+    // A stage that throws leaves the sequences at different points of the frame (some tracked but not fused, clocks apart, tracking
+    // results pending): the "bit-identical to separate instances" guarantee is gone and cannot be restored from here, so the group
+    // refuses further frames instead of silently continuing.
+    if (failed) throw std::runtime_error("CoFusionGroup: a previous processFrames failed part-way; the sequences are out of step (destroy the group)");
+    try { stepAll(frames, inPoses); }
+    catch (...) {
+        failed = true;
+        (void)cf_join(ctx);  // leave no forked lane behind
+        throw;
+    }
+}
+
+void CoFusionGroup::stepAll(const FrameData* frames, const Mat4f* const* inPoses)
+{
     const int S = (int)seqs.size();
-    check(ctx, cf_join(ctx), "cf_join");  // (a previous call that threw inside a forked region)
     for (int s = 0; s < S; s++) seqs[s]->frameBegin(frames[s], inPoses ? inPoses[s] : nullptr, 1.f, false);
     {   // ONE set of tracking launches for the trackers of every sequence that tracks this frame
         PhaseTimer t(PhaseTimes::Track);

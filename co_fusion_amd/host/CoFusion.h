@@ -74,8 +74,15 @@ struct Distributed {
     int (*allreduce_i64)(int64_t* buf, uint64_t n, void* user) = nullptr;  // 0 on success
     void* user = nullptr;
     bool active() const { return world > 1; }
-    // the background map (by far the largest) alone on rank 0, objects round-robin over the other ranks
-    int owner(unsigned id) const { return (world <= 1 || id == 0) ? 0 : 1 + (int)((id - 1) % (unsigned)(world - 1)); }
+    // the background map (by far the largest) alone on rank 0, objects round-robin over the other ranks; colocate (Config::
+    // colocateBackground, BASELINE.json configs[3]: "8 object models sharded one-per-GPU"): objects round-robin over ALL ranks, the
+    // background shares rank 0 with the objects that land there
+    bool colocate = false;
+    int owner(unsigned id) const
+    {
+        if (world <= 1 || id == 0) return 0;
+        return colocate ? (int)((id - 1) % (unsigned)world) : 1 + (int)((id - 1) % (unsigned)(world - 1));
+    }
     // Background split over the ranks (Config::shardBackground): every rank keeps a replica of the background map and takes a share of
     // its two reductions -- the surfel range it rasterises into the index map (MIN all-reduce of the z-keys) and the image rows it
     // reduces in the ICP step (SUM all-reduce of the normal-equation accumulators after every launch of the Gauss-Newton loop).
@@ -236,6 +243,13 @@ class CoFusion {
         // model-parallel operation only: split the background's index-map rasterisation (by surfel range) and ICP reduction (by image
         // rows) over all ranks, each holding a replica of the background map (see Distributed::shardBackground)
         bool shardBackground = false;
+        // model-parallel operation only: object models round-robin over ALL ranks, the background sharing rank 0 with the objects that
+        // land there (BASELINE.json configs[3]: 8 object models one per GPU); default: the background alone on rank 0
+        bool colocateBackground = false;
+        // CoFusion's `reloc` constructor argument (CoFusion.h:47, -rl on the command line): the failure detection of the frame loop --
+        // a frame whose background ICP error / pose covariance is out of bounds is not fused, and after ten such frames the camera is
+        // `lost`: no fusion, the clock stops (CoFusion.cpp:225, 301-338, 463, 495).  The fern-based recovery is out of scope.
+        bool reloc = false;
         // host threads that enqueue the per-model surfel passes (fusion, clean-up, prediction) beside the calling thread, one model's
         // chain of launches each.  Pays when the host's launch rate is the limit (a profiler attached, a slow or busy host); on an idle
         // host the calling thread alone keeps the lanes fed (610 / 606 / 604 fps with 0 / 2 / 4 helpers), hence default
@@ -270,6 +284,7 @@ class CoFusion {
     ModelPointer getBackgroundModel() { return globalModel; }
     const Mat4f& getCurrPose() const { return globalModel->getPose(); }
     int getTick() const { return tick; }
+    bool getLost() const { return lost; }  // CoFusion::getLost (CoFusion.h:183-185): the camera is lost (Config::reloc)
     const uint8_t* maskDevice() const { return mask_dev; }
     Segmentation& segmentation() { return *labelGenerator; }
     cf_ctx* context() { return ctx; }
@@ -322,7 +337,8 @@ class CoFusion {
     int64_t* rcclStage = nullptr;      // device staging buffer of the host-buffer all-reduce (initRccl)
     uint64_t rcclStageWords = 0;
     bool capReported = false;  // the model cap suppressed a spawn and said so
-    bool lost = false;
+    bool lost = false;          // CoFusion.h:362 (reloc)
+    int trackingCount = 0;      // CoFusion.h:364
     // device frame buffers (CoFusion::textures)
     // filtered depth + its pyramid are double buffered: the filter of frame t+1 runs on an auxiliary stream while the fusion
     // passes of frame t still read frame t's filtered depth (processFrame)
@@ -358,11 +374,14 @@ class CoFusionGroup {
     // one frame of EVERY sequence: frames[s] goes to sequence s (inPoses: nullable, entries nullable)
     void processFrames(const FrameData* frames, const Mat4f* const* inPoses = nullptr);
     cf_ctx* context() { return ctx; }
+    bool hasFailed() const { return failed; }
 
   private:
+    void stepAll(const FrameData* frames, const Mat4f* const* inPoses);
     CoFusion::Config cfg;
     cf_ctx* ctx = nullptr;
     std::vector<std::unique_ptr<CoFusion>> seqs;
+    bool failed = false;  // a stage threw: the sequences are out of step, further frames are refused
 };
 
 }  // namespace cofusion

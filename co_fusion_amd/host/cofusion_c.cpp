@@ -7,14 +7,13 @@
 #include <string>
 #include <vector>
 
-#include <rccl/rccl.h>
 
 #include "CoFusion.h"
 #include "KlgIO.h"
 
 using namespace cofusion;
 
-struct cofusion_handle { CoFusion* cf; };
+struct cofusion_handle { CoFusion* cf; bool borrowed = false; };  // borrowed: a sequence of a lock-step group (owned and stepped by the group)
 struct cofusion_group { CoFusionGroup* g; std::vector<cofusion_handle> handles; };  // handles: borrowed views of the sequences
 static thread_local std::string g_err;
 
@@ -40,6 +39,8 @@ void cofusion_default_config(cofusion_config* c)
     c->mid_frame_predict = d.midFramePredict;
     c->shard_background = d.shardBackground;
     c->enqueue_threads = d.enqueueThreads;
+    c->colocate_background = d.colocateBackground;
+    c->reloc = d.reloc;
 }
 
 static CoFusion::Config to_config(const cofusion_config* c)
@@ -57,6 +58,8 @@ static CoFusion::Config to_config(const cofusion_config* c)
     d.midFramePredict = c->mid_frame_predict != 0;
     d.shardBackground = c->shard_background != 0;
     d.enqueueThreads = c->enqueue_threads < 0 ? 0 : c->enqueue_threads;
+    d.colocateBackground = c->colocate_background != 0;
+    d.reloc = c->reloc != 0;
     return d;
 }
 
@@ -67,12 +70,18 @@ int cofusion_create(const cofusion_config* c, cofusion_handle** out)
     GUARD(*out = new cofusion_handle{new CoFusion(d)});
     return 0;
 }
-void cofusion_destroy(cofusion_handle* h) { if (h) { delete h->cf; delete h; } }
+void cofusion_destroy(cofusion_handle* h)
+{
+    if (!h || h->borrowed) return;  // a group's sequence belongs to the group (cofusion_group_destroy)
+    delete h->cf; delete h;
+}
 const char* cofusion_last_error(void) { return g_err.c_str(); }
 int cofusion_set_stream(cofusion_handle* h, void* s) { return cf_set_stream(h->cf->context(), s); }
 
 static int run_frame(cofusion_handle* h, const FrameData& f, const float* in_pose)
 {
+    if (!h) { g_err = "null handle"; return -1; }
+    if (h->borrowed) { g_err = "this handle is a sequence of a lock-step group: step it with cofusion_group_process_frames"; return -1; }
     Mat4f p;
     if (in_pose) for (int i = 0; i < 16; i++) p.m[i] = in_pose[i];
     GUARD(h->cf->processFrame(f, in_pose ? &p : nullptr));
@@ -90,6 +99,7 @@ int cofusion_process_frame_device(cofusion_handle* h, int64_t ts, const float* d
 }
 int cofusion_num_models(cofusion_handle* h) { return (int)h->cf->getModels().size(); }
 int cofusion_tick(cofusion_handle* h) { return h->cf->getTick(); }
+int cofusion_is_lost(cofusion_handle* h) { return h && h->cf->getLost() ? 1 : 0; }
 
 static Model* model_at(cofusion_handle* h, int index)
 {
@@ -174,7 +184,7 @@ int cofusion_group_create(const cofusion_config* c, int sequences, cofusion_grou
     const CoFusion::Config d = to_config(c);
     try {
         cofusion_group* g = new cofusion_group{new CoFusionGroup(d, sequences), std::vector<cofusion_handle>()};
-        for (int s = 0; s < sequences; s++) g->handles.push_back(cofusion_handle{&g->g->sequence(s)});
+        for (int s = 0; s < sequences; s++) g->handles.push_back(cofusion_handle{&g->g->sequence(s), true});
         *out = g;
     }
     catch (const std::exception& e) { g_err = e.what(); return -1; }
@@ -208,11 +218,10 @@ int cofusion_group_process_frames_device(cofusion_group* g, const int64_t* ts, c
 
 int cofusion_rccl_unique_id(void* id128)
 {
-    // (ncclGetUniqueId directly: creating the id needs no context, and rank 0 calls this before any instance exists)
-    static_assert(sizeof(ncclUniqueId) == CF_RCCL_ID_BYTES, "ncclUniqueId is 128 bytes");
+    // (creating the id needs no context: rank 0 calls this before any instance exists.  Forwarded to the C-ABI library, the only one
+    // of the two that links RCCL)
     if (!id128) { g_err = "null id buffer"; return -1; }
-    const ncclResult_t r = ncclGetUniqueId(static_cast<ncclUniqueId*>(id128));
-    if (r != ncclSuccess) { g_err = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r); return -1; }
+    if (cf_rccl_unique_id(id128) != CF_OK) { g_err = "cf_rccl_unique_id (ncclGetUniqueId) failed"; return -1; }
     return 0;
 }
 int cofusion_init_rccl(cofusion_handle* h, const void* id128)

@@ -21,7 +21,7 @@ SYMBOLS = [
     "cf_rgba_to_intensity", "cf_sobel", "cf_project_cloud", "cf_icp_step", "cf_icp_step_band", "cf_rgb_residual", "cf_rgb_step",
     "cf_so3_step", "cf_odom_create", "cf_odom_destroy", "cf_odom_init_icp_model", "cf_odom_init_rgb_model",
     "cf_odom_init_rgb", "cf_odom_init_models_batch", "cf_odom_init_models_batch_frames", "cf_odom_init_first_rgb", "cf_odom_init_icp", "cf_so3_create", "cf_so3_destroy", "cf_so3_first_frame", "cf_so3_prealign", "cf_so3_commit", "cf_odom_set_prealignment", "cf_odom_get_incremental_transformation",
-    "cf_odom_track_batch_async", "cf_odom_fetch_result", "cf_odom_bind_frame_maps", "cf_odom_share_frame_maps", "cf_odom_set_culling", "cf_odom_set_band", "cf_set_collective", "cf_model_predict_indices_sharded", "cf_odom_buffer",
+    "cf_odom_track_batch_async", "cf_odom_fetch_result", "cf_odom_get_covariance", "cf_odom_bind_frame_maps", "cf_odom_share_frame_maps", "cf_odom_set_culling", "cf_odom_set_band", "cf_set_collective", "cf_model_predict_indices_sharded", "cf_odom_buffer",
     "cf_bilateral", "cf_model_create", "cf_model_destroy", "cf_model_initialise", "cf_model_count",
     "cf_model_predict_indices", "cf_model_predict_indices_tracked", "cf_model_index_keys", "cf_model_index_resolve", "cf_model_combined_predict", "cf_model_prefetch_fill_ratio", "cf_model_perform_fill_in", "cf_model_requires_fill_in",
     "cf_model_fuse", "cf_model_clean", "cf_model_download_map", "cf_model_upload_map", "cf_model_buffer",
@@ -52,7 +52,7 @@ HOST_SYMBOLS = [
     "cofusion_process_frame", "cofusion_process_frame_device", "cofusion_num_models", "cofusion_tick", "cofusion_model_info",
     "cofusion_model_download", "cofusion_model_icp_stats", "cofusion_model_cull_box", "cofusion_model_tracking_inputs", "cofusion_mask_device", "cofusion_context", "cofusion_set_crf",
     "cofusion_save_ply", "cofusion_export_poses", "cofusion_set_export_segmentation", "cofusion_klg_open", "cofusion_klg_next", "cofusion_klg_set_reference_compatible", "cofusion_klg_close",
-    "cofusion_klg_create", "cofusion_klg_write", "cofusion_klg_finish", "cofusion_debug_phase_ms", "cofusion_set_allreduce", "cofusion_set_allreduce_device", "cofusion_group_create", "cofusion_group_destroy", "cofusion_group_size", "cofusion_group_sequence", "cofusion_group_set_stream", "cofusion_group_process_frames", "cofusion_group_process_frames_device", "cofusion_rccl_unique_id", "cofusion_init_rccl", "cofusion_broadcast", "cofusion_model_owned",
+    "cofusion_klg_create", "cofusion_klg_write", "cofusion_klg_finish", "cofusion_debug_phase_ms", "cofusion_set_allreduce", "cofusion_set_allreduce_device", "cofusion_group_create", "cofusion_group_destroy", "cofusion_group_size", "cofusion_group_sequence", "cofusion_group_set_stream", "cofusion_group_process_frames", "cofusion_group_process_frames_device", "cofusion_rccl_unique_id", "cofusion_init_rccl", "cofusion_broadcast", "cofusion_model_owned", "cofusion_is_lost",
 ]
 _host = None
 

@@ -19,20 +19,18 @@ import torch
 import torch.distributed as dist
 
 
-def assign_models(model_ids: Sequence[int], world: int) -> Dict[int, List[int]]:
-    """Placement of active models on ranks: the background (id 0, by far the largest map) alone on rank 0
-    as long as there are enough ranks, objects round-robin over the remaining ranks."""
+def assign_models(model_ids: Sequence[int], world: int, colocate: bool = False) -> Dict[int, List[int]]:
+    """Placement of active models on ranks (host/CoFusion.h: Distributed::owner): the background (id 0, by far the largest map)
+    alone on rank 0 and object id k on rank 1 + (k - 1) % (world - 1); with `colocate` (cofusion_config.colocate_background,
+    BASELINE.json configs[3]: one object model per GPU) object id k on rank (k - 1) % world, the background sharing rank 0."""
     out: Dict[int, List[int]] = {r: [] for r in range(world)}
-    objs = [m for m in model_ids if m != 0]
-    if 0 in model_ids:
-        out[0].append(0)
-    if world == 1:
-        out[0].extend(objs)
-        return out
-    first = 1 if len(objs) >= world - 1 or world > 1 else 0
-    ranks = list(range(first, world)) or [0]
-    for k, m in enumerate(objs):
-        out[ranks[k % len(ranks)]].append(m)
+    for m in model_ids:
+        if world <= 1 or m == 0:
+            out[0].append(m)
+        elif colocate:
+            out[(m - 1) % world].append(m)
+        else:
+            out[1 + (m - 1) % (world - 1)].append(m)
     return out
 
 

@@ -36,6 +36,12 @@ typedef struct {
                                  * loop); needs cf_set_collective on the context (cofusion_context).  Default 0. */
     int enqueue_threads;        /* helper threads that enqueue the per-model surfel passes (one model's launch chain each) beside the calling
                                  * thread; 0 = none (default).  Results do not depend on it. */
+    int colocate_background;    /* model-parallel operation: 1 = object models round-robin over ALL ranks, the background shares rank 0
+                                 * (BASELINE.json configs[3]: one object model per GPU); 0 (default) = the background alone on rank 0 */
+    int reloc;                  /* CoFusion's `reloc` constructor argument (CoFusion.h:47): failure detection of the frame loop -- frames
+                                 * with a background ICP error >= 1e-4 or a pose-covariance diagonal entry > 1e-4 are not fused, after
+                                 * more than ten in a row the camera is lost (no fusion, the clock stops; CoFusion.cpp:225,301-338).
+                                 * cofusion_is_lost reports it.  Default 0. */
 } cofusion_config;
 
 void cofusion_default_config(cofusion_config *cfg);
@@ -52,6 +58,8 @@ int cofusion_process_frame_device(cofusion_handle *h, int64_t timestamp, const f
                                   const float *in_pose);
 int cofusion_num_models(cofusion_handle *h);
 int cofusion_tick(cofusion_handle *h);
+/* CoFusion::getLost (CoFusion.h:183-185): 1 while the camera is lost (cofusion_config.reloc) */
+int cofusion_is_lost(cofusion_handle *h);
 /* per model (list order, 0 = background): id, surfel count, pose T(model <- camera), confidence threshold */
 int cofusion_model_info(cofusion_handle *h, int index, unsigned *id, unsigned *count, float pose[16], float *conf_threshold);
 int cofusion_model_download(cofusion_handle *h, int index, float *surfels, uint32_t capacity, uint32_t *count);

@@ -252,6 +252,10 @@ int cf_odom_get_incremental_transformation(cf_odom *od, float trans[3], float ro
 int cf_odom_track_batch_async(cf_ctx *ctx, cf_odom *const *ods, int n, const float *const *poses_in /* n x [16] */,
                               const cf_track_opts *opts, float *const *icp_err_surfaces /* nullable entries */);
 int cf_odom_fetch_result(cf_odom *od, float trans[3], float rot[9], cf_track_stats *stats);
+/* RGBDOdometry::getCovariance (RGBDOdometry.h:60, RGBDOdometry.cpp:479: lastA.cast<double>().lu().inverse()) of a tracking call's
+ * statistics: partial-pivot LU inverse of the 6x6 normal matrix, row-major f64 [36], on the host (the caller already holds lastA).
+ * A singular lastA gives inf / NaN entries, as Eigen's does. */
+int cf_odom_get_covariance(const cf_track_stats *stats, double cov[36]);
 /* test access to internal device pyramids (same `which` numbering as the oracle's orc_odom_buffer) */
 /* share the frame-wide current vertex/normal pyramids between models (all models track the same frame,
  * cudafuncs.cu:119); pass NULL arrays to return to the odom-private maps written by cf_odom_init_icp */

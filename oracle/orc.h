@@ -134,6 +134,8 @@ typedef struct {
 /* trans[3]/rot[9] (row-major) in-out; err_surface nullable [H*W] */
 void orc_odom_get_incremental_transformation(orc_odometry *o, float trans[3], float rot[9], const orc_track_opts *opts,
                                              float *icp_err_surface, orc_track_stats *stats);
+/* RGBDOdometry::getCovariance (RGBDOdometry.cpp:479): lastA.cast<double>().lu().inverse(), row-major 6x6 in and out */
+void orc_covariance(const double lastA[36], double cov[36]);
 /* test access to internal pyramids: which = 0 vmap_curr,1 nmap_curr,2 vmap_g_prev,3 nmap_g_prev (planar f32),
  * 4 lastDepth,5 nextDepth (f32), 6 lastImage,7 nextImage,8 lastNextImage (u8), 9 dIdx,10 dIdy (s16) */
 const void *orc_odom_buffer(const orc_odometry *o, int which, int level);

@@ -9,10 +9,25 @@
  * Slic.cpp:33-46,73-75) and densecrf (martinruenz/densecrf fork, install.sh:84; call sites
  * Segmentation.cpp:221,436-437,452,462-470), neither of which is vendored.  They are replaced by their
  * published algorithms, stated here:
- *   SLIC  (Achanta et al.; gSLICr settings: 16 px superpixels on a regular grid, 5 iterations, RGB, coherence
- *         weight 0.6, no connectivity enforcement): 5 x {assign every pixel to the nearest of the 3x3
- *         neighbouring grid centres under D = dRGB^2/20^2 + 0.6 * dxy^2/16^2 (first minimum in dy,dx scan
- *         order); recentre from integer sums}.
+ *   SLIC  = gSLICr's engine as published (carlren/gSLICr: gSLICr_Lib/engines/gSLICr_seg_engine.cpp `Perform_Segmentation`,
+ *         gSLICr_seg_engine_GPU.cu constructor, gSLICr_seg_engine_shared.h), under the settings of Slic.cpp:33-43 (spixel_size 16,
+ *         coh_weight 0.6, no_iters 5, RGB, GIVEN_SIZE, no connectivity enforcement).  Restated statement by statement:
+ *           - init_cluster_centers_shared: centre k of grid cell (cx, cy) at pixel (cx*16 + 8, cy*16 + 8), colour of that pixel;
+ *           - schedule of Perform_Segmentation: init; assign; 5 x {update; assign}  -- SIX association passes, the labels are
+ *             those of the last one;
+ *           - find_center_association_shared: the pixel's own grid cell (x/16, y/16) and its 3x3 neighbours, i (dy) outer, j (dx)
+ *             inner, strict `<` (first minimum wins), distance compute_slic_distance =
+ *                 sqrtf(dcolor * max_color_dist + coh_weight * dxy * max_xy_dist)
+ *             with the constructor's normalisers max_color_dist = (5.0f / (1.7321f * 255))^2 (RGB case) and
+ *             max_xy_dist = (1.0f / (1.4142f * spixel_size))^2, all in f32;
+ *           - update_cluster_center + finalize_reduction_result_shared: centre and colour = f32 sum / (float)no_pixels over the
+ *             pixels carrying the label (their sums are integers < 2^24, so gSLICr's f32 block reduction is exact and equals the
+ *             integer sums used here); a cluster without pixels is left at centre (0,0), colour 0 (the reset value).
+ *         What is NOT restated because it cannot be known from here: nvcc's contraction of `a*b + c` into FMA inside
+ *         compute_slic_distance (this file, like every f32 expression of the oracle, is compiled without contraction), and image
+ *         sizes that are not multiples of 16 (gSLICr rounds the grid up, Slic.cpp:28-30 rounds it down and would index past its
+ *         tables; the pixel's cell is clamped to the last one here).  Until round 4 this stand-in used D = dRGB^2/20^2 +
+ *         0.6 dxy^2/16^2 and 5 association passes -- a colour : space ratio ten times gSLICr's.
  *   CRF   (Kraehenbuehl & Koltun 2011, as used through DenseCRF2D): mean-field with an EXACT evaluation of
  *         the two Gaussian kernels over the 1200 nodes (densecrf approximates them on a permutohedral
  *         lattice), symmetric normalisation D^-1/2 K D^-1/2, Potts compatibility.
@@ -40,8 +55,17 @@ void orc_slic(const uint8_t *rgba, int cols, int rows, int32_t *labels)
             float *k = c + (size_t)(cy * gx + cx) * 5;
             k[0] = (float)px; k[1] = (float)py; k[2] = (float)p[0]; k[3] = (float)p[1]; k[4] = (float)p[2];
         }
-    const float inv_color = 1.0f / (20.0f * 20.0f), inv_xy = 0.6f / ((float)SPIX * (float)SPIX);
-    for (int it = 0; it < iters; it++) {
+    /* seg_engine_GPU constructor: normalising factors, squared (f32 throughout) */
+    float max_color_dist = 5.0f / (1.7321f * 255), max_xy_dist = 1.0f / (1.4142f * SPIX);
+    max_color_dist *= max_color_dist; max_xy_dist *= max_xy_dist;
+    const float weight = 0.6f; /* Slic.cpp:37 coh_weight */
+    for (int it = 0; it <= iters; it++) {   /* Perform_Segmentation: assign; no_iters x {update; assign} */
+        if (it > 0)
+            for (int k = 0; k < K; k++) {   /* finalize_reduction_result_shared */
+                const long long *s = sum + (size_t)k * 6;
+                float *cc = c + (size_t)k * 5;
+                for (int q = 0; q < 5; q++) cc[q] = s[5] ? (float)s[q] / (float)s[5] : 0.0f;
+            }
         memset(sum, 0, sizeof(long long) * 6 * (size_t)K);
         for (int y = 0; y < rows; y++)
             for (int x = 0; x < cols; x++) {
@@ -49,7 +73,7 @@ void orc_slic(const uint8_t *rgba, int cols, int rows, int32_t *labels)
                 int cx0 = x / SPIX, cy0 = y / SPIX;
                 if (cx0 >= gx) cx0 = gx - 1;
                 if (cy0 >= gy) cy0 = gy - 1;
-                float best = FLT_MAX; int bl = cy0 * gx + cx0;
+                float best = 999999.9999f; int bl = cy0 * gx + cx0;
                 for (int dy = -1; dy <= 1; dy++)
                     for (int dx = -1; dx <= 1; dx++) {
                         const int cx = cx0 + dx, cy = cy0 + dy;
@@ -57,19 +81,14 @@ void orc_slic(const uint8_t *rgba, int cols, int rows, int32_t *labels)
                         const float *k = c + (size_t)(cy * gx + cx) * 5;
                         const float dr = (float)p[0] - k[2], dg = (float)p[1] - k[3], db = (float)p[2] - k[4];
                         const float ex = (float)x - k[0], ey = (float)y - k[1];
-                        const float d = (dr * dr + dg * dg + db * db) * inv_color + (ex * ex + ey * ey) * inv_xy;
+                        const float dcolor = dr * dr + dg * dg + db * db, dxy = ex * ex + ey * ey;
+                        const float d = sqrtf(dcolor * max_color_dist + weight * dxy * max_xy_dist);
                         if (d < best) { best = d; bl = cy * gx + cx; }
                     }
                 labels[(size_t)y * cols + x] = bl;
                 long long *s = sum + (size_t)bl * 6;
                 s[0] += x; s[1] += y; s[2] += p[0]; s[3] += p[1]; s[4] += p[2]; s[5] += 1;
             }
-        for (int k = 0; k < K; k++) {
-            const long long *s = sum + (size_t)k * 6;
-            if (s[5] == 0) continue;
-            float *cc = c + (size_t)k * 5;
-            for (int q = 0; q < 5; q++) cc[q] = (float)s[q] / (float)s[5];
-        }
     }
     free(c); free(sum);
 }

@@ -950,3 +950,41 @@ void orc_odom_get_incremental_transformation(orc_odometry *o, float trans[3], fl
         for (int i = 0; i < ORC_NUM_PYRS; i++) { uint8_t *t = o->lastNextImage[i]; o->lastNextImage[i] = o->nextImage[i]; o->nextImage[i] = t; }
     memcpy(trans, tcurr, 12); memcpy(rot, Rcurr, 36);
 }
+
+/* ------------------------------------------------------------- covariance (-rl) ---- */
+/* RGBDOdometry::getCovariance, RGBDOdometry.cpp:479: `lastA.cast<double>().lu().inverse()`.  Eigen's lu() is PartialPivLU: for every
+ * column k the row with the largest |entry| at or below the diagonal becomes the pivot row (first maximum wins), the column below
+ * the pivot is divided by it, the trailing block gets the rank-1 update; inverse() solves P A X = I column by column (unit-lower
+ * forward substitution, upper back substitution).  Eigen is not in the tree: the ORDER of the additions inside its triangular
+ * solves is not restated (it only matters in the last bits; the caller compares the diagonal with 1e-4, CoFusion.cpp:301-338).
+ * A zero pivot is divided by as it stands, like Eigen does: the result then holds inf / NaN, and `NaN > 1e-4` is false. */
+void orc_covariance(const double lastA[36], double cov[36])
+{
+    double lu[36];
+    int perm[6];
+    memcpy(lu, lastA, sizeof(lu));
+    for (int i = 0; i < 6; i++) perm[i] = i;
+    for (int k = 0; k < 6; k++) {
+        int piv = k; double big = fabs(lu[k * 6 + k]);
+        for (int r = k + 1; r < 6; r++) { const double a = fabs(lu[r * 6 + k]); if (a > big) { big = a; piv = r; } }
+        if (piv != k) {
+            for (int c = 0; c < 6; c++) { const double t = lu[k * 6 + c]; lu[k * 6 + c] = lu[piv * 6 + c]; lu[piv * 6 + c] = t; }
+            const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+        }
+        if (big != 0.0)   /* (Eigen skips the division of an all-zero column and records the singularity) */
+            for (int r = k + 1; r < 6; r++) lu[r * 6 + k] /= lu[k * 6 + k];
+        for (int r = k + 1; r < 6; r++)
+            for (int c = k + 1; c < 6; c++) lu[r * 6 + c] -= lu[r * 6 + k] * lu[k * 6 + c];
+    }
+    for (int j = 0; j < 6; j++) {
+        double x[6];
+        for (int i = 0; i < 6; i++) x[i] = (perm[i] == j) ? 1.0 : 0.0;   /* P e_j */
+        for (int i = 0; i < 6; i++)
+            for (int c = 0; c < i; c++) x[i] -= lu[i * 6 + c] * x[c];
+        for (int i = 5; i >= 0; i--) {
+            for (int c = i + 1; c < 6; c++) x[i] -= lu[i * 6 + c] * x[c];
+            x[i] /= lu[i * 6 + i];
+        }
+        for (int i = 0; i < 6; i++) cov[i * 6 + j] = x[i];
+    }
+}

@@ -25,6 +25,7 @@ void ref_odo_track(void* p, float* trans, float* rot_row_major, int rgb_only, fl
 
 namespace {
 bool g_reference_tracker = false;             // ref_cf_use_reference_tracker
+bool g_reloc = false;                         // ref_cf_set_reloc: the constructor's `reloc` argument (CoFusion.h:47) of the next instance
 orc_cam g_cam;
 int g_w = 0, g_h = 0;
 float g_outlier = 3.0f;                       // GUI default of the outlier coefficient (GUI.h:213), set through Model::GPUSetup
@@ -66,6 +67,14 @@ PinOdometry::PinOdometry(int width, int height, float cx, float cy, float fx, fl
     if (g_reference_tracker) ref = ref_odo_create(width, height, cx, cy, fx, fy);
 }
 PinOdometry::~PinOdometry() { orc_odom_destroy((orc_odometry*)orc); if (ref) ref_odo_destroy(ref); }
+Eigen::MatrixXd PinOdometry::getCovariance()
+{   // RGBDOdometry.cpp:479
+    double cov[36];
+    orc_covariance(lastA, cov);
+    Eigen::MatrixXd m(6, 6);
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) m(i, j) = cov[i * 6 + j];
+    return m;
+}
 void PinOdometry::initFirstRGB(GPUTexture* rgb)
 {
     orc_odom_init_first_rgb((orc_odometry*)orc, rgb->data<uint8_t>());
@@ -124,7 +133,8 @@ void Model::performTracking(bool frameToFrameRGB, bool rgbOnly, float icpWeight,
         ref_odo_init_rgb(r, rgb->data<uint8_t>());
         float trans[3] = {pose(0, 3), pose(1, 3), pose(2, 3)}, rot[9], stats[6];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rot[i * 3 + j] = pose(i, j);
-        ref_odo_track(r, trans, rot, rgbOnly ? 1 : 0, icpWeight, pyramid ? 1 : 0, fastOdom ? 1 : 0, so3 ? 1 : 0, impl->icp_error.data(), stats, nullptr, nullptr);
+        double lastb[6];
+        ref_odo_track(r, trans, rot, rgbOnly ? 1 : 0, icpWeight, pyramid ? 1 : 0, fastOdom ? 1 : 0, so3 ? 1 : 0, impl->icp_error.data(), stats, impl->odom->lastA, lastb);
         impl->odom->lastICPError = stats[0]; impl->odom->lastICPCount = stats[1];
         for (int i = 0; i < 3; i++) { pose(i, 3) = trans[i]; for (int j = 0; j < 3; j++) pose(i, j) = rot[i * 3 + j]; }
         return;
@@ -137,6 +147,7 @@ void Model::performTracking(bool frameToFrameRGB, bool rgbOnly, float icpWeight,
     orc_track_stats st;
     orc_odom_get_incremental_transformation(od, trans, rot, &o, impl->icp_error.data(), &st);
     impl->odom->lastICPError = st.last_icp_error; impl->odom->lastICPCount = st.last_icp_count;
+    memcpy(impl->odom->lastA, st.lastA, sizeof(st.lastA));
     for (int i = 0; i < 3; i++) { pose(i, 3) = trans[i]; for (int j = 0; j < 3; j++) pose(i, j) = rot[i * 3 + j]; }
 }
 void Model::predictIndices(int time, float depthCutoff, int timeDelta)
@@ -202,7 +213,7 @@ CoFusion::CoFusion(int width, int height, float fx, float fy, float cx, float cy
     : modelMatchingType(Model::MatchingType::Drost), newModelListeners(0), inactiveModelListeners(0), modelToModel(width, height, cx, cy, fx, fy),
       tick(1), timeDelta(2147483647 / 2) /* openLoop, MainController.cpp:328 */, icpCountThresh(40000), icpErrThresh(5e-05f), covThresh(1e-05f),
       deforms(0), fernDeforms(0), consSample(20), imageBuff(height / 20, width / 20), consBuff(height / 20, width / 20),
-      timesBuff(height / 20, width / 20), closeLoops(false), iclnuim(false), reloc(false), lost(false), lastFrameRecovery(false), trackingCount(0),
+      timesBuff(height / 20, width / 20), closeLoops(false), iclnuim(false), reloc(g_reloc), lost(false), lastFrameRecovery(false), trackingCount(0),
       maxDepthProcessed(20.0f), rgbOnly(false), icpWeight(icpThresh), pyramid(true), fastOdom(false), initConfThresGlobal(initConfidenceGlobal),
       initConfThresObject(initConfidenceObject), fernThresh(0.3095f), so3(so3_), frameToFrameRGB(false), depthCutoff(depthCut),
       modelSpawnOffset(modelSpawnOffset_), exportSegmentation(false)
@@ -256,6 +267,8 @@ void* ref_cf_create(int w, int h, float fx, float fy, float cx, float cy, float 
 void ref_cf_destroy(void* p) { delete (CoFusion*)p; }
 // 1: models created from now on track with the reference's own RGBDOdometry class instead of the oracle's restatement of it
 void ref_cf_use_reference_tracker(int on) { g_reference_tracker = on != 0; }
+void ref_cf_set_reloc(int on) { g_reloc = on != 0; }
+int ref_cf_lost(void* p) { return ((CoFusion*)p)->isLost() ? 1 : 0; }
 void ref_cf_set_tracking_options(void* p, int rgb_only, int pyramid, int fast_odom, int frame_to_frame_rgb)
 {
     ((CoFusion*)p)->setTrackingOptions(rgb_only != 0, pyramid != 0, fast_odom != 0, frame_to_frame_rgb != 0);

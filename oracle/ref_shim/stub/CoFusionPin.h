@@ -5,7 +5,8 @@
 // cut out of the file where it lies at build time -- behind this header.  The real CoFusion.h drags in OpenGL, Pangolin, the
 // deformation graph, the fern database and every shader wrapper; this header declares the class with the members those functions
 // use (names, types and defaults as in CoFusion.h:266-391 and the constructor's initialiser list, CoFusion.cpp:21-77) and
-// compile-only stand-ins for the collaborators of branches that are off in Co-Fusion (closeLoops, reloc).  The passes a frame
+// compile-only stand-ins for the collaborators of the loop-closure branch, which is off in Co-Fusion (closeLoops == false; the
+// relocalisation switch `reloc` is a constructor argument and pinned: ref_cf_set_reloc).  The passes a frame
 // consists of run on the CPU oracle (stub/Model/Model.h, ref_cofusion.cpp): the pin is about the ORDER and CONDITIONS of the
 // frame loop, i.e. SURVEY.md 8 row a17.
 #pragma once
@@ -90,6 +91,7 @@ class CoFusion {
     ModelList& getModels() { return models; }
     GPUTexture* maskTexture() { return textures[GPUTexture::MASK]; }
     int getTick() const { return tick; }
+    bool isLost() const { return lost; }           // CoFusion::getLost (CoFusion.cpp:846-848)
     Segmentation& segmentation() { return labelGenerator; }
     void setTrackingOptions(bool rgbOnly_, bool pyramid_, bool fastOdom_, bool frameToFrameRGB_)   // CoFusion::setRgbOnly / setPyramid / setFastOdom / setFrameToFrameRGB
     { rgbOnly = rgbOnly_; pyramid = pyramid_; fastOdom = fastOdom_; frameToFrameRGB = frameToFrameRGB_; }

@@ -40,13 +40,14 @@ class PinOdometry {
     ~PinOdometry();
     PinOdometry(const PinOdometry&) = delete;
     void initFirstRGB(GPUTexture* rgb);
-    Eigen::MatrixXd getCovariance() { return Eigen::MatrixXd(); }
+    Eigen::MatrixXd getCovariance();                       // ref_cofusion.cpp: orc_covariance of the last tracking call's lastA
     template <class... A> void initICPModel(A&&...) {}   // (dead loop-closure branch of processFrame)
     template <class... A> void initRGBModel(A&&...) {}
     template <class... A> void initICP(A&&...) {}
     template <class... A> void initRGB(A&&...) {}
     template <class... A> void getIncrementalTransformation(A&&...) {}
     float lastICPError = 0, lastICPCount = 0;
+    double lastA[36] = {0};
     void* orc = nullptr;  // orc_odometry*
     void* ref = nullptr;  // the reference's own RGBDOdometry behind ref_odo.cpp's C entry points (ref_cf_use_reference_tracker)
 };

@@ -10,8 +10,8 @@ import numpy as np
 W, H = 160, 128
 # name -> (objects in the scene, frames, conf_global, spawn offset, ground-truth masks, multiple models)
 SCENARIOS = {
-    "crf_two_objects": (2, 14, 0.5, 3, False, True),
-    "crf_four_objects": (4, 18, 0.5, 1, False, True),
+    "crf_two_objects": (2, 20, 0.5, 3, False, True),
+    "crf_four_objects": (4, 26, 0.5, 1, False, True),
     "gt_masks_three_objects": (3, 10, 0.5, 2, True, True),
     "gt_masks_fill_in_tracking": (3, 8, 10.0, 2, True, True),
     "static": (2, 5, 10.0, 20, False, False),
@@ -32,6 +32,16 @@ OPTIONS = {
     "icp_only": dict(icp_weight=100.0),
 }
 FACADE_ONLY = set(OPTIONS)
+# CoFusion's `reloc` constructor argument (-rl; CoFusion.cpp:225, 301-338, 463, 495): frames whose background tracking is out of bounds
+# are not fused, after more than ten in a row the camera is lost (no fusion, the clock stops).  BLACKOUT: frames in which the sensor is
+# covered (no depth, black image) -- the tracker finds no correspondence, lastICPError is NaN, the covariance of a zero matrix is NaN / inf.
+SCENARIOS.update({
+    "reloc_static_lost": (0, 22, 0.5, 20, False, False),    # 13 covered frames: lost from the 11th on, and for good (no fern database)
+    "reloc_static_recovers": (0, 14, 0.5, 20, False, False),  # 4 covered frames: skipped, then tracking and fusion resume
+    "reloc_two_objects": (2, 14, 0.5, 3, False, True),        # the switch on a multi-model run
+})
+RELOC = {"reloc_static_lost", "reloc_static_recovers", "reloc_two_objects"}
+BLACKOUT = {"reloc_static_lost": range(5, 18), "reloc_static_recovers": range(5, 9), "reloc_two_objects": range(9, 11)}
 
 
 def _sha(a):
@@ -46,6 +56,8 @@ def frames_of(name):
     out = []
     for t in range(n_frames):
         d, rgb, label, _ = sc.render(cam, t, noise=True)
+        if t in BLACKOUT.get(name, ()):
+            d = np.zeros_like(d); rgb = np.zeros_like(rgb)
         out.append((d, rgb, synth.rgb_to_rgba(rgb), (label * 40).astype(np.uint8) if use_gt else None))
     return cam, out
 
@@ -62,14 +74,14 @@ def run_reference(name):
     import refcofusion
     _, _, conf_global, spawn, _, multi = SCENARIOS[name]
     cam, frames = frames_of(name)
-    cf = refcofusion.RefCoFusion(cam, conf_global=conf_global, spawn_offset=spawn, multi=multi, **OPTIONS.get(name, {}))
+    cf = refcofusion.RefCoFusion(cam, conf_global=conf_global, spawn_offset=spawn, multi=multi, reloc=name in RELOC, **OPTIONS.get(name, {}))
     rows = []
     for t, (d, rgb, _, gt) in enumerate(frames):
         cf.process_frame(d, rgb, gt_mask=gt, timestamp=t, in_pose=injected_pose(name, t))
         ms = [cf.model(i) for i in range(cf.num_models)]
         rows.append(dict(ids=[m["id"] for m in ms], counts=[m["count"] for m in ms], poses=[_sha(m["pose"]) for m in ms],
                          surfels=[_sha(m["surfels"]) for m in ms], conf=[float(m["conf_threshold"]) for m in ms],
-                         unseen=[m["unseen"] for m in ms], mask=_sha(cf.mask()), tick=cf.tick,
+                         unseen=[m["unseen"] for m in ms], mask=_sha(cf.mask()), tick=cf.tick, lost=int(cf.lost),
                          pose_log=[m["last_pose_log"].copy() for m in ms]))
     return rows
 
@@ -80,20 +92,20 @@ def run_oracle(name):
     cam, frames = frames_of(name)
     rows = []
     if multi:
-        cf = om.MultiPipeline(cam, conf_global=conf_global, spawn_offset=spawn)
+        cf = om.MultiPipeline(cam, conf_global=conf_global, spawn_offset=spawn, reloc=name in RELOC)
         for d, _, rgba, gt in frames:
             cf.process_frame(d, rgba, gt_mask=gt)
             ms = cf.models
             rows.append(dict(ids=[m.id for m in ms], counts=[m.surfels.shape[0] for m in ms], poses=[_sha(m.pose) for m in ms],
                              surfels=[_sha(m.surfels) for m in ms], conf=[float(np.float32(m.conf_threshold)) for m in ms],
-                             unseen=[m.unseen for m in ms], mask=_sha(cf.mask), tick=cf.tick))
+                             unseen=[m.unseen for m in ms], mask=_sha(cf.mask), tick=cf.tick, lost=int(cf.reloc.lost)))
     else:
         import orc_pipeline as op
-        cf = op.StaticPipeline(cam, conf_global=conf_global)
+        cf = op.StaticPipeline(cam, conf_global=conf_global, reloc=name in RELOC)
         for t, (d, _, rgba, _) in enumerate(frames):
             cf.process_frame(d, rgba, in_pose=injected_pose(name, t))
             rows.append(dict(ids=[0], counts=[cf.surfels.shape[0]], poses=[_sha(cf.pose)], surfels=[_sha(cf.surfels)],
-                             conf=[float(np.float32(conf_global))], unseen=[0], mask=_sha(cf.mask), tick=cf.tick))
+                             conf=[float(np.float32(conf_global))], unseen=[0], mask=_sha(cf.mask), tick=cf.tick, lost=int(cf.reloc.lost)))
     return rows
 
 
@@ -120,7 +132,7 @@ def run_reference_isolated(name):
     return json.loads(line[len("CFPIN_JSON"):])
 
 
-def differences(ref_rows, orc_rows, keys=("ids", "counts", "poses", "surfels", "unseen", "mask", "tick")):
+def differences(ref_rows, orc_rows, keys=("ids", "counts", "poses", "surfels", "unseen", "mask", "tick", "lost")):
     out = []
     for t, (a, b) in enumerate(zip(ref_rows, orc_rows)):
         for k in keys:

@@ -4,7 +4,9 @@ kernels under the CPU emulator, f32 tree reductions (reduce.cu:90-185), Eigen-st
 poses of every frame are stored.  tests/test_cpu_refpin.py plays the same streams with the oracle's exact-integer tracker (the bits the
 HIP path reproduces, tests/test_configs_gpu.py) and bounds the trajectory difference (ATE).
 
-The emulator needs about a minute per tracked model and frame, so this runs once here (CPU container) and the result is committed:
+The emulator needs ~10 s per tracked model and frame (round 4: its fiber switch is a dozen instructions of our own instead of
+swapcontext's system call, oracle/ref_shim/cusim.cpp -- 30x; until then ~110 s at 160x128 and ~5 min at 640x480), so this runs once here
+(CPU container, the scenarios side by side: ~25 min) and the result is committed:
 
     python tests/golden/make_ref_traj_golden.py [scenario ...]      ->  tests/golden/ref_traj_v1.npz
 """
@@ -35,9 +37,9 @@ SCENARIOS = {
 }
 
 
-SCENARIOS["static_camera_640"] = (0, 12, 10.0, 20, False)   # the static scenario at BASELINE.json's own frame size (~5 min per tracked frame)
-SCENARIOS["crf_two_objects_640"] = (2, 24, 0.5, 3, True)    # ... and the motion-CRF scenario: at this size the objects cover ~15 000 pixels each
-SCENARIOS["gt_masks_two_objects_640"] = (2, 16, 0.5, 3, True, True)   # ... and ground-truth masks: three models in lock-step from frame 6 on
+SCENARIOS["static_camera_640"] = (0, 100, 10.0, 20, False)  # the static scenario at BASELINE.json's own frame size: 100 frames, 0.40 m of camera path
+SCENARIOS["crf_two_objects_640"] = (2, 60, 0.5, 3, True)    # ... and the motion-CRF scenario: at this size the objects cover ~15 000 pixels each
+SCENARIOS["gt_masks_two_objects_640"] = (2, 60, 0.5, 3, True, True)   # ... and ground-truth masks: three models in lock-step from frame 6 to 53
 SIZES = {"static_camera_640": (640, 480), "crf_two_objects_640": (640, 480), "gt_masks_two_objects_640": (640, 480)}
 
 
@@ -49,27 +51,10 @@ def uses_gt_masks(name):
     return len(SCENARIOS[name]) > 5 and bool(SCENARIOS[name][5])
 
 
-def object_frames_before_loss(poses, ids, slot, jump=0.05):
-    """At 160x128 an object covers a few hundred pixels and the reference's own tracker loses it now and then (its pose jumps by 10-25 cm
-    between frames on an object that moves 1.5 cm, or no pose is ever accepted): from there on the iteration is chaotic and no two
-    arithmetics agree.  Frames of model slot `slot` before the first frame-to-frame jump of more than `jump` metres in the
-    reference-arithmetic run -- the frames in which object poses are compared."""
-    out = []
-    for t in range(poses.shape[0]):
-        if ids[t, slot] < 0:
-            continue
-        if t > 0 and ids[t - 1, slot] == ids[t, slot] and np.linalg.norm(poses[t, slot, :3, 3] - poses[t - 1, slot, :3, 3]) > jump:
-            break
-        out.append(t)
-    return out
-
-
-# Object trajectories that ARE comparable: model slot -> bound in metres on every frame of the run.  With ground-truth masks at 640x480
-# the first object (slot 1, ~5 000 surfels, a steady 1 cm per frame) is tracked stably by the reference's own class, and the oracle / the
-# HIP facade stay within 3.5e-4 m of it over all 13 frames of its life; the second object's own track oscillates by +-2 cm per frame in the
-# reference run and the arithmetics differ by up to 2.2 cm on it -- reported by the tests, not asserted.  Scenarios not listed here use
-# object_frames_before_loss.
-OBJECT_BOUNDS = {"gt_masks_two_objects_640": {1: 1e-3}}
+# Frames over which the model lists of a run with the exact-integer tracker must equal those of the reference-arithmetic run where the
+# lists DO depend on tracked poses (motion CRF: spawn / deactivation are threshold decisions, they may shift by a frame under different
+# rounding).  One model or ground-truth masks: the whole run (tests/trajpin.py).
+MIN_LIST_PREFIX = {"crf_two_objects": 8, "crf_two_objects_640": 10}
 
 
 # camera ATE bounds (rmse, per frame) in metres.  BASELINE.json's bar is 1e-3 m ATE; the per-frame bound is twice that.  The ground-truth

@@ -97,10 +97,10 @@ class OModel:
     def combined_predict(self, tick):
         self.pred = op.combined_predict(self.surfels, self.pose, self.cam, self.w, self.h, 20.0, self.conf_threshold, tick, tick, TIME_DELTA)
 
-    def perform_fill_in(self, rgba, depth_filt):
+    def perform_fill_in(self, rgba, depth_filt, lost=False):
         if self.fill_in_enabled:
             img, vc, nr, _ = self.pred
-            self.fill = op.fill_in(vc, nr, img, depth_filt, rgba, self.cam)
+            self.fill = op.fill_in(vc, nr, img, depth_filt, rgba, self.cam, pass_geom=lost, pass_rgb=lost)
 
     def fuse(self, tick, rgba, mask, depth, depth_filt, weight_mult):
         idx, vc, ct, nr = self.index
@@ -116,7 +116,8 @@ class OModel:
 
 class MultiPipeline:
     def __init__(self, cam, depth_cutoff=5.0, icp_weight=10.0, conf_global=10.0, conf_object=0.01, outlier_coeff=3.0, so3=True,
-                 spawn_offset=22, seg_params=None, max_models=16):
+                 spawn_offset=22, seg_params=None, max_models=16, reloc=False):
+        self.reloc = op.Reloc(reloc)
         self.ocam = orc.Cam(cam.fx, cam.fy, cam.cx, cam.cy)
         self.w, self.h = cam.width, cam.height
         self.depth_cutoff, self.icp_weight, self.outlier, self.so3 = depth_cutoff, icp_weight, outlier_coeff, so3
@@ -146,7 +147,7 @@ class MultiPipeline:
     def _predict(self, rgba, depth_filt):
         for m in self.models:
             m.combined_predict(self.tick)
-            m.perform_fill_in(rgba, depth_filt)
+            m.perform_fill_in(rgba, depth_filt, self.reloc.lost)
 
     def _track(self, depth_filt, rgba):
         pyr = orc.depth_pyramid(depth_filt)
@@ -174,6 +175,8 @@ class MultiPipeline:
             self.global_model.odom.init_first_rgb(rgba)
         else:
             self._track(depth_filt, rgba)
+            tracking_ok = self.reloc.after_tracking(self.global_model.stats)   # CoFusion.cpp:225, 301-338 (the order against the
+            # segmentation block does not matter: nothing in between reads trackingCount / lost)
             if self.spawn_offset < self.model_spawn_offset:
                 self.spawn_offset += 1
             allow_new = self.spawn_offset >= self.model_spawn_offset and len(self.models) < self.max_models
@@ -215,9 +218,11 @@ class MultiPipeline:
                 m = self.models[i]
                 m.conf_threshold = np.float32(min(max(m.conf_threshold, np.float32(md[i]["avgConfidence"])), np.float32(9.0)))
             self._predict(rgba, depth_filt)
-            for m in self.models: m.predict_indices(self.tick)
-            for m in self.models: m.fuse(self.tick, rgba, self.mask, depth, depth_filt, 1.0)
-            for m in self.models: m.predict_indices(self.tick)
-            for m in self.models: m.clean(self.tick, depth_filt, self.mask, self.outlier)
+            if tracking_ok and not self.reloc.lost:   # CoFusion.cpp:463
+                for m in self.models: m.predict_indices(self.tick)
+                for m in self.models: m.fuse(self.tick, rgba, self.mask, depth, depth_filt, 1.0)
+                for m in self.models: m.predict_indices(self.tick)
+                for m in self.models: m.clean(self.tick, depth_filt, self.mask, self.outlier)
         self._predict(rgba, depth_filt)
-        self.tick += 1
+        if not self.reloc.lost:                       # CoFusion.cpp:495
+            self.tick += 1

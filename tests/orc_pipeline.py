@@ -65,6 +65,42 @@ def fill_in(pv, pn, pimg, depth, rgba, cam, pass_geom=False, pass_rgb=False):
     return ov, on, oi
 
 
+def covariance(lastA):
+    """RGBDOdometry::getCovariance (RGBDOdometry.cpp:479) of a tracker's last normal matrix (row-major 6x6 f64)"""
+    a = np.ascontiguousarray(np.asarray(lastA, np.float64).reshape(36))
+    out = np.zeros(36, np.float64)
+    lib.orc_covariance(a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out.reshape(6, 6)
+
+
+class Reloc:
+    """CoFusion's `reloc` switch (constructor argument, CoFusion.h:47): trackingOk / trackingCount / lost of CoFusion::processFrame
+    (CoFusion.cpp:225, 301-338).  Without the fern database (closeLoops is off in Co-Fusion) lastFrameRecovery never becomes true,
+    so a lost camera stays lost."""
+
+    def __init__(self, on):
+        self.on, self.lost, self.tracking_count = bool(on), False, 0
+
+    def after_tracking(self, stats):
+        """-> trackingOk of this frame (the background's tracker statistics); updates trackingCount / lost"""
+        if not self.on:
+            return True
+        ok = float(np.float32(stats.last_icp_error)) < 1e-04           # (a float compared with the double literal; NaN: false)
+        if not self.lost:
+            cov = covariance(stats.lastA)
+            for i in range(6):
+                if cov[i, i] > 1e-04:
+                    ok = False
+                    break
+            if not ok:
+                self.tracking_count += 1
+                if self.tracking_count > 10:
+                    self.lost = True
+            else:
+                self.tracking_count = 0
+        return ok
+
+
 def requires_fill_in(pimg, ratio=0.75):
     h, w = pimg.shape[:2]
     return bool(lib.orc_requires_fill_in(P(u8(pimg)), w, h, C.c_float(ratio)))
@@ -102,7 +138,8 @@ class StaticPipeline:
 
     TIME_DELTA = 2 ** 31 // 2 - 1  # openLoop: std::numeric_limits<int>::max() / 2 (MainController.cpp:328)
 
-    def __init__(self, cam, depth_cutoff=5.0, icp_weight=10.0, conf_global=10.0, outlier_coeff=3.0, so3=True):
+    def __init__(self, cam, depth_cutoff=5.0, icp_weight=10.0, conf_global=10.0, outlier_coeff=3.0, so3=True, reloc=False):
+        self.reloc = Reloc(reloc)
         self.cam = orc.Cam(cam.fx, cam.fy, cam.cx, cam.cy)
         self.w, self.h = cam.width, cam.height
         self.depth_cutoff = depth_cutoff
@@ -126,7 +163,7 @@ class StaticPipeline:
         self.pred = combined_predict(self.surfels, self.pose, self.cam, self.w, self.h, self.max_depth_processed,
                                      self.conf_threshold, self.tick, self.tick, self.TIME_DELTA)
         img, vc, nr, _ = self.pred
-        self.fill = fill_in(vc, nr, img, depth_filt, rgba, self.cam)
+        self.fill = fill_in(vc, nr, img, depth_filt, rgba, self.cam, pass_geom=self.reloc.lost, pass_rgb=self.reloc.lost)
 
     def process_frame(self, depth, rgba, in_pose=None):
         depth_filt = bilateral(depth, self.depth_cutoff)
@@ -150,18 +187,22 @@ class StaticPipeline:
                 tr, rot, self.stats = self.odom.track(self.pose[:3, 3], self.pose[:3, :3], icp_weight=self.icp_weight, so3=self.so3)
                 self.pose = np.eye(4, dtype=np.float32)
                 self.pose[:3, :3] = rot; self.pose[:3, 3] = tr
+                tracking_ok = self.reloc.after_tracking(self.stats)   # CoFusion.cpp:225, 301-338
             else:
                 self.pose = f32(in_pose).copy(); self.last_pose = self.pose.copy()
+                tracking_ok = True
             self._predict(rgba, depth_filt)
-            idx, vc, ct, nr = predict_indices(self.surfels, self.pose, self.cam, self.w, self.h, self.max_depth_processed, self.tick,
-                                              self.TIME_DELTA)
-            wgt = fusion_weight(self.pose, self.last_pose, 1.0)
-            self.surfels, new = fuse(self.surfels, idx, vc, nr, rgba, depth, depth_filt, self.mask, self.pose, self.cam, self.tick,
-                                     wgt, 0, self.max_depth_processed)
-            idx, vc, ct, nr = predict_indices(self.surfels, self.pose, self.cam, self.w, self.h, self.max_depth_processed, self.tick,
-                                              self.TIME_DELTA)
-            self.surfels = clean(self.surfels, new, idx, vc, ct, depth_filt, self.mask, self.pose, self.cam, self.tick,
-                                 self.conf_threshold, self.outlier_coeff, self.TIME_DELTA, 0)
+            if tracking_ok and not self.reloc.lost:                   # CoFusion.cpp:463
+                idx, vc, ct, nr = predict_indices(self.surfels, self.pose, self.cam, self.w, self.h, self.max_depth_processed, self.tick,
+                                                  self.TIME_DELTA)
+                wgt = fusion_weight(self.pose, self.last_pose, 1.0)
+                self.surfels, new = fuse(self.surfels, idx, vc, nr, rgba, depth, depth_filt, self.mask, self.pose, self.cam, self.tick,
+                                         wgt, 0, self.max_depth_processed)
+                idx, vc, ct, nr = predict_indices(self.surfels, self.pose, self.cam, self.w, self.h, self.max_depth_processed, self.tick,
+                                                  self.TIME_DELTA)
+                self.surfels = clean(self.surfels, new, idx, vc, ct, depth_filt, self.mask, self.pose, self.cam, self.tick,
+                                     self.conf_threshold, self.outlier_coeff, self.TIME_DELTA, 0)
         self._predict(rgba, depth_filt)
-        self.tick += 1
+        if not self.reloc.lost:                                       # CoFusion.cpp:495
+            self.tick += 1
         return self.pose.copy(), self.surfels.shape[0]

@@ -13,11 +13,12 @@ from orc import P, f32, u8
 
 class RefCoFusion:
     def __init__(self, cam, conf_global=10.0, conf_object=0.01, depth_cutoff=5.0, icp_weight=10.0, so3=True, spawn_offset=20, multi=True,
-                 rgb_only=False, pyramid=True, fast_odom=False, frame_to_frame_rgb=False, reference_tracker=False):
+                 rgb_only=False, pyramid=True, fast_odom=False, frame_to_frame_rgb=False, reference_tracker=False, reloc=False):
         """reference_tracker: every model tracks with the reference's own RGBDOdometry class (its CUDA kernels under the emulator, f32 tree
         reductions, Core/Utils/RGBDOdometry.cpp:217-477) instead of the oracle's restatement with exact integer sums"""
         self.lib = ref.lib()
         self.lib.ref_cf_use_reference_tracker(int(reference_tracker))
+        self.lib.ref_cf_set_reloc(int(reloc))   # the constructor's `reloc` argument (CoFusion.h:47; -rl)
         self.lib.ref_cf_create.restype = C.c_void_p
         self.w, self.h = cam.width, cam.height
         self.h_ = self.lib.ref_cf_create(self.w, self.h, C.c_float(cam.fx), C.c_float(cam.fy), C.c_float(cam.cx), C.c_float(cam.cy),
@@ -41,6 +42,10 @@ class RefCoFusion:
     @property
     def tick(self):
         return self.lib.ref_cf_tick(C.c_void_p(self.h_))
+
+    @property
+    def lost(self):
+        return bool(self.lib.ref_cf_lost(C.c_void_p(self.h_)))
 
     def model(self, i):
         mid = C.c_uint(); conf = C.c_float(); unseen = C.c_uint(); nlog = C.c_int()

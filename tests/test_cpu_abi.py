@@ -111,14 +111,15 @@ def test_sqrt_gate_bounds_terminate_and_decide_exactly(libs):
 
 
 def test_library_links_rccl_and_resolves_it(libs):
-    """RCCL is called from inside the library (csrc/rccl_comm.hip, host/cofusion_c.cpp): both shared objects import the nccl* entry
-    points, and they resolve when the libraries are loaded (no GPU needed to create a unique id is NOT assumed: only symbol resolution
-    and the argument checks are exercised here)."""
-    for path, needed in ((libs.LIB_PATH, {"ncclAllReduce", "ncclBroadcast", "ncclCommInitRank", "ncclCommDestroy", "ncclGetUniqueId"}),
-                         (libs.HOST_LIB_PATH, {"ncclGetUniqueId"})):
+    """RCCL is called from inside the C-ABI library (csrc/rccl_comm.hip): it imports the nccl* entry points, and they resolve when the
+    library is loaded (no GPU needed to create a unique id is NOT assumed: only symbol resolution and the argument checks are exercised
+    here).  The facade library reaches RCCL only through the C-ABI (cofusion_rccl_unique_id forwards to cf_rccl_unique_id): ONE library
+    depends on RCCL."""
+    for path, needed, exact in ((libs.LIB_PATH, {"ncclAllReduce", "ncclBroadcast", "ncclCommInitRank", "ncclCommDestroy", "ncclGetUniqueId"}, False),
+                                (libs.HOST_LIB_PATH, set(), True)):
         out = subprocess.check_output(["nm", "-D", "--undefined-only", path]).decode()
         imported = set(re.findall(r" U (nccl\w+)", out))
-        assert needed <= imported, f"{os.path.basename(path)} imports {sorted(imported)}"
+        assert needed <= imported and (not exact or imported == needed), f"{os.path.basename(path)} imports {sorted(imported)}"
     lib = libs.load()          # dlopen succeeded: librccl.so.1 was found and every nccl symbol bound
     host = libs.load_host()
     assert lib.cf_rccl_init(None, None, 0, 1) != 0 and lib.cf_rccl_allreduce(None, None, 0, 0, None) != 0
@@ -140,3 +141,39 @@ def test_division_by_the_image_width_is_exact(tmp_path):
                            os.path.join(root, "tests", "native", "idiv_check.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout + r.stderr
+
+
+def test_covariance_of_the_normal_matrix_matches_the_oracle(libs):
+    """cf_odom_get_covariance (RGBDOdometry::getCovariance, RGBDOdometry.cpp:479: partial-pivot LU inverse of lastA) is host arithmetic:
+    against the oracle's statement of it on well-conditioned, nearly singular, pivoting and all-zero matrices (the covered-sensor case of
+    the -rl branch: NaN pattern included), bit for bit."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    from co_fusion_amd import api
+    lib = libs.load()
+    rng = np.random.default_rng(11)
+    mats = []
+    for n in (6, 7, 40, 5000):
+        J = rng.normal(size=(n, 6)) * rng.uniform(0.1, 30.0, size=6)
+        mats.append(J.T @ J)
+    P = np.eye(6)[[3, 0, 5, 1, 4, 2]]
+    mats += [P @ mats[2], np.zeros((6, 6)), np.diag([1.0, 2.0, 0.0, 4.0, 5.0, 6.0]), mats[0] * 1e-30]
+    for A in mats:
+        st = api.TrackStats()
+        a = np.ascontiguousarray(A, np.float64).reshape(36)
+        for i in range(36):
+            st.lastA[i] = a[i]
+        got = np.zeros(36, np.float64); want = np.zeros(36, np.float64)
+        assert lib.cf_odom_get_covariance(C.byref(st), got.ctypes.data_as(C.c_void_p)) == 0
+        orc.lib.orc_covariance(a.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p))
+        assert got.tobytes() == want.tobytes() or (np.isnan(got) == np.isnan(want)).all() and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+    ok = np.linalg.inv(mats[2])
+    st = api.TrackStats()
+    for i in range(36):
+        st.lastA[i] = mats[2].reshape(36)[i]
+    got = np.zeros(36)
+    lib.cf_odom_get_covariance(C.byref(st), got.ctypes.data_as(C.c_void_p))
+    assert np.allclose(got.reshape(6, 6), ok, rtol=1e-9, atol=0)
+    assert lib.cf_odom_get_covariance(None, got.ctypes.data_as(C.c_void_p)) != 0

@@ -93,6 +93,9 @@ def test_assign_models_and_bands_single_process():
     assert parallel.assign_models([0, 1, 2], 1) == {0: [0, 1, 2]}
     pl = parallel.assign_models([0, 1, 2, 3, 4, 5, 6, 7, 8], 8)
     assert pl[0] == [0] and all(len(v) >= 1 for v in pl.values())
+    # BASELINE.json configs[3]: 8 object models one per GPU, the background sharing rank 0 (cofusion_config.colocate_background)
+    pc = parallel.assign_models([0, 1, 2, 3, 4, 5, 6, 7, 8], 8, colocate=True)
+    assert pc[0] == [0, 1] and all(pc[r] == [r + 1] for r in range(1, 8))
     bands = parallel.row_bands(480, 8)
     assert bands[0].start == 0 and bands[-1].stop == 480 and sum(len(b) for b in bands) == 480
 
@@ -112,3 +115,21 @@ def test_bench_gpus_2_respawns_and_reports_two_ranks():
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2
     assert out["scaling"] == "strong" and out["config"]["parallel"] == "models"   # default partition of N > 1: models over ranks
     assert out["ms_per_step"] >= 2.0 * 0.9        # MAX over ranks: rank 1 sleeps 2 ms per step
+
+
+def test_bench_gpus_8_defaults_to_configs3_with_one_object_per_rank():
+    """the driver's `--gpus 8` line runs BASELINE.json's own 8-GPU configuration (configs[3]: 8 objects + background, one object model
+    per GPU) and says so; up to 5 GPUs the metric's configs[2].  --dry-run: no GPU here."""
+    import json
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.parse(["--gpus", "1"]).workload == "objects4" and bench.parse(["--gpus", "4"]).workload == "objects4"
+    assert bench.parse(["--gpus", "8"]).workload == "objects8" and bench.parse(["--gpus", "8", "--workload", "objects4"]).workload == "objects4"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and "configs[3]" in out["config"]["workload"]
+    pl = out["config"]["placement"]
+    assert len(pl) == 9 and pl["0"] == 0 and sorted(pl[str(k)] for k in range(1, 9)) == list(range(8)), pl

@@ -49,6 +49,9 @@ def _run(S, W, H, n_obj, frames, use_gt=False, device_frames=False, **kw):
                 singles[s].process_frame(depths[s], rgbs[s], mask=None if masks is None else masks[s], timestamp=t)
         _compare(group, singles, t, f"{S} x {n_obj} objects")
         most = max(most, max(q.num_models for q in singles))
+    # a sequence of a group is stepped by the group only: its borrowed handle refuses a frame of its own
+    with pytest.raises(facade.CoFusionError, match="lock-step group"):
+        group.sequences[0].process_frame(depths[0], rgbs[0], timestamp=frames)
     group.close()
     for q in singles:
         q.close()

@@ -242,6 +242,21 @@ def test_screen_box_culling_leaves_the_gauss_newton_loop_bit_identical():
     otr, orot, ost = od.track(pose[:3, 3], pose[:3, :3])
     assert t1.tobytes() == np.asarray(otr, np.float32).tobytes() and r1.tobytes() == np.asarray(orot, np.float32).tobytes()
     assert s1.last_icp_count == ost.last_icp_count
+    # a SECOND tracking call on the same preparation (retries, A/B loops): the bounding-box accumulator was latched and zeroed by the first
+    # call, so the second one must fall back to the whole image instead of reading an empty box and culling every workgroup
+    def run_twice(cull):
+        g = api.Odometry(ctx)
+        g.set_culling(cull)
+        g.init_first_rgb(d(fp["rgba0"])); g.init_icp_model(d(v4), d(n4), pose); g.init_rgb_model(d(fp["img"]))
+        g.init_icp(ctx.depth_pyramid(d(fp["d1"])), 20.0); g.init_rgb(d(fp["rgba1"]))
+        g.track(pose[:3, 3], pose[:3, :3])
+        out = g.track(pose[:3, 3], pose[:3, :3])
+        g.close()
+        return out
+    ta, ra, sa = run_twice(False)
+    tb, rb, sb = run_twice(True)
+    assert ta.tobytes() == tb.tobytes() and ra.tobytes() == rb.tobytes() and sa.last_icp_count == sb.last_icp_count > 100
+    assert list(sb.cull_box) == [0, 0, W - 1, H - 1], "second call on one preparation: whole image"
     # an empty prediction: everything culled
     z4 = np.zeros_like(v4)
     t2, r2, s2, _ = run(z4, z4, True)
