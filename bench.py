@@ -404,10 +404,7 @@ def main(argv=None):
             boxed.append(max(0, min(b[2], W - 1) - max(b[0], 0) + 1) * max(0, min(b[3], H - 1) - max(b[1], 0) + 1))
         processed = 24 * W * H + 24 * sum(boxed) + 11 * n_models * W * H
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=pmc_traffic(args.workload, W * H),
-                        traffic_source="HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this workload (profiles/r03_icp_traffic.json: "
-                                       "FETCH_SIZE x2 + WRITE_SIZE x1, factors measured by tools/microbench/fetch_calib.hip); counters cannot be read "
-                                       "from inside the benchmark process",
+                        traffic=pmc_traffic(args.workload, W * H)[0], traffic_source=pmc_traffic(args.workload, W * H)[1],
                         kernel="cf::icp_reduce_kernel<PPT,%d>: ICP reduction of all lock-step models || their RGB residual passes, pyramid level 0"
                                % (4 if n_models > 1 else 0),
                         launches=int(prof.icp_launches), avg_us=round(avg_us, 3), bytes_per_launch=bpl,
@@ -698,6 +695,8 @@ def reference_trajectory_check(args, multi):
         return dict(rmse=round(rep["rmse"], 9), max=round(rep["max"], 9), frames=rep["frames"], scenario=name,
                     lists_identical_frames=rep["lists_identical_frames"], count_first_diff_frame=rep["count_first_diff_frame"],
                     count_max_abs_diff=rep["count_max_abs_diff"], count_max_rel_diff=round(rep["count_max_rel_diff"], 7),
+                    background_count_max_abs_diff=rep["background_count_max_abs_diff"],
+                    background_count_max_rel_diff=round(rep["background_count_max_rel_diff"], 7),
                     objects={k: dict(frames=v["frames"], max_m=round(v["max_m"], 7), bound_m=v["bound_m"]) for k, v in rep["objects"].items()},
                     bound_m=1e-3, source="live: HIP facade on the scenario's stream against tests/golden/ref_traj_v1.npz (frame loop tracked by the "
                                          "reference's own RGBDOdometry class, oracle/ref_shim)")
@@ -745,18 +744,35 @@ def secondary_static(args, torch, facade, local_rank, warmup=30, steps=120):
         return dict(error=str(e))
 
 
+def kernel_source_sha():
+    """sha256 of the file that holds the dominant kernel: a committed counter pass is only quoted for the build it was taken on"""
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "co_fusion_amd", "csrc", "track_reduce.hip"), "rb").read()).hexdigest()
+
+
 def pmc_traffic(workload, pixels):
-    """HBM-side bytes per launch of the level-0 ICP kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE cannot be collected from inside this process); null when no pass matches this workload/shape."""
-    for name in ("r03_icp_traffic.json", "r02_icp_traffic.json", "r01_icp_traffic.json"):
+    """(HBM-side bytes per launch of the level-0 ICP kernel, where it comes from) from the committed rocprofv3 PMC passes -- FETCH_SIZE and
+    WRITE_SIZE cannot be collected from inside this process.  The newest pass is used, and only if it was taken on THIS source of the
+    kernel (kernel_source_sha256 in the JSON, tools/make_traffic_json.py): a stale figure is reported as null, with the reason."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_icp_traffic.json")), reverse=True)
+    sha = kernel_source_sha()
+    for path in files:
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", name)))
-        except OSError:
+            t = json.load(open(path))
+        except (OSError, ValueError):
             continue
         for e in (t if isinstance(t, list) else [t]):
             if e.get("workload") == workload and e.get("pixels") == pixels:
-                return int(e["traffic_bytes_per_launch"])
-    return None
+                name = os.path.basename(path)
+                if e.get("kernel_source_sha256") != sha:
+                    return None, (f"profiles/{name} was taken on another build of csrc/track_reduce.hip (sha256 {str(e.get('kernel_source_sha256'))[:12]} != "
+                                  f"{sha[:12]}): not quoted; re-run tools/gpu_pmc.sh + tools/make_traffic_json.py")
+                return int(e["traffic_bytes_per_launch"]), (f"HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this workload on this build (profiles/{name}: "
+                                                            "FETCH_SIZE x2 + WRITE_SIZE x1, factors measured by tools/microbench/fetch_calib.hip); counters cannot "
+                                                            "be read from inside the benchmark process")
+        break   # only the newest pass counts
+    return None, "no committed counter pass for this workload"
 
 
 def native_oracle():

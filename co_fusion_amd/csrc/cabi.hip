@@ -62,14 +62,9 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     memset(ctx->h_state_pool, 0, sizeof(OdomDev) * cf_ctx::kStateSlots);
     if (int r = dmalloc(ctx, &ctx->d_model_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_so3_sync, (size_t)ctx->cfg.max_models + 1)) return r;
-    if (int r = dmalloc(ctx, &ctx->d_pre_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
-    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pre_ptrs), sizeof(OdomDev*) * (ctx->cfg.max_models + 1)));
-    if (const char* e = getenv("CF_GN_MODE")) ctx->gn_mode = atoi(e);  // diagnostic: 0 = three launches per iteration
-    if (const char* e = getenv("CF_ICP_LAUNCH")) {  // diagnostic: "threads,pixels_per_thread"
-        int t = 0, p = 0;
-        if (sscanf(e, "%d,%d", &t, &p) == 2 && cf_set_icp_launch(ctx, t, p) != CF_OK) { ctx->set_error("CF_ICP_LAUNCH: bad value"); return CF_EINVAL; }
-    }
-    if (const char* e = getenv("CF_ICP_ARITH")) {  // "product" (default) / "gram": rounding specification of the ICP sums (cf_set_icp_arith)
+    // the ONE environment switch of the library: CF_ICP_ARITH = "product" (default) / "gram", the rounding specification of the ICP sums
+    // for every context of the process (cf_set_icp_arith sets it per context; launch shape and data path have setters only)
+    if (const char* e = getenv("CF_ICP_ARITH")) {
         if (cf_set_icp_arith(ctx, (!strcmp(e, "gram") || !strcmp(e, "1")) ? CF_ICP_ARITH_GRAM : (!strcmp(e, "product") || !strcmp(e, "0")) ? CF_ICP_ARITH_PRODUCT : -1) != CF_OK) {
             ctx->set_error("CF_ICP_ARITH: product | gram"); return CF_EINVAL;
         }
@@ -95,7 +90,6 @@ void cf_destroy(cf_ctx* ctx)
     (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_cand_scratch);
     (void)hipFree(ctx->d_state_pool); (void)hipHostFree(ctx->h_state_pool);
     (void)hipHostFree(ctx->h_scratch_state); (void)hipHostFree(ctx->h_model_ptrs); (void)hipHostFree(ctx->h_out);
-    (void)hipFree(ctx->d_pre_ptrs); (void)hipHostFree(ctx->h_pre_ptrs);
     if (ctx->prof.events) {
         for (int i = 0; i < ctx->prof.capacity; i++) (void)hipEventDestroy(ctx->prof.events[i]);
         delete[] ctx->prof.events;
@@ -729,80 +723,6 @@ int cf_odom_init_first_rgb(cf_odom* od, const uint8_t* rgba)
     return CF_OK;
 }
 
-// ---- SO(3) pre-alignment of a frame (cf_so3) ----
-int cf_so3_create(cf_ctx* ctx, cf_so3** out)
-{
-    if (!ctx || !out) return CF_EINVAL;
-    cf_so3* h = new cf_so3();
-    h->ctx = ctx; *out = h;
-    const int W = ctx->cfg.width, H = ctx->cfg.height;
-    for (int i = 0; i < CF_NUM_PYRS; i++) {
-        const size_t n = (size_t)(W >> i) * (H >> i);
-        if (int r = dmalloc(ctx, &h->last[i], n)) return r;
-        if (int r = dmalloc(ctx, &h->next[i], n)) return r;
-    }
-    if (int r = dmalloc(ctx, &h->d_state, 1)) return r;
-    if (int r = dmalloc(ctx, &h->d_ptr, 1)) return r;
-    if (int r = dmalloc(ctx, &h->d_sync, 1)) return r;
-    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&h->h_state), sizeof(OdomDev), hipHostMallocCoherent));
-    memset(h->h_state, 0, sizeof(OdomDev));
-    HIPCHK(ctx, hipMemcpyAsync(h->d_ptr, &h->d_state, sizeof(OdomDev*), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return CF_OK;
-}
-void cf_so3_destroy(cf_so3* h)
-{
-    if (!h) return;
-    (void)hipStreamSynchronize(h->ctx->stream);
-    for (int i = 0; i < CF_NUM_PYRS; i++) { (void)hipFree(h->last[i]); (void)hipFree(h->next[i]); }
-    (void)hipFree(h->d_state); (void)hipFree(h->d_ptr); (void)hipFree(h->d_sync); (void)hipHostFree(h->h_state);
-    delete h;
-}
-static int so3_pyramid(cf_so3* h, const uint8_t* rgba, uint8_t* const* dst)
-{
-    cf_ctx* ctx = h->ctx; hipStream_t s = ctx->cur();
-    const int W = ctx->cfg.width, H = ctx->cfg.height;
-    launch_intensity(s, rgba, W, H, dst[0]);   // imageBGRToIntensity + pyrDownUcharGauss x2, as initFirstRGB / populateRGBDData
-    for (int i = 0; i + 1 < CF_NUM_PYRS; i++) launch_pyrdown_u8(s, dst[i], W >> i, H >> i, dst[i + 1]);
-    LAUNCHCHK(ctx);
-    return CF_OK;
-}
-int cf_so3_first_frame(cf_so3* h, const uint8_t* rgba)
-{   // RGBDOdometry::initFirstRGB (RGBDOdometry.cpp:206-215) for every tracker this frame will spawn
-    if (!h || !rgba) return CF_EINVAL;
-    h->have_last = true; h->pending = false;
-    return so3_pyramid(h, rgba, h->last);
-}
-int cf_so3_prealign(cf_so3* h, const uint8_t* rgba)
-{
-    if (!h || !rgba) return CF_EINVAL;
-    cf_ctx* ctx = h->ctx;
-    if (!h->have_last) { ctx->set_error("cf_so3_prealign: no previous frame (cf_so3_first_frame)"); return CF_ESTATE; }
-    if (int r = so3_pyramid(h, rgba, h->next)) return r;
-    OdomDev* st = h->h_state;
-    for (int i = 0; i < CF_NUM_PYRS; i++) { st->lastNextImage[i] = h->last[i]; st->nextImage[i] = h->next[i]; }
-    st->intr = cf_cam{ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy};
-    st->width = ctx->cfg.width; st->height = ctx->cfg.height; st->cull = 0;
-    memset(&st->stats, 0, sizeof(st->stats));
-    HIPCHK(ctx, hipMemcpyAsync(h->d_state, st, sizeof(OdomDev), hipMemcpyHostToDevice, ctx->cur()));
-    launch_so3_frame(ctx->cur(), h->d_ptr, h->d_sync);
-    LAUNCHCHK(ctx);
-    h->pending = true;
-    return CF_OK;
-}
-int cf_so3_commit(cf_so3* h)
-{   // the image swap after getIncrementalTransformation (RGBDOdometry.cpp:469-473): the pre-aligned frame becomes the last one
-    if (!h) return CF_EINVAL;
-    if (h->pending) { for (int i = 0; i < CF_NUM_PYRS; i++) std::swap(h->last[i], h->next[i]); h->pending = false; }
-    return CF_OK;
-}
-int cf_odom_set_prealignment(cf_odom* od, cf_so3* h)
-{
-    if (!od || (h && h->ctx != od->ctx)) return CF_EINVAL;
-    od->pre = h;
-    return CF_OK;
-}
-
 int cf_odom_init_icp(cf_odom* od, const float* const depth_pyr[CF_NUM_PYRS], float depth_cutoff)
 {  // RGBDOdometry.cpp:110-118
     if (!od || !depth_pyr) return CF_EINVAL;
@@ -915,7 +835,11 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
     h->distThres = od->distThres; h->angleThres = od->angleThres; h->sobelScale = od->sobelScale;
     h->maxDepthDeltaRGB = od->maxDepthDeltaRGB; h->icpWeight = opts->icp_weight;
     h->icp = icp; h->rgb = rgb; h->rgbOnly = opts->rgb_only;
-    static const bool no_box = getenv("CF_NO_SCREEN_BOX") != nullptr;  // diagnostics: A/B of the screen-box culling on one box
+#ifdef CF_ABLATE
+    static const bool no_box = getenv("CF_NO_SCREEN_BOX") != nullptr;  // diagnostics build: A/B of the screen-box culling on one box
+#else
+    constexpr bool no_box = false;
+#endif
     // the screen box the previous tracking call ended with sizes this call's launches (launch_icp_kernel_arith); the pinned host state
     // holds it once that call's results were fetched
     if (h->cull && !ctx->state_readback_pending) memcpy(od->box_hint, h->stats.cull_box, sizeof(od->box_hint));
@@ -954,8 +878,12 @@ static void fill_rgb_args(cf_ctx* ctx, cf_odom* const* ods, int n, RgbArgs out[3
 
 static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3])
 {
-    static const bool no_zcull = getenv("CF_NO_ZCULL") != nullptr;  // diagnostics: A/B of the depth-interval culling on one box
+#ifdef CF_ABLATE
+    static const bool no_zcull = getenv("CF_NO_ZCULL") != nullptr;  // diagnostics build: A/B of the depth-interval culling on one box
     static const bool no_occ = getenv("CF_NO_OCC") != nullptr;      // ... and of the occupancy look-up
+#else
+    constexpr bool no_zcull = false, no_occ = false;
+#endif
     const cf_cam intr = {ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy};
     for (int l = 0; l < CF_NUM_PYRS; l++) {
         IcpArgs& a = out[l];
@@ -1009,14 +937,7 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
             HIPCHK(ctx, hipMemcpyAsync(ods[m]->d_state, ods[m]->h_state, sizeof(OdomDev), hipMemcpyHostToDevice, ctx->stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_model_ptrs, ctx->h_model_ptrs, sizeof(OdomDev*) * n, hipMemcpyHostToDevice, ctx->stream));
-    // frame pre-alignments (cf_so3): when every tracker of the batch has one enqueued, the SO(3) iterations are not repeated here
-    bool use_pre = opts->so3 != 0;
-    for (int m = 0; m < n; m++) use_pre = use_pre && ods[m]->pre && ods[m]->pre->pending;
-    if (use_pre) {
-        for (int m = 0; m < n; m++) ctx->h_pre_ptrs[m] = ods[m]->pre->d_state;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_pre_ptrs, ctx->h_pre_ptrs, sizeof(OdomDev*) * n, hipMemcpyHostToDevice, ctx->stream));
-    }
-    const bool so3_here = opts->so3 != 0 && !use_pre;
+    const bool so3_here = opts->so3 != 0;
     const bool icp = !opts->rgb_only && opts->icp_weight > 0;
     const bool rgb = opts->rgb_only || opts->icp_weight < 100;
     IcpArgs icp_args[3];
@@ -1036,8 +957,7 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     cf::ProfSink* prof = nullptr;
     if (ctx->prof.enabled > 0 && (ctx->prof_calls++ % (unsigned)ctx->prof.enabled) == 0) prof = &ctx->prof;
     if (!launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, any_split ? &hook : nullptr, icp_args, rgb_args, n,
-                         ctx->cfg.width, ctx->cfg.height, so3_here, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, prof, h_states,
-                         use_pre ? ctx->d_pre_ptrs : nullptr)) {
+                         ctx->cfg.width, ctx->cfg.height, so3_here, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, prof, h_states)) {
         ctx->set_error("tracking: the registered collective failed inside the Gauss-Newton loop");
         return CF_ESTATE;
     }
@@ -1163,7 +1083,11 @@ int cf_odom_bench_icp(cf_odom* od, int level, int iters, float* avg_us)
 {
     if (!od || level < 0 || level >= CF_NUM_PYRS || iters <= 0 || !avg_us) return CF_EINVAL;
     cf_ctx* ctx = od->ctx;
-    const char* ab = getenv("CF_ICP_ABLATE");
+#ifdef CF_ABLATE
+    const char* ab = getenv("CF_ICP_ABLATE");   // diagnostics build: ablation bits of the launch (track_reduce.hip: ABL)
+#else
+    const char* ab = nullptr;
+#endif
     IcpArgs all[3];
     cf_odom* ods[1] = {od};
     fill_icp_args(ctx, ods, 1, all);

@@ -33,7 +33,6 @@ struct cf_model {
     // same for the fill-in ratio of the latest splat prediction (computed right after combinedPredict)
     bool ratio_valid = false;
     hipEvent_t ratio_event = nullptr;
-    float* d_tinv = nullptr;          // [16] device-resident inverse pose of cf_model_predict_indices_tracked
     float* buf[2] = {nullptr, nullptr};  // ping-pong surfel buffers (Model::vbos[2])
     int target = 0;
     float* staged = nullptr;          // clean staging [max_surfels + N/4]
@@ -122,7 +121,6 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     if (int r = dmalloc(ctx, &m->offsets, M + Q)) return r;
     if (int r = dmalloc(ctx, &m->block_sums, (M + Q) / 2048 + N / 2048 + 16)) return r;
     if (int r = dmalloc(ctx, &m->d_count, 1)) return r;
-    if (int r = dmalloc(ctx, &m->d_tinv, 16)) return r;
     if (int r = dmalloc(ctx, &m->d_nfresh, 1)) return r;
     if (int r = dmalloc(ctx, &m->d_tmp2, 4)) return r;
     if (int r = dmalloc(ctx, &m->records, N * 12)) return r;
@@ -172,7 +170,7 @@ void cf_model_destroy(cf_model* m)
     void* ptrs[] = {m->buf[0], m->buf[1], m->staged, m->flags, m->offsets, m->block_sums, m->d_count, m->d_nfresh, m->d_tmp2, m->records,
                     m->fresh, m->new_flags, m->new_offsets, m->owner, m->fb_rec, m->fb_raw, m->fb_filt, m->keys, m->index, m->vertConf,
                     m->colorTime, m->normRad, m->splat_image, m->splat_vertex, m->splat_normal, m->splat_time, m->fill_vertex,
-                    m->fill_normal, m->fill_image, m->tcx, m->tcy, m->rays, m->d_tinv};
+                    m->fill_normal, m->fill_image, m->tcx, m->tcy, m->rays};
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(m->h_counts);
     if (m->count_event) (void)hipEventDestroy(m->count_event);
@@ -257,23 +255,6 @@ int cf_model_predict_indices(cf_model* m, const float pose[16], int time, float 
     if (int r = count_bound(m, &nb)) return r;
     launch_predict_indices(ctx->cur(), m->buf[m->target], m->d_count, nb, t_inv, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
                            maxDepth, time, timeDelta, m->keys, m->index, m->vertConf, m->colorTime, m->normRad);
-    LAUNCHCHK(ctx);
-    return CF_OK;
-}
-
-// predictIndices under the pose a tracker has just computed, WITHOUT the host having seen that pose: the transform is derived on the
-// device from the tracker's state (Rcurr | tcurr as the last solve of the Gauss-Newton schedule left them; the same statement as
-// inv44f, so the index map has the bits of cf_model_predict_indices(pose fetched by cf_odom_fetch_result)).  The frame loop enqueues
-// every model's first index map right behind the tracking launches, beside the segmentation, instead of behind the frame's host wait.
-int cf_model_predict_indices_tracked(cf_model* m, cf_odom* od, int time, float maxDepth, int timeDelta)
-{
-    if (!m || !od || m->ctx != od->ctx) return CF_EINVAL;
-    cf_ctx* ctx = m->ctx;
-    uint32_t nb = 0;
-    if (int r = count_bound(m, &nb)) return r;
-    launch_pose_tinv(ctx->cur(), od->d_state, m->d_tinv);
-    launch_predict_indices(ctx->cur(), m->buf[m->target], m->d_count, nb, nullptr, ctx_cam(ctx), ctx->cfg.width, ctx->cfg.height,
-                           maxDepth, time, timeDelta, m->keys, m->index, m->vertConf, m->colorTime, m->normRad, m->d_tinv);
     LAUNCHCHK(ctx);
     return CF_OK;
 }

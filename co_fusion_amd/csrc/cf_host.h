@@ -29,14 +29,12 @@ struct cf_ctx {
     cf::OdomDev* h_scratch_state = nullptr;  // pinned
     cf::OdomDev** d_model_ptrs = nullptr;
     cf::OdomDev** h_model_ptrs = nullptr;  // pinned
-    const cf::OdomDev** d_pre_ptrs = nullptr;   // per tracker of a batch: the frame pre-alignment it adopts
-    const cf::OdomDev** h_pre_ptrs = nullptr;   // pinned
     uint8_t* d_cand_scratch = nullptr;
     cf::So3Sync* d_so3_sync = nullptr;  // [max_models]
     int gn_mode = 1;                    // launch_gn_track mode (1: record slots between the residual pass and the RGB step)
     // device / pinned-host pools of the trackers' state structs: a batch of trackers is uploaded / read back with ONE
     // copy over its slot range instead of one copy per tracker
-    static constexpr int kStateSlots = 64;
+    static constexpr int kStateSlots = 256;  // (up to 255 models per sequence; trackers beyond the pool keep state blocks of their own)
     cf::OdomDev* d_state_pool = nullptr;
     cf::OdomDev* h_state_pool = nullptr;  // pinned
     bool slot_used[kStateSlots]{};
@@ -63,19 +61,6 @@ struct cf_ctx {
     void set_error(const std::string& m);
 };
 extern "C" int cf_wait_stream(cf_ctx* ctx);   // the frame's host wait (cabi.hip)
-
-// SO(3) pre-alignment of a frame, ahead of (and shared by) the trackers of that frame: RGBDOdometry.cpp:239-310 reads the previous and
-// the new frame's level-2 intensity images only
-struct cf_so3 {
-    cf_ctx* ctx = nullptr;
-    uint8_t* last[3]{};             // intensity pyramid of the last TRACKED frame (every tracker's lastNextImage)
-    uint8_t* next[3]{};             // ... of the frame being pre-aligned
-    cf::OdomDev* d_state = nullptr;   // the kernel's state block: images, intrinsics, size in; rotation + statistics out
-    cf::OdomDev* h_state = nullptr;   // pinned
-    cf::OdomDev** d_ptr = nullptr;    // one-entry model list
-    cf::So3Sync* d_sync = nullptr;
-    bool have_last = false, pending = false;   // pending: a pre-alignment of `next` is enqueued and not yet committed
-};
 
 // Device-resident RGBDOdometry (Core/Utils/RGBDOdometry.h:78-137)
 struct cf_odom {
@@ -122,5 +107,4 @@ struct cf_odom {
     float angleSqLt = 0, distSqLe = 0;  // exact radicand bounds of the two ICP gates
     float minGrad[3]{};
     bool pending_so3_swap = false;
-    cf_so3* pre = nullptr;           // cf_odom_set_prealignment: adopt this frame pre-alignment instead of iterating per tracker
 };

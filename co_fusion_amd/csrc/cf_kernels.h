@@ -257,9 +257,7 @@ struct GnHook { int (*fn)(void* user, int op, void* dev_buf, uint64_t words, voi
 bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */, So3Sync* so3_syncs /* [n] */,
                      const GnHook* hook, const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3,
                      bool pyramid, bool fast_odom, bool rgb, bool icp, int mode, ProfSink* prof,
-                     OdomDev* const* h_states = nullptr /* [n] pinned host copies the last solve publishes to */,
-                     const OdomDev* const* d_pre = nullptr /* device array [n]: frame pre-alignments to adopt (with so3 == false) */);
-void launch_so3_frame(hipStream_t s, OdomDev* const* d_model, So3Sync* sync);
+                     OdomDev* const* h_states = nullptr /* [n] pinned host copies the last solve publishes to */);
 float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, int ablate, int reps, hipEvent_t e0, hipEvent_t e1);
 float sqrt_gate_lt(float T);  // smallest x with sqrtf(x) >= T
 float sqrt_gate_le(float T);  // largest x with sqrtf(x) <= T
@@ -288,15 +286,13 @@ void launch_feedback(hipStream_t s, const uint8_t* rgba, const float* depth, int
 void launch_scatter_records(hipStream_t s, const float* rec, const unsigned* flags, const unsigned* offsets, long long n, float* out,
                             unsigned out_base);
 void launch_init(hipStream_t s, const float* raw, const float* filt, const unsigned* raw_count, long long max_n, float* out);
-// t_inv_dev (nullable): the transform as 16 floats in device memory (launch_pose_tinv) instead of the host array t_inv (then nullable)
 void launch_index_keys(hipStream_t s, const float* surfels, const unsigned* count, unsigned id_begin, unsigned id_end, const float t_inv[16],
-                       cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, const float* t_inv_dev = nullptr);
+                       cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys);
 void launch_index_resolve(hipStream_t s, const float* surfels, const float t_inv[16], int cols, int rows, unsigned long long* keys,
-                          unsigned* index, float* vertConf, float* colorTime, float* normRad, const float* t_inv_dev = nullptr);
+                          unsigned* index, float* vertConf, float* colorTime, float* normRad);
 void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                             int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, unsigned* index,
-                            float* vertConf, float* colorTime, float* normRad, const float* t_inv_dev = nullptr);
-void launch_pose_tinv(hipStream_t s, const OdomDev* state, float* t_inv_dev /* [16] */);
+                            float* vertConf, float* colorTime, float* normRad);
 void launch_splat_rays(hipStream_t s, cf_cam cam, int cols, int rows, float* rays /* [rows*cols*4] */);
 void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                              int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,

@@ -24,7 +24,10 @@ using namespace cf;
 namespace cf {
 
 constexpr int kSpix = 16;
-constexpr int kMaxL = 16;  // labels incl. the "new model" label
+constexpr int kMaxL = 256;  // label capacity of the kernels' static tables (labels incl. the "new model" label): model ids are 8 bits and 255
+                           // marks a rejected superpixel, the reference's own limit (CoFusion.cpp:631-634, Segmentation.cpp).  A segmenter's
+                           // buffers are sized for cf_segmenter::Lcap = the context's max_models (cf_config), 16 by default.
+constexpr int kAccTile = 16;  // models per pass of the accumulation kernel (their pointers travel in the kernel arguments up to this many)
 
 // ---------------------------------------------------------------------------------- SLIC ----
 __global__ void slic_init_kernel(const uchar4* __restrict__ rgba, int cols, int gx, int K, float* __restrict__ centres)
@@ -103,7 +106,8 @@ __device__ __forceinline__ long long q32(float v)
 
 struct AccArgs {
     const int* labels; const float* depth;
-    const float* icp[kMaxL]; const float4* vconf[kMaxL];
+    const float* icp[kAccTile]; const float4* vconf[kAccTile];   // the first kAccTile models' images (kernel arguments: no pointer chasing)
+    const float* const* icp_dev; const float4* const* vconf_dev;  // all n_models of them in device memory when there are more
     int n_models, cols, rows, gx, gy;
     unsigned* spix_count;            // [K]
     unsigned* depth_count;           // [K]
@@ -117,7 +121,7 @@ __global__ void __launch_bounds__(256) seg_accumulate_kernel(const AccArgs a)
     __shared__ int s_lab[9];
     __shared__ unsigned s_cnt[9], s_dcnt[9];
     __shared__ unsigned long long s_dsum[9];
-    __shared__ unsigned long long s_icp[kMaxL][9], s_conf[kMaxL][9];
+    __shared__ unsigned long long s_icp[kAccTile][9], s_conf[kAccTile][9];
     const int cx0 = blockIdx.x, cy0 = blockIdx.y, t = threadIdx.x;
     const int K = a.gx * a.gy;
     if (t < 9) {
@@ -125,7 +129,7 @@ __global__ void __launch_bounds__(256) seg_accumulate_kernel(const AccArgs a)
         s_lab[t] = (cx < 0 || cy < 0 || cx >= a.gx || cy >= a.gy) ? -1 : cy * a.gx + cx;
         s_cnt[t] = 0; s_dcnt[t] = 0; s_dsum[t] = 0;
     }
-    for (int k = t; k < kMaxL * 9; k += 256) { s_icp[k / 9][k % 9] = 0; s_conf[k / 9][k % 9] = 0; }
+    for (int k = t; k < kAccTile * 9; k += 256) { s_icp[k / 9][k % 9] = 0; s_conf[k / 9][k % 9] = 0; }
     __syncthreads();
     const int x = cx0 * kSpix + (t & 15), y = cy0 * kSpix + (t >> 4);
     const int q = y * a.cols + x;
@@ -136,19 +140,34 @@ __global__ void __launch_bounds__(256) seg_accumulate_kernel(const AccArgs a)
     atomicAdd(&s_cnt[slot], 1u);
     const float d = a.depth[q];
     if (d > 0.02f) { atomicAdd(&s_dcnt[slot], 1u); atomicAdd(&s_dsum[slot], (unsigned long long)q32(d)); }
-    for (int m = 0; m < a.n_models; m++) {
-        atomicAdd(&s_icp[m][slot], (unsigned long long)q32(a.icp[m][q]));
-        atomicAdd(&s_conf[m][slot], (unsigned long long)q32(a.vconf[m][q].w));
+    // the models in tiles of kAccTile (one pass for up to 16 models: what a frame normally has)
+    for (int m0 = 0; m0 < a.n_models; m0 += kAccTile) {
+        const int nm = min(kAccTile, a.n_models - m0);
+        if (m0 > 0) {
+            __syncthreads();
+            for (int k = t; k < kAccTile * 9; k += 256) { s_icp[k / 9][k % 9] = 0; s_conf[k / 9][k % 9] = 0; }
+            __syncthreads();
+        }
+        for (int m = 0; m < nm; m++) {
+            const float* icp = a.n_models <= kAccTile ? a.icp[m] : a.icp_dev[m0 + m];
+            const float4* vc = a.n_models <= kAccTile ? a.vconf[m] : a.vconf_dev[m0 + m];
+            atomicAdd(&s_icp[m][slot], (unsigned long long)q32(icp[q]));
+            atomicAdd(&s_conf[m][slot], (unsigned long long)q32(vc[q].w));
+        }
+        __syncthreads();
+        if (t < 9 && s_lab[t] >= 0) {
+            const int L = s_lab[t];
+            for (int m = 0; m < nm; m++) {
+                if (s_icp[m][t]) atomicAdd(&a.icp_sum[(size_t)(m0 + m) * K + L], s_icp[m][t]);
+                if (s_conf[m][t]) atomicAdd(&a.conf_sum[(size_t)(m0 + m) * K + L], s_conf[m][t]);
+            }
+        }
     }
     __syncthreads();
     if (t < 9 && s_lab[t] >= 0) {
         const int L = s_lab[t];
         if (s_cnt[t]) atomicAdd(&a.spix_count[L], s_cnt[t]);
         if (s_dcnt[t]) { atomicAdd(&a.depth_count[L], s_dcnt[t]); atomicAdd(&a.depth_sum[L], s_dsum[t]); }
-        for (int m = 0; m < a.n_models; m++) {
-            if (s_icp[m][t]) atomicAdd(&a.icp_sum[(size_t)m * K + L], s_icp[m][t]);
-            if (s_conf[m][t]) atomicAdd(&a.conf_sum[(size_t)m * K + L], s_conf[m][t]);
-        }
     }
 }
 
@@ -231,11 +250,11 @@ __global__ void __launch_bounds__(256) crf_init_kernel(const float* __restrict__
     if (i >= n) return;
     float mx = -unary[i * L];
     for (int l = 1; l < L; l++) if (-unary[i * L + l] > mx) mx = -unary[i * L + l];
-    float e[kMaxL], s = 0;
-    for (int l = 0; l < L; l++) { e[l] = det_expf(-unary[i * L + l] - mx); s += e[l]; }
-    for (int l = 0; l < L; l++) Q[i * L + l] = e[l] / s;
+    float s = 0;
+    for (int l = 0; l < L; l++) s += det_expf(-unary[i * L + l] - mx);
+    for (int l = 0; l < L; l++) Q[i * L + l] = det_expf(-unary[i * L + l] - mx) / s;   // (the same expression: the same bits as the summand)
 }
-// one mean-field step, part 1: chunk partials of K1*Q and K2*Q; partial[((c*n + i)*2 + which)*kMaxL + l].
+// one mean-field step, part 1: chunk partials of K1*Q and K2*Q; partial[((c*n + i)*2 + which)*L + l].
 // One lane per (node i, chunk c, label l) -- grid (n/64, chunks, labels): the sums inside a chunk are sequential by definition, so
 // the only parallelism is across nodes, chunks and labels, and with one lane per (node, chunk) only ~300 waves existed for 1024
 // SIMDs.  The chunk is walked five nodes at a time so that the kernel-matrix loads of a group are in flight together (the sums
@@ -269,29 +288,31 @@ __global__ void __launch_bounds__(64) crf_message_kernel(int L, int n, const flo
         a += K1t[j * n + i] * q;
         b += K2t[j * n + i] * q;
     }
-    float* out = partial + ((size_t)(c * n + i) * 2) * kMaxL;
-    out[l] = a; out[kMaxL + l] = b;
+    float* out = partial + ((size_t)(c * n + i) * 2) * L;
+    out[l] = a; out[L + l] = b;
 }
 static void launch_crf_message(hipStream_t st, dim3 grid, int L, int n, const float* K1t, const float* K2t, const float* Q, float* partial)
 {
     crf_message_kernel<<<dim3(grid.x, grid.y, L), 64, 0, st>>>(L, n, K1t, K2t, Q, partial);
 }
-// part 2: chunk totals in chunk order, unary, softmax over the labels.  Thread (node g, label l): 16 nodes x 16 label
-// slots per workgroup; the 32 chunk partials of a (node, label) are loaded independently and summed in chunk order,
-// the softmax runs over the node's LDS row exactly like expAndNormalize.
+// part 2: chunk totals in chunk order, unary, softmax over the labels.  Thread (node g, label l): 256 / LS nodes x LS label slots per
+// workgroup (LS = 16 for up to 16 labels, a power of two up to 256 beyond); the chunk partials of a (node, label) are loaded
+// independently and summed in chunk order, the softmax runs over the node's LDS row exactly like expAndNormalize.
+template <int LS>
 __global__ void __launch_bounds__(256) crf_update_kernel(const float* __restrict__ unary, int L, int n, const float* __restrict__ partial,
                                                          float w_smooth, float w_app, float* __restrict__ Qn)
 {
-    __shared__ float s_t[16][kMaxL];
-    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const int i = blockIdx.x * 16 + g;
+    constexpr int G = 256 / LS;
+    __shared__ float s_t[G][LS];
+    const int g = threadIdx.x / LS, l = threadIdx.x % LS;
+    const int i = blockIdx.x * G + g;
     float tmp = 0;
     if (i < n && l < L) {
         float pa[kCrfChunks], pb[kCrfChunks];
 #pragma unroll
         for (int c = 0; c < kCrfChunks; c++) {
-            const float* in = partial + ((size_t)(c * n + i) * 2) * kMaxL;
-            pa[c] = in[l]; pb[c] = in[kMaxL + l];
+            const float* in = partial + ((size_t)(c * n + i) * 2) * L;
+            pa[c] = in[l]; pb[c] = in[L + l];
         }
         float a = 0, b = 0;
 #pragma unroll
@@ -307,6 +328,14 @@ __global__ void __launch_bounds__(256) crf_update_kernel(const float* __restrict
         for (int k = 0; k < L; k++) sum += det_expf(s_t[g][k] - mx);
         Qn[i * L + l] = det_expf(tmp - mx) / sum;
     }
+}
+static void launch_crf_update(hipStream_t st, const float* unary, int L, int n, const float* partial, float w_smooth, float w_app, float* Qn)
+{
+    if (L <= 16) crf_update_kernel<16><<<(n + 15) / 16, 256, 0, st>>>(unary, L, n, partial, w_smooth, w_app, Qn);
+    else if (L <= 32) crf_update_kernel<32><<<(n + 7) / 8, 256, 0, st>>>(unary, L, n, partial, w_smooth, w_app, Qn);
+    else if (L <= 64) crf_update_kernel<64><<<(n + 3) / 4, 256, 0, st>>>(unary, L, n, partial, w_smooth, w_app, Qn);
+    else if (L <= 128) crf_update_kernel<128><<<(n + 1) / 2, 256, 0, st>>>(unary, L, n, partial, w_smooth, w_app, Qn);
+    else crf_update_kernel<256><<<n, 256, 0, st>>>(unary, L, n, partial, w_smooth, w_app, Qn);
 }
 
 
@@ -561,7 +590,7 @@ struct SegPostArgs {
 // component numbers live in LDS, the sequential sums of the statistics run one wave per model (wave_sequential_sum).
 constexpr int kSegMaxK = 4800;
 constexpr int kPoseWords = 18;   // cf_seg_publish_poses: 16 pose words + ICP error + ICP inlier count, one 64-bit slot per f32 bit pattern
-constexpr int kCcLds = 512;   // components whose statistics fit in LDS (a frame has tens)
+constexpr int kCcLds = 256;   // components whose statistics fit in LDS (a frame has tens)
 __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
 {
     const int K = a.K, gx = a.gx, L = a.L, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
@@ -773,88 +802,13 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
     if (a.result_host) {
         const unsigned* src = reinterpret_cast<const unsigned*>(a.result);
         unsigned* dst = reinterpret_cast<unsigned*>(a.result_host);
-        for (int k = tid; k < (int)(sizeof(cf_seg_result) / 4); k += T) dst[k] = src[k];
+        const int words = (int)((offsetof(cf_seg_result, model) + sizeof(cf_seg_model) * (size_t)n_md) / 4);   // header + the rows in use
+        for (int k = tid; k < words; k += T) dst[k] = src[k];
     }
     if (a.low_map_host)
         for (int k = tid; k < (K + 3) / 4; k += T) a.low_map_host[k] = reinterpret_cast<const unsigned*>(map)[k];
 }
 
-
-// One whole mean-field step in one launch: a workgroup owns 16 nodes x all 16 chunks (thread = (node, chunk)), walks its chunk for all
-// labels, parks the chunk partials in LDS, and the first 16 x L threads add them in chunk order, apply the unary and the softmax --
-// exactly crf_message_kernel + crf_update_kernel, minus one launch boundary and the round trip of the partials through memory.
-template <int LT>
-__global__ void __launch_bounds__(256) crf_step_kernel(int L, int n, const float* __restrict__ unary, const float* __restrict__ K1t,
-                                                       const float* __restrict__ K2t, const float* __restrict__ Q, float w_smooth, float w_app,
-                                                       float* __restrict__ Qn)
-{
-    constexpr int LL = LT > 0 ? LT : kMaxL;
-    __shared__ float s_a[kCrfChunks][16][LL], s_b[kCrfChunks][16][LL];
-    __shared__ float s_t[16][LL];
-    const int ii = threadIdx.x & 15, c = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + ii;
-    const int len = (n + kCrfChunks - 1) / kCrfChunks, j0 = c * len, j1 = min(n, j0 + len);
-    float a[LL], b[LL];
-#pragma unroll
-    for (int l = 0; l < LL; l++) { a[l] = 0; b[l] = 0; }
-    if (i < n) {
-        int j = j0;
-        for (; j + 5 <= j1; j += 5) {
-            float k1[5], k2[5];
-#pragma unroll
-            for (int u = 0; u < 5; u++) { k1[u] = K1t[(j + u) * n + i]; k2[u] = K2t[(j + u) * n + i]; }
-#pragma unroll
-            for (int u = 0; u < 5; u++)
-#pragma unroll
-                for (int l = 0; l < LL; l++)
-                    if (LT > 0 || l < L) { const float q = Q[(j + u) * L + l]; a[l] += k1[u] * q; b[l] += k2[u] * q; }
-        }
-        for (; j < j1; j++) {
-            const float k1 = K1t[j * n + i], k2 = K2t[j * n + i];
-#pragma unroll
-            for (int l = 0; l < LL; l++)
-                if (LT > 0 || l < L) { const float q = Q[j * L + l]; a[l] += k1 * q; b[l] += k2 * q; }
-        }
-    }
-#pragma unroll
-    for (int l = 0; l < LL; l++) { s_a[c][ii][l] = a[l]; s_b[c][ii][l] = b[l]; }
-    __syncthreads();
-    const int g = threadIdx.x / LL, l = threadIdx.x - g * LL;   // (node of the tile, label) for the first 16 x LL threads
-    const int gi = blockIdx.x * 16 + g;
-    const bool act = g < 16 && gi < n && l < L;
-    float tmp = 0;
-    if (act) {
-        float sa = 0, sb = 0;
-#pragma unroll
-        for (int cc = 0; cc < kCrfChunks; cc++) { sa += s_a[cc][g][l]; sb += s_b[cc][g][l]; }
-        tmp = (-unary[gi * L + l] - (-w_smooth * sa)) - (-w_app * sb);
-        s_t[g][l] = tmp;
-    }
-    __syncthreads();
-    if (act) {
-        float mx = s_t[g][0];
-        for (int k = 1; k < L; k++) if (s_t[g][k] > mx) mx = s_t[g][k];
-        float sum = 0;
-        for (int k = 0; k < L; k++) sum += det_expf(s_t[g][k] - mx);
-        Qn[gi * L + l] = det_expf(tmp - mx) / sum;
-    }
-}
-static void launch_crf_step(hipStream_t st, int L, int n, const float* unary, const float* K1t, const float* K2t, const float* Q, float ws,
-                            float wa, float* Qn)
-{
-    const int grid = (n + 15) / 16;
-    switch (L) {
-        case 1: crf_step_kernel<1><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
-        case 2: crf_step_kernel<2><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
-        case 3: crf_step_kernel<3><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
-        case 4: crf_step_kernel<4><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
-        case 5: crf_step_kernel<5><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
-        case 6: crf_step_kernel<6><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
-        case 7: crf_step_kernel<7><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
-        case 8: crf_step_kernel<8><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
-        default: crf_step_kernel<0><<<grid, 256, 0, st>>>(L, n, unary, K1t, K2t, Q, ws, wa, Qn); break;
-    }
-}
 
 }  // namespace cf
 
@@ -892,6 +846,9 @@ __global__ void __launch_bounds__(64) pose_publish_kernel(const PosePublishArgs 
 struct cf_segmenter {
     cf_ctx* ctx = nullptr;
     int gx = 0, gy = 0, K = 0;
+    int Lcap = 16;                       // label capacity of the buffers = max(16, the context's max_models) (a new label needs a free model slot)
+    const void** d_acc_ptrs = nullptr;   // [2][Lcap] device copies of the models' ICP-error / vertex-confidence image pointers (> kAccTile models)
+    const void** h_acc_ptrs = nullptr;   // pinned staging of the same
     int* labels = nullptr;
     float* centres = nullptr;
     unsigned long long* slic_sums = nullptr;
@@ -900,17 +857,17 @@ struct cf_segmenter {
     int* resample = nullptr;
     unsigned char* low_map = nullptr;
     float *feat1 = nullptr, *feat2 = nullptr, *raw = nullptr, *norm = nullptr, *K1t = nullptr, *K2t = nullptr;
-    float* partial = nullptr;            // chunk partial sums [kCrfChunks][K][2][kMaxL]
+    float* partial = nullptr;            // chunk partial sums [kCrfChunks][K][2][Lcap]
     std::vector<float> smooth_cache;     // host copy of the smoothness features K1t was built from
     float *unary = nullptr, *Q0 = nullptr, *Q1 = nullptr;
     // device-side unaries / post-processing (cf_seg_sums / cf_seg_infer / cf_seg_fetch)
-    float *raw_mean = nullptr, *low_mean = nullptr;   // [(1 + 2 kMaxL)][K]
+    float *raw_mean = nullptr, *low_mean = nullptr;   // [(1 + 2 Lcap)][K]
     float *avg_conf = nullptr, *depth_range = nullptr;
     int *parent = nullptr, *comp = nullptr, *cc = nullptr;
     cf_seg_result* d_result = nullptr;
     cf_seg_result* h_result = nullptr;   // pinned
     unsigned char* h_low_map = nullptr;  // pinned [K]
-    long long* h_pose_tail = nullptr;    // pinned [kMaxL][kPoseWords]: the tail of the sums block after the caller's all-reduce
+    long long* h_pose_tail = nullptr;    // pinned [Lcap][kPoseWords]: the tail of the sums block after the caller's all-reduce
     bool poses_published = false;
     bool grid_kernel_built = false;      // K1t holds the kernel of the grid's own smoothness features (seg_feat1_kernel)
 };
@@ -920,6 +877,21 @@ static int seg_malloc(cf_ctx* ctx, T** p, size_t count)
 {
     HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
     HIPCHK(ctx, hipMemsetAsync(*p, 0, count * sizeof(T), ctx->stream));
+    return CF_OK;
+}
+
+// the models' image pointers of the accumulation launch: kernel arguments for up to kAccTile models, a device table beyond
+static int acc_pointers(cf_segmenter* s, AccArgs& a, int n_models, const float* const* icp_err, const float* const* vertconf4)
+{
+    if (n_models <= kAccTile) {
+        for (int m = 0; m < n_models; m++) { a.icp[m] = icp_err[m]; a.vconf[m] = reinterpret_cast<const float4*>(vertconf4[m]); }
+        return CF_OK;
+    }
+    cf_ctx* ctx = s->ctx;
+    for (int m = 0; m < n_models; m++) { s->h_acc_ptrs[m] = icp_err[m]; s->h_acc_ptrs[s->Lcap + m] = vertconf4[m]; }
+    HIPCHK(ctx, hipMemcpyAsync(s->d_acc_ptrs, s->h_acc_ptrs, sizeof(void*) * 2 * (size_t)s->Lcap, hipMemcpyHostToDevice, ctx->stream));
+    a.icp_dev = reinterpret_cast<const float* const*>(s->d_acc_ptrs);
+    a.vconf_dev = reinterpret_cast<const float4* const*>(s->d_acc_ptrs + s->Lcap);
     return CF_OK;
 }
 
@@ -933,7 +905,10 @@ int cf_seg_create(cf_ctx* ctx, cf_segmenter** out)
     cf_segmenter* s = new cf_segmenter();
     s->ctx = ctx; s->gx = ctx->cfg.width / kSpix; s->gy = ctx->cfg.height / kSpix; s->K = s->gx * s->gy;
     *out = s;
-    const size_t N = (size_t)ctx->cfg.width * ctx->cfg.height, K = (size_t)s->K;
+    s->Lcap = ctx->cfg.max_models < 16 ? 16 : (ctx->cfg.max_models > kMaxL - 1 ? kMaxL - 1 : ctx->cfg.max_models);   // at least 16 (as before round 4); ids 0..254, 255 = rejected
+    const size_t N = (size_t)ctx->cfg.width * ctx->cfg.height, K = (size_t)s->K, Lc = (size_t)s->Lcap;
+    if (int r = seg_malloc(ctx, &s->d_acc_ptrs, 2 * Lc)) return r;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_acc_ptrs), sizeof(void*) * 2 * Lc));
     if (int r = seg_malloc(ctx, &s->labels, N)) return r;
     if (int r = seg_malloc(ctx, &s->centres, K * 5)) return r;
     if (int r = seg_malloc(ctx, &s->slic_sums, K * 6)) return r;
@@ -941,9 +916,9 @@ int cf_seg_create(cf_ctx* ctx, cf_segmenter** out)
     if (int r = seg_malloc(ctx, &s->depth_count, K)) return r;
     if (int r = seg_malloc(ctx, &s->depth_sum, K)) return r;
     // [icp | conf | pose tail] in one block: one collective of a model-parallel caller covers all of it (cf_seg_publish_poses)
-    if (int r = seg_malloc(ctx, &s->icp_sum, 2 * K * kMaxL + kMaxL * kPoseWords)) return r;
-    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_pose_tail), sizeof(long long) * kMaxL * kPoseWords));
-    s->conf_sum = s->icp_sum + K * kMaxL;
+    if (int r = seg_malloc(ctx, &s->icp_sum, 2 * K * Lc + Lc * kPoseWords)) return r;
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_pose_tail), sizeof(long long) * Lc * kPoseWords));
+    s->conf_sum = s->icp_sum + K * Lc;
     if (int r = seg_malloc(ctx, &s->resample, K)) return r;
     if (int r = seg_malloc(ctx, &s->low_map, K)) return r;
     if (int r = seg_malloc(ctx, &s->feat1, K * 2)) return r;
@@ -952,13 +927,13 @@ int cf_seg_create(cf_ctx* ctx, cf_segmenter** out)
     if (int r = seg_malloc(ctx, &s->norm, K)) return r;
     if (int r = seg_malloc(ctx, &s->K1t, K * K)) return r;
     if (int r = seg_malloc(ctx, &s->K2t, K * K)) return r;
-    if (int r = seg_malloc(ctx, &s->partial, (size_t)kCrfChunks * K * 2 * kMaxL)) return r;
-    if (int r = seg_malloc(ctx, &s->unary, K * kMaxL)) return r;
-    if (int r = seg_malloc(ctx, &s->Q0, K * kMaxL)) return r;
-    if (int r = seg_malloc(ctx, &s->Q1, K * kMaxL)) return r;
-    if (int r = seg_malloc(ctx, &s->raw_mean, K * (3 + 2 * kMaxL))) return r;  // raw sums + the two lists of empty superpixels
-    if (int r = seg_malloc(ctx, &s->low_mean, K * (1 + 2 * kMaxL))) return r;
-    if (int r = seg_malloc(ctx, &s->avg_conf, (size_t)kMaxL)) return r;
+    if (int r = seg_malloc(ctx, &s->partial, (size_t)kCrfChunks * K * 2 * Lc)) return r;
+    if (int r = seg_malloc(ctx, &s->unary, K * Lc)) return r;
+    if (int r = seg_malloc(ctx, &s->Q0, K * Lc)) return r;
+    if (int r = seg_malloc(ctx, &s->Q1, K * Lc)) return r;
+    if (int r = seg_malloc(ctx, &s->raw_mean, K * (3 + 2 * Lc))) return r;  // raw sums + the two lists of empty superpixels
+    if (int r = seg_malloc(ctx, &s->low_mean, K * (1 + 2 * Lc))) return r;
+    if (int r = seg_malloc(ctx, &s->avg_conf, Lc)) return r;
     if (int r = seg_malloc(ctx, &s->depth_range, (size_t)1)) return r;
     if (int r = seg_malloc(ctx, &s->parent, K)) return r;
     if (int r = seg_malloc(ctx, &s->comp, K)) return r;
@@ -977,11 +952,12 @@ void cf_seg_destroy(cf_segmenter* s)
     (void)hipStreamSynchronize(s->ctx->stream);
     void* ptrs[] = {s->labels, s->centres, s->slic_sums, s->spix_count, s->depth_count, s->depth_sum, s->icp_sum, s->resample,
                     s->low_map, s->feat1, s->feat2, s->raw, s->norm, s->K1t, s->K2t, s->partial, s->unary, s->Q0, s->Q1,
-                    s->raw_mean, s->low_mean, s->avg_conf, s->depth_range, s->parent, s->comp, s->cc, s->d_result};
+                    s->raw_mean, s->low_mean, s->avg_conf, s->depth_range, s->parent, s->comp, s->cc, s->d_result, (void*)s->d_acc_ptrs};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->h_result) (void)hipHostFree(s->h_result);
     if (s->h_low_map) (void)hipHostFree(s->h_low_map);
     if (s->h_pose_tail) (void)hipHostFree(s->h_pose_tail);
+    if (s->h_acc_ptrs) (void)hipHostFree(s->h_acc_ptrs);
     delete s;
 }
 
@@ -1009,18 +985,18 @@ int cf_seg_accumulate(cf_segmenter* s, const float* depth, int n_models, const f
                       uint32_t* spix_count_host, uint32_t* depth_count_host, int64_t* depth_sum_host, int64_t* icp_sum_host,
                       int64_t* conf_sum_host, int32_t* resample_labels_host)
 {
-    if (!s || !depth || n_models < 0 || n_models > kMaxL) return CF_EINVAL;
+    if (!s || !depth || n_models < 0 || n_models > s->Lcap) return CF_EINVAL;
     cf_ctx* ctx = s->ctx; hipStream_t st = ctx->stream;
     const size_t K = (size_t)s->K;
     HIPCHK(ctx, hipMemsetAsync(s->spix_count, 0, sizeof(unsigned) * K, st));
     HIPCHK(ctx, hipMemsetAsync(s->depth_count, 0, sizeof(unsigned) * K, st));
     HIPCHK(ctx, hipMemsetAsync(s->depth_sum, 0, sizeof(unsigned long long) * K, st));
-    HIPCHK(ctx, hipMemsetAsync(s->icp_sum, 0, sizeof(unsigned long long) * K * kMaxL, st));
-    HIPCHK(ctx, hipMemsetAsync(s->conf_sum, 0, sizeof(unsigned long long) * K * kMaxL, st));
+    HIPCHK(ctx, hipMemsetAsync(s->icp_sum, 0, sizeof(unsigned long long) * K * (size_t)s->Lcap, st));
+    HIPCHK(ctx, hipMemsetAsync(s->conf_sum, 0, sizeof(unsigned long long) * K * (size_t)s->Lcap, st));
     AccArgs a;
     memset(&a, 0, sizeof(a));
     a.labels = s->labels; a.depth = depth; a.n_models = n_models; a.cols = ctx->cfg.width; a.rows = ctx->cfg.height; a.gx = s->gx; a.gy = s->gy;
-    for (int m = 0; m < n_models; m++) { a.icp[m] = icp_err[m]; a.vconf[m] = reinterpret_cast<const float4*>(vertconf4[m]); }
+    if (int r = acc_pointers(s, a, n_models, icp_err, vertconf4)) return r;
     a.spix_count = s->spix_count; a.depth_count = s->depth_count; a.depth_sum = s->depth_sum; a.icp_sum = s->icp_sum; a.conf_sum = s->conf_sum;
     seg_accumulate_kernel<<<dim3(s->gx, s->gy), 256, 0, st>>>(a);
     seg_resample_kernel<<<(s->K + 255) / 256, 256, 0, st>>>(s->labels, ctx->cfg.width, ctx->cfg.height, s->gx, s->gy, s->resample);
@@ -1042,7 +1018,7 @@ int cf_seg_accumulate(cf_segmenter* s, const float* depth, int n_models, const f
 int cf_seg_crf(cf_segmenter* s, const float* unary_host, int L, const float* feat_smooth_host, const float* feat_app_host,
                float w_smooth, float w_app, int iterations, float* Q_host)
 {
-    if (!s || !unary_host || !Q_host || L <= 0 || L > kMaxL) return CF_EINVAL;
+    if (!s || !unary_host || !Q_host || L <= 0 || L > s->Lcap) return CF_EINVAL;
     cf_ctx* ctx = s->ctx; hipStream_t st = ctx->stream;
     const int n = s->K;
     HIPCHK(ctx, hipMemcpyAsync(s->unary, unary_host, sizeof(float) * n * L, hipMemcpyHostToDevice, st));
@@ -1068,7 +1044,7 @@ int cf_seg_crf(cf_segmenter* s, const float* unary_host, int L, const float* fea
     float *q = s->Q0, *qn = s->Q1;
     for (int it = 0; it < iterations; it++) {
         launch_crf_message(st, gc, L, n, s->K1t, s->K2t, q, s->partial);
-        crf_update_kernel<<<(n + 15) / 16, 256, 0, st>>>(s->unary, L, n, s->partial, w_smooth, w_app, qn);
+        launch_crf_update(st, s->unary, L, n, s->partial, w_smooth, w_app, qn);
         float* t = q; q = qn; qn = t;
     }
     LAUNCHCHK(ctx);
@@ -1097,7 +1073,7 @@ static int enqueue_accumulate(cf_segmenter* s, const float* depth, int n_models,
     AccArgs a;
     memset(&a, 0, sizeof(a));
     a.labels = s->labels; a.depth = depth; a.n_models = n_models; a.cols = ctx->cfg.width; a.rows = ctx->cfg.height; a.gx = s->gx; a.gy = s->gy;
-    for (int m = 0; m < n_models; m++) { a.icp[m] = icp_err[m]; a.vconf[m] = reinterpret_cast<const float4*>(vertconf4[m]); }
+    if (int r = acc_pointers(s, a, n_models, icp_err, vertconf4)) return r;
     a.spix_count = s->spix_count; a.depth_count = s->depth_count; a.depth_sum = s->depth_sum; a.icp_sum = s->icp_sum; a.conf_sum = s->conf_sum;
     seg_accumulate_kernel<<<dim3(s->gx, s->gy), 256, 0, st>>>(a);
     seg_resample_kernel<<<(s->K + 255) / 256, 256, 0, st>>>(s->labels, ctx->cfg.width, ctx->cfg.height, s->gx, s->gy, s->resample);
@@ -1106,16 +1082,16 @@ static int enqueue_accumulate(cf_segmenter* s, const float* depth, int n_models,
 }
 
 // Slic::downsample* sums of the frame and of every model (Slic.h:48-120), left on the device.  *sums_dev (nullable) receives the
-// device address of the per-model sums -- int64 [2][16][K]: ICP-error sums of model m at [0][m][.], confidence sums at [1][m][.] --
+// device address of the per-model sums -- int64 [2][max_models][K]: ICP-error sums of model m at [0][m][.], confidence sums at [1][m][.] --
 // which a model-parallel caller SUM-all-reduces in place over the ranks before cf_seg_infer (owners contribute, everybody else
 // passes zero images).  The accumulators are expected zero on entry; cf_seg_infer leaves them zero again.
 int cf_seg_sums(cf_segmenter* s, const float* depth, int n_models, const float* const* icp_err, const float* const* vertconf4,
                 int64_t** sums_dev, uint64_t* sums_words)
 {
-    if (!s || !depth || n_models <= 0 || n_models > kMaxL || !icp_err || !vertconf4) return CF_EINVAL;
+    if (!s || !depth || n_models <= 0 || n_models > s->Lcap || !icp_err || !vertconf4) return CF_EINVAL;
     if (int r = enqueue_accumulate(s, depth, n_models, icp_err, vertconf4)) return r;
     if (sums_dev) *sums_dev = reinterpret_cast<int64_t*>(s->icp_sum);
-    if (sums_words) *sums_words = 2ull * kMaxL * (uint64_t)s->K + (uint64_t)kMaxL * kPoseWords;  // the pose tail rides along (zeros unless published)
+    if (sums_words) *sums_words = 2ull * (uint64_t)s->Lcap * (uint64_t)s->K + (uint64_t)s->Lcap * kPoseWords;  // the pose tail rides along (zeros unless published)
     return CF_OK;
 }
 
@@ -1124,11 +1100,11 @@ int cf_seg_sums(cf_segmenter* s, const float* depth, int n_models, const float* 
 // Replaces a separate (blocking) pose exchange per frame.
 int cf_seg_publish_poses(cf_segmenter* s, int n_models, cf_odom* const* trackers)
 {
-    if (!s || n_models <= 0 || n_models > kMaxL || !trackers) return CF_EINVAL;
+    if (!s || n_models <= 0 || n_models > s->Lcap || !trackers) return CF_EINVAL;
     PosePublishArgs a{};
     a.n = n_models;
     for (int m = 0; m < n_models; m++) a.st[m] = trackers[m] ? trackers[m]->d_state : nullptr;
-    pose_publish_kernel<<<kMaxL, 64, 0, s->ctx->stream>>>(a, reinterpret_cast<long long*>(s->icp_sum) + 2 * (size_t)kMaxL * s->K);
+    pose_publish_kernel<<<s->Lcap, 64, 0, s->ctx->stream>>>(a, reinterpret_cast<long long*>(s->icp_sum) + 2 * (size_t)s->Lcap * s->K);
     LAUNCHCHK(s->ctx);
     s->poses_published = true;
     return CF_OK;
@@ -1136,7 +1112,7 @@ int cf_seg_publish_poses(cf_segmenter* s, int n_models, cf_odom* const* trackers
 // words: [n_models][18] (16 pose words row-major, ICP error, ICP inlier count) as written by the owners; valid after cf_seg_fetch
 int cf_seg_fetch_poses(cf_segmenter* s, int n_models, int64_t* words_host)
 {
-    if (!s || n_models <= 0 || n_models > kMaxL || !words_host) return CF_EINVAL;
+    if (!s || n_models <= 0 || n_models > s->Lcap || !words_host) return CF_EINVAL;
     if (!s->poses_published) { s->ctx->set_error("cf_seg_fetch_poses: no poses were published for this inference"); return CF_ESTATE; }
     HIPCHK(s->ctx, hipStreamSynchronize(s->ctx->stream));
     memcpy(words_host, s->h_pose_tail, sizeof(int64_t) * (size_t)n_models * kPoseWords);
@@ -1151,7 +1127,7 @@ int cf_seg_infer(cf_segmenter* s, const cf_seg_params* P, const uint8_t* rgba, i
 {
     if (!s || !P || !rgba || !model_ids || !full_dev || n_models <= 0) return CF_EINVAL;
     const int L = n_models + (allow_new ? 1 : 0);
-    if (L > kMaxL) { s->ctx->set_error("segmentation: more than 16 labels"); return CF_EINVAL; }
+    if (L > s->Lcap) { s->ctx->set_error("segmentation: more labels than the context's max_models (" + std::to_string(s->Lcap) + ")"); return CF_EINVAL; }
     cf_ctx* ctx = s->ctx; hipStream_t st = ctx->stream;
     const int n = s->K;
     const int g2 = (n * n + 255) / 256, g1 = (n + 255) / 256;
@@ -1181,9 +1157,8 @@ int cf_seg_infer(cf_segmenter* s, const cf_seg_params* P, const uint8_t* rgba, i
     crf_init_kernel<<<g1, 256, 0, st>>>(s->unary, L, n, s->Q0);
     float *q = s->Q0, *qn = s->Q1;
     for (int it = 0; it < P->crfIterations; it++) {
-        // (one fused launch per step -- crf_step_kernel -- measured 17.6 us against 9.4 + 4.9 us for the pair: kept for reference only)
         launch_crf_message(st, gc, L, n, s->K1t, s->K2t, q, s->partial);
-        crf_update_kernel<<<(n + 15) / 16, 256, 0, st>>>(s->unary, L, n, s->partial, P->weightSmoothness, P->weightAppearance, qn);
+        launch_crf_update(st, s->unary, L, n, s->partial, P->weightSmoothness, P->weightAppearance, qn);
         float* t = q; q = qn; qn = t;
     }
     SegPostArgs p;
@@ -1201,8 +1176,8 @@ int cf_seg_infer(cf_segmenter* s, const cf_seg_params* P, const uint8_t* rgba, i
     seg_upsample_kernel<<<(N + 255) / 256, 256, 0, st>>>(s->labels, s->low_map, N, full_dev);
     LAUNCHCHK(ctx);
     if (s->poses_published) {  // the tail now holds what the caller's all-reduce made of it; the next frame starts from zeros again
-        long long* tail = reinterpret_cast<long long*>(s->icp_sum) + 2 * (size_t)kMaxL * s->K;
-        HIPCHK(ctx, hipMemcpyAsync(s->h_pose_tail, tail, sizeof(long long) * kMaxL * kPoseWords, hipMemcpyDeviceToHost, st));
+        long long* tail = reinterpret_cast<long long*>(s->icp_sum) + 2 * (size_t)s->Lcap * s->K;
+        HIPCHK(ctx, hipMemcpyAsync(s->h_pose_tail, tail, sizeof(long long) * (size_t)s->Lcap * kPoseWords, hipMemcpyDeviceToHost, st));
     }
     return CF_OK;
 }

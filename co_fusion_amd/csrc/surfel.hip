@@ -30,7 +30,12 @@ static inline int gridFor(long long n) { return (int)((n + kB - 1) / kB); }
 static inline int gridXcd(long long n, int chunk = 1) { const int q = 8 * (chunk > 1 ? chunk : 1); return (gridFor(n) + q - 1) / q * q; }  // xcd_block is a bijection on it
 // chunk > 0: the XCDs take turns on runs of `chunk` consecutive logical workgroups (locality inside a run, balance between the XCDs
 // when the cost per workgroup drifts along the buffer); chunk < 0: one band per XCD; 0: plain round-robin (the hardware's order).
+// (the orders in use were chosen by measurement, DESIGN-NOTES.md; a diagnostics build -- make ABLATE=1 -- reads them from the environment)
+#ifdef CF_ABLATE
 static int xcd_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static constexpr int xcd_env(const char*, int dflt) { return dflt; }
+#endif
 __device__ __forceinline__ int xcd_block(int chunk)
 {
     const int b = blockIdx.x;
@@ -82,89 +87,6 @@ __global__ void __launch_bounds__(kB) bilateral_kernel(const float* __restrict__
         }
     }
     out[i] = sum1 / sum2;
-}
-
-// Packed-f32 flavour (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per lane and instruction) of bilateral_kernel: one pixel per
-// lane as before, but the taps (dx, dx + 1) of a window row are evaluated TOGETHER -- one 8-byte load {row[x+dx], row[x+dx+1]}, the
-// weight arithmetic on both elements at once -- and only the two running sums keep the reference's sequential order
-// (sum += a; sum += b).  Same operations on the same values: identical bits.  det_expf is evaluated without branches (its argument is
-// <= 0 or NaN here: one select after the polynomial), a wave whose pixels all keep their whole window inside the image
-// columns skips the column tests, and in the others a tap outside the image is excluded from the sums by a select.
-// (Measured and dropped: two PIXELS per lane on the same instructions -- half as many waves, each a chain of dependent packed
-// operations with a wait state after every one of them: 90.9 against 57.5 us, profiles/r05e.)
-typedef float bl_v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int bl_cvt_i32(float v) { int r; asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(v)); return r; }  // saturating, NaN -> 0
-__device__ __forceinline__ bl_v2f bl_expf_nonpos(bl_v2f x)
-{   // det_expf(x) for x <= 0 or NaN, both elements (the x > 88 exit cannot be taken).  The polynomial runs on every argument: for
-    // x <= -87 (incl. -inf) its result is discarded by the select below, and a NaN argument comes out as NaN by itself, which is
-    // what det_expf returns for it (the conversion saturates / maps NaN to 0, so nothing here is undefined).
-    const bl_v2f t = x * 1.44269504088896341f;
-    const bl_v2f n = {rintf(t.x), rintf(t.y)};
-    bl_v2f r = x - n * 0.693145751953125f;
-    r = r - n * 1.42860682030941723212e-6f;
-    bl_v2f p = {1.0f / 720.0f, 1.0f / 720.0f};
-    p = p * r + 1.0f / 120.0f;
-    p = p * r + 1.0f / 24.0f;
-    p = p * r + 1.0f / 6.0f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
-    bl_v2f e = {ldexpf(p.x, bl_cvt_i32(n.x)), ldexpf(p.y, bl_cvt_i32(n.y))};
-    e.x = (x.x <= -87.0f) ? 0.0f : e.x;
-    e.y = (x.y <= -87.0f) ? 0.0f : e.y;
-    return e;
-}
-template <bool INTERIOR>
-__device__ __forceinline__ void bilateral_rows_tap2(const float* __restrict__ depth, int cols, int rows, int x, int y, float value,
-                                                    float& sum1, float& sum2)
-{
-    const bl_v2f vv = {value, value};
-#pragma unroll
-    for (int dy = -6; dy <= 6; ++dy) {
-        const int cy = y + dy;
-        if (cy < 0 || cy >= rows) continue;
-        const float* __restrict__ rowp = depth + (size_t)cy * cols + x;
-#pragma unroll
-        for (int dx = -6; dx <= 6; dx += 2) {   // taps (dx, dx + 1); the 13th tap of the row is evaluated alone (second element unused)
-            const bool two = dx + 1 <= 6;
-            bool inA = true, inB = two;
-            bl_v2f tmp;
-            if (INTERIOR) {
-                if (two) tmp = *reinterpret_cast<const bl_v2f*>(rowp + dx);   // 4-byte aligned 8-byte load
-                else { tmp.x = rowp[dx]; tmp.y = 0.0f; }
-            } else {
-                const int ca = x + dx, cb = x + dx + 1;
-                inA = ca >= 0 && ca < cols; inB = two && cb >= 0 && cb < cols;
-                tmp.x = inA ? rowp[dx] : 0.0f;
-                tmp.y = inB ? rowp[dx + 1] : 0.0f;
-            }
-            const bl_v2f cs = {(float)(dx * dx + dy * dy) * 0.024691358f, (float)((dx + 1) * (dx + 1) + dy * dy) * 0.024691358f};
-            const bl_v2f d = vv - tmp;
-            const bl_v2f color2 = d * d;
-            const bl_v2f w = bl_expf_nonpos(-(cs + color2 * 555.556f));
-            const bl_v2f tw = tmp * w;
-            if (inA) { sum1 += tw.x; sum2 += w.x; }
-            if (inB) { sum1 += tw.y; sum2 += w.y; }
-        }
-    }
-}
-__global__ void __launch_bounds__(kB) bilateral_tap2_kernel(const float* __restrict__ depth, int cols, int rows, float maxD,
-                                                            float* __restrict__ out)
-{
-    const int i = blockIdx.x * kB + threadIdx.x;
-    const bool alive = i < cols * rows;
-    const int y = alive ? i / cols : 0, x = alive ? i - y * cols : 0;
-    const float value = alive ? depth[i] : 0.0f;
-    const bool ok = alive && !(value > maxD || value < 0.3f);
-    float sum1 = 0, sum2 = 0;
-    if (__any(ok)) {
-        const bool interior = !alive || (x >= 6 && x + 6 < cols);
-        if (__all(interior)) {
-            if (ok) bilateral_rows_tap2<true>(depth, cols, rows, x, y, value, sum1, sum2);
-        } else if (ok)
-            bilateral_rows_tap2<false>(depth, cols, rows, x, y, value, sum1, sum2);
-    }
-    if (alive) out[i] = ok ? sum1 / sum2 : 0.0f;
 }
 
 // ==================================================================== ordered compaction (scan) ====
@@ -363,28 +285,25 @@ __device__ __forceinline__ bool index_project(const float4 pc, const float4 ct, 
 }
 
 // t_dev (nullable): the transform in device memory instead of the kernel argument -- the inverse of a pose the tracker has just left
-// in HBM (pose_tinv_kernel), for passes that are enqueued before the host has seen that pose
-__global__ void __launch_bounds__(kB) index_splat_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count, Mat4 t_arg,
-                                                         const Mat4* __restrict__ t_dev, cf_cam cam, int cols, int rows, float maxDepth, int time,
+__global__ void __launch_bounds__(kB) index_splat_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count, Mat4 t_inv,
+                                                         cf_cam cam, int cols, int rows, float maxDepth, int time,
                                                          int timeDelta, unsigned id_begin, unsigned id_end, unsigned long long* __restrict__ keys)
 {
     // [id_begin, id_end): the surfel range of this launch (the whole map, or a rank's shard of it)
     const unsigned id = id_begin + blockIdx.x * kB + threadIdx.x;
     if (id >= *count || id >= id_end) return;
-    const Mat4 t_inv = t_dev ? *t_dev : t_arg;
     f3 ph; int q;
     if (!index_project(surfels[id * 3], surfels[id * 3 + 1], t_inv, cam, cols, rows, maxDepth, time, timeDelta, ph, q)) return;
     atomicMin(&keys[q], zkey(ph.z, id));
 }
 
-__global__ void __launch_bounds__(kB) index_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_arg, const Mat4* __restrict__ t_dev, int N,
+__global__ void __launch_bounds__(kB) index_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_inv, int N,
                                                            unsigned long long* __restrict__ keys, unsigned* __restrict__ index,
                                                            float4* __restrict__ vertConf, float4* __restrict__ colorTime,
                                                            float4* __restrict__ normRad)
 {
     const int q = blockIdx.x * kB + threadIdx.x;
     if (q >= N) return;
-    const Mat4 t_inv = t_dev ? *t_dev : t_arg;
     const unsigned long long k = keys[q];
     keys[q] = kEmptyKey;  // leave the z-buffer cleared for the next pass (no memset launch per projection)
     if (k == kEmptyKey) {
@@ -909,11 +828,7 @@ __global__ void set_count2_kernel(unsigned* out, unsigned* out_host, unsigned v)
 // ------------------------------------------------------------------------------- launchers ----
 void launch_bilateral(hipStream_t s, const float* depth, int cols, int rows, float maxD, float* out)
 {
-    // CF_BILATERAL_TAP2=1: the packed-f32 flavour (identical bits; 56 against 57 us, +2 % on a lock-step group of 12 sequences, nothing on
-    // one sequence -- profiles/r05f: the taps are chains of dependent operations, not issue slots; left off)
-    static const int tap2 = xcd_env("CF_BILATERAL_TAP2", 0);
-    if (tap2 && cols >= 16) bilateral_tap2_kernel<<<gridFor((long long)cols * rows), kB, 0, s>>>(depth, cols, rows, maxD, out);
-    else bilateral_kernel<<<gridFor((long long)cols * rows), kB, 0, s>>>(depth, cols, rows, maxD, out);
+    bilateral_kernel<<<gridFor((long long)cols * rows), kB, 0, s>>>(depth, cols, rows, maxD, out);
 }
 
 static Mat4 mat4_from(const float m[16]) { Mat4 r; for (int i = 0; i < 16; i++) r.m[i] = m[i]; return r; }
@@ -935,55 +850,27 @@ void launch_init(hipStream_t s, const float* raw, const float* filt, const unsig
                                               reinterpret_cast<float4*>(out));
 }
 void launch_index_keys(hipStream_t s, const float* surfels, const unsigned* count, unsigned id_begin, unsigned id_end, const float t_inv[16],
-                       cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, const float* t_inv_dev)
+                       cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys)
 {
-    const Mat4 T = t_inv ? mat4_from(t_inv) : Mat4{};
+    const Mat4 T = mat4_from(t_inv);
     if (id_end > id_begin)
-        index_splat_kernel<<<gridFor(id_end - id_begin), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, reinterpret_cast<const Mat4*>(t_inv_dev),
+        index_splat_kernel<<<gridFor(id_end - id_begin), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T,
                                                                      cam, cols, rows, maxDepth, time, timeDelta, id_begin, id_end, keys);
 }
 void launch_index_resolve(hipStream_t s, const float* surfels, const float t_inv[16], int cols, int rows, unsigned long long* keys,
-                          unsigned* index, float* vertConf, float* colorTime, float* normRad, const float* t_inv_dev)
+                          unsigned* index, float* vertConf, float* colorTime, float* normRad)
 {
     const int N = cols * rows;
-    index_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), t_inv ? mat4_from(t_inv) : Mat4{},
-                                                   reinterpret_cast<const Mat4*>(t_inv_dev), N, keys, index,
+    index_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), mat4_from(t_inv), N, keys, index,
                                                    reinterpret_cast<float4*>(vertConf), reinterpret_cast<float4*>(colorTime),
                                                    reinterpret_cast<float4*>(normRad));
 }
-// inverse of the pose a tracker left in its device state (Rcurr | tcurr after the last solve of the schedule): the statement of
-// inv44f (cabi_model.hip) / Mat4f::inverse (host/CoFusion.cpp), so the bits equal what the host computes from the fetched pose
-__global__ void pose_tinv_kernel(const OdomDev* __restrict__ st, Mat4* __restrict__ out)
-{
-    float a[16];
-    for (int r = 0; r < 3; r++) { a[r * 4 + 0] = st->Rcurr[r * 3 + 0]; a[r * 4 + 1] = st->Rcurr[r * 3 + 1]; a[r * 4 + 2] = st->Rcurr[r * 3 + 2]; a[r * 4 + 3] = st->tcurr[r]; }
-    const float c00 = a[5] * a[10] - a[6] * a[9];
-    const float c01 = a[6] * a[8] - a[4] * a[10];
-    const float c02 = a[4] * a[9] - a[5] * a[8];
-    const float det = a[0] * c00 + a[1] * c01 + a[2] * c02;
-    const float id = 1.0f / det;
-    float Li[9];
-    Li[0] = c00 * id; Li[1] = (a[2] * a[9] - a[1] * a[10]) * id; Li[2] = (a[1] * a[6] - a[2] * a[5]) * id;
-    Li[3] = c01 * id; Li[4] = (a[0] * a[10] - a[2] * a[8]) * id; Li[5] = (a[2] * a[4] - a[0] * a[6]) * id;
-    Li[6] = c02 * id; Li[7] = (a[1] * a[8] - a[0] * a[9]) * id; Li[8] = (a[0] * a[5] - a[1] * a[4]) * id;
-    Mat4 o;
-    for (int i = 0; i < 3; i++) {
-        o.m[i * 4 + 0] = Li[i * 3 + 0]; o.m[i * 4 + 1] = Li[i * 3 + 1]; o.m[i * 4 + 2] = Li[i * 3 + 2];
-        o.m[i * 4 + 3] = -(Li[i * 3 + 0] * a[3] + Li[i * 3 + 1] * a[7] + Li[i * 3 + 2] * a[11]);
-    }
-    o.m[12] = 0; o.m[13] = 0; o.m[14] = 0; o.m[15] = 1;
-    *out = o;
-}
-void launch_pose_tinv(hipStream_t s, const OdomDev* state, float* t_inv_dev)
-{
-    pose_tinv_kernel<<<1, 1, 0, s>>>(state, reinterpret_cast<Mat4*>(t_inv_dev));
-}
 void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                             int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, unsigned* index,
-                            float* vertConf, float* colorTime, float* normRad, const float* t_inv_dev)
+                            float* vertConf, float* colorTime, float* normRad)
 {
-    launch_index_keys(s, surfels, count, 0, count_bound, t_inv, cam, cols, rows, maxDepth, time, timeDelta, keys, t_inv_dev);
-    launch_index_resolve(s, surfels, t_inv, cols, rows, keys, index, vertConf, colorTime, normRad, t_inv_dev);
+    launch_index_keys(s, surfels, count, 0, count_bound, t_inv, cam, cols, rows, maxDepth, time, timeDelta, keys);
+    launch_index_resolve(s, surfels, t_inv, cols, rows, keys, index, vertConf, colorTime, normRad);
 }
 void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                              int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,

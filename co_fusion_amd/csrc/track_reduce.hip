@@ -730,7 +730,7 @@ __device__ __forceinline__ void so3_gradient(const uint8_t* __restrict__ img, in
 // one (grid-strided over blockIdx.x) pass over the level-2 images; this workgroup's totals[0..10] end up in LDS
 __device__ __forceinline__ void so3_pass(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
                                          const m33& B, const m33& Ki, const float* __restrict__ krlr, int cols, int rows,
-                                         unsigned long long (*lds)[16], unsigned long long* totals)
+                                         unsigned long long (*lds)[16], unsigned long long* totals, int block, int blocks)
 {
     constexpr float lim = (float)(1 << ((50 - kFixSO3) / 2));
     constexpr float scale = (float)(1 << kFixSO3);
@@ -740,7 +740,7 @@ __device__ __forceinline__ void so3_pass(const uint8_t* __restrict__ lastImage, 
     for (int k = 0; k < 16; k++) acc[k] = 0;
     const float a = krlr[0], b = krlr[1], c = krlr[2], d = krlr[3], e = krlr[4], f = krlr[5], g = krlr[6], h = krlr[7],
                 ii = krlr[8];
-    for (int k = blockIdx.x * T + threadIdx.x; k < N; k += gridDim.x * T) {
+    for (int k = block * T + threadIdx.x; k < N; k += blocks * T) {
         const int y = k / cols, x = k - y * cols;
         const f3 unwarped = {(float)x, (float)y, 1.0f};
         const f3 warped = mul(B, unwarped);
@@ -825,21 +825,44 @@ __global__ void __launch_bounds__(1024) so3_step_kernel(const uint8_t* __restric
 {
     __shared__ unsigned long long lds[16][16];
     __shared__ unsigned long long totals[16];
-    so3_pass(lastImage, nextImage, B, Ki, krlr.m, cols, rows, lds, totals);
+    so3_pass(lastImage, nextImage, B, Ki, krlr.m, cols, rows, lds, totals, blockIdx.x, gridDim.x);
     if (threadIdx.x < 16) out16[threadIdx.x] = totals[threadIdx.x];
 }
 
 // Whole SO3 pre-alignment (RGBDOdometry.cpp:239-310) in ONE launch.  The pass over the 160x120 level is VALU-bound
 // on a single CU (10.5 us per iteration, measured), so kSo3Blocks co-resident workgroups per model share it:
 // each reduces its pixels, adds its 11 fixed-point totals to the iteration's slot of a global accumulator and
-// meets the others at an atomic arrival counter; every workgroup then reads the totals (device-scope atomic
-// loads) and runs the identical 3x3 solve + Rodrigues on its own LDS copy of the state, so nothing but integer
-// atomics crosses workgroups and the data-dependent early exits stay uniform.  The last workgroup to leave
-// re-zeroes the sync block for the next frame.  Also seeds resultRt and the first iteration's krkInv/kt.
-// pre (nullable, with do_so3 == 0): per model, the state of a FRAME pre-alignment (cf_so3: this same kernel run ahead on the frame's two
-// intensity images, which is all the pre-alignment depends on) whose rotation and statistics are adopted instead of iterating here.
+// meets the others at an atomic arrival counter; every workgroup then reads the totals and runs the identical 3x3
+// solve + Rodrigues on its own LDS copy of the state, so nothing but integer atomics crosses workgroups and the
+// data-dependent early exits stay uniform.  The last workgroup to leave re-zeroes the sync block for the next frame.
+// Also seeds resultRt and the first iteration's krkInv/kt.
+//
+// ONE XCD PER MODEL (round 4).  Until round 4 the meeting was device-scope: atomics through the fabric, a release fence that writes the
+// XCD's L2 back, polling loads that bypass it -- tools/microbench/xcd_barrier.hip measures 9.1 us for such a barrier of 32 workgroups
+// (11.3 us across the chip) against 1.1 us when the workgroups share an XCD and meet in its L2 (atomics at workgroup scope execute in
+// the L2, and so do the returning atomics the counters and sums are read with; nothing is written back).  The launch therefore has 8 x
+// kSo3Blocks workgroups per model and keeps those whose index is (model mod 8) modulo 8: the dispatcher deals consecutive workgroups
+// round-robin over the XCDs (what xcd_logical_block relies on too), so they share one.  Should that ever not hold, the arrival
+// counters live in different L2s, the bounded wait below expires and raises the fault word -- cf_odom_fetch_result returns CF_ESTATE
+// instead of a pose from partial sums.  The sums are integers: the bits do not depend on any of this.
+// Reads that are answered by the L2 itself: a RETURNING read-modify-write (OR with 0).  A load marked sc0 is a group-scope load, which
+// the CU's vector L1 may serve -- with it the workgroups spun on a stale arrival count (reproduced in tools/microbench/xcd_barrier.hip).
+__device__ __forceinline__ unsigned l2_read_u32(unsigned* p)
+{
+    unsigned v;
+    const unsigned zero = 0;
+    asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(zero) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned long long l2_read_u64(unsigned long long* p)
+{
+    unsigned long long v;
+    const unsigned long long zero = 0;
+    asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(zero) : "memory");
+    return v;
+}
 __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __restrict__ models, So3Sync* __restrict__ syncs, int do_so3,
-                                                           int first_level, const OdomDev* const* __restrict__ pre)
+                                                           int first_level)
 {
     OdomDev* od = models[blockIdx.y];
     So3Sync* sync = syncs + blockIdx.y;
@@ -855,8 +878,12 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
     __shared__ float s_jtj[9], s_jtr[3], s_delta[3], s_fws[15];
     __shared__ int s_iws[3];
     const int L = 2, cols = od->width >> L, rows = od->height >> L;
-    const bool lead = blockIdx.x == 0;  // the workgroup that publishes statistics and the final state
-    const unsigned G = gridDim.x;
+    // with the pre-alignment the launch is 8 x kSo3Blocks wide: this model's workgroups are the ones on XCD (model mod 8)
+    const bool one_xcd = do_so3 && gridDim.x > 1;
+    if (one_xcd && (blockIdx.x & 7) != (blockIdx.y & 7)) return;
+    const int bx = one_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const bool lead = bx == 0;  // the workgroup that publishes statistics and the final state
+    const unsigned G = one_xcd ? gridDim.x >> 3 : gridDim.x;
     if (threadIdx.x == 0) {
         for (int k = 0; k < 9; k++) { s_resultR[k] = (k % 4 == 0) ? 1.0 : 0.0; s_lastResultR[k] = s_resultR[k]; s_Rlr[k] = (k % 4 == 0) ? 1.f : 0.f; }
         k_matrix(cam_level(od->intr, L), s_K);
@@ -879,23 +906,24 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
             __syncthreads();
             m33 B, Ki;
             for (int k = 0; k < 9; k++) { B.m[k] = s_basis[k]; Ki.m[k] = s_kinv[k]; }
-            so3_pass(lastNext, next, B, Ki, s_krlr, cols, rows, lds, totals);  // ends with this workgroup's totals in LDS
+            so3_pass(lastNext, next, B, Ki, s_krlr, cols, rows, lds, totals, bx, (int)G);  // ends with this workgroup's totals in LDS
             if (G > 1) {
-                if (threadIdx.x < 64) {  // wave 0: publish, arrive, wait, collect
+                if (threadIdx.x < 64) {  // wave 0: publish, arrive, wait, collect -- everything in this XCD's L2
                     unsigned long long* slot = sync->acc[it];
-                    if (threadIdx.x < 11 && totals[threadIdx.x] != 0) atomicAdd(&slot[threadIdx.x], totals[threadIdx.x]);
-                    __threadfence();
+                    if (threadIdx.x < 11 && totals[threadIdx.x] != 0)
+                        __hip_atomic_fetch_add(&slot[threadIdx.x], totals[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the L2 has taken this wave's sums before it arrives
                     if (threadIdx.x == 0) {
-                        atomicAdd(&sync->arrive, 1u);
+                        __hip_atomic_fetch_add(&sync->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         const unsigned target = (unsigned)(it + 1) * G;
                         unsigned spins = 0;
-                        while (__hip_atomic_load(&sync->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        while (l2_read_u32(&sync->arrive) < target) {
                             if (++spins > (1u << 22)) { od->stats.fault = 1; break; }  // never hang the GPU; the host reports CF_ESTATE
                             __builtin_amdgcn_s_sleep(1);
                         }
                     }
-                    __threadfence();
-                    if (threadIdx.x < 16) totals[threadIdx.x] = __hip_atomic_load(&slot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_wave_barrier();
+                    if (threadIdx.x < 16) totals[threadIdx.x] = l2_read_u64(&slot[threadIdx.x]);
                 }
                 __syncthreads();
             }
@@ -932,7 +960,7 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
             if (s_done) break;
         }
         if (G > 1 && threadIdx.x == 0) {  // last one out resets the sync block (all workgroups are past their final read)
-            if (atomicAdd(&sync->depart, 1u) == G - 1) {
+            if (__hip_atomic_fetch_add(&sync->depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == G - 1) {
                 for (int it = 0; it < 10; it++)
                     for (int w = 0; w < 16; w++) sync->acc[it][w] = 0;
                 sync->arrive = 0; sync->depart = 0;
@@ -963,13 +991,6 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
         if (do_so3)
             for (int x = 0; x < 3; x++)
                 for (int y = 0; y < 3; y++) od->resultRt[x * 4 + y] = s_resultR[x * 3 + y];
-        else if (pre && pre[blockIdx.y]) {
-            const OdomDev* p = pre[blockIdx.y];
-            for (int x = 0; x < 3; x++)
-                for (int y = 0; y < 3; y++) od->resultRt[x * 4 + y] = p->resultRt[x * 4 + y];
-            od->stats.so3_iterations = p->stats.so3_iterations; od->stats.last_so3_error = p->stats.last_so3_error;
-            od->stats.last_so3_count = p->stats.last_so3_count; od->stats.fault |= p->stats.fault;
-        }
         od->lastRGBError = 3.402823466e+38F;
         od->level_done = 0;
         od->residual[0] = 0; od->residual[1] = 0;
@@ -1330,7 +1351,7 @@ void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, 
 // Kept as separate launches.
 bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const GnHook* hook, const IcpArgs icp_args[3],
                      const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, int mode,
-                     ProfSink* prof, OdomDev* const* h_states, const OdomDev* const* d_pre)
+                     ProfSink* prof, OdomDev* const* h_states)
 {
     int iterations[3];
     iterations[0] = fast_odom ? 3 : 10;
@@ -1338,7 +1359,7 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
     iterations[2] = pyramid ? 4 : 0;
     int first_level = 2;
     while (first_level > 0 && iterations[first_level] == 0) first_level--;
-    so3_prealign_kernel<<<dim3(so3 ? kSo3Blocks : 1, n), 256, 0, s>>>(d_models, so3_syncs, so3 ? 1 : 0, first_level, so3 ? nullptr : d_pre);
+    so3_prealign_kernel<<<dim3(so3 ? 8 * kSo3Blocks : 1, n), 256, 0, s>>>(d_models, so3_syncs, so3 ? 1 : 0, first_level);  // (8x: one XCD per model)
     GnArgs gn{};
     gn.icp_gram = cfg.gram;
     for (int m = 0; m < n; m++) {
@@ -1400,13 +1421,6 @@ float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const R
     (void)hipStreamSynchronize(s);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     return ms * 1000.f / reps;
-}
-
-// the SO(3) pre-alignment of a FRAME (cf_so3): the kernel above on a one-entry model list whose state only carries the two level-2
-// intensity images, the intrinsics and the image size
-void launch_so3_frame(hipStream_t s, OdomDev* const* d_model /* device array of 1 */, So3Sync* sync)
-{
-    so3_prealign_kernel<<<dim3(kSo3Blocks, 1), 256, 0, s>>>(d_model, sync, 1, 2, nullptr);
 }
 
 // ---- stand-alone steps (C-ABI parity with computeRgbResidual / rgbStep) -------------------

@@ -142,7 +142,7 @@ Model::Model(cf_ctx* c, unsigned char id_, float confidenceThresh, bool enableFi
     check(ctx, cf_model_create(ctx, maxSurfels, &model), "cf_model_create");
     check(ctx, cf_odom_create(ctx, &odom), "cf_odom_create");
     // object models cover a small part of the image: their ICP launches skip the gathers into empty blocks of the prediction
-    if (!enableFillIn && !std::getenv("CF_NO_CULLING")) check(ctx, cf_odom_set_culling(odom, 1), "cf_odom_set_culling");
+    if (!enableFillIn) check(ctx, cf_odom_set_culling(odom, 1), "cf_odom_set_culling");
     // icpError texture (Model.cpp:112-117), f32 [H*W]; zero-initialised like the reference's upload (GPUTexture.cpp:48-53)
     void* p = nullptr;
     uint64_t bytes = 0;
@@ -228,12 +228,6 @@ void Model::predictIndices(int time, float depthCutoff, int timeDelta)
     if (!owned) return;
     if (shards > 1) check(ctx, cf_model_predict_indices_sharded(model, pose.m, time, depthCutoff, timeDelta, shard, shards), "predictIndices (sharded)");
     else check(ctx, cf_model_predict_indices(model, pose.m, time, depthCutoff, timeDelta), "predictIndices");
-}
-void Model::predictIndicesTracked(int time, float depthCutoff, int timeDelta, int lane)
-{
-    if (!owned) return;
-    check(ctx, cf_model_predict_indices_tracked(model, odom, time, depthCutoff, timeDelta), "predictIndices (tracked pose)");
-    preIndexedTick = time; preIndexedLane = lane;
 }
 void Model::combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta)
 {
@@ -766,10 +760,6 @@ CoFusion::CoFusion(const Config& c, cf_ctx* shared, int sequenceIndex)
     dist.colocate = cfg.colocateBackground;
     if (cfg.reloc && dist.world > 1) throw std::runtime_error("CoFusion: reloc (failure detection) is a single-GPU option (the background's normal matrix is not exchanged between ranks)");
     labelGenerator.reset(new Segmentation(ctx, cfg.width, cfg.height, &dist));
-    // experiment, off by default (CF_FRAME_SO3=1): the SO(3) pre-alignment once per frame and ahead of the tracking launches (cf_so3).
-    // Bit-identical; measured +0.6 % on configs[2] and -1.9 % on configs[1]: beside the previous frame's fusion passes
-    // the pre-alignment is late as often as it is early
-    if (std::getenv("CF_FRAME_SO3") != nullptr) check(ctx, cf_so3_create(ctx, &frameSo3), "cf_so3_create");
     const size_t N = (size_t)cfg.width * cfg.height;
     void* p = nullptr;
     check(ctx, cf_malloc(ctx, N * 4, &p), "cf_malloc"); depth_dev = static_cast<float*>(p);
@@ -798,7 +788,6 @@ CoFusion::CoFusion(const Config& c, cf_ctx* shared, int sequenceIndex)
     globalModel->loggingPoses = cfg.enablePoseLogging;
     models.push_back(globalModel);
     int helpers = cfg.enqueueThreads;
-    if (const char* e = std::getenv("CF_ENQUEUE_THREADS")) helpers = std::atoi(e);
     if (helpers > 0 && useLanes) pool = std::make_shared<EnqueuePool>(helpers > 7 ? 7 : helpers);
 }
 
@@ -811,7 +800,6 @@ CoFusion::~CoFusion()
     cf_free(ctx, rgba_dev); cf_free(ctx, rgb_dev); cf_free(ctx, mask_dev);
     for (int b = 0; b < 2; b++) if (stage[b]) cf_free_host(ctx, stage[b]);
     labelGenerator.reset();
-    if (frameSo3) cf_so3_destroy(frameSo3);
     if (rcclStage) cf_free(ctx, rcclStage);
     if (ownsCtx) cf_destroy(ctx);
 }
@@ -872,7 +860,7 @@ void CoFusion::modelPasses(Model& model, bool fuse, float weightMultiplier, bool
 {
     if (fuse) {
         // (the first index map of a tracked model was enqueued right behind its tracking, beside the segmentation: processFrame)
-        if (model.preIndexedTick != tick) model.predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
+        model.predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
         model.fuse(tick, curRgba, mask_dev, curDepth, depthFiltered_dev, maxDepthProcessed, weightMultiplier);
         model.predictIndices(tick, maxDepthProcessed, cfg.timeDelta);
         model.clean(tick, cfg.timeDelta, maxDepthProcessed, depthFiltered_dev, mask_dev, cfg.outlierCoefficient);
@@ -904,7 +892,7 @@ void CoFusion::fuseAndPredict(bool fuse, float weightMultiplier, bool lost, bool
     if (!threaded) {
         for (int i = 0; i < n; i++) {
             // a model whose first index map is already queued on a lane continues on that lane (stream order is the dependency)
-            check(ctx, cf_fork(ctx, (fuse && list[i]->preIndexedTick == tick) ? list[i]->preIndexedLane : (laneOffset + i) % lanes), "cf_fork");
+            check(ctx, cf_fork(ctx, (laneOffset + i) % lanes), "cf_fork");
             modelPasses(*list[i], fuse, weightMultiplier, lost);
         }
         if (join) check(ctx, cf_join(ctx), "cf_join");
@@ -941,7 +929,6 @@ void CoFusion::trackCollect(TrackBatch& batch, const float* const depthPyr[3])
         it.model = m.get(); it.owner = owner; it.frameRgba = curRgba; it.maxDepth = maxDepthProcessed;
         for (int l = 0; l < 3; l++) it.depthPyr[l] = depthPyr[l];
         m->trackingInputs(m->requiresFillIn(), cfg.frameToFrameRGB, it.predV, it.predN, it.predImg);
-        check(ctx, cf_odom_set_prealignment(m->odom, (cfg.so3 && frameSo3) ? frameSo3 : nullptr), "set_prealignment");
         batch.items.push_back(it);
         trackPending.push_back(m.get());
     }
@@ -990,7 +977,6 @@ void CoFusion::fetchTracking(bool exchange)
     }
     // the image swap of a tracked frame (RGBDOdometry.cpp:469-473) -- on every rank, also one that owns no tracker this frame: a model
     // it is given later starts from the last TRACKED frame's image like everybody else's
-    if (frameSo3) check(ctx, cf_so3_commit(frameSo3), "cf_so3_commit");
     trackPending.clear();
     if (exchange) exchangeTracking();
 }
@@ -1069,17 +1055,12 @@ void CoFusion::frameBegin(const FrameData& frame, const Mat4f* inPose, float wei
     if (headAside) check(ctx, cf_fork_after(ctx, 6, markBase + (int)b), "cf_fork_after");
     check(ctx, cf_bilateral(ctx, curDepth, cfg.width, cfg.height, cfg.depthCutoff, depthFiltered_dev), "filterDepth");
     if (willTrack) check(ctx, cf_depth_pyramid(ctx, depthFiltered_dev, cfg.width, cfg.height, depthPyr1, depthPyr2), "generateCUDATextures");
-    // The SO(3) pre-alignment every tracker starts with (RGBDOdometry.cpp:239-310) reads the previous and the new frame's intensity
-    // images only: done ONCE for the frame and here -- with a device-resident frame on the auxiliary stream, beside the previous
-    // frame's fusion passes -- instead of at the head of the tracking launches (55 us of the critical path)
-    if (willTrack && cfg.so3 && frameSo3) check(ctx, cf_so3_prealign(frameSo3, curRgba), "cf_so3_prealign");
     if (headAside) check(ctx, cf_join_lane(ctx, 6), "cf_join_lane");
 
     st.pyr[0] = depthFiltered_dev; st.pyr[1] = depthPyr1; st.pyr[2] = depthPyr2;
     if (tick == 1) {
         globalModel->initialise(curRgba, curDepth, depthFiltered_dev, tick, maxDepthProcessed);
         if (globalModel->isOwned()) check(ctx, cf_odom_init_first_rgb(globalModel->getFrameOdometry(), curRgba), "initFirstRGB");
-        if (frameSo3) check(ctx, cf_so3_first_frame(frameSo3, curRgba), "cf_so3_first_frame");
     } else if (willTrack) {
         // the superpixels only depend on the colour image: SLIC runs on an auxiliary stream beside the (latency-bound)
         // tracking launches and is joined before the segmentation needs it
@@ -1101,32 +1082,18 @@ void CoFusion::frameSegment(int lane)
     if (tick == 1) return;
     if (bootstrap || !inPose) {
         if (st.slicAside) check(ctx, cf_join_lane(ctx, 7), "cf_join_lane");
-        // Every tracked model's first index map (CoFusion.cpp:316-318) depends on its new pose only, and the pose is in device
-        // memory when the Gauss-Newton loop ends: enqueued here, on the models' lanes, it runs beside the segmentation instead
-        // of behind the frame's host wait.  Not when the pose is overridden afterwards (bootstrap), not for shadows / shards.
-        if (preIndex && !bootstrap && !cfg.rgbOnly && !lost && !dist.active() && !pool) {
-            int i = 0;
-            const bool lanes = models.size() > 1 && useLanes;
-            for (auto& m : models) {
-                if (!m->isOwned() || m->shards > 1) continue;
-                if (lanes) check(ctx, cf_fork(ctx, i % 6), "cf_fork");
-                m->predictIndicesTracked(tick, maxDepthProcessed, cfg.timeDelta, i % 6);
-                i++;
-            }
-            if (lanes) check(ctx, cf_main(ctx), "cf_main");
-        }
-        // a new label needs a free model slot: the segmenter holds at most 16 labels and the context was sized for
-        // cfg.maxModels trackers (the reference allows 256 ids, CoFusion.cpp:631-634; its GUI never gets there)
+        // a new label needs a free model slot: the context (trackers' staging, the segmenter's label dimension) was sized for
+        // cfg.maxModels models, at most 255 -- model ids are 8 bits and 255 marks a rejected superpixel (CoFusion.cpp:631-634)
         bool allowNew = false;
-        const bool segOnDevice = cfg.enableMultipleModels && !frame.mask && !segOnHost;
+        const bool segOnDevice = cfg.enableMultipleModels && !frame.mask;
         // (a sequence of a lock-step group puts its segmentation chain on a lane: the chains of the other sequences run beside it)
         if (lane >= 0 && segOnDevice) check(ctx, cf_fork(ctx, lane), "cf_fork");
         if (cfg.enableMultipleModels) {
             if (spawnOffset < cfg.modelSpawnOffset) spawnOffset++;
-            const size_t modelCap = (size_t)std::min(cfg.maxModels, 16);
+            const size_t modelCap = (size_t)std::min(cfg.maxModels, 255);
             allowNew = spawnOffset >= cfg.modelSpawnOffset && models.size() < modelCap;
             if (spawnOffset >= cfg.modelSpawnOffset && !allowNew && !capReported) {  // say so once: the reference would go on to 256 ids
-                fprintf(stderr, "[cofusion] %zu active models: the model cap (min(max_models, 16)) suppresses further spawns\n", models.size());
+                fprintf(stderr, "[cofusion] %zu active models: the model cap (min(max_models, 255)) suppresses further spawns\n", models.size());
                 capReported = true;
             }
         }

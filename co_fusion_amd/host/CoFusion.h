@@ -119,10 +119,6 @@ class Model {
               float weightMultiplier);
     void clean(int time, int timeDelta, float depthCutoff, const float* depthFiltered, const uint8_t* mask, float outlierCoeff);
     void predictIndices(int time, float depthCutoff, int timeDelta);
-    // the same pass under the pose the model's tracker has just left on the device (cf_model_predict_indices_tracked): enqueued behind
-    // the tracking launches, before the host has fetched the pose.  Remembers the tick and the lane it was issued on.
-    void predictIndicesTracked(int time, float depthCutoff, int timeDelta, int lane);
-    int preIndexedTick = -1, preIndexedLane = 0;
     void combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta);
     void performFillIn(const uint8_t* rgba, const float* depthFiltered, bool frameToFrameRGB, bool lost);
     bool requiresFillIn(float ratio = 0.75f);
@@ -322,7 +318,6 @@ class CoFusion {
     void fetchTracking(bool exchange);
     void exchangeTracking();
     std::vector<Model*> trackPending;
-    bool segOnHost = std::getenv("CF_SEG_HOST") != nullptr;  // diagnostic: host-side unaries / component analysis
     Distributed dist;
 
     cf_ctx* ctx = nullptr;
@@ -333,7 +328,6 @@ class CoFusion {
     int tick = 1;
     float maxDepthProcessed = 20.0f;
     unsigned spawnOffset = 0;
-    cf_so3* frameSo3 = nullptr;        // SO(3) pre-alignment of the frame, once and ahead of its trackers (cf_so3)
     int64_t* rcclStage = nullptr;      // device staging buffer of the host-buffer all-reduce (initRccl)
     uint64_t rcclStageWords = 0;
     bool capReported = false;  // the model cap suppressed a spawn and said so
@@ -354,8 +348,7 @@ class CoFusion {
     float modelKeepConfThreshold = 0.3f;
     bool enableSmartModelDelete = true;
     std::string exportSegmentationPrefix;
-    bool useLanes = std::getenv("CF_NO_LANES") == nullptr;  // per-model auxiliary streams (diagnostic switch)
-    bool preIndex = std::getenv("CF_PREINDEX") != nullptr;  // experiment, off: first index maps enqueued behind the tracking, beside the segmentation (measured slower)
+    bool useLanes = true;  // per-model auxiliary streams
     std::shared_ptr<EnqueuePool> pool;                      // Config::enqueueThreads helpers
     void modelPasses(Model& model, bool fuse, float weightMultiplier, bool lost);
     void fuseAndPredict(bool fuse, float weightMultiplier, bool lost, bool join = true, int laneOffset = 0);

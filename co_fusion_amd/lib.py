@@ -20,10 +20,10 @@ SYMBOLS = [
     "cf_transform_maps", "cf_vertices_to_depth", "cf_pyrdown_gauss_f32", "cf_pyrdown_gauss_u8",
     "cf_rgba_to_intensity", "cf_sobel", "cf_project_cloud", "cf_icp_step", "cf_icp_step_band", "cf_rgb_residual", "cf_rgb_step",
     "cf_so3_step", "cf_odom_create", "cf_odom_destroy", "cf_odom_init_icp_model", "cf_odom_init_rgb_model",
-    "cf_odom_init_rgb", "cf_odom_init_models_batch", "cf_odom_init_models_batch_frames", "cf_odom_init_first_rgb", "cf_odom_init_icp", "cf_so3_create", "cf_so3_destroy", "cf_so3_first_frame", "cf_so3_prealign", "cf_so3_commit", "cf_odom_set_prealignment", "cf_odom_get_incremental_transformation",
+    "cf_odom_init_rgb", "cf_odom_init_models_batch", "cf_odom_init_models_batch_frames", "cf_odom_init_first_rgb", "cf_odom_init_icp", "cf_odom_get_incremental_transformation",
     "cf_odom_track_batch_async", "cf_odom_fetch_result", "cf_odom_get_covariance", "cf_odom_bind_frame_maps", "cf_odom_share_frame_maps", "cf_odom_set_culling", "cf_odom_set_band", "cf_set_collective", "cf_model_predict_indices_sharded", "cf_odom_buffer",
     "cf_bilateral", "cf_model_create", "cf_model_destroy", "cf_model_initialise", "cf_model_count",
-    "cf_model_predict_indices", "cf_model_predict_indices_tracked", "cf_model_index_keys", "cf_model_index_resolve", "cf_model_combined_predict", "cf_model_prefetch_fill_ratio", "cf_model_perform_fill_in", "cf_model_requires_fill_in",
+    "cf_model_predict_indices", "cf_model_index_keys", "cf_model_index_resolve", "cf_model_combined_predict", "cf_model_prefetch_fill_ratio", "cf_model_perform_fill_in", "cf_model_requires_fill_in",
     "cf_model_fuse", "cf_model_clean", "cf_model_download_map", "cf_model_upload_map", "cf_model_buffer",
     "cf_fusion_weight", "cf_seg_create", "cf_seg_destroy", "cf_seg_slic", "cf_seg_accumulate", "cf_seg_crf", "cf_seg_upsample", "cf_seg_sums", "cf_seg_infer", "cf_seg_fetch", "cf_seg_publish_poses", "cf_seg_fetch_poses",
     "cf_seg_labels",

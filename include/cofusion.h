@@ -16,9 +16,10 @@ typedef struct cofusion_handle cofusion_handle;
 typedef struct {
     int width, height;
     float fx, fy, cx, cy;
-    int device, max_surfels, max_models; /* at most min(max_models, 16) models are active at a time: the device segmentation holds 16
-                                          * labels (15 models + the "new model" label).  The reference allows 256 ids (CoFusion.cpp:631-634);
-                                          * beyond the cap new objects are not spawned (reported once on stderr) */
+    int device, max_surfels, max_models; /* at most min(max_models, 255) models are active at a time (default 16): the context's tracker
+                                          * staging and the segmentation's label dimension are sized by it; ids are 8 bits and 255 marks
+                                          * a rejected superpixel (the reference's own limit, CoFusion.cpp:631-634).  Beyond the cap new
+                                          * objects are not spawned (reported once on stderr) */
     float conf_global_init, conf_object_init, depth_cutoff, icp_weight, outlier_coefficient;
     int fast_odom, so3, frame_to_frame_rgb, pyramid, rgb_only;
     unsigned model_spawn_offset;

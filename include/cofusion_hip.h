@@ -224,20 +224,6 @@ int cf_odom_init_models_batch(cf_ctx *ctx, cf_odom *const *ods, int n, const flo
 int cf_odom_init_models_batch_frames(cf_ctx *ctx, cf_odom *const *ods, int n, const float *const *pred_vertex4,
                                      const float *const *pred_normal4, const uint8_t *const *pred_rgba, const float *const *poses /* n x [16] */,
                                      const uint8_t *const *frame_rgba /* n */);
-/* SO(3) pre-alignment of a FRAME.  RGBDOdometry::getIncrementalTransformation starts with up to ten SO(3) iterations
- * (RGBDOdometry.cpp:239-310) that read the previous and the new frame's level-2 intensity images and nothing else -- every tracker of a
- * frame repeats the same computation, and none of it depends on the maps.  cf_so3 does it once per frame and AHEAD: cf_so3_prealign only
- * needs the new colour image (e.g. on an auxiliary stream beside the previous frame's fusion passes), trackers that were given the handle
- * (cf_odom_set_prealignment) adopt its rotation and statistics at the start of cf_odom_track_batch_async instead of iterating -- the
- * same bits.  cf_so3_first_frame = initFirstRGB; cf_so3_commit = the image swap after a tracked frame (not after frames whose pose was
- * injected). */
-typedef struct cf_so3 cf_so3;
-int cf_so3_create(cf_ctx *ctx, cf_so3 **out);
-void cf_so3_destroy(cf_so3 *h);
-int cf_so3_first_frame(cf_so3 *h, const uint8_t *rgba);
-int cf_so3_prealign(cf_so3 *h, const uint8_t *rgba);
-int cf_so3_commit(cf_so3 *h);
-int cf_odom_set_prealignment(cf_odom *od, cf_so3 *h /* nullable */);
 /* initICP(depthPyramid, maskPyramid, depthCutoff) :48-49 (frame -> model); the mask pyramid is dead in the
  * reference (cudafuncs.cu:119) and therefore not part of the ABI */
 int cf_odom_init_icp(cf_odom *od, const float *const depth_pyr[CF_NUM_PYRS], float depth_cutoff);
@@ -308,10 +294,6 @@ int cf_model_initialise(cf_model *m, const uint8_t *rgba, const float *depth_raw
 int cf_model_count(cf_model *m, uint32_t *count);
 /* Model::predictIndices -> ModelProjection::predictIndices (ModelProjection.cpp:105-157) */
 int cf_model_predict_indices(cf_model *m, const float pose[16], int time, float maxDepth, int timeDelta);
-/* the same pass under the pose the tracker `od` has just computed and left in its device state -- without the host having fetched that
- * pose (cf_odom_fetch_result): the inverse is formed on the device with the statement the host uses, so the index map has the same bits.
- * Lets a frame loop enqueue every model's first index map right behind the tracking launches instead of behind its host wait. */
-int cf_model_predict_indices_tracked(cf_model *m, cf_odom *od, int time, float maxDepth, int timeDelta);
 /* predictIndices in two halves for a surfel map sharded over GPUs: rasterise the surfels [surfel_begin, surfel_end) into
  * keys_dev (u64 [H*W], filled by the call; smaller key = nearer surfel, ties -> lower id, empty = all ones), MIN-all-reduce
  * the key maps over the ranks as unsigned 64-bit integers, then resolve the reduced map into the model's index textures. */
@@ -381,6 +363,7 @@ typedef struct {
     float minRelSizeNew, maxRelSizeNew;                            /* 0.015, 0.4 */
     int crfIterations;                                             /* 10 */
 } cf_seg_params;
+#define CF_SEG_MAX_ENTRIES 256   /* model ids are 8 bits (CoFusion.cpp:631-634) and 255 marks a rejected superpixel: at most 255 models + the new label */
 typedef struct {  /* SegmentationResult::ModelData (Segmentation.h:45-71) */
     uint32_t id, superPixelCount;
     float avgConfidence, depthMean, depthStd;
@@ -389,7 +372,7 @@ typedef struct {  /* SegmentationResult::ModelData (Segmentation.h:45-71) */
 typedef struct {
     int32_t has_new_label, n_models;   /* n_models: rows of model[] (the new label's row is dropped when it got no superpixel) */
     float depth_range;
-    cf_seg_model model[17];
+    cf_seg_model model[CF_SEG_MAX_ENTRIES];   /* rows [0, n_models) are valid */
 } cf_seg_result;
 int cf_seg_sums(cf_segmenter *s, const float *depth, int n_models, const float *const *icp_err, const float *const *vertconf4,
                 int64_t **sums_dev, uint64_t *sums_words);
@@ -397,7 +380,7 @@ int cf_seg_infer(cf_segmenter *s, const cf_seg_params *params, const uint8_t *rg
                  uint32_t next_model_id, int allow_new, uint8_t *full_dev);
 int cf_seg_fetch(cf_segmenter *s, cf_seg_result *out, uint8_t *low_map_host);
 /* Model-parallel callers (one process per GPU, each tracking some of the models): the block cf_seg_sums hands out ends in a tail of
- * 16 x 18 words.  cf_seg_publish_poses (between cf_seg_sums and the caller's in-place SUM all-reduce of the block) writes there, for
+ * max_models x 18 words.  cf_seg_publish_poses (between cf_seg_sums and the caller's in-place SUM all-reduce of the block) writes there, for
  * every model tracked by THIS process (trackers[m] != NULL), the tracked pose (row-major 4x4) + ICP error + ICP inlier count as f32
  * bit patterns, zeros for the others; the all-reduce then leaves every model's pose on every rank, and cf_seg_fetch_poses hands
  * them out after cf_seg_infer / cf_seg_fetch ([n_models][18] words) -- no separate pose exchange, no extra host wait. */

@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 warnings.filterwarnings("ignore", category=RuntimeWarning)
 
-MAXM = 12
+MAXM = 24
 OUT = os.path.join(HERE, "configs_v1.npz")
 
 # name -> parameters of the seeded stream and of the pipeline (the same keyword names tests/test_configs_gpu.py hands to the facade)
@@ -45,6 +45,9 @@ SCENARIOS = {
     "objects8_640_200": dict(W=640, H=480, n_obj=8, frames=200, multi=True, conf_global=0.5, spawn_offset=2),
     # configs[4] at its own size: 1280x960, 4 moving objects + background, motion CRF on (the facade runs it with 32 M surfels per model)
     "objects4_1280": dict(W=1280, H=960, n_obj=4, frames=48, multi=True, conf_global=0.5, spawn_offset=2),
+    # MORE than 16 models at a time (round 4: the cap follows max_models up to the reference's 255 ids, CoFusion.cpp:631-634): 28 moving
+    # objects, ground-truth label masks (label * 9), a spawn per frame -- 27 models spawned in 34 frames, up to 19 alive together
+    "objects28_320_gt": dict(W=320, H=240, n_obj=28, frames=34, multi=True, conf_global=0.5, spawn_offset=1, gt_scale=9, max_models=64),
 }
 
 
@@ -69,13 +72,14 @@ def run_oracle(sc_name, n_frames=None, log=None):
     p = SCENARIOS[sc_name]
     cam = synth.Camera.scaled(p["W"], p["H"])
     sc = synth.Scene(n_obj=p["n_obj"])
-    ref = om.MultiPipeline(cam, conf_global=p["conf_global"], spawn_offset=p["spawn_offset"]) if p["multi"] else op.StaticPipeline(cam, conf_global=p["conf_global"])
+    ref = (om.MultiPipeline(cam, conf_global=p["conf_global"], spawn_offset=p["spawn_offset"], max_models=p.get("max_models", 16)) if p["multi"]
+           else op.StaticPipeline(cam, conf_global=p["conf_global"]))
     t0 = time.time()
     for t in range(n_frames or p["frames"]):
-        d, rgb, _, _ = sc.render(cam, t, noise=True)
+        d, rgb, lab, _ = sc.render(cam, t, noise=True)
         rgba = synth.rgb_to_rgba(rgb)
         if p["multi"]:
-            ref.process_frame(d, rgba)
+            ref.process_frame(d, rgba, gt_mask=(lab * p["gt_scale"]).astype(np.uint8) if p.get("gt_scale") else None)
             ms = ref.models
             rec = dict(ids=[m.id for m in ms], counts=[m.surfels.shape[0] for m in ms], poses=[m.pose.copy() for m in ms],
                        conf=[np.float32(m.conf_threshold) for m in ms], mask_sha=digest(ref.mask), surf_sha=[digest(m.surfels) for m in ms])

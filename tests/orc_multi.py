@@ -123,7 +123,7 @@ class MultiPipeline:
         self.depth_cutoff, self.icp_weight, self.outlier, self.so3 = depth_cutoff, icp_weight, outlier_coeff, so3
         self.conf_object = conf_object
         self.model_spawn_offset = spawn_offset
-        self.max_models = min(max_models, 16)  # host/CoFusion.cpp: a new label needs a free model slot
+        self.max_models = min(max_models, 255)  # host/CoFusion.cpp: a new label needs a free model slot (ids are 8 bits, 255 = rejected)
         self.spawn_offset = 0
         self.seg_params = seg_params or SegParams.defaults()
         self.tick = 1

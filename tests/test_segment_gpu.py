@@ -23,7 +23,7 @@ class SegModel(C.Structure):
 
 
 class SegResult(C.Structure):
-    _fields_ = [("has_new_label", C.c_int32), ("n_models", C.c_int32), ("depth_range", C.c_float), ("model", SegModel * 17)]
+    _fields_ = [("has_new_label", C.c_int32), ("n_models", C.c_int32), ("depth_range", C.c_float), ("model", SegModel * 256)]
 
 
 def _bits(x):
@@ -109,13 +109,23 @@ def _scenarios():
     d[:64, :] = 0.0; d[200:264, 300:364] = 0.0
     lab = np.zeros((GY, GX), np.int64); lab[:, :1] = 1; lab[10:20, 15:25] = 2
     out.append(("depth holes + border object", om.SegParams.defaults(), rgba_noise, d, [0, 1, 2], errs_from_labels(lab, 3), [vc(1.0, d)] * 3, 3, True))
+    # MORE THAN 16 LABELS (round 4: the label dimension follows the context's max_models up to the reference's 255 ids): 24 models in
+    # vertical bands + a new label, unary only and with the default CRF; 40 models, the accumulation in three tiles of 16
+    for n, params, name in ((24, unary_only, "24 models + new label, unary only"), (24, om.SegParams.defaults(), "24 models + new label, default CRF"),
+                            (40, unary_only, "40 models")):
+        lab = (xx * n // GX + (yy // 5) * 3) % n
+        e = errs_from_labels(lab, n, hi=0.08)
+        hole = _block_image(rng.random((GY, GX)) < 0.1) > 0
+        for m in range(n):
+            e[m][:] = np.where(hole, 0.3, e[m])
+        out.append((name, params, rgba_noise, depth_ramp, [0] + list(range(3, 3 + n - 1)), e, [vc(1.0, depth_ramp)] * n, 3 + n - 1, n == 24))
     return out
 
 
 def test_segmentation_stage_on_adversarial_label_images():
     from co_fusion_amd import api, synth
     cam = synth.Camera.scaled(W, H)
-    ctx = api.Context(W, H, cam.fx, cam.fy, cam.cx, cam.cy)
+    ctx = api.Context(W, H, cam.fx, cam.fy, cam.cx, cam.cy, max_models=48)
     seg = C.c_void_p()
     ctx._check(ctx.lib.cf_seg_create(ctx.h, C.byref(seg)))
     components = []

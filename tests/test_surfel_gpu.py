@@ -60,72 +60,6 @@ def test_bilateral_exact(ctx):
         _same(M.bilateral(ctx, ctx.to_device(f), 5.0).cpu().numpy(), op.bilateral(f, 5.0), f"bilateral {shape}")
 
 
-def test_bilateral_packed_flavour_exact():
-    """CF_BILATERAL_TAP2=1 (the packed-f32 flavour of the filter, off by default; the switch is read once per process): the same cases"""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, CF_BILATERAL_TAP2="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", f"{__file__}::test_bilateral_exact", f"{__file__}::test_static_pipeline_lockstep"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-@pytest.mark.parametrize("conf_global,n_frames,n_obj", [(10.0, 6, 0), (0.5, 8, 2)])
-def test_static_pipeline_lockstep(ctx, conf_global, n_frames, n_obj):
-    """Frame loop in lock-step.  conf 10 = reference default (fill-in tracking at start), conf 0.5
-    makes the splat prediction / model tracking / merge paths active from the second frame on."""
-    from co_fusion_amd import model as M
-    cam = synth.Camera.scaled(W, H)
-    sc = synth.Scene(n_obj=n_obj)
-    ref = op.StaticPipeline(cam, conf_global=conf_global)
-    import hip_pipeline
-    gpu = hip_pipeline.StaticPipeline(ctx, max_surfels=1 << 19, conf_global=conf_global)
-    ref_pose = {}
-    own_pose = {}
-
-    def _sync(tick, pose):  # keep later stages comparable even if a pose LSB differed; remember the GPU's own result
-        own_pose[tick] = pose.copy()
-        return ref_pose[tick]
-    gpu.sync_pose = _sync
-    exact = 0
-    merged_total = 0
-    for t in range(n_frames):
-        d, rgb, _, _ = sc.render(cam, t, noise=True)
-        rgba = synth.rgb_to_rgba(rgb)
-        tick = ref.tick
-        prev = ref.surfels.copy()
-        rp, rn = ref.process_frame(d, rgba)
-        ref_pose[tick] = rp
-        gp, gn = gpu.process_frame(ctx.to_device(d), ctx.to_device(rgba))
-        if tick > 1:
-            # the pose the GPU tracker produced on its own (before the sync hook) is in gpu.stats / compare via odom
-            assert gpu.stats.last_icp_count == ref.stats.last_icp_count, f"frame {t}: inliers"
-            np.testing.assert_allclose(np.array(gpu.stats.lastb), np.array(ref.stats.lastb), rtol=1e-9, atol=1e-12)
-            np.testing.assert_allclose(own_pose[tick], rp, atol=1e-6, rtol=0, err_msg=f"frame {t}: tracked pose")
-            exact += int(np.array_equal(own_pose[tick], rp))
-        np.testing.assert_allclose(gp, rp, atol=1e-6, rtol=0)
-        assert gn == rn, f"frame {t}: surfel count {gn} vs {rn}"
-        _same(gpu.model.download_map(), ref.surfels, f"frame {t}: surfel buffer")
-        img, vc, nr, tm = ref.pred
-        _same(gpu.model.buffer(4), img, f"frame {t}: splat image")
-        _same(gpu.model.buffer(5), vc, f"frame {t}: splat vertexConf")
-        _same(gpu.model.buffer(6), nr, f"frame {t}: splat normalRad")
-        _same(gpu.model.buffer(7), tm, f"frame {t}: splat time")
-        fv, fn, fi = ref.fill
-        _same(gpu.model.buffer(8), fv, f"frame {t}: fill vertex")
-        _same(gpu.model.buffer(9), fn, f"frame {t}: fill normal")
-        _same(gpu.model.buffer(10), fi, f"frame {t}: fill image")
-        if tick > 1 and prev.shape[0] == ref.surfels.shape[0]:
-            pass
-        if tick > 1:
-            merged_total += int((ref.surfels[:, 7] == tick).sum())
-    print(f"poses bit-identical on {exact} of {n_frames - 1} tracked frames")
-    assert merged_total > 1000, "the merge/update path was not exercised"
-    if conf_global < 1:
-        assert (ref.pred[1][..., 2] > 0).mean() > 0.3, "the splat prediction path was not exercised"
-    gpu.close()
-
 
 def test_index_map_exact(ctx):
     from co_fusion_amd import model as M

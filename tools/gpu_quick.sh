@@ -1,15 +1,21 @@
 #!/bin/bash
-# quick GPU check: facade + config parity, configs[2]/[1] bench lines, optional rocprof (PROF=1)
+# quick GPU check: a chosen set of tests (TESTS="..." [K="expr"]), configs[2]/[1] bench lines, optional rocprof (PROF=1)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-quick}
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-timeout 400 python -m pytest tests/test_facade_gpu.py tests/test_track_gpu.py ${EXTRA_TESTS:-} -m gpu -x -q > $O/pytest.log 2>&1; echo "tests rc=$?"; tail -3 $O/pytest.log
+if [ -n "${K:-}" ]; then
+  timeout ${TEST_TIMEOUT:-600} python -m pytest ${TESTS:-tests/test_facade_gpu.py tests/test_track_gpu.py} -m gpu -x -q -k "$K" > $O/pytest.log 2>&1; echo "tests rc=$?"
+else
+  timeout ${TEST_TIMEOUT:-600} python -m pytest ${TESTS:-tests/test_facade_gpu.py tests/test_track_gpu.py} -m gpu -x -q > $O/pytest.log 2>&1; echo "tests rc=$?"
+fi
+tail -${TAIL:-4} $O/pytest.log
 : > $O/sweep.jsonl
-timeout 150 python bench.py --workload objects4 --steps 100 --warmup 20 --no-cpu-baseline --no-extras >> $O/sweep.jsonl 2>> $O/sweep.err
-timeout 150 python bench.py --workload static --steps 120 --warmup 30 --no-cpu-baseline --no-extras >> $O/sweep.jsonl 2>> $O/sweep.err
+for A in ${LINES:-objects4 static}; do
+  timeout 150 python bench.py --workload $A --steps 100 --warmup 20 --no-cpu-baseline --no-extras ${BENCH_ARGS:-} >> $O/sweep.jsonl 2>> $O/sweep.err
+done
 python - <<PY
 import json
 for l in open("$O/sweep.jsonl"):
