@@ -83,6 +83,7 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
 
 void cf_destroy(cf_ctx* ctx)
 {
+    if (ctx && ctx->batch_event) (void)hipEventDestroy(ctx->batch_event);
     if (!ctx) return;
     (void)hipStreamSynchronize(ctx->stream);
     (void)cf_rccl_destroy(ctx);

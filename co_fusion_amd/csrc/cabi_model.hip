@@ -30,6 +30,7 @@ struct cf_model {
     // points that expose the number to the host (cf_model_count, download, buffer 11) resolve it on demand.
     bool count_pending = false;
     hipEvent_t count_event = nullptr;
+    hipEvent_t count_wait = nullptr;  // the event that marks the pending count: count_event, or the context's batch event (cf_models_frame_passes)
     // same for the fill-in ratio of the latest splat prediction (computed right after combinedPredict)
     bool ratio_valid = false;
     hipEvent_t ratio_event = nullptr;
@@ -198,6 +199,7 @@ static int post_count(cf_model* m, uint32_t upper_bound)
 {
     cf_ctx* ctx = m->ctx;
     HIPCHK(ctx, hipEventRecord(m->count_event, ctx->cur()));
+    m->count_wait = m->count_event;
     m->count_host = upper_bound;
     m->count_pending = true;
     return CF_OK;
@@ -206,7 +208,8 @@ static int post_count(cf_model* m, uint32_t upper_bound)
 static int count_bound(cf_model* m, uint32_t* out)
 {
     if (m->count_pending) {
-        if (hipEventQuery(m->count_event) == hipSuccess) { if (int r = adopt_count(m)) return r; }
+        if (!m->count_wait) { if (int r = sync_count(m)) return r; *out = m->count_host; return CF_OK; }   // (a batch that failed before recording its event)
+        if (hipEventQuery(m->count_wait) == hipSuccess) { if (int r = adopt_count(m)) return r; }
         else (void)hipGetLastError();  // hipErrorNotReady is not an error here
     }
     *out = m->count_host;
@@ -215,7 +218,8 @@ static int count_bound(cf_model* m, uint32_t* out)
 static int exact_count(cf_model* m, uint32_t* out)
 {
     if (m->count_pending) {
-        HIPCHK(m->ctx, hipEventSynchronize(m->count_event));
+        if (!m->count_wait) { if (int r = sync_count(m)) return r; *out = m->count_host; return CF_OK; }
+        HIPCHK(m->ctx, hipEventSynchronize(m->count_wait));
         if (int r = adopt_count(m)) return r;
     }
     *out = m->count_host;
@@ -414,6 +418,110 @@ int cf_model_clean(cf_model* m, const float pose[16], int time, float confThresh
     const uint32_t upper = bound < m->max_surfels ? bound : m->max_surfels;
     if (int r = post_count(m, upper)) return r;
     if (count_out) return exact_count(m, count_out);  // the GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN query: waits
+    return CF_OK;
+}
+
+// The second half of a frame for several models in lock-step (see the header): the statements of cf_model_predict_indices / _fuse /
+// _clean / _combined_predict, every stage one batched launch.
+int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float depth_cutoff, float outlier_coeff, int time_delta)
+{
+    if (!ctx || !items || n <= 0) return CF_EINVAL;
+    hipStream_t s = ctx->cur();
+    const int W = ctx->cfg.width, H = ctx->cfg.height; const long long N = (long long)W * H;
+    const cf_cam cam = ctx_cam(ctx);
+    std::vector<int> fusing;
+    for (int k = 0; k < n; k++) {
+        const cf_model_pass& it = items[k];
+        if (!it.model || it.model->ctx != ctx || !it.pose || !it.rgba || !it.depth_filtered) return CF_EINVAL;
+        if (it.do_fuse) { if (!it.mask || !it.depth_raw) return CF_EINVAL; fusing.push_back(k); }
+    }
+    auto index_pass = [&](const std::vector<int>& which) -> int {
+        std::vector<IndexPassArgs> a(which.size());
+        for (size_t q = 0; q < which.size(); q++) {
+            const cf_model_pass& it = items[which[q]]; cf_model* m = it.model;
+            uint32_t nb = 0;
+            if (int r = count_bound(m, &nb)) return r;
+            IndexPassArgs& p = a[q];
+            p.surfels = m->buf[m->target]; p.count = m->d_count; p.id_begin = 0; p.id_end = nb; inv44f(it.pose, p.t_inv); p.maxDepth = depth_cutoff;
+            p.time = it.time; p.timeDelta = time_delta; p.keys = m->keys; p.index = m->index; p.vertConf = m->vertConf; p.colorTime = m->colorTime;
+            p.normRad = m->normRad;
+        }
+        launch_index_keys_batch(s, a.data(), (int)a.size(), cam, W, H);
+        launch_index_resolve_batch(s, a.data(), (int)a.size(), cam, W, H);
+        return CF_OK;
+    };
+    if (!fusing.empty()) {
+        const int nf = (int)fusing.size();
+        if (int r = index_pass(fusing)) return r;
+        // Model::fuse (Model.cpp:408-563)
+        std::vector<SurfelFuseArgs> fa(nf);
+        std::vector<ScanPassArgs> sa(nf);
+        std::vector<UpdatePassArgs> ua(nf);
+        for (int q = 0; q < nf; q++) {
+            const cf_model_pass& it = items[fusing[q]]; cf_model* m = it.model;
+            SurfelFuseArgs& a = fa[q];
+            a.index = m->index; a.vertConf = m->vertConf; a.normRad = m->normRad; a.rgba = it.rgba; a.depth_raw = it.depth_raw; a.depth_filt = it.depth_filtered;
+            a.mask = it.mask; a.tcx = m->tcx; a.tcy = m->tcy; memcpy(a.pose, it.pose, sizeof(a.pose)); a.cam = cam; a.inv_fx = m->inv_fx;
+            a.inv_fy = m->inv_fy; a.cols = W; a.rows = H; a.time = it.time; a.weighting = it.weighting; a.maskID = it.mask_id; a.maxDepth = it.fuse_max_depth;
+            a.records = m->records; a.new_flags = m->new_flags; a.owner = m->owner;
+            sa[q] = ScanPassArgs{m->records, m->new_flags, N, m->block_sums, m->d_nfresh, 0, m->fresh, nullptr};
+            uint32_t nb = 0;
+            if (int r = count_bound(m, &nb)) return r;
+            ua[q] = UpdatePassArgs{m->buf[m->target], m->d_count, nb, m->owner, m->records, it.time, m->buf[1 - m->target]};
+        }
+        launch_associate_batch(s, fa.data(), nf);
+        launch_scan_scatter_batch(s, sa.data(), nf);   // the new unstable vertices in column-major draw order (transform feedback of data.geom)
+        launch_update_batch(s, ua.data(), nf);          // update.vert over all surfels into the other buffer, then swap (Model.cpp:559)
+        for (int q = 0; q < nf; q++) items[fusing[q]].model->target = 1 - items[fusing[q]].model->target;
+        if (int r = index_pass(fusing)) return r;
+        // Model::clean (Model.cpp:565-697)
+        std::vector<CleanPassArgs> ca(nf);
+        std::vector<uint32_t> upper(nf);
+        for (int q = 0; q < nf; q++) {
+            const cf_model_pass& it = items[fusing[q]]; cf_model* m = it.model;
+            uint32_t nb = 0;
+            if (int r = count_bound(m, &nb)) return r;
+            const unsigned bound = nb + (unsigned)((W / 2) * (H / 2));
+            if (bound > m->max_surfels + (unsigned)(W * H / 4 + 64)) return CF_ENOMEM;
+            CleanPassArgs& c = ca[q];
+            c.h.index = m->index; c.h.vertConf = m->vertConf; c.h.colorTime = m->colorTime; c.h.depth_filt = it.depth_filtered; c.h.mask = it.mask;
+            inv44f(it.pose, c.h.t_inv); c.h.cam = cam; c.h.cols = W; c.h.rows = H; c.h.time = it.time; c.h.confThreshold = it.conf_threshold;
+            c.h.outlierCoeff = outlier_coeff; c.h.timeDelta = time_delta; c.h.maskID = it.mask_id;
+            c.surfels = m->buf[m->target]; c.count = m->d_count; c.fresh = m->fresh; c.n_fresh = m->d_nfresh; c.total_bound = bound; c.staged = m->staged;
+            c.flags = m->flags;
+            sa[q] = ScanPassArgs{m->staged, m->flags, (long long)bound, m->block_sums, m->d_count, 0, m->buf[1 - m->target], m->h_counts};  // the kept total IS the new count
+            upper[q] = bound < m->max_surfels ? bound : m->max_surfels;
+        }
+        launch_clean_batch(s, ca.data(), nf);
+        launch_scan_scatter_batch(s, sa.data(), nf);
+        // the compactions write the new counts into pinned host memory themselves; ONE event (recorded below, behind the prediction
+        // launches: the host does not keep the GPU waiting for five event records here) marks them all.  Until it has completed the
+        // models carry the upper bound.
+        if (!ctx->batch_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->batch_event, hipEventDisableTiming));
+        for (int q = 0; q < nf; q++) {
+            cf_model* m = items[fusing[q]].model;
+            m->target = 1 - m->target;
+            m->count_host = upper[q]; m->count_pending = true; m->count_wait = nullptr;   // (nullptr until the event below is recorded)
+        }
+    }
+    // combinedPredict(maxDepthProcessed, time, time, timeDelta) of every model (CoFusion.cpp:533-545)
+    std::vector<SplatPassArgs> pa(n);
+    for (int k = 0; k < n; k++) {
+        const cf_model_pass& it = items[k]; cf_model* m = it.model;
+        uint32_t nb = m->count_host;   // (exact, or the upper bound the clean stage has just set)
+        if (!(m->count_pending && !m->count_wait)) { if (int r = count_bound(m, &nb)) return r; }
+        SplatPassArgs& p = pa[k];
+        p.surfels = m->buf[m->target]; p.count = m->d_count; p.count_bound = nb; inv44f(it.pose, p.t_inv); p.maxDepth = depth_cutoff;
+        p.confThreshold = it.conf_threshold; p.time = it.time; p.maxTime = it.time; p.timeDelta = time_delta; p.rays = m->rays; p.keys = m->keys;
+        p.image = m->splat_image; p.vertexConf = m->splat_vertex; p.normalRad = m->splat_normal; p.time16 = m->splat_time;
+        m->ratio_valid = false;  // a new prediction: any prefetched fill-in ratio is stale
+    }
+    launch_combined_predict_batch(s, pa.data(), n, cam, W, H);
+    LAUNCHCHK(ctx);
+    if (!fusing.empty()) {
+        HIPCHK(ctx, hipEventRecord(ctx->batch_event, s));
+        for (int k : fusing) items[k].model->count_wait = ctx->batch_event;
+    }
     return CF_OK;
 }
 

@@ -38,6 +38,7 @@ struct cf_ctx {
     cf::OdomDev* d_state_pool = nullptr;
     cf::OdomDev* h_state_pool = nullptr;  // pinned
     bool slot_used[kStateSlots]{};
+    hipEvent_t batch_event = nullptr;     // cf_models_frame_passes: ONE event behind a batch's compactions marks all its models' counts
     bool state_readback_pending = false;  // a range read-back is in flight: host state must not be rewritten before it lands
     // auxiliary streams for independent per-model work of one frame (cf_fork / cf_join)
     static constexpr int kLanes = 8;

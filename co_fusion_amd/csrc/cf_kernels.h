@@ -263,6 +263,18 @@ float sqrt_gate_lt(float T);  // smallest x with sqrtf(x) >= T
 float sqrt_gate_le(float T);  // largest x with sqrtf(x) <= T
 
 // ---- surfel launchers (surfel.hip) ----
+// Every pass exists as a LOCK-STEP BATCH: one launch covers the models of a frame (or of several sequences' frames), kSurfBatch at a
+// time -- the workgroups of the launch are dealt to the models (surfel.hip: BatchHdr).  The single-model launchers are batches of one.
+constexpr int kSurfBatch = 16;   // models per launch (their arguments travel in the 4 KB kernel-argument segment)
+struct IndexPassArgs {   // Model::predictIndices of one model: rasterise surfels [id_begin, id_end) into the z-keys, resolve
+    const float* surfels; const unsigned* count; unsigned id_begin, id_end; float t_inv[16]; float maxDepth; int time, timeDelta;
+    unsigned long long* keys; unsigned* index; float* vertConf; float* colorTime; float* normRad;
+};
+struct SplatPassArgs {   // ModelProjection::combinedPredict of one model
+    const float* surfels; const unsigned* count; unsigned count_bound; float t_inv[16]; float maxDepth, confThreshold; int time, maxTime, timeDelta;
+    const float* rays; unsigned long long* keys; uint8_t* image; float* vertexConf; float* normalRad; uint16_t* time16;
+};
+struct UpdatePassArgs { const float* in; const unsigned* count; unsigned count_bound; unsigned* owner; const float* records; int time; float* out; };
 struct SurfelFuseArgs {
     const unsigned* index; const float* vertConf; const float* normRad;
     const uint8_t* rgba; const float* depth_raw; const float* depth_filt; const uint8_t* mask;
@@ -276,6 +288,20 @@ struct SurfelCleanArgs {
     const float* depth_filt; const uint8_t* mask;
     float t_inv[16]; cf_cam cam; int cols, rows, time; float confThreshold, outlierCoeff; int timeDelta, maskID;
 };
+struct CleanPassArgs {   // Model::clean of one model
+    SurfelCleanArgs h; const float* surfels; const unsigned* count; const float* fresh; const unsigned* n_fresh; unsigned total_bound;
+    float* staged; unsigned* flags;
+};
+struct ScanPassArgs {    // one ordered compaction (transform feedback): the flagged 48 B records of rec [n] to out, their number (+ add) to *total
+    const float* rec; const unsigned* flags; long long n; unsigned* block_sums; unsigned* total; unsigned add_to_total; float* out; unsigned* total_host;
+};
+void launch_index_keys_batch(hipStream_t s, const IndexPassArgs* items, int n, cf_cam cam, int cols, int rows);
+void launch_index_resolve_batch(hipStream_t s, const IndexPassArgs* items, int n, cf_cam cam, int cols, int rows);
+void launch_combined_predict_batch(hipStream_t s, const SplatPassArgs* items, int n, cf_cam cam, int cols, int rows);
+void launch_associate_batch(hipStream_t s, const SurfelFuseArgs* items, int n);   // zeroes every model's new_flags first
+void launch_update_batch(hipStream_t s, const UpdatePassArgs* items, int n);
+void launch_clean_batch(hipStream_t s, const CleanPassArgs* items, int n);
+void launch_scan_scatter_batch(hipStream_t s, const ScanPassArgs* items, int n);
 void launch_bilateral(hipStream_t s, const float* depth, int cols, int rows, float maxD, float* out);
 void launch_exclusive_scan(hipStream_t s, const unsigned* flags, long long n, unsigned* offsets, unsigned* block_sums, unsigned* total,
                            unsigned add_to_total);

@@ -36,11 +36,43 @@ static int xcd_env(const char* name, int dflt) { const char* e = getenv(name); r
 #else
 static constexpr int xcd_env(const char*, int dflt) { return dflt; }
 #endif
-__device__ __forceinline__ int xcd_block(int chunk)
+// LOCK-STEP BATCHES (round 4).  The surfel passes of a frame are the same chain of ~16 kernels for every model, and an object model's
+// share of each is a few dozen workgroups: as one chain per model on its own stream (rounds 1-3) the five chains of configs[2] took
+// 450 us of a 1.5 ms frame -- the HIP streams share a handful of hardware queues, so chains ran one after another, 100 launch-floor
+// kernels in all (profiles/r4e timeline).  Now every stage is ONE launch for all models of the batch, exactly as the tracking
+// launches have been since round 1: a one-dimensional grid [model 0's workgroups | model 1's | ...], the running totals in the
+// kernel arguments (BatchHdr), each model's arguments beside them.  A workgroup finds its model with 15 scalar compares and then
+// runs the unchanged per-model code on its virtual block index.  Every model's share starts at a multiple of 8 workgroups, so the
+// XCD of a workgroup (hardware id mod 8) is also that of its virtual index (xcd_block).
+struct BatchHdr { int n; int blk_end[kSurfBatch]; };
+template <class A> struct Batch { BatchHdr h; A m[kSurfBatch]; };
+struct VBlock { int model, bid, nblk; };
+__device__ __forceinline__ VBlock batch_decode(const BatchHdr& h)
 {
     const int b = blockIdx.x;
+    int slot = 0;
+#pragma unroll
+    for (int k = 0; k < kSurfBatch - 1; k++) slot += (b >= h.blk_end[k]) ? 1 : 0;
+    const int start = slot ? h.blk_end[slot - 1] : 0;
+    return VBlock{slot, b - start, h.blk_end[slot] - start};
+}
+// host side: the table of a launch from the models' workgroup counts (each padded to a multiple of 8); returns the grid size
+template <class A>
+static int batch_layout(Batch<A>& B, const int* blocks, int n)
+{
+    int total = 0;
+    B.h.n = n;
+    for (int k = 0; k < kSurfBatch; k++) {
+        if (k < n) total += (blocks[k] + 7) / 8 * 8;
+        B.h.blk_end[k] = k < n ? total : 0x7fffffff;
+    }
+    return total;
+}
+
+__device__ __forceinline__ int xcd_block(int chunk, int b, int nblk)
+{
     if (chunk == 0) return b;
-    const int per = (int)gridDim.x >> 3, x = b & 7, r = b >> 3;  // XCD, rank inside the XCD
+    const int per = nblk >> 3, x = b & 7, r = b >> 3;  // XCD, rank inside the XCD
     if (chunk < 0) return x * per + r;
     const int lb = ((r / chunk) * 8 + x) * chunk + (r % chunk);
     return lb;  // (the grid is a multiple of 8 * chunk: a bijection)
@@ -92,9 +124,17 @@ __global__ void __launch_bounds__(kB) bilateral_kernel(const float* __restrict__
 // ==================================================================== ordered compaction (scan) ====
 // Exclusive scan of u32 flags in three phases; blocks of kScanItems elements.
 static constexpr int kScanItems = 2048;  // 256 threads x 8
-__global__ void __launch_bounds__(256) scan_block_sums_kernel(const unsigned* __restrict__ flags, long long n, unsigned* __restrict__ block_sums)
+struct ScanArgs {   // one ordered compaction: flags [n] -> block sums -> the flagged 48 B records of rec moved to out, in order
+    const float4* rec; const unsigned* flags; long long n; unsigned* block_sums; unsigned* total; unsigned add_to_total; float4* out;
+    unsigned* total_host;
+};
+__global__ void __launch_bounds__(256) scan_block_sums_kernel(const Batch<ScanArgs> B)
 {
-    const long long base = (long long)blockIdx.x * kScanItems;
+    const VBlock vb = batch_decode(B.h);
+    const ScanArgs& a = B.m[vb.model];
+    const unsigned* __restrict__ flags = a.flags; const long long n = a.n; unsigned* __restrict__ block_sums = a.block_sums;
+    if ((long long)vb.bid * kScanItems >= n) return;   // (padding workgroups of the batch layout)
+    const long long base = (long long)vb.bid * kScanItems;
     unsigned s = 0;
     for (int k = 0; k < 8; k++) {
         const long long i = base + k * 256 + threadIdx.x;
@@ -104,7 +144,7 @@ __global__ void __launch_bounds__(256) scan_block_sums_kernel(const unsigned* __
     __shared__ unsigned w[4];
     if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+    if (threadIdx.x == 0) block_sums[vb.bid] = w[0] + w[1] + w[2] + w[3];
 }
 // single workgroup: exclusive scan of the block sums (nb <= 1024*64), total -> *total
 __global__ void __launch_bounds__(1024) scan_spine_kernel(unsigned* __restrict__ block_sums, int nb, unsigned* __restrict__ total,
@@ -162,19 +202,24 @@ __global__ void set_count2_kernel(unsigned* out, unsigned* out_host, unsigned v)
 // sums of the workgroups before it (at most a few hundred values), scans its 2048 flags -- eight consecutive flags per thread, so
 // one pass and two barriers -- and moves the flagged 48 B records straight to their place; the last workgroup publishes the total.
 // Replaces {spine scan, per-element offsets, scatter} = three launches and an offsets array.
-__global__ void __launch_bounds__(256) scan_scatter_kernel(const float4* __restrict__ rec, const unsigned* __restrict__ flags, long long n,
-                                                           const unsigned* __restrict__ block_sums, unsigned* __restrict__ total,
-                                                           unsigned add_to_total, float4* __restrict__ out, unsigned* __restrict__ total_host)
+__global__ void __launch_bounds__(256) scan_scatter_kernel(const Batch<ScanArgs> B)
 {
+    const VBlock vb = batch_decode(B.h);
+    const ScanArgs& a = B.m[vb.model];
+    const float4* __restrict__ rec = a.rec; const unsigned* __restrict__ flags = a.flags; const long long n = a.n;
+    const unsigned* __restrict__ block_sums = a.block_sums; unsigned* __restrict__ total = a.total; const unsigned add_to_total = a.add_to_total;
+    float4* __restrict__ out = a.out; unsigned* __restrict__ total_host = a.total_host;
+    const int nb = (int)((n + kScanItems - 1) / kScanItems);   // workgroups that hold elements (the batch layout pads to a multiple of 8)
+    if (vb.bid >= nb) return;
     __shared__ unsigned wsum[4], s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned b = 0;
-    for (int k = tid; k < (int)blockIdx.x; k += 256) b += block_sums[k];
+    for (int k = tid; k < vb.bid; k += 256) b += block_sums[k];
     for (int o = 32; o > 0; o >>= 1) b += __shfl_xor((int)b, o, 64);
     if (lane == 0) wsum[wave] = b;
     __syncthreads();
     if (tid == 0) s_base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    const long long i0 = (long long)blockIdx.x * kScanItems + (long long)tid * 8;
+    const long long i0 = (long long)vb.bid * kScanItems + (long long)tid * 8;
     unsigned f[8];
     if (i0 + 8 <= n) {
         const uint4 a = *reinterpret_cast<const uint4*>(flags + i0), c = *reinterpret_cast<const uint4*>(flags + i0 + 4);
@@ -200,27 +245,49 @@ __global__ void __launch_bounds__(256) scan_scatter_kernel(const float4* __restr
             out[o] = rec[r]; out[o + 1] = rec[r + 1]; out[o + 2] = rec[r + 2];
             off++;
         }
-    if (blockIdx.x == gridDim.x - 1 && tid == 255) {  // the last thread's running offset is the total
+    if (vb.bid == nb - 1 && tid == 255) {  // the last thread's running offset is the total
         *total = off + add_to_total;
         if (total_host) *total_host = off + add_to_total;  // pinned host memory: the read-back needs no copy command on the stream
     }
 }
 
+// n models' compactions in two launches; a model without elements (n == 0) only has its total set
+void launch_scan_scatter_batch(hipStream_t s, const ScanPassArgs* items, int n_items)
+{
+    for (int base = 0; base < n_items; base += kSurfBatch) {
+        const int nb = n_items - base < kSurfBatch ? n_items - base : kSurfBatch;
+        Batch<ScanArgs> B;
+        int blocks[kSurfBatch], any = 0;
+        for (int k = 0; k < nb; k++) {
+            const ScanPassArgs& h = items[base + k];
+            B.m[k] = ScanArgs{reinterpret_cast<const float4*>(h.rec), h.flags, h.n, h.block_sums, h.total, h.add_to_total, reinterpret_cast<float4*>(h.out), h.total_host};
+            blocks[k] = (int)((B.m[k].n + kScanItems - 1) / kScanItems);
+            any += blocks[k];
+            if (blocks[k] == 0) set_count2_kernel<<<1, 1, 0, s>>>(B.m[k].total, B.m[k].total_host, B.m[k].add_to_total);
+        }
+        if (!any) continue;
+        const int grid = batch_layout(B, blocks, nb);
+        scan_block_sums_kernel<<<grid, 256, 0, s>>>(B);
+        scan_scatter_kernel<<<grid, 256, 0, s>>>(B);
+    }
+}
 void launch_scan_scatter(hipStream_t s, const float* rec, const unsigned* flags, long long n, unsigned* block_sums, unsigned* total,
                          unsigned add_to_total, float* out, unsigned* total_host)
 {
-    const int nb = (int)((n + kScanItems - 1) / kScanItems);
-    if (nb == 0) { set_count2_kernel<<<1, 1, 0, s>>>(total, total_host, add_to_total); return; }
-    scan_block_sums_kernel<<<nb, 256, 0, s>>>(flags, n, block_sums);
-    scan_scatter_kernel<<<nb, 256, 0, s>>>(reinterpret_cast<const float4*>(rec), flags, n, block_sums, total, add_to_total,
-                                           reinterpret_cast<float4*>(out), total_host);
+    const ScanPassArgs a{rec, flags, n, block_sums, total, add_to_total, out, total_host};
+    launch_scan_scatter_batch(s, &a, 1);
 }
 
 void launch_exclusive_scan(hipStream_t s, const unsigned* flags, long long n, unsigned* offsets, unsigned* block_sums, unsigned* total,
                            unsigned add_to_total)
 {
     const int nb = (int)((n + kScanItems - 1) / kScanItems);
-    if (nb > 0) scan_block_sums_kernel<<<nb, 256, 0, s>>>(flags, n, block_sums);
+    if (nb > 0) {
+        Batch<ScanArgs> B;
+        B.m[0] = ScanArgs{nullptr, flags, n, block_sums, total, add_to_total, nullptr, nullptr};
+        const int grid = batch_layout(B, &nb, 1);
+        scan_block_sums_kernel<<<grid, 256, 0, s>>>(B);
+    }
     scan_spine_kernel<<<1, 1024, 0, s>>>(block_sums, nb, total, add_to_total);
     if (nb > 0) scan_offsets_kernel<<<nb, 256, 0, s>>>(flags, n, block_sums, offsets);
 }
@@ -284,26 +351,33 @@ __device__ __forceinline__ bool index_project(const float4 pc, const float4 ct, 
     return true;
 }
 
-// t_dev (nullable): the transform in device memory instead of the kernel argument -- the inverse of a pose the tracker has just left
-__global__ void __launch_bounds__(kB) index_splat_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count, Mat4 t_inv,
-                                                         cf_cam cam, int cols, int rows, float maxDepth, int time,
-                                                         int timeDelta, unsigned id_begin, unsigned id_end, unsigned long long* __restrict__ keys)
+struct IndexArgs {   // predictIndices of one model (both kernels)
+    const float4* surfels; const unsigned* count; Mat4 t_inv; float maxDepth; int time, timeDelta; unsigned id_begin, id_end;
+    unsigned long long* keys; unsigned* index; float4* vertConf; float4* colorTime; float4* normRad;
+};
+struct FrameGeom { cf_cam cam; int cols, rows; };   // what the models of a launch share
+
+__global__ void __launch_bounds__(kB) index_splat_kernel(const Batch<IndexArgs> B, const FrameGeom g)
 {
+    const VBlock vb = batch_decode(B.h);
+    const IndexArgs& a = B.m[vb.model];
+    const float4* __restrict__ surfels = a.surfels;
     // [id_begin, id_end): the surfel range of this launch (the whole map, or a rank's shard of it)
-    const unsigned id = id_begin + blockIdx.x * kB + threadIdx.x;
-    if (id >= *count || id >= id_end) return;
+    const unsigned id = a.id_begin + vb.bid * kB + threadIdx.x;
+    if (id >= *a.count || id >= a.id_end) return;
     f3 ph; int q;
-    if (!index_project(surfels[id * 3], surfels[id * 3 + 1], t_inv, cam, cols, rows, maxDepth, time, timeDelta, ph, q)) return;
-    atomicMin(&keys[q], zkey(ph.z, id));
+    if (!index_project(surfels[id * 3], surfels[id * 3 + 1], a.t_inv, g.cam, g.cols, g.rows, a.maxDepth, a.time, a.timeDelta, ph, q)) return;
+    atomicMin(&a.keys[q], zkey(ph.z, id));
 }
 
-__global__ void __launch_bounds__(kB) index_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_inv, int N,
-                                                           unsigned long long* __restrict__ keys, unsigned* __restrict__ index,
-                                                           float4* __restrict__ vertConf, float4* __restrict__ colorTime,
-                                                           float4* __restrict__ normRad)
+__global__ void __launch_bounds__(kB) index_resolve_kernel(const Batch<IndexArgs> B, const FrameGeom g)
 {
-    const int q = blockIdx.x * kB + threadIdx.x;
-    if (q >= N) return;
+    const VBlock vb = batch_decode(B.h);
+    const IndexArgs& a = B.m[vb.model];
+    const float4* __restrict__ surfels = a.surfels; unsigned long long* __restrict__ keys = a.keys; unsigned* __restrict__ index = a.index;
+    float4* __restrict__ vertConf = a.vertConf; float4* __restrict__ colorTime = a.colorTime; float4* __restrict__ normRad = a.normRad;
+    const int q = vb.bid * kB + threadIdx.x;
+    if (q >= g.cols * g.rows) return;
     const unsigned long long k = keys[q];
     keys[q] = kEmptyKey;  // leave the z-buffer cleared for the next pass (no memset launch per projection)
     if (k == kEmptyKey) {
@@ -313,8 +387,8 @@ __global__ void __launch_bounds__(kB) index_resolve_kernel(const float4* __restr
     }
     const unsigned id = (unsigned)k;
     const float4 pc = surfels[id * 3], ct = surfels[id * 3 + 1], nr = surfels[id * 3 + 2];
-    const f3 ph = xform_point(t_inv, f3{pc.x, pc.y, pc.z});
-    const f3 n = normalized(xform_dir(t_inv, f3{nr.x, nr.y, nr.z}));
+    const f3 ph = xform_point(a.t_inv, f3{pc.x, pc.y, pc.z});
+    const f3 n = normalized(xform_dir(a.t_inv, f3{nr.x, nr.y, nr.z}));
     index[q] = id;
     vertConf[q] = make_float4(ph.x, ph.y, ph.z, pc.w);
     colorTime[q] = ct;
@@ -381,20 +455,26 @@ __global__ void __launch_bounds__(kB) splat_rays_kernel(cf_cam cam, int cols, in
     rays[q] = make_float4(l.x, l.y, l.z, 0.f);
 }
 
-__global__ void __launch_bounds__(kB) splat_raster_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count, Mat4 t_inv,
-                                                          cf_cam cam, int cols, int rows, float maxDepth, float confThreshold, int time,
-                                                          int maxTime, int timeDelta, const float4* __restrict__ rays,
-                                                          unsigned long long* __restrict__ keys)
+struct SplatArgs {   // combinedPredict of one model (both kernels)
+    const float4* surfels; const unsigned* count; Mat4 t_inv; float maxDepth, confThreshold; int time, maxTime, timeDelta;
+    const float4* rays; unsigned long long* keys; uchar4* image; float4* vertexConf; float4* normalRad; unsigned short* time16;
+};
+
+__global__ void __launch_bounds__(kB) splat_raster_kernel(const Batch<SplatArgs> B, const FrameGeom g)
 {
+    const VBlock vb = batch_decode(B.h);
+    const SplatArgs& a = B.m[vb.model];
+    const float4* __restrict__ surfels = a.surfels; const float4* __restrict__ rays = a.rays; unsigned long long* __restrict__ keys = a.keys;
+    const int cols = g.cols, rows = g.rows;
     // four lanes per surfel: the fragments of a point sprite are independent (the z-test is an atomicMin), and a
     // lane walking a 5x5 footprint alone is a chain of 25 dependent ray loads; the set-up is recomputed per lane
-    const unsigned gt = blockIdx.x * kB + threadIdx.x;
+    const unsigned gt = vb.bid * kB + threadIdx.x;
     const unsigned id = gt >> 2;
     const int sub = (int)(gt & 3u);
-    if (id >= *count) return;
+    if (id >= *a.count) return;
     SplatSetup s;
-    if (!splat_setup(surfels[id * 3], surfels[id * 3 + 1], surfels[id * 3 + 2], t_inv, cam, cols, rows, maxDepth, confThreshold, time, maxTime,
-                     timeDelta, s))
+    if (!splat_setup(surfels[id * 3], surfels[id * 3 + 1], surfels[id * 3 + 2], a.t_inv, g.cam, cols, rows, a.maxDepth, a.confThreshold, a.time,
+                     a.maxTime, a.timeDelta, s))
         return;
     const int w = s.x_hi - s.x_lo + 1, h = s.y_hi - s.y_lo + 1;
     if (w <= 0 || h <= 0) return;
@@ -403,20 +483,22 @@ __global__ void __launch_bounds__(kB) splat_raster_kernel(const float4* __restri
     while (fy < h) {
         const int px = s.x_lo + fx, py = s.y_lo + fy;
         float z;
-        if (splat_fragment(s, rays, cols, px, py, maxDepth, z)) atomicMin(&keys[py * cols + px], zkey(z, id));
+        if (splat_fragment(s, rays, cols, px, py, a.maxDepth, z)) atomicMin(&keys[py * cols + px], zkey(z, id));
         fx += 4;
         while (fx >= w) { fx -= w; fy++; }
     }
 }
 
-__global__ void __launch_bounds__(kB) splat_resolve_kernel(const float4* __restrict__ surfels, Mat4 t_inv, cf_cam cam, int cols, int rows,
-                                                           float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
-                                                           const float4* __restrict__ rays, unsigned long long* __restrict__ keys,
-                                                           uchar4* __restrict__ image,
-                                                           float4* __restrict__ vertexConf, float4* __restrict__ normalRad,
-                                                           unsigned short* __restrict__ time16)
+__global__ void __launch_bounds__(kB) splat_resolve_kernel(const Batch<SplatArgs> B, const FrameGeom g)
 {
-    const int q = blockIdx.x * kB + threadIdx.x;
+    const VBlock vb = batch_decode(B.h);
+    const SplatArgs& a = B.m[vb.model];
+    const float4* __restrict__ surfels = a.surfels; const float4* __restrict__ rays = a.rays; unsigned long long* __restrict__ keys = a.keys;
+    uchar4* __restrict__ image = a.image; float4* __restrict__ vertexConf = a.vertexConf; float4* __restrict__ normalRad = a.normalRad;
+    unsigned short* __restrict__ time16 = a.time16;
+    const int cols = g.cols, rows = g.rows;
+    const cf_cam cam = g.cam;
+    const int q = vb.bid * kB + threadIdx.x;
     if (q >= cols * rows) return;
     const unsigned long long k = keys[q];
     keys[q] = kEmptyKey;  // leave the z-buffer cleared for the next pass (no memset launch per projection)
@@ -430,9 +512,9 @@ __global__ void __launch_bounds__(kB) splat_resolve_kernel(const float4* __restr
     const int py = q / cols, px = q - py * cols;
     const float4 pc = surfels[id * 3], ct = surfels[id * 3 + 1], nr = surfels[id * 3 + 2];
     SplatSetup s;
-    splat_setup(pc, ct, nr, t_inv, cam, cols, rows, maxDepth, confThreshold, time, maxTime, timeDelta, s);
+    splat_setup(pc, ct, nr, a.t_inv, cam, cols, rows, a.maxDepth, a.confThreshold, a.time, a.maxTime, a.timeDelta, s);
     float z;
-    splat_fragment(s, rays, cols, px, py, maxDepth, z);
+    splat_fragment(s, rays, cols, px, py, a.maxDepth, z);
     const f3 col = decode_color(ct.x);
     image[q] = make_uchar4((unsigned char)glsl_round(col.x * 255.0f), (unsigned char)glsl_round(col.y * 255.0f),
                            (unsigned char)glsl_round(col.z * 255.0f), 255);
@@ -525,16 +607,18 @@ __device__ __forceinline__ float bilerp(float a, float b, float c, float d, floa
 static constexpr int kAssocItems = kB / 4;   // pixels per workgroup
 static constexpr int kPatchStride = 7 * 16 + 1;  // words per staged neighbourhood (+1: odd stride, no bank conflicts)
 
-__global__ void __launch_bounds__(kB) associate_kernel(const FuseArgs a, int xcd)
+__global__ void __launch_bounds__(kB) associate_kernel(const Batch<FuseArgs> B, int xcd)
 {
     __shared__ float s_patch[kAssocItems * kPatchStride];
+    const VBlock vb = batch_decode(B.h);
+    const FuseArgs& a = B.m[vb.model];
     const int cols = a.cols, rows = a.rows;
     // Only pixels whose integer coordinates share the parity of `time` survive the shader's first test
     // ((int)x == i, (int)y == j: the texcoords are pixel centres), so the launch enumerates just that quarter of
     // the image; new_flags is cleared by a memset beforehand.
     const int par = a.time % 2;
     const int n_i = (cols - par + 1) / 2, n_j = (rows - par + 1) / 2;
-    const int gt = xcd_block(xcd) * kB + threadIdx.x;
+    const int gt = xcd_block(xcd, vb.bid, vb.nblk) * kB + threadIdx.x;
     const int t = gt >> 2, sub = gt & 3;
     float* const P = s_patch + (threadIdx.x >> 2) * kPatchStride;  // word c of texel k: P[c * 16 + k]
     bool alive = t < n_i * n_j;
@@ -653,12 +737,15 @@ __global__ void __launch_bounds__(kB) associate_kernel(const FuseArgs a, int xcd
 }
 
 // update.vert:38-111 (reads the winning record through the owner index; resets the owner slot)
-__global__ void __launch_bounds__(kB) update_kernel(const float4* __restrict__ in, const unsigned* __restrict__ count,
-                                                    unsigned* __restrict__ owner, const float4* __restrict__ records, int time,
-                                                    float4* __restrict__ out)
+struct UpdateArgs { const float4* in; const unsigned* count; unsigned* owner; const float4* records; int time; float4* out; };
+__global__ void __launch_bounds__(kB) update_kernel(const Batch<UpdateArgs> B)
 {
-    const unsigned id = blockIdx.x * kB + threadIdx.x;
-    if (id >= *count) return;
+    const VBlock vb = batch_decode(B.h);
+    const UpdateArgs& ua = B.m[vb.model];
+    const float4* __restrict__ in = ua.in; unsigned* __restrict__ owner = ua.owner; const float4* __restrict__ records = ua.records;
+    float4* __restrict__ out = ua.out; const int time = ua.time;
+    const unsigned id = vb.bid * kB + threadIdx.x;
+    if (id >= *ua.count) return;
     const float4 pc = in[id * 3], ct = in[id * 3 + 1], nr = in[id * 3 + 2];
     const unsigned ow = owner[id];
     if (ow == 0xFFFFFFFFu) { out[id * 3] = pc; out[id * 3 + 1] = ct; out[id * 3 + 2] = nr; return; }
@@ -695,6 +782,9 @@ struct CleanArgs {
     const unsigned* index; const float4* vertConf; const float4* colorTime;
     const float* depth_filt; const unsigned char* mask;
     Mat4 t_inv; cf_cam cam; int cols, rows, time; float confThreshold, outlierCoeff; int timeDelta, maskID;
+    // (the launch's per-model buffers, kernel parameters until round 4)
+    const float4* surfels; const unsigned* count; const float4* fresh; const unsigned* n_fresh; unsigned total_bound; float4* staged; unsigned* flags;
+    int xcd;   // workgroup order of THIS model's share (xcd_block): runs of 64 per XCD for a large map, the hardware's order for a small one
 };
 
 // The 4x4 half-pixel window touches at most a 4x4 texel neighbourhood of the index map textures.  Reading it
@@ -706,13 +796,16 @@ struct CleanArgs {
 // (only reachable through the f32 loop-counter corner cases) fall back to the global fetch.
 static constexpr int kCleanItems = kB / 4;
 
-__global__ void __launch_bounds__(kB) clean_kernel(const float4* __restrict__ surfels, const unsigned* __restrict__ count,
-                                                   const float4* __restrict__ fresh, const unsigned* __restrict__ n_fresh, const CleanArgs a,
-                                                   unsigned total_bound, float4* __restrict__ staged, unsigned* __restrict__ flags, int xcd)
+__global__ void __launch_bounds__(kB) clean_kernel(const Batch<CleanArgs> B)
 {
     __shared__ float s_patch[kCleanItems * kPatchStride];
+    const VBlock vb = batch_decode(B.h);
+    const CleanArgs& a = B.m[vb.model];
+    const float4* __restrict__ surfels = a.surfels; const unsigned* __restrict__ count = a.count; const float4* __restrict__ fresh = a.fresh;
+    const unsigned* __restrict__ n_fresh = a.n_fresh; const unsigned total_bound = a.total_bound; float4* __restrict__ staged = a.staged;
+    unsigned* __restrict__ flags = a.flags;
     float* const P = s_patch + (threadIdx.x >> 2) * kPatchStride;  // word c of texel t: P[c * 16 + t]
-    const unsigned gt = (unsigned)xcd_block(xcd) * kB + threadIdx.x;
+    const unsigned gt = (unsigned)xcd_block(a.xcd, vb.bid, vb.nblk) * kB + threadIdx.x;
     const unsigned k = gt >> 2;
     const int sub = (int)(gt & 3u);
     const unsigned n_old = *count, n_all = n_old + *n_fresh;
@@ -821,6 +914,15 @@ __global__ void __launch_bounds__(kB) clean_kernel(const float4* __restrict__ su
     staged[(size_t)k * 3] = pc; staged[(size_t)k * 3 + 1] = ct; staged[(size_t)k * 3 + 2] = nr;
 }
 
+// zero-fill of one u32 buffer per model (the new-surfel flags before association: one launch instead of a memset per model)
+struct FillArgs { uint4* p; long long n16; };   // n16: 16-byte words
+__global__ void __launch_bounds__(kB) fill_zero_kernel(const Batch<FillArgs> B)
+{
+    const VBlock vb = batch_decode(B.h);
+    const FillArgs& a = B.m[vb.model];
+    const long long i = (long long)vb.bid * kB + threadIdx.x;
+    if (i < a.n16) a.p[i] = make_uint4(0, 0, 0, 0);
+}
 __global__ void add_counts_kernel(const unsigned* a, const unsigned* b, unsigned* out) { *out = *a + *b; }
 __global__ void set_count_kernel(unsigned* out, unsigned v) { *out = v; }
 __global__ void set_count2_kernel(unsigned* out, unsigned* out_host, unsigned v) { *out = v; if (out_host) *out_host = v; }
@@ -849,21 +951,56 @@ void launch_init(hipStream_t s, const float* raw, const float* filt, const unsig
     init_kernel<<<gridFor(max_n), kB, 0, s>>>(reinterpret_cast<const float4*>(raw), reinterpret_cast<const float4*>(filt), raw_count,
                                               reinterpret_cast<float4*>(out));
 }
+// the arguments of a batched launch travel in the 4 KB kernel-argument segment
+static_assert(sizeof(Batch<FuseArgs>) + 16 <= 4096 && sizeof(Batch<CleanArgs>) + 16 <= 4096 && sizeof(Batch<IndexArgs>) + sizeof(FrameGeom) <= 4096 &&
+              sizeof(Batch<SplatArgs>) + sizeof(FrameGeom) <= 4096 && sizeof(Batch<ScanArgs>) <= 4096, "lower kSurfBatch");
+// ---- predictIndices -------------------------------------------------------------------------------------------------------------
+static IndexArgs index_args(const IndexPassArgs& h)
+{
+    return IndexArgs{reinterpret_cast<const float4*>(h.surfels), h.count, mat4_from(h.t_inv), h.maxDepth, h.time, h.timeDelta, h.id_begin, h.id_end,
+                     h.keys, h.index, reinterpret_cast<float4*>(h.vertConf), reinterpret_cast<float4*>(h.colorTime), reinterpret_cast<float4*>(h.normRad)};
+}
+void launch_index_keys_batch(hipStream_t s, const IndexPassArgs* items, int n_items, cf_cam cam, int cols, int rows)
+{
+    const FrameGeom g{cam, cols, rows};
+    for (int base = 0; base < n_items; base += kSurfBatch) {
+        const int nb = n_items - base < kSurfBatch ? n_items - base : kSurfBatch;
+        Batch<IndexArgs> B;
+        int blocks[kSurfBatch], any = 0;
+        for (int k = 0; k < nb; k++) {
+            B.m[k] = index_args(items[base + k]);
+            blocks[k] = B.m[k].id_end > B.m[k].id_begin ? gridFor(B.m[k].id_end - B.m[k].id_begin) : 0;
+            any += blocks[k];
+        }
+        if (any) index_splat_kernel<<<batch_layout(B, blocks, nb), kB, 0, s>>>(B, g);
+    }
+}
+void launch_index_resolve_batch(hipStream_t s, const IndexPassArgs* items, int n_items, cf_cam cam, int cols, int rows)
+{
+    const FrameGeom g{cam, cols, rows};
+    for (int base = 0; base < n_items; base += kSurfBatch) {
+        const int nb = n_items - base < kSurfBatch ? n_items - base : kSurfBatch;
+        Batch<IndexArgs> B;
+        int blocks[kSurfBatch];
+        for (int k = 0; k < nb; k++) { B.m[k] = index_args(items[base + k]); blocks[k] = gridFor((long long)cols * rows); }
+        index_resolve_kernel<<<batch_layout(B, blocks, nb), kB, 0, s>>>(B, g);
+    }
+}
 void launch_index_keys(hipStream_t s, const float* surfels, const unsigned* count, unsigned id_begin, unsigned id_end, const float t_inv[16],
                        cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys)
 {
-    const Mat4 T = mat4_from(t_inv);
-    if (id_end > id_begin)
-        index_splat_kernel<<<gridFor(id_end - id_begin), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T,
-                                                                     cam, cols, rows, maxDepth, time, timeDelta, id_begin, id_end, keys);
+    IndexPassArgs a{};
+    a.surfels = surfels; a.count = count; a.id_begin = id_begin; a.id_end = id_end; for (int q = 0; q < 16; q++) a.t_inv[q] = t_inv[q];
+    a.maxDepth = maxDepth; a.time = time; a.timeDelta = timeDelta; a.keys = keys;
+    launch_index_keys_batch(s, &a, 1, cam, cols, rows);
 }
 void launch_index_resolve(hipStream_t s, const float* surfels, const float t_inv[16], int cols, int rows, unsigned long long* keys,
                           unsigned* index, float* vertConf, float* colorTime, float* normRad)
 {
-    const int N = cols * rows;
-    index_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), mat4_from(t_inv), N, keys, index,
-                                                   reinterpret_cast<float4*>(vertConf), reinterpret_cast<float4*>(colorTime),
-                                                   reinterpret_cast<float4*>(normRad));
+    IndexPassArgs a{};
+    a.surfels = surfels; for (int q = 0; q < 16; q++) a.t_inv[q] = t_inv[q]; a.keys = keys; a.index = index; a.vertConf = vertConf; a.colorTime = colorTime;
+    a.normRad = normRad;
+    launch_index_resolve_batch(s, &a, 1, cf_cam{}, cols, rows);
 }
 void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                             int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys, unsigned* index,
@@ -872,19 +1009,37 @@ void launch_predict_indices(hipStream_t s, const float* surfels, const unsigned*
     launch_index_keys(s, surfels, count, 0, count_bound, t_inv, cam, cols, rows, maxDepth, time, timeDelta, keys);
     launch_index_resolve(s, surfels, t_inv, cols, rows, keys, index, vertConf, colorTime, normRad);
 }
+// ---- combinedPredict ------------------------------------------------------------------------------------------------------------
+void launch_combined_predict_batch(hipStream_t s, const SplatPassArgs* items, int n_items, cf_cam cam, int cols, int rows)
+{
+    const FrameGeom g{cam, cols, rows};
+    for (int base = 0; base < n_items; base += kSurfBatch) {
+        const int nb = n_items - base < kSurfBatch ? n_items - base : kSurfBatch;
+        Batch<SplatArgs> B;
+        int blocks[kSurfBatch], any = 0;
+        for (int k = 0; k < nb; k++) {
+            const SplatPassArgs& h = items[base + k];
+            B.m[k] = SplatArgs{reinterpret_cast<const float4*>(h.surfels), h.count, mat4_from(h.t_inv), h.maxDepth, h.confThreshold, h.time, h.maxTime,
+                               h.timeDelta, reinterpret_cast<const float4*>(h.rays), h.keys, reinterpret_cast<uchar4*>(h.image),
+                               reinterpret_cast<float4*>(h.vertexConf), reinterpret_cast<float4*>(h.normalRad), h.time16};
+            blocks[k] = h.count_bound > 0 ? gridFor(4ll * h.count_bound) : 0;
+            any += blocks[k];
+        }
+        if (any) splat_raster_kernel<<<batch_layout(B, blocks, nb), kB, 0, s>>>(B, g);
+        for (int k = 0; k < nb; k++) blocks[k] = gridFor((long long)cols * rows);
+        splat_resolve_kernel<<<batch_layout(B, blocks, nb), kB, 0, s>>>(B, g);
+    }
+}
 void launch_combined_predict(hipStream_t s, const float* surfels, const unsigned* count, unsigned count_bound, const float t_inv[16], cf_cam cam,
                              int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
                              const float* rays, unsigned long long* keys, uint8_t* image, float* vertexConf, float* normalRad,
                              uint16_t* time16)
 {
-    const int N = cols * rows;
-    const Mat4 T = mat4_from(t_inv);
-    if (count_bound > 0)
-        splat_raster_kernel<<<gridFor(4ll * count_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, T, cam, cols, rows, maxDepth,
-                                                                confThreshold, time, maxTime, timeDelta, reinterpret_cast<const float4*>(rays), keys);
-    splat_resolve_kernel<<<gridFor(N), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), T, cam, cols, rows, maxDepth, confThreshold, time, maxTime,
-                                                   timeDelta, reinterpret_cast<const float4*>(rays), keys, reinterpret_cast<uchar4*>(image), reinterpret_cast<float4*>(vertexConf),
-                                                   reinterpret_cast<float4*>(normalRad), time16);
+    SplatPassArgs a{};
+    a.surfels = surfels; a.count = count; a.count_bound = count_bound; for (int q = 0; q < 16; q++) a.t_inv[q] = t_inv[q]; a.maxDepth = maxDepth;
+    a.confThreshold = confThreshold; a.time = time; a.maxTime = maxTime; a.timeDelta = timeDelta; a.rays = rays; a.keys = keys; a.image = image;
+    a.vertexConf = vertexConf; a.normalRad = normalRad; a.time16 = time16;
+    launch_combined_predict_batch(s, &a, 1, cam, cols, rows);
 }
 void launch_splat_rays(hipStream_t s, cf_cam cam, int cols, int rows, float* rays)
 {
@@ -902,38 +1057,88 @@ void launch_fill_ratio(hipStream_t s, const uint8_t* pimg, int cols, int rows, u
 {
     fill_ratio_kernel<<<1, 1024, 0, s>>>(reinterpret_cast<const uchar4*>(pimg), cols, rows, out2, out2_host);
 }
-void launch_associate(hipStream_t s, const SurfelFuseArgs& h)
+// ---- fuse: association (+ the flag buffers zeroed in one launch), update ---------------------------------------------------------------
+void launch_associate_batch(hipStream_t s, const SurfelFuseArgs* items, int n_items)
 {
-    FuseArgs a;
-    a.index = h.index; a.vertConf = reinterpret_cast<const float4*>(h.vertConf); a.normRad = reinterpret_cast<const float4*>(h.normRad);
-    a.rgba = reinterpret_cast<const uchar4*>(h.rgba); a.depth_raw = h.depth_raw; a.depth_filt = h.depth_filt; a.mask = h.mask;
-    a.tcx = h.tcx; a.tcy = h.tcy; a.pose = mat4_from(h.pose); a.cam = h.cam; a.inv_fx = h.inv_fx; a.inv_fy = h.inv_fy;
-    a.cols = h.cols; a.rows = h.rows; a.time = h.time; a.weighting = h.weighting; a.maskID = h.maskID; a.maxDepth = h.maxDepth;
-    a.records = reinterpret_cast<float4*>(h.records); a.new_flags = h.new_flags; a.owner = h.owner;
-    (void)hipMemsetAsync(h.new_flags, 0, sizeof(unsigned) * (size_t)h.cols * h.rows, s);
-    const int par = h.time % 2;
-    const long long n = (long long)((h.cols - par + 1) / 2) * ((h.rows - par + 1) / 2);
-    static const int chunk = xcd_env("CF_XCD_ASSOC", 0);
-    associate_kernel<<<gridXcd(4 * n, chunk), kB, 0, s>>>(a, chunk);
+    constexpr int chunk = xcd_env("CF_XCD_ASSOC", 0);
+    for (int base = 0; base < n_items; base += kSurfBatch) {
+        const int nb = n_items - base < kSurfBatch ? n_items - base : kSurfBatch;
+        Batch<FuseArgs> B;
+        Batch<FillArgs> Z;
+        int blocks[kSurfBatch], zblocks[kSurfBatch];
+        for (int k = 0; k < nb; k++) {
+            const SurfelFuseArgs& h = items[base + k];
+            FuseArgs& a = B.m[k];
+            a.index = h.index; a.vertConf = reinterpret_cast<const float4*>(h.vertConf); a.normRad = reinterpret_cast<const float4*>(h.normRad);
+            a.rgba = reinterpret_cast<const uchar4*>(h.rgba); a.depth_raw = h.depth_raw; a.depth_filt = h.depth_filt; a.mask = h.mask;
+            a.tcx = h.tcx; a.tcy = h.tcy; a.pose = mat4_from(h.pose); a.cam = h.cam; a.inv_fx = h.inv_fx; a.inv_fy = h.inv_fy;
+            a.cols = h.cols; a.rows = h.rows; a.time = h.time; a.weighting = h.weighting; a.maskID = h.maskID; a.maxDepth = h.maxDepth;
+            a.records = reinterpret_cast<float4*>(h.records); a.new_flags = h.new_flags; a.owner = h.owner;
+            const int par = h.time % 2;
+            const long long n = (long long)((h.cols - par + 1) / 2) * ((h.rows - par + 1) / 2);
+            blocks[k] = gridXcd(4 * n, chunk);
+            const long long n16 = ((long long)h.cols * h.rows + 3) / 4;   // (new_flags holds cols * rows words: cf_model_create rounds it up)
+            Z.m[k] = FillArgs{reinterpret_cast<uint4*>(h.new_flags), n16};
+            zblocks[k] = gridFor(n16);
+        }
+        fill_zero_kernel<<<batch_layout(Z, zblocks, nb), kB, 0, s>>>(Z);
+        associate_kernel<<<batch_layout(B, blocks, nb), kB, 0, s>>>(B, chunk);
+    }
+}
+void launch_associate(hipStream_t s, const SurfelFuseArgs& h) { launch_associate_batch(s, &h, 1); }
+void launch_update_batch(hipStream_t s, const UpdatePassArgs* items, int n_items)
+{
+    for (int base = 0; base < n_items; base += kSurfBatch) {
+        const int nb = n_items - base < kSurfBatch ? n_items - base : kSurfBatch;
+        Batch<UpdateArgs> B;
+        int blocks[kSurfBatch], any = 0;
+        for (int k = 0; k < nb; k++) {
+            const UpdatePassArgs& h = items[base + k];
+            B.m[k] = UpdateArgs{reinterpret_cast<const float4*>(h.in), h.count, h.owner, reinterpret_cast<const float4*>(h.records), h.time,
+                                reinterpret_cast<float4*>(h.out)};
+            blocks[k] = h.count_bound > 0 ? gridFor(h.count_bound) : 0;
+            any += blocks[k];
+        }
+        if (any) update_kernel<<<batch_layout(B, blocks, nb), kB, 0, s>>>(B);
+    }
 }
 void launch_update(hipStream_t s, const float* in, const unsigned* count, unsigned count_bound, unsigned* owner, const float* records, int time,
                    float* out)
 {
-    if (count_bound > 0)
-        update_kernel<<<gridFor(count_bound), kB, 0, s>>>(reinterpret_cast<const float4*>(in), count, owner, reinterpret_cast<const float4*>(records),
-                                                          time, reinterpret_cast<float4*>(out));
+    const UpdatePassArgs a{in, count, count_bound, owner, records, time, out};
+    launch_update_batch(s, &a, 1);
+}
+// ---- clean ----------------------------------------------------------------------------------------------------------------------
+void launch_clean_batch(hipStream_t s, const CleanPassArgs* items, int n_items)
+{
+    constexpr int chunk = xcd_env("CF_XCD_CLEAN", 64);
+    for (int base = 0; base < n_items; base += kSurfBatch) {
+        const int nb = n_items - base < kSurfBatch ? n_items - base : kSurfBatch;
+        Batch<CleanArgs> B;
+        int blocks[kSurfBatch], any = 0;
+        for (int k = 0; k < nb; k++) {
+            const CleanPassArgs& p = items[base + k];
+            const SurfelCleanArgs& h = p.h;
+            CleanArgs& a = B.m[k];
+            a.index = h.index; a.vertConf = reinterpret_cast<const float4*>(h.vertConf); a.colorTime = reinterpret_cast<const float4*>(h.colorTime);
+            a.depth_filt = h.depth_filt; a.mask = h.mask; a.t_inv = mat4_from(h.t_inv); a.cam = h.cam; a.cols = h.cols; a.rows = h.rows; a.time = h.time;
+            a.confThreshold = h.confThreshold; a.outlierCoeff = h.outlierCoeff; a.timeDelta = h.timeDelta; a.maskID = h.maskID;
+            a.surfels = reinterpret_cast<const float4*>(p.surfels); a.count = p.count; a.fresh = reinterpret_cast<const float4*>(p.fresh);
+            a.n_fresh = p.n_fresh; a.total_bound = p.total_bound; a.staged = reinterpret_cast<float4*>(p.staged); a.flags = p.flags;
+            // (the XCD-ordered runs need a share that is a multiple of 8 x 64 workgroups: for an object model of a few thousand surfels
+            // that padding would be a third again of its workgroups, all of them empty)
+            a.xcd = gridFor(4ll * p.total_bound) >= 4 * 8 * chunk ? chunk : 0;
+            blocks[k] = p.total_bound > 0 ? gridXcd(4ll * p.total_bound, a.xcd) : 0;
+            any += blocks[k];
+        }
+        if (any) clean_kernel<<<batch_layout(B, blocks, nb), kB, 0, s>>>(B);
+    }
 }
 void launch_clean(hipStream_t s, const float* surfels, const unsigned* count, const float* fresh, const unsigned* n_fresh, unsigned total_bound,
                   const SurfelCleanArgs& h, float* staged, unsigned* flags)
 {
-    CleanArgs a;
-    a.index = h.index; a.vertConf = reinterpret_cast<const float4*>(h.vertConf); a.colorTime = reinterpret_cast<const float4*>(h.colorTime);
-    a.depth_filt = h.depth_filt; a.mask = h.mask; a.t_inv = mat4_from(h.t_inv); a.cam = h.cam; a.cols = h.cols; a.rows = h.rows; a.time = h.time;
-    a.confThreshold = h.confThreshold; a.outlierCoeff = h.outlierCoeff; a.timeDelta = h.timeDelta; a.maskID = h.maskID;
-    static const int chunk = xcd_env("CF_XCD_CLEAN", 64);
-    if (total_bound > 0)
-        clean_kernel<<<gridXcd(4ll * total_bound, chunk), kB, 0, s>>>(reinterpret_cast<const float4*>(surfels), count, reinterpret_cast<const float4*>(fresh), n_fresh,
-                                                         a, total_bound, reinterpret_cast<float4*>(staged), flags, chunk);
+    const CleanPassArgs a{h, surfels, count, fresh, n_fresh, total_bound, staged, flags};
+    launch_clean_batch(s, &a, 1);
 }
 void launch_add_counts(hipStream_t s, const unsigned* a, const unsigned* b, unsigned* out) { add_counts_kernel<<<1, 1, 0, s>>>(a, b, out); }
 void launch_set_count(hipStream_t s, unsigned* out, unsigned v) { set_count_kernel<<<1, 1, 0, s>>>(out, v); }

@@ -873,8 +873,39 @@ void CoFusion::modelPasses(Model& model, bool fuse, float weightMultiplier, bool
 // touch disjoint buffers (shared inputs: frame, mask), so each model's whole chain goes to its own stream, without a barrier
 // between fusion and prediction; with Config::enqueueThreads the chains are also ENQUEUED by different host threads (~19 launches
 // per model: worth it when the host's launch rate is the limit).
+// LOCK-STEP (round 4, single-process operation): the passes of all models as one chain of batched launches (cf_models_frame_passes) --
+// every stage one launch whose workgroups are dealt to the models -- instead of one chain of ~16 launch-floor kernels per model on
+// per-model streams (which share a few hardware queues: the five chains of configs[2] ran mostly one after another, 450 us of a
+// 1.5 ms frame).  The model-parallel modes keep the per-model path: a rank's passes differ from the other ranks' and a split
+// background talks to them from inside its index pass.
+void CoFusion::frameFuseCollect(std::vector<cf_model_pass>& items)
+{
+    for (auto& m : models) {
+        cf_model_pass it{};
+        it.model = m->model; it.pose = m->pose.m; it.rgba = curRgba; it.mask = mask_dev; it.depth_raw = curDepth; it.depth_filtered = depthFiltered_dev;
+        it.do_fuse = st.fuseNow ? 1 : 0; it.time = tick;
+        it.fuse_max_depth = maxDepthProcessed < m->getMaxDepth() ? maxDepthProcessed : m->getMaxDepth();  // std::min(depthCutoff, maxDepth), Model.cpp:443
+        it.weighting = m->computeFusionWeight(st.weightMultiplier); it.mask_id = (int)m->getID(); it.conf_threshold = m->getConfidenceThreshold();
+        items.push_back(it);
+    }
+}
+void CoFusion::frameFuseFinish()
+{
+    for (auto& m : models) {
+        m->prefetchFillRatio();  // requiresFillIn() of the next frame asks about THIS prediction
+        m->performFillIn(curRgba, depthFiltered_dev, cfg.frameToFrameRGB, lost);
+    }
+}
+
 void CoFusion::fuseAndPredict(bool fuse, float weightMultiplier, bool lost, bool join, int laneOffset)
 {
+    if (passesBatched() && fuse == st.fuseNow && weightMultiplier == st.weightMultiplier) {
+        std::vector<cf_model_pass> items;
+        frameFuseCollect(items);
+        check(ctx, cf_models_frame_passes(ctx, items.data(), (int)items.size(), maxDepthProcessed, cfg.outlierCoefficient, cfg.timeDelta), "cf_models_frame_passes");
+        frameFuseFinish();
+        return;
+    }
     // (a sequence of a lock-step group puts even a single model's chain on a lane -- the chains of the OTHER sequences run beside it --
     // and leaves the join to the group)
     const bool overlap = (models.size() > 1 || !join) && useLanes;
@@ -1306,12 +1337,14 @@ void CoFusionGroup::stepAll(const FrameData* frames, const Mat4f* const* inPoses
     for (int s = 0; s < S; s++) seqs[s]->frameSegment(s % 6);
     check(ctx, cf_join(ctx), "cf_join");
     for (int s = 0; s < S; s++) seqs[s]->frameCollect();
-    int lane = 0;
-    for (int s = 0; s < S; s++) {  // the chains of all sequences side by side on the lanes, one join
-        seqs[s]->frameFuse(false, lane);
-        lane += (int)seqs[s]->getModels().size();
+    {   // the surfel passes of ALL sequences' models in one chain of batched launches
+        PhaseTimer t(PhaseTimes::Fuse);
+        std::vector<cf_model_pass> items;
+        for (int s = 0; s < S; s++) seqs[s]->frameFuseCollect(items);
+        check(ctx, cf_models_frame_passes(ctx, items.data(), (int)items.size(), seqs[0]->depthLimit(), cfg.outlierCoefficient, cfg.timeDelta),
+              "cf_models_frame_passes");
+        for (int s = 0; s < S; s++) seqs[s]->frameFuseFinish();
     }
-    check(ctx, cf_join(ctx), "cf_join");
     for (int s = 0; s < S; s++) seqs[s]->frameEnd();
 }
 

@@ -299,6 +299,12 @@ class CoFusion {
     void frameSegment(int lane);   // segmentation enqueued (lane >= 0: on that lane of the context, beside other sequences' chains)
     void frameCollect();           // the frame's host wait (poses + segmentation decisions), model bookkeeping
     void frameFuse(bool join, int laneOffset);
+    // ... in two halves for a lock-step group: every sequence adds its models' passes to ONE batch (cf_models_frame_passes), the group
+    // launches it, each sequence then runs its fill-in
+    bool passesBatched() const { return !dist.active(); }
+    float depthLimit() const { return maxDepthProcessed; }
+    void frameFuseCollect(std::vector<cf_model_pass>& items);
+    void frameFuseFinish();
     void frameEnd();
 
   private:

@@ -320,6 +320,25 @@ int cf_model_fuse(cf_model *m, const float pose[16], int time, const uint8_t *rg
 /* Model::clean (Model.cpp:565-697); count_out = surfels written (the GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN query) */
 int cf_model_clean(cf_model *m, const float pose[16], int time, float confThreshold, float outlierCoeff, int timeDelta,
                    const float *depth_filtered, const uint8_t *mask, int maskID, uint32_t *count_out);
+/* The second half of a frame for SEVERAL models in lock-step (CoFusion.cpp:316-330 and 346 / 533-545): what the reference runs as six
+ * loops over the models -- predictIndices, fuse, predictIndices, clean for every model that fuses, combinedPredict(time, time) for all --
+ * as ONE chain of launches whose workgroups are dealt to the models (the way the tracking launches carry all trackers): an object
+ * model's share of a pass is a few dozen workgroups, and a chain of ~16 launch-floor kernels per model, one model after another,
+ * was a third of a multi-object frame.  The items may belong to different sequences (own frame images, own clock).  Identical
+ * results to the per-model calls in the same order; the surfel counts travel back asynchronously as with cf_model_clean. */
+typedef struct {
+    cf_model *model;
+    const float *pose;                       /* [16] row-major T(model <- camera) */
+    const uint8_t *rgba, *mask;              /* the model's frame: RGBA8, label mask (device) */
+    const float *depth_raw, *depth_filtered;
+    int do_fuse;                             /* 0: prediction only (CoFusion.cpp:463: !rgbOnly && trackingOk && !lost) */
+    int time;                                /* the sequence's tick */
+    float fuse_max_depth;                    /* min(depthCutoff, model maxDepth) (Model.cpp:443) */
+    float weighting;                         /* Model::computeFusionWeight */
+    int mask_id;
+    float conf_threshold;
+} cf_model_pass;
+int cf_models_frame_passes(cf_ctx *ctx, const cf_model_pass *items, int n, float depth_cutoff, float outlier_coeff, int time_delta);
 /* Model::downloadMap (Model.cpp:867-899): `count` surfels of 12 floats */
 int cf_model_download_map(cf_model *m, float *host_surfels, uint32_t capacity, uint32_t *count);
 int cf_model_upload_map(cf_model *m, const float *host_surfels, uint32_t count);
