@@ -701,13 +701,13 @@ int cf_odom_init_models_batch_frames(cf_ctx* ctx, cf_odom* const* ods, int n, co
             if (!od || !pred_v4[base + k] || !pred_n4[base + k] || !pred_rgba[base + k] || !poses[base + k] || !frame_rgba[base + k]) return CF_EINVAL;
             mb.m[k] = model_maps_args(od, pred_v4[base + k], pred_n4[base + k], poses[base + k]);
             rb.c[2 * k] = rgbd_chain(od, pred_rgba[base + k], od->lastDepth, od->lastImage);   // initRGBModel
+            rb.c[2 * k].v4 = pred_v4[base + k];  // (the snapshot vmaps_tmp is written by the same launch: read the prediction it copies)
             rb.c[2 * k + 1] = rgbd_chain(od, frame_rgba[base + k], od->nextDepth, od->nextImage);        // initRGB
             // ... whose depth pyramid would be a second copy of the first chain's (same source, same cutoff): intensity only
             for (int i = 0; i < CF_NUM_PYRS; ++i) rb.c[2 * k + 1].depth[i] = nullptr;
             od->next_depth_is_last = true;
         }
-        launch_model_maps(s, mb, nb);
-        launch_rgbd_pyramids(s, rb, 2 * nb, W, H, ods[base]->maxDepthRGB);
+        launch_model_maps_and_pyramids(s, mb, nb, rb, 2 * nb, W, H, ods[base]->maxDepthRGB);
     }
     LAUNCHCHK(ctx);
     return CF_OK;
@@ -915,15 +915,19 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     if (!ctx || !ods || n <= 0 || n > ctx->cfg.max_models || n > kMaxBatch || !poses_in || !opts) return CF_EINVAL;
     const bool want_rgb = opts->rgb_only || opts->icp_weight < 100;
     if (ctx->state_readback_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ctx->state_readback_pending = false; }
+    // a batch of <= kPrepBatch trackers with the SO3 pre-alignment: the RGB preparation rides in the pre-alignment's launch
+    const bool prep_fused = want_rgb && opts->so3 != 0 && n <= kPrepBatch;
+    RgbPrepBatch prep{};
     for (int base = 0; base < n; base += kPrepBatch) {  // the preparation launches hold kPrepBatch trackers each
         const int nb = n - base < kPrepBatch ? n - base : kPrepBatch;
-        RgbPrepBatch prep{};
+        if (base) prep = RgbPrepBatch{};
         for (int m = base; m < base + nb; m++) {
             if (int r = odom_prepare(ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr, &prep.m[m - base])) return r;
             ctx->h_model_ptrs[m] = ods[m]->d_state;
         }
-        if (want_rgb) launch_rgb_prep(ctx->stream, prep, nb, ctx->cfg.width, ctx->cfg.height);
+        if (want_rgb && !prep_fused) launch_rgb_prep(ctx->stream, prep, nb, ctx->cfg.width, ctx->cfg.height);
     }
+    if (prep_fused) rgb_prep_levels(prep, n, ctx->cfg.width, ctx->cfg.height);
     // state upload: one copy over the slot range when every tracker of the batch lives in the pool (the host copies of
     // other trackers in the range equal their device copies: both are only written by a tracking call + its read-back)
     int lo = cf_ctx::kStateSlots, hi = -1;
@@ -958,7 +962,8 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     cf::ProfSink* prof = nullptr;
     if (ctx->prof.enabled > 0 && (ctx->prof_calls++ % (unsigned)ctx->prof.enabled) == 0) prof = &ctx->prof;
     if (!launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, any_split ? &hook : nullptr, icp_args, rgb_args, n,
-                         ctx->cfg.width, ctx->cfg.height, so3_here, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, prof, h_states)) {
+                         ctx->cfg.width, ctx->cfg.height, so3_here, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, prof, h_states,
+                         prep_fused ? &prep : nullptr)) {
         ctx->set_error("tracking: the registered collective failed inside the Gauss-Newton loop");
         return CF_ESTATE;
     }

@@ -109,6 +109,7 @@ struct RgbdBatch { RgbdChain c[2 * kPrepBatch]; };
 void launch_model_maps(hipStream_t s, const ModelMapsBatch& b, int n);  // needs cols % 4 == 0 && rows % 4 == 0
 void launch_frame_maps(hipStream_t s, FrameMapsArgs a, int W, int H);
 void launch_rgbd_pyramids(hipStream_t s, const RgbdBatch& b, int n_chains, int W, int H, float cutoff);
+void launch_model_maps_and_pyramids(hipStream_t s, const ModelMapsBatch& mb, int n, const RgbdBatch& rb, int n_chains, int W, int H, float cutoff);
 void launch_rgb_prep(hipStream_t s, RgbPrepBatch b, int n, int W, int H);
 
 // ---- reduction launchers (track_reduce.hip) ----
@@ -257,7 +258,10 @@ struct GnHook { int (*fn)(void* user, int op, void* dev_buf, uint64_t words, voi
 bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */, So3Sync* so3_syncs /* [n] */,
                      const GnHook* hook, const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3,
                      bool pyramid, bool fast_odom, bool rgb, bool icp, int mode, ProfSink* prof,
-                     OdomDev* const* h_states = nullptr /* [n] pinned host copies the last solve publishes to */);
+                     OdomDev* const* h_states = nullptr /* [n] pinned host copies the last solve publishes to */,
+                     const RgbPrepBatch* prep = nullptr /* n <= kPrepBatch models' RGB preparation (levels filled: rgb_prep_levels), run in the
+                                                           first launch beside the SO3 pre-alignment */);
+void rgb_prep_levels(RgbPrepBatch& b, int n, int W, int H);
 float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, int ablate, int reps, hipEvent_t e0, hipEvent_t e1);
 float sqrt_gate_lt(float T);  // smallest x with sqrtf(x) >= T
 float sqrt_gate_le(float T);  // largest x with sqrtf(x) <= T

@@ -6,6 +6,7 @@
 // Results are bit-identical to the CPU oracle (same IEEE operation order, -ffp-contract=off).
 #include "cf_device.h"
 #include "cf_kernels.h"
+#include "track_prep_dev.h"
 
 namespace cf {
 
@@ -219,24 +220,25 @@ __global__ void __launch_bounds__(kBlock) pyrdown_u8_kernel(const uint8_t* __res
 
 // RGBDOdometry::populateRGBDData (RGBDOdometry.cpp:177-194) issues a depth chain and an intensity chain that do not
 // depend on each other: each pyramid step of both shares one launch (workgroups [0, nd) depth, the rest intensity).
-__global__ void __launch_bounds__(kBlock) rgbd_base_kernel(const RgbdBatch b, int N, float cutoff)
+__device__ __forceinline__ void rgbd_base_body(const RgbdBatch& b, int N, float cutoff, int bx, int by)
 {
-    const RgbdChain& c = b.c[blockIdx.y];  // one (depth, intensity) chain per grid row: models x {prediction, frame}
+    const RgbdChain& c = b.c[by];  // one (depth, intensity) chain per grid row: models x {prediction, frame}
     const float4* __restrict__ v4 = reinterpret_cast<const float4*>(c.v4);
     const uchar4* __restrict__ rgba = reinterpret_cast<const uchar4*>(c.rgba);
     const int nb = (N + kBlock - 1) / kBlock;
-    if ((int)blockIdx.x < nb) {  // verticesToDepthKernel, cudafuncs.cu:602-613
-        const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (bx < nb) {  // verticesToDepthKernel, cudafuncs.cu:602-613
+        const int i = bx * kBlock + threadIdx.x;
         if (i >= N || !c.depth[0]) return;  // (a chain without a depth pyramid: the intensity half only)
         const float z = v4[i].z;
         c.depth[0][i] = (z > cutoff || z <= 0) ? qnan() : z;
     } else {                     // bgr2IntensityKernel, cudafuncs.cu:626-639
-        const int i = (blockIdx.x - nb) * kBlock + threadIdx.x;
+        const int i = (bx - nb) * kBlock + threadIdx.x;
         if (i >= N) return;
         const uchar4 s = rgba[i];
         c.image[0][i] = (uint8_t)(int)((float)s.x * 0.114f + (float)s.y * 0.299f + (float)s.z * 0.587f);
     }
 }
+__global__ void __launch_bounds__(kBlock) rgbd_base_kernel(const RgbdBatch b, int N, float cutoff) { rgbd_base_body(b, N, cutoff, (int)blockIdx.x, (int)blockIdx.y); }
 __global__ void __launch_bounds__(kBlock) rgbd_pyrdown_kernel(const RgbdBatch b, int level, int scols, int srows)
 {
     const RgbdChain& c = b.c[blockIdx.y];
@@ -325,12 +327,6 @@ __global__ void __launch_bounds__(kBlock) cloud_kernel(const float* __restrict__
 // per level) and dependent stages recomputed in registers with the same expressions, so the outputs -- including
 // which planes are left untouched for invalid pixels -- are bit-identical to the chain of single kernels.
 // =================================================================================================
-__device__ __forceinline__ int level_of(const Level3& L, int b, int& lb)
-{
-    const int lv = b < L.blk_end[0] ? 0 : (b < L.blk_end[1] ? 1 : 2);
-    lb = b - (lv ? L.blk_end[lv - 1] : 0);
-    return lv;
-}
 
 // vmap_kernel + nmap_kernel for the three levels (RGBDOdometry::initICP, RGBDOdometry.cpp:116-143)
 __global__ void __launch_bounds__(kBlock) frame_maps_kernel(const FrameMapsArgs a)
@@ -383,65 +379,8 @@ __global__ void __launch_bounds__(kBlock) frame_maps_kernel(const FrameMapsArgs 
     }
 }
 
-// sobel_kernel + rgb_cand_kernel + cloud_kernel for the three levels (RGBDOdometry.cpp:231-235, :333)
-__global__ void __launch_bounds__(kBlock) rgb_prep_kernel(const RgbPrepBatch b)
-{
-    const RgbPrepArgs& a = b.m[blockIdx.y];  // one tracked model per grid row
-    int lb;
-    const int lv = level_of(a.L, blockIdx.x, lb);
-    const int cols = a.L.cols[lv], rows = a.L.rows[lv];
-    const int k = lb * kBlock + threadIdx.x;
-    if (k >= cols * rows) return;
-    const int y = k / cols, x = k - y * cols;
-    const uint8_t* __restrict__ src = a.nextImage[lv];
-    // cloud (independent of the rest)
-    {
-        const float z = a.lastDepth[lv][k];
-        float* __restrict__ cloud3 = a.cloud[lv];
-        cloud3[k * 3 + 0] = (x - a.cx[lv]) * z * a.fx_inv[lv];
-        cloud3[k * 3 + 1] = (y - a.cy[lv]) * z * a.fy_inv[lv];
-        cloud3[k * 3 + 2] = z;
-    }
-    // Sobel
-    float dxv = 0, dyv = 0;
-    constexpr float sx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
-    constexpr float sy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
-    if (x >= 1 && y >= 1 && x <= cols - 2 && y <= rows - 2) {
-        const uint8_t* __restrict__ p0 = src + (y - 1) * cols + (x - 1);
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float s = (float)p0[r * cols + c];
-                dxv += s * sx[8 - (r * 3 + c)];
-                dyv += s * sy[8 - (r * 3 + c)];
-            }
-    } else {
-        int kk = 8;
-        for (int j = max(y - 1, 0); j <= min(y + 1, rows - 1); j++)
-            for (int c = max(x - 1, 0); c <= min(x + 1, cols - 1); c++) {
-                const float s = (float)src[j * cols + c];
-                dxv += s * kSobelX[kk];
-                dyv += s * kSobelY[kk];
-                --kk;
-            }
-    }
-    const int16_t dx16 = (int16_t)(int)dxv, dy16 = (int16_t)(int)dyv;
-    a.dIdx[lv][k] = dx16; a.dIdy[lv][k] = dy16;
-    // candidate mask
-    uint8_t ok = 0;
-    if (x < cols - 5 && y < rows - 1) {
-        bool valid = true;
-        for (int u = max(y - 2, 0); u < min(y + 2, rows); u++)
-            for (int v = max(x - 2, 0); v < min(x + 2, cols); v++) valid = valid && (src[u * cols + v] > 0);
-        if (valid) {
-            const int valx = dx16, valy = dy16;
-            const float mTwo = (float)((valx * valx) + (valy * valy));
-            if (mTwo >= a.minScale[lv] && !is_nan(a.nextDepth[lv][k])) ok = 1;
-        }
-    }
-    a.cand[lv][k] = ok;
-}
+// sobel_kernel + rgb_cand_kernel + cloud_kernel for the three levels: rgb_prep_body (track_prep_dev.h)
+__global__ void __launch_bounds__(kBlock) rgb_prep_kernel(const RgbPrepBatch b) { rgb_prep_body(b.m[blockIdx.y], (int)blockIdx.x); }
 
 // copy_maps + resize_map<false/true> x2 + transform_maps x3 (RGBDOdometry::initICPModel, RGBDOdometry.cpp:145-174):
 // one thread per level-2 pixel owns its 4x4 level-0 block.  The resize chain runs on the untransformed values,
@@ -535,13 +474,13 @@ __device__ __forceinline__ MapVal lane_mapval(const MapVal& m, int src_lane)
     o.have = __shfl((int)m.have, src_lane, 64) != 0;
     return o;
 }
-__global__ void __launch_bounds__(256) model_maps_tiled_kernel(const ModelMapsBatch b)
+__device__ __forceinline__ void model_maps_tiled_body(const ModelMapsBatch& b, int bx, int by)
 {
-    const ModelMapsArgs& a = b.m[blockIdx.y];  // one tracked model per grid row
+    const ModelMapsArgs& a = b.m[by];  // one tracked model per grid row
     const int cols = a.cols, rows = a.rows, N0 = cols * rows, c1 = cols >> 1, c2 = cols >> 2, N1 = N0 >> 2, N2 = N0 >> 4;
     const int lane = threadIdx.x & 63, lx = lane & 15, ly = lane >> 4;
     const int tiles_x = cols >> 4;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tile = bx * 4 + (threadIdx.x >> 6);
     if (tile >= tiles_x * (rows >> 2)) return;  // whole waves leave
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x = tx * 16 + lx, y = ty * 4 + ly, i0 = y * cols + x;
@@ -607,6 +546,16 @@ __global__ void __launch_bounds__(256) model_maps_tiled_kernel(const ModelMapsBa
         }
     }
 }
+__global__ void __launch_bounds__(256) model_maps_tiled_kernel(const ModelMapsBatch b) { model_maps_tiled_body(b, (int)blockIdx.x, (int)blockIdx.y); }
+// {model maps || base level of the depth / intensity pyramids} of a batch of trackers in ONE launch: the two passes read the same
+// predictions and write different buffers; alone each is a 10-25 us kernel in the chain in front of the Gauss-Newton loop.  A
+// one-dimensional grid: [model-map workgroups of all models | pyramid-base workgroups of all chains].
+__global__ void __launch_bounds__(256) prep_fused_kernel(const ModelMapsBatch mb, int mm_bx, int mm_total, const RgbdBatch rb, int N, float cutoff, int rb_bx)
+{
+    const int b = blockIdx.x;
+    if (b < mm_total) { const int by = b / mm_bx; model_maps_tiled_body(mb, b - by * mm_bx, by); }
+    else { const int r = b - mm_total, by = r / rb_bx; rgbd_base_body(rb, N, cutoff, r - by * rb_bx, by); }
+}
 
 // ------------------------------------------------------------------ launchers ----
 static Level3 levels3(int W, int H)
@@ -619,6 +568,11 @@ void launch_frame_maps(hipStream_t s, FrameMapsArgs a, int W, int H)
 {
     a.L = levels3(W, H);
     frame_maps_kernel<<<a.L.blk_end[2], kBlock, 0, s>>>(a);
+}
+void rgb_prep_levels(RgbPrepBatch& b, int n, int W, int H)
+{
+    const Level3 L = levels3(W, H);
+    for (int m = 0; m < n; m++) b.m[m].L = L;
 }
 void launch_rgb_prep(hipStream_t s, RgbPrepBatch b, int n, int W, int H)
 {
@@ -636,6 +590,20 @@ void launch_model_maps(hipStream_t s, const ModelMapsBatch& b, int n)
     }
     const int t = (cols >> 2) * (rows >> 2);
     model_maps_kernel<<<dim3((t + 63) / 64, n), 64, 0, s>>>(b);
+}
+void launch_model_maps_and_pyramids(hipStream_t s, const ModelMapsBatch& mb, int n, const RgbdBatch& rb, int n_chains, int W, int H, float cutoff)
+{
+    static_assert(kBlock == 256, "the fused launch runs both bodies with 256 threads");
+    const int cols = mb.m[0].cols, rows = mb.m[0].rows;
+    if (cols % 16 == 0 && rows % 4 == 0) {
+        const int mm_bx = ((cols >> 4) * (rows >> 2) + 3) / 4, rb_bx = 2 * grid_for(W * H);
+        prep_fused_kernel<<<mm_bx * n + rb_bx * n_chains, 256, 0, s>>>(mb, mm_bx, mm_bx * n, rb, W * H, cutoff, rb_bx);
+    } else {
+        launch_model_maps(s, mb, n);
+        rgbd_base_kernel<<<dim3(2 * grid_for(W * H), n_chains), kBlock, 0, s>>>(rb, W * H, cutoff);
+    }
+    for (int i = 0; i + 1 < 3; i++)
+        rgbd_pyrdown_kernel<<<dim3(2 * grid_for(((W >> i) / 2) * ((H >> i) / 2)), n_chains), kBlock, 0, s>>>(rb, i, W >> i, H >> i);
 }
 void launch_rgbd_pyramids(hipStream_t s, const RgbdBatch& b, int n_chains, int W, int H, float cutoff)
 {

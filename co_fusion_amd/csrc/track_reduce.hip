@@ -18,6 +18,7 @@
 //    4 MiB L2 across the 19 iterations of a frame.
 #include "cf_device.h"
 #include "cf_kernels.h"
+#include "track_prep_dev.h"
 
 namespace cf {
 
@@ -861,11 +862,20 @@ __device__ __forceinline__ unsigned long long l2_read_u64(unsigned long long* p)
     asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(zero) : "memory");
     return v;
 }
+// The launch is one-dimensional: [gx workgroups per model of the pre-alignment | prep_bx workgroups per model of the RGB preparation
+// (Sobel + candidate mask + cloud: rgb_prep_body)].  The two read the same pyramids and depend on nothing of each other; the
+// pre-alignment is a latency chain on 16 workgroups per model, the preparation fills the rest of the chip meanwhile.
 __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __restrict__ models, So3Sync* __restrict__ syncs, int do_so3,
-                                                           int first_level)
+                                                           int first_level, int gx, int so3_blocks, const RgbPrepBatch prep, int prep_bx)
 {
-    OdomDev* od = models[blockIdx.y];
-    So3Sync* sync = syncs + blockIdx.y;
+    if ((int)blockIdx.x >= so3_blocks) {
+        const int r = (int)blockIdx.x - so3_blocks, m = r / prep_bx;
+        rgb_prep_body(prep.m[m], r - m * prep_bx);
+        return;
+    }
+    const int by = (int)blockIdx.x / gx, bxx = (int)blockIdx.x - by * gx;  // gx is 1 or a multiple of 8: bxx mod 8 is the XCD
+    OdomDev* od = models[by];
+    So3Sync* sync = syncs + by;
     __shared__ unsigned long long lds[16][16];
     __shared__ unsigned long long totals[16];
     __shared__ float s_basis[9], s_kinv[9], s_krlr[9];
@@ -879,11 +889,11 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
     __shared__ int s_iws[3];
     const int L = 2, cols = od->width >> L, rows = od->height >> L;
     // with the pre-alignment the launch is 8 x kSo3Blocks wide: this model's workgroups are the ones on XCD (model mod 8)
-    const bool one_xcd = do_so3 && gridDim.x > 1;
-    if (one_xcd && (blockIdx.x & 7) != (blockIdx.y & 7)) return;
-    const int bx = one_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const bool one_xcd = do_so3 && gx > 1;
+    if (one_xcd && (bxx & 7) != (by & 7)) return;
+    const int bx = one_xcd ? (bxx >> 3) : bxx;
     const bool lead = bx == 0;  // the workgroup that publishes statistics and the final state
-    const unsigned G = one_xcd ? gridDim.x >> 3 : gridDim.x;
+    const unsigned G = one_xcd ? (unsigned)gx >> 3 : (unsigned)gx;
     if (threadIdx.x == 0) {
         for (int k = 0; k < 9; k++) { s_resultR[k] = (k % 4 == 0) ? 1.0 : 0.0; s_lastResultR[k] = s_resultR[k]; s_Rlr[k] = (k % 4 == 0) ? 1.f : 0.f; }
         k_matrix(cam_level(od->intr, L), s_K);
@@ -1351,7 +1361,7 @@ void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, 
 // Kept as separate launches.
 bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const GnHook* hook, const IcpArgs icp_args[3],
                      const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, int mode,
-                     ProfSink* prof, OdomDev* const* h_states)
+                     ProfSink* prof, OdomDev* const* h_states, const RgbPrepBatch* prep)
 {
     int iterations[3];
     iterations[0] = fast_odom ? 3 : 10;
@@ -1359,7 +1369,12 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
     iterations[2] = pyramid ? 4 : 0;
     int first_level = 2;
     while (first_level > 0 && iterations[first_level] == 0) first_level--;
-    so3_prealign_kernel<<<dim3(so3 ? 8 * kSo3Blocks : 1, n), 256, 0, s>>>(d_models, so3_syncs, so3 ? 1 : 0, first_level);  // (8x: one XCD per model)
+    {
+        const int gx = so3 ? 8 * kSo3Blocks : 1;  // (8x: one XCD per model)
+        static const RgbPrepBatch none{};
+        const int prep_bx = prep ? prep->m[0].L.blk_end[2] : 0;
+        so3_prealign_kernel<<<gx * n + prep_bx * n, 256, 0, s>>>(d_models, so3_syncs, so3 ? 1 : 0, first_level, gx, gx * n, prep ? *prep : none, prep_bx);
+    }
     GnArgs gn{};
     gn.icp_gram = cfg.gram;
     for (int m = 0; m < n; m++) {
