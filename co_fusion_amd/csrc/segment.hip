@@ -104,11 +104,18 @@ __device__ __forceinline__ long long q32(float v)
     return __double2ll_rn((double)c * 4294967296.0);
 }
 
+// The kernels of the segmentation chain take the arguments of up to kSegBatch segmenters (the sequences of a lock-step group, all of
+// one image size) in the kernel-argument segment and pick theirs with the grid's last dimension: one chain of launches for the group
+// instead of one per sequence.  A single segmenter is a batch of one.
+constexpr int kSegBatch = 8;
+template <class A, int N = kSegBatch> struct SegBatch { A m[N]; };
+
 struct AccArgs {
     const int* labels; const float* depth;
     const float* icp[kAccTile]; const float4* vconf[kAccTile];   // the first kAccTile models' images (kernel arguments: no pointer chasing)
     const float* const* icp_dev; const float4* const* vconf_dev;  // all n_models of them in device memory when there are more
     int n_models, cols, rows, gx, gy;
+    int* resample;                   // nullable: [K] labels at the resample coordinates, written by the launch's extra grid row
     unsigned* spix_count;            // [K]
     unsigned* depth_count;           // [K]
     unsigned long long* depth_sum;   // [K]
@@ -116,13 +123,23 @@ struct AccArgs {
     unsigned long long* conf_sum;    // [n][K]
 };
 
-__global__ void __launch_bounds__(256) seg_accumulate_kernel(const AccArgs a)
+__global__ void __launch_bounds__(256) seg_accumulate_kernel(const SegBatch<AccArgs> B)
 {
+    const AccArgs& a = B.m[blockIdx.z];
     __shared__ int s_lab[9];
     __shared__ unsigned s_cnt[9], s_dcnt[9];
     __shared__ unsigned long long s_dsum[9];
     __shared__ unsigned long long s_icp[kAccTile][9], s_conf[kAccTile][9];
     const int cx0 = blockIdx.x, cy0 = blockIdx.y, t = threadIdx.x;
+    if (cy0 == a.gy) {  // the extra grid row: labels at the "empty superpixel" resample coordinates (Slic.h:192-206; index / spixelY is the reference's)
+        const int k = cx0 * 256 + t;
+        if (k >= a.gx * a.gy) return;
+        int x = (int)((k % a.gx) * kSpix + kSpix * 0.5), y = (int)((k / a.gy) * kSpix + kSpix * 0.5);
+        if (y >= a.rows) y = a.rows - 1;
+        if (x >= a.cols) x = a.cols - 1;
+        a.resample[k] = a.labels[y * a.cols + x];
+        return;
+    }
     const int K = a.gx * a.gy;
     if (t < 9) {
         const int dx = t % 3 - 1, dy = t / 3 - 1, cx = cx0 + dx, cy = cy0 + dy;
@@ -182,87 +199,134 @@ __global__ void seg_resample_kernel(const int* __restrict__ labels, int cols, in
     out[k] = labels[y * cols + x];
 }
 
-__global__ void __launch_bounds__(256) seg_upsample_kernel(const int* __restrict__ labels, const unsigned char* __restrict__ low_map, int N,
-                                                           unsigned char* __restrict__ full)
+struct UpsampleArgs { const int* labels; const unsigned char* low_map; unsigned char* full; };
+__global__ void __launch_bounds__(256) seg_upsample_kernel(const SegBatch<UpsampleArgs> B, int N)
 {
+    const UpsampleArgs& a = B.m[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < N) full[i] = low_map[labels[i]];
+    if (i < N) a.full[i] = a.low_map[a.labels[i]];
+}
+static void launch_upsample(hipStream_t st, const int* labels, const unsigned char* low_map, int N, unsigned char* full)
+{
+    SegBatch<UpsampleArgs> B{};
+    B.m[0] = UpsampleArgs{labels, low_map, full};
+    seg_upsample_kernel<<<dim3((N + 255) / 256, 1), 256, 0, st>>>(B, N);
 }
 
 // ------------------------------------------------------------------------------- dense CRF ----
+// The symmetric-normalised Gaussian kernel K[i][j] = norm_i * exp(-|f_i - f_j|^2 / 2) * norm_j of a feature set, stored transposed.
+// All sums over the n nodes (normalisation and message passing) run in kCrfChunks contiguous chunks of ceil(n / kCrfChunks) indices:
+// sequential inside a chunk, chunk totals added in chunk order (the oracle states the same order).  A thread that walks all n nodes
+// alone made the 1200-node mean field 61 % of a multi-object frame (10 x 192 us + 2 x 294 us, measured); with the chunked order one
+// wave covers 64 nodes x one chunk.
+// Until round 4 the build was four launches (raw matrix, chunk partials, norm, scale: 5.9 + 4.7 + 4.6 + 9.6 us and three boundaries for
+// 1200 nodes, re-reading the 5.8 MB raw matrix twice, once transposed).  Now two: the exponentials are cheap, so both passes recompute
+// them from the features (the SAME expression: raw[i][j] and raw[j][i] agree bit for bit, (a - b)^2 == (b - a)^2) and no raw matrix exists.
+constexpr int kCrfChunks = 16;
 template <int D>
-__global__ void __launch_bounds__(256) crf_raw_kernel(const float* __restrict__ feat, int n, float* __restrict__ raw)
+__device__ __forceinline__ float crf_raw(const float* fi, const float* fj)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n * n) return;
-    const int i = idx / n, j = idx - i * n;
     float d2 = 0;
 #pragma unroll
-    for (int d = 0; d < D; d++) { const float t = feat[i * D + d] - feat[j * D + d]; d2 += t * t; }
-    raw[idx] = det_expf(-0.5f * d2);
+    for (int d = 0; d < D; d++) { const float t = fi[d] - fj[d]; d2 += t * t; }
+    return det_expf(-0.5f * d2);
 }
-// All sums over the n nodes (normalisation and message passing) run in kCrfChunks contiguous chunks of
-// ceil(n / kCrfChunks) indices: sequential inside a chunk, chunk totals added in chunk order (the oracle states
-// the same order).  A thread that walks all n nodes alone made the 1200-node mean field 61 % of a multi-object
-// frame (10 x 192 us + 2 x 294 us, measured); with the chunked order one wave covers 64 nodes x one chunk and
-// (n/64) x 16 workgroups spread over the whole device.
-constexpr int kCrfChunks = 16;
-// partial[c][i] = sum over chunk c of raw[i][j]  (raw is bitwise symmetric: read column-wise, coalesced)
-__global__ void __launch_bounds__(64) crf_norm_partial_kernel(const float* __restrict__ raw, int n, float* __restrict__ partial)
+// One segmenter's buffers of the mean field (a batch entry of every CRF launch)
+struct CrfSeq {
+    const float* feat; float* norm; float* Kt;      // kernel-matrix build: features in, normalisation scratch, matrix out
+    const float* K1t; const float* K2t;             // mean field: smoothness and appearance kernels
+    const float* unary; float* Q0; float* Q1; float* partial;
+    int L;
+};
+struct CrfBatch { CrfSeq m[kSegBatch]; };
+// norm_i = 1/sqrt(sum_c (sum over chunk c of raw[i][j]) + 1e-20).  A workgroup owns R nodes: its 1024 threads fill the R rows of the raw
+// matrix in LDS (the exponentials, fully parallel), then one thread per (row, chunk) adds its chunk in node order and one per row the
+// chunk totals in chunk order.  (One lane per (node, chunk) evaluating its 75 exponentials one after the other took 21.9 us.)
+template <int D>
+__global__ void __launch_bounds__(1024) crf_rownorm_kernel(const CrfBatch B, int n, int R)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
-    if (i >= n) return;
-    const int len = (n + kCrfChunks - 1) / kCrfChunks, j0 = c * len, j1 = min(n, j0 + len);
-    float s = 0;
-    int j = j0;
-    for (; j + 25 <= j1; j += 25) {  // independent loads in flight together, additions in node order
-        float v[25];
+    const float* __restrict__ feat = B.m[blockIdx.y].feat; float* __restrict__ norm = B.m[blockIdx.y].norm;
+    extern __shared__ float s_raw[];  // [R][n]
+    __shared__ float s_fi[8 * D];
+    __shared__ float s_part[8][kCrfChunks];
+    const int tid = threadIdx.x, i0 = blockIdx.x * R;
+    if (tid < R * D && i0 * D + tid < n * D) s_fi[tid] = feat[i0 * D + tid];
+    __syncthreads();
+    for (int e = tid; e < R * n; e += 1024) {
+        const int il = e / n, j = e - il * n;
+        float fj[D];
 #pragma unroll
-        for (int u = 0; u < 25; u++) v[u] = raw[(j + u) * n + i];
-#pragma unroll
-        for (int u = 0; u < 25; u++) s += v[u];
+        for (int d = 0; d < D; d++) fj[d] = feat[j * D + d];
+        s_raw[e] = (i0 + il < n) ? crf_raw<D>(s_fi + il * D, fj) : 0.f;
     }
-    for (; j < j1; j++) s += raw[j * n + i];
-    partial[c * n + i] = s;
-}
-// norm_i = 1/sqrt(sum_c partial[c][i] + 1e-20)
-__global__ void __launch_bounds__(256) crf_norm_kernel(const float* __restrict__ partial, int n, float* __restrict__ norm)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0;
-    for (int c = 0; c < kCrfChunks; c++) s += partial[c * n + i];
-    norm[i] = 1.0f / sqrtf(s + 1e-20f);
-}
-// Kt[j][i] = (norm_i * raw[i][j]) * norm_j   (value of the symmetric-normalised kernel K[i][j], stored transposed)
-__global__ void __launch_bounds__(256) crf_scale_kernel(const float* __restrict__ raw, const float* __restrict__ norm, int n,
-                                                        float* __restrict__ Kt)
-{
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n * n) return;
-    const int j = idx / n, i = idx - j * n;
-    Kt[idx] = norm[i] * raw[i * n + j] * norm[j];
+    __syncthreads();
+    if (tid < R * kCrfChunks) {
+        const int il = tid / kCrfChunks, c = tid - il * kCrfChunks;
+        const int len = (n + kCrfChunks - 1) / kCrfChunks, j0 = c * len, j1 = min(n, j0 + len);
+        const float* row = s_raw + il * n;
+        float sum = 0;
+        for (int j = j0; j < j1; j++) sum += row[j];
+        s_part[il][c] = sum;
+    }
+    __syncthreads();
+    if (tid < R && i0 + tid < n) {
+        float t = 0;
+        for (int k = 0; k < kCrfChunks; k++) t += s_part[tid][k];
+        norm[i0 + tid] = 1.0f / sqrtf(t + 1e-20f);
+    }
 }
 // expAndNormalize of -unary
-__global__ void __launch_bounds__(256) crf_init_kernel(const float* __restrict__ unary, int L, int n, float* __restrict__ Q)
+__device__ __forceinline__ void crf_init_node(const float* __restrict__ unary, int L, int i, float* __restrict__ Q)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     float mx = -unary[i * L];
     for (int l = 1; l < L; l++) if (-unary[i * L + l] > mx) mx = -unary[i * L + l];
     float s = 0;
     for (int l = 0; l < L; l++) s += det_expf(-unary[i * L + l] - mx);
     for (int l = 0; l < L; l++) Q[i * L + l] = det_expf(-unary[i * L + l] - mx) / s;   // (the same expression: the same bits as the summand)
 }
-// one mean-field step, part 1: chunk partials of K1*Q and K2*Q; partial[((c*n + i)*2 + which)*L + l].
-// One lane per (node i, chunk c, label l) -- grid (n/64, chunks, labels): the sums inside a chunk are sequential by definition, so
-// the only parallelism is across nodes, chunks and labels, and with one lane per (node, chunk) only ~300 waves existed for 1024
-// SIMDs.  The chunk is walked five nodes at a time so that the kernel-matrix loads of a group are in flight together (the sums
-// stay in node order).
-__global__ void __launch_bounds__(64) crf_message_kernel(int L, int n, const float* __restrict__ K1t, const float* __restrict__ K2t,
-                                                         const float* __restrict__ Q, float* __restrict__ partial)
+// Kt[j][i] = (norm_i * raw[i][j]) * norm_j.  Workgroups beyond the matrix's (g2 of them) run expAndNormalize of -unary for the mean
+// field's first marginals (with_init): independent work that was a 4.7 us launch of its own.
+template <int D>
+__global__ void __launch_bounds__(256) crf_kernel_matrix_kernel(const CrfBatch B, int n, int g2, int with_init)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y, l = blockIdx.z;
+    const CrfSeq& m = B.m[blockIdx.y];
+    if ((int)blockIdx.x >= g2) {
+        const int i = ((int)blockIdx.x - g2) * 256 + threadIdx.x;
+        if (with_init && i < n) crf_init_node(m.unary, m.L, i, m.Q0);
+        return;
+    }
+    const float* __restrict__ feat = m.feat; const float* __restrict__ norm = m.norm; float* __restrict__ Kt = m.Kt;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int j = idx / n, i = idx - j * n;
+    float fi[D], fj[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) { fi[d] = feat[i * D + d]; fj[d] = feat[j * D + d]; }
+    Kt[idx] = norm[i] * crf_raw<D>(fi, fj) * norm[j];
+}
+// the kernel matrices of S feature sets (+ the first marginals beside them)
+template <int D>
+static void launch_crf_kernel_matrix(hipStream_t st, const CrfBatch& B, int S, int n, bool with_init)
+{
+    const int g2 = (n * n + 255) / 256, g1 = (n + 255) / 256;
+    int R = (int)(48u * 1024u / (sizeof(float) * (size_t)n));  // rows of the raw matrix per workgroup: what 48 KB of LDS hold, at most 8
+    R = R > 8 ? 8 : (R < 1 ? 1 : R);                          // (n <= 12288 nodes; 640x480 has 1200, 1280x960 4800)
+    crf_rownorm_kernel<D><<<dim3((n + R - 1) / R, S), 1024, sizeof(float) * (size_t)R * n, st>>>(B, n, R);
+    crf_kernel_matrix_kernel<D><<<dim3(g2 + (with_init ? g1 : 0), S), 256, 0, st>>>(B, n, g2, with_init ? 1 : 0);
+}
+// one mean-field step, part 1: chunk partials of K1*Q and K2*Q; partial[((c*n + i)*2 + which)*L + l].
+// One lane per (node i, chunk c, label l) -- grid (n/64, chunks x labels, batch entries): the sums inside a chunk are sequential
+// by definition, so the only parallelism is across nodes, chunks and labels, and with one lane per (node, chunk) only ~300 waves existed
+// for 1024 SIMDs.  The chunk is walked 25 nodes at a time so that the kernel-matrix loads of a group are in flight together (the sums
+// stay in node order).  flip: the marginals are read from Q1 (odd steps) / Q0 (even steps).
+__global__ void __launch_bounds__(64) crf_message_kernel(const CrfBatch B, int n, int flip)
+{
+    const CrfSeq& m = B.m[blockIdx.z];
+    const int L = m.L, l = blockIdx.y / kCrfChunks, c = blockIdx.y % kCrfChunks;  // grid.y = chunks x the batch's largest label count
+    if (l >= L) return;
+    const float* __restrict__ K1t = m.K1t; const float* __restrict__ K2t = m.K2t;
+    const float* __restrict__ Q = flip ? m.Q1 : m.Q0; float* __restrict__ partial = m.partial;
+    const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const int len = (n + kCrfChunks - 1) / kCrfChunks, j0 = c * len, j1 = min(n, j0 + len);
     float a = 0, b = 0;
@@ -291,17 +355,15 @@ __global__ void __launch_bounds__(64) crf_message_kernel(int L, int n, const flo
     float* out = partial + ((size_t)(c * n + i) * 2) * L;
     out[l] = a; out[L + l] = b;
 }
-static void launch_crf_message(hipStream_t st, dim3 grid, int L, int n, const float* K1t, const float* K2t, const float* Q, float* partial)
-{
-    crf_message_kernel<<<dim3(grid.x, grid.y, L), 64, 0, st>>>(L, n, K1t, K2t, Q, partial);
-}
 // part 2: chunk totals in chunk order, unary, softmax over the labels.  Thread (node g, label l): 256 / LS nodes x LS label slots per
 // workgroup (LS = 16 for up to 16 labels, a power of two up to 256 beyond); the chunk partials of a (node, label) are loaded
 // independently and summed in chunk order, the softmax runs over the node's LDS row exactly like expAndNormalize.
 template <int LS>
-__global__ void __launch_bounds__(256) crf_update_kernel(const float* __restrict__ unary, int L, int n, const float* __restrict__ partial,
-                                                         float w_smooth, float w_app, float* __restrict__ Qn)
+__global__ void __launch_bounds__(256) crf_update_kernel(const CrfBatch B, int n, float w_smooth, float w_app, int flip)
 {
+    const CrfSeq& m = B.m[blockIdx.y];
+    const int L = m.L;
+    const float* __restrict__ unary = m.unary; const float* __restrict__ partial = m.partial; float* __restrict__ Qn = flip ? m.Q0 : m.Q1;
     constexpr int G = 256 / LS;
     __shared__ float s_t[G][LS];
     const int g = threadIdx.x / LS, l = threadIdx.x % LS;
@@ -329,13 +391,23 @@ __global__ void __launch_bounds__(256) crf_update_kernel(const float* __restrict
         Qn[i * L + l] = det_expf(tmp - mx) / sum;
     }
 }
-static void launch_crf_update(hipStream_t st, const float* unary, int L, int n, const float* partial, float w_smooth, float w_app, float* Qn)
+// `iterations` mean-field steps of S batch entries from Q0; returns 1 when the last marginals are in Q1
+static int launch_mean_field(hipStream_t st, CrfBatch& B, int S, int n, int iterations, float w_smooth, float w_app)
 {
-    if (L <= 16) crf_update_kernel<16><<<(n + 15) / 16, 256, 0, st>>>(unary, L, n, partial, w_smooth, w_app, Qn);
-    else if (L <= 32) crf_update_kernel<32><<<(n + 7) / 8, 256, 0, st>>>(unary, L, n, partial, w_smooth, w_app, Qn);
-    else if (L <= 64) crf_update_kernel<64><<<(n + 3) / 4, 256, 0, st>>>(unary, L, n, partial, w_smooth, w_app, Qn);
-    else if (L <= 128) crf_update_kernel<128><<<(n + 1) / 2, 256, 0, st>>>(unary, L, n, partial, w_smooth, w_app, Qn);
-    else crf_update_kernel<256><<<n, 256, 0, st>>>(unary, L, n, partial, w_smooth, w_app, Qn);
+    int Lmax = 0;
+    for (int e = 0; e < S; e++) Lmax = B.m[e].L > Lmax ? B.m[e].L : Lmax;
+    const dim3 gm((n + 63) / 64, kCrfChunks * Lmax, S);
+    int flip = 0;
+    for (int it = 0; it < iterations; it++) {
+        crf_message_kernel<<<gm, 64, 0, st>>>(B, n, flip);
+        if (Lmax <= 16) crf_update_kernel<16><<<dim3((n + 15) / 16, S), 256, 0, st>>>(B, n, w_smooth, w_app, flip);
+        else if (Lmax <= 32) crf_update_kernel<32><<<dim3((n + 7) / 8, S), 256, 0, st>>>(B, n, w_smooth, w_app, flip);
+        else if (Lmax <= 64) crf_update_kernel<64><<<dim3((n + 3) / 4, S), 256, 0, st>>>(B, n, w_smooth, w_app, flip);
+        else if (Lmax <= 128) crf_update_kernel<128><<<dim3((n + 1) / 2, S), 256, 0, st>>>(B, n, w_smooth, w_app, flip);
+        else crf_update_kernel<256><<<dim3(n, S), 256, 0, st>>>(B, n, w_smooth, w_app, flip);
+        flip ^= 1;
+    }
+    return flip;
 }
 
 
@@ -424,8 +496,9 @@ __device__ __forceinline__ void wave_sequential_sum2(float& sa, float& sb, int n
 // order by the reference: an empty superpixel k reads entry `read`, which has ALREADY been divided when read < k and is still the
 // raw sum when read > k.  Non-empty entries do not depend on anything else (phase 1, parallel); the rare empty ones are replayed in
 // index order by one lane per array (phase 2) from a list built with an ordered scan.
-__global__ void __launch_bounds__(1024) seg_unary_kernel(const SegUnaryArgs a)
+__global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnaryArgs> B)
 {
+    const SegUnaryArgs a = B.m[blockIdx.x];  // (by value: the fields are loaded into scalar registers once, ahead of the phases)
     const int K = a.K, n = a.n_models, A = 1 + 2 * n, L = a.L;
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float s_min[16], s_max[16];
@@ -567,11 +640,12 @@ __global__ void seg_feat1_kernel(int gx, int K, float* __restrict__ feat1)
     feat1[k * 2 + 0] = (float)(k % gx) / 2.0f; feat1[k * 2 + 1] = (float)(k / gx) / 2.0f;
 }
 
-struct SegPostArgs {
+template <int CAP>
+struct SegPostArgsT {
     int K, gx, gy, n_models, L, allow_new, width, height;
     unsigned next_id;
     float minRelSizeNew, maxRelSizeNew;
-    unsigned ids[kMaxL + 1];         // model ids in list order (+ the new label's id)
+    unsigned ids[CAP];               // model ids in list order (+ the new label's id)
     const float* Q;                  // [K][L] marginals
     const float* low_depth;          // [K]
     const float* avg_conf;           // [n]
@@ -591,8 +665,12 @@ struct SegPostArgs {
 constexpr int kSegMaxK = 4800;
 constexpr int kPoseWords = 18;   // cf_seg_publish_poses: 16 pose words + ICP error + ICP inlier count, one 64-bit slot per f32 bit pattern
 constexpr int kCcLds = 256;   // components whose statistics fit in LDS (a frame has tens)
-__global__ void __launch_bounds__(1024) seg_post_kernel(const SegPostArgs a)
+using SegPostArgs = SegPostArgsT<kMaxL + 1>;   // one segmenter with up to 256 labels ...
+using SegPostArgs16 = SegPostArgsT<17>;        // ... or kSegBatch of them with up to 16 models + a new label each
+template <int CAP, int N>
+__global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostArgsT<CAP>, N> B)
 {
+    const SegPostArgsT<CAP>& a = B.m[blockIdx.x];
     const int K = a.K, gx = a.gx, L = a.L, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int n_md = a.n_models + (a.allow_new ? 1 : 0);
     __shared__ int s_changed, s_min_label;
@@ -856,7 +934,7 @@ struct cf_segmenter {
     unsigned long long *depth_sum = nullptr, *icp_sum = nullptr, *conf_sum = nullptr;
     int* resample = nullptr;
     unsigned char* low_map = nullptr;
-    float *feat1 = nullptr, *feat2 = nullptr, *raw = nullptr, *norm = nullptr, *K1t = nullptr, *K2t = nullptr;
+    float *feat1 = nullptr, *feat2 = nullptr, *norm = nullptr, *K1t = nullptr, *K2t = nullptr;
     float* partial = nullptr;            // chunk partial sums [kCrfChunks][K][2][Lcap]
     std::vector<float> smooth_cache;     // host copy of the smoothness features K1t was built from
     float *unary = nullptr, *Q0 = nullptr, *Q1 = nullptr;
@@ -923,7 +1001,6 @@ int cf_seg_create(cf_ctx* ctx, cf_segmenter** out)
     if (int r = seg_malloc(ctx, &s->low_map, K)) return r;
     if (int r = seg_malloc(ctx, &s->feat1, K * 2)) return r;
     if (int r = seg_malloc(ctx, &s->feat2, K * 6)) return r;
-    if (int r = seg_malloc(ctx, &s->raw, K * K)) return r;
     if (int r = seg_malloc(ctx, &s->norm, K)) return r;
     if (int r = seg_malloc(ctx, &s->K1t, K * K)) return r;
     if (int r = seg_malloc(ctx, &s->K2t, K * K)) return r;
@@ -951,7 +1028,7 @@ void cf_seg_destroy(cf_segmenter* s)
     if (!s) return;
     (void)hipStreamSynchronize(s->ctx->stream);
     void* ptrs[] = {s->labels, s->centres, s->slic_sums, s->spix_count, s->depth_count, s->depth_sum, s->icp_sum, s->resample,
-                    s->low_map, s->feat1, s->feat2, s->raw, s->norm, s->K1t, s->K2t, s->partial, s->unary, s->Q0, s->Q1,
+                    s->low_map, s->feat1, s->feat2, s->norm, s->K1t, s->K2t, s->partial, s->unary, s->Q0, s->Q1,
                     s->raw_mean, s->low_mean, s->avg_conf, s->depth_range, s->parent, s->comp, s->cc, s->d_result, (void*)s->d_acc_ptrs};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->h_result) (void)hipHostFree(s->h_result);
@@ -998,7 +1075,12 @@ int cf_seg_accumulate(cf_segmenter* s, const float* depth, int n_models, const f
     a.labels = s->labels; a.depth = depth; a.n_models = n_models; a.cols = ctx->cfg.width; a.rows = ctx->cfg.height; a.gx = s->gx; a.gy = s->gy;
     if (int r = acc_pointers(s, a, n_models, icp_err, vertconf4)) return r;
     a.spix_count = s->spix_count; a.depth_count = s->depth_count; a.depth_sum = s->depth_sum; a.icp_sum = s->icp_sum; a.conf_sum = s->conf_sum;
-    seg_accumulate_kernel<<<dim3(s->gx, s->gy), 256, 0, st>>>(a);
+    {
+        SegBatch<AccArgs> B;
+        memset(&B, 0, sizeof(B));
+        B.m[0] = a;
+        seg_accumulate_kernel<<<dim3(s->gx, s->gy, 1), 256, 0, st>>>(B);
+    }
     seg_resample_kernel<<<(s->K + 255) / 256, 256, 0, st>>>(s->labels, ctx->cfg.width, ctx->cfg.height, s->gx, s->gy, s->resample);
     LAUNCHCHK(ctx);
     HIPCHK(ctx, hipMemcpyAsync(spix_count_host, s->spix_count, sizeof(unsigned) * K, hipMemcpyDeviceToHost, st));
@@ -1013,6 +1095,26 @@ int cf_seg_accumulate(cf_segmenter* s, const float* depth, int n_models, const f
     return CF_OK;
 }
 
+static CrfSeq crf_seq(cf_segmenter* s, int L)
+{
+    CrfSeq m{};
+    m.feat = s->feat2; m.norm = s->norm; m.Kt = s->K2t; m.K1t = s->K1t; m.K2t = s->K2t;
+    m.unary = s->unary; m.Q0 = s->Q0; m.Q1 = s->Q1; m.partial = s->partial; m.L = L;
+    return m;
+}
+// the smoothness kernel K1t from feat1 (make_features: the grid's own features first -- seg_feat1_kernel)
+static void build_grid_kernel(cf_segmenter* s, bool make_features)
+{
+    hipStream_t st = s->ctx->stream;
+    const int n = s->K;
+    if (make_features) seg_feat1_kernel<<<(n + 255) / 256, 256, 0, st>>>(s->gx, n, s->feat1);
+    CrfBatch B;
+    memset(&B, 0, sizeof(B));
+    B.m[0] = crf_seq(s, 0);
+    B.m[0].feat = s->feat1; B.m[0].Kt = s->K1t;
+    launch_crf_kernel_matrix<2>(st, B, 1, n, false);
+}
+
 // DenseCRF2D inference as used by Segmentation.cpp:436-480 (exact kernels, see the file header).
 // unary [K*L] row-per-node, feat_smooth [K*2], feat_app [K*6] host in; Q [K*L] host out (synchronous).
 int cf_seg_crf(cf_segmenter* s, const float* unary_host, int L, const float* feat_smooth_host, const float* feat_app_host,
@@ -1023,30 +1125,19 @@ int cf_seg_crf(cf_segmenter* s, const float* unary_host, int L, const float* fea
     const int n = s->K;
     HIPCHK(ctx, hipMemcpyAsync(s->unary, unary_host, sizeof(float) * n * L, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(s->feat2, feat_app_host, sizeof(float) * n * 6, hipMemcpyHostToDevice, st));
-    const int g2 = (n * n + 255) / 256, g1 = (n + 255) / 256;
-    const dim3 gc((n + 63) / 64, kCrfChunks);
     // the smoothness kernel only depends on the superpixel grid: rebuilt only when its features change
     const bool same_smooth = s->smooth_cache.size() == (size_t)n * 2 && memcmp(s->smooth_cache.data(), feat_smooth_host, sizeof(float) * n * 2) == 0;
     if (!same_smooth) {
         HIPCHK(ctx, hipMemcpyAsync(s->feat1, feat_smooth_host, sizeof(float) * n * 2, hipMemcpyHostToDevice, st));
-        crf_raw_kernel<2><<<g2, 256, 0, st>>>(s->feat1, n, s->raw);
-        crf_norm_partial_kernel<<<gc, 64, 0, st>>>(s->raw, n, s->partial);
-        crf_norm_kernel<<<g1, 256, 0, st>>>(s->partial, n, s->norm);
-        crf_scale_kernel<<<g2, 256, 0, st>>>(s->raw, s->norm, n, s->K1t);
+        build_grid_kernel(s, false);
         s->smooth_cache.assign(feat_smooth_host, feat_smooth_host + (size_t)n * 2);
         s->grid_kernel_built = false;
     }
-    crf_raw_kernel<6><<<g2, 256, 0, st>>>(s->feat2, n, s->raw);
-    crf_norm_partial_kernel<<<gc, 64, 0, st>>>(s->raw, n, s->partial);
-    crf_norm_kernel<<<g1, 256, 0, st>>>(s->partial, n, s->norm);
-    crf_scale_kernel<<<g2, 256, 0, st>>>(s->raw, s->norm, n, s->K2t);
-    crf_init_kernel<<<g1, 256, 0, st>>>(s->unary, L, n, s->Q0);
-    float *q = s->Q0, *qn = s->Q1;
-    for (int it = 0; it < iterations; it++) {
-        launch_crf_message(st, gc, L, n, s->K1t, s->K2t, q, s->partial);
-        launch_crf_update(st, s->unary, L, n, s->partial, w_smooth, w_app, qn);
-        float* t = q; q = qn; qn = t;
-    }
+    CrfBatch B;
+    memset(&B, 0, sizeof(B));
+    B.m[0] = crf_seq(s, L);
+    launch_crf_kernel_matrix<6>(st, B, 1, n, true);
+    const float* q = launch_mean_field(st, B, 1, n, iterations, w_smooth, w_app) ? s->Q1 : s->Q0;
     LAUNCHCHK(ctx);
     HIPCHK(ctx, hipMemcpyAsync(Q_host, q, sizeof(float) * n * L, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
@@ -1061,22 +1152,37 @@ int cf_seg_upsample(cf_segmenter* s, const uint8_t* low_map_host, uint8_t* full_
     const int N = ctx->cfg.width * ctx->cfg.height;
     HIPCHK(ctx, hipMemcpyAsync(s->low_map, low_map_host, (size_t)s->K, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));  // low_map_host may be a caller stack/heap buffer
-    seg_upsample_kernel<<<(N + 255) / 256, 256, 0, st>>>(s->labels, s->low_map, N, full_dev);
+    launch_upsample(st, s->labels, s->low_map, N, full_dev);
     LAUNCHCHK(ctx);
     return CF_OK;
 }
 
 // ---- device-resident flavour: sums -> [collective] -> unaries -> mean field -> post-processing -> mask, no host wait ----
-static int enqueue_accumulate(cf_segmenter* s, const float* depth, int n_models, const float* const* icp_err, const float* const* vertconf4)
+// One entry of a batched segmentation: what cf_seg_sums + cf_seg_infer take for one segmenter
+struct SegJob {
+    cf_segmenter* s; const float* depth; int n_models; const float* const* icp_err; const float* const* vertconf4;
+    const uint8_t* rgba; const uint32_t* model_ids; uint32_t next_model_id; int allow_new; uint8_t* full_dev;
+};
+// the sums of S <= kSegBatch segmenters of one image size in ONE launch (+ the resample labels in its extra grid row)
+static int enqueue_accumulate(cf_ctx* ctx, const SegJob* jobs, int S)
 {
-    cf_ctx* ctx = s->ctx; hipStream_t st = ctx->stream;
-    AccArgs a;
-    memset(&a, 0, sizeof(a));
-    a.labels = s->labels; a.depth = depth; a.n_models = n_models; a.cols = ctx->cfg.width; a.rows = ctx->cfg.height; a.gx = s->gx; a.gy = s->gy;
-    if (int r = acc_pointers(s, a, n_models, icp_err, vertconf4)) return r;
-    a.spix_count = s->spix_count; a.depth_count = s->depth_count; a.depth_sum = s->depth_sum; a.icp_sum = s->icp_sum; a.conf_sum = s->conf_sum;
-    seg_accumulate_kernel<<<dim3(s->gx, s->gy), 256, 0, st>>>(a);
-    seg_resample_kernel<<<(s->K + 255) / 256, 256, 0, st>>>(s->labels, ctx->cfg.width, ctx->cfg.height, s->gx, s->gy, s->resample);
+    hipStream_t st = ctx->stream;
+    cf_segmenter* s0 = jobs[0].s;
+    SegBatch<AccArgs> B;
+    memset(&B, 0, sizeof(B));
+    const bool ride = s0->gy <= 256;  // (gx workgroups of 256 threads cover the K = gx * gy resample points)
+    for (int e = 0; e < S; e++) {
+        cf_segmenter* s = jobs[e].s;
+        AccArgs& a = B.m[e];
+        a.labels = s->labels; a.depth = jobs[e].depth; a.n_models = jobs[e].n_models; a.cols = ctx->cfg.width; a.rows = ctx->cfg.height; a.gx = s->gx; a.gy = s->gy;
+        if (int r = acc_pointers(s, a, jobs[e].n_models, jobs[e].icp_err, jobs[e].vertconf4)) return r;
+        a.spix_count = s->spix_count; a.depth_count = s->depth_count; a.depth_sum = s->depth_sum; a.icp_sum = s->icp_sum; a.conf_sum = s->conf_sum;
+        a.resample = ride ? s->resample : nullptr;
+    }
+    seg_accumulate_kernel<<<dim3(s0->gx, s0->gy + (ride ? 1 : 0), S), 256, 0, st>>>(B);
+    if (!ride)
+        for (int e = 0; e < S; e++)
+            seg_resample_kernel<<<(jobs[e].s->K + 255) / 256, 256, 0, st>>>(jobs[e].s->labels, ctx->cfg.width, ctx->cfg.height, s0->gx, s0->gy, jobs[e].s->resample);
     LAUNCHCHK(ctx);
     return CF_OK;
 }
@@ -1089,7 +1195,9 @@ int cf_seg_sums(cf_segmenter* s, const float* depth, int n_models, const float* 
                 int64_t** sums_dev, uint64_t* sums_words)
 {
     if (!s || !depth || n_models <= 0 || n_models > s->Lcap || !icp_err || !vertconf4) return CF_EINVAL;
-    if (int r = enqueue_accumulate(s, depth, n_models, icp_err, vertconf4)) return r;
+    SegJob job{};
+    job.s = s; job.depth = depth; job.n_models = n_models; job.icp_err = icp_err; job.vertconf4 = vertconf4;
+    if (int r = enqueue_accumulate(s->ctx, &job, 1)) return r;
     if (sums_dev) *sums_dev = reinterpret_cast<int64_t*>(s->icp_sum);
     if (sums_words) *sums_words = 2ull * (uint64_t)s->Lcap * (uint64_t)s->K + (uint64_t)s->Lcap * kPoseWords;  // the pose tail rides along (zeros unless published)
     return CF_OK;
@@ -1120,64 +1228,114 @@ int cf_seg_fetch_poses(cf_segmenter* s, int n_models, int64_t* words_host)
     return CF_OK;
 }
 
-// Everything after the sums (Segmentation.cpp:160-706): unaries, 10 mean-field steps, arg-max, connected components, gates,
-// statistics, up-sampling of the label map into full_dev.  Only enqueues; the decisions arrive with cf_seg_fetch.
+}  // extern "C"
+// Everything after the sums (Segmentation.cpp:160-706) for S <= kSegBatch segmenters of one image size in one chain of launches: unaries,
+// kernel matrices, mean-field steps, arg-max / connected components / gates / statistics, up-sampling into full_dev.  CAP: the capacity
+// of the id table in the post-processing arguments (17 for a batch, 257 for one segmenter with many labels).
+template <int CAP, int N>
+static int enqueue_infer(cf_ctx* ctx, const cf_seg_params* P, const SegJob* jobs, int S)
+{
+    hipStream_t st = ctx->stream;
+    const int n = jobs[0].s->K;
+    SegBatch<SegUnaryArgs> U;
+    CrfBatch C;
+    SegBatch<SegPostArgsT<CAP>, N> PB;
+    SegBatch<UpsampleArgs> UP;
+    memset(&U, 0, sizeof(U)); memset(&C, 0, sizeof(C)); memset(&PB, 0, sizeof(PB)); memset(&UP, 0, sizeof(UP));
+    for (int e = 0; e < S; e++) {
+        cf_segmenter* s = jobs[e].s;
+        const int n_models = jobs[e].n_models, L = n_models + (jobs[e].allow_new ? 1 : 0);
+        SegUnaryArgs& u = U.m[e];
+        u.K = n; u.gx = s->gx; u.gy = s->gy; u.n_models = n_models; u.L = L; u.allow_new = jobs[e].allow_new ? 1 : 0;
+        u.unaryWeightError = P->unaryWeightError; u.unaryKError = P->unaryKError; u.unaryThresholdNew = P->unaryThresholdNew;
+        u.scaleFeaturesRGB = P->scaleFeaturesRGB; u.scaleFeaturesDepth = P->scaleFeaturesDepth; u.scaleFeaturesPos = P->scaleFeaturesPos;
+        u.spix_count = s->spix_count; u.depth_count = s->depth_count; u.depth_sum = s->depth_sum; u.icp_sum = s->icp_sum; u.conf_sum = s->conf_sum;
+        u.resample = s->resample; u.rgba = reinterpret_cast<const uchar4*>(jobs[e].rgba);
+        u.raw = s->raw_mean; u.low = s->low_mean; u.unary = s->unary; u.feat2 = s->feat2; u.avg_conf = s->avg_conf; u.depth_range = s->depth_range;
+        C.m[e] = crf_seq(s, L);
+    }
+    seg_unary_kernel<<<S, 1024, 0, st>>>(U);
+    for (int e = 0; e < S; e++) {
+        cf_segmenter* s = jobs[e].s;
+        if (!s->grid_kernel_built) {  // the smoothness kernel only depends on the superpixel grid: built once per segmenter
+            build_grid_kernel(s, true);
+            s->grid_kernel_built = true;
+            s->smooth_cache.clear();
+        }
+    }
+    launch_crf_kernel_matrix<6>(st, C, S, n, true);
+    const int flip = launch_mean_field(st, C, S, n, P->crfIterations, P->weightSmoothness, P->weightAppearance);
+    for (int e = 0; e < S; e++) {
+        cf_segmenter* s = jobs[e].s;
+        const int n_models = jobs[e].n_models, L = n_models + (jobs[e].allow_new ? 1 : 0);
+        SegPostArgsT<CAP>& p = PB.m[e];
+        p.K = n; p.gx = s->gx; p.gy = s->gy; p.n_models = n_models; p.L = L; p.allow_new = jobs[e].allow_new ? 1 : 0;
+        p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.next_id = jobs[e].next_model_id;
+        p.minRelSizeNew = P->minRelSizeNew; p.maxRelSizeNew = P->maxRelSizeNew;
+        for (int m = 0; m < n_models; m++) p.ids[m] = jobs[e].model_ids[m];
+        if (jobs[e].allow_new) p.ids[n_models] = jobs[e].next_model_id;
+        p.Q = flip ? s->Q1 : s->Q0; p.low_depth = s->low_mean; p.avg_conf = s->avg_conf; p.depth_range = s->depth_range;
+        p.parent = s->parent; p.comp = s->comp; p.cc = s->cc; p.low_map = s->low_map; p.result = s->d_result;
+        p.result_host = s->h_result; p.low_map_host = reinterpret_cast<unsigned*>(s->h_low_map);
+        UP.m[e] = UpsampleArgs{s->labels, s->low_map, jobs[e].full_dev};
+    }
+    seg_post_kernel<CAP, N><<<S, 1024, 0, st>>>(PB);
+    const int Npx = ctx->cfg.width * ctx->cfg.height;
+    seg_upsample_kernel<<<dim3((Npx + 255) / 256, S), 256, 0, st>>>(UP, Npx);
+    LAUNCHCHK(ctx);
+    for (int e = 0; e < S; e++) {
+        cf_segmenter* s = jobs[e].s;
+        if (s->poses_published) {  // the tail now holds what the caller's all-reduce made of it; the next frame starts from zeros again
+            long long* tail = reinterpret_cast<long long*>(s->icp_sum) + 2 * (size_t)s->Lcap * s->K;
+            HIPCHK(ctx, hipMemcpyAsync(s->h_pose_tail, tail, sizeof(long long) * (size_t)s->Lcap * kPoseWords, hipMemcpyDeviceToHost, st));
+        }
+    }
+    return CF_OK;
+}
+
+extern "C" {
+// Only enqueues; the decisions arrive with cf_seg_fetch.
 int cf_seg_infer(cf_segmenter* s, const cf_seg_params* P, const uint8_t* rgba, int n_models, const uint32_t* model_ids, uint32_t next_model_id,
                  int allow_new, uint8_t* full_dev)
 {
     if (!s || !P || !rgba || !model_ids || !full_dev || n_models <= 0) return CF_EINVAL;
     const int L = n_models + (allow_new ? 1 : 0);
     if (L > s->Lcap) { s->ctx->set_error("segmentation: more labels than the context's max_models (" + std::to_string(s->Lcap) + ")"); return CF_EINVAL; }
-    cf_ctx* ctx = s->ctx; hipStream_t st = ctx->stream;
-    const int n = s->K;
-    const int g2 = (n * n + 255) / 256, g1 = (n + 255) / 256;
-    const dim3 gc((n + 63) / 64, kCrfChunks);
-    SegUnaryArgs u;
-    memset(&u, 0, sizeof(u));
-    u.K = n; u.gx = s->gx; u.gy = s->gy; u.n_models = n_models; u.L = L; u.allow_new = allow_new ? 1 : 0;
-    u.unaryWeightError = P->unaryWeightError; u.unaryKError = P->unaryKError; u.unaryThresholdNew = P->unaryThresholdNew;
-    u.scaleFeaturesRGB = P->scaleFeaturesRGB; u.scaleFeaturesDepth = P->scaleFeaturesDepth; u.scaleFeaturesPos = P->scaleFeaturesPos;
-    u.spix_count = s->spix_count; u.depth_count = s->depth_count; u.depth_sum = s->depth_sum; u.icp_sum = s->icp_sum; u.conf_sum = s->conf_sum;
-    u.resample = s->resample; u.rgba = reinterpret_cast<const uchar4*>(rgba);
-    u.raw = s->raw_mean; u.low = s->low_mean; u.unary = s->unary; u.feat2 = s->feat2; u.avg_conf = s->avg_conf; u.depth_range = s->depth_range;
-    seg_unary_kernel<<<1, 1024, 0, st>>>(u);
-    if (!s->grid_kernel_built) {  // the smoothness kernel only depends on the superpixel grid: built once
-        seg_feat1_kernel<<<g1, 256, 0, st>>>(s->gx, n, s->feat1);
-        crf_raw_kernel<2><<<g2, 256, 0, st>>>(s->feat1, n, s->raw);
-        crf_norm_partial_kernel<<<gc, 64, 0, st>>>(s->raw, n, s->partial);
-        crf_norm_kernel<<<g1, 256, 0, st>>>(s->partial, n, s->norm);
-        crf_scale_kernel<<<g2, 256, 0, st>>>(s->raw, s->norm, n, s->K1t);
-        s->grid_kernel_built = true;
-        s->smooth_cache.clear();
+    SegJob job{};
+    job.s = s; job.n_models = n_models; job.rgba = rgba; job.model_ids = model_ids; job.next_model_id = next_model_id; job.allow_new = allow_new; job.full_dev = full_dev;
+    if (L <= 16) return enqueue_infer<17, kSegBatch>(s->ctx, P, &job, 1);
+    return enqueue_infer<kMaxL + 1, 1>(s->ctx, P, &job, 1);
+}
+
+// cf_seg_sums + cf_seg_infer of several segmenters of ONE context (the sequences of a lock-step group) through shared launches: the
+// chain of ~30 launch-floor kernels is issued once per kSegBatch segmenters instead of once per segmenter.  Per segmenter the results
+// are those of the two single calls, bit for bit; the decisions arrive with each segmenter's cf_seg_fetch.  No collective can sit between
+// the sums and the inference here (single-process callers).
+int cf_seg_run_batch(cf_ctx* ctx, const cf_seg_params* P, const cf_seg_job* jobs_in, int n_jobs)
+{
+    if (!ctx || !P || !jobs_in || n_jobs <= 0) return CF_EINVAL;
+    std::vector<SegJob> jobs((size_t)n_jobs);
+    bool batchable = true;
+    for (int e = 0; e < n_jobs; e++) {
+        const cf_seg_job& j = jobs_in[e];
+        if (!j.seg || j.seg->ctx != ctx || !j.depth || !j.icp_err || !j.vertconf4 || !j.rgba || !j.model_ids || !j.full_dev || j.n_models <= 0) return CF_EINVAL;
+        const int L = j.n_models + (j.allow_new ? 1 : 0);
+        if (L > j.seg->Lcap) { ctx->set_error("segmentation: more labels than the context's max_models (" + std::to_string(j.seg->Lcap) + ")"); return CF_EINVAL; }
+        for (int k = 0; k < e; k++) if (jobs_in[k].seg == j.seg) return CF_EINVAL;
+        batchable = batchable && L <= 16 && j.seg->K == jobs_in[0].seg->K && j.seg->gx == jobs_in[0].seg->gx;
+        jobs[e] = SegJob{j.seg, j.depth, j.n_models, j.icp_err, j.vertconf4, j.rgba, j.model_ids, j.next_model_id, j.allow_new, j.full_dev};
     }
-    crf_raw_kernel<6><<<g2, 256, 0, st>>>(s->feat2, n, s->raw);
-    crf_norm_partial_kernel<<<gc, 64, 0, st>>>(s->raw, n, s->partial);
-    crf_norm_kernel<<<g1, 256, 0, st>>>(s->partial, n, s->norm);
-    crf_scale_kernel<<<g2, 256, 0, st>>>(s->raw, s->norm, n, s->K2t);
-    crf_init_kernel<<<g1, 256, 0, st>>>(s->unary, L, n, s->Q0);
-    float *q = s->Q0, *qn = s->Q1;
-    for (int it = 0; it < P->crfIterations; it++) {
-        launch_crf_message(st, gc, L, n, s->K1t, s->K2t, q, s->partial);
-        launch_crf_update(st, s->unary, L, n, s->partial, P->weightSmoothness, P->weightAppearance, qn);
-        float* t = q; q = qn; qn = t;
+    if (!batchable) {  // (a sequence with more than 16 labels: one chain per segmenter)
+        for (int e = 0; e < n_jobs; e++) {
+            if (int r = enqueue_accumulate(ctx, &jobs[e], 1)) return r;
+            if (int r = cf_seg_infer(jobs[e].s, P, jobs[e].rgba, jobs[e].n_models, jobs[e].model_ids, jobs[e].next_model_id, jobs[e].allow_new, jobs[e].full_dev)) return r;
+        }
+        return CF_OK;
     }
-    SegPostArgs p;
-    memset(&p, 0, sizeof(p));
-    p.K = n; p.gx = s->gx; p.gy = s->gy; p.n_models = n_models; p.L = L; p.allow_new = allow_new ? 1 : 0;
-    p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.next_id = next_model_id;
-    p.minRelSizeNew = P->minRelSizeNew; p.maxRelSizeNew = P->maxRelSizeNew;
-    for (int m = 0; m < n_models; m++) p.ids[m] = model_ids[m];
-    if (allow_new) p.ids[n_models] = next_model_id;
-    p.Q = q; p.low_depth = s->low_mean; p.avg_conf = s->avg_conf; p.depth_range = s->depth_range;
-    p.parent = s->parent; p.comp = s->comp; p.cc = s->cc; p.low_map = s->low_map; p.result = s->d_result;
-    p.result_host = s->h_result; p.low_map_host = reinterpret_cast<unsigned*>(s->h_low_map);
-    seg_post_kernel<<<1, 1024, 0, st>>>(p);
-    const int N = ctx->cfg.width * ctx->cfg.height;
-    seg_upsample_kernel<<<(N + 255) / 256, 256, 0, st>>>(s->labels, s->low_map, N, full_dev);
-    LAUNCHCHK(ctx);
-    if (s->poses_published) {  // the tail now holds what the caller's all-reduce made of it; the next frame starts from zeros again
-        long long* tail = reinterpret_cast<long long*>(s->icp_sum) + 2 * (size_t)s->Lcap * s->K;
-        HIPCHK(ctx, hipMemcpyAsync(s->h_pose_tail, tail, sizeof(long long) * (size_t)s->Lcap * kPoseWords, hipMemcpyDeviceToHost, st));
+    for (int base = 0; base < n_jobs; base += kSegBatch) {
+        const int S = n_jobs - base < kSegBatch ? n_jobs - base : kSegBatch;
+        if (int r = enqueue_accumulate(ctx, &jobs[base], S)) return r;
+        if (int r = enqueue_infer<17, kSegBatch>(ctx, P, &jobs[base], S)) return r;
     }
     return CF_OK;
 }

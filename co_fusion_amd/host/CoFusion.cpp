@@ -388,13 +388,47 @@ void Segmentation::enqueueCRF(ModelList& models, const float* depth_dev, const u
         posesPublished = true;
         dist->sumDevice(ctx, sums_dev, words);  // exact: integer sums, every word has exactly one contributor
     }
+    const cf_seg_params P = deviceParams();
+    check(ctx, cf_seg_infer(seg, &P, rgba_dev, n_models, ids.data(), nextModelID, allowNew ? 1 : 0, full_dev), "cf_seg_infer");
+    pendingModels = n_models;
+}
+
+cf_seg_params Segmentation::deviceParams() const
+{
     cf_seg_params P{};
     P.unaryWeightError = unaryWeightError; P.unaryKError = unaryKError; P.unaryThresholdNew = unaryThresholdNew;
     P.weightAppearance = weightAppearance; P.weightSmoothness = weightSmoothness;
     P.scaleFeaturesRGB = scaleFeaturesRGB; P.scaleFeaturesDepth = scaleFeaturesDepth; P.scaleFeaturesPos = scaleFeaturesPos;
     P.minRelSizeNew = minRelSizeNew; P.maxRelSizeNew = maxRelSizeNew; P.crfIterations = (int)crfIterations;
-    check(ctx, cf_seg_infer(seg, &P, rgba_dev, n_models, ids.data(), nextModelID, allowNew ? 1 : 0, full_dev), "cf_seg_infer");
+    return P;
+}
+
+void Segmentation::collectCRF(ModelList& models, const float* depth_dev, const uint8_t* rgba_dev, unsigned char nextModelID, bool allowNew,
+                              uint8_t* full_dev, cf_seg_job& job)
+{
+    if (dist && dist->active()) throw std::runtime_error("Segmentation::collectCRF: batched segmentation is for single-process sequences");
+    const int n_models = (int)models.size();
+    if (!slicStarted) check(ctx, cf_seg_slic(seg, rgba_dev), "cf_seg_slic");  // otherwise enqueued by startSlic() beside the tracking
+    slicStarted = false;
+    jobIcp.resize(n_models); jobConf.resize(n_models); jobIds.resize(n_models);
+    int m = 0;
+    for (auto& mdl : models) {
+        jobIcp[m] = mdl->icpErrorSurface(); jobConf[m] = mdl->vertexConfProjection(); jobIds[m] = mdl->getID();
+        m++;
+    }
+    posesPublished = false;
+    job = cf_seg_job{};
+    job.seg = seg; job.depth = depth_dev; job.n_models = n_models; job.icp_err = jobIcp.data(); job.vertconf4 = jobConf.data();
+    job.rgba = rgba_dev; job.model_ids = jobIds.data(); job.next_model_id = nextModelID; job.allow_new = allowNew ? 1 : 0; job.full_dev = full_dev;
     pendingModels = n_models;
+}
+
+void Segmentation::runBatch(cf_ctx* ctx, const Segmentation& params, const std::vector<cf_seg_job>& jobs)
+{
+    if (jobs.empty()) return;
+    PhaseTimer pt(PhaseTimes::SegSlicAccumulate);
+    const cf_seg_params P = params.deviceParams();
+    check(ctx, cf_seg_run_batch(ctx, &P, jobs.data(), (int)jobs.size()), "cf_seg_run_batch");
 }
 
 bool Segmentation::fetchPublishedPoses(size_t nModels, std::vector<int64_t>& words)
@@ -1104,7 +1138,7 @@ void CoFusion::frameBegin(const FrameData& frame, const Mat4f* inPose, float wei
     }
 }
 
-void CoFusion::frameSegment(int lane)
+void CoFusion::frameSegment(std::vector<cf_seg_job>* jobs)
 {
     const FrameData& frame = *st.frame;
     const Mat4f* inPose = st.inPose;
@@ -1117,8 +1151,6 @@ void CoFusion::frameSegment(int lane)
         // cfg.maxModels models, at most 255 -- model ids are 8 bits and 255 marks a rejected superpixel (CoFusion.cpp:631-634)
         bool allowNew = false;
         const bool segOnDevice = cfg.enableMultipleModels && !frame.mask;
-        // (a sequence of a lock-step group puts its segmentation chain on a lane: the chains of the other sequences run beside it)
-        if (lane >= 0 && segOnDevice) check(ctx, cf_fork(ctx, lane), "cf_fork");
         if (cfg.enableMultipleModels) {
             if (spawnOffset < cfg.modelSpawnOffset) spawnOffset++;
             const size_t modelCap = (size_t)std::min(cfg.maxModels, 255);
@@ -1130,8 +1162,11 @@ void CoFusion::frameSegment(int lane)
         }
         // the motion segmentation reads device data only (ICP error surfaces, predictions): enqueued right behind the tracking
         // launches, so that poses AND segmentation decisions are collected by ONE host wait
-        if (segOnDevice) labelGenerator->enqueueCRF(models, curDepth, curRgba, getNextModelID(), allowNew, mask_dev);
-        if (lane >= 0 && segOnDevice) check(ctx, cf_main(ctx), "cf_main");
+        // (a sequence of a lock-step group only describes its chain: the group issues the chains of all sequences as ONE)
+        if (segOnDevice && jobs) {
+            jobs->emplace_back();
+            labelGenerator->collectCRF(models, curDepth, curRgba, getNextModelID(), allowNew, mask_dev, jobs->back());
+        } else if (segOnDevice) labelGenerator->enqueueCRF(models, curDepth, curRgba, getNextModelID(), allowNew, mask_dev);
         st.allowNew = allowNew; st.segOnDevice = segOnDevice;
     }
 }
@@ -1275,7 +1310,7 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
 {
     frameBegin(frame, inPose, weightMultiplier, bootstrap);
     if (st.willTrack) { PhaseTimer t(PhaseTimes::Track); trackModels(st.pyr); }
-    frameSegment(-1);
+    frameSegment(nullptr);
     frameCollect();
     frameFuse(true, 0);
     frameEnd();
@@ -1332,10 +1367,15 @@ void CoFusionGroup::stepAll(const FrameData* frames, const Mat4f* const* inPoses
         for (int s = 0; s < S; s++) if (seqs[s]->frameTracks()) seqs[s]->trackCollect(batch);
         CoFusion::trackLaunch(ctx, batch, cfg);
     }
-    // the segmentation chains of the multi-object sequences side by side on the lanes (each is ~35 launch-floor kernels: alone it
-    // leaves the GPU idle), one join, then ONE host wait for the poses and the decisions of all sequences
-    for (int s = 0; s < S; s++) seqs[s]->frameSegment(s % 6);
-    check(ctx, cf_join(ctx), "cf_join");
+    // the segmentation chains of the multi-object sequences as ONE chain of batched launches (each chain is ~30 launch-floor kernels:
+    // alone it leaves the GPU idle, and on lanes side by side the chains only stretched each other), then ONE host wait for the poses
+    // and the decisions of all sequences
+    {
+        std::vector<cf_seg_job> jobs;
+        jobs.reserve((size_t)S);
+        for (int s = 0; s < S; s++) seqs[s]->frameSegment(&jobs);
+        Segmentation::runBatch(ctx, seqs[0]->segmentation(), jobs);
+    }
     for (int s = 0; s < S; s++) seqs[s]->frameCollect();
     {   // the surfel passes of ALL sequences' models in one chain of batched launches
         PhaseTimer t(PhaseTimes::Fuse);

@@ -184,6 +184,12 @@ class Segmentation {
     void enqueueCRF(ModelList& models, const float* depth_dev, const uint8_t* rgba_dev, unsigned char nextModelID, bool allowNew,
                     uint8_t* fullSegmentation_dev);
     SegmentationResult finishCRF();
+    // ... of several sequences through shared launches (lock-step groups): collectCRF does what enqueueCRF does up to the launches and
+    // describes them as a job (its arrays live in this object until the next call), runBatch enqueues the jobs of all sequences in one
+    // chain (cf_seg_run_batch); finishCRF as usual.  Single-process sequences only.
+    void collectCRF(ModelList& models, const float* depth_dev, const uint8_t* rgba_dev, unsigned char nextModelID, bool allowNew,
+                    uint8_t* fullSegmentation_dev, cf_seg_job& job);
+    static void runBatch(cf_ctx* ctx, const Segmentation& params, const std::vector<cf_seg_job>& jobs);
     // model-parallel operation: enqueueCRF put every owner's tracked pose behind the sums it all-reduces; after the frame's host wait
     // this hands out [models][18] words (pose row-major, ICP error, ICP inlier count as f32 bit patterns).  false: nothing was published
     bool fetchPublishedPoses(size_t nModels, std::vector<int64_t>& words);
@@ -208,6 +214,9 @@ class Segmentation {
     int pendingModels = 0;        // models of the segmentation enqueueCRF left in flight
     bool posesPublished = false;  // ... which carries the owners' poses in its all-reduce
     float* zeroImage = nullptr;   // device zeros [H*W*4] standing in for the ICP error / confidence maps of shadow models
+    std::vector<const float*> jobIcp, jobConf;  // collectCRF's arrays
+    std::vector<uint32_t> jobIds;
+    cf_seg_params deviceParams() const;
 };
 
 class CoFusion {
@@ -296,7 +305,8 @@ class CoFusion {
     bool frameTracks() const { return st.willTrack; }
     void trackCollect(TrackBatch& batch) { trackCollect(batch, st.pyr); }
     static void trackLaunch(cf_ctx* ctx, TrackBatch& batch, const Config& cfg);
-    void frameSegment(int lane);   // segmentation enqueued (lane >= 0: on that lane of the context, beside other sequences' chains)
+    // segmentation enqueued (jobs != nullptr: described as a job for the group's shared launches instead -- Segmentation::runBatch)
+    void frameSegment(std::vector<cf_seg_job>* jobs);
     void frameCollect();           // the frame's host wait (poses + segmentation decisions), model bookkeeping
     void frameFuse(bool join, int laneOffset);
     // ... in two halves for a lock-step group: every sequence adds its models' passes to ONE batch (cf_models_frame_passes), the group

@@ -25,7 +25,7 @@ SYMBOLS = [
     "cf_bilateral", "cf_model_create", "cf_model_destroy", "cf_model_initialise", "cf_model_count",
     "cf_model_predict_indices", "cf_model_index_keys", "cf_model_index_resolve", "cf_model_combined_predict", "cf_model_prefetch_fill_ratio", "cf_model_perform_fill_in", "cf_model_requires_fill_in",
     "cf_model_fuse", "cf_model_clean", "cf_models_frame_passes", "cf_model_download_map", "cf_model_upload_map", "cf_model_buffer",
-    "cf_fusion_weight", "cf_seg_create", "cf_seg_destroy", "cf_seg_slic", "cf_seg_accumulate", "cf_seg_crf", "cf_seg_upsample", "cf_seg_sums", "cf_seg_infer", "cf_seg_fetch", "cf_seg_publish_poses", "cf_seg_fetch_poses",
+    "cf_fusion_weight", "cf_seg_create", "cf_seg_destroy", "cf_seg_slic", "cf_seg_accumulate", "cf_seg_crf", "cf_seg_upsample", "cf_seg_sums", "cf_seg_infer", "cf_seg_run_batch", "cf_seg_fetch", "cf_seg_publish_poses", "cf_seg_fetch_poses",
     "cf_seg_labels",
     "cf_depth_pyramid", "cf_set_icp_launch", "cf_set_icp_arith", "cf_get_icp_arith", "cf_set_gn_mode", "cf_profile_enable", "cf_profile_read", "cf_odom_bench_icp",
     "cf_rccl_unique_id", "cf_rccl_init", "cf_rccl_allreduce", "cf_rccl_broadcast", "cf_rccl_info", "cf_rccl_destroy",

@@ -398,6 +398,24 @@ int cf_seg_sums(cf_segmenter *s, const float *depth, int n_models, const float *
 int cf_seg_infer(cf_segmenter *s, const cf_seg_params *params, const uint8_t *rgba, int n_models, const uint32_t *model_ids,
                  uint32_t next_model_id, int allow_new, uint8_t *full_dev);
 int cf_seg_fetch(cf_segmenter *s, cf_seg_result *out, uint8_t *low_map_host);
+/* cf_seg_sums + cf_seg_infer of SEVERAL segmenters of one context -- the sequences of a lock-step group (the reference runs one
+ * performSegmentation per CoFusion instance, Segmentation.cpp:124-706) -- through shared launches: the chain of ~30 small kernels is
+ * issued once per 8 segmenters (all of one image size, <= 16 labels each; otherwise one chain per segmenter) instead of once per
+ * segmenter.  Per segmenter the results are those of the two single calls, bit for bit; each segmenter's decisions arrive with its
+ * own cf_seg_fetch.  Single-process callers only: no collective can sit between the sums and the inference. */
+typedef struct cf_seg_job {
+    cf_segmenter *seg;
+    const float *depth;                 /* cf_seg_sums' arguments */
+    int32_t n_models;
+    const float *const *icp_err;
+    const float *const *vertconf4;
+    const uint8_t *rgba;                /* cf_seg_infer's arguments */
+    const uint32_t *model_ids;
+    uint32_t next_model_id;
+    int32_t allow_new;
+    uint8_t *full_dev;
+} cf_seg_job;
+int cf_seg_run_batch(cf_ctx *ctx, const cf_seg_params *params, const cf_seg_job *jobs, int n_jobs);
 /* Model-parallel callers (one process per GPU, each tracking some of the models): the block cf_seg_sums hands out ends in a tail of
  * max_models x 18 words.  cf_seg_publish_poses (between cf_seg_sums and the caller's in-place SUM all-reduce of the block) writes there, for
  * every model tracked by THIS process (trackers[m] != NULL), the tracked pose (row-major 4x4) + ICP error + ICP inlier count as f32

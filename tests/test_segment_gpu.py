@@ -49,6 +49,15 @@ def _run_hip(ctx, seg, params, rgba, depth, ids, icp, vc, next_id, allow_new):
     return res, low.reshape(GY, GX), full.cpu().numpy()
 
 
+_REFS = {}
+
+
+def _ref(sc):  # the oracle's result of a scenario, shared by the tests of this module
+    if sc[0] not in _REFS:
+        _REFS[sc[0]] = om.segment_crf(sc[1], sc[2], sc[3], sc[4], sc[5], sc[6], sc[7], sc[8])
+    return _REFS[sc[0]]
+
+
 def _compare(name, res, low, full, ref):
     assert np.array_equal(low, ref["low"]), f"{name}: low-resolution labels differ in {np.count_nonzero(low != ref['low'])} superpixels"
     assert np.array_equal(full, ref["full"]), f"{name}: full-resolution mask"
@@ -129,8 +138,9 @@ def test_segmentation_stage_on_adversarial_label_images():
     seg = C.c_void_p()
     ctx._check(ctx.lib.cf_seg_create(ctx.h, C.byref(seg)))
     components = []
-    for name, params, rgba, depth, ids, icp, vcs, next_id, allow_new in _scenarios():
-        ref = om.segment_crf(params, rgba, depth, ids, icp, vcs, next_id, allow_new)
+    for sc in _scenarios():
+        name, params, rgba, depth, ids, icp, vcs, next_id, allow_new = sc
+        ref = _ref(sc)
         p = params.__class__.from_buffer_copy(params)
         for rep in range(2):  # twice: the kernels leave their accumulators clean for the next frame
             res, low, full = _run_hip(ctx, seg, p, rgba, depth, ids, icp, vcs, next_id, allow_new)
@@ -138,4 +148,56 @@ def test_segmentation_stage_on_adversarial_label_images():
         components.append(len(np.unique(ref["low"])))
     assert max(components) >= 2
     ctx.lib.cf_seg_destroy(seg)
+    ctx.close()
+
+
+class SegJob(C.Structure):
+    _fields_ = [("seg", C.c_void_p), ("depth", C.c_void_p), ("n_models", C.c_int32), ("icp_err", C.c_void_p), ("vertconf4", C.c_void_p),
+                ("rgba", C.c_void_p), ("model_ids", C.c_void_p), ("next_model_id", C.c_uint32), ("allow_new", C.c_int32), ("full_dev", C.c_void_p)]
+
+
+def test_batched_segmentation_of_several_segmenters_matches_the_oracle():
+    """cf_seg_run_batch: the chains of several segmenters of one context (the sequences of a lock-step group) through shared launches --
+    every scenario on a segmenter of its own, all of one parameter set in ONE call (more than eight: two chunks; a scenario with more
+    than 16 labels: the per-segmenter fallback), twice (clean accumulators), each against the oracle."""
+    from co_fusion_amd import api, synth
+    cam = synth.Camera.scaled(W, H)
+    ctx = api.Context(W, H, cam.fx, cam.fy, cam.cx, cam.cy, max_models=48)
+    ctx.lib.cf_seg_run_batch.restype = C.c_int
+    ctx.lib.cf_seg_run_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    groups = {}
+    for sc in _scenarios():
+        groups.setdefault(bytes(sc[1]), []).append(sc)
+    sizes = []
+    for key, scs in groups.items():
+        small = [sc for sc in scs if len(sc[4]) + (1 if sc[8] else 0) <= 16]
+        for batch in ([small, scs] if len(small) != len(scs) else [scs]):  # all-small: batched launches; with a big one: the fallback
+            sizes.append(len(batch))
+            segs, keep, jobs = [], [], (SegJob * len(batch))()
+            for k, (name, params, rgba, depth, ids, icp, vcs, next_id, allow_new) in enumerate(batch):
+                seg = C.c_void_p()
+                ctx._check(ctx.lib.cf_seg_create(ctx.h, C.byref(seg)))
+                segs.append(seg)
+                n = len(ids)
+                t = [ctx.to_device(rgba), ctx.to_device(depth), ctx.to_device(np.zeros((H, W), np.uint8))] + [ctx.to_device(a) for a in icp] + [ctx.to_device(a) for a in vcs]
+                icp_arr = (C.c_void_p * n)(*[x.data_ptr() for x in t[3:3 + n]])
+                vc_arr = (C.c_void_p * n)(*[x.data_ptr() for x in t[3 + n:]])
+                id_arr = (C.c_uint32 * n)(*ids)
+                keep.append((t, icp_arr, vc_arr, id_arr))
+                jobs[k] = SegJob(seg.value, t[1].data_ptr(), n, C.cast(icp_arr, C.c_void_p).value, C.cast(vc_arr, C.c_void_p).value,
+                                 t[0].data_ptr(), C.cast(id_arr, C.c_void_p).value, next_id, int(allow_new), t[2].data_ptr())
+            p = batch[0][1].__class__.from_buffer_copy(batch[0][1])
+            refs = [_ref(sc) for sc in batch]
+            for rep in range(2):
+                for k in range(len(batch)):
+                    ctx._check(ctx.lib.cf_seg_slic(segs[k], C.c_void_p(keep[k][0][0].data_ptr())))
+                ctx._check(ctx.lib.cf_seg_run_batch(ctx.h, C.byref(p), C.cast(jobs, C.c_void_p), len(batch)))
+                for k, sc in enumerate(batch):
+                    res = SegResult()
+                    low = np.zeros(GX * GY, np.uint8)
+                    ctx._check(ctx.lib.cf_seg_fetch(segs[k], C.byref(res), low.ctypes.data_as(C.c_void_p)))
+                    _compare(f"batched {sc[0]} (pass {rep}, {len(batch)} jobs)", res, low.reshape(GY, GX), keep[k][0][2].cpu().numpy(), refs[k])
+            for seg in segs:
+                ctx.lib.cf_seg_destroy(seg)
+    assert max(sizes) >= 2
     ctx.close()
