@@ -60,7 +60,6 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     if (int r = dmalloc(ctx, &ctx->d_state_pool, (size_t)cf_ctx::kStateSlots)) return r;
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state_pool), sizeof(OdomDev) * cf_ctx::kStateSlots, hipHostMallocCoherent));  // the last solve stores into it
     memset(ctx->h_state_pool, 0, sizeof(OdomDev) * cf_ctx::kStateSlots);
-    if (int r = dmalloc(ctx, &ctx->d_model_ptrs, (size_t)ctx->cfg.max_models + 1)) return r;
     if (int r = dmalloc(ctx, &ctx->d_so3_sync, (size_t)ctx->cfg.max_models + 1)) return r;
     // the ONE environment switch of the library: CF_ICP_ARITH = "product" (default) / "gram", the rounding specification of the ICP sums
     // for every context of the process (cf_set_icp_arith sets it per context; launch shape and data path have setters only)
@@ -71,7 +70,6 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     }
     if (int r = dmalloc(ctx, &ctx->d_cand_scratch, (size_t)cfg->width * cfg->height)) return r;
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scratch_state), sizeof(OdomDev)));
-    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_model_ptrs), sizeof(OdomDev*) * (ctx->cfg.max_models + 1)));
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_out), sizeof(unsigned long long) * 64));
     ctx->prof.capacity = 8192;
     ctx->prof.events = new hipEvent_t[ctx->prof.capacity];
@@ -88,9 +86,9 @@ void cf_destroy(cf_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     (void)cf_rccl_destroy(ctx);
     (void)hipFree(ctx->d_acc_a); (void)hipFree(ctx->d_acc_b); (void)hipFree(ctx->d_out);
-    (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_model_ptrs); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_cand_scratch);
+    (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_cand_scratch);
     (void)hipFree(ctx->d_state_pool); (void)hipHostFree(ctx->h_state_pool);
-    (void)hipHostFree(ctx->h_scratch_state); (void)hipHostFree(ctx->h_model_ptrs); (void)hipHostFree(ctx->h_out);
+    (void)hipHostFree(ctx->h_scratch_state); (void)hipHostFree(ctx->h_out);
     if (ctx->prof.events) {
         for (int i = 0; i < ctx->prof.capacity; i++) (void)hipEventDestroy(ctx->prof.events[i]);
         delete[] ctx->prof.events;
@@ -393,8 +391,6 @@ static int scratch_begin(cf_ctx* ctx, int cols, int rows)
 static int scratch_commit(cf_ctx* ctx)
 {
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_scratch_state, ctx->h_scratch_state, sizeof(OdomDev), hipMemcpyHostToDevice, ctx->stream));
-    ctx->h_model_ptrs[0] = ctx->d_scratch_state;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_model_ptrs, ctx->h_model_ptrs, sizeof(OdomDev*), hipMemcpyHostToDevice, ctx->stream));
     return CF_OK;
 }
 static int fetch_totals(cf_ctx* ctx, const unsigned long long* acc, int words)
@@ -923,25 +919,13 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
         if (base) prep = RgbPrepBatch{};
         for (int m = base; m < base + nb; m++) {
             if (int r = odom_prepare(ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr, &prep.m[m - base])) return r;
-            ctx->h_model_ptrs[m] = ods[m]->d_state;
         }
         if (want_rgb && !prep_fused) launch_rgb_prep(ctx->stream, prep, nb, ctx->cfg.width, ctx->cfg.height);
     }
     if (prep_fused) rgb_prep_levels(prep, n, ctx->cfg.width, ctx->cfg.height);
-    // state upload: one copy over the slot range when every tracker of the batch lives in the pool (the host copies of
-    // other trackers in the range equal their device copies: both are only written by a tracking call + its read-back)
-    int lo = cf_ctx::kStateSlots, hi = -1;
-    for (int m = 0; m < n; m++) {
-        if (ods[m]->slot < 0) { lo = -1; break; }
-        lo = ods[m]->slot < lo ? ods[m]->slot : lo; hi = ods[m]->slot > hi ? ods[m]->slot : hi;
-    }
-    if (lo >= 0) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_state_pool + lo, ctx->h_state_pool + lo, sizeof(OdomDev) * (hi - lo + 1), hipMemcpyHostToDevice, ctx->stream));
-    } else {
-        for (int m = 0; m < n; m++)
-            HIPCHK(ctx, hipMemcpyAsync(ods[m]->d_state, ods[m]->h_state, sizeof(OdomDev), hipMemcpyHostToDevice, ctx->stream));
-    }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_model_ptrs, ctx->h_model_ptrs, sizeof(OdomDev*) * n, hipMemcpyHostToDevice, ctx->stream));
+    // (no state upload here: the first launch of the schedule reads the pinned host states itself -- so3_prealign_kernel)
+    TrackerStates states{};
+    for (int m = 0; m < n; m++) { states.dev[m] = ods[m]->d_state; states.host[m] = ods[m]->h_state; }
     const bool so3_here = opts->so3 != 0;
     const bool icp = !opts->rgb_only && opts->icp_weight > 0;
     const bool rgb = opts->rgb_only || opts->icp_weight < 100;
@@ -961,7 +945,7 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     // host time (static 640x480: 1275 frames/s without, 1210 with events on every call), sampling keeps the figure and the cost apart
     cf::ProfSink* prof = nullptr;
     if (ctx->prof.enabled > 0 && (ctx->prof_calls++ % (unsigned)ctx->prof.enabled) == 0) prof = &ctx->prof;
-    if (!launch_gn_track(ctx->stream, ctx->icp_launch, ctx->d_model_ptrs, ctx->d_so3_sync, any_split ? &hook : nullptr, icp_args, rgb_args, n,
+    if (!launch_gn_track(ctx->stream, ctx->icp_launch, states, ctx->d_so3_sync, any_split ? &hook : nullptr, icp_args, rgb_args, n,
                          ctx->cfg.width, ctx->cfg.height, so3_here, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, prof, h_states,
                          prep_fused ? &prep : nullptr)) {
         ctx->set_error("tracking: the registered collective failed inside the Gauss-Newton loop");

@@ -27,8 +27,6 @@ struct cf_ctx {
     unsigned long long* h_out = nullptr;  // pinned
     cf::OdomDev* d_scratch_state = nullptr;
     cf::OdomDev* h_scratch_state = nullptr;  // pinned
-    cf::OdomDev** d_model_ptrs = nullptr;
-    cf::OdomDev** h_model_ptrs = nullptr;  // pinned
     uint8_t* d_cand_scratch = nullptr;
     cf::So3Sync* d_so3_sync = nullptr;  // [max_models]
     int gn_mode = 1;                    // launch_gn_track mode (1: record slots between the residual pass and the RGB step)

@@ -255,7 +255,9 @@ struct So3Sync { unsigned long long acc[10][16]; unsigned arrive, depart; };
 // hook: called after every {ICP || residual} launch for each model whose reduction is split over GPUs (split[m] != 0) with that
 // model's grouped ICP accumulators (kGroups * 32 words): the caller's in-place SUM all-reduce over the ranks, enqueued on `s`
 struct GnHook { int (*fn)(void* user, int op, void* dev_buf, uint64_t words, void* stream); void* user; int split[kMaxBatch]; };
-bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models /* device array of n pointers */, So3Sync* so3_syncs /* [n] */,
+// the trackers of a lock-step schedule: device states and the pinned host copies the first launch uploads them from
+struct TrackerStates { OdomDev* dev[kMaxBatch]; const OdomDev* host[kMaxBatch]; };
+bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, So3Sync* so3_syncs /* [n] */,
                      const GnHook* hook, const IcpArgs icp_args[3], const RgbArgs rgb_args[3], int n, int width, int height, bool so3,
                      bool pyramid, bool fast_odom, bool rgb, bool icp, int mode, ProfSink* prof,
                      OdomDev* const* h_states = nullptr /* [n] pinned host copies the last solve publishes to */,

@@ -865,7 +865,11 @@ __device__ __forceinline__ unsigned long long l2_read_u64(unsigned long long* p)
 // The launch is one-dimensional: [gx workgroups per model of the pre-alignment | prep_bx workgroups per model of the RGB preparation
 // (Sobel + candidate mask + cloud: rgb_prep_body)].  The two read the same pyramids and depend on nothing of each other; the
 // pre-alignment is a latency chain on 16 workgroups per model, the preparation fills the rest of the chip meanwhile.
-__global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __restrict__ models, So3Sync* __restrict__ syncs, int do_so3,
+//
+// The tracker state of the call arrives here as well: the host fills its pinned copy, every pre-alignment workgroup stages that copy into
+// LDS (one coalesced read over PCIe, hidden beside the preparation workgroups) and the lead workgroup of each tracker stores it into the
+// device state the rest of the schedule reads -- no copy command in front of the loop (two of them cost ~10 us on the stream per frame).
+__global__ void __launch_bounds__(256) so3_prealign_kernel(const TrackerStates ts, So3Sync* __restrict__ syncs, int do_so3,
                                                            int first_level, int gx, int so3_blocks, const RgbPrepBatch prep, int prep_bx)
 {
     if ((int)blockIdx.x >= so3_blocks) {
@@ -874,8 +878,9 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
         return;
     }
     const int by = (int)blockIdx.x / gx, bxx = (int)blockIdx.x - by * gx;  // gx is 1 or a multiple of 8: bxx mod 8 is the XCD
-    OdomDev* od = models[by];
+    OdomDev* const god = ts.dev[by];
     So3Sync* sync = syncs + by;
+    __shared__ OdomDev s_od;
     __shared__ unsigned long long lds[16][16];
     __shared__ unsigned long long totals[16];
     __shared__ float s_basis[9], s_kinv[9], s_krlr[9];
@@ -887,20 +892,30 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
     __shared__ double s_lastResultR[9];
     __shared__ float s_jtj[9], s_jtr[3], s_delta[3], s_fws[15];
     __shared__ int s_iws[3];
-    const int L = 2, cols = od->width >> L, rows = od->height >> L;
     // with the pre-alignment the launch is 8 x kSo3Blocks wide: this model's workgroups are the ones on XCD (model mod 8)
     const bool one_xcd = do_so3 && gx > 1;
     if (one_xcd && (bxx & 7) != (by & 7)) return;
     const int bx = one_xcd ? (bxx >> 3) : bxx;
-    const bool lead = bx == 0;  // the workgroup that publishes statistics and the final state
+    const bool lead = bx == 0;  // the workgroup that uploads the state, publishes statistics and the final state
     const unsigned G = one_xcd ? (unsigned)gx >> 3 : (unsigned)gx;
+    {
+        static_assert(sizeof(OdomDev) % 4 == 0, "OdomDev is staged as 32-bit words");
+        constexpr int kWords = (int)(sizeof(OdomDev) / 4);
+        const unsigned* __restrict__ src = reinterpret_cast<const unsigned*>(ts.host[by]);
+        for (int k = threadIdx.x; k < kWords; k += 256) reinterpret_cast<unsigned*>(&s_od)[k] = src[k];
+        __syncthreads();
+        if (lead) for (int k = threadIdx.x; k < kWords; k += 256) reinterpret_cast<unsigned*>(god)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
+        __syncthreads();  // (the lead's later stores into the device state follow the upload)
+    }
+    const OdomDev* const od = &s_od;  // what the host passed; results go to the device state (god)
+    const int L = 2, cols = od->width >> L, rows = od->height >> L;
     if (threadIdx.x == 0) {
         for (int k = 0; k < 9; k++) { s_resultR[k] = (k % 4 == 0) ? 1.0 : 0.0; s_lastResultR[k] = s_resultR[k]; s_Rlr[k] = (k % 4 == 0) ? 1.f : 0.f; }
         k_matrix(cam_level(od->intr, L), s_K);
         inv33<double>(s_K, s_Kinv);
         s_lastError = 3.402823466e+38F / 2; s_lastCount = 3.402823466e+38F / 2;
         s_done = 0;
-        if (lead) { od->stats.so3_iterations = 0; od->stats.last_so3_error = 0; od->stats.last_so3_count = 0; }
+        if (lead) { god->stats.so3_iterations = 0; god->stats.last_so3_error = 0; god->stats.last_so3_count = 0; }
     }
     __syncthreads();
     if (do_so3) {
@@ -928,7 +943,7 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
                         const unsigned target = (unsigned)(it + 1) * G;
                         unsigned spins = 0;
                         while (l2_read_u32(&sync->arrive) < target) {
-                            if (++spins > (1u << 22)) { od->stats.fault = 1; break; }  // never hang the GPU; the host reports CF_ESTATE
+                            if (++spins > (1u << 22)) { god->stats.fault = 1; break; }  // never hang the GPU; the host reports CF_ESTATE
                             __builtin_amdgcn_s_sleep(1);
                         }
                     }
@@ -940,7 +955,7 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
             if (threadIdx.x == 0) {
                 float jtj[9], jtr[3], residual[2];
                 so3_unpack(totals, jtj, jtr, residual);
-                if (lead) od->stats.so3_iterations = it + 1;
+                if (lead) god->stats.so3_iterations = it + 1;
                 float err = sqrtf(residual[0]) / residual[1];
                 float cnt = residual[1];
                 if (err < s_lastError && (double)fabsf(s_lastError - cnt) < 0.001) {
@@ -964,7 +979,7 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
                     mul33<float>(ru, s_Rlr, nr);
                     for (int k = 0; k < 9; k++) { s_Rlr[k] = nr[k]; s_resultR[k] = nr[k]; }
                 }
-                if (lead) { od->stats.last_so3_error = err; od->stats.last_so3_count = cnt; }
+                if (lead) { god->stats.last_so3_error = err; god->stats.last_so3_count = cnt; }
             }
             __syncthreads();
             if (s_done) break;
@@ -991,20 +1006,20 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(OdomDev* const* __res
         float zb[2] = {-__int_as_float(0x7f800000), __int_as_float(0x7f800000)};
         if (od->cull) screen_box(lo, hi, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, lane, ib, zb);
         if (lane == 0) {
-            for (int k = 0; k < 3; k++) { od->box_lo[k] = lo[k]; od->box_hi[k] = hi[k]; }
-            for (int k = 0; k < 4; k++) od->stats.cull_box[k] = ib[k];
-            od->cull_z[0] = zb[0]; od->cull_z[1] = zb[1];
+            for (int k = 0; k < 3; k++) { god->box_lo[k] = lo[k]; god->box_hi[k] = hi[k]; }
+            for (int k = 0; k < 4; k++) god->stats.cull_box[k] = ib[k];
+            god->cull_z[0] = zb[0]; god->cull_z[1] = zb[1];
         }
     }
     if (lead && threadIdx.x == 0) {
-        for (int k = 0; k < 16; k++) od->resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+        for (int k = 0; k < 16; k++) god->resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
         if (do_so3)
             for (int x = 0; x < 3; x++)
-                for (int y = 0; y < 3; y++) od->resultRt[x * 4 + y] = s_resultR[x * 3 + y];
-        od->lastRGBError = 3.402823466e+38F;
-        od->level_done = 0;
-        od->residual[0] = 0; od->residual[1] = 0;
-        prepare_iteration(od, first_level);
+                for (int y = 0; y < 3; y++) god->resultRt[x * 4 + y] = s_resultR[x * 3 + y];
+        god->lastRGBError = 3.402823466e+38F;
+        god->level_done = 0;
+        god->residual[0] = 0; god->residual[1] = 0;
+        prepare_iteration(god, first_level);
     }
 }
 
@@ -1359,7 +1374,7 @@ void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, 
 // grid barrier, a chain of about five device-scope memory round trips of ~1.5 us each across the XCDs, whereas a dependent
 // launch costs ~2.5 us (tools/microbench/launch_floor.hip).  On this part the kernel boundary IS the cheapest grid barrier.
 // Kept as separate launches.
-bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3Sync* so3_syncs, const GnHook* hook, const IcpArgs icp_args[3],
+bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, So3Sync* so3_syncs, const GnHook* hook, const IcpArgs icp_args[3],
                      const RgbArgs rgb_args[3], int n, int width, int height, bool so3, bool pyramid, bool fast_odom, bool rgb, bool icp, int mode,
                      ProfSink* prof, OdomDev* const* h_states, const RgbPrepBatch* prep)
 {
@@ -1373,7 +1388,7 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, OdomDev* const* d_models, So3
         const int gx = so3 ? 8 * kSo3Blocks : 1;  // (8x: one XCD per model)
         static const RgbPrepBatch none{};
         const int prep_bx = prep ? prep->m[0].L.blk_end[2] : 0;
-        so3_prealign_kernel<<<gx * n + prep_bx * n, 256, 0, s>>>(d_models, so3_syncs, so3 ? 1 : 0, first_level, gx, gx * n, prep ? *prep : none, prep_bx);
+        so3_prealign_kernel<<<gx * n + prep_bx * n, 256, 0, s>>>(states, so3_syncs, so3 ? 1 : 0, first_level, gx, gx * n, prep ? *prep : none, prep_bx);
     }
     GnArgs gn{};
     gn.icp_gram = cfg.gram;
