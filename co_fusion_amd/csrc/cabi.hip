@@ -677,9 +677,22 @@ int cf_odom_init_models_batch(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
 int cf_odom_init_models_batch_frames(cf_ctx* ctx, cf_odom* const* ods, int n, const float* const* pred_v4, const float* const* pred_n4,
                                      const uint8_t* const* pred_rgba, const float* const* poses, const uint8_t* const* frame_rgba)
 {
+    return cf_odom_init_models_batch_select(ctx, ods, n, pred_v4, pred_n4, pred_rgba, nullptr, nullptr, nullptr, nullptr, 0.f, poses, frame_rgba);
+}
+
+// ... and with the fill-in decision of every tracker taken by the kernels (see the header): no host wait for the previous frame
+int cf_odom_init_models_batch_select(cf_ctx* ctx, cf_odom* const* ods, int n, const float* const* pred_v4, const float* const* pred_n4,
+                                     const uint8_t* const* pred_rgba, const float* const* alt_v4, const float* const* alt_n4,
+                                     const uint8_t* const* alt_rgba, const uint32_t* const* fill_counts, float ratio,
+                                     const float* const* poses, const uint8_t* const* frame_rgba)
+{
     if (!ctx || !ods || n <= 0 || !pred_v4 || !pred_n4 || !pred_rgba || !poses || !frame_rgba) return CF_EINVAL;
+    const bool choose = alt_v4 && alt_n4 && alt_rgba && fill_counts;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
     if (W % 4 || H % 4) {
+        if (choose)
+            for (int k = 0; k < n; k++)
+                if (fill_counts[k]) { ctx->set_error("cf_odom_init_models_batch_select: the device-side choice needs width and height to be multiples of 4"); return CF_EINVAL; }
         for (int k = 0; k < n; k++) {
             if (int r = cf_odom_init_icp_model(ods[k], pred_v4[k], pred_n4[k], poses[k])) return r;
             if (int r = cf_odom_init_rgb_model(ods[k], pred_rgba[k])) return r;
@@ -698,6 +711,11 @@ int cf_odom_init_models_batch_frames(cf_ctx* ctx, cf_odom* const* ods, int n, co
             mb.m[k] = model_maps_args(od, pred_v4[base + k], pred_n4[base + k], poses[base + k]);
             rb.c[2 * k] = rgbd_chain(od, pred_rgba[base + k], od->lastDepth, od->lastImage);   // initRGBModel
             rb.c[2 * k].v4 = pred_v4[base + k];  // (the snapshot vmaps_tmp is written by the same launch: read the prediction it copies)
+            if (choose && fill_counts[base + k]) {
+                if (!alt_v4[base + k] || !alt_n4[base + k] || !alt_rgba[base + k]) return CF_EINVAL;
+                mb.m[k].alt_v4 = alt_v4[base + k]; mb.m[k].alt_n4 = alt_n4[base + k]; mb.m[k].sel = fill_counts[base + k]; mb.m[k].sel_ratio = ratio;
+                rb.c[2 * k].alt_v4 = alt_v4[base + k]; rb.c[2 * k].alt_rgba = alt_rgba[base + k]; rb.c[2 * k].sel = fill_counts[base + k]; rb.c[2 * k].sel_ratio = ratio;
+            }
             rb.c[2 * k + 1] = rgbd_chain(od, frame_rgba[base + k], od->nextDepth, od->nextImage);        // initRGB
             // ... whose depth pyramid would be a second copy of the first chain's (same source, same cutoff): intensity only
             for (int i = 0; i < CF_NUM_PYRS; ++i) rb.c[2 * k + 1].depth[i] = nullptr;

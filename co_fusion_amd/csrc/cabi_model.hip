@@ -372,6 +372,13 @@ int cf_model_requires_fill_in(cf_model* m, float ratio, int* out)
     return CF_OK;
 }
 
+int cf_model_fill_ratio_device(cf_model* m, const uint32_t** counts_dev)
+{
+    if (!m || !counts_dev) return CF_EINVAL;
+    *counts_dev = m->ratio_valid ? m->d_tmp2 + 2 : nullptr;
+    return CF_OK;
+}
+
 // Model::fuse (Model.cpp:408-563).  Needs cf_model_predict_indices for the same pose first.
 int cf_model_fuse(cf_model* m, const float pose[16], int time, const uint8_t* rgba, const uint8_t* mask, const float* depth_raw,
                   const float* depth_filt, float maxDepth, float weighting, int maskID)

@@ -92,6 +92,8 @@ struct RgbPrepArgs {
 };
 struct ModelMapsArgs {
     const float* pred_v4; const float* pred_n4;  // RGBA32F prediction (vertex+conf, normal+radius)
+    const float* alt_v4; const float* alt_n4;    // ... replaced by these when (float)sel[0] / (float)sel[1] < sel_ratio (sel nullable: no choice)
+    const unsigned* sel; float sel_ratio;
     float* snapshot;                             // copy of pred_v4 kept by the tracker (RGBDOdometry::vmaps_tmp)
     float* vmap[3]; float* nmap[3];
     int cols, rows;
@@ -104,7 +106,10 @@ struct ModelMapsArgs {
 constexpr int kPrepBatch = 8;
 struct ModelMapsBatch { ModelMapsArgs m[kPrepBatch]; };
 struct RgbPrepBatch { RgbPrepArgs m[kPrepBatch]; };
-struct RgbdChain { const float* v4; const uint8_t* rgba; float* depth[3]; uint8_t* image[3]; };  // verticesToDepth + intensity + pyramids
+struct RgbdChain {  // verticesToDepth + intensity + pyramids
+    const float* v4; const uint8_t* rgba; float* depth[3]; uint8_t* image[3];
+    const float* alt_v4; const uint8_t* alt_rgba; const unsigned* sel; float sel_ratio;  // the choice of ModelMapsArgs
+};
 struct RgbdBatch { RgbdChain c[2 * kPrepBatch]; };
 void launch_model_maps(hipStream_t s, const ModelMapsBatch& b, int n);  // needs cols % 4 == 0 && rows % 4 == 0
 void launch_frame_maps(hipStream_t s, FrameMapsArgs a, int W, int H);

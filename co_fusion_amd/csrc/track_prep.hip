@@ -223,8 +223,9 @@ __global__ void __launch_bounds__(kBlock) pyrdown_u8_kernel(const uint8_t* __res
 __device__ __forceinline__ void rgbd_base_body(const RgbdBatch& b, int N, float cutoff, int bx, int by)
 {
     const RgbdChain& c = b.c[by];  // one (depth, intensity) chain per grid row: models x {prediction, frame}
-    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(c.v4);
-    const uchar4* __restrict__ rgba = reinterpret_cast<const uchar4*>(c.rgba);
+    const bool alt = c.sel && (float)c.sel[0] / (float)c.sel[1] < c.sel_ratio;  // (CoFusion::requiresFillIn, decided here: cf_kernels.h)
+    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(alt ? c.alt_v4 : c.v4);
+    const uchar4* __restrict__ rgba = reinterpret_cast<const uchar4*>(alt ? c.alt_rgba : c.rgba);
     const int nb = (N + kBlock - 1) / kBlock;
     if (bx < nb) {  // verticesToDepthKernel, cudafuncs.cu:602-613
         const int i = bx * kBlock + threadIdx.x;
@@ -425,8 +426,9 @@ __global__ void __launch_bounds__(64) model_maps_kernel(const ModelMapsBatch b)
     bool any_valid = false;  // does this thread's 4x4 block hold any predicted surface?
     const int Y2 = t / c2, X2 = t - Y2 * c2;
     const int cols = a.cols, rows = a.rows, N0 = cols * rows, c1 = cols >> 1, N1 = N0 >> 2, N2 = N0 >> 4;
-    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(a.pred_v4);
-    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(a.pred_n4);
+    const bool alt = a.sel && (float)a.sel[0] / (float)a.sel[1] < a.sel_ratio;
+    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(alt ? a.alt_v4 : a.pred_v4);
+    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(alt ? a.alt_n4 : a.pred_n4);
     float4* __restrict__ snap = reinterpret_cast<float4*>(a.snapshot);
     m33 R; for (int k = 0; k < 9; k++) R.m[k] = a.R[k];
     const f3 tr = {a.t[0], a.t[1], a.t[2]};
@@ -484,8 +486,9 @@ __device__ __forceinline__ void model_maps_tiled_body(const ModelMapsBatch& b, i
     if (tile >= tiles_x * (rows >> 2)) return;  // whole waves leave
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x = tx * 16 + lx, y = ty * 4 + ly, i0 = y * cols + x;
-    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(a.pred_v4);
-    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(a.pred_n4);
+    const bool alt = a.sel && (float)a.sel[0] / (float)a.sel[1] < a.sel_ratio;  // (CoFusion::requiresFillIn, decided here: cf_kernels.h)
+    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(alt ? a.alt_v4 : a.pred_v4);
+    const float4* __restrict__ n4 = reinterpret_cast<const float4*>(alt ? a.alt_n4 : a.pred_n4);
     float4* __restrict__ snap = reinterpret_cast<float4*>(a.snapshot);
     m33 R; for (int k = 0; k < 9; k++) R.m[k] = a.R[k];
     const f3 tr = {a.t[0], a.t[1], a.t[2]};

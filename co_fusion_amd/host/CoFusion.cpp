@@ -249,6 +249,13 @@ bool Model::requiresFillIn(float ratio)
     check(ctx, cf_model_requires_fill_in(model, ratio, &out), "requiresFillIn");
     return out != 0;
 }
+const uint32_t* Model::fillRatioDevice() const
+{
+    if (!allowsFillIn() || !owned) return nullptr;
+    const uint32_t* counts = nullptr;
+    check(ctx, cf_model_fill_ratio_device(model, &counts), "fill_ratio_device");
+    return counts;
+}
 std::vector<float> Model::downloadMap() const
 {
     if (!owned) return {};
@@ -993,7 +1000,15 @@ void CoFusion::trackCollect(TrackBatch& batch, const float* const depthPyr[3])
         TrackBatch::Item it;
         it.model = m.get(); it.owner = owner; it.frameRgba = curRgba; it.maxDepth = maxDepthProcessed;
         for (int l = 0; l < 3; l++) it.depthPyr[l] = depthPyr[l];
-        m->trackingInputs(m->requiresFillIn(), cfg.frameToFrameRGB, it.predV, it.predN, it.predImg);
+        // CoFusion::requiresFillIn (CoFusion.cpp:547-565) asks about the previous frame's last prediction.  Answering it here would make
+        // the host wait for that frame to drain before this one can be enqueued; with the counts prefetched the preparation kernels
+        // take the decision themselves and get both sets of inputs.
+        it.altV = nullptr; it.altN = nullptr; it.altImg = nullptr;
+        it.fillCounts = (cfg.width % 4 == 0 && cfg.height % 4 == 0) ? m->fillRatioDevice() : nullptr;
+        if (it.fillCounts) {
+            m->trackingInputs(false, cfg.frameToFrameRGB, it.predV, it.predN, it.predImg);
+            m->trackingInputs(true, cfg.frameToFrameRGB, it.altV, it.altN, it.altImg);
+        } else m->trackingInputs(m->requiresFillIn(), cfg.frameToFrameRGB, it.predV, it.predN, it.predImg);
         batch.items.push_back(it);
         trackPending.push_back(m.get());
     }
@@ -1005,12 +1020,14 @@ void CoFusion::trackLaunch(cf_ctx* ctx, TrackBatch& batch, const Config& cfg)
     if (n == 0) return;
     // Model::initICP of every model (initICPModel + initRGBModel + initICP + initRGB), batched: one launch per preparation kernel for
     // all models of the batch
-    std::vector<cf_odom*> ods; std::vector<const float*> pv, pn, pp; std::vector<const uint8_t*> pi, fr;
+    std::vector<cf_odom*> ods; std::vector<const float*> pv, pn, pp, av, an; std::vector<const uint8_t*> pi, fr, ai; std::vector<const uint32_t*> fc;
     for (auto& it : batch.items) {
         ods.push_back(it.model->odom); pv.push_back(it.predV); pn.push_back(it.predN); pi.push_back(it.predImg); pp.push_back(it.model->pose.m);
         fr.push_back(it.frameRgba);
+        av.push_back(it.altV); an.push_back(it.altN); ai.push_back(it.altImg); fc.push_back(it.fillCounts);
     }
-    check(ctx, cf_odom_init_models_batch_frames(ctx, ods.data(), (int)n, pv.data(), pn.data(), pi.data(), pp.data(), fr.data()), "init_models_batch");
+    check(ctx, cf_odom_init_models_batch_select(ctx, ods.data(), (int)n, pv.data(), pn.data(), pi.data(), av.data(), an.data(), ai.data(), fc.data(),
+                                                0.75f /* Model::requiresFillIn's default ratio */, pp.data(), fr.data()), "init_models_batch");
     for (auto& it : batch.items) it.model->bindFrameMaps(it.depthPyr, it.maxDepth, it.owner);
     cf_track_opts opts{};
     opts.rgb_only = cfg.rgbOnly; opts.pyramid = cfg.pyramid; opts.fast_odom = cfg.fastOdom; opts.so3 = cfg.so3; opts.icp_weight = cfg.icpWeight;

@@ -122,6 +122,9 @@ class Model {
     void combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta);
     void performFillIn(const uint8_t* rgba, const float* depthFiltered, bool frameToFrameRGB, bool lost);
     bool requiresFillIn(float ratio = 0.75f);
+    // the same question left to the kernels that prepare the tracking (cf_odom_init_models_batch_select): device address of the counts
+    // the last prefetchFillRatio() left, nullptr when this model never fills in or nothing was prefetched.  Never waits.
+    const uint32_t* fillRatioDevice() const;
     void prefetchFillRatio();
     bool allowsFillIn() const { return fillIn; }
     std::vector<float> downloadMap() const;  // count x 12 floats
@@ -298,7 +301,9 @@ class CoFusion {
     // ---- the stages of processFrame (see CoFusion.cpp); CoFusionGroup runs them stage by stage over its sequences ----
     struct TrackBatch {   // the trackers of one set of lock-step launches: the owned models of one frame, or of several sequences' frames
         struct Item { Model* model; Model* owner; const float* depthPyr[3]; const uint8_t* frameRgba; float maxDepth;
-                      const float* predV; const float* predN; const uint8_t* predImg; };
+                      const float* predV; const float* predN; const uint8_t* predImg;
+                      // the fill-in flavour of the three and the device counts that decide between them (fillCounts == nullptr: no choice)
+                      const float* altV; const float* altN; const uint8_t* altImg; const uint32_t* fillCounts; };
         std::vector<Item> items;
     };
     void frameBegin(const FrameData& frame, const Mat4f* inPose, float weightMultiplier, bool bootstrap);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "cf_transform_maps", "cf_vertices_to_depth", "cf_pyrdown_gauss_f32", "cf_pyrdown_gauss_u8",
     "cf_rgba_to_intensity", "cf_sobel", "cf_project_cloud", "cf_icp_step", "cf_icp_step_band", "cf_rgb_residual", "cf_rgb_step",
     "cf_so3_step", "cf_odom_create", "cf_odom_destroy", "cf_odom_init_icp_model", "cf_odom_init_rgb_model",
-    "cf_odom_init_rgb", "cf_odom_init_models_batch", "cf_odom_init_models_batch_frames", "cf_odom_init_first_rgb", "cf_odom_init_icp", "cf_odom_get_incremental_transformation",
+    "cf_odom_init_rgb", "cf_odom_init_models_batch", "cf_odom_init_models_batch_frames", "cf_odom_init_models_batch_select", "cf_model_fill_ratio_device", "cf_odom_init_first_rgb", "cf_odom_init_icp", "cf_odom_get_incremental_transformation",
     "cf_odom_track_batch_async", "cf_odom_fetch_result", "cf_odom_get_covariance", "cf_odom_bind_frame_maps", "cf_odom_share_frame_maps", "cf_odom_set_culling", "cf_odom_set_band", "cf_set_collective", "cf_model_predict_indices_sharded", "cf_odom_buffer",
     "cf_bilateral", "cf_model_create", "cf_model_destroy", "cf_model_initialise", "cf_model_count",
     "cf_model_predict_indices", "cf_model_index_keys", "cf_model_index_resolve", "cf_model_combined_predict", "cf_model_prefetch_fill_ratio", "cf_model_perform_fill_in", "cf_model_requires_fill_in",

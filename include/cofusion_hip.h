@@ -224,6 +224,17 @@ int cf_odom_init_models_batch(cf_ctx *ctx, cf_odom *const *ods, int n, const flo
 int cf_odom_init_models_batch_frames(cf_ctx *ctx, cf_odom *const *ods, int n, const float *const *pred_vertex4,
                                      const float *const *pred_normal4, const uint8_t *const *pred_rgba, const float *const *poses /* n x [16] */,
                                      const uint8_t *const *frame_rgba /* n */);
+/* ... and with the choice between two sets of predictions per tracker made ON THE DEVICE: Model::initICP (Model.cpp:350-367) tracks against
+ * the fill-in images when CoFusion::requiresFillIn (CoFusion.cpp:547-565) says so, and that answer comes from a count over the
+ * previous frame's last prediction -- a host that asks for it (cf_model_requires_fill_in) has to wait for the previous frame to
+ * drain before it can enqueue this one.  Here tracker k uses alt_*[k] instead of pred_*[k] when
+ * (float)counts[0] / (float)counts[1] < ratio with counts = fill_counts[k] (device, from cf_model_fill_ratio_device; the very
+ * expression of cf_model_requires_fill_in); fill_counts[k] == NULL (or the arrays NULL): no choice, pred_*[k]. */
+int cf_odom_init_models_batch_select(cf_ctx *ctx, cf_odom *const *ods, int n, const float *const *pred_vertex4,
+                                     const float *const *pred_normal4, const uint8_t *const *pred_rgba,
+                                     const float *const *alt_vertex4, const float *const *alt_normal4, const uint8_t *const *alt_rgba,
+                                     const uint32_t *const *fill_counts, float ratio, const float *const *poses /* n x [16] */,
+                                     const uint8_t *const *frame_rgba /* n */);
 /* initICP(depthPyramid, maskPyramid, depthCutoff) :48-49 (frame -> model); the mask pyramid is dead in the
  * reference (cudafuncs.cu:119) and therefore not part of the ABI */
 int cf_odom_init_icp(cf_odom *od, const float *const depth_pyr[CF_NUM_PYRS], float depth_cutoff);
@@ -314,6 +325,9 @@ int cf_model_perform_fill_in(cf_model *m, const uint8_t *rgba, const float *dept
                              int passthrough_rgb);
 /* CoFusion::requiresFillIn (CoFusion.cpp:547-565); out = 1 when fewer than `ratio` of the sampled pixels are set */
 int cf_model_requires_fill_in(cf_model *m, float ratio, int *out);
+/* device address of the two counts (covered, total) the last cf_model_prefetch_fill_ratio left, for cf_odom_init_models_batch_select;
+ * *counts_dev = NULL when no prefetch is pending (the caller then asks cf_model_requires_fill_in).  Does not wait. */
+int cf_model_fill_ratio_device(cf_model *m, const uint32_t **counts_dev);
 /* Model::fuse (Model.cpp:408-563); weighting = Model::computeFusionWeight; maxDepth = min(depthCutoff, model maxDepth) */
 int cf_model_fuse(cf_model *m, const float pose[16], int time, const uint8_t *rgba, const uint8_t *mask, const float *depth_raw,
                   const float *depth_filtered, float maxDepth, float weighting, int maskID);
