@@ -171,7 +171,10 @@ def test_batched_segmentation_of_several_segmenters_matches_the_oracle():
     sizes = []
     for key, scs in groups.items():
         small = [sc for sc in scs if len(sc[4]) + (1 if sc[8] else 0) <= 16]
-        for batch in ([small, scs] if len(small) != len(scs) else [scs]):  # all-small: batched launches; with a big one: the fallback
+        # all-small: batched launches; with a big one: the per-segmenter fallback; the small ones three times over: more than eight
+        # segmenters in one call (two chunks of the batched launches)
+        batches = ([small, scs] if len(small) != len(scs) else [scs]) + ([small * 3] if 2 < len(small) and len(small) * 3 > 8 else [])
+        for batch in batches:
             sizes.append(len(batch))
             segs, keep, jobs = [], [], (SegJob * len(batch))()
             for k, (name, params, rgba, depth, ids, icp, vcs, next_id, allow_new) in enumerate(batch):
