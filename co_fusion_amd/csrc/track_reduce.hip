@@ -186,7 +186,7 @@ template <bool COMPACT> __device__ void rgb_residual_body(const RgbArgs& ra, int
 // VALU budget (the kernel is VALU-bound once several models share a launch): PPT pixels per lane feed ONE
 // 32 x u64 butterfly; a wave whose pixels cannot produce a correspondence (projection out of view, model map empty
 // there -- the common case for object models, which cover a small part of the image) leaves after the projection.
-static_assert(sizeof(IcpArgs) + sizeof(RgbArgs) + 16 <= 4096, "the kernel-argument segment holds 4 KB: lower kMaxBatch");
+static_assert(sizeof(IcpArgs) + sizeof(RgbArgs) + 16 <= 4096, "the kernel-argument segment holds 4 KB: lower kMaxBatch");  // (rgb_slot_step_kernel takes both as well)
 //
 // GRAM (cf_set_icp_arith 1): the accumulation and the butterfly are replaced by the matrix cores -- the rows are rounded to integers,
 // staged through LDS as signed 8-bit limbs and contracted over the wave's pixels by v_mfma_i32_32x32x32_i8 (cf_device.h: gram_*);
@@ -413,7 +413,10 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     const int band0 = rb * cols, band1 = (re > 0 ? re : rows) * cols;
     // the error surface (last level-0 iteration) is written for the WHOLE image on every rank of a split model -- the segmentation
     // reads all of it -- while only the band's pixels enter the sums
-    const bool whole = (args.flags & 1) && ma.err != nullptr && ma.row_end > 0;
+    // (flags & 1: this launch writes the error surfaces; & 2: ... except those of culled trackers, which spare workgroups of the RGB
+    // step's launch write -- icp_error_surface_body -- so that the culling stays on)
+    const bool err_here = (args.flags & 1) && !((args.flags & 2) && ma.cull);
+    const bool whole = err_here && ma.err != nullptr && ma.row_end > 0;
     const int pix0 = whole ? 0 : band0, pix1 = whole ? N : band1;
     const int nlog = (pix1 - pix0 + T * PPT - 1) >> __builtin_ctz(T * PPT);  // (workgroup sizes are powers of two: cf_set_icp_launch)
     // (the slot is sized for the whole image; a model with a row band has fewer logical blocks, and the XCD interleave below is a
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     // different XCDs), so what survives the culling is spread over the whole chip.
     const int lb = (ma.cull && !ABL(1024)) ? bx : xcd_logical_block(bx, nlog);  // (1024: timing ablation, bands for everybody)
     if (lb >= nlog) return;
-    float* __restrict__ errs = (args.flags & 1) ? ma.err : nullptr;
+    float* __restrict__ errs = err_here ? ma.err : nullptr;
 
     const int i0 = pix0 + (lb * T + threadIdx.x) * PPT;
     bool in_range = i0 < pix1;  // cols is a multiple of PPT, so the whole vector is in range
@@ -433,7 +436,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
     // Screen-box culling on the whole-image mapping (Gram form, several pixels per lane, stand-alone steps): a workgroup whose pixel
     // run misses the rectangle leaves after one scalar load; inside a workgroup that straddles it, the waves outside load nothing and
     // go straight to the commit.  Not on the error-surface iteration, which writes every pixel.
-    if (ma.cull && !(args.flags & 1)) {
+    if (ma.cull && !err_here) {
         if (ABL(8)) return;  // timing ablation: culled models do nothing
         const int L = 2 - args.occ_shift;
         const int bx0 = (st->stats.cull_box[0] >> L) - 1, by0 = (st->stats.cull_box[1] >> L) - 1, bx1 = (st->stats.cull_box[2] >> L) + 1, by1 = (st->stats.cull_box[3] >> L) + 1;
@@ -1230,6 +1233,39 @@ __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int ne
     gn_solve_body(args.icp_gram ? -1 : kFixICP, args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level, args.od_host[blockIdx.x]);
 }
 
+// The ICP error surface (icpStep's optional output, reduce.cu:327-331 / RGBDOdometry.cpp:414-431: the distance between every pixel's
+// vertex and the model vertex it projects onto, 0 when not finite / out of view) of the last level-0 iteration, one pixel per lane.
+// Until round 4 that iteration's {ICP || residual} launch wrote it for every tracker, which kept the launch from culling anything
+// (23.8 us against 15.4 us for the nine iterations before it); now the culled trackers stay culled and this body writes THEIR
+// surfaces in spare workgroups of the RGB step's launch that follows -- the pose it reads is still the iteration's (the solve comes
+// after), the expressions are those of icp_run, the bits the same.  Unculled trackers write theirs in the ICP pass as before.
+__device__ __forceinline__ void icp_error_surface_body(const IcpArgs& args, const IcpModelArgs& ma, int blk)
+{
+    float* __restrict__ errs = ma.err;
+    if (!errs || !ma.cull) return;  // (an unculled tracker wrote its surface in the ICP pass it ran over the whole image anyway)
+    StatePtr st = (StatePtr)ma.st;
+    const int cols = args.cols, rows = args.rows, N = cols * rows;
+    const int i = blk * 256 + (int)threadIdx.x;
+    const bool in_range = i < N;
+    float vx = qnan(), vy = qnan(), vz = qnan();
+    if (in_range) { vx = ma.vc[i]; vy = ma.vc[i + N]; vz = ma.vc[i + 2 * N]; }
+    if (!st->icp || st->level_done) return;  // (icp_run leaves before it writes anything)
+    m33 Rcurr, Rprev_inv;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { Rcurr.m[k] = st->Rcurr[k]; Rprev_inv.m[k] = st->Rprev_inv[k]; }
+    const f3 tcurr = {st->tcurr[0], st->tcurr[1], st->tcurr[2]};
+    const f3 tprev = {st->tprev[0], st->tprev[1], st->tprev[2]};
+    if (!in_range) return;
+    const IcpProj pr = icp_project(Rcurr, tcurr, Rprev_inv, tprev, args.intr, cols, rows, f3{vx, vy, vz});
+    f3 vprev = {qnan(), qnan(), qnan()};
+    bool occupied = pr.inb != 0;
+    if (occupied && ma.occ) occupied = ma.occ[(pr.uy >> args.occ_shift) * args.occ_w + (pr.ux >> args.occ_shift)] != 0;
+    if (occupied) vprev = f3{ma.vp[pr.g], ma.vp[pr.g + N], ma.vp[pr.g + 2 * N]};
+    float err = 0.f;
+    if (pr.inb) { const float dist = norm(vprev - pr.vcurr_g); err = is_finite(dist) ? dist : 0.0f; }
+    errs[i] = err;
+}
+
 // RGB step over the per-workgroup record slots the residual pass left (grid: one workgroup per slot x models).  A slot holds at
 // most 4 x producer-workgroup-size records and typically < 10 % of that; thread r reads record r of its slot speculatively together
 // with the slot's count, so the pass has the same two dependent memory round trips as rgb_step_kernel on a tenth of the bytes.
@@ -1237,8 +1273,10 @@ __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int ne
 // Measured and dropped (round 2, profiles/r02b): running this pass and the solve in ONE launch -- 32 workgroups per model reduce a
 // global list, fence, arrive at a counter, workgroup 0 waits and solves.  22.6 us per launch against 6.3 + 8.4 us for the two
 // separate kernels plus one boundary: the device-scope release fence and the arrival wait cost more than a kernel boundary does.
-__global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra)
+// Workgroups beyond the n_slots of the step (last level-0 iteration only) write the ICP error surface: icp_error_surface_body.
+__global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra, const IcpArgs ea, int n_slots)
 {
+    if ((int)blockIdx.x >= n_slots) { icp_error_surface_body(ea, ea.m[blockIdx.y], (int)blockIdx.x - n_slots); return; }
     const RgbModelArgs& m = ra.m[blockIdx.y];
     const OdomDev* __restrict__ od = m.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1306,7 +1344,7 @@ static void launch_icp_kernel_arith(hipStream_t s, IcpLaunch cfg, const IcpArgs&
     int blocks[kMaxBatch];
     for (int m = 0; m < n; m++) {
         IcpModelArgs& ma = args.m[m];
-        const bool ok = icp && ma.cull && ma.box_blocks > 0 && !GRAM && cfg.ppt == 1 && !(args.flags & 1) && args.row_end == 0 && ma.row_end == 0;
+        const bool ok = icp && ma.cull && ma.box_blocks > 0 && !GRAM && cfg.ppt == 1 && (!(args.flags & 1) || (args.flags & 2)) && args.row_end == 0 && ma.row_end == 0;
         ma.box_blocks = ok ? (ma.box_blocks < full ? ((ma.box_blocks + 7) / 8) * 8 : full) : 0;
         blocks[m] = ok ? ma.box_blocks : full;
     }
@@ -1399,6 +1437,12 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
         gn.od_host[m] = h_states ? h_states[m] : nullptr;
     }
     const bool slots = mode != 0;
+    // the error surfaces of the last level-0 iteration: those of culled trackers by spare workgroups of the RGB step's launch when
+    // there is one (then these trackers stay culled in that iteration's {ICP || residual} launch: IcpArgs::flags 3), the others --
+    // and all of them without such a launch -- by the ICP launch itself (flags 1)
+    bool any_culled = false;
+    for (int m = 0; m < n; m++) any_culled = any_culled || (icp_args[0].m[m].cull && icp_args[0].m[m].err);
+    const bool err_aside = icp && rgb && slots && any_culled;
     bool hook_failed = false;
     for (int i = 2; i >= 0; i--) {
         const int N = (width >> i) * (height >> i);
@@ -1416,7 +1460,7 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
                 // the roofline figure is quoted on the dominant kernel: the level-0 instantiation
                 const bool timed = prof && prof->enabled && i == 0 && prof->used + 4 <= prof->capacity;
                 IcpArgs a = icp_args[i];
-                a.flags = (i == 0 && last_of_level) ? 1 : 0;
+                a.flags = (i == 0 && last_of_level) ? (err_aside ? 3 : 1) : 0;
                 launch_icp_rgbres(s, cfg, a, ra, icp, rgb, n, i, timed ? prof->events[prof->used] : nullptr,
                                   timed ? prof->events[prof->used + 1] : nullptr);
                 if (timed) {
@@ -1429,7 +1473,11 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
                 for (int m = 0; m < n; m++)
                     if (hook->split[m] && hook->fn(hook->user, 0, gn.icp_acc[m], (uint64_t)kGroups * 32, (void*)s) != 0) hook_failed = true;
             if (rgb) {
-                if (slots) rgb_slot_step_kernel<<<dim3((N + ra.slot_px - 1) / ra.slot_px, n), 256, 0, s>>>(ra);
+                if (slots) {
+                    const int n_slots = (N + ra.slot_px - 1) / ra.slot_px;
+                    const bool with_err = err_aside && i == 0 && last_of_level;
+                    rgb_slot_step_kernel<<<dim3(n_slots + (with_err ? (N + 255) / 256 : 0), n), 256, 0, s>>>(ra, icp_args[i], n_slots);
+                }
                 else rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(ra);
             }
             gn_solve_kernel<<<n, 256, 0, s>>>(gn, next_level, last_of_level ? 1 : 0);
