@@ -38,7 +38,6 @@ struct cf_model {
     int target = 0;
     float* staged = nullptr;          // clean staging [max_surfels + N/4]
     unsigned* flags = nullptr;        // [max_surfels + N/4]
-    unsigned* offsets = nullptr;
     unsigned* block_sums = nullptr;
     unsigned* d_count = nullptr;      // device surfel count
     unsigned* d_nfresh = nullptr;     // appended new-unstable count
@@ -48,7 +47,6 @@ struct cf_model {
     float* records = nullptr;         // [N*12]
     float* fresh = nullptr;           // new unstable surfels [N/4 * 12] (Model::newUnstableBuffer)
     unsigned* new_flags = nullptr;    // [N]
-    unsigned* new_offsets = nullptr;  // [N]
     unsigned* owner = nullptr;        // [max_surfels]
     float* fb_rec = nullptr;          // feedback records (raw), [N*12]
     float* fb_raw = nullptr;          // compacted raw feedback [N*12]
@@ -119,7 +117,6 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     if (int r = dmalloc(ctx, &m->buf[1], M * 12)) return r;
     if (int r = dmalloc(ctx, &m->staged, (M + Q) * 12)) return r;
     if (int r = dmalloc(ctx, &m->flags, M + Q)) return r;
-    if (int r = dmalloc(ctx, &m->offsets, M + Q)) return r;
     if (int r = dmalloc(ctx, &m->block_sums, (M + Q) / 2048 + N / 2048 + 16)) return r;
     if (int r = dmalloc(ctx, &m->d_count, 1)) return r;
     if (int r = dmalloc(ctx, &m->d_nfresh, 1)) return r;
@@ -127,7 +124,6 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     if (int r = dmalloc(ctx, &m->records, N * 12)) return r;
     if (int r = dmalloc(ctx, &m->fresh, Q * 12)) return r;
     if (int r = dmalloc(ctx, &m->new_flags, N)) return r;
-    if (int r = dmalloc(ctx, &m->new_offsets, N)) return r;
     if (int r = dmalloc(ctx, &m->owner, M)) return r;
     HIPCHK(ctx, hipMemsetAsync(m->owner, 0xFF, M * sizeof(unsigned), ctx->cur()));
     if (int r = dmalloc(ctx, &m->fb_rec, N * 12)) return r;
@@ -168,8 +164,8 @@ void cf_model_destroy(cf_model* m)
 {
     if (!m) return;
     (void)hipStreamSynchronize(m->ctx->cur());
-    void* ptrs[] = {m->buf[0], m->buf[1], m->staged, m->flags, m->offsets, m->block_sums, m->d_count, m->d_nfresh, m->d_tmp2, m->records,
-                    m->fresh, m->new_flags, m->new_offsets, m->owner, m->fb_rec, m->fb_raw, m->fb_filt, m->keys, m->index, m->vertConf,
+    void* ptrs[] = {m->buf[0], m->buf[1], m->staged, m->flags, m->block_sums, m->d_count, m->d_nfresh, m->d_tmp2, m->records,
+                    m->fresh, m->new_flags, m->owner, m->fb_rec, m->fb_raw, m->fb_filt, m->keys, m->index, m->vertConf,
                     m->colorTime, m->normRad, m->splat_image, m->splat_vertex, m->splat_normal, m->splat_time, m->fill_vertex,
                     m->fill_normal, m->fill_image, m->tcx, m->tcy, m->rays};
     for (void* p : ptrs) (void)hipFree(p);

@@ -314,14 +314,10 @@ void launch_update_batch(hipStream_t s, const UpdatePassArgs* items, int n);
 void launch_clean_batch(hipStream_t s, const CleanPassArgs* items, int n);
 void launch_scan_scatter_batch(hipStream_t s, const ScanPassArgs* items, int n);
 void launch_bilateral(hipStream_t s, const float* depth, int cols, int rows, float maxD, float* out);
-void launch_exclusive_scan(hipStream_t s, const unsigned* flags, long long n, unsigned* offsets, unsigned* block_sums, unsigned* total,
-                           unsigned add_to_total);
 void launch_scan_scatter(hipStream_t s, const float* rec, const unsigned* flags, long long n, unsigned* block_sums, unsigned* total,
                          unsigned add_to_total, float* out, unsigned* total_host = nullptr /* pinned mirror of *total */);
 void launch_feedback(hipStream_t s, const uint8_t* rgba, const float* depth, int cols, int rows, cf_cam cam, float inv_fx, float inv_fy,
                      const float* tcx, const float* tcy, int time, float maxDepth, float* rec, unsigned* flags);
-void launch_scatter_records(hipStream_t s, const float* rec, const unsigned* flags, const unsigned* offsets, long long n, float* out,
-                            unsigned out_base);
 void launch_init(hipStream_t s, const float* raw, const float* filt, const unsigned* raw_count, long long max_n, float* out);
 void launch_index_keys(hipStream_t s, const float* surfels, const unsigned* count, unsigned id_begin, unsigned id_end, const float t_inv[16],
                        cf_cam cam, int cols, int rows, float maxDepth, int time, int timeDelta, unsigned long long* keys);
@@ -342,7 +338,6 @@ void launch_update(hipStream_t s, const float* in, const unsigned* count, unsign
                    float* out);
 void launch_clean(hipStream_t s, const float* surfels, const unsigned* count, const float* fresh, const unsigned* n_fresh, unsigned total_bound,
                   const SurfelCleanArgs& h, float* staged, unsigned* flags);
-void launch_add_counts(hipStream_t s, const unsigned* a, const unsigned* b, unsigned* out);
 void launch_set_count(hipStream_t s, unsigned* out, unsigned v);
 
 }  // namespace cf

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(kB) bilateral_kernel(const float* __restrict__
 }
 
 // ==================================================================== ordered compaction (scan) ====
-// Exclusive scan of u32 flags in three phases; blocks of kScanItems elements.
+// Ordered compaction of flagged records in blocks of kScanItems elements: block sums, then scan-and-scatter.
 static constexpr int kScanItems = 2048;  // 256 threads x 8
 struct ScanArgs {   // one ordered compaction: flags [n] -> block sums -> the flagged 48 B records of rec moved to out, in order
     const float4* rec; const unsigned* flags; long long n; unsigned* block_sums; unsigned* total; unsigned add_to_total; float4* out;
@@ -146,56 +146,6 @@ __global__ void __launch_bounds__(256) scan_block_sums_kernel(const Batch<ScanAr
     __syncthreads();
     if (threadIdx.x == 0) block_sums[vb.bid] = w[0] + w[1] + w[2] + w[3];
 }
-// single workgroup: exclusive scan of the block sums (nb <= 1024*64), total -> *total
-__global__ void __launch_bounds__(1024) scan_spine_kernel(unsigned* __restrict__ block_sums, int nb, unsigned* __restrict__ total,
-                                                          unsigned add_to_total)
-{
-    __shared__ unsigned part[1024];
-    const int per = (nb + 1023) / 1024;
-    const int b0 = threadIdx.x * per;
-    unsigned s = 0;
-    for (int k = 0; k < per; k++) if (b0 + k < nb) s += block_sums[b0 + k];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        unsigned v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned run = part[threadIdx.x] - s;  // exclusive prefix of this thread's chunk
-    for (int k = 0; k < per; k++)
-        if (b0 + k < nb) { const unsigned v = block_sums[b0 + k]; block_sums[b0 + k] = run; run += v; }
-    if (threadIdx.x == 1023) *total = part[1023] + add_to_total;
-}
-// per-element exclusive offsets
-__global__ void __launch_bounds__(256) scan_offsets_kernel(const unsigned* __restrict__ flags, long long n,
-                                                           const unsigned* __restrict__ block_sums, unsigned* __restrict__ offsets)
-{
-    __shared__ unsigned wsum[4];
-    __shared__ unsigned carry;
-    const long long base = (long long)blockIdx.x * kScanItems;
-    if (threadIdx.x == 0) carry = block_sums[blockIdx.x];
-    __syncthreads();
-    for (int k = 0; k < 8; k++) {
-        const long long i = base + k * 256 + threadIdx.x;
-        const unsigned f = (i < n) ? flags[i] : 0;
-        // wave inclusive scan
-        unsigned v = f;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up((int)v, o, 64); if (lane >= o) v += t; }
-        if (lane == 63) wsum[wave] = v;
-        __syncthreads();
-        unsigned wbase = 0;
-        for (int w = 0; w < wave; w++) wbase += wsum[w];
-        const unsigned c = carry;
-        if (i < n) offsets[i] = c + wbase + v - f;
-        __syncthreads();
-        if (threadIdx.x == 255) carry = c + wbase + v;
-        __syncthreads();
-    }
-}
-
 __global__ void set_count_kernel(unsigned* out, unsigned v);
 __global__ void set_count2_kernel(unsigned* out, unsigned* out_host, unsigned v);
 // Ordered compaction in TWO launches (scan_block_sums_kernel, then this): every workgroup derives its own base from the block
@@ -278,20 +228,6 @@ void launch_scan_scatter(hipStream_t s, const float* rec, const unsigned* flags,
     launch_scan_scatter_batch(s, &a, 1);
 }
 
-void launch_exclusive_scan(hipStream_t s, const unsigned* flags, long long n, unsigned* offsets, unsigned* block_sums, unsigned* total,
-                           unsigned add_to_total)
-{
-    const int nb = (int)((n + kScanItems - 1) / kScanItems);
-    if (nb > 0) {
-        Batch<ScanArgs> B;
-        B.m[0] = ScanArgs{nullptr, flags, n, block_sums, total, add_to_total, nullptr, nullptr};
-        const int grid = batch_layout(B, &nb, 1);
-        scan_block_sums_kernel<<<grid, 256, 0, s>>>(B);
-    }
-    scan_spine_kernel<<<1, 1024, 0, s>>>(block_sums, nb, total, add_to_total);
-    if (nb > 0) scan_offsets_kernel<<<nb, 256, 0, s>>>(flags, n, block_sums, offsets);
-}
-
 // ============================================================================ frame-1 bootstrap ====
 // vertex_feedback.vert:40-68 (+ .geom): thread per pixel (row-major for coalescing); the record and
 // its flag are stored at the COLUMN-major rank i*rows+j, the order the reference draws the points in.
@@ -315,15 +251,6 @@ __global__ void __launch_bounds__(kB) feedback_kernel(const uchar4* __restrict__
     rec[rank * 3 + 2] = make_float4(n.x, n.y, n.z, get_radius(p.z, n.z, inv_fx, inv_fy));
 }
 
-__global__ void __launch_bounds__(kB) scatter_records_kernel(const float4* __restrict__ rec, const unsigned* __restrict__ flags,
-                                                             const unsigned* __restrict__ offsets, long long n, float4* __restrict__ out,
-                                                             unsigned out_base)
-{
-    const long long r = (long long)blockIdx.x * kB + threadIdx.x;
-    if (r >= n || !flags[r]) return;
-    const size_t o = (size_t)(out_base + offsets[r]) * 3;
-    out[o] = rec[r * 3]; out[o + 1] = rec[r * 3 + 1]; out[o + 2] = rec[r * 3 + 2];
-}
 
 // Model::initialise (Model.cpp:227-272) + init_unstable.vert: attr 0/1 raw, attr 2 filtered, same index
 __global__ void __launch_bounds__(kB) init_kernel(const float4* __restrict__ raw, const float4* __restrict__ filt,
@@ -923,7 +850,6 @@ __global__ void __launch_bounds__(kB) fill_zero_kernel(const Batch<FillArgs> B)
     const long long i = (long long)vb.bid * kB + threadIdx.x;
     if (i < a.n16) a.p[i] = make_uint4(0, 0, 0, 0);
 }
-__global__ void add_counts_kernel(const unsigned* a, const unsigned* b, unsigned* out) { *out = *a + *b; }
 __global__ void set_count_kernel(unsigned* out, unsigned v) { *out = v; }
 __global__ void set_count2_kernel(unsigned* out, unsigned* out_host, unsigned v) { *out = v; if (out_host) *out_host = v; }
 
@@ -940,11 +866,6 @@ void launch_feedback(hipStream_t s, const uint8_t* rgba, const float* depth, int
 {
     feedback_kernel<<<gridFor((long long)cols * rows), kB, 0, s>>>(reinterpret_cast<const uchar4*>(rgba), depth, cols, rows, cam.cx, cam.cy, inv_fx,
                                                                    inv_fy, tcx, tcy, time, maxDepth, reinterpret_cast<float4*>(rec), flags);
-}
-void launch_scatter_records(hipStream_t s, const float* rec, const unsigned* flags, const unsigned* offsets, long long n, float* out,
-                            unsigned out_base)
-{
-    scatter_records_kernel<<<gridFor(n), kB, 0, s>>>(reinterpret_cast<const float4*>(rec), flags, offsets, n, reinterpret_cast<float4*>(out), out_base);
 }
 void launch_init(hipStream_t s, const float* raw, const float* filt, const unsigned* raw_count, long long max_n, float* out)
 {
@@ -1140,7 +1061,6 @@ void launch_clean(hipStream_t s, const float* surfels, const unsigned* count, co
     const CleanPassArgs a{h, surfels, count, fresh, n_fresh, total_bound, staged, flags};
     launch_clean_batch(s, &a, 1);
 }
-void launch_add_counts(hipStream_t s, const unsigned* a, const unsigned* b, unsigned* out) { add_counts_kernel<<<1, 1, 0, s>>>(a, b, out); }
 void launch_set_count(hipStream_t s, unsigned* out, unsigned v) { set_count_kernel<<<1, 1, 0, s>>>(out, v); }
 
 }  // namespace cf
