@@ -390,6 +390,7 @@ static int scratch_begin(cf_ctx* ctx, int cols, int rows)
 }
 static int scratch_commit(cf_ctx* ctx)
 {
+    refresh_hot(ctx->h_scratch_state);   // the kernels read pose / flags through the hot block (cf_kernels.h: GnHot)
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_scratch_state, ctx->h_scratch_state, sizeof(OdomDev), hipMemcpyHostToDevice, ctx->stream));
     return CF_OK;
 }
@@ -425,7 +426,7 @@ int cf_icp_step_band(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], co
     h->nmap_g_prev[0] = nmap_g_prev; h->distThres = dist_thres; h->angleThres = angle_thres; h->err_surface = err_surface;
     if (int r = scratch_commit(ctx)) return r;
     IcpArgs a{};
-    a.m[0] = IcpModelArgs{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, ctx->d_scratch_state, ctx->d_acc_a, err_surface, ctx->d_acc_b, nullptr, 0, 0};
+    a.m[0] = IcpModelArgs{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, ctx->d_scratch_state, ctx->d_acc_a, err_surface, nullptr, 0, 0};
     a.cols = cols; a.rows = rows; a.intr = intr; a.distThres = dist_thres; a.angleThres = angle_thres;
     a.angleSqLt = sqrt_gate_lt(angle_thres); a.distSqLe = sqrt_gate_le(dist_thres);
     a.flags = err_surface ? 1 : 0;
@@ -559,6 +560,7 @@ int cf_odom_create(cf_ctx* ctx, cf_odom** out)
     if (int r = dmalloc(ctx, &od->rgb_acc, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &od->occ, ((size_t)(W >> 2) * (H >> 2) + 3) / 4 * 4)) return r;
     if (int r = dmalloc(ctx, &od->aabb, 8)) return r;
+    if (int r = dmalloc(ctx, &od->res_range, 8)) return r;
     for (int k = 0; k < cf_ctx::kStateSlots && od->slot < 0; k++)
         if (!ctx->slot_used[k]) { ctx->slot_used[k] = true; od->slot = k; }
     if (od->slot >= 0) {
@@ -593,7 +595,7 @@ void cf_odom_destroy(cf_odom* od)
         (void)hipFree(od->dIdx[i]); (void)hipFree(od->dIdy[i]); (void)hipFree(od->cloud[i]); (void)hipFree(od->corres[i]);
         (void)hipFree(od->cand[i]); (void)hipFree(od->zrange[i]);
     }
-    (void)hipFree(od->icp_acc); (void)hipFree(od->rgb_acc); (void)hipFree(od->occ); (void)hipFree(od->aabb);
+    (void)hipFree(od->icp_acc); (void)hipFree(od->rgb_acc); (void)hipFree(od->occ); (void)hipFree(od->aabb); (void)hipFree(od->res_range);
     if (od->slot >= 0) od->ctx->slot_used[od->slot] = false;
     else { (void)hipFree(od->d_state); (void)hipHostFree(od->h_state); }
     delete od;
@@ -610,6 +612,7 @@ static ModelMapsArgs model_maps_args(cf_odom* od, const float* pred_v4, const fl
     const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
     const float t[3] = {pose[3], pose[7], pose[11]};
     memcpy(a.R, R, sizeof(R)); memcpy(a.t, t, sizeof(t));
+    memcpy(od->map_pose, R, sizeof(R)); memcpy(od->map_pose + 9, t, sizeof(t));
     a.occ = od->occ; od->occ_valid = true;
     // the bounding box only pays for models that are culled (a model that fills the image would add atomics for nothing)
     const bool tiled = a.cols % 16 == 0 && a.rows % 4 == 0;  // launch_model_maps: the pass that reduces the box
@@ -859,7 +862,13 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
     // holds it once that call's results were fetched
     if (h->cull && !ctx->state_readback_pending) memcpy(od->box_hint, h->stats.cull_box, sizeof(od->box_hint));
     else od->box_hint[0] = kNoBoxHint;
+    // ... and likewise the record slots its residual passes needed (a culled tracker's candidate mask is empty outside its prediction)
+    for (int i = 0; i < CF_NUM_PYRS; i++) od->res_hint[i] = (h->cull && h->res_range && !ctx->state_readback_pending) ? h->res_seen[i] : -1;
     h->aabb_acc = od->aabb; h->cull = (od->use_occ && od->box_valid && od->band_end == 0 && !no_box) ? 1 : 0;
+    memcpy(h->box_R, od->map_pose, 36); memcpy(h->box_t, od->map_pose + 9, 12);
+    h->res_range = (h->cull && rgb) ? od->res_range : nullptr;
+    for (int i = 0; i < CF_NUM_PYRS; i++) h->res_seen[i] = -1;
+    if (rgb) prep->res_range = h->res_range;
     // the first launch of a tracking call latches the accumulator and zeroes it (so3_prealign_kernel): a second tracking call on the
     // same preparation would read an empty box and cull every workgroup.  It falls back to the whole image instead.
     od->box_valid = false;
@@ -887,6 +896,7 @@ static void fill_rgb_args(cf_ctx* ctx, cf_odom* const* ods, int n, RgbArgs out[3
         for (int m = 0; m < n; m++) {
             a.m[m] = rgb_model_args(ods[m]->h_state, ods[m]->d_state, l);
             a.m[m].no_counts = (ods[m]->band_end > 0 && !ods[m]->band_counts) ? 1 : 0;
+            a.m[m].res_blocks = a.m[m].res_range ? residual_blocks_for(ods[m]->res_hint[l]) : 0;
         }
     }
 }
@@ -914,7 +924,7 @@ static void fill_icp_args(cf_ctx* ctx, cf_odom* const* ods, int n, IcpArgs out[3
             a.m[m] = IcpModelArgs{od->ext_vmap_curr[l] ? od->ext_vmap_curr[l] : od->vmap_curr[l],
                                   od->ext_nmap_curr[l] ? od->ext_nmap_curr[l] : od->nmap_curr[l],
                                   od->vmap_g_prev[l], od->nmap_g_prev[l], od->d_state, od->icp_acc,
-                                  od->h_state->err_surface, od->rgb_acc, (od->use_occ && od->occ_valid && !no_occ) ? od->occ : nullptr,
+                                  od->h_state->err_surface, (od->use_occ && od->occ_valid && !no_occ) ? od->occ : nullptr,
                                   od->band_end > 0 ? (od->band_begin >> l) : 0, od->band_end > 0 ? (od->band_end >> l) : 0,
                                   od->h_state->cull,
                                   no_zcull ? nullptr : (od->ext_vmap_curr[l] ? od->ext_zrange[l] : (od->zrange_valid ? od->zrange[l] : nullptr)),
@@ -974,7 +984,17 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     // diagnostics: CF_ICP_REPLAY=<call> re-launches the level-0 {ICP || residual} launch of that tracking call (its converged state) back
     // to back under a list of ablation masks and prints the durations -- the decomposition of the launch quoted in DESIGN.md 4.1
     static const int replay_call = getenv("CF_ICP_REPLAY") ? atoi(getenv("CF_ICP_REPLAY")) : -1;
-    static int calls_seen = 0;
+    static const int trace_call = getenv("CF_ICP_TRACE") ? atoi(getenv("CF_ICP_TRACE")) : -1;   // per-workgroup stamps of that call's level-0 launch
+    static int calls_seen = 0, trace_calls_seen = 0;
+    if (trace_call >= 0 && trace_calls_seen++ == trace_call) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        trace_icp_level0(ctx->stream, ctx->icp_launch, icp_args[0], rgb_args[0], n, ctx->gn_mode, getenv("CF_ICP_TRACE_OUT") ? getenv("CF_ICP_TRACE_OUT") : "icp_trace.txt");
+        for (int m = 0; m < n; m++) {
+            HIPCHK(ctx, hipMemsetAsync(ods[m]->icp_acc, 0, sizeof(unsigned long long) * kGroups * 32, ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(ods[m]->rgb_acc, 0, sizeof(unsigned long long) * kGroups * 32, ctx->stream));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (replay_call >= 0 && calls_seen++ == replay_call) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         const int masks[] = {0, 8, 16, 32, 8 | 32, 256, 256 | 32, 256 | 16 | 8, 8 | 256 | 32, 256 | 32 | 512, 256 | 32 | 1024, 1024};

@@ -93,7 +93,10 @@ struct cf_odom {
     bool occ_valid = false;          // the map describes the current model maps
     bool use_occ = false;            // cf_odom_set_culling: occupancy look-up + screen-box culling of the ICP reduction
     unsigned* aabb = nullptr;        // 8 words: bounding-box accumulator of the model maps (OdomDev::aabb_acc)
+    float map_pose[12]{};            // R (9) | t (3) of the pose the model maps were prepared with: the camera frame of the bounding frustum
     int box_hint[4] = {0x7fffffff, 0, 0, 0};  // level-0 screen box at the end of the previous tracking call (kNoBoxHint: none): sizes the culled launches
+    unsigned* res_range = nullptr;   // 8 words: first / last candidate chunk per level of the RGB residual pass (OdomDev::res_range)
+    int res_hint[3] = {-1, -1, -1};  // record slots per level between them in the previous tracking call (-1: unknown): sizes the residual launches
     bool box_valid = false;          // the model-map pass of this frame fed the accumulator
     int band_begin = 0, band_end = 0;  // cf_odom_set_band: this rank's rows of the model's reductions (0, 0: all rows)
     bool band_counts = true;           // this rank adds the residual pass's count / sigma (exactly one rank of a split does)            // cf_odom_set_culling: worth it for models that cover a small part of the image

@@ -11,6 +11,26 @@ namespace cf {
 
 constexpr int kGroups = 64;  // accumulation groups for the grouped integer atomics
 
+// HOT STATE of a tracker (round 5): everything the workgroups of the per-iteration launches read from the device-resident state,
+// packed into three 64-byte scalar-cache lines.  The solve of the previous launch wrote the state on another XCD, so the first wave on
+// every CU takes its scalar loads of it all the way to memory; spread over the 1 KB OdomDev, and tested field by field (`!st->icp ||
+// st->level_done`, then the pose, then the box), those were three to five DEPENDENT round trips in front of every first-round wave.
+// Now: one clause of s_load_dwordx16 (lines 0 + 1 for the ICP reduction, line 2 for the residual pass and the RGB step), one wait.
+// A derived copy: the fields of OdomDev stay the source of truth; refresh_hot() re-derives it wherever the state is written (host
+// preparation, the first launch of the schedule, every solve).
+struct alignas(64) GnHot {
+    // line 0
+    int icp, level_done; float cull_z[2];
+    float Rcurr[9], tcurr[3];
+    // line 1
+    float Rprev_inv[9], tprev[3];
+    int cull_box[4];
+    // line 2
+    int rgb, rgbOnly, level_done2, pad;
+    float krkInv[9], kt[3];
+};
+static_assert(sizeof(GnHot) == 192, "three 64-byte lines");
+
 // Device-resident mirror of RGBDOdometry's members (Core/Utils/RGBDOdometry.h:78-137) plus the
 // Gauss-Newton state that the reference keeps in host locals (RGBDOdometry.cpp:217-477).
 struct OdomDev {
@@ -40,11 +60,16 @@ struct OdomDev {
     float minGrad[3];
     float icpWeight;
     int icp, rgb, rgbOnly;
-    // screen-box culling of the ICP reduction (cf_odom_set_culling): the global-frame bounding box of the model's predicted vertices is
-    // accumulated by the model-map pass into aabb_acc (6 order-preserving keys, zero = empty), latched into box_lo / box_hi by the first
-    // kernel of the Gauss-Newton loop and re-projected into the current camera after every pose update (ibox)
+    // screen-box culling of the ICP reduction (cf_odom_set_culling): the bounding frustum of the model's predicted vertices (pixel
+    // rectangle + depth interval in the prediction camera) is accumulated by the model-map pass into aabb_acc (6 order-preserving keys,
+    // zero = empty), latched into box_lo / box_hi by the first kernel of the Gauss-Newton loop and re-projected into the current camera
+    // after every pose update (screen_box)
     unsigned* aabb_acc;
     int cull;
+    float box_R[9], box_t[3];   // pose of the camera the prediction was rendered from: the frame box_lo / box_hi are expressed in
+    // culled trackers: first / last 256-pixel chunk with an RGB candidate per level (RgbPrepArgs::res_range; null: not tracked) --
+    // the residual workgroups of the loop cover the record slots between them only
+    unsigned* res_range;
     // Gauss-Newton state
     float Rprev[9], tprev[3], Rprev_inv[9], Rcurr[9], tcurr[3];
     double resultRt[16];
@@ -52,14 +77,27 @@ struct OdomDev {
     float lastRGBError;
     int level_done;
     float residual[2];
-    float box_lo[3], box_hi[3];  // bounding box of the model's predicted vertices, global frame (box_lo[0] > box_hi[0]: no valid vertex)
+    float box_lo[3], box_hi[3];  // bounding frustum of the model's predicted vertices in the prediction camera (box_R / box_t): level-0 pixel
+                                 // rectangle [0..1] and depth interval [2] (box_lo[0] > box_hi[0]: no valid vertex)
+    int res_seen[3];             // record slots between the first and the last RGB candidate of each level in this call (-1: not
+                                 // tracked): sizes the residual part of the next call's launches (the last solve writes it)
     float cull_z[2];             // depth interval (current camera) of that box dilated by distThres: a 64-pixel run of the current frame
                                  // whose valid depths all lie outside cannot find a correspondence (-inf, +inf: no depth culling)
     // (the screen box itself -- the level-0 pixel rectangle outside of which no pixel of the current frame can find a correspondence
     // under Rcurr / tcurr -- is stats.cull_box)
     // outputs
     cf_track_stats stats;
+    GnHot hot;   // (last: 64-byte aligned, inside the region the solve writes back)
 };
+__host__ __device__ inline void refresh_hot(OdomDev* od)
+{
+    GnHot& h = od->hot;
+    h.icp = od->icp; h.level_done = od->level_done; h.cull_z[0] = od->cull_z[0]; h.cull_z[1] = od->cull_z[1];
+    for (int k = 0; k < 9; k++) { h.Rcurr[k] = od->Rcurr[k]; h.Rprev_inv[k] = od->Rprev_inv[k]; h.krkInv[k] = od->krkInv[k]; }
+    for (int k = 0; k < 3; k++) { h.tcurr[k] = od->tcurr[k]; h.tprev[k] = od->tprev[k]; h.kt[k] = od->kt[k]; }
+    for (int k = 0; k < 4; k++) h.cull_box[k] = od->stats.cull_box[k];
+    h.rgb = od->rgb; h.rgbOnly = od->rgbOnly; h.level_done2 = od->level_done; h.pad = 0;
+}
 
 // ---- prep launchers (track_prep.hip) ----
 void launch_vmap(hipStream_t s, const float* depth, int cols, int rows, cf_cam intr, float cutoff, float* vmap);
@@ -89,6 +127,8 @@ struct RgbPrepArgs {
     const uint8_t* nextImage[3]; const float* nextDepth[3]; const float* lastDepth[3];
     int16_t* dIdx[3]; int16_t* dIdy[3]; uint8_t* cand[3]; float* cloud[3];
     float minScale[3], fx_inv[3], fy_inv[3], cx[3], cy[3];
+    unsigned* res_range;         // nullable, [3][2]: per level ~(first chunk), last chunk + 1 of the 256-pixel chunks that hold a candidate
+                                 // (atomicMax; zero = none; cleared by the last solve of the schedule)
 };
 struct ModelMapsArgs {
     const float* pred_v4; const float* pred_n4;  // RGBA32F prediction (vertex+conf, normal+radius)
@@ -99,7 +139,7 @@ struct ModelMapsArgs {
     int cols, rows;
     float R[9], t[3];
     unsigned char* occ;                          // nullable: occupancy map of the prediction (1 byte per 4x4 block)
-    unsigned* aabb;                              // nullable: bounding box of the transformed level-0 vertices (OdomDev::aabb_acc)
+    unsigned* aabb;                              // nullable: bounding frustum of the valid level-0 vertices, camera frame (OdomDev::aabb_acc)
 };
 // batches: one grid row per tracked model (<= kPrepBatch), so that a frame with several models still issues each
 // preparation kernel once
@@ -144,7 +184,6 @@ struct IcpModelArgs {
     const OdomDev* st;                  // device-resident pose + flags
     unsigned long long* acc;            // [kGroups][32] grouped accumulators
     float* err;                         // nullable ICP error surface [rows*cols]
-    unsigned long long* rgb_acc;        // the model's RGB accumulators (used by the solve kernel's arguments)
     const unsigned char* occ;           // nullable: occupancy map of the model maps (model_maps_kernel), 1 byte per 4x4 level-0 block
     int row_begin, row_end;             // row band of THIS model's reduction (row_end == 0: all rows): its share when the model's
                                         // reduction is split over GPUs
@@ -180,12 +219,17 @@ inline int box_blocks_for(const int box_hint[4], int L, int cols, int rows, int 
     int want = (((runs + wpb - 1) / wpb + 7) / 8) * 8;
     return want < 8 ? 8 : want;
 }
+// Residual workgroups for a culled tracker at one level: the record slots between the first and the last RGB candidate of the previous
+// tracking call (OdomDev::res_seen; < 0: unknown -> 0 = one workgroup per slot of the level) + 25 % + 2 -- the workgroups walk on by
+// their number if this call's range is longer than that.
+inline int residual_blocks_for(int seen) { return seen < 0 ? 0 : seen + seen / 4 + 2; }
 // solve-kernel arguments (by value)
 struct GnArgs {
     OdomDev* od[kMaxBatch];
     unsigned long long* icp_acc[kMaxBatch];
     unsigned long long* rgb_acc[kMaxBatch];
     OdomDev* od_host[kMaxBatch];   // nullable: pinned host copies of the states; the LAST solve of a schedule publishes its result there
+    int slot_px;                   // pixels per record slot of the residual pass (RgbArgs::slot_px): unit of OdomDev::res_seen
     int icp_gram;                  // rounding specification of the ICP sums (IcpLaunch::gram): selects the scales of the unpack
 };
 // RGB residual / RGB step arguments (by value): everything but the pose-dependent state arrives in the kernarg
@@ -199,6 +243,10 @@ struct RgbModelArgs {
                                         // rank does, and the accumulators are summed over the ranks (split reduction)
     uint2* recs;                        // record slots of the device-resident loop (aliases corres: N x 8 B)
     unsigned* slot_counts;              // records per slot (behind the records in the same buffer)
+    const unsigned* res_range;          // nullable (culled trackers): this level's pair of OdomDev::res_range -- only the record slots
+                                        // between the first and the last candidate chunk are visited (the others hold no record)
+    int res_blocks;                     // residual workgroups of this tracker in the launch (0: one per slot of the level); fewer than the
+                                        // slots in range: the workgroups walk on by res_blocks
 };
 struct RgbArgs {
     RgbModelArgs m[kMaxBatch];
@@ -214,7 +262,8 @@ inline RgbModelArgs rgb_model_args(const OdomDev* h /* host mirror */, OdomDev* 
     return RgbModelArgs{d_state, h->cand[level], h->nextDepth[level], h->lastDepth[level], h->lastImage[level], h->nextImage[level],
                         h->corres[level], h->cloud[level], h->dIdx[level], h->dIdy[level], h->icp_acc, h->rgb_acc, 0,
                         reinterpret_cast<uint2*>(h->corres[level]),
-                        reinterpret_cast<unsigned*>(reinterpret_cast<uint2*>(h->corres[level]) + (size_t)(h->width >> level) * (h->height >> level))};
+                        reinterpret_cast<unsigned*>(reinterpret_cast<uint2*>(h->corres[level]) + (size_t)(h->width >> level) * (h->height >> level)),
+                        h->res_range ? h->res_range + 2 * level : nullptr, 0};
 }
 struct IcpArgs {
     IcpModelArgs m[kMaxBatch];
@@ -226,13 +275,12 @@ struct IcpArgs {
     int flags;                          // bit0: write the error surface
     int row_begin, row_end;             // row band to reduce; row_end == 0: all rows
     IDiv cdiv;                          // make_idiv(cols), set by the launchers
-    // layout of the one-dimensional grid (set by the launchers, icp_reduce_kernel): running totals of the ICP workgroups per slot, the
-    // model of every slot, residual workgroups per model
-    int blk_end[kMaxBatch];
-    int blk_model[kMaxBatch];
-    int n_res_blocks;
-    IDiv res_div;                       // make_idiv(n_res_blocks)
+    // layout of the one-dimensional grid (set by the launchers, icp_reduce_kernel): running totals of the workgroups per slot -- a slot
+    // is the ICP reduction or the residual pass of one model -- and what every slot is; unused slots end at INT_MAX
+    int slot_end[2 * kMaxBatch];
+    unsigned char slot_desc[2 * kMaxBatch];   // model | kResidualSlot
 };
+constexpr unsigned char kResidualSlot = 0x80;
 void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void launch_rgb_residual(hipStream_t s, const RgbArgs& ra, int n);
 void launch_rgb_step(hipStream_t s, const RgbArgs& ra, int n);
@@ -270,6 +318,9 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
                                                            first launch beside the SO3 pre-alignment */);
 void rgb_prep_levels(RgbPrepBatch& b, int n, int W, int H);
 float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, int ablate, int reps, hipEvent_t e0, hipEvent_t e1);
+#ifdef CF_ABLATE
+void trace_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, const char* path);
+#endif
 float sqrt_gate_lt(float T);  // smallest x with sqrtf(x) >= T
 float sqrt_gate_le(float T);  // largest x with sqrtf(x) <= T
 

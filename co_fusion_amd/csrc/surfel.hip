@@ -981,7 +981,7 @@ void launch_fill_ratio(hipStream_t s, const uint8_t* pimg, int cols, int rows, u
 // ---- fuse: association (+ the flag buffers zeroed in one launch), update ---------------------------------------------------------------
 void launch_associate_batch(hipStream_t s, const SurfelFuseArgs* items, int n_items)
 {
-    constexpr int chunk = xcd_env("CF_XCD_ASSOC", 0);
+    const int chunk = xcd_env("CF_XCD_ASSOC", 0);
     for (int base = 0; base < n_items; base += kSurfBatch) {
         const int nb = n_items - base < kSurfBatch ? n_items - base : kSurfBatch;
         Batch<FuseArgs> B;
@@ -1032,7 +1032,7 @@ void launch_update(hipStream_t s, const float* in, const unsigned* count, unsign
 // ---- clean ----------------------------------------------------------------------------------------------------------------------
 void launch_clean_batch(hipStream_t s, const CleanPassArgs* items, int n_items)
 {
-    constexpr int chunk = xcd_env("CF_XCD_CLEAN", 64);
+    const int chunk = xcd_env("CF_XCD_CLEAN", 64);
     for (int base = 0; base < n_items; base += kSurfBatch) {
         const int nb = n_items - base < kSurfBatch ? n_items - base : kSurfBatch;
         Batch<CleanArgs> B;

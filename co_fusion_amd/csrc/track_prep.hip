@@ -526,16 +526,17 @@ __device__ __forceinline__ void model_maps_tiled_body(const ModelMapsBatch& b, i
         // occupancy of this 4x4 block: lanes lx..lx+3 of the four tile rows
         if (a.occ) a.occ[i2] = ((valid_bits >> lx) & 0x000F000F000F000Full) != 0 ? 1 : 0;
     }
-    // bounding box of the transformed level-0 vertices (what the ICP reduction gathers as vprev; the coarser levels are averages
-    // of these): the Gauss-Newton loop projects it into the current camera to cull workgroups that cannot find a correspondence.
+    // Bounding FRUSTUM of the prediction, in its own camera: the pixel rectangle of the valid level-0 vertices and the interval of their
+    // depths (the coarser levels are averages of these).  A pixel of the current frame finds a correspondence only if its vertex, taken
+    // into this camera, projects onto a valid pixel -- it lies in that pixel's pyramid -- at a depth within distThres of the model's
+    // (reduce.cu:321-325): inside the rectangle's frustum between zmin - distThres and zmax + distThres.  The Gauss-Newton loop projects
+    // that frustum piece into the current camera (screen_box) and culls everything outside.  (Until round 5: the axis-aligned box of the
+    // vertices in the GLOBAL frame, dilated by distThres in every direction -- 53 pixels sideways at one metre.)
     // Six order-preserving keys, atomicMax each (the lower bounds as complemented keys), zero = empty.
     if (a.aabb && valid_bits != 0) {
         const float inf = __int_as_float(0x7f800000);
         float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
-        if (valid && !is_nan(v0.p.x)) {
-            const f3 d = mul(R, v0.p) + tr;
-            lo[0] = hi[0] = d.x; lo[1] = hi[1] = d.y; lo[2] = hi[2] = d.z;
-        }
+        if (valid && !is_nan(v0.p.x) && !is_nan(vs.z)) { lo[0] = hi[0] = (float)x; lo[1] = hi[1] = (float)y; lo[2] = hi[2] = vs.z; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
 #pragma unroll

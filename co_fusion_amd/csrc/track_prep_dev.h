@@ -19,7 +19,8 @@ __device__ __forceinline__ void rgb_prep_body(const RgbPrepArgs& a, int bx)
     const int lv = level_of(a.L, bx, lb);
     const int cols = a.L.cols[lv], rows = a.L.rows[lv];
     const int k = lb * 256 + (int)threadIdx.x;
-    if (k >= cols * rows) return;
+    uint8_t ok = 0;
+    if (k < cols * rows) {
     const int y = k / cols, x = k - y * cols;
     const uint8_t* __restrict__ src = a.nextImage[lv];
     // cloud (independent of the rest)
@@ -57,7 +58,6 @@ __device__ __forceinline__ void rgb_prep_body(const RgbPrepArgs& a, int bx)
     const int16_t dx16 = (int16_t)(int)dxv, dy16 = (int16_t)(int)dyv;
     a.dIdx[lv][k] = dx16; a.dIdy[lv][k] = dy16;
     // candidate mask
-    uint8_t ok = 0;
     if (x < cols - 5 && y < rows - 1) {
         bool valid = true;
         for (int u = max(y - 2, 0); u < min(y + 2, rows); u++)
@@ -69,5 +69,14 @@ __device__ __forceinline__ void rgb_prep_body(const RgbPrepArgs& a, int bx)
         }
     }
     a.cand[lv][k] = ok;
+    }
+    // Culled trackers (object models): the first and the last 256-pixel chunk of the level that holds a candidate at all.  The residual
+    // workgroups of the Gauss-Newton loop are dealt the record slots between the two (rgb_residual_body) instead of the whole image's --
+    // an object's mask is empty outside its prediction.  Two atomics per chunk WITH a candidate; words: ~first (0 = none seen), last + 1.
+    if (a.res_range) {
+        if (__syncthreads_or(ok)) {
+            if (threadIdx.x == 0) { atomicMax(&a.res_range[2 * lv], ~(unsigned)lb); atomicMax(&a.res_range[2 * lv + 1], (unsigned)lb + 1u); }
+        }
+    }
 }
 }  // namespace cf

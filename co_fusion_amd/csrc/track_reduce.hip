@@ -109,30 +109,37 @@ __device__ __forceinline__ IcpProj icp_project(const m33& Rcurr, const f3& tcurr
 }
 
 // ------------------------------------------------------------------------------------------------
-// Screen-box culling.  A pixel of the current frame finds a correspondence only if its vertex, moved into the global frame
-// (vcurr_g = Rcurr * vcurr + tcurr), lies within distThres of a predicted model vertex (reduce.cu:321-325), i.e. inside the
-// bounding box of the model's predicted vertices dilated by distThres.  Taken back into the current camera and projected, that
-// box bounds the pixels that can contribute: everything outside adds exact zeros and is skipped before it loads anything.
-// Object models cover a few percent of the image, so most of their workgroups leave after one scalar load.
-// The rectangle is conservative: the box is dilated by 1 % + 1 mm on top of distThres (f32 rounding of the per-pixel
-// arithmetic is ~1e-6 relative), the projection by 3 pixels, and any corner that is not clearly in front of the camera (or not
-// finite) gives the whole image.  Called by a whole wave; the result is valid in every lane.
-__device__ __forceinline__ void screen_box(const float* lo, const float* hi, const float* Rcurr, const float* tcurr, cf_cam intr,
-                                           float distThres, int W, int H, int lane, int (&out)[4], float (&zout)[2])
+// Screen-box culling.  A pixel of the current frame finds a correspondence only if its vertex, taken into the camera the prediction was
+// rendered from (vcurr_cp = Rprev^-1 (Rcurr vcurr + tcurr - tprev)), projects onto a VALID pixel of the prediction -- i.e. lies inside
+// that pixel's pyramid -- and is within distThres of the model vertex there (reduce.cu:321-325), hence at a depth within distThres of it.
+// All such vertices lie in one frustum piece of the prediction camera: the pixel rectangle of the valid predicted vertices (lo / hi [0..1],
+// level-0 pixels; model_maps_tiled_body) between the depths lo[2] - distThres and hi[2] + distThres.  Its eight corners, taken into the
+// current camera and projected, bound the pixels that can contribute (a projective map takes the convex piece into the convex hull of
+// the corners' images): everything outside adds exact zeros and is skipped before it loads anything.
+// Conservative: the rectangle is widened by 3 pixels (a level-l pixel of the model maps is valid only if its 2^l x 2^l level-0 sources
+// are, and its pyramid overhangs them by 2^(l-1) level-0 pixels; + rounding of the per-pixel f32 projection), the depths by 1 % + 1 mm on
+// top of distThres, the projected rectangle by 3 pixels, and a near plane that is not clearly in front of either camera (or anything
+// not finite) gives the whole image.  Called by a whole wave; the result is valid in every lane.
+// Rb / tb: pose of the prediction camera (OdomDev::box_R / box_t).
+__device__ __forceinline__ void screen_box(const float* lo, const float* hi, const float* Rb, const float* tb, const float* Rcurr, const float* tcurr,
+                                           cf_cam intr, float distThres, int W, int H, int lane, int (&out)[4], float (&zout)[2])
 {
     const float finf = __int_as_float(0x7f800000);
     zout[0] = -finf; zout[1] = finf;
     if (!(lo[0] <= hi[0])) { out[0] = 1; out[1] = 1; out[2] = 0; out[3] = 0; return; }  // no predicted vertex: nothing can match
     const float m = distThres * 1.01f + 1e-3f;
-    const float dx = ((lane & 1) ? hi[0] + m : lo[0] - m) - tcurr[0];
-    const float dy = ((lane & 2) ? hi[1] + m : lo[1] - m) - tcurr[1];
-    const float dz = ((lane & 4) ? hi[2] + m : lo[2] - m) - tcurr[2];
-    // Rcurr^T (Rcurr is a rotation up to f32 rounding)
+    const float px = (lane & 1) ? hi[0] + 3.f : lo[0] - 3.f, py = (lane & 2) ? hi[1] + 3.f : lo[1] - 3.f;
+    const float znear = lo[2] - m, pz = (lane & 4) ? hi[2] + m : znear;
+    const float cx_ = (px - intr.cx) / intr.fx * pz, cy_ = (py - intr.cy) / intr.fy * pz;
+    // into the global frame, then into the current camera: Rcurr^T (Rcurr is a rotation up to f32 rounding)
+    const float dx = (Rb[0] * cx_ + Rb[1] * cy_ + Rb[2] * pz + tb[0]) - tcurr[0];
+    const float dy = (Rb[3] * cx_ + Rb[4] * cy_ + Rb[5] * pz + tb[1]) - tcurr[1];
+    const float dz = (Rb[6] * cx_ + Rb[7] * cy_ + Rb[8] * pz + tb[2]) - tcurr[2];
     const float xc = Rcurr[0] * dx + Rcurr[3] * dy + Rcurr[6] * dz;
     const float yc = Rcurr[1] * dx + Rcurr[4] * dy + Rcurr[7] * dz;
     const float zc = Rcurr[2] * dx + Rcurr[5] * dy + Rcurr[8] * dz;
     const float u = intr.fx * xc / zc + intr.cx, v = intr.fy * yc / zc + intr.cy;
-    const bool bad = !(zc > 0.05f) || !is_finite(u) || !is_finite(v);
+    const bool bad = !(znear > 0.05f) || !(zc > 0.05f) || !is_finite(u) || !is_finite(v);
     float u0 = u, u1 = u, v0 = v, v1 = v, z0 = zc, z1 = zc;
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) {
@@ -171,7 +178,7 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nlog)
     return (b & 7) * per + (b >> 3);
 }
 
-template <bool COMPACT> __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk);
+template <bool COMPACT> __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk, int nblk);
 
 // One launch per Gauss-Newton iteration carries BOTH pose-dependent streaming passes, which are independent
 // of each other: workgroups [0, n_icp_blocks) run the ICP reduction, the rest the RGB residual pass
@@ -206,9 +213,52 @@ extern __shared__ int gram_lds[];
 // (wave-uniform) loads are scalar loads whatever the compiler can prove about the stores around them -- with the run loop in the kernel
 // it fell back to per-lane vector loads of the pose, 44 more VGPRs and three waves of occupancy less.
 typedef const __attribute__((address_space(4))) OdomDev* StatePtr;
+// the hot state (cf_kernels.h: GnHot), one 64-byte line per s_load_dwordx16; hot_pin() keeps the loads of a clause together in front of
+// ONE wait (without it the compiler sinks each load to its first use: a chain of dependent round trips to memory again)
+typedef int hot16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ hot16 hot_line(StatePtr st, int line)
+{
+    return *(reinterpret_cast<const __attribute__((address_space(4))) hot16*>(&st->hot) + line);
+}
+__device__ __forceinline__ void hot_pin(const hot16& a) { asm volatile("" :: "s"(a)); }
+__device__ __forceinline__ void hot_pin(const hot16& a, const hot16& b) { asm volatile("" :: "s"(a), "s"(b)); }
+// (by value through __int_as_float: __builtin_bit_cast(float, l[k]) on a vector ELEMENT reads element 0 with this compiler -- ROCm 7.2 clang)
+__device__ __forceinline__ float hot_f(const hot16& l, int k) { const int v = l[k]; return __int_as_float(v); }
+struct IcpHot {   // lines 0 + 1
+    int icp, level_done; float zlo, zhi; m33 Rcurr, Rprev_inv; f3 tcurr, tprev; int box[4];
+};
+__device__ __forceinline__ IcpHot icp_hot(StatePtr st)
+{
+    hot16 l0 = hot_line(st, 0), l1 = hot_line(st, 1);
+    hot_pin(l0, l1);
+    IcpHot h;
+    h.icp = l0[0]; h.level_done = l0[1]; h.zlo = hot_f(l0, 2); h.zhi = hot_f(l0, 3);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { h.Rcurr.m[k] = hot_f(l0, 4 + k); h.Rprev_inv.m[k] = hot_f(l1, k); }
+    h.tcurr = f3{hot_f(l0, 13), hot_f(l0, 14), hot_f(l0, 15)};
+    h.tprev = f3{hot_f(l1, 9), hot_f(l1, 10), hot_f(l1, 11)};
+#pragma unroll
+    for (int k = 0; k < 4; k++) h.box[k] = l1[12 + k];
+    return h;
+}
+struct RgbHot { int rgb, rgbOnly, level_done; float krk[9], kt[3]; };   // line 2
+__device__ __forceinline__ RgbHot rgb_hot(StatePtr st)
+{
+    hot16 l2 = hot_line(st, 2);
+    hot_pin(l2);
+    RgbHot h;
+    h.rgb = l2[0]; h.rgbOnly = l2[1]; h.level_done = l2[2];
+#pragma unroll
+    for (int k = 0; k < 9; k++) h.krk[k] = hot_f(l2, 4 + k);
+#pragma unroll
+    for (int k = 0; k < 3; k++) h.kt[k] = hot_f(l2, 13 + k);
+    return h;
+}
+static_assert(offsetof(GnHot, Rcurr) == 16 && offsetof(GnHot, tcurr) == 52 && offsetof(GnHot, Rprev_inv) == 64 && offsetof(GnHot, tprev) == 100 &&
+              offsetof(GnHot, cull_box) == 112 && offsetof(GnHot, rgb) == 128 && offsetof(GnHot, krkInv) == 144 && offsetof(GnHot, kt) == 180, "icp_hot / rgb_hot spell the layout out");
 
 template <int PPT, bool GRAM>
-__device__ __forceinline__ bool icp_run(const IcpArgs& args, const IcpModelArgs& ma, StatePtr st, int i0, bool in_range,
+__device__ __forceinline__ bool icp_run(const IcpArgs& args, const IcpModelArgs& ma, StatePtr st, const IcpHot& pre, bool have_pre, int i0, bool in_range,
                                         bool whole, int band0, int band1, float* __restrict__ errs, int abl, int lane, int wave,
                                         unsigned long long& v, bool& gram_has, bool& done)
 {
@@ -224,12 +274,12 @@ __device__ __forceinline__ bool icp_run(const IcpArgs& args, const IcpModelArgs&
         load_vec<PPT>(vc + i0, vx); load_vec<PPT>(vc + i0 + N, vy); load_vec<PPT>(vc + i0 + 2 * N, vz);
         load_vec<PPT>(nc + i0, nx); load_vec<PPT>(nc + i0 + N, ny); load_vec<PPT>(nc + i0 + 2 * N, nz);
     }
-    if (!st->icp || st->level_done) return false;
-    m33 Rcurr, Rprev_inv;
-#pragma unroll
-    for (int i = 0; i < 9; i++) { Rcurr.m[i] = st->Rcurr[i]; Rprev_inv.m[i] = st->Rprev_inv[i]; }
-    const f3 tcurr = {st->tcurr[0], st->tcurr[1], st->tcurr[2]};
-    const f3 tprev = {st->tprev[0], st->tprev[1], st->tprev[2]};
+    IcpHot hs = pre;                              // (a caller that had to look at the box first hands the state in; otherwise its one
+                                                  // scalar round trip runs beside the plane loads just issued)
+    if (!have_pre) hs = icp_hot(st);
+    if (!hs.icp || hs.level_done) return false;
+    const m33 Rcurr = hs.Rcurr, Rprev_inv = hs.Rprev_inv;
+    const f3 tcurr = hs.tcurr, tprev = hs.tprev;
 
     // projection + gather of the model maps
     IcpProj pr[PPT];
@@ -332,10 +382,9 @@ __device__ __forceinline__ bool icp_run(const IcpArgs& args, const IcpModelArgs&
     return true;
 }
 
-// GRID.  One-dimensional: [ICP workgroups of slot 0 | slot 1 | ... | residual workgroups of model 0 | model 1 | ...], IcpArgs::blk_end
-// holds the running totals of the ICP part, IcpArgs::blk_model the model of every slot (the launcher puts the culled models first:
-// their waves have the longest chain of dependent memory round trips).  Every slot starts at a multiple of 8, so hardware workgroup b
-// and its slot-local index agree on the XCD (b % 8).
+// GRID.  One-dimensional, in SLOTS: a slot is the ICP reduction or the RGB residual pass of one model.  IcpArgs::slot_end holds the running
+// totals of the workgroups, IcpArgs::slot_desc what every slot is; the launcher orders them longest work first (launch_icp_kernel_arith).
+// Every slot starts at a multiple of 8, so hardware workgroup b and its slot-local index agree on the XCD (b % 8).
 //  * A model that is not culled gets one workgroup per run of T * PPT pixels of its image (or row band), XCD x owning the x-th
 //    horizontal band (xcd_logical_block).
 //  * A CULLED model (IcpModelArgs::box_blocks > 0) gets box_blocks workgroups -- sized by the host from the screen box the model ended
@@ -344,22 +393,22 @@ __device__ __forceinline__ bool icp_run(const IcpArgs& args, const IcpModelArgs&
 //    when the box has more runs than the host expected.  Until round 4 a culled model had the whole image's workgroups, 80 % of
 //    which read the box and left: 4 800 of the 7 500 workgroups of a five-model level-0 launch, dispatched ahead of the work that the
 //    launch waits for.  Sums are integers: which wave adds which pixel does not change a bit.
-template <int PPT, int LEVEL_TAG, bool GRAM>
-__global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, const RgbArgs ra, int n_icp_blocks)
+template <int PPT, bool GRAM>
+__device__ __forceinline__ void icp_reduce_body(const IcpArgs& args, const RgbArgs& ra, int n_icp_blocks)
 {
     const int b = blockIdx.x;
-    if (b >= n_icp_blocks) {
-        const int rb = b - n_icp_blocks;
-        const int model = args.n_res_blocks > 1 ? idiv(rb, args.res_div) : rb;
-        if (ABL(32) || (ABL(16) && args.m[model].cull)) return;  // timing ablations (CF_ICP_REPLAY)
-        if (ra.compact) rgb_residual_body<true>(ra, model, rb - model * args.n_res_blocks);
-        else rgb_residual_body<false>(ra, model, rb - model * args.n_res_blocks);
-        return;
-    }
     int slot = 0;
 #pragma unroll
-    for (int k = 0; k < kMaxBatch - 1; k++) slot += (b >= args.blk_end[k]) ? 1 : 0;  // (one wide scalar load of the table, 15 compares; unused slots end at INT_MAX)
-    const int model = args.blk_model[slot], bx = b - (slot ? args.blk_end[slot - 1] : 0);
+    for (int k = 0; k < 2 * kMaxBatch - 1; k++) slot += (b >= args.slot_end[k]) ? 1 : 0;  // (two wide scalar loads of the table, 31 compares; unused slots end at INT_MAX)
+    const int slot0 = slot ? args.slot_end[slot - 1] : 0, bx = b - slot0;
+    const unsigned desc = args.slot_desc[slot];
+    const int model = (int)(desc & 0x7fu);
+    if (desc & kResidualSlot) {
+        if (ABL(32) || (ABL(16) && args.m[model].cull)) return;  // timing ablations (CF_ICP_REPLAY)
+        if (ra.compact) rgb_residual_body<true>(ra, model, bx, args.slot_end[slot] - slot0);
+        else rgb_residual_body<false>(ra, model, bx, 0);
+        return;
+    }
     const IcpModelArgs& ma = args.m[model];
     if (ABL(256) && !ma.cull) return;  // timing ablation (CF_ICP_REPLAY): unculled models do nothing
     StatePtr st = (StatePtr)ma.st;
@@ -372,14 +421,15 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
 
     if (ma.box_blocks > 0) {  // culled model, runs of its screen box (the launcher: PPT == 1, product form, no error surface)
         if (ABL(8)) return;  // timing ablation: culled models do nothing
-        if (!st->icp || st->level_done) return;
+        const IcpHot hs = icp_hot(st);
+        if (!hs.icp || hs.level_done) return;
         const int L = 2 - args.occ_shift;
-        const int box[4] = {st->stats.cull_box[0], st->stats.cull_box[1], st->stats.cull_box[2], st->stats.cull_box[3]};
+        const int box[4] = {hs.box[0], hs.box[1], hs.box[2], hs.box[3]};
         const CullRuns cr = cull_runs(box, L, cols, rows);
         if (ABL(512)) return;  // timing ablation (CF_ICP_REPLAY): the cull test alone
         const int wpb = T >> 6, stride = ma.box_blocks * wpb;
         const float rcp = __builtin_amdgcn_rcpf((float)(cr.nrx > 0 ? cr.nrx : 1));
-        const float zlo = st->cull_z[0], zhi = st->cull_z[1];
+        const float zlo = hs.zlo, zhi = hs.zhi;
 #pragma nounroll
         for (int r = bx * wpb + __builtin_amdgcn_readfirstlane(wave); r < cr.total; r += stride) {
             int start;
@@ -399,7 +449,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
             if (in_range && ma.zr) { const float2 zz = ma.zr[start >> 6]; if (!(zz.x <= zhi && zz.y >= zlo)) in_range = false; }
             const int i0 = start + lane;
             unsigned long long vr = 0;
-            if (!icp_run<1, false>(args, ma, st, i0, in_range && i0 < N, false, 0, N, nullptr, abl, lane, wave, vr, gram_has, done)) return;
+            if (!icp_run<1, false>(args, ma, st, hs, true, i0, in_range && i0 < N, false, 0, N, nullptr, abl, lane, wave, vr, gram_has, done)) return;
             if (done) return;
             v += vr;
         }
@@ -431,15 +481,18 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
 
     const int i0 = pix0 + (lb * T + threadIdx.x) * PPT;
     bool in_range = i0 < pix1;  // cols is a multiple of PPT, so the whole vector is in range
+    const bool cull_here = ma.cull && !err_here;
+    IcpHot hs{};
+    if (cull_here) hs = icp_hot(st);
     // (Measured and dropped, round 3: issuing the plane loads BEFORE the box test, so that in-box waves would not pay the box's scalar
     // round trip in front of them: 22.3 against 21.5 us.)
     // Screen-box culling on the whole-image mapping (Gram form, several pixels per lane, stand-alone steps): a workgroup whose pixel
     // run misses the rectangle leaves after one scalar load; inside a workgroup that straddles it, the waves outside load nothing and
     // go straight to the commit.  Not on the error-surface iteration, which writes every pixel.
-    if (ma.cull && !err_here) {
+    if (cull_here) {
         if (ABL(8)) return;  // timing ablation: culled models do nothing
         const int L = 2 - args.occ_shift;
-        const int bx0 = (st->stats.cull_box[0] >> L) - 1, by0 = (st->stats.cull_box[1] >> L) - 1, bx1 = (st->stats.cull_box[2] >> L) + 1, by1 = (st->stats.cull_box[3] >> L) + 1;
+        const int bx0 = (hs.box[0] >> L) - 1, by0 = (hs.box[1] >> L) - 1, bx1 = (hs.box[2] >> L) + 1, by1 = (hs.box[3] >> L) + 1;
         const int p0 = pix0 + lb * T * PPT, p1 = min(p0 + T * PPT, pix1) - 1;  // first / last pixel of this workgroup
         const int r0 = idiv(p0, args.cdiv), r1 = idiv(p1, args.cdiv);
         if (r1 < by0 || r0 > by1) return;
@@ -451,7 +504,7 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
         // ... and by depth: the run of 64 pixels this wave owns (per pixel of a lane) carries the interval of its valid depths
         // (frame_maps_kernel); if it misses the interval the model's dilated box spans in this camera, no pixel of the run can match
         if (in_range && ma.zr && w0 <= w1) {
-            const float zlo = st->cull_z[0], zhi = st->cull_z[1];
+            const float zlo = hs.zlo, zhi = hs.zhi;
             bool any = false;
 #pragma unroll
             for (int p = 0; p < PPT; p++) {
@@ -461,10 +514,37 @@ __global__ void __launch_bounds__(1024) icp_reduce_kernel(const IcpArgs args, co
             if (!any) in_range = false;
         }
     }
-    if (!icp_run<PPT, GRAM>(args, ma, st, i0, in_range, whole, band0, band1, errs, abl, lane, wave, v, gram_has, done)) return;
+    if (!icp_run<PPT, GRAM>(args, ma, st, hs, cull_here, i0, in_range, whole, band0, band1, errs, abl, lane, wave, v, gram_has, done)) return;
     if (done) return;
     if constexpr (GRAM) gram_block_commit(gram_lds, gram_has, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
     else block_commit32<16>(v, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
+}
+
+#ifdef CF_ABLATE
+// diagnostics build: per-workgroup begin / end stamps of one launch (CF_ICP_TRACE, cabi.hip) -- [workgroup][4] = begin, end (100 MHz
+// constant clock), XCC_ID | HW_ID << 8, 0
+__device__ unsigned long long* g_icp_trace = nullptr;
+#endif
+template <int PPT, int LEVEL_TAG, bool GRAM>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PPT == 1 && !GRAM ? 7 : 1))) icp_reduce_kernel(const IcpArgs args, const RgbArgs ra, int n_icp_blocks)
+{
+#ifdef CF_ABLATE
+    unsigned long long* const tr = g_icp_trace;
+    unsigned long long t0 = 0;
+    if (tr) t0 = wall_clock64();
+#endif
+    icp_reduce_body<PPT, GRAM>(args, ra, n_icp_blocks);
+#ifdef CF_ABLATE
+    if (tr) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t1 = wall_clock64();
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u, hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            unsigned long long* o = tr + (size_t)blockIdx.x * 4;
+            o[0] = t0; o[1] = t1; o[2] = xcc | ((unsigned long long)hwid << 8); o[3] = 0;
+        }
+    }
+#endif
 }
 
 // host side: the f32 bounds that decide "sqrtf(x) < T" and "sqrtf(x) <= T" exactly (sqrtf is correctly rounded, monotonic)
@@ -540,23 +620,40 @@ __device__ __forceinline__ bool rgb_residual_pixel(const RgbArgs& ra, const RgbM
 // workgroup are packed into that workgroup's own slot of the record buffer (8 B records, slot = 4 x workgroup size; places
 // inside the slot come from LDS atomics, the count goes to slot_counts[workgroup]) -- no global atomic and no extra memory
 // round trip on the producer side.  The order inside a slot depends on the schedule, the sums taken over it do not.
+//
+// Slots of a culled tracker (round 5).  An object model's candidate mask is empty outside its prediction, and until round 5 the
+// ~1200 waves per object that found nothing but an empty mask word were 4 800 of the level-0 launch's 16 700.  The preparation now
+// records the first and the last 256-pixel chunk with a candidate (RgbModelArgs::res_range); this tracker's `nblk` workgroups -- sized by
+// the host from what the previous call saw -- take the slots in between, walking on by nblk when there are more than expected.
+// Slots outside hold no record: the RGB step applies the same test instead of reading their (stale) counts.
+struct SlotRange { int first, last; };
+__device__ __forceinline__ SlotRange residual_slot_range(const RgbArgs& ra, const RgbModelArgs& m, int n_slots)
+{
+    if (!m.res_range) return SlotRange{0, n_slots - 1};
+    const unsigned lo_inv = m.res_range[0], hi_p1 = m.res_range[1];   // (uniform: scalar loads)
+    if (hi_p1 == 0) return SlotRange{0, -1};
+    const int sh = __builtin_ctz(ra.slot_px) - 8;                     // slot_px = 4 x workgroup size: a power of two >= 256
+    return SlotRange{(int)((~lo_inv) >> sh), min((int)((hi_p1 - 1u) >> sh), n_slots - 1)};
+}
+
 template <bool COMPACT>
-__device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
+__device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk, int nblk)
 {
     const RgbModelArgs& m = ra.m[model];
-    const OdomDev* __restrict__ od = m.st;
+    StatePtr st = (StatePtr)m.st;
     const int cols = ra.cols, rows = ra.rows, N = cols * rows;
     const int T = blockDim.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if constexpr (!COMPACT) {
-        if (!od->rgb || od->level_done) return;
+        const RgbHot hs = rgb_hot(st);
+        if (!hs.rgb || hs.level_done) return;
         const int k = blk * T + threadIdx.x;
         int cnt = 0, sig = 0;
         if (k < N) {
             cf_dataterm c; c.zero_x = c.zero_y = c.one_x = c.one_y = 0; c.diff = 0.f; c.valid = 0;
             if (m.cand[k]) {
                 int u0, v0; float diff;
-                if (rgb_residual_pixel(ra, m, od->krkInv, od->kt, k, m.nextDepth[k], (float)m.nextImage[k], u0, v0, diff)) {
+                if (rgb_residual_pixel(ra, m, hs.krk, hs.kt, k, m.nextDepth[k], (float)m.nextImage[k], u0, v0, diff)) {
                     const int y = idiv(k, ra.cdiv), x = k - y * cols;
                     c.zero_x = (int16_t)u0; c.zero_y = (int16_t)v0; c.one_x = (int16_t)x; c.one_y = (int16_t)y;
                     c.diff = diff; c.valid = 1;
@@ -580,12 +677,17 @@ __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
         }
     } else {
         __shared__ int s_n, s_sig;
+        const int n_slots = (N + T * 4 - 1) / (T * 4);
+        const SlotRange sr = residual_slot_range(ra, m, n_slots);
+        const RgbHot hs = rgb_hot(st);   // (one scalar clause beside the range's)
+        const bool on = hs.rgb && !hs.level_done;  // uniform
+        if (!on) return;
+#pragma nounroll
+        for (blk += sr.first; blk <= sr.last; blk += max(nblk, 1)) {
         const int k0 = (blk * T + threadIdx.x) * 4;  // cols % 4 == 0: the four pixels share a row
         unsigned cw = 0;
         if (k0 < N) cw = *reinterpret_cast<const unsigned*>(m.cand + k0);
         if (threadIdx.x == 0) { s_n = 0; s_sig = 0; }
-        const bool on = od->rgb && !od->level_done;  // uniform
-        if (!on) return;
         __syncthreads();
         if (__any(cw != 0)) {
             int g[4], dq[4], nvalid = 0, sig = 0;
@@ -595,15 +697,30 @@ __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
                 d1[0] = dv.x; d1[1] = dv.y; d1[2] = dv.z; d1[3] = dv.w;
                 iw = *reinterpret_cast<const unsigned*>(m.nextImage + k0);
             }
+            // RGBResidual::getProducts (reduce.cu:785-865), the pose-dependent half, in three phases so that the gathers of a thread's four
+            // pixels are in flight TOGETHER: until round 5 each pixel ran project -> gather depth -> test -> gather intensity before the
+            // next one started -- eight dependent round trips per thread, 6 us per background workgroup (tools/icp_trace_summary.py).
+            const int y = idiv(k0, ra.cdiv), x0 = k0 - y * cols;
+            float td1[4]; int gi[4]; bool inb[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int x = x0 + p;
+                td1[p] = (float)(d1[p] * (hs.krk[6] * x + hs.krk[7] * y + hs.krk[8]) + hs.kt[2]);
+                const int u0 = f2i_rn((d1[p] * (hs.krk[0] * x + hs.krk[1] * y + hs.krk[2]) + hs.kt[0]) / td1[p]);
+                const int v0 = f2i_rn((d1[p] * (hs.krk[3] * x + hs.krk[4] * y + hs.krk[5]) + hs.kt[1]) / td1[p]);
+                inb[p] = ((cw >> (8 * p)) & 0xffu) != 0 && u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows;
+                gi[p] = inb[p] ? v0 * cols + u0 : 0;
+            }
+            float d0[4]; unsigned li[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) { d0[p] = 0.f; li[p] = 0; if (inb[p]) { d0[p] = m.lastDepth[gi[p]]; li[p] = m.lastImage[gi[p]]; } }
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 g[p] = -1; dq[p] = 0;
-                if ((cw >> (8 * p)) & 0xffu) {
-                    int u0, v0; float diff;
-                    if (rgb_residual_pixel(ra, m, od->krkInv, od->kt, k0 + p, d1[p], (float)((iw >> (8 * p)) & 0xffu), u0, v0, diff)) {
-                        g[p] = v0 * cols + u0; dq[p] = (int)diff;  // next - last intensity: an integer in [-255, 255]
-                        nvalid++; sig += (int)(diff * diff);
-                    }
+                if (inb[p] && d0[p] > 0 && fabsf(td1[p] - d0[p]) <= ra.maxDepthDelta && li[p] != 0) {
+                    const float diff = (float)((iw >> (8 * p)) & 0xffu) - (float)li[p];
+                    g[p] = gi[p]; dq[p] = (int)diff;  // next - last intensity: an integer in [-255, 255]
+                    nvalid++; sig += (int)(diff * diff);
                 }
             }
             int wn = nvalid, ws = sig;
@@ -630,10 +747,11 @@ __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk)
             if (bn && !m.no_counts) atomicAdd(&dst[29], (unsigned long long)bn);
             if (g4 && !m.no_counts) atomicAdd(&dst[30], (unsigned long long)(long long)g4);
         }
+        }   // (thread 0 has read s_n / s_sig before it clears them for the next slot; everybody else meets it at the barrier behind that)
     }
 }
 
-__global__ void __launch_bounds__(1024) rgb_residual_kernel(const RgbArgs ra) { rgb_residual_body<false>(ra, blockIdx.y, blockIdx.x); }
+__global__ void __launch_bounds__(1024) rgb_residual_kernel(const RgbArgs ra) { rgb_residual_body<false>(ra, blockIdx.y, blockIdx.x, 0); }
 
 // sum of word `w` over the groups (wave 0 only; result valid in all lanes of wave 0)
 __device__ __forceinline__ unsigned long long group_sum(const unsigned long long* acc, int w, int lane)
@@ -680,14 +798,14 @@ __device__ __forceinline__ void rgb_step_row(const RgbArgs& ra, const RgbModelAr
 __global__ void __launch_bounds__(256) rgb_step_kernel(const RgbArgs ra)
 {
     const RgbModelArgs& m = ra.m[blockIdx.y];
-    OdomDev* const od = m.st;
-    if (od->rgb && !od->level_done) {
+    const RgbHot hs = rgb_hot((StatePtr)m.st);
+    if (hs.rgb && !hs.level_done) {
         const int cols = ra.cols, rows = ra.rows, N = cols * rows;
         __shared__ float s_sigma;
         if (threadIdx.x < 64) {
             const long long cnt = (long long)group_sum(m.icp_acc, 29, threadIdx.x);
             const long long sg = (long long)group_sum(m.icp_acc, 30, threadIdx.x);
-            if (threadIdx.x == 0) s_sigma = sigma_val_from((int)cnt, (int)sg, od->rgbOnly);
+            if (threadIdx.x == 0) s_sigma = sigma_val_from((int)cnt, (int)sg, hs.rgbOnly);
         }
         const int i = blockIdx.x * 256 + threadIdx.x;
         int4 raw = make_int4(0, 0, 0, 0);
@@ -1007,7 +1125,7 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(const TrackerStates t
         if (__shfl((int)key, 3, 64) == 0) { lo[0] = 1.f; hi[0] = 0.f; }  // never written: empty
         int ib[4] = {0, 0, od->width - 1, od->height - 1};
         float zb[2] = {-__int_as_float(0x7f800000), __int_as_float(0x7f800000)};
-        if (od->cull) screen_box(lo, hi, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, lane, ib, zb);
+        if (od->cull) screen_box(lo, hi, od->box_R, od->box_t, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, lane, ib, zb);
         if (lane == 0) {
             for (int k = 0; k < 3; k++) { god->box_lo[k] = lo[k]; god->box_hi[k] = hi[k]; }
             for (int k = 0; k < 4; k++) god->stats.cull_box[k] = ib[k];
@@ -1023,6 +1141,7 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(const TrackerStates t
         god->level_done = 0;
         god->residual[0] = 0; god->residual[1] = 0;
         prepare_iteration(god, first_level);
+        refresh_hot(god);   // what the workgroups of the per-iteration launches read (cf_kernels.h: GnHot)
     }
 }
 
@@ -1070,7 +1189,7 @@ static_assert(kGramBits[0] == 20 && kGramBits[2] == 20 && kGramBits[3] == 17 && 
 //  * only Rodrigues and the 3x3 pose composition stay on one lane.
 // Must be called by all 256 threads of a workgroup.
 __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigned long long* icp_acc, unsigned long long* rgb_acc, int next_level,
-                                              int last_of_level, OdomDev* god_host)
+                                              int last_of_level, OdomDev* god_host, int slot_px)
 {
     __shared__ OdomDev s_od;
     __shared__ unsigned long long s_icp[32], s_rgb[32];
@@ -1192,7 +1311,7 @@ __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigne
     __syncthreads();
     if (next_level >= 0 && od->cull && tid >= 128 && tid < 192) {  // an idle wave: the screen box under the new pose
         int ib[4]; float zb[2];
-        screen_box(od->box_lo, od->box_hi, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, tid - 128, ib, zb);
+        screen_box(od->box_lo, od->box_hi, od->box_R, od->box_t, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, tid - 128, ib, zb);
         if (tid == 128) {
             od->stats.cull_box[0] = ib[0]; od->stats.cull_box[1] = ib[1]; od->stats.cull_box[2] = ib[2]; od->stats.cull_box[3] = ib[3];
             od->cull_z[0] = zb[0]; od->cull_z[1] = zb[1];
@@ -1213,12 +1332,37 @@ __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigne
             const int r = tid - 16;
             od->kt[r] = (float)(s_K[r * 3 + 0] * s_Rt[3] + s_K[r * 3 + 1] * s_Rt[7] + s_K[r * 3 + 2] * s_Rt[11]);
         }
-    } else if (tid == 0 && od->rgb) {  // end of the schedule: divergence guard (RGBDOdometry.cpp:464-467)
-        const float d0 = od->tcurr[0] - od->tprev[0], d1 = od->tcurr[1] - od->tprev[1], d2 = od->tcurr[2] - od->tprev[2];
-        if ((double)sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
-            for (int k = 0; k < 9; k++) od->Rcurr[k] = od->Rprev[k];
-            for (int k = 0; k < 3; k++) od->tcurr[k] = od->tprev[k];
+    } else {
+        if (tid == 0 && od->rgb) {  // end of the schedule: divergence guard (RGBDOdometry.cpp:464-467)
+            const float d0 = od->tcurr[0] - od->tprev[0], d1 = od->tcurr[1] - od->tprev[1], d2 = od->tcurr[2] - od->tprev[2];
+            if ((double)sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
+                for (int k = 0; k < 9; k++) od->Rcurr[k] = od->Rprev[k];
+                for (int k = 0; k < 3; k++) od->tcurr[k] = od->tprev[k];
+            }
         }
+        // ... and the candidate range of a culled tracker: how many record slots each level needed goes back to the host (it sizes the
+        // next call's residual workgroups), the accumulator is cleared for the next call's preparation
+        if (tid >= 64 && tid < 67 && od->res_range) {
+            unsigned* rr = od->res_range + 2 * (tid - 64);
+            const unsigned lo_inv = rr[0], hi_p1 = rr[1];
+            const int sh = __builtin_ctz(slot_px) - 8;
+            od->res_seen[tid - 64] = hi_p1 ? (int)(((hi_p1 - 1u) >> sh) - ((~lo_inv) >> sh)) + 1 : 0;
+            rr[0] = 0; rr[1] = 0;
+        }
+    }
+    __syncthreads();
+    if (tid < 48) {   // refresh_hot(od), one word per lane: hot word `tid` <- its source field
+        constexpr int o_icp = (int)(offsetof(OdomDev, icp) / 4), o_ld = (int)(offsetof(OdomDev, level_done) / 4), o_cz = (int)(offsetof(OdomDev, cull_z) / 4),
+                      o_Rc = (int)(offsetof(OdomDev, Rcurr) / 4), o_tc = (int)(offsetof(OdomDev, tcurr) / 4), o_Ri = (int)(offsetof(OdomDev, Rprev_inv) / 4),
+                      o_tp = (int)(offsetof(OdomDev, tprev) / 4), o_cb = (int)((offsetof(OdomDev, stats) + offsetof(cf_track_stats, cull_box)) / 4),
+                      o_rgb = (int)(offsetof(OdomDev, rgb) / 4), o_ro = (int)(offsetof(OdomDev, rgbOnly) / 4), o_krk = (int)(offsetof(OdomDev, krkInv) / 4),
+                      o_kt = (int)(offsetof(OdomDev, kt) / 4), o_hot = (int)(offsetof(OdomDev, hot) / 4);
+        const int w = tid;
+        const int src = w < 1 ? o_icp : w < 2 ? o_ld : w < 4 ? o_cz + (w - 2) : w < 13 ? o_Rc + (w - 4) : w < 16 ? o_tc + (w - 13) : w < 25 ? o_Ri + (w - 16)
+                      : w < 28 ? o_tp + (w - 25) : w < 32 ? o_cb + (w - 28) : w < 33 ? o_rgb : w < 34 ? o_ro : w < 35 ? o_ld : w < 36 ? -1
+                      : w < 45 ? o_krk + (w - 36) : o_kt + (w - 45);
+        unsigned* words = reinterpret_cast<unsigned*>(&s_od);
+        words[o_hot + w] = src >= 0 ? words[src] : 0u;
     }
     __syncthreads();
     for (int k = kMutableFrom + tid; k < kWords; k += 256) reinterpret_cast<unsigned*>(god)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
@@ -1230,7 +1374,7 @@ __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigne
 
 __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int next_level, int last_of_level)
 {
-    gn_solve_body(args.icp_gram ? -1 : kFixICP, args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level, args.od_host[blockIdx.x]);
+    gn_solve_body(args.icp_gram ? -1 : kFixICP, args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level, args.od_host[blockIdx.x], args.slot_px);
 }
 
 // The ICP error surface (icpStep's optional output, reduce.cu:327-331 / RGBDOdometry.cpp:414-431: the distance between every pixel's
@@ -1249,12 +1393,10 @@ __device__ __forceinline__ void icp_error_surface_body(const IcpArgs& args, cons
     const bool in_range = i < N;
     float vx = qnan(), vy = qnan(), vz = qnan();
     if (in_range) { vx = ma.vc[i]; vy = ma.vc[i + N]; vz = ma.vc[i + 2 * N]; }
-    if (!st->icp || st->level_done) return;  // (icp_run leaves before it writes anything)
-    m33 Rcurr, Rprev_inv;
-#pragma unroll
-    for (int k = 0; k < 9; k++) { Rcurr.m[k] = st->Rcurr[k]; Rprev_inv.m[k] = st->Rprev_inv[k]; }
-    const f3 tcurr = {st->tcurr[0], st->tcurr[1], st->tcurr[2]};
-    const f3 tprev = {st->tprev[0], st->tprev[1], st->tprev[2]};
+    const IcpHot hs = icp_hot(st);
+    if (!hs.icp || hs.level_done) return;  // (icp_run leaves before it writes anything)
+    const m33 Rcurr = hs.Rcurr, Rprev_inv = hs.Rprev_inv;
+    const f3 tcurr = hs.tcurr, tprev = hs.tprev;
     if (!in_range) return;
     const IcpProj pr = icp_project(Rcurr, tcurr, Rprev_inv, tprev, args.intr, cols, rows, f3{vx, vy, vz});
     f3 vprev = {qnan(), qnan(), qnan()};
@@ -1278,18 +1420,22 @@ __global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra, co
 {
     if ((int)blockIdx.x >= n_slots) { icp_error_surface_body(ea, ea.m[blockIdx.y], (int)blockIdx.x - n_slots); return; }
     const RgbModelArgs& m = ra.m[blockIdx.y];
-    const OdomDev* __restrict__ od = m.st;
+    const RgbHot hs = rgb_hot((StatePtr)m.st);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t slot0 = (size_t)blockIdx.x * ra.slot_px;
-    const unsigned n = m.slot_counts[blockIdx.x];
+    unsigned n = m.slot_counts[blockIdx.x];
+    {   // (a slot outside a culled tracker's candidate range was not visited by the residual pass: its count is stale, it holds nothing)
+        const SlotRange sr = residual_slot_range(ra, m, n_slots);
+        if ((int)blockIdx.x < sr.first || (int)blockIdx.x > sr.last) n = 0;
+    }
     uint2 rc = make_uint2(0, 0);
     if (tid < ra.slot_px && slot0 + tid < (size_t)ra.cols * ra.rows) rc = m.recs[slot0 + tid];   // speculative: valid if tid < n
-    if (!(od->rgb && !od->level_done) || n == 0) return;  // uniform
+    if (!(hs.rgb && !hs.level_done) || n == 0) return;  // uniform
     __shared__ float s_sigma;
     if (tid < 64) {
         const long long cnt = (long long)group_sum(m.icp_acc, 29, tid);
         const long long sg = (long long)group_sum(m.icp_acc, 30, tid);
-        if (tid == 0) s_sigma = sigma_val_from((int)cnt, (int)sg, od->rgbOnly);
+        if (tid == 0) s_sigma = sigma_val_from((int)cnt, (int)sg, hs.rgbOnly);
     }
     __syncthreads();
     const float sigma = s_sigma;
@@ -1328,6 +1474,9 @@ __global__ void __launch_bounds__(64) acc_total_kernel(const unsigned long long*
 // ------------------------------------------------------------------------------ launchers ----
 // ev0/ev1 (nullable) receive the dispatch's own begin/end timestamps (the figures rocprofv3 reports), not the
 // stream time around it.  n_res_blocks > 0 appends the RGB residual workgroups to the same launch.
+#ifdef CF_ABLATE
+static IcpArgs g_last_icp_args; static int g_last_n_icp_blocks = 0, g_last_grid = 0;
+#endif
 template <int TAG, bool GRAM>
 static void launch_icp_kernel_arith(hipStream_t s, IcpLaunch cfg, const IcpArgs& args_in, const RgbArgs& ra_in, bool icp, int n_res_blocks, int n,
                                     hipEvent_t ev0, hipEvent_t ev1)
@@ -1348,14 +1497,56 @@ static void launch_icp_kernel_arith(hipStream_t s, IcpLaunch cfg, const IcpArgs&
         ma.box_blocks = ok ? (ma.box_blocks < full ? ((ma.box_blocks + 7) / 8) * 8 : full) : 0;
         blocks[m] = ok ? ma.box_blocks : full;
     }
-    int n_icp_blocks = 0, slot = 0;
-    if (icp)
-        for (int pass = 0; pass < 2; pass++)  // culled models first
-            for (int m = 0; m < n; m++)
-                if ((args.m[m].box_blocks > 0) == (pass == 0)) { n_icp_blocks += blocks[m]; args.blk_end[slot] = n_icp_blocks; args.blk_model[slot] = m; slot++; }
-    for (; slot < kMaxBatch; slot++) { args.blk_end[slot] = 0x7fffffff; args.blk_model[slot] = 0; }
-    args.n_res_blocks = n_res_blocks; args.res_div = make_idiv(n_res_blocks > 1 ? n_res_blocks : 2);
-    const dim3 grid(n_icp_blocks + n_res_blocks * n);
+    // residual workgroups: one per record slot of the level, or the caller's RgbModelArgs::res_blocks (culled trackers: the slots between
+    // the first and the last candidate the previous call saw, residual_blocks_for)
+    for (int m = 0; m < n && n_res_blocks > 0; m++) {
+        RgbModelArgs& rm = ra.m[m];
+        if (!ra.compact || !rm.res_range || rm.res_blocks <= 0 || rm.res_blocks > n_res_blocks) rm.res_blocks = n_res_blocks;
+        if (!ra.compact) rm.res_range = nullptr;
+    }
+    // ORDER OF THE SLOTS = order of dispatch.  The launch is a little over one round of resident workgroups (about 1 400 at a time,
+    // tools/icp_trace_summary.py), so what is dispatched last ends last: longest work first -- the residual pass of the unculled
+    // trackers (a background workgroup finds ~100 correspondences: 6 us), their ICP reduction (4.6 us), then the culled trackers' runs
+    // (3-5 us) and their residual slots (2 us).  Until round 5 the culled runs came first and the residual passes last: the launch ended
+    // on a 5 us tail of background residual workgroups.  Every slot is padded to a multiple of 8 workgroups so that the hardware
+    // workgroup id and the slot-local index agree on the XCD; the padding leaves at once.
+    int total = 0, slot = 0, n_icp_blocks = 0;
+    auto add = [&](int m, bool residual, int count) {
+        total += ((count + 7) / 8) * 8;
+        args.slot_end[slot] = total; args.slot_desc[slot] = (unsigned char)(m | (residual ? kResidualSlot : 0)); slot++;
+        if (!residual) n_icp_blocks += count;
+    };
+#ifdef CF_ABLATE
+    static const int order = getenv("CF_ICP_ORDER") ? atoi(getenv("CF_ICP_ORDER")) : 1;
+#else
+    constexpr int order = 1;
+#endif
+    const bool res = n_res_blocks > 0;
+    auto culled = [&](int m) { return args.m[m].box_blocks > 0 || (args.m[m].cull && ra.m[m].res_range); };
+    if (order == 0) {          // rounds 3-4: culled ICP, unculled ICP, residual passes
+        for (int pass = 0; pass < 2 && icp; pass++) for (int m = 0; m < n; m++) if ((args.m[m].box_blocks > 0) == (pass == 0)) add(m, false, blocks[m]);
+        for (int m = 0; m < n && res; m++) add(m, true, ra.m[m].res_blocks);
+    } else if (order == 2) {   // unculled ICP, unculled residual, culled ICP, culled residual
+        for (int m = 0; m < n && icp; m++) if (!(args.m[m].box_blocks > 0)) add(m, false, blocks[m]);
+        for (int m = 0; m < n && res; m++) if (!culled(m)) add(m, true, ra.m[m].res_blocks);
+        for (int m = 0; m < n && icp; m++) if (args.m[m].box_blocks > 0) add(m, false, blocks[m]);
+        for (int m = 0; m < n && res; m++) if (culled(m)) add(m, true, ra.m[m].res_blocks);
+    } else if (order == 3) {   // unculled residual, culled ICP, unculled ICP, culled residual
+        for (int m = 0; m < n && res; m++) if (!culled(m)) add(m, true, ra.m[m].res_blocks);
+        for (int m = 0; m < n && icp; m++) if (args.m[m].box_blocks > 0) add(m, false, blocks[m]);
+        for (int m = 0; m < n && icp; m++) if (!(args.m[m].box_blocks > 0)) add(m, false, blocks[m]);
+        for (int m = 0; m < n && res; m++) if (culled(m)) add(m, true, ra.m[m].res_blocks);
+    } else {                   // longest first
+        for (int m = 0; m < n && res; m++) if (!culled(m)) add(m, true, ra.m[m].res_blocks);
+        for (int m = 0; m < n && icp; m++) if (!(args.m[m].box_blocks > 0)) add(m, false, blocks[m]);
+        for (int m = 0; m < n && icp; m++) if (args.m[m].box_blocks > 0) add(m, false, blocks[m]);
+        for (int m = 0; m < n && res; m++) if (culled(m)) add(m, true, ra.m[m].res_blocks);
+    }
+    for (; slot < 2 * kMaxBatch; slot++) { args.slot_end[slot] = 0x7fffffff; args.slot_desc[slot] = 0; }
+    const dim3 grid(total);
+#ifdef CF_ABLATE
+    g_last_icp_args = args; g_last_n_icp_blocks = n_icp_blocks; g_last_grid = (int)grid.x;
+#endif
     const unsigned lds = GRAM ? (unsigned)(cfg.threads / 64) * kGramWaveDwords * sizeof(int) : 0u;
     if (!ev0 && !ev1) {  // plain launches (also what a stream capture records)
         switch (cfg.ppt) {
@@ -1430,10 +1621,11 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
     }
     GnArgs gn{};
     gn.icp_gram = cfg.gram;
+    gn.slot_px = cfg.threads * 4;
     for (int m = 0; m < n; m++) {
         gn.od[m] = const_cast<OdomDev*>(icp_args[0].m[m].st);
         gn.icp_acc[m] = icp_args[0].m[m].acc;
-        gn.rgb_acc[m] = icp_args[0].m[m].rgb_acc;
+        gn.rgb_acc[m] = rgb_args[0].m[m].rgb_acc;
         gn.od_host[m] = h_states ? h_states[m] : nullptr;
     }
     const bool slots = mode != 0;
@@ -1500,6 +1692,42 @@ float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const R
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     return ms * 1000.f / reps;
 }
+
+#ifdef CF_ABLATE
+// diagnostics (CF_ICP_TRACE): the level-0 {ICP || residual} launch of a batch three times back to back, the third with per-workgroup
+// stamps; writes "workgroup kind model begin_ns end_ns xcc hwid" lines (kind: 0 culled ICP, 1 unculled ICP, 2 residual) to `path`
+void trace_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, const char* path)
+{
+    IcpArgs a = a0; a.flags = 0;
+    RgbArgs ra = r0; ra.compact = slots ? 1 : 0; ra.slot_px = cfg.threads * 4;
+    unsigned long long* d = nullptr; unsigned long long* none = nullptr;
+    const size_t cap = 1u << 16;
+    if (hipMalloc(reinterpret_cast<void**>(&d), cap * 32) != hipSuccess) return;
+    (void)hipMemset(d, 0, cap * 32);
+    for (int i = 0; i < 2; i++) launch_icp_rgbres(s, cfg, a, ra, true, true, n, 0, nullptr, nullptr);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_trace), &d, sizeof(d));
+    launch_icp_rgbres(s, cfg, a, ra, true, true, n, 0, nullptr, nullptr);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_trace), &none, sizeof(none));
+    std::vector<unsigned long long> h((size_t)g_last_grid * 4);
+    (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    FILE* f = fopen(path, "w");
+    if (!f) return;
+    unsigned long long tmin = ~0ull;
+    for (int b = 0; b < g_last_grid; b++) if (h[(size_t)b * 4] && h[(size_t)b * 4] < tmin) tmin = h[(size_t)b * 4];
+    fprintf(f, "# grid %d icp_blocks %d trackers %d\n", g_last_grid, g_last_n_icp_blocks, n);
+    for (int b = 0; b < g_last_grid; b++) {
+        int slot = 0; while (slot < 2 * kMaxBatch - 1 && b >= g_last_icp_args.slot_end[slot]) slot++;
+        const int model = g_last_icp_args.slot_desc[slot] & 0x7f;
+        const int kind = (g_last_icp_args.slot_desc[slot] & kResidualSlot) ? 2 : (g_last_icp_args.m[model].box_blocks > 0 ? 0 : 1);
+        const unsigned long long* o = &h[(size_t)b * 4];
+        fprintf(f, "%d %d %d %lld %lld %u %u\n", b, kind, model, (long long)(o[0] - tmin) * 10, (long long)(o[1] - tmin) * 10, (unsigned)(o[2] & 255u), (unsigned)(o[2] >> 8));
+    }
+    fclose(f);
+}
+#endif
 
 // ---- stand-alone steps (C-ABI parity with computeRgbResidual / rgbStep) -------------------
 void launch_rgb_residual(hipStream_t s, const RgbArgs& ra, int n)

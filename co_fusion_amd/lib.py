@@ -11,7 +11,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CF_HIP_LIB: another build of the C-ABI library (A/B micro-benchmarks against an earlier build; diagnostics only)
-LIB_PATH = os.environ.get("CF_HIP_LIB") or os.path.join(_HERE, "lib", "libcofusion_hip.so")
+# CF_LIB_DIR: a whole diagnostics build (make ABLATE=1 LIBDIR=../lib_ablate in csrc/ and host/: both libraries side by side)
+_LIB_DIR = os.environ.get("CF_LIB_DIR") or os.path.join(_HERE, "lib")
+LIB_PATH = os.environ.get("CF_HIP_LIB") or os.path.join(_LIB_DIR, "libcofusion_hip.so")
 
 # every symbol include/cofusion_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -46,7 +48,7 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
-HOST_LIB_PATH = os.path.join(_HERE, "lib", "libcofusion.so")
+HOST_LIB_PATH = os.path.join(_LIB_DIR, "libcofusion.so")
 HOST_SYMBOLS = [
     "cofusion_default_config", "cofusion_create", "cofusion_destroy", "cofusion_last_error", "cofusion_set_stream",
     "cofusion_process_frame", "cofusion_process_frame_device", "cofusion_num_models", "cofusion_tick", "cofusion_model_info",
