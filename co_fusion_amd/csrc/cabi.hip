@@ -557,7 +557,10 @@ int cf_odom_create(cf_ctx* ctx, cf_odom** out)
         od->ext_vmap_curr[i] = nullptr; od->ext_nmap_curr[i] = nullptr; od->ext_zrange[i] = nullptr;
     }
     if (int r = dmalloc(ctx, &od->icp_acc, (size_t)kGroups * 32)) return r;
-    if (int r = dmalloc(ctx, &od->rgb_acc, (size_t)kGroups * 32)) return r;
+    {   // 64 groups of grouped atomics, or (cf_set_gn_mode 2) one row of totals per workgroup of the RGB step: a workgroup per 2 record slots
+        const size_t slots0 = (n0 + 255) / 256, quads0 = (slots0 + 1) / 2;   // (slots of >= 256 pixels: cf_set_icp_launch allows 64-thread workgroups)
+        if (int r = dmalloc(ctx, &od->rgb_acc, (quads0 > (size_t)kGroups ? quads0 : (size_t)kGroups) * 32)) return r;
+    }
     if (int r = dmalloc(ctx, &od->occ, ((size_t)(W >> 2) * (H >> 2) + 3) / 4 * 4)) return r;
     if (int r = dmalloc(ctx, &od->aabb, 8)) return r;
     if (int r = dmalloc(ctx, &od->res_range, 8)) return r;
@@ -867,6 +870,7 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
     h->aabb_acc = od->aabb; h->cull = (od->use_occ && od->box_valid && od->band_end == 0 && !no_box) ? 1 : 0;
     memcpy(h->box_R, od->map_pose, 36); memcpy(h->box_t, od->map_pose + 9, 12);
     h->res_range = (h->cull && rgb) ? od->res_range : nullptr;
+    h->host_twin = od->h_state;
     for (int i = 0; i < CF_NUM_PYRS; i++) h->res_seen[i] = -1;
     if (rgb) prep->res_range = h->res_range;
     // the first launch of a tracking call latches the accumulator and zeroes it (so3_prealign_kernel): a second tracking call on the
@@ -985,6 +989,13 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     // to back under a list of ablation masks and prints the durations -- the decomposition of the launch quoted in DESIGN.md 4.1
     static const int replay_call = getenv("CF_ICP_REPLAY") ? atoi(getenv("CF_ICP_REPLAY")) : -1;
     static const int trace_call = getenv("CF_ICP_TRACE") ? atoi(getenv("CF_ICP_TRACE")) : -1;   // per-workgroup stamps of that call's level-0 launch
+    static const int step_trace_call = getenv("CF_STEP_TRACE") ? atoi(getenv("CF_STEP_TRACE")) : -1;   // phases of that call's fused RGB step + solve launch
+    static int step_trace_seen = 0;
+    if (step_trace_call >= 0 && step_trace_seen++ == step_trace_call) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        trace_step_solve(ctx->stream, ctx->icp_launch, icp_args[0], rgb_args[0], ctx->d_so3_sync, n, getenv("CF_ICP_TRACE_OUT") ? getenv("CF_ICP_TRACE_OUT") : "step_trace.txt");
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     static int calls_seen = 0, trace_calls_seen = 0;
     if (trace_call >= 0 && trace_calls_seen++ == trace_call) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1086,7 +1097,7 @@ int cf_odom_get_covariance(const cf_track_stats* stats, double cov[36])
 
 int cf_set_gn_mode(cf_ctx* ctx, int mode)
 {
-    if (!ctx || mode < 0 || mode > 1) return CF_EINVAL;
+    if (!ctx || mode < 0 || mode > 2) return CF_EINVAL;
     ctx->gn_mode = mode;
     return CF_OK;
 }

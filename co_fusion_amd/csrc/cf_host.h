@@ -29,7 +29,8 @@ struct cf_ctx {
     cf::OdomDev* h_scratch_state = nullptr;  // pinned
     uint8_t* d_cand_scratch = nullptr;
     cf::So3Sync* d_so3_sync = nullptr;  // [max_models]
-    int gn_mode = 1;                    // launch_gn_track mode (1: record slots between the residual pass and the RGB step)
+    int gn_mode = 1;                    // launch_gn_track mode (1: record slots between the residual pass and the RGB step; 2: ... whose last
+                                        // workgroup per tracker runs the solve -- measured slower, DESIGN-NOTES R5; 0: DataTerm image)
     // device / pinned-host pools of the trackers' state structs: a batch of trackers is uploaded / read back with ONE
     // copy over its slot range instead of one copy per tracker
     static constexpr int kStateSlots = 256;  // (up to 255 models per sequence; trackers beyond the pool keep state blocks of their own)

@@ -33,6 +33,7 @@ static_assert(sizeof(GnHot) == 192, "three 64-byte lines");
 
 // Device-resident mirror of RGBDOdometry's members (Core/Utils/RGBDOdometry.h:78-137) plus the
 // Gauss-Newton state that the reference keeps in host locals (RGBDOdometry.cpp:217-477).
+struct OdomDev;
 struct OdomDev {
     // pyramids (level 0..2)
     const float* vmap_curr[3];
@@ -70,6 +71,7 @@ struct OdomDev {
     // culled trackers: first / last 256-pixel chunk with an RGB candidate per level (RgbPrepArgs::res_range; null: not tracked) --
     // the residual workgroups of the loop cover the record slots between them only
     unsigned* res_range;
+    OdomDev* host_twin;          // nullable: the pinned host copy of this state; the LAST solve of a schedule publishes its result there
     // Gauss-Newton state
     float Rprev[9], tprev[3], Rprev_inv[9], Rcurr[9], tcurr[3];
     double resultRt[16];
@@ -265,6 +267,7 @@ inline RgbModelArgs rgb_model_args(const OdomDev* h /* host mirror */, OdomDev* 
                         reinterpret_cast<unsigned*>(reinterpret_cast<uint2*>(h->corres[level]) + (size_t)(h->width >> level) * (h->height >> level)),
                         h->res_range ? h->res_range + 2 * level : nullptr, 0};
 }
+constexpr int kMaxSlots = 2 * kMaxBatch + 4;    // ICP + residual slot per model, one slot for all error surfaces (+ padding to a multiple of 4)
 struct IcpArgs {
     IcpModelArgs m[kMaxBatch];
     int cols, rows;
@@ -277,10 +280,12 @@ struct IcpArgs {
     IDiv cdiv;                          // make_idiv(cols), set by the launchers
     // layout of the one-dimensional grid (set by the launchers, icp_reduce_kernel): running totals of the workgroups per slot -- a slot
     // is the ICP reduction or the residual pass of one model -- and what every slot is; unused slots end at INT_MAX
-    int slot_end[2 * kMaxBatch];
-    unsigned char slot_desc[2 * kMaxBatch];   // model | kResidualSlot
+    int slot_end[kMaxSlots];
+    unsigned char slot_desc[kMaxSlots];       // model | kResidualSlot, or kErrorSlot
+    int err_blocks; IDiv err_div;             // workgroups per error surface inside the error slot
 };
-constexpr unsigned char kResidualSlot = 0x80;
+constexpr unsigned char kResidualSlot = 0x80;   // the model's RGB residual pass
+constexpr unsigned char kErrorSlot = 0x40;      // the error surfaces of the culled models (last level-0 iteration), err_blocks workgroups each, one pixel per lane
 void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void launch_rgb_residual(hipStream_t s, const RgbArgs& ra, int n);
 void launch_rgb_step(hipStream_t s, const RgbArgs& ra, int n);
@@ -302,9 +307,13 @@ struct ProfSink {  // hipEvent pairs recorded around every ICP-reduce launch whe
 // device-resident Gauss-Newton loop over `n` models (lock-step; blockIdx.y = model)
 // cross-workgroup state of the SO3 pre-alignment (zero between launches): per-iteration totals + arrival counters
 constexpr int kSo3Blocks = 16;
-struct So3Sync { unsigned long long acc[10][16]; unsigned arrive, depart; };
+constexpr int kStepSubs = 16;   // first-level ticket counters of the RGB step (mode 2), one 128-byte line each
+struct So3Sync { unsigned long long acc[10][16]; unsigned arrive, depart;
+                 unsigned step_top, pad;                  // second-level ticket: first-level counters whose workgroups have all committed
+                 unsigned step_sub[kStepSubs][32]; };     // [j][0]: committed workgroups among the slots = j (mod kStepSubs)
 // mode 0: {ICP || residual -> DataTerm image} + rgb_step over the image + solve;
 // mode 1: {ICP || residual -> per-workgroup record slots} + rgb step over the slots + solve
+// mode 2: {ICP || residual -> record slots} + {rgb step over the slots, the tracker's workgroups on ONE XCD; the last to commit solves}
 // hook: called after every {ICP || residual} launch for each model whose reduction is split over GPUs (split[m] != 0) with that
 // model's grouped ICP accumulators (kGroups * 32 words): the caller's in-place SUM all-reduce over the ranks, enqueued on `s`
 struct GnHook { int (*fn)(void* user, int op, void* dev_buf, uint64_t words, void* stream); void* user; int split[kMaxBatch]; };
@@ -319,6 +328,7 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
 void rgb_prep_levels(RgbPrepBatch& b, int n, int W, int H);
 float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, int ablate, int reps, hipEvent_t e0, hipEvent_t e1);
 #ifdef CF_ABLATE
+void trace_step_solve(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, So3Sync* syncs, int n, const char* path);
 void trace_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, const char* path);
 #endif
 float sqrt_gate_lt(float T);  // smallest x with sqrtf(x) >= T

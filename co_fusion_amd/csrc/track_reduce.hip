@@ -71,7 +71,9 @@ __device__ __forceinline__ void se3_accumulate_dyn(const float (&row)[7], unsign
 
 // ------------------------------------------------------------------------------------------------
 // cross-wave combine + grouped atomics.  v = wave total of word ((lane>>1)&31) (wave_reduce32_u64).
-template <int MAXW>
+// XCD_LOCAL: the atomics are performed in the L2 of THIS XCD (workgroup scope) -- for sums that only workgroups of the same XCD add to and
+// read back (rgb_step_solve_kernel).
+template <int MAXW, bool XCD_LOCAL = false>
 __device__ __forceinline__ void block_commit32(unsigned long long v, int lane, int wave, int nwaves,
                                                unsigned long long* __restrict__ dst /* [32] of this group */)
 {
@@ -81,8 +83,20 @@ __device__ __forceinline__ void block_commit32(unsigned long long v, int lane, i
     if (threadIdx.x < 32) {
         unsigned long long t = 0;
         for (int w = 0; w < nwaves; w++) t += lds[w][threadIdx.x];
-        if (t != 0) atomicAdd(&dst[threadIdx.x], t);
+        if (t != 0) {
+            if constexpr (XCD_LOCAL) __hip_atomic_fetch_add(&dst[threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else atomicAdd(&dst[threadIdx.x], t);
+        }
     }
+}
+
+// ... the workgroup's 32 totals (4 waves) stored as one row: no atomic, no read-modify-write in the L2 (rgb_step_solve_kernel)
+__device__ __forceinline__ void block_store32(unsigned long long v, int lane, int wave, unsigned long long* __restrict__ row /* [32] */)
+{
+    __shared__ unsigned long long lds[4][32];
+    if ((lane & 1) == 0) lds[wave][lane >> 1] = v;
+    __syncthreads();
+    if (threadIdx.x < 32) row[threadIdx.x] = lds[0][threadIdx.x] + lds[1][threadIdx.x] + lds[2][threadIdx.x] + lds[3][threadIdx.x];
 }
 
 // ================================================================================================
@@ -193,7 +207,7 @@ template <bool COMPACT> __device__ void rgb_residual_body(const RgbArgs& ra, int
 // VALU budget (the kernel is VALU-bound once several models share a launch): PPT pixels per lane feed ONE
 // 32 x u64 butterfly; a wave whose pixels cannot produce a correspondence (projection out of view, model map empty
 // there -- the common case for object models, which cover a small part of the image) leaves after the projection.
-static_assert(sizeof(IcpArgs) + sizeof(RgbArgs) + 16 <= 4096, "the kernel-argument segment holds 4 KB: lower kMaxBatch");  // (rgb_slot_step_kernel takes both as well)
+static_assert(sizeof(IcpArgs) + sizeof(RgbArgs) + 64 <= 4096, "the kernel-argument segment holds 4 KB: lower kMaxBatch");  // (rgb_slot_step_kernel takes both as well)
 //
 // GRAM (cf_set_icp_arith 1): the accumulation and the butterfly are replaced by the matrix cores -- the rows are rounded to integers,
 // staged through LDS as signed 8-bit limbs and contracted over the wave's pixels by v_mfma_i32_32x32x32_i8 (cf_device.h: gram_*);
@@ -382,6 +396,38 @@ __device__ __forceinline__ bool icp_run(const IcpArgs& args, const IcpModelArgs&
     return true;
 }
 
+// The ICP error surface (icpStep's optional output, reduce.cu:327-331 / RGBDOdometry.cpp:414-431: the distance between every pixel's
+// vertex and the model vertex it projects onto, 0 when not finite / out of view) of the last level-0 iteration, one pixel per lane.
+// Until round 4 that iteration's ICP pass wrote it for every tracker, which kept the launch from culling anything (23.8 us against
+// 15.4 us for the nine iterations before it); now the culled trackers stay culled and this body writes THEIR surfaces in slots of their
+// own (kErrorSlot) of the same launch -- the same pose, the expressions of icp_run, the same bits.  (Round 4 had these workgroups in the
+// RGB step's launch that follows; with the solve inside that launch -- rgb_step_solve_kernel -- the pose would change under them.)
+// Unculled trackers write theirs in the ICP pass as before.
+__device__ __forceinline__ void icp_error_surface_body(const IcpArgs& args, const IcpModelArgs& ma, int blk)
+{
+    float* __restrict__ errs = ma.err;
+    if (!errs || !ma.cull) return;  // (an unculled tracker wrote its surface in the ICP pass it ran over the whole image anyway)
+    StatePtr st = (StatePtr)ma.st;
+    const int cols = args.cols, rows = args.rows, N = cols * rows;
+    const int i = blk * (int)blockDim.x + (int)threadIdx.x;
+    const bool in_range = i < N;
+    float vx = qnan(), vy = qnan(), vz = qnan();
+    if (in_range) { vx = ma.vc[i]; vy = ma.vc[i + N]; vz = ma.vc[i + 2 * N]; }
+    const IcpHot hs = icp_hot(st);
+    if (!hs.icp || hs.level_done) return;  // (icp_run leaves before it writes anything)
+    const m33 Rcurr = hs.Rcurr, Rprev_inv = hs.Rprev_inv;
+    const f3 tcurr = hs.tcurr, tprev = hs.tprev;
+    if (!in_range) return;
+    const IcpProj pr = icp_project(Rcurr, tcurr, Rprev_inv, tprev, args.intr, cols, rows, f3{vx, vy, vz});
+    f3 vprev = {qnan(), qnan(), qnan()};
+    bool occupied = pr.inb != 0;
+    if (occupied && ma.occ) occupied = ma.occ[(pr.uy >> args.occ_shift) * args.occ_w + (pr.ux >> args.occ_shift)] != 0;
+    if (occupied) vprev = f3{ma.vp[pr.g], ma.vp[pr.g + N], ma.vp[pr.g + 2 * N]};
+    float err = 0.f;
+    if (pr.inb) { const float dist = norm(vprev - pr.vcurr_g); err = is_finite(dist) ? dist : 0.0f; }
+    errs[i] = err;
+}
+
 // GRID.  One-dimensional, in SLOTS: a slot is the ICP reduction or the RGB residual pass of one model.  IcpArgs::slot_end holds the running
 // totals of the workgroups, IcpArgs::slot_desc what every slot is; the launcher orders them longest work first (launch_icp_kernel_arith).
 // Every slot starts at a multiple of 8, so hardware workgroup b and its slot-local index agree on the XCD (b % 8).
@@ -399,10 +445,19 @@ __device__ __forceinline__ void icp_reduce_body(const IcpArgs& args, const RgbAr
     const int b = blockIdx.x;
     int slot = 0;
 #pragma unroll
-    for (int k = 0; k < 2 * kMaxBatch - 1; k++) slot += (b >= args.slot_end[k]) ? 1 : 0;  // (two wide scalar loads of the table, 31 compares; unused slots end at INT_MAX)
+    for (int k = 0; k < kMaxSlots - 1; k++) slot += (b >= args.slot_end[k]) ? 1 : 0;  // (wide scalar loads of the table, 35 compares; unused slots end at INT_MAX)
     const int slot0 = slot ? args.slot_end[slot - 1] : 0, bx = b - slot0;
     const unsigned desc = args.slot_desc[slot];
-    const int model = (int)(desc & 0x7fu);
+    const int model = (int)(desc & 0x3fu);
+    if (desc & kErrorSlot) {   // the k-th culled tracker with a surface
+        const int k = args.err_blocks > 1 ? idiv(bx, args.err_div) : bx;
+        int em = -1, seen = 0;
+#pragma unroll
+        for (int q = 0; q < kMaxBatch; q++)
+            if (args.m[q].cull && args.m[q].err) { if (seen == k) em = q; seen++; }
+        if (em >= 0) icp_error_surface_body(args, args.m[em], bx - k * args.err_blocks);
+        return;
+    }
     if (desc & kResidualSlot) {
         if (ABL(32) || (ABL(16) && args.m[model].cull)) return;  // timing ablations (CF_ICP_REPLAY)
         if (ra.compact) rgb_residual_body<true>(ra, model, bx, args.slot_end[slot] - slot0);
@@ -463,8 +518,8 @@ __device__ __forceinline__ void icp_reduce_body(const IcpArgs& args, const RgbAr
     const int band0 = rb * cols, band1 = (re > 0 ? re : rows) * cols;
     // the error surface (last level-0 iteration) is written for the WHOLE image on every rank of a split model -- the segmentation
     // reads all of it -- while only the band's pixels enter the sums
-    // (flags & 1: this launch writes the error surfaces; & 2: ... except those of culled trackers, which spare workgroups of the RGB
-    // step's launch write -- icp_error_surface_body -- so that the culling stays on)
+    // (flags & 1: this launch writes the error surfaces; & 2: ... those of culled trackers in the launch's error slot --
+    // icp_error_surface_body -- so that their ICP pass stays culled)
     const bool err_here = (args.flags & 1) && !((args.flags & 2) && ma.cull);
     const bool whole = err_here && ma.err != nullptr && ma.row_end > 0;
     const int pix0 = whole ? 0 : band0, pix1 = whole ? N : band1;
@@ -1188,8 +1243,11 @@ static_assert(kGramBits[0] == 20 && kGramBits[2] == 20 && kGramBits[3] == 17 && 
 //    one wave (ldlt_solve6_wave), and K^-1 of the next level is formed by another wave meanwhile,
 //  * only Rodrigues and the 3x3 pose composition stay on one lane.
 // Must be called by all 256 threads of a workgroup.
+// RGB_IN_L2: the RGB sums were added by workgroup-scope atomics of this launch (rgb_step_solve_kernel): they are read where they live,
+// in this XCD's L2, with agent-scope loads -- a plain load may be served by the CU's L1.
+template <bool RGB_IN_L2 = false>
 __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigned long long* icp_acc, unsigned long long* rgb_acc, int next_level,
-                                              int last_of_level, OdomDev* god_host, int slot_px)
+                                              int last_of_level, OdomDev* god_host, int slot_px, int part_first = 0, int part_last = -1)
 {
     __shared__ OdomDev s_od;
     __shared__ unsigned long long s_icp[32], s_rgb[32];
@@ -1206,6 +1264,21 @@ __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigne
     {   // 256 threads: word = t & 31, slice = t >> 5 (8 slices of 8 groups)
         const int w = tid & 31, sl = tid >> 5;
         unsigned long long a = 0, b = 0;
+        if constexpr (RGB_IN_L2) {   // rgb_acc holds one row of 32 totals per workgroup of the step, rows part_first .. part_last (rgb_step_solve_kernel).
+            // Agent-scope loads: never served by the CU's L1, answered by the L2 the rows were stored to
+            for (int g = sl * (kGroups / 8); g < (sl + 1) * (kGroups / 8); g++) a += icp_acc[(size_t)g * 32 + w];
+            for (int r0 = part_first + sl; r0 <= part_last; r0 += 64) {   // eight rows in flight per lane (a rolled loop waits for every load)
+                unsigned long long t[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int r = r0 + 8 * k;
+                    t[k] = __hip_atomic_load(&rgb_acc[(size_t)(r <= part_last ? r : part_last) * 32 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (r > part_last) t[k] = 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) b += t[k];
+            }
+        } else
         for (int g = sl * (kGroups / 8); g < (sl + 1) * (kGroups / 8); g++) {
             a += icp_acc[(size_t)g * 32 + w];
             b += rgb_acc[(size_t)g * 32 + w];
@@ -1368,44 +1441,14 @@ __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigne
     for (int k = kMutableFrom + tid; k < kWords; k += 256) reinterpret_cast<unsigned*>(god)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
     // end of the schedule: the result (pose, statistics, fault word) goes to the tracker's pinned host copy as well -- the frame's host
     // wait finds it there without a copy command behind the loop on the stream
-    if (god_host && next_level < 0)
-        for (int k = kMutableFrom + tid; k < kWords; k += 256) reinterpret_cast<unsigned*>(god_host)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
+    OdomDev* const twin = god_host ? god_host : s_od.host_twin;
+    if (twin && next_level < 0)
+        for (int k = kMutableFrom + tid; k < kWords; k += 256) reinterpret_cast<unsigned*>(twin)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
 }
 
 __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int next_level, int last_of_level)
 {
     gn_solve_body(args.icp_gram ? -1 : kFixICP, args.od[blockIdx.x], args.icp_acc[blockIdx.x], args.rgb_acc[blockIdx.x], next_level, last_of_level, args.od_host[blockIdx.x], args.slot_px);
-}
-
-// The ICP error surface (icpStep's optional output, reduce.cu:327-331 / RGBDOdometry.cpp:414-431: the distance between every pixel's
-// vertex and the model vertex it projects onto, 0 when not finite / out of view) of the last level-0 iteration, one pixel per lane.
-// Until round 4 that iteration's {ICP || residual} launch wrote it for every tracker, which kept the launch from culling anything
-// (23.8 us against 15.4 us for the nine iterations before it); now the culled trackers stay culled and this body writes THEIR
-// surfaces in spare workgroups of the RGB step's launch that follows -- the pose it reads is still the iteration's (the solve comes
-// after), the expressions are those of icp_run, the bits the same.  Unculled trackers write theirs in the ICP pass as before.
-__device__ __forceinline__ void icp_error_surface_body(const IcpArgs& args, const IcpModelArgs& ma, int blk)
-{
-    float* __restrict__ errs = ma.err;
-    if (!errs || !ma.cull) return;  // (an unculled tracker wrote its surface in the ICP pass it ran over the whole image anyway)
-    StatePtr st = (StatePtr)ma.st;
-    const int cols = args.cols, rows = args.rows, N = cols * rows;
-    const int i = blk * 256 + (int)threadIdx.x;
-    const bool in_range = i < N;
-    float vx = qnan(), vy = qnan(), vz = qnan();
-    if (in_range) { vx = ma.vc[i]; vy = ma.vc[i + N]; vz = ma.vc[i + 2 * N]; }
-    const IcpHot hs = icp_hot(st);
-    if (!hs.icp || hs.level_done) return;  // (icp_run leaves before it writes anything)
-    const m33 Rcurr = hs.Rcurr, Rprev_inv = hs.Rprev_inv;
-    const f3 tcurr = hs.tcurr, tprev = hs.tprev;
-    if (!in_range) return;
-    const IcpProj pr = icp_project(Rcurr, tcurr, Rprev_inv, tprev, args.intr, cols, rows, f3{vx, vy, vz});
-    f3 vprev = {qnan(), qnan(), qnan()};
-    bool occupied = pr.inb != 0;
-    if (occupied && ma.occ) occupied = ma.occ[(pr.uy >> args.occ_shift) * args.occ_w + (pr.ux >> args.occ_shift)] != 0;
-    if (occupied) vprev = f3{ma.vp[pr.g], ma.vp[pr.g + N], ma.vp[pr.g + 2 * N]};
-    float err = 0.f;
-    if (pr.inb) { const float dist = norm(vprev - pr.vcurr_g); err = is_finite(dist) ? dist : 0.0f; }
-    errs[i] = err;
 }
 
 // RGB step over the per-workgroup record slots the residual pass left (grid: one workgroup per slot x models).  A slot holds at
@@ -1415,10 +1458,8 @@ __device__ __forceinline__ void icp_error_surface_body(const IcpArgs& args, cons
 // Measured and dropped (round 2, profiles/r02b): running this pass and the solve in ONE launch -- 32 workgroups per model reduce a
 // global list, fence, arrive at a counter, workgroup 0 waits and solves.  22.6 us per launch against 6.3 + 8.4 us for the two
 // separate kernels plus one boundary: the device-scope release fence and the arrival wait cost more than a kernel boundary does.
-// Workgroups beyond the n_slots of the step (last level-0 iteration only) write the ICP error surface: icp_error_surface_body.
-__global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra, const IcpArgs ea, int n_slots)
+__global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra, int n_slots)
 {
-    if ((int)blockIdx.x >= n_slots) { icp_error_surface_body(ea, ea.m[blockIdx.y], (int)blockIdx.x - n_slots); return; }
     const RgbModelArgs& m = ra.m[blockIdx.y];
     const RgbHot hs = rgb_hot((StatePtr)m.st);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1460,6 +1501,111 @@ __global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra, co
         v = wave_reduce32_u64(acc, lane);
     }
     block_commit32<4>(v, lane, wave, 4, m.rgb_acc + (size_t)(blockIdx.x % kGroups) * 32);
+}
+
+// MODE 2 (round 5): the RGB step and the solve in ONE launch.  Rounds 2-3 measured this twice with device-scope synchronisation and lost
+// both times (a release fence per workgroup writes the XCD's L2 back; returning device-scope atomics cost a memory round trip each).
+// What round 4's SO(3) kernel showed is that workgroups of ONE XCD can meet in its L2 for ~1.5 us: so the step workgroups of tracker m
+// are placed on XCD m mod 8 (hardware workgroup b runs on XCD b mod 8: tools/microbench/xcc_map.hip), add their sums with
+// workgroup-scope atomics -- performed in that L2 --, wait for them, and take a ticket there.  Nobody waits for anybody: the workgroup
+// that draws the last ticket runs the solve (gn_solve_body reads the RGB sums back from the L2 with agent-scope loads), the others
+// leave.  What the solve writes (state, cleared accumulators, the ticket counter) is written back at the end of the kernel like any
+// other store.  One launch boundary (~2.5 us) and the solve kernel's own ramp less per Gauss-Newton iteration: 57 -> 38 launches per
+// frame.  The sums are integers: which workgroup adds what, and who solves, does not change a bit.
+// Grid: 8 x n_quads x ceil(n / 8) workgroups, n_quads = ceil(n_slots / 2) (two record slots per workgroup), b = 8 * (quad + n_quads * (m / 8)) + m % 8.
+__global__ void __launch_bounds__(256) rgb_step_solve_kernel(const RgbArgs ra, So3Sync* __restrict__ syncs, int n_slots, int n_quads, IDiv quad_div,
+                                                             int n, int icp_fix, int next_level, int last_of_level)
+{
+    const int b = (int)blockIdx.x;
+#ifdef CF_ABLATE
+    unsigned long long* const tr = g_icp_trace ? g_icp_trace + (size_t)b * 8 : nullptr;
+    if (tr && threadIdx.x == 0) { tr[0] = wall_clock64(); tr[1] = tr[2] = tr[3] = tr[4] = 0; tr[5] = 0xffff; }
+#define STAMP(k) do { if (tr && threadIdx.x == 0) tr[k] = wall_clock64(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+    const int q = b >> 3, hi = n_quads > 1 ? idiv(q, quad_div) : q;
+    const int model = (b & 7) + 8 * hi, quad = q - hi * n_quads;
+    if (model >= n) return;
+    const RgbModelArgs& m = ra.m[model];
+    const RgbHot hs = rgb_hot((StatePtr)m.st);
+    SlotRange sr = residual_slot_range(ra, m, n_slots);
+    const bool no_slot = sr.last < sr.first;   // a culled tracker without a single candidate: its first workgroup stands in (and solves)
+    if (no_slot) { sr.first = 0; sr.last = 0; }
+    const int qf = sr.first >> 1, ql = sr.last >> 1;
+    if (quad < qf || quad > ql) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Two record slots per workgroup, two waves per slot (`quad`: the pair's index).  The tracker's workgroups share ONE XCD: a workgroup
+    // per slot (round 4's shape) makes the background's 300 slots two rounds of residency there (measured: +4 us), a WAVE per slot leaves a
+    // slot with 700 records to eleven dependent passes of one wave (measured: +8 us).  150 workgroups x 4 waves fit the XCD in one round.
+    const int slot = quad * 2 + (wave >> 1), half = tid & 127;
+    const bool slot_ok = !no_slot && slot >= sr.first && slot <= sr.last;
+    const size_t slot0 = (size_t)slot * ra.slot_px;
+    const unsigned nrec = slot_ok ? m.slot_counts[slot] : 0u;
+    uint2 rc = make_uint2(0, 0);
+    if (slot_ok && slot0 + half < (size_t)ra.cols * ra.rows) rc = m.recs[slot0 + half];   // speculative: valid if half < nrec
+    if (hs.rgb && !hs.level_done) {  // uniform
+        unsigned long long v = 0;
+        if (nrec != 0) {   // (wave-uniform)
+            const long long cnt = (long long)group_sum(m.icp_acc, 29, lane);
+            const long long sg = (long long)group_sum(m.icp_acc, 30, lane);
+            const float sigma = sigma_val_from((int)cnt, (int)sg, hs.rgbOnly);
+            const int F = rgb_fix_bits(sigma);
+            const float lim = ldexpf(1.0f, (50 - F) / 2), scale = ldexpf(1.0f, F);
+            unsigned long long acc[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) acc[k] = 0;
+            unsigned long long terms = 0;
+            for (unsigned r = half; r < nrec; r += 128) {
+                if (r >= 128) rc = m.recs[slot0 + r];
+                float row[7];
+                rgb_step_row(ra, m, sigma, (float)((int)(rc.y >> 22) - 256), (int)rc.x, (int)(rc.y & 0x3fffffu), row);
+                se3_accumulate_dyn(row, acc, lim, scale);
+                terms++;
+            }
+            if (__any(terms != 0)) {
+#pragma unroll
+                for (int k = 0; k < 28; k++) acc[k] -= terms * kMagicBits;
+                acc[28] = terms;
+                v = wave_reduce32_u64(acc, lane);
+            }
+        }
+        STAMP(1);
+        block_store32(v, lane, wave, m.rgb_acc + (size_t)quad * 32);
+    } else if (tid < 32) m.rgb_acc[(size_t)quad * 32 + tid] = 0;
+#ifdef CF_ABLATE
+    if (tr && threadIdx.x == 0) tr[5] = (unsigned long long)model;
+#endif
+    // The tickets, drawn by the wave that issued the atomics, once the L2 has taken them.  Two levels: returning atomics on ONE address
+    // take the L2 ~17 ns each, so a workgroup draws from the counter of its quad's residue class mod kStepSubs (each in a cache line of
+    // its own), and the last of a class draws from the tracker's top counter.
+    __shared__ int s_last;
+    So3Sync* const sync = syncs + model;
+    if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(2);
+        if (tid == 0) {
+            static_assert(kStepSubs == 16, "the class arithmetic below shifts by 4");
+            const int j = quad & (kStepSubs - 1);
+            // quads = j (mod kStepSubs) inside [qf, ql]; classes that have any
+            const unsigned in_class = (unsigned)(((ql - j) >> 4) - ((qf - 1 - j) >> 4));
+            const int span = ql - qf + 1;
+            const unsigned classes = (unsigned)(span < kStepSubs ? span : kStepSubs);
+            int last = 0;
+            if (__hip_atomic_fetch_add(&sync->step_sub[j][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == in_class - 1u) {
+                sync->step_sub[j][0] = 0;   // (every ticket of this class is drawn; the next launch finds the counter cleared)
+                if (__hip_atomic_fetch_add(&sync->step_top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == classes - 1u) { sync->step_top = 0; last = 1; }
+            }
+            s_last = last;
+        }
+    }
+    STAMP(3);
+    __syncthreads();
+    if (!s_last) return;
+    OdomDev* const god = m.st;
+    gn_solve_body<true>(icp_fix, god, m.icp_acc, m.rgb_acc, next_level, last_of_level, nullptr, ra.slot_px, qf, ql);
+    STAMP(4);
+#undef STAMP
 }
 
 // total of the grouped accumulator -> out[32] (stand-alone steps)
@@ -1542,7 +1688,14 @@ static void launch_icp_kernel_arith(hipStream_t s, IcpLaunch cfg, const IcpArgs&
         for (int m = 0; m < n && icp; m++) if (args.m[m].box_blocks > 0) add(m, false, blocks[m]);
         for (int m = 0; m < n && res; m++) if (culled(m)) add(m, true, ra.m[m].res_blocks);
     }
-    for (; slot < 2 * kMaxBatch; slot++) { args.slot_end[slot] = 0x7fffffff; args.slot_desc[slot] = 0; }
+    // ... and the error surfaces of the culled trackers on the iteration that writes them (flags 3), one pixel per lane: one slot
+    args.err_blocks = (args.cols * args.rows + cfg.threads - 1) / cfg.threads; args.err_div = make_idiv(args.err_blocks > 1 ? args.err_blocks : 2);
+    if (icp && (args.flags & 3) == 3) {
+        int n_err = 0;
+        for (int m = 0; m < n; m++) n_err += (args.m[m].cull && args.m[m].err) ? 1 : 0;
+        if (n_err) { total += ((n_err * args.err_blocks + 7) / 8) * 8; args.slot_end[slot] = total; args.slot_desc[slot] = kErrorSlot; slot++; }
+    }
+    for (; slot < kMaxSlots; slot++) { args.slot_end[slot] = 0x7fffffff; args.slot_desc[slot] = 0; }
     const dim3 grid(total);
 #ifdef CF_ABLATE
     g_last_icp_args = args; g_last_n_icp_blocks = n_icp_blocks; g_last_grid = (int)grid.x;
@@ -1629,12 +1782,11 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
         gn.od_host[m] = h_states ? h_states[m] : nullptr;
     }
     const bool slots = mode != 0;
-    // the error surfaces of the last level-0 iteration: those of culled trackers by spare workgroups of the RGB step's launch when
-    // there is one (then these trackers stay culled in that iteration's {ICP || residual} launch: IcpArgs::flags 3), the others --
-    // and all of them without such a launch -- by the ICP launch itself (flags 1)
+    // the error surfaces of the last level-0 iteration: those of culled trackers by an error slot of that iteration's launch (these
+    // trackers stay culled in their ICP pass: IcpArgs::flags 3), the others by their ICP pass itself (flags 1)
     bool any_culled = false;
     for (int m = 0; m < n; m++) any_culled = any_culled || (icp_args[0].m[m].cull && icp_args[0].m[m].err);
-    const bool err_aside = icp && rgb && slots && any_culled;
+    const bool err_aside = icp && any_culled;
     bool hook_failed = false;
     for (int i = 2; i >= 0; i--) {
         const int N = (width >> i) * (height >> i);
@@ -1664,11 +1816,16 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
             if (hook && hook->fn)  // split reductions: the partial sums of this rank's row band become the totals on every rank
                 for (int m = 0; m < n; m++)
                     if (hook->split[m] && hook->fn(hook->user, 0, gn.icp_acc[m], (uint64_t)kGroups * 32, (void*)s) != 0) hook_failed = true;
+            if (rgb && mode == 2) {   // the RGB step's last workgroup of every tracker solves
+                const int n_slots = (N + ra.slot_px - 1) / ra.slot_px, n_quads = (n_slots + 1) / 2;
+                rgb_step_solve_kernel<<<8 * n_quads * ((n + 7) / 8), 256, 0, s>>>(ra, so3_syncs, n_slots, n_quads, make_idiv(n_quads > 1 ? n_quads : 2), n,
+                                                                                 cfg.gram ? -1 : kFixICP, next_level, last_of_level ? 1 : 0);
+                continue;
+            }
             if (rgb) {
                 if (slots) {
                     const int n_slots = (N + ra.slot_px - 1) / ra.slot_px;
-                    const bool with_err = err_aside && i == 0 && last_of_level;
-                    rgb_slot_step_kernel<<<dim3(n_slots + (with_err ? (N + 255) / 256 : 0), n), 256, 0, s>>>(ra, icp_args[i], n_slots);
+                    rgb_slot_step_kernel<<<dim3(n_slots, n), 256, 0, s>>>(ra, n_slots);
                 }
                 else rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(ra);
             }
@@ -1694,6 +1851,39 @@ float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const R
 }
 
 #ifdef CF_ABLATE
+// diagnostics (CF_STEP_TRACE): one level-0 {ICP || residual} launch + one traced rgb_step_solve_kernel launch (next_level 0: the state moves
+// on by one iteration; the caller's results are garbage afterwards); lines "workgroup model begin step commit ticket solve_end" in ns
+void trace_step_solve(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, So3Sync* syncs, int n, const char* path)
+{
+    IcpArgs a = a0; a.flags = 0;
+    RgbArgs ra = r0; ra.compact = 1; ra.slot_px = cfg.threads * 4;
+    const int N = ra.cols * ra.rows, n_slots = (N + ra.slot_px - 1) / ra.slot_px, n_quads = (n_slots + 1) / 2, grid = 8 * n_quads * ((n + 7) / 8);
+    unsigned long long* d = nullptr; unsigned long long* none = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), (size_t)grid * 64) != hipSuccess) return;
+    FILE* f = fopen(path, "w");
+    for (int rep = 0; rep < 3 && f; rep++) {
+        (void)hipMemset(d, 0, (size_t)grid * 64);
+        launch_icp_rgbres(s, cfg, a, ra, true, true, n, 0, nullptr, nullptr);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_trace), &d, sizeof(d));
+        rgb_step_solve_kernel<<<grid, 256, 0, s>>>(ra, syncs, n_slots, n_quads, make_idiv(n_quads > 1 ? n_quads : 2), n, cfg.gram ? -1 : kFixICP, 0, 0);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_trace), &none, sizeof(none));
+        std::vector<unsigned long long> h((size_t)grid * 8);
+        (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long tmin = ~0ull;
+        for (int b = 0; b < grid; b++) if (h[(size_t)b * 8] && h[(size_t)b * 8] < tmin) tmin = h[(size_t)b * 8];
+        fprintf(f, "# rep %d grid %d trackers %d\n", rep, grid, n);
+        for (int b = 0; b < grid; b++) {
+            const unsigned long long* o = &h[(size_t)b * 8];
+            if (!o[0] || o[5] == 0xffff) continue;
+            auto rel = [&](unsigned long long t) { return t ? (long long)(t - tmin) * 10 : -1ll; };
+            fprintf(f, "%d %d %lld %lld %lld %lld %lld\n", b, (int)o[5], rel(o[0]), rel(o[1]), rel(o[2]), rel(o[3]), rel(o[4]));
+        }
+    }
+    if (f) fclose(f);
+    (void)hipFree(d);
+}
 // diagnostics (CF_ICP_TRACE): the level-0 {ICP || residual} launch of a batch three times back to back, the third with per-workgroup
 // stamps; writes "workgroup kind model begin_ns end_ns xcc hwid" lines (kind: 0 culled ICP, 1 unculled ICP, 2 residual) to `path`
 void trace_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, const char* path)
@@ -1719,8 +1909,8 @@ void trace_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const Rgb
     for (int b = 0; b < g_last_grid; b++) if (h[(size_t)b * 4] && h[(size_t)b * 4] < tmin) tmin = h[(size_t)b * 4];
     fprintf(f, "# grid %d icp_blocks %d trackers %d\n", g_last_grid, g_last_n_icp_blocks, n);
     for (int b = 0; b < g_last_grid; b++) {
-        int slot = 0; while (slot < 2 * kMaxBatch - 1 && b >= g_last_icp_args.slot_end[slot]) slot++;
-        const int model = g_last_icp_args.slot_desc[slot] & 0x7f;
+        int slot = 0; while (slot < kMaxSlots - 1 && b >= g_last_icp_args.slot_end[slot]) slot++;
+        const int model = g_last_icp_args.slot_desc[slot] & 0x3f;
         const int kind = (g_last_icp_args.slot_desc[slot] & kResidualSlot) ? 2 : (g_last_icp_args.m[model].box_blocks > 0 ? 0 : 1);
         const unsigned long long* o = &h[(size_t)b * 4];
         fprintf(f, "%d %d %d %lld %lld %u %u\n", b, kind, model, (long long)(o[0] - tmin) * 10, (long long)(o[1] - tmin) * 10, (unsigned)(o[2] & 255u), (unsigned)(o[2] >> 8));

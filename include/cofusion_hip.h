@@ -441,8 +441,10 @@ int cf_seg_fetch_poses(cf_segmenter *s, int n_models, int64_t *words_host);
 int cf_seg_labels(cf_segmenter *s, void **dptr, uint64_t *bytes);
 
 /* data path between the RGB residual pass and the RGB step inside the device-resident Gauss-Newton loop.  1 (default): the
- * residual pass packs the valid correspondences of each workgroup into 8 B records; 0: the reference's 16 B DataTerm record
- * per pixel (diagnostic / comparison).  Results are bit-identical. */
+ * residual pass packs the valid correspondences of each workgroup into 8 B records, RGB step and 6x6 solve are launches of their
+ * own (three launches per iteration); 2: the same records, the RGB step's workgroups of a tracker share one XCD and the last of
+ * them to finish runs the solve (two launches per iteration; measured slower at 640x480, kept as an option); 0: the reference's
+ * 16 B DataTerm record per pixel (diagnostic / comparison).  Results are bit-identical in all three. */
 int cf_set_gn_mode(cf_ctx *ctx, int mode);
 /* launch-shape tuning of the ICP reduction (GPUConfig.h:51-58 in the reference) */
 int cf_set_icp_launch(cf_ctx *ctx, int threads, int pixels_per_thread);
