@@ -267,7 +267,7 @@ inline RgbModelArgs rgb_model_args(const OdomDev* h /* host mirror */, OdomDev* 
                         reinterpret_cast<unsigned*>(reinterpret_cast<uint2*>(h->corres[level]) + (size_t)(h->width >> level) * (h->height >> level)),
                         h->res_range ? h->res_range + 2 * level : nullptr, 0};
 }
-constexpr int kMaxSlots = 2 * kMaxBatch + 4;    // ICP + residual slot per model, one slot for all error surfaces (+ padding to a multiple of 4)
+constexpr int kMaxSlots = 2 * kMaxBatch;        // an ICP and a residual slot per model
 struct IcpArgs {
     IcpModelArgs m[kMaxBatch];
     int cols, rows;
@@ -281,11 +281,10 @@ struct IcpArgs {
     // layout of the one-dimensional grid (set by the launchers, icp_reduce_kernel): running totals of the workgroups per slot -- a slot
     // is the ICP reduction or the residual pass of one model -- and what every slot is; unused slots end at INT_MAX
     int slot_end[kMaxSlots];
-    unsigned char slot_desc[kMaxSlots];       // model | kResidualSlot, or kErrorSlot
-    int err_blocks; IDiv err_div;             // workgroups per error surface inside the error slot
+    unsigned char slot_desc[kMaxSlots];       // model | kResidualSlot
+    int slots_used;
 };
 constexpr unsigned char kResidualSlot = 0x80;   // the model's RGB residual pass
-constexpr unsigned char kErrorSlot = 0x40;      // the error surfaces of the culled models (last level-0 iteration), err_blocks workgroups each, one pixel per lane
 void launch_icp_level(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, int n, int level, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void launch_rgb_residual(hipStream_t s, const RgbArgs& ra, int n);
 void launch_rgb_step(hipStream_t s, const RgbArgs& ra, int n);

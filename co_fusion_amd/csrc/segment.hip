@@ -319,6 +319,9 @@ static void launch_crf_kernel_matrix(hipStream_t st, const CrfBatch& B, int S, i
 // by definition, so the only parallelism is across nodes, chunks and labels, and with one lane per (node, chunk) only ~300 waves existed
 // for 1024 SIMDs.  The chunk is walked 25 nodes at a time so that the kernel-matrix loads of a group are in flight together (the sums
 // stay in node order).  flip: the marginals are read from Q1 (odd steps) / Q0 (even steps).
+// Measured and dropped in round 5 (both bit-identical, DESIGN-NOTES R5): message + update as ONE launch -- a 1024-thread workgroup owning
+// 8 nodes, wave = chunk, lane = (node, label), chunk sums through LDS: 13.8 us per step against 7.6 + 4.9 -- and four nodes per lane
+// with 16-byte kernel-matrix loads: 8.2 against 7.6 us.  The step is three dependent rounds of loads behind a launch, not load issue.
 __global__ void __launch_bounds__(64) crf_message_kernel(const CrfBatch B, int n, int flip)
 {
     const CrfSeq& m = B.m[blockIdx.z];

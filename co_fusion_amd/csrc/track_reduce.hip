@@ -399,10 +399,10 @@ __device__ __forceinline__ bool icp_run(const IcpArgs& args, const IcpModelArgs&
 // The ICP error surface (icpStep's optional output, reduce.cu:327-331 / RGBDOdometry.cpp:414-431: the distance between every pixel's
 // vertex and the model vertex it projects onto, 0 when not finite / out of view) of the last level-0 iteration, one pixel per lane.
 // Until round 4 that iteration's ICP pass wrote it for every tracker, which kept the launch from culling anything (23.8 us against
-// 15.4 us for the nine iterations before it); now the culled trackers stay culled and this body writes THEIR surfaces in slots of their
-// own (kErrorSlot) of the same launch -- the same pose, the expressions of icp_run, the same bits.  (Round 4 had these workgroups in the
-// RGB step's launch that follows; with the solve inside that launch -- rgb_step_solve_kernel -- the pose would change under them.)
-// Unculled trackers write theirs in the ICP pass as before.
+// 15.4 us for the nine iterations before it); now the culled trackers stay culled and THEIR surfaces are written by a launch of its own
+// between that iteration's {ICP || residual} launch and its RGB step (icp_error_surface_kernel) -- the same pose, the expressions of
+// icp_run, the same bits.  (Round 4 had these workgroups in the RGB step's launch; with the solve inside that launch --
+// rgb_step_solve_kernel, cf_set_gn_mode 2 -- the pose would change under them.)  Unculled trackers write theirs in the ICP pass as before.
 __device__ __forceinline__ void icp_error_surface_body(const IcpArgs& args, const IcpModelArgs& ma, int blk)
 {
     float* __restrict__ errs = ma.err;
@@ -428,6 +428,8 @@ __device__ __forceinline__ void icp_error_surface_body(const IcpArgs& args, cons
     errs[i] = err;
 }
 
+__global__ void __launch_bounds__(256) icp_error_surface_kernel(const IcpArgs args) { icp_error_surface_body(args, args.m[blockIdx.y], (int)blockIdx.x); }
+
 // GRID.  One-dimensional, in SLOTS: a slot is the ICP reduction or the RGB residual pass of one model.  IcpArgs::slot_end holds the running
 // totals of the workgroups, IcpArgs::slot_desc what every slot is; the launcher orders them longest work first (launch_icp_kernel_arith).
 // Every slot starts at a multiple of 8, so hardware workgroup b and its slot-local index agree on the XCD (b % 8).
@@ -444,20 +446,16 @@ __device__ __forceinline__ void icp_reduce_body(const IcpArgs& args, const RgbAr
 {
     const int b = blockIdx.x;
     int slot = 0;
+    if (args.slots_used <= 12) {   // (up to six trackers: the common case pays 11 compares, not 31)
 #pragma unroll
-    for (int k = 0; k < kMaxSlots - 1; k++) slot += (b >= args.slot_end[k]) ? 1 : 0;  // (wide scalar loads of the table, 35 compares; unused slots end at INT_MAX)
+        for (int k = 0; k < 11; k++) slot += (b >= args.slot_end[k]) ? 1 : 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kMaxSlots - 1; k++) slot += (b >= args.slot_end[k]) ? 1 : 0;  // (two wide scalar loads of the table, 31 compares; unused slots end at INT_MAX)
+    }
     const int slot0 = slot ? args.slot_end[slot - 1] : 0, bx = b - slot0;
     const unsigned desc = args.slot_desc[slot];
-    const int model = (int)(desc & 0x3fu);
-    if (desc & kErrorSlot) {   // the k-th culled tracker with a surface
-        const int k = args.err_blocks > 1 ? idiv(bx, args.err_div) : bx;
-        int em = -1, seen = 0;
-#pragma unroll
-        for (int q = 0; q < kMaxBatch; q++)
-            if (args.m[q].cull && args.m[q].err) { if (seen == k) em = q; seen++; }
-        if (em >= 0) icp_error_surface_body(args, args.m[em], bx - k * args.err_blocks);
-        return;
-    }
+    const int model = (int)(desc & 0x7fu);
     if (desc & kResidualSlot) {
         if (ABL(32) || (ABL(16) && args.m[model].cull)) return;  // timing ablations (CF_ICP_REPLAY)
         if (ra.compact) rgb_residual_body<true>(ra, model, bx, args.slot_end[slot] - slot0);
@@ -518,8 +516,8 @@ __device__ __forceinline__ void icp_reduce_body(const IcpArgs& args, const RgbAr
     const int band0 = rb * cols, band1 = (re > 0 ? re : rows) * cols;
     // the error surface (last level-0 iteration) is written for the WHOLE image on every rank of a split model -- the segmentation
     // reads all of it -- while only the band's pixels enter the sums
-    // (flags & 1: this launch writes the error surfaces; & 2: ... those of culled trackers in the launch's error slot --
-    // icp_error_surface_body -- so that their ICP pass stays culled)
+    // (flags & 1: this launch writes the error surfaces; & 2: ... except those of culled trackers, which icp_error_surface_kernel
+    // writes right behind this launch, so that their ICP pass stays culled)
     const bool err_here = (args.flags & 1) && !((args.flags & 2) && ma.cull);
     const bool whole = err_here && ma.err != nullptr && ma.row_end > 0;
     const int pix0 = whole ? 0 : band0, pix1 = whole ? N : band1;
@@ -1688,13 +1686,7 @@ static void launch_icp_kernel_arith(hipStream_t s, IcpLaunch cfg, const IcpArgs&
         for (int m = 0; m < n && icp; m++) if (args.m[m].box_blocks > 0) add(m, false, blocks[m]);
         for (int m = 0; m < n && res; m++) if (culled(m)) add(m, true, ra.m[m].res_blocks);
     }
-    // ... and the error surfaces of the culled trackers on the iteration that writes them (flags 3), one pixel per lane: one slot
-    args.err_blocks = (args.cols * args.rows + cfg.threads - 1) / cfg.threads; args.err_div = make_idiv(args.err_blocks > 1 ? args.err_blocks : 2);
-    if (icp && (args.flags & 3) == 3) {
-        int n_err = 0;
-        for (int m = 0; m < n; m++) n_err += (args.m[m].cull && args.m[m].err) ? 1 : 0;
-        if (n_err) { total += ((n_err * args.err_blocks + 7) / 8) * 8; args.slot_end[slot] = total; args.slot_desc[slot] = kErrorSlot; slot++; }
-    }
+    args.slots_used = slot;
     for (; slot < kMaxSlots; slot++) { args.slot_end[slot] = 0x7fffffff; args.slot_desc[slot] = 0; }
     const dim3 grid(total);
 #ifdef CF_ABLATE
@@ -1782,8 +1774,8 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
         gn.od_host[m] = h_states ? h_states[m] : nullptr;
     }
     const bool slots = mode != 0;
-    // the error surfaces of the last level-0 iteration: those of culled trackers by an error slot of that iteration's launch (these
-    // trackers stay culled in their ICP pass: IcpArgs::flags 3), the others by their ICP pass itself (flags 1)
+    // the error surfaces of the last level-0 iteration: those of culled trackers by a launch of its own behind that iteration's
+    // {ICP || residual} launch (these trackers stay culled in their ICP pass: IcpArgs::flags 3), the others by their ICP pass (flags 1)
     bool any_culled = false;
     for (int m = 0; m < n; m++) any_culled = any_culled || (icp_args[0].m[m].cull && icp_args[0].m[m].err);
     const bool err_aside = icp && any_culled;
@@ -1812,6 +1804,10 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
                     prof->bytes += (uint64_t)N * ((icp ? 24 + 24 * (uint64_t)n : 0) + (rgb ? (slots ? kRgbResidualBytesCompact : kRgbResidualBytes) * (uint64_t)n : 0));
                     prof->launches += 1;
                 }
+            }
+            if (err_aside && i == 0 && last_of_level) {
+                IcpArgs e = icp_args[i]; e.cdiv = make_idiv(e.cols);
+                icp_error_surface_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(e);
             }
             if (hook && hook->fn)  // split reductions: the partial sums of this rank's row band become the totals on every rank
                 for (int m = 0; m < n; m++)
@@ -1910,7 +1906,7 @@ void trace_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const Rgb
     fprintf(f, "# grid %d icp_blocks %d trackers %d\n", g_last_grid, g_last_n_icp_blocks, n);
     for (int b = 0; b < g_last_grid; b++) {
         int slot = 0; while (slot < kMaxSlots - 1 && b >= g_last_icp_args.slot_end[slot]) slot++;
-        const int model = g_last_icp_args.slot_desc[slot] & 0x3f;
+        const int model = g_last_icp_args.slot_desc[slot] & 0x7f;
         const int kind = (g_last_icp_args.slot_desc[slot] & kResidualSlot) ? 2 : (g_last_icp_args.m[model].box_blocks > 0 ? 0 : 1);
         const unsigned long long* o = &h[(size_t)b * 4];
         fprintf(f, "%d %d %d %lld %lld %u %u\n", b, kind, model, (long long)(o[0] - tmin) * 10, (long long)(o[1] - tmin) * 10, (unsigned)(o[2] & 255u), (unsigned)(o[2] >> 8));
