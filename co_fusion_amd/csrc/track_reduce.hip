@@ -378,10 +378,11 @@ __device__ __forceinline__ bool icp_run(const IcpArgs& args, const IcpModelArgs&
             }
         } else
         if (__any(any_found) || abl != 0) {
+            // (every lane's every product carries the magic number's bits: 64 * PPT of them per word come off ONCE, behind the butterfly --
+            // wrapping 64-bit arithmetic -- instead of 28 two-instruction subtractions per lane)
             unsigned long long acc[32];
 #pragma unroll
-            for (int k = 0; k < 28; k++) acc[k] = 0ull - (unsigned long long)PPT * kMagicBits;
-            acc[28] = acc[29] = acc[30] = acc[31] = 0;
+            for (int k = 0; k < 32; k++) acc[k] = 0;
 #pragma unroll
             for (int p = 0; p < PPT; p++) {
                 if (!(abl & 1)) se3_accumulate<kFixICP>(row[p], acc);
@@ -390,6 +391,7 @@ __device__ __forceinline__ bool icp_run(const IcpArgs& args, const IcpModelArgs&
             }
             if (abl & 2) { if (acc[0] + acc[28] == 0x1234567ull) ma.acc[lane] = acc[5]; done = true; return true; }
             v = wave_reduce32_u64(acc, lane);
+            if (((lane >> 1) & 31) < 28 && !(abl & 1)) v -= 64ull * (unsigned long long)PPT * kMagicBits;
             if (abl & 4) { if (v == 0x1234567ull) ma.acc[lane] = v; done = true; return true; }
         }
     }
@@ -445,24 +447,37 @@ template <int PPT, bool GRAM>
 __device__ __forceinline__ void icp_reduce_body(const IcpArgs& args, const RgbArgs& ra, int n_icp_blocks)
 {
     const int b = blockIdx.x;
-    int slot = 0;
-    if (args.slots_used <= 12) {   // (up to six trackers: the common case pays 11 compares, not 31)
+    // Slot decode on the scalar unit, from ONE clause of kernel-argument loads: table entries and descriptor bytes by static index (a
+    // dynamic index into the argument segment is a dependent load each), the slot's bounds picked up along the way.  Then the model's
+    // argument block as one more clause (pinned: the compiler otherwise loads field by field at first use -- ten dependent scalar
+    // round trips in front of a wave's first vector load, each a miss for the first wave on a CU).
+    int slot0 = 0, send, desc;
+    {
+        int e[12], d[12];
 #pragma unroll
-        for (int k = 0; k < 11; k++) slot += (b >= args.slot_end[k]) ? 1 : 0;
-    } else {
+        for (int k = 0; k < 12; k++) { e[k] = args.slot_end[k]; d[k] = args.slot_desc[k]; }
+        asm volatile("" :: "s"(e[0]), "s"(e[1]), "s"(e[2]), "s"(e[3]), "s"(e[4]), "s"(e[5]), "s"(e[6]), "s"(e[7]), "s"(e[8]), "s"(e[9]), "s"(e[10]), "s"(e[11]),
+                     "s"(d[0]), "s"(d[4]), "s"(d[8]), "s"(args.slots_used), "s"(ra.compact), "s"(ra.slot_px), "s"((int)blockDim.x));
+        send = e[0]; desc = d[0];
 #pragma unroll
-        for (int k = 0; k < kMaxSlots - 1; k++) slot += (b >= args.slot_end[k]) ? 1 : 0;  // (two wide scalar loads of the table, 31 compares; unused slots end at INT_MAX)
+        for (int k = 1; k < 12; k++) { const bool ge = b >= e[k - 1]; slot0 = ge ? e[k - 1] : slot0; send = ge ? e[k] : send; desc = ge ? d[k] : desc; }
     }
-    const int slot0 = slot ? args.slot_end[slot - 1] : 0, bx = b - slot0;
-    const unsigned desc = args.slot_desc[slot];
+    if (args.slots_used > 12) {   // (more than six trackers: the rest of the table)
+#pragma unroll
+        for (int k = 12; k < kMaxSlots; k++) { const bool ge = b >= args.slot_end[k - 1]; slot0 = ge ? args.slot_end[k - 1] : slot0; send = ge ? args.slot_end[k] : send; desc = ge ? (int)args.slot_desc[k] : desc; }
+    }
+    const int bx = b - slot0;
     const int model = (int)(desc & 0x7fu);
     if (desc & kResidualSlot) {
         if (ABL(32) || (ABL(16) && args.m[model].cull)) return;  // timing ablations (CF_ICP_REPLAY)
-        if (ra.compact) rgb_residual_body<true>(ra, model, bx, args.slot_end[slot] - slot0);
+        if (ra.compact) rgb_residual_body<true>(ra, model, bx, send - slot0);
         else rgb_residual_body<false>(ra, model, bx, 0);
         return;
     }
-    const IcpModelArgs& ma = args.m[model];
+    const IcpModelArgs ma = args.m[model];
+    asm volatile("" :: "s"(ma.vc), "s"(ma.nc), "s"(ma.vp), "s"(ma.np), "s"(ma.st), "s"(ma.acc), "s"(ma.err), "s"(ma.occ), "s"(ma.zr), "s"(ma.row_begin), "s"(ma.row_end),
+                 "s"(ma.cull), "s"(ma.box_blocks), "s"(args.cols), "s"(args.rows), "s"(args.flags), "s"(args.occ_shift), "s"(args.occ_w), "s"(args.cdiv.M), "s"(args.cdiv.s),
+                 "s"(args.row_begin), "s"(args.row_end), "s"(args.intr.fx), "s"(args.intr.fy), "s"(args.intr.cx), "s"(args.intr.cy), "s"(args.angleSqLt), "s"(args.distSqLe));
     if (ABL(256) && !ma.cull) return;  // timing ablation (CF_ICP_REPLAY): unculled models do nothing
     StatePtr st = (StatePtr)ma.st;
     const int cols = args.cols, rows = args.rows, N = cols * rows;
@@ -680,6 +695,32 @@ __device__ __forceinline__ bool rgb_residual_pixel(const RgbArgs& ra, const RgbM
 // the host from what the previous call saw -- take the slots in between, walking on by nblk when there are more than expected.
 // Slots outside hold no record: the RGB step applies the same test instead of reading their (stale) counts.
 struct SlotRange { int first, last; };
+// (the two words through the constant address space -- the preparation wrote them launches ago --, from a dummy address when the tracker
+// has no range, so that the load is unconditional and can share a clause with the hot state's: rgb_hot_and_range)
+__device__ __forceinline__ SlotRange residual_slot_range_from(const RgbArgs& ra, bool ranged, unsigned lo_inv, unsigned hi_p1, int n_slots)
+{
+    if (!ranged) return SlotRange{0, n_slots - 1};
+    if (hi_p1 == 0) return SlotRange{0, -1};
+    const int sh = __builtin_ctz(ra.slot_px) - 8;                     // slot_px = 4 x workgroup size: a power of two >= 256
+    return SlotRange{(int)((~lo_inv) >> sh), min((int)((hi_p1 - 1u) >> sh), n_slots - 1)};
+}
+__device__ __forceinline__ RgbHot rgb_hot_and_range(const RgbArgs& ra, const RgbModelArgs& m, int n_slots, SlotRange& sr)
+{
+    StatePtr st = (StatePtr)m.st;
+    typedef const __attribute__((address_space(4))) unsigned* U4;
+    U4 rp = m.res_range ? (U4)m.res_range : (U4)&st->hot;
+    const hot16 l2 = hot_line(st, 2);
+    const unsigned lo_inv = rp[0], hi_p1 = rp[1];
+    asm volatile("" :: "s"(l2), "s"(lo_inv), "s"(hi_p1));
+    sr = residual_slot_range_from(ra, m.res_range != nullptr, lo_inv, hi_p1, n_slots);
+    RgbHot h;
+    h.rgb = l2[0]; h.rgbOnly = l2[1]; h.level_done = l2[2];
+#pragma unroll
+    for (int k = 0; k < 9; k++) h.krk[k] = hot_f(l2, 4 + k);
+#pragma unroll
+    for (int k = 0; k < 3; k++) h.kt[k] = hot_f(l2, 13 + k);
+    return h;
+}
 __device__ __forceinline__ SlotRange residual_slot_range(const RgbArgs& ra, const RgbModelArgs& m, int n_slots)
 {
     if (!m.res_range) return SlotRange{0, n_slots - 1};
@@ -692,7 +733,9 @@ __device__ __forceinline__ SlotRange residual_slot_range(const RgbArgs& ra, cons
 template <bool COMPACT>
 __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk, int nblk)
 {
-    const RgbModelArgs& m = ra.m[model];
+    const RgbModelArgs m = ra.m[model];   // (one clause of kernel-argument loads: see icp_reduce_body)
+    asm volatile("" :: "s"(m.st), "s"(m.cand), "s"(m.nextDepth), "s"(m.lastDepth), "s"(m.lastImage), "s"(m.nextImage), "s"(m.icp_acc), "s"(m.recs), "s"(m.slot_counts),
+                 "s"(m.res_range), "s"(m.no_counts), "s"(m.corres), "s"(ra.cols), "s"(ra.rows), "s"(ra.slot_px), "s"(ra.cdiv.M), "s"(ra.cdiv.s), "s"(ra.maxDepthDelta));
     StatePtr st = (StatePtr)m.st;
     const int cols = ra.cols, rows = ra.rows, N = cols * rows;
     const int T = blockDim.x;
@@ -731,8 +774,8 @@ __device__ void rgb_residual_body(const RgbArgs& ra, int model, int blk, int nbl
     } else {
         __shared__ int s_n, s_sig;
         const int n_slots = (N + T * 4 - 1) / (T * 4);
-        const SlotRange sr = residual_slot_range(ra, m, n_slots);
-        const RgbHot hs = rgb_hot(st);   // (one scalar clause beside the range's)
+        SlotRange sr;
+        const RgbHot hs = rgb_hot_and_range(ra, m, n_slots, sr);   // (one scalar clause for the state and the range)
         const bool on = hs.rgb && !hs.level_done;  // uniform
         if (!on) return;
 #pragma nounroll
@@ -1458,15 +1501,16 @@ __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int ne
 // separate kernels plus one boundary: the device-scope release fence and the arrival wait cost more than a kernel boundary does.
 __global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra, int n_slots)
 {
-    const RgbModelArgs& m = ra.m[blockIdx.y];
-    const RgbHot hs = rgb_hot((StatePtr)m.st);
+    const RgbModelArgs m = ra.m[blockIdx.y];
+    asm volatile("" :: "s"(m.st), "s"(m.icp_acc), "s"(m.rgb_acc), "s"(m.recs), "s"(m.slot_counts), "s"(m.res_range), "s"(m.cloud), "s"(m.dIdx), "s"(m.dIdy),
+                 "s"(ra.cols), "s"(ra.rows), "s"(ra.slot_px), "s"(ra.sobelScale), "s"(ra.il.fx), "s"(ra.il.fy));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t slot0 = (size_t)blockIdx.x * ra.slot_px;
     unsigned n = m.slot_counts[blockIdx.x];
-    {   // (a slot outside a culled tracker's candidate range was not visited by the residual pass: its count is stale, it holds nothing)
-        const SlotRange sr = residual_slot_range(ra, m, n_slots);
-        if ((int)blockIdx.x < sr.first || (int)blockIdx.x > sr.last) n = 0;
-    }
+    SlotRange sr;
+    const RgbHot hs = rgb_hot_and_range(ra, m, n_slots, sr);
+    // (a slot outside a culled tracker's candidate range was not visited by the residual pass: its count is stale, it holds nothing)
+    if ((int)blockIdx.x < sr.first || (int)blockIdx.x > sr.last) n = 0;
     uint2 rc = make_uint2(0, 0);
     if (tid < ra.slot_px && slot0 + tid < (size_t)ra.cols * ra.rows) rc = m.recs[slot0 + tid];   // speculative: valid if tid < n
     if (!(hs.rgb && !hs.level_done) || n == 0) return;  // uniform
@@ -1648,12 +1692,12 @@ static void launch_icp_kernel_arith(hipStream_t s, IcpLaunch cfg, const IcpArgs&
         if (!ra.compact || !rm.res_range || rm.res_blocks <= 0 || rm.res_blocks > n_res_blocks) rm.res_blocks = n_res_blocks;
         if (!ra.compact) rm.res_range = nullptr;
     }
-    // ORDER OF THE SLOTS = order of dispatch.  The launch is a little over one round of resident workgroups (about 1 400 at a time,
-    // tools/icp_trace_summary.py), so what is dispatched last ends last: longest work first -- the residual pass of the unculled
-    // trackers (a background workgroup finds ~100 correspondences: 6 us), their ICP reduction (4.6 us), then the culled trackers' runs
-    // (3-5 us) and their residual slots (2 us).  Until round 5 the culled runs came first and the residual passes last: the launch ended
-    // on a 5 us tail of background residual workgroups.  Every slot is padded to a multiple of 8 workgroups so that the hardware
-    // workgroup id and the slot-local index agree on the XCD; the padding leaves at once.
+    // ORDER OF THE SLOTS = order of dispatch: the culled trackers' runs (the longest chain of dependent round trips: box, depth interval,
+    // planes, occupancy, gather), the unculled ICP reductions, then the residual passes.  Seven orders were measured in round 5 (longest work
+    // first, residual passes first, ...; a diagnostics build reads CF_ICP_ORDER): 13.8-14.0 us for this one, 14.0-14.5 us for the others --
+    // the launch is a little over one round of resident workgroups and its length is the sum of everybody's residency, not its tail
+    // (tools/icp_trace_summary.py).  Every slot is padded to a multiple of 8 workgroups so that the hardware workgroup id and the
+    // slot-local index agree on the XCD; the padding leaves at once.
     int total = 0, slot = 0, n_icp_blocks = 0;
     auto add = [&](int m, bool residual, int count) {
         total += ((count + 7) / 8) * 8;
@@ -1661,14 +1705,26 @@ static void launch_icp_kernel_arith(hipStream_t s, IcpLaunch cfg, const IcpArgs&
         if (!residual) n_icp_blocks += count;
     };
 #ifdef CF_ABLATE
-    static const int order = getenv("CF_ICP_ORDER") ? atoi(getenv("CF_ICP_ORDER")) : 1;
+    static const int order = getenv("CF_ICP_ORDER") ? atoi(getenv("CF_ICP_ORDER")) : 0;
 #else
-    constexpr int order = 1;
+    constexpr int order = 0;
 #endif
     const bool res = n_res_blocks > 0;
     auto culled = [&](int m) { return args.m[m].box_blocks > 0 || (args.m[m].cull && ra.m[m].res_range); };
     if (order == 0) {          // rounds 3-4: culled ICP, unculled ICP, residual passes
         for (int pass = 0; pass < 2 && icp; pass++) for (int m = 0; m < n; m++) if ((args.m[m].box_blocks > 0) == (pass == 0)) add(m, false, blocks[m]);
+        for (int m = 0; m < n && res; m++) add(m, true, ra.m[m].res_blocks);
+    } else if (order == 4) {   // culled ICP, unculled residual, unculled ICP, culled residual
+        for (int m = 0; m < n && icp; m++) if (args.m[m].box_blocks > 0) add(m, false, blocks[m]);
+        for (int m = 0; m < n && res; m++) if (!culled(m)) add(m, true, ra.m[m].res_blocks);
+        for (int m = 0; m < n && icp; m++) if (!(args.m[m].box_blocks > 0)) add(m, false, blocks[m]);
+        for (int m = 0; m < n && res; m++) if (culled(m)) add(m, true, ra.m[m].res_blocks);
+    } else if (order == 5) {   // culled ICP, unculled ICP, culled residual, unculled residual
+        for (int pass = 0; pass < 2 && icp; pass++) for (int m = 0; m < n; m++) if ((args.m[m].box_blocks > 0) == (pass == 0)) add(m, false, blocks[m]);
+        for (int m = 0; m < n && res; m++) if (culled(m)) add(m, true, ra.m[m].res_blocks);
+        for (int m = 0; m < n && res; m++) if (!culled(m)) add(m, true, ra.m[m].res_blocks);
+    } else if (order == 6) {   // unculled ICP, culled ICP, residual passes
+        for (int pass = 0; pass < 2 && icp; pass++) for (int m = 0; m < n; m++) if ((args.m[m].box_blocks > 0) == (pass == 1)) add(m, false, blocks[m]);
         for (int m = 0; m < n && res; m++) add(m, true, ra.m[m].res_blocks);
     } else if (order == 2) {   // unculled ICP, unculled residual, culled ICP, culled residual
         for (int m = 0; m < n && icp; m++) if (!(args.m[m].box_blocks > 0)) add(m, false, blocks[m]);
