@@ -382,6 +382,15 @@ def main(argv=None):
     cf.profile_enable(False)
     fps = args.steps * (1 if model_parallel else world) * S / dt
 
+    # Parity of the run itself ("make the 8-GPU tier check, not just time"): a digest of the state the timed steps ended in --
+    # model ids, poses, confidence thresholds, surfel counts (summed over their owners), the label mask.  With object models spread over
+    # the GPUs, rank 0 then plays the SAME frames through a single-GPU instance and compares: the line says whether N GPUs gave the bits
+    # one GPU gives.  (Independent replicas: rank 0's sequence is the N = 1 sequence; its digest is the same at every N.)
+    parity = None
+    try:
+        parity = parity_vs_n1(args, torch, dist, facade, cf, streams[0], rank, world, local_rank, model_parallel, W, H, cam, P, pre_masks, use_gt, gt_mask)
+    except Exception as e:  # noqa: BLE001 -- the headline line must not depend on this leg
+        parity = dict(error=str(e))
     replicas = None
     if world > 1 and not args.no_extras:
         try:
@@ -437,6 +446,8 @@ def main(argv=None):
                                background="split over the ranks (replicated map; surfel-range index map + row-band ICP with all-reduce)" if (model_parallel and args.shard_background) else "one rank",
                                frames=("broadcast from rank 0 every step, consumed in stream order" if model_parallel else "ring of device-resident frames, complete before each call (device_frames_complete=1)")),
                    roofline=roofline)
+        if parity is not None:
+            out["parity_vs_n1"] = parity
         if replicas is not None:
             out["replicas"] = replicas
         if world == 1 and S == 1 and not args.no_extras:
@@ -453,6 +464,62 @@ def main(argv=None):
         st["cf"].close()
     if dist is not None:
         dist.destroy_process_group()
+    return out
+
+
+def state_digest(cf, counts=None):
+    """sha256 over (number of models; per model: id, pose bits, confidence threshold bits, surfel count) + the label mask"""
+    import hashlib
+    h = hashlib.sha256()
+    n = cf.num_models
+    h.update(np.int32(n).tobytes())
+    for i in range(n):
+        info = cf.model_info(i)
+        h.update(np.int32(info["id"]).tobytes()); h.update(np.ascontiguousarray(info["pose"], np.float32).tobytes())
+        h.update(np.float32(info["conf_threshold"]).tobytes())
+        h.update(np.int64(info["count"] if counts is None else counts[i]).tobytes())
+    h.update(np.ascontiguousarray(cf.mask()).tobytes())
+    return h.hexdigest()
+
+
+def parity_vs_n1(args, torch, dist, facade, cf, st, rank, world, local_rank, model_parallel, W, H, cam, P, pre_masks, use_gt, gt_mask):
+    total = P + args.warmup + args.steps
+    if not model_parallel:
+        return dict(sha256=state_digest(cf), frames_played=total,
+                    what="ids, poses, confidence thresholds, surfel counts, label mask after the timed steps; the same at every N (rank 0's sequence)") if rank == 0 else None
+    n = cf.num_models
+    dev = torch.device("cuda", local_rank)
+    own = torch.tensor([cf.model_info(i)["count"] if cf.model_owned(i) else 0 for i in range(n)], dtype=torch.int64,
+                       device=dev if dist.get_backend() == "nccl" else "cpu")
+    owners = torch.tensor([1 if cf.model_owned(i) else 0 for i in range(n)], dtype=torch.int64, device=own.device)
+    dist.all_reduce(own); dist.all_reduce(owners)
+    if args.shard_background and n:   # every rank holds a replica of the split background: counted once
+        own[0] = own[0] // max(1, int(owners[0].item()))
+    out = None
+    if rank == 0:
+      try:   # (whatever happens here, rank 0 meets the others at the barrier below)
+        sha_par = state_digest(cf, counts=[int(v) for v in own.cpu().tolist()])
+        single = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels, enable_multiple_models=1,
+                                 device_frames_complete=1)
+        if args.icp_ppt:
+            single.set_icp_launch(args.icp_threads, args.icp_ppt)
+        if args.gn_mode >= 0:
+            single.set_gn_mode(args.gn_mode)
+        for i in range(total):
+            k = frame_index(i, args.frames)
+            f = st["frames"][k]
+            if (i < P and pre_masks == "gt") or use_gt:
+                single.process_frame(f["depth"], f["rgb"], mask=gt_mask(f), timestamp=i)
+            else:
+                single.process_frame_device(st["resident"][k]["depth"], st["resident"][k]["rgba"], timestamp=i)
+        sha_one = state_digest(single)
+        single.close()
+        out = dict(identical=(sha_par == sha_one), sha256=sha_par, sha256_one_gpu=sha_one, frames_played=total,
+                   what="rank 0 replayed the same frames through a single-GPU instance after the timed steps: ids, poses, confidence thresholds, "
+                        "surfel counts (from their owners), label mask")
+      except Exception as e:  # noqa: BLE001
+        out = dict(error=str(e))
+    dist.barrier()
     return out
 
 

@@ -1389,9 +1389,27 @@ void CoFusionGroup::stepAll(const FrameData* frames, const Mat4f* const* inPoses
     // and the decisions of all sequences
     {
         std::vector<cf_seg_job> jobs;
+        std::vector<int> owner;   // the sequence every job belongs to
         jobs.reserve((size_t)S);
-        for (int s = 0; s < S; s++) seqs[s]->frameSegment(&jobs);
-        Segmentation::runBatch(ctx, seqs[0]->segmentation(), jobs);
+        for (int s = 0; s < S; s++) {
+            const size_t before = jobs.size();
+            seqs[s]->frameSegment(&jobs);
+            if (jobs.size() > before) owner.push_back(s);
+        }
+        // cf_seg_run_batch takes ONE parameter set per chain: sequences whose CRF settings differ (cofusion_set_crf on a borrowed handle)
+        // get chains of their own, so that every sequence still equals a separate instance bit for bit
+        std::vector<char> done(jobs.size(), 0);
+        for (size_t a = 0; a < jobs.size(); a++) {
+            if (done[a]) continue;
+            const cf_seg_params Pa = seqs[owner[a]]->segmentation().deviceParams();
+            std::vector<cf_seg_job> chain;
+            for (size_t b = a; b < jobs.size(); b++) {
+                if (done[b]) continue;
+                const cf_seg_params Pb = seqs[owner[b]]->segmentation().deviceParams();
+                if (memcmp(&Pa, &Pb, sizeof(Pa)) == 0) { chain.push_back(jobs[b]); done[b] = 1; }
+            }
+            Segmentation::runBatch(ctx, seqs[owner[a]]->segmentation(), chain);
+        }
     }
     for (int s = 0; s < S; s++) seqs[s]->frameCollect();
     {   // the surfel passes of ALL sequences' models in one chain of batched launches

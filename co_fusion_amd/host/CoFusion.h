@@ -219,7 +219,8 @@ class Segmentation {
     float* zeroImage = nullptr;   // device zeros [H*W*4] standing in for the ICP error / confidence maps of shadow models
     std::vector<const float*> jobIcp, jobConf;  // collectCRF's arrays
     std::vector<uint32_t> jobIds;
-    cf_seg_params deviceParams() const;
+  public:
+    cf_seg_params deviceParams() const;   // (the group compares the sequences' settings: one batched chain per distinct set)
 };
 
 class CoFusion {

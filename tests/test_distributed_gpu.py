@@ -104,7 +104,7 @@ def test_surfel_range_sharded_index_map_min_allreduce_is_exact(tmp_path):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
 
 
-def _mp_worker(rank, world, port, out_dir, use_gt, shard_bg=False, size=(320, 240), n_frames=9, n_obj=2):
+def _mp_worker(rank, world, port, out_dir, use_gt, shard_bg=False, size=(320, 240), n_frames=9, n_obj=2, rccl=False):
     import sys
     import warnings
     here = os.path.dirname(os.path.abspath(__file__))
@@ -112,15 +112,23 @@ def _mp_worker(rank, world, port, out_dir, use_gt, shard_bg=False, size=(320, 24
     warnings.filterwarnings("ignore", category=RuntimeWarning)
     from co_fusion_amd import facade, synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = rank if rccl else 0   # rccl: one GPU per rank, the library's own RCCL communicator; otherwise gloo callbacks on the one GPU
+    if rccl:
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         W, H = size
         cam = synth.Camera.scaled(W, H)
         sc = synth.Scene(n_obj=n_obj)
-        kw = dict(max_surfels=1 << (22 if W > 640 else 21 if W > 320 else 19), conf_global_init=0.5, model_spawn_offset=2, enable_multiple_models=1)
+        kw = dict(max_surfels=1 << (22 if W > 640 else 21 if W > 320 else 19), conf_global_init=0.5, model_spawn_offset=2, enable_multiple_models=1, device=dev)
         single = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, **kw)                  # the whole job on one GPU
         par = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, rank=rank, world=world, shard_background=int(shard_bg), **kw)   # this rank's share
-        par.set_allreduce()
+        if rccl:
+            par.init_rccl()
+        else:
+            par.set_allreduce()
         msgs, owned_any, shadow_any = [], False, False
         for t in range(n_frames):
             d, rgb, lab, _ = sc.render(cam, t, noise=True)
@@ -188,6 +196,51 @@ def test_background_split_at_1280x960_matches_single_gpu(tmp_path, world):
     mp.spawn(_mp_worker, args=(world, port, str(tmp_path), False, True, (1280, 960), 18, 4), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+# ---- two (or more) devices: the same comparisons over the library's RCCL communicator, one GPU per rank ("no test in the
+# tree runs two RCCL ranks even when two devices are visible").  Skipped on the one-GPU box these tests are developed on; an 8-GPU node
+# runs them.
+_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs (one RCCL rank per device)")
+
+
+@_two_gpus
+@pytest.mark.parametrize("use_gt", [False, True])
+def test_model_parallel_frame_loop_over_rccl_matches_single_gpu(tmp_path, use_gt):
+    """object models on GPU 1, the background on GPU 0, poses and segmentation sums exchanged by ncclAllReduce inside the library
+    (cofusion_init_rccl): every frame's poses, masks, thresholds and the owned surfel maps equal the single-GPU run bit for bit"""
+    world = min(torch.cuda.device_count(), 3)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_mp_worker, args=(world, port, str(tmp_path), use_gt, False, (320, 240), 9, 2, True), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+@_two_gpus
+def test_background_split_over_rccl_ranks_matches_single_gpu(tmp_path):
+    """the split background at 640x480 over two RCCL ranks on two GPUs: MIN all-reduce of the index-map keys, SUM all-reduce of the
+    normal equations after every launch of the Gauss-Newton loop -- both ncclAllReduce in place on the context's stream"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_mp_worker, args=(2, port, str(tmp_path), False, True, (640, 480), 8, 4, True), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+@_two_gpus
+def test_bench_line_checks_itself_against_one_gpu(tmp_path):
+    """bench.py --gpus 2: the line's parity_vs_n1 says that two GPUs produced the bits one GPU produces on the same frames"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--preroll", "40",
+                          "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_world"] == 2, line["config"]
+    assert line["parity_vs_n1"].get("identical") is True, line["parity_vs_n1"]
 
 
 def test_library_rccl_communicator_executes_on_the_gpu():

@@ -25,13 +25,16 @@ def _compare(group, singles, t, what):
             assert a.model_download(i).tobytes() == b.model_download(i).tobytes(), f"{what} frame {t} sequence {s} model {i}: surfels"
 
 
-def _run(S, W, H, n_obj, frames, use_gt=False, device_frames=False, **kw):
+def _run(S, W, H, n_obj, frames, use_gt=False, device_frames=False, crf=None, **kw):
     import torch
     from co_fusion_amd import facade
     cam = synth.Camera.scaled(W, H)
     scenes = [synth.Scene(n_obj=n_obj, seed=1234 + 17 * s) for s in range(S)]
     group = facade.CoFusionGroup(S, W, H, cam.fx, cam.fy, cam.cx, cam.cy, **kw)
     singles = [facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, **kw) for _ in range(S)]
+    for s, c in enumerate(crf or []):   # per-sequence CRF settings (cofusion_set_crf on the borrowed handle and on the separate instance)
+        if c:
+            group.sequences[s].set_crf(**c); singles[s].set_crf(**c)
     most = 0
     for t in range(frames):
         rendered = [sc.render(cam, t, noise=True) for sc in scenes]
@@ -72,6 +75,15 @@ def test_multi_object_sequences_in_lockstep_match_separate_instances():
     """two multi-object sequences with the motion CRF: spawning happens at different frames in the two sequences, each keeps its own
     segmentation and model list"""
     most = _run(2, 320, 240, 3, 12, conf_global_init=0.5, model_spawn_offset=2, enable_multiple_models=1, max_surfels=1 << 19)
+    assert most >= 2, "no object model was spawned"
+
+
+def test_sequences_with_different_crf_settings_keep_their_own():
+    """the group's batched segmentation chain took sequence 0's CRF parameters for everybody.  Two sequences whose settings
+    differ (weights, new-label threshold, 6 instead of 10 mean-field steps) still equal separate instances bit for bit: sequences with
+    different settings get chains of their own"""
+    most = _run(2, 320, 240, 3, 12, conf_global_init=0.5, model_spawn_offset=2, enable_multiple_models=1, max_surfels=1 << 19,
+                crf=[None, dict(weight_appearance=5.0, weight_smoothness=3.0, threshold_new=4.5, iterations=6)])
     assert most >= 2, "no object model was spawned"
 
 
