@@ -100,6 +100,7 @@ def parse(argv=None):
                          "rounded once and contracted on the matrix cores; the oracle legs follow")
     ap.add_argument("--gn-mode", type=int, default=-1, help="-1: library default; 0: three launches per GN iteration; 1: two")
     ap.add_argument("--max-surfels", type=int, default=None)
+    ap.add_argument("--late-index-maps", action="store_true", help="A/B: rasterise the index maps after the frame's host wait (round 4) instead of before it")
     ap.add_argument("--enqueue-threads", type=int, default=None, help="host threads enqueueing the per-model surfel passes (library default: 0)")
     ap.add_argument("--parallel", default=None, choices=["streams", "models"],
                     help="N > 1: 'models' (default for object workloads) = ONE sequence, its object models placed on the GPUs (strong "
@@ -273,6 +274,7 @@ def main(argv=None):
                               # single GPU / independent streams: the ring of frames is resident before timing starts; model-parallel:
                               # ranks > 0 receive every frame by broadcast just before the call, so frames are consumed in stream order
                               device_frames_complete=0 if model_parallel else 1,
+                              **(dict(early_index_maps=0) if args.late_index_maps else {}),
                               **(dict(enqueue_threads=args.enqueue_threads) if args.enqueue_threads is not None else {}),
                               **(dict(rank=rank, world=world, shard_background=int(args.shard_background),
                                       colocate_background=int(n_obj >= world)) if model_parallel else {}))
@@ -422,6 +424,19 @@ def main(argv=None):
                         frac_icp_bytes_only=round(icp_only / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4),
                         bytes_processed_per_launch=int(processed), pixels_in_screen_boxes=[int(v) for v in boxed],
                         frac_bytes_processed=round(processed / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4))
+        # the surfel stage against ITS roofline: SURVEY 8(d)'s 384 B per surfel and model-frame over the stream time of the
+        # stage's chain of batched launches (index maps, association, compactions, update, clean, prediction), sampled like the ICP launch
+        surf = None
+        if prof.surfel_calls:
+            s_us = 1e3 * prof.surfel_ms_total / prof.surfel_calls
+            s_gbs = (prof.surfel_bytes / 1e9) / (prof.surfel_ms_total / 1e3)
+            surf = dict(bound="hbm", achieved=round(s_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(s_gbs / HBM_PEAK_GBS, 4),
+                        stage="cf_models_frame_passes: 2 index maps + association + update + clean + 2 compactions + prediction of all models, 12 batched launches",
+                        chains=int(prof.surfel_calls), avg_us=round(s_us, 1), bytes_per_chain=int(prof.surfel_bytes / prof.surfel_calls), surfels=int(sum(counts)),
+                        bytes_per_surfel="8 passes x 48 B for a fusing model (SURVEY 8d: 2 index + 2 splat reads, update R+W, clean R+W)",
+                        note="latency-bound: ~330 k surfels are 0.13 GB per frame -- 16 us at the HBM peak -- behind twelve dependent launches with scatter / "
+                             "gather passes (atomicMin z-keys, 4x4 window gathers); the image-space outputs (56 B per pixel and index map, 38 B per pixel "
+                             "of the prediction) are not in the byte count")
         out = dict(metric="frames/sec at 640x480 (N active models) + ICP-reduce achieved HBM GB/s vs peak", value=round(fps, 2),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 4),
                    higher_is_better=True, scaling="strong" if model_parallel else "weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -446,6 +461,8 @@ def main(argv=None):
                                background="split over the ranks (replicated map; surfel-range index map + row-band ICP with all-reduce)" if (model_parallel and args.shard_background) else "one rank",
                                frames=("broadcast from rank 0 every step, consumed in stream order" if model_parallel else "ring of device-resident frames, complete before each call (device_frames_complete=1)")),
                    roofline=roofline)
+        if surf is not None:
+            out["roofline_surfel"] = surf
         if parity is not None:
             out["parity_vs_n1"] = parity
         if replicas is not None:

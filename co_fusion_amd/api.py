@@ -43,7 +43,8 @@ class TrackStats(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("icp_ms_total", C.c_double), ("icp_launches", C.c_uint64), ("icp_bytes", C.c_uint64)]
+    _fields_ = [("icp_ms_total", C.c_double), ("icp_launches", C.c_uint64), ("icp_bytes", C.c_uint64),
+                ("surfel_ms_total", C.c_double), ("surfel_calls", C.c_uint64), ("surfel_bytes", C.c_uint64)]
 
 
 DATATERM = np.dtype([("zero_x", "<i2"), ("zero_y", "<i2"), ("one_x", "<i2"), ("one_y", "<i2"), ("diff", "<f4"),

@@ -82,6 +82,7 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
 void cf_destroy(cf_ctx* ctx)
 {
     if (ctx && ctx->batch_event) (void)hipEventDestroy(ctx->batch_event);
+    if (ctx) for (int i = 0; i < cf_ctx::kSurfEvents; i++) if (ctx->surf_events[i]) (void)hipEventDestroy(ctx->surf_events[i]);
     if (!ctx) return;
     (void)hipStreamSynchronize(ctx->stream);
     (void)cf_rccl_destroy(ctx);
@@ -326,7 +327,14 @@ int cf_profile_read(cf_ctx* ctx, cf_profile* out, int reset)
     ctx->prof_ms_accum = ms;
     ctx->prof.used = 0;
     out->icp_ms_total = ms; out->icp_launches = ctx->prof.launches; out->icp_bytes = ctx->prof.bytes;
-    if (reset) { ctx->prof_ms_accum = 0; ctx->prof.launches = 0; ctx->prof.bytes = 0; }
+    for (int i = 0; i + 1 < ctx->surf_used; i += 2) {
+        float t = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&t, ctx->surf_events[i], ctx->surf_events[i + 1]));
+        ctx->surf_ms_accum += t;
+    }
+    ctx->surf_used = 0;
+    out->surfel_ms_total = ctx->surf_ms_accum; out->surfel_calls = ctx->surf_calls; out->surfel_bytes = ctx->surf_bytes;
+    if (reset) { ctx->prof_ms_accum = 0; ctx->prof.launches = 0; ctx->prof.bytes = 0; ctx->surf_ms_accum = 0; ctx->surf_calls = 0; ctx->surf_bytes = 0; }
     return CF_OK;
 }
 

@@ -62,6 +62,12 @@ struct cf_model {
     float *fill_vertex = nullptr, *fill_normal = nullptr;
     uint8_t* fill_image = nullptr;
     float *tcx = nullptr, *tcy = nullptr;
+    // cf_models_preindex: the inverse of the tracked pose in device memory, the tracker it came from, and whether the index map of the
+    // current frame was already rasterised with it (cf_models_frame_passes then skips its first index pass -- if the pose it is given is
+    // the tracker's, bit for bit)
+    float* t_inv_dev = nullptr;
+    const cf_odom* preindex_od = nullptr;
+    int preindex_time = -1;
     float* rays = nullptr;  // per-pixel view rays of the splat fragment stage, float4 [H*W]
     float inv_fx = 0, inv_fy = 0;
 };
@@ -74,23 +80,7 @@ static int dmalloc(cf_ctx* ctx, T** p, size_t count)
     return CF_OK;
 }
 
-static void inv44f(const float a[16], float o[16])
-{  // pose.inverse(): linear part by cofactors (same statement as the oracle)
-    const float c00 = a[5] * a[10] - a[6] * a[9];
-    const float c01 = a[6] * a[8] - a[4] * a[10];
-    const float c02 = a[4] * a[9] - a[5] * a[8];
-    const float det = a[0] * c00 + a[1] * c01 + a[2] * c02;
-    const float id = 1.0f / det;
-    float Li[9];
-    Li[0] = c00 * id; Li[1] = (a[2] * a[9] - a[1] * a[10]) * id; Li[2] = (a[1] * a[6] - a[2] * a[5]) * id;
-    Li[3] = c01 * id; Li[4] = (a[0] * a[10] - a[2] * a[8]) * id; Li[5] = (a[2] * a[4] - a[0] * a[6]) * id;
-    Li[6] = c02 * id; Li[7] = (a[1] * a[8] - a[0] * a[9]) * id; Li[8] = (a[0] * a[5] - a[1] * a[4]) * id;
-    for (int i = 0; i < 3; i++) {
-        o[i * 4 + 0] = Li[i * 3 + 0]; o[i * 4 + 1] = Li[i * 3 + 1]; o[i * 4 + 2] = Li[i * 3 + 2];
-        o[i * 4 + 3] = -(Li[i * 3 + 0] * a[3] + Li[i * 3 + 1] * a[7] + Li[i * 3 + 2] * a[11]);
-    }
-    o[12] = 0; o[13] = 0; o[14] = 0; o[15] = 1;
-}
+using cf::inv44f;   // (cf_kernels.h: shared with the device)
 
 static inline cf_cam ctx_cam(const cf_ctx* ctx) { return cf_cam{ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy}; }
 
@@ -145,6 +135,7 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     if (int r = dmalloc(ctx, &m->tcx, (size_t)W)) return r;
     if (int r = dmalloc(ctx, &m->tcy, (size_t)H)) return r;
     if (int r = dmalloc(ctx, &m->rays, N * 4)) return r;
+    if (int r = dmalloc(ctx, &m->t_inv_dev, 16)) return r;
     launch_splat_rays(ctx->cur(), ctx_cam(ctx), W, H, m->rays);
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->h_counts), sizeof(unsigned) * 4, hipHostMallocCoherent));  // kernels store the counts here
     HIPCHK(ctx, hipEventCreateWithFlags(&m->count_event, hipEventDisableTiming));
@@ -167,7 +158,7 @@ void cf_model_destroy(cf_model* m)
     void* ptrs[] = {m->buf[0], m->buf[1], m->staged, m->flags, m->block_sums, m->d_count, m->d_nfresh, m->d_tmp2, m->records,
                     m->fresh, m->new_flags, m->owner, m->fb_rec, m->fb_raw, m->fb_filt, m->keys, m->index, m->vertConf,
                     m->colorTime, m->normRad, m->splat_image, m->splat_vertex, m->splat_normal, m->splat_time, m->fill_vertex,
-                    m->fill_normal, m->fill_image, m->tcx, m->tcy, m->rays};
+                    m->fill_normal, m->fill_image, m->tcx, m->tcy, m->rays, m->t_inv_dev};
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(m->h_counts);
     if (m->count_event) (void)hipEventDestroy(m->count_event);
@@ -424,6 +415,46 @@ int cf_model_clean(cf_model* m, const float pose[16], int time, float confThresh
     return CF_OK;
 }
 
+// The FIRST index pass of the frame's surfel chain, enqueued before the host has seen the tracked poses (see the header): the trackers'
+// device states give the poses.  cf_models_frame_passes skips its own first index pass for a model prepared here -- after checking that
+// the pose it is handed is the tracker's result bit for bit (an overridden pose simply rasterises again).
+int cf_models_preindex(cf_ctx* ctx, const cf_model_preindex* items, int n, float depth_cutoff, int time_delta)
+{
+    if (!ctx || !items || n <= 0) return CF_EINVAL;
+    hipStream_t s = ctx->cur();
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    std::vector<const cf::OdomDev*> states((size_t)n);
+    std::vector<float*> outs((size_t)n);
+    std::vector<IndexPassArgs> a((size_t)n);
+    for (int k = 0; k < n; k++) {
+        cf_model* m = items[k].model; const cf_odom* od = items[k].odom;
+        if (!m || !od || m->ctx != ctx || od->ctx != ctx) return CF_EINVAL;
+        uint32_t nb = 0;
+        if (int r = count_bound(m, &nb)) return r;
+        states[k] = od->d_state; outs[k] = m->t_inv_dev;
+        IndexPassArgs& p = a[k];
+        p.surfels = m->buf[m->target]; p.count = m->d_count; p.id_begin = 0; p.id_end = nb; p.maxDepth = depth_cutoff; p.time = items[k].time;
+        p.timeDelta = time_delta; p.keys = m->keys; p.index = m->index; p.vertConf = m->vertConf; p.colorTime = m->colorTime; p.normRad = m->normRad;
+        p.t_inv_dev = m->t_inv_dev;
+    }
+    launch_pose_tinv(s, states.data(), outs.data(), n);
+    launch_index_keys_batch(s, a.data(), n, ctx_cam(ctx), W, H);
+    launch_index_resolve_batch(s, a.data(), n, ctx_cam(ctx), W, H);
+    LAUNCHCHK(ctx);
+    for (int k = 0; k < n; k++) { items[k].model->preindex_od = items[k].odom; items[k].model->preindex_time = items[k].time; }
+    return CF_OK;
+}
+// is the index map of `m` already the one the first index pass of this chain would produce?
+static bool preindexed_with(const cf_model* m, const float pose[16], int time)
+{
+    if (!m->preindex_od || m->preindex_time != time) return false;
+    const cf::OdomDev* h = m->preindex_od->h_state;   // (fetched: the caller has the pose from there)
+    for (int r = 0; r < 3; r++) {
+        if (memcmp(&pose[r * 4], &h->Rcurr[r * 3], 12) != 0 || memcmp(&pose[r * 4 + 3], &h->tcurr[r], 4) != 0) return false;
+    }
+    return pose[12] == 0 && pose[13] == 0 && pose[14] == 0 && pose[15] == 1;
+}
+
 // The second half of a frame for several models in lock-step (see the header): the statements of cf_model_predict_indices / _fuse /
 // _clean / _combined_predict, every stage one batched launch.
 int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float depth_cutoff, float outlier_coeff, int time_delta)
@@ -437,6 +468,29 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
         const cf_model_pass& it = items[k];
         if (!it.model || it.model->ctx != ctx || !it.pose || !it.rgba || !it.depth_filtered) return CF_EINVAL;
         if (it.do_fuse) { if (!it.mask || !it.depth_raw) return CF_EINVAL; fusing.push_back(k); }
+    }
+    // everything that can fail is checked BEFORE the first launch: a return from the middle of the chain would leave every
+    // fusing model half-fused with its buffers flipped and no count posted.  The clean stage's staging bound only depends on the count
+    // the model enters the chain with (the update pass rewrites the surfels in place, new ones wait in `fresh`).
+    for (int k : fusing) {
+        cf_model* m = items[k].model;
+        uint32_t nb = 0;
+        if (int r = count_bound(m, &nb)) return r;
+        if (nb + (unsigned)((W / 2) * (H / 2)) > m->max_surfels + (unsigned)(W * H / 4 + 64)) {
+            ctx->set_error("cf_models_frame_passes: a model's surfel buffer cannot hold the clean stage's staging area (max_surfels too small)");
+            return CF_ENOMEM;
+        }
+    }
+    for (int k = 0; k < n; k++) { uint32_t nb = 0; if (int r = count_bound(items[k].model, &nb)) return r; }
+    // profiling (cf_profile_enable N): an event pair around every N-th chain + its algorithmic bytes
+    int surf_ev = -1;
+    if (ctx->prof.enabled > 0 && (ctx->surf_calls_seen++ % (unsigned)ctx->prof.enabled) == 0 && ctx->surf_used + 2 <= cf_ctx::kSurfEvents) {
+        for (int e = ctx->surf_used; e < ctx->surf_used + 2; e++)
+            if (!ctx->surf_events[e]) HIPCHK(ctx, hipEventCreate(&ctx->surf_events[e]));
+        surf_ev = ctx->surf_used; ctx->surf_used += 2;
+        HIPCHK(ctx, hipEventRecord(ctx->surf_events[surf_ev], s));
+        for (int k = 0; k < n; k++) ctx->surf_bytes += (uint64_t)items[k].model->count_host * 48u * (items[k].do_fuse ? 8u : 2u);
+        ctx->surf_calls++;
     }
     auto index_pass = [&](const std::vector<int>& which) -> int {
         std::vector<IndexPassArgs> a(which.size());
@@ -455,7 +509,11 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
     };
     if (!fusing.empty()) {
         const int nf = (int)fusing.size();
-        if (int r = index_pass(fusing)) return r;
+        {   // (models whose index map cf_models_preindex already rasterised with this very pose skip the pass)
+            std::vector<int> todo;
+            for (int k : fusing) if (!preindexed_with(items[k].model, items[k].pose, items[k].time)) todo.push_back(k);
+            if (!todo.empty()) { if (int r = index_pass(todo)) return r; }
+        }
         // Model::fuse (Model.cpp:408-563)
         std::vector<SurfelFuseArgs> fa(nf);
         std::vector<ScanPassArgs> sa(nf);
@@ -521,10 +579,12 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
     }
     launch_combined_predict_batch(s, pa.data(), n, cam, W, H);
     LAUNCHCHK(ctx);
+    if (surf_ev >= 0) HIPCHK(ctx, hipEventRecord(ctx->surf_events[surf_ev + 1], s));
     if (!fusing.empty()) {
         HIPCHK(ctx, hipEventRecord(ctx->batch_event, s));
         for (int k : fusing) items[k].model->count_wait = ctx->batch_event;
     }
+    for (int k = 0; k < n; k++) { items[k].model->preindex_od = nullptr; items[k].model->preindex_time = -1; }
     return CF_OK;
 }
 

@@ -58,6 +58,11 @@ struct cf_ctx {
     unsigned prof_calls = 0;           // tracking calls seen while profiling is on (events are attached to every prof.enabled-th call)
     cf::ProfSink prof{};
     double prof_ms_accum = 0;
+    // ... and event pairs around the sampled surfel chains (cf_models_frame_passes)
+    static constexpr int kSurfEvents = 64;
+    hipEvent_t surf_events[kSurfEvents]{};
+    int surf_used = 0; unsigned surf_calls_seen = 0;
+    double surf_ms_accum = 0; uint64_t surf_calls = 0, surf_bytes = 0;
     void set_error(const std::string& m);
 };
 extern "C" int cf_wait_stream(cf_ctx* ctx);   // the frame's host wait (cabi.hip)

@@ -340,7 +340,30 @@ constexpr int kSurfBatch = 16;   // models per launch (their arguments travel in
 struct IndexPassArgs {   // Model::predictIndices of one model: rasterise surfels [id_begin, id_end) into the z-keys, resolve
     const float* surfels; const unsigned* count; unsigned id_begin, id_end; float t_inv[16]; float maxDepth; int time, timeDelta;
     unsigned long long* keys; unsigned* index; float* vertConf; float* colorTime; float* normRad;
+    const float* t_inv_dev;   // nullable: the inverse pose in device memory (launch_pose_tinv) instead of t_inv -- an index pass enqueued
+                              // before the host has seen the tracked pose (cf_models_preindex)
 };
+// pose.inverse() of a rigid transform: linear part by cofactors (the statement of the oracle, orc_surfel.c); host and device
+__host__ __device__ inline void inv44f(const float a[16], float o[16])
+{
+    const float c00 = a[5] * a[10] - a[6] * a[9];
+    const float c01 = a[6] * a[8] - a[4] * a[10];
+    const float c02 = a[4] * a[9] - a[5] * a[8];
+    const float det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    const float id = 1.0f / det;
+    float Li[9];
+    Li[0] = c00 * id; Li[1] = (a[2] * a[9] - a[1] * a[10]) * id; Li[2] = (a[1] * a[6] - a[2] * a[5]) * id;
+    Li[3] = c01 * id; Li[4] = (a[0] * a[10] - a[2] * a[8]) * id; Li[5] = (a[2] * a[4] - a[0] * a[6]) * id;
+    Li[6] = c02 * id; Li[7] = (a[1] * a[8] - a[0] * a[9]) * id; Li[8] = (a[0] * a[5] - a[1] * a[4]) * id;
+    for (int i = 0; i < 3; i++) {
+        o[i * 4 + 0] = Li[i * 3 + 0]; o[i * 4 + 1] = Li[i * 3 + 1]; o[i * 4 + 2] = Li[i * 3 + 2];
+        o[i * 4 + 3] = -(Li[i * 3 + 0] * a[3] + Li[i * 3 + 1] * a[7] + Li[i * 3 + 2] * a[11]);
+    }
+    o[12] = 0; o[13] = 0; o[14] = 0; o[15] = 1;
+}
+// the tracked poses of n trackers (their device states, as the last solve left them), inverted into out[k][16]: what the index pass of a
+// model needs of its pose, without the host
+void launch_pose_tinv(hipStream_t s, const OdomDev* const* states, float* const* out, int n);
 struct SplatPassArgs {   // ModelProjection::combinedPredict of one model
     const float* surfels; const unsigned* count; unsigned count_bound; float t_inv[16]; float maxDepth, confThreshold; int time, maxTime, timeDelta;
     const float* rays; unsigned long long* keys; uint8_t* image; float* vertexConf; float* normalRad; uint16_t* time16;

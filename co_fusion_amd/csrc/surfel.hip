@@ -281,7 +281,37 @@ __device__ __forceinline__ bool index_project(const float4 pc, const float4 ct, 
 struct IndexArgs {   // predictIndices of one model (both kernels)
     const float4* surfels; const unsigned* count; Mat4 t_inv; float maxDepth; int time, timeDelta; unsigned id_begin, id_end;
     unsigned long long* keys; unsigned* index; float4* vertConf; float4* colorTime; float4* normRad;
+    const float* t_inv_dev;   // nullable: the matrix in device memory instead (IndexPassArgs::t_inv_dev)
 };
+__device__ __forceinline__ Mat4 index_matrix(const IndexArgs& a)
+{
+    if (!a.t_inv_dev) return a.t_inv;
+    Mat4 m;
+#pragma unroll
+    for (int k = 0; k < 16; k++) m.m[k] = a.t_inv_dev[k];   // (uniform address: one request per wave)
+    return m;
+}
+struct PoseTinvBatch { const OdomDev* st[kSurfBatch]; float* out[kSurfBatch]; };
+__global__ void __launch_bounds__(64) pose_tinv_kernel(const PoseTinvBatch B, int n)
+{
+    const int k = threadIdx.x;
+    if (k >= n) return;
+    const OdomDev* st = B.st[k];
+    float pose[16], inv[16];
+    for (int r = 0; r < 3; r++) { pose[r * 4 + 0] = st->Rcurr[r * 3 + 0]; pose[r * 4 + 1] = st->Rcurr[r * 3 + 1]; pose[r * 4 + 2] = st->Rcurr[r * 3 + 2]; pose[r * 4 + 3] = st->tcurr[r]; }
+    pose[12] = 0; pose[13] = 0; pose[14] = 0; pose[15] = 1;   // (the facade's Model::pose after a tracking call: CoFusion::fetchTracking)
+    inv44f(pose, inv);
+    for (int q = 0; q < 16; q++) B.out[k][q] = inv[q];
+}
+void launch_pose_tinv(hipStream_t s, const OdomDev* const* states, float* const* out, int n)
+{
+    for (int base = 0; base < n; base += kSurfBatch) {
+        const int nb = n - base < kSurfBatch ? n - base : kSurfBatch;
+        PoseTinvBatch B{};
+        for (int k = 0; k < nb; k++) { B.st[k] = states[base + k]; B.out[k] = out[base + k]; }
+        pose_tinv_kernel<<<1, 64, 0, s>>>(B, nb);
+    }
+}
 struct FrameGeom { cf_cam cam; int cols, rows; };   // what the models of a launch share
 
 __global__ void __launch_bounds__(kB) index_splat_kernel(const Batch<IndexArgs> B, const FrameGeom g)
@@ -293,7 +323,8 @@ __global__ void __launch_bounds__(kB) index_splat_kernel(const Batch<IndexArgs> 
     const unsigned id = a.id_begin + vb.bid * kB + threadIdx.x;
     if (id >= *a.count || id >= a.id_end) return;
     f3 ph; int q;
-    if (!index_project(surfels[id * 3], surfels[id * 3 + 1], a.t_inv, g.cam, g.cols, g.rows, a.maxDepth, a.time, a.timeDelta, ph, q)) return;
+    const Mat4 T = index_matrix(a);
+    if (!index_project(surfels[id * 3], surfels[id * 3 + 1], T, g.cam, g.cols, g.rows, a.maxDepth, a.time, a.timeDelta, ph, q)) return;
     atomicMin(&a.keys[q], zkey(ph.z, id));
 }
 
@@ -314,8 +345,9 @@ __global__ void __launch_bounds__(kB) index_resolve_kernel(const Batch<IndexArgs
     }
     const unsigned id = (unsigned)k;
     const float4 pc = surfels[id * 3], ct = surfels[id * 3 + 1], nr = surfels[id * 3 + 2];
-    const f3 ph = xform_point(a.t_inv, f3{pc.x, pc.y, pc.z});
-    const f3 n = normalized(xform_dir(a.t_inv, f3{nr.x, nr.y, nr.z}));
+    const Mat4 T = index_matrix(a);
+    const f3 ph = xform_point(T, f3{pc.x, pc.y, pc.z});
+    const f3 n = normalized(xform_dir(T, f3{nr.x, nr.y, nr.z}));
     index[q] = id;
     vertConf[q] = make_float4(ph.x, ph.y, ph.z, pc.w);
     colorTime[q] = ct;
@@ -879,7 +911,8 @@ static_assert(sizeof(Batch<FuseArgs>) + 16 <= 4096 && sizeof(Batch<CleanArgs>) +
 static IndexArgs index_args(const IndexPassArgs& h)
 {
     return IndexArgs{reinterpret_cast<const float4*>(h.surfels), h.count, mat4_from(h.t_inv), h.maxDepth, h.time, h.timeDelta, h.id_begin, h.id_end,
-                     h.keys, h.index, reinterpret_cast<float4*>(h.vertConf), reinterpret_cast<float4*>(h.colorTime), reinterpret_cast<float4*>(h.normRad)};
+                     h.keys, h.index, reinterpret_cast<float4*>(h.vertConf), reinterpret_cast<float4*>(h.colorTime), reinterpret_cast<float4*>(h.normRad),
+                     h.t_inv_dev};
 }
 void launch_index_keys_batch(hipStream_t s, const IndexPassArgs* items, int n_items, cf_cam cam, int cols, int rows)
 {

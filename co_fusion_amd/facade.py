@@ -20,7 +20,7 @@ class Config(C.Structure):
                 ("pyramid", C.c_int), ("rgb_only", C.c_int), ("model_spawn_offset", C.c_uint), ("enable_multiple_models", C.c_int),
                 ("enable_pose_logging", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("device_frames_complete", C.c_int),
                 ("mid_frame_predict", C.c_int), ("shard_background", C.c_int), ("enqueue_threads", C.c_int),
-                ("colocate_background", C.c_int), ("reloc", C.c_int)]
+                ("colocate_background", C.c_int), ("reloc", C.c_int), ("early_index_maps", C.c_int)]
 
 
 class CoFusionError(RuntimeError):

@@ -829,7 +829,9 @@ CoFusion::CoFusion(const Config& c, cf_ctx* shared, int sequenceIndex)
     globalModel->loggingPoses = cfg.enablePoseLogging;
     models.push_back(globalModel);
     int helpers = cfg.enqueueThreads;
-    if (helpers > 0 && useLanes) pool = std::make_shared<EnqueuePool>(helpers > 7 ? 7 : helpers);
+    // (the helper threads only ever enqueue the per-model chains of the model-parallel modes: single-process operation runs all models'
+    // passes as one chain of batched launches -- passesBatched -- and would never use them)
+    if (helpers > 0 && useLanes && dist.active()) pool = std::make_shared<EnqueuePool>(helpers > 7 ? 7 : helpers);
 }
 
 CoFusion::~CoFusion()
@@ -1328,10 +1330,23 @@ bool CoFusion::processFrame(const FrameData& frame, const Mat4f* inPose, float w
     frameBegin(frame, inPose, weightMultiplier, bootstrap);
     if (st.willTrack) { PhaseTimer t(PhaseTimes::Track); trackModels(st.pyr); }
     frameSegment(nullptr);
+    framePreIndex();
     frameCollect();
     frameFuse(true, 0);
     frameEnd();
     return false;
+}
+
+// The first index maps of the surfel chain (Model::predictIndices before Model::fuse, CoFusion.cpp:316-318) enqueued BEHIND the
+// segmentation and BEFORE the frame's host wait, with the poses the trackers left on the device: the GPU rasterises them while the host
+// collects poses and decisions and prepares the rest of the chain (cf_models_preindex).  Single-process operation only (the chain of
+// batched launches); a model that is not fused afterwards has had its index map overwritten early -- nothing reads it in between.
+void CoFusion::framePreIndex()
+{
+    if (!cfg.earlyIndexMaps || !passesBatched() || trackPending.empty() || cfg.rgbOnly || lost) return;
+    std::vector<cf_model_preindex> items;
+    for (Model* m : trackPending) items.push_back(cf_model_preindex{m->model, m->odom, (int)tick});
+    check(ctx, cf_models_preindex(ctx, items.data(), (int)items.size(), maxDepthProcessed, cfg.timeDelta), "cf_models_preindex");
 }
 
 // ------------------------------------------------------------------------ CoFusionGroup ----

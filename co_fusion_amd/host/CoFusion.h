@@ -259,6 +259,8 @@ class CoFusion {
         // a frame whose background ICP error / pose covariance is out of bounds is not fused, and after ten such frames the camera is
         // `lost`: no fusion, the clock stops (CoFusion.cpp:225, 301-338, 463, 495).  The fern-based recovery is out of scope.
         bool reloc = false;
+        // the index maps of the tracked models rasterised before the frame's host wait, with the poses on the device (framePreIndex)
+        bool earlyIndexMaps = true;
         // host threads that enqueue the per-model surfel passes (fusion, clean-up, prediction) beside the calling thread, one model's
         // chain of launches each.  Pays when the host's launch rate is the limit (a profiler attached, a slow or busy host); on an idle
         // host the calling thread alone keeps the lanes fed (610 / 606 / 604 fps with 0 / 2 / 4 helpers), hence default
@@ -313,6 +315,7 @@ class CoFusion {
     static void trackLaunch(cf_ctx* ctx, TrackBatch& batch, const Config& cfg);
     // segmentation enqueued (jobs != nullptr: described as a job for the group's shared launches instead -- Segmentation::runBatch)
     void frameSegment(std::vector<cf_seg_job>* jobs);
+    void framePreIndex();
     void frameCollect();           // the frame's host wait (poses + segmentation decisions), model bookkeeping
     void frameFuse(bool join, int laneOffset);
     // ... in two halves for a lock-step group: every sequence adds its models' passes to ONE batch (cf_models_frame_passes), the group

@@ -41,6 +41,7 @@ void cofusion_default_config(cofusion_config* c)
     c->enqueue_threads = d.enqueueThreads;
     c->colocate_background = d.colocateBackground;
     c->reloc = d.reloc;
+    c->early_index_maps = d.earlyIndexMaps;
 }
 
 static CoFusion::Config to_config(const cofusion_config* c)
@@ -60,6 +61,7 @@ static CoFusion::Config to_config(const cofusion_config* c)
     d.enqueueThreads = c->enqueue_threads < 0 ? 0 : c->enqueue_threads;
     d.colocateBackground = c->colocate_background != 0;
     d.reloc = c->reloc != 0;
+    d.earlyIndexMaps = c->early_index_maps != 0;
     return d;
 }
 

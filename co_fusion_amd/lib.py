@@ -26,7 +26,7 @@ SYMBOLS = [
     "cf_odom_track_batch_async", "cf_odom_fetch_result", "cf_odom_get_covariance", "cf_odom_bind_frame_maps", "cf_odom_share_frame_maps", "cf_odom_set_culling", "cf_odom_set_band", "cf_set_collective", "cf_model_predict_indices_sharded", "cf_odom_buffer",
     "cf_bilateral", "cf_model_create", "cf_model_destroy", "cf_model_initialise", "cf_model_count",
     "cf_model_predict_indices", "cf_model_index_keys", "cf_model_index_resolve", "cf_model_combined_predict", "cf_model_prefetch_fill_ratio", "cf_model_perform_fill_in", "cf_model_requires_fill_in",
-    "cf_model_fuse", "cf_model_clean", "cf_models_frame_passes", "cf_model_download_map", "cf_model_upload_map", "cf_model_buffer",
+    "cf_model_fuse", "cf_model_clean", "cf_models_frame_passes", "cf_models_preindex", "cf_model_download_map", "cf_model_upload_map", "cf_model_buffer",
     "cf_fusion_weight", "cf_seg_create", "cf_seg_destroy", "cf_seg_slic", "cf_seg_accumulate", "cf_seg_crf", "cf_seg_upsample", "cf_seg_sums", "cf_seg_infer", "cf_seg_run_batch", "cf_seg_fetch", "cf_seg_publish_poses", "cf_seg_fetch_poses",
     "cf_seg_labels",
     "cf_depth_pyramid", "cf_set_icp_launch", "cf_set_icp_arith", "cf_get_icp_arith", "cf_set_gn_mode", "cf_profile_enable", "cf_profile_read", "cf_odom_bench_icp",

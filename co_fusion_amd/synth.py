@@ -55,7 +55,9 @@ def _texture(p, seed, base):
 class Scene:
     """Static room + clutter + moving objects."""
 
-    def __init__(self, n_obj: int = 0, seed: int = 1234):
+    def __init__(self, n_obj: int = 0, seed: int = 1234, kinds: str | None = None):
+        """kinds: None = spheres and boxes alternate (the scenes of rounds 1-4); "box" = textured boxes only (no rotationally symmetric
+        shape: every object's pose is observable, tests/golden/make_ref_traj_golden.py: crf_two_boxes_640)"""
         rng = np.random.default_rng(seed)
         self.seed = seed
         # room interior, world frame = first camera frame (camera looks along +z, y down)
@@ -72,7 +74,7 @@ class Scene:
             self.clutter.append((lo, hi, rng.uniform(0.5, 1.0, size=3), 100 + i))
         self.objects = []
         for i in range(n_obj):
-            kind = "sphere" if i % 2 == 0 else "box"
+            kind = kinds if kinds else ("sphere" if i % 2 == 0 else "box")
             size = rng.uniform(0.12, 0.2) if kind == "sphere" else rng.uniform(0.2, 0.35, size=3)
             c0 = np.array([rng.uniform(-0.7, 0.7), rng.uniform(-0.3, 0.4), rng.uniform(0.9, 1.5)])
             amp = rng.uniform(0.10, 0.25, size=3) * np.array([1.0, 0.4, 0.5])

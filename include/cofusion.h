@@ -35,14 +35,19 @@ typedef struct {
                                  * share of its index-map rasterisation (surfel range, MIN all-reduce of the z-keys) and of its ICP
                                  * reduction (image rows, SUM all-reduce of the accumulators after every launch of the Gauss-Newton
                                  * loop); needs cf_set_collective on the context (cofusion_context).  Default 0. */
-    int enqueue_threads;        /* helper threads that enqueue the per-model surfel passes (one model's launch chain each) beside the calling
-                                 * thread; 0 = none (default).  Results do not depend on it. */
+    int enqueue_threads;        /* model-parallel operation (world > 1) only: helper threads that enqueue the per-model surfel passes (one
+                                 * model's launch chain each) beside the calling thread; 0 = none (default).  A single process runs the
+                                 * passes of all models as one chain of batched launches and ignores it.  Results do not depend on it. */
     int colocate_background;    /* model-parallel operation: 1 = object models round-robin over ALL ranks, the background shares rank 0
                                  * (BASELINE.json configs[3]: one object model per GPU); 0 (default) = the background alone on rank 0 */
     int reloc;                  /* CoFusion's `reloc` constructor argument (CoFusion.h:47): failure detection of the frame loop -- frames
                                  * with a background ICP error >= 1e-4 or a pose-covariance diagonal entry > 1e-4 are not fused, after
                                  * more than ten in a row the camera is lost (no fusion, the clock stops; CoFusion.cpp:225,301-338).
                                  * cofusion_is_lost reports it.  Default 0. */
+    int early_index_maps;       /* 1 (default): the index maps of the tracked models are rasterised with the poses the trackers left ON THE
+                                 * DEVICE, behind the segmentation and before the frame's host wait (cf_models_preindex), so the GPU works
+                                 * while the host reads poses and decisions; 0: with the rest of the surfel chain, after the wait.  Results are
+                                 * identical either way. */
 } cofusion_config;
 
 void cofusion_default_config(cofusion_config *cfg);

@@ -353,6 +353,18 @@ typedef struct {
     float conf_threshold;
 } cf_model_pass;
 int cf_models_frame_passes(cf_ctx *ctx, const cf_model_pass *items, int n, float depth_cutoff, float outlier_coeff, int time_delta);
+/* The first index pass of that chain (Model::predictIndices before Model::fuse, CoFusion.cpp:316-318) for models that were tracked this
+ * frame, enqueued BEFORE the host waits for the tracking results: the pose comes from the tracker's device state (inverted by a small
+ * kernel), so the GPU rasterises the index maps while the host wakes up, reads poses and segmentation decisions and prepares the rest
+ * of the chain (a 45-60 us hole in the queue per frame until round 5).  cf_models_frame_passes skips its first index pass for such a
+ * model when the pose it is given equals the tracker's result bit for bit, and rasterises again otherwise (overridden pose).  A model
+ * that is not fused afterwards (tracking lost, deactivated) just had its index map overwritten early: nothing reads it in between. */
+typedef struct {
+    cf_model *model;
+    const cf_odom *odom;   /* the tracker whose result is the model's pose for this frame */
+    int time;              /* the sequence's tick, as cf_model_pass::time */
+} cf_model_preindex;
+int cf_models_preindex(cf_ctx *ctx, const cf_model_preindex *items, int n, float depth_cutoff, int time_delta);
 /* Model::downloadMap (Model.cpp:867-899): `count` surfels of 12 floats */
 int cf_model_download_map(cf_model *m, float *host_surfels, uint32_t capacity, uint32_t *count);
 int cf_model_upload_map(cf_model *m, const float *host_surfels, uint32_t count);
@@ -470,6 +482,10 @@ typedef struct {
     uint64_t icp_bytes;    /* algorithmic bytes of those launches: per level-0 pixel (24 + 24*M) for the ICP reduction of the M
                             * lock-step models + 11*M for the residual passes that share the launch (27*M with
                             * cf_set_gn_mode 0, which writes the 16 B DataTerm records) */
+    double surfel_ms_total;   /* stream time of the sampled cf_models_frame_passes chains (index maps, fuse, clean, compactions, prediction) */
+    uint64_t surfel_calls;
+    uint64_t surfel_bytes;    /* algorithmic bytes of those chains: 8 passes x 48 B per surfel of every fusing model (2 index + 2
+                               * splat reads, update read + write, clean read + write), 2 x 48 B per surfel of a model that is only predicted */
 } cf_profile;
 /* on = 0: off; on = N >= 1: attach begin/end events to the level-0 launches of every N-th tracking call (sampling keeps the host cost
  * of the event pairs out of the measured frame rate) */

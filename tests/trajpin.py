@@ -169,7 +169,7 @@ def stream(name, F):
     have = _STREAMS.setdefault(name, [])
     if len(have) < F:
         cam = synth.Camera.scaled(*g.size(name))
-        sc = synth.Scene(n_obj=g.SCENARIOS[name][0])
+        sc = g.scene(name)
         for t in range(len(have), F):
             d, rgb, lab, _ = sc.render(cam, t, noise=True)
             have.append((d, rgb, lab))
