@@ -424,6 +424,11 @@ def main(argv=None):
                         frac_icp_bytes_only=round(icp_only / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4),
                         bytes_processed_per_launch=int(processed), pixels_in_screen_boxes=[int(v) for v in boxed],
                         frac_bytes_processed=round(processed / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4))
+        if pmc_traffic.rocprof_us:   # the same launches in the committed rocprofv3 --kernel-trace run of this build (shorter: see the file)
+            roofline.update(rocprofv3_avg_us=pmc_traffic.rocprof_us, frac_rocprofv3=round(bpl / pmc_traffic.rocprof_us / 1e3 / HBM_PEAK_GBS, 4),
+                            rocprofv3_source="profiles/r5*_icp_level0_timed_launches.txt: kernel durations of the timed steps' level-0 launches under rocprofv3 "
+                                             "--kernel-trace; `avg_us` above is this process's own begin / end events on the plain stream, where a launch's "
+                                             "begin stamp also covers the end-of-kernel cache maintenance of the launch in front of it")
         # the surfel stage against ITS roofline: SURVEY 8(d)'s 384 B per surfel and model-frame over the stream time of the
         # stage's chain of batched launches (index maps, association, compactions, update, clean, prediction), sampled like the ICP launch
         surf = None
@@ -776,7 +781,16 @@ def reference_trajectory_check(args, multi):
         name = "crf_two_objects_640" if multi else "static_camera_640"
         poses, ids, counts = trajpin.play_facade(name, args.icp_arith)
         rep = trajpin.compare(name, poses, ids, counts, arith=args.icp_arith, log=lambda s: None)
-        return dict(rmse=round(rep["rmse"], 9), max=round(rep["max"], 9), frames=rep["frames"], scenario=name,
+        tight = None
+        if multi and "gt_masks_two_boxes_640" in trajpin.scenarios():
+            # ... and the scenario in which EVERY object is held to the tight bounds (two textured boxes, ground-truth masks: round 5)
+            p2, i2, c2 = trajpin.play_facade("gt_masks_two_boxes_640", args.icp_arith)
+            r2 = trajpin.compare("gt_masks_two_boxes_640", p2, i2, c2, arith=args.icp_arith, log=lambda s: None)
+            tight = dict(scenario="gt_masks_two_boxes_640", frames=r2["frames"], camera_rmse=round(r2["rmse"], 9), camera_max=round(r2["max"], 9),
+                         lists_identical_frames=r2["lists_identical_frames"],
+                         objects={k: dict(frames=v["frames"], max_m=round(v["max_m"], 7), bound_m=v["bound_m"], stable_in_reference=v["stable_in_reference"],
+                                          count_max_rel_diff=round(v["count_max_rel_diff"], 5)) for k, v in r2["objects"].items()})
+        return dict(rmse=round(rep["rmse"], 9), max=round(rep["max"], 9), frames=rep["frames"], scenario=name, well_conditioned_objects=tight,
                     lists_identical_frames=rep["lists_identical_frames"], count_first_diff_frame=rep["count_first_diff_frame"],
                     count_max_abs_diff=rep["count_max_abs_diff"], count_max_rel_diff=round(rep["count_max_rel_diff"], 7),
                     background_count_max_abs_diff=rep["background_count_max_abs_diff"],
@@ -852,11 +866,15 @@ def pmc_traffic(workload, pixels):
                 if e.get("kernel_source_sha256") != sha:
                     return None, (f"profiles/{name} was taken on another build of csrc/track_reduce.hip (sha256 {str(e.get('kernel_source_sha256'))[:12]} != "
                                   f"{sha[:12]}): not quoted; re-run tools/gpu_pmc.sh + tools/make_traffic_json.py")
+                pmc_traffic.rocprof_us = e.get("rocprofv3_avg_us")
                 return int(e["traffic_bytes_per_launch"]), (f"HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this workload on this build (profiles/{name}: "
                                                             "FETCH_SIZE x2 + WRITE_SIZE x1, factors measured by tools/microbench/fetch_calib.hip); counters cannot "
                                                             "be read from inside the benchmark process")
         break   # only the newest pass counts
     return None, "no committed counter pass for this workload"
+
+
+pmc_traffic.rocprof_us = None
 
 
 def native_oracle():

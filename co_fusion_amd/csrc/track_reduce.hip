@@ -1119,7 +1119,12 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(const TrackerStates t
         static_assert(sizeof(OdomDev) % 4 == 0, "OdomDev is staged as 32-bit words");
         constexpr int kWords = (int)(sizeof(OdomDev) / 4);
         const unsigned* __restrict__ src = reinterpret_cast<const unsigned*>(ts.host[by]);
-        for (int k = threadIdx.x; k < kWords; k += 256) reinterpret_cast<unsigned*>(&s_od)[k] = src[k];
+        constexpr int kPer = (kWords + 255) / 256;   // (both loads of a thread in flight together: they cross PCIe)
+        unsigned w[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; q++) w[q] = ((int)threadIdx.x + 256 * q < kWords) ? src[threadIdx.x + 256 * q] : 0u;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) if ((int)threadIdx.x + 256 * q < kWords) reinterpret_cast<unsigned*>(&s_od)[threadIdx.x + 256 * q] = w[q];
         __syncthreads();
         if (lead) for (int k = threadIdx.x; k < kWords; k += 256) reinterpret_cast<unsigned*>(god)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
         __syncthreads();  // (the lead's later stores into the device state follow the upload)
@@ -1301,7 +1306,12 @@ __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigne
     constexpr int kMutableFrom = (int)(offsetof(OdomDev, Rprev) / 4);
     const int tid = threadIdx.x;
     OdomDev* const od = &s_od;
-    for (int k = tid; k < kWords; k += 256) reinterpret_cast<unsigned*>(&s_od)[k] = reinterpret_cast<const unsigned*>(god)[k];
+    // the state's words and the accumulator words in ONE flight of loads (a rolled copy loop waits for every load before it stores to
+    // LDS: two dependent round trips in front of the accumulator loads, ~1.5 us of every solve until round 5)
+    constexpr int kPer = (kWords + 255) / 256;
+    unsigned stw[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; q++) stw[q] = (tid + 256 * q < kWords) ? reinterpret_cast<const unsigned*>(god)[tid + 256 * q] : 0u;
     {   // 256 threads: word = t & 31, slice = t >> 5 (8 slices of 8 groups)
         const int w = tid & 31, sl = tid >> 5;
         unsigned long long a = 0, b = 0;
@@ -1326,6 +1336,8 @@ __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigne
         }
         s_part[0][sl][w] = a; s_part[1][sl][w] = b;
     }
+#pragma unroll
+    for (int q = 0; q < kPer; q++) if (tid + 256 * q < kWords) reinterpret_cast<unsigned*>(&s_od)[tid + 256 * q] = stw[q];
     if (tid >= 64 && tid < 64 + 72) (&s_Af[0][0])[tid - 64] = 0.f;
     if (tid >= 192 && tid < 192 + 12) (&s_bf[0][0])[tid - 192] = 0.f;
     __syncthreads();

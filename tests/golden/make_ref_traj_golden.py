@@ -40,16 +40,21 @@ SCENARIOS = {
 SCENARIOS["static_camera_640"] = (0, 100, 10.0, 20, False)  # the static scenario at BASELINE.json's own frame size: 100 frames, 0.40 m of camera path
 SCENARIOS["crf_two_objects_640"] = (2, 60, 0.5, 3, True)    # ... and the motion-CRF scenario: at this size the objects cover ~15 000 pixels each
 SCENARIOS["gt_masks_two_objects_640"] = (2, 60, 0.5, 3, True, True)   # ... and ground-truth masks: three models in lock-step from frame 6 to 53
-# round 5: the motion-CRF scenario with WELL-CONDITIONED objects -- two textured boxes, no sphere -- so that every object
-# the run keeps is held to the tight bounds of tests/trajpin.py (OBJECT_BOUND_M, COUNT_REL_OBJECT), not to the jitter-scaled fallback
-SCENARIOS["crf_two_boxes_640"] = (2, 70, 0.5, 3, True)
-SIZES = {"static_camera_640": (640, 480), "crf_two_objects_640": (640, 480), "gt_masks_two_objects_640": (640, 480), "crf_two_boxes_640": (640, 480)}
-SCENE_KW = {"crf_two_boxes_640": dict(kinds="box", seed=4321)}
+# round 5: WELL-CONDITIONED objects -- two textured boxes, no sphere -- so that every object the run keeps is held to
+# the tight bounds of tests/trajpin.py (OBJECT_BOUND_M, COUNT_REL_OBJECT), not to the jitter-scaled fallback.  With ground-truth masks: a
+# motion-CRF run of the same scene (crf_two_boxes_640, generated once: DESIGN-NOTES R5.7) spawns its second object at frame 15 under
+# one arithmetic and after frame 21 under the other -- a freshly spawned model of ~900 surfels is ill-conditioned whatever its shape --
+# and from there the two runs are different experiments (the camera ends 4 mm apart).  It is NOT in the asserted fixture.
+SCENARIOS["gt_masks_two_boxes_640"] = (2, 60, 0.5, 3, True, True)
+SIZES = {"static_camera_640": (640, 480), "crf_two_objects_640": (640, 480), "gt_masks_two_objects_640": (640, 480), "gt_masks_two_boxes_640": (640, 480),
+         "crf_two_boxes_640": (640, 480)}
+SCENE_KW = {"gt_masks_two_boxes_640": dict(kinds="box", seed=4321), "crf_two_boxes_640": dict(kinds="box", seed=4321)}
+SCENARIOS_NOT_ASSERTED = {"crf_two_boxes_640": (2, 70, 0.5, 3, True)}   # (play() accepts it: `python make_ref_traj_golden.py crf_two_boxes_640`)
 
 
 def scene(name):
     from co_fusion_amd import synth
-    return synth.Scene(n_obj=SCENARIOS[name][0], **SCENE_KW.get(name, {}))
+    return synth.Scene(n_obj=(SCENARIOS.get(name) or SCENARIOS_NOT_ASSERTED[name])[0], **SCENE_KW.get(name, {}))
 
 
 def size(name):
@@ -57,7 +62,8 @@ def size(name):
 
 
 def uses_gt_masks(name):
-    return len(SCENARIOS[name]) > 5 and bool(SCENARIOS[name][5])
+    e = SCENARIOS.get(name) or SCENARIOS_NOT_ASSERTED[name]
+    return len(e) > 5 and bool(e[5])
 
 
 # Frames over which the model lists of a run with the exact-integer tracker must equal those of the reference-arithmetic run where the
@@ -80,7 +86,7 @@ def play(name, reference_tracker, n_frames=None, log=None):
     """poses [F, MAXM, 4, 4], ids [F, MAXM] (-1: no model), counts [F, MAXM] of the pinned frame loop"""
     import refcofusion
     from co_fusion_amd import synth
-    n_obj, frames, conf_global, spawn, multi = SCENARIOS[name][:5]
+    n_obj, frames, conf_global, spawn, multi = (SCENARIOS.get(name) or SCENARIOS_NOT_ASSERTED[name])[:5]
     gt = uses_gt_masks(name)
     F = n_frames or frames
     cam = synth.Camera.scaled(*size(name))

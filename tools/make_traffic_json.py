@@ -23,6 +23,9 @@ def averages(path, tag):
 
 def main():
     src, out = sys.argv[1], sys.argv[2]
+    # optional: rocprofv3 --kernel-trace durations of the same launches on the same build ("objects4=12.48,static=9.64": average us of the
+    # level-0 launches of the timed steps, profiles/rNN_icp_level0_timed_launches.txt) -- bench.py quotes them beside its own events
+    rocprof = dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in sys.argv[3].split(",")) if len(sys.argv) > 3 else {}
     sha = hashlib.sha256(open(os.path.join(ROOT, "co_fusion_amd", "csrc", "track_reduce.hip"), "rb").read()).hexdigest()
     entries = []
     for tag, workload, what in (("icp_reduce_kernel<1, 4, false>", "objects4", "ICP reduction of the lock-step models || their RGB residual passes, level 0, box-indexed grids"),
@@ -35,6 +38,7 @@ def main():
                             dispatches=min(nf, nw), kernel_source_sha256=sha,
                             correction="traffic = 2*FETCH_SIZE*1024 + 1*WRITE_SIZE*1024 (factors measured by tools/microbench/fetch_calib.hip in the same call: pmc_calibration_*.txt)",
                             traffic_bytes_per_launch=int(2 * f * 1024 + w * 1024),
+                            **({"rocprofv3_avg_us": rocprof[workload]} if workload in rocprof else {}),
                             source=f"{os.path.basename(src.rstrip('/'))}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5` (tools/gpu_pmc.sh)"))
     json.dump(entries, open(out, "w"), indent=1)
     print(json.dumps(entries, indent=1))
