@@ -94,7 +94,7 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip host-input rate / ATE / secondary legs")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work per CPU-baseline leg")
     ap.add_argument("--icp-threads", type=int, default=256)
-    ap.add_argument("--icp-ppt", type=int, default=0, help="pixels per lane of the ICP reduction (0: library default)")
+    ap.add_argument("--icp-ppt", type=int, default=0, help="pixels per lane of the ICP reduction of unculled trackers (0: library default = 2 at pyramid level 0, 1 below)")
     ap.add_argument("--icp-arith", default=None, choices=["product", "gram"],
                     help="rounding specification of the ICP sums (cf_set_icp_arith; default: the library's): products rounded once / row entries "
                          "rounded once and contracted on the matrix cores; the oracle legs follow")

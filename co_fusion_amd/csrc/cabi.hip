@@ -52,7 +52,7 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     HIPCHK(ctx, hipSetDevice(cfg->device));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    ctx->icp_launch = IcpLaunch{256, 1, 0};
+    ctx->icp_launch = IcpLaunch{256, 0, 0};   // (0 pixels per lane: launch_icp_rgbres chooses by level)
     if (int r = dmalloc(ctx, &ctx->d_acc_a, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &ctx->d_acc_b, (size_t)kGroups * 32)) return r;
     if (int r = dmalloc(ctx, &ctx->d_out, 64)) return r;
@@ -299,7 +299,7 @@ int cf_rgb_to_rgba(cf_ctx* ctx, const uint8_t* rgb_dev, int cols, int rows, uint
 int cf_set_icp_launch(cf_ctx* ctx, int threads, int ppt)
 {
     if (!ctx || (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024) ||
-        (ppt != 1 && ppt != 2 && ppt != 4))
+        (ppt != 0 && ppt != 1 && ppt != 2 && ppt != 4))
         return CF_EINVAL;
     ctx->icp_launch = IcpLaunch{threads, ppt, ctx->icp_launch.gram};
     return CF_OK;

@@ -204,6 +204,22 @@ __device__ __forceinline__ unsigned long long wave_reduce16_u64(const unsigned l
     return ((unsigned long long)b << 32) | a;
 }
 
+// 8-value flavour (the ICP commit, one word group per wave): lane l ends with the total of value index ((l >> 3) & 7)
+__device__ __forceinline__ unsigned long long wave_reduce8_u64(const unsigned long long (&acc)[8], int lane)
+{
+    unsigned lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { lo[i] = (unsigned)acc[i]; hi[i] = (unsigned)(acc[i] >> 32); }
+    swap32_step<4>(lo, hi);
+    swap16_step<2>(lo, hi);
+    dpp_step<1, kDppRor8>(lo, hi, (lane & 8) != 0);
+    unsigned a = lo[0], b = hi[0];
+    add64(a, b, dpp_u32<kDppHalfMirror>(a), dpp_u32<kDppHalfMirror>(b));   // (lane i <-> 7 - i, then i ^ 2, then i ^ 1: all eight lanes of a group)
+    add64(a, b, dpp_u32<kDppXor2>(a), dpp_u32<kDppXor2>(b));
+    add64(a, b, dpp_u32<kDppXor1>(a), dpp_u32<kDppXor1>(b));
+    return ((unsigned long long)b << 32) | a;
+}
+
 // ---- Gram form of the ICP sums (cf_set_icp_arith 1; oracle: ORC_ICP_ARITH_GRAM) -------------------------------------------
 // Every row ENTRY is rounded once to a fixed-point grid: q_i = RNE(clamp(row_i, +-kGramLim[i]) * 2^kGramBits[i]), |q_i| <= 2^22;
 // entry 7 is 1 for a found correspondence.  The 29 words are entries of the Gram matrix sum_pixels q q^T of that integer matrix,

@@ -19,7 +19,7 @@ struct cf_ctx {
     hipStream_t own_stream = nullptr;
     std::string last_error;
     std::mutex error_mutex;            // helper threads bound with cf_thread_lane may fail at the same time
-    cf::IcpLaunch icp_launch{256, 1};
+    cf::IcpLaunch icp_launch{256, 0};
     // scratch for the stand-alone reduction steps
     unsigned long long* d_acc_a = nullptr;
     unsigned long long* d_acc_b = nullptr;

@@ -70,6 +70,60 @@ __device__ __forceinline__ void se3_accumulate_dyn(const float (&row)[7], unsign
 }
 
 // ------------------------------------------------------------------------------------------------
+// Product form of the ICP sums, round 5: the lanes add their products into the WORKGROUP's accumulators in LDS -- word k of lane l at
+// [k][l], 64-bit LDS atomics without return, no bank conflicts -- and the butterfly runs ONCE per workgroup over what all waves (and
+// all runs of a wave) left there, split over four waves (seven or eight words each).  Until then every wave ran the 32 x u64 butterfly
+// on its own registers: 190 of the ~510 VALU instructions of a wave that the launch is bound by, and the 64 accumulator registers
+// that set its occupancy.  Only lanes with a correspondence add; each adds the magic number's bits once per word, so the count of
+// correspondences (word 28: a counter of its own, one LDS add per wave) times those bits comes off behind the butterfly.  Integer
+// sums: who adds what in which order does not change a bit.
+constexpr int kIcpLdsWords = 28;
+__shared__ unsigned long long s_icp_acc[kIcpLdsWords][64];
+__shared__ unsigned s_icp_found;
+__device__ __forceinline__ void lds_add_u64(unsigned long long* p, unsigned long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void icp_lds_zero()   // (workgroup-uniform; the barrier behind it is the caller's)
+{
+    for (int i = threadIdx.x; i < kIcpLdsWords * 64; i += blockDim.x) (&s_icp_acc[0][0])[i] = 0;
+    if (threadIdx.x == 0) s_icp_found = 0;
+}
+template <int F>
+__device__ __forceinline__ void se3_accumulate_lds(const float (&row)[7], int lane)
+{
+    constexpr float lim = (float)(1 << ((50 - F) / 2));
+    constexpr float scale = (F == 32) ? 4294967296.0f : (float)(1u << (F & 31));
+    unsigned long long* col = &s_icp_acc[0][lane];
+    double r[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) r[i] = (double)clamp_row(row[i], lim);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double rs = (double)(clamp_row(row[i], lim) * scale);
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            if (j >= i) lds_add_u64(col + 64 * (7 * i - (i * (i - 1)) / 2 + (j - i)), (unsigned long long)__double_as_longlong(fma(rs, r[j], kMagic)));
+    }
+    lds_add_u64(col + 64 * 27, (unsigned long long)__double_as_longlong(fma(r[6] * (double)scale, r[6], kMagic)));
+}
+// ... and the workgroup's totals to its accumulator group in memory (all waves call it: the barrier is inside).  Wave g of the first
+// four reduces words 8 g .. 8 g + 7 (fewer than four waves: they take turns); lanes 8 i of a wave end with word 8 g + i.
+__device__ __forceinline__ void icp_lds_commit(int lane, int wave, int nwaves, unsigned long long* __restrict__ dst /* [32] of this group */)
+{
+    __syncthreads();
+    const unsigned found = s_icp_found;
+    if (found == 0) return;
+    for (int g = wave; g < 4; g += nwaves) {
+        unsigned long long acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = (g < 3 || k < 4) ? s_icp_acc[(g < 3 || k < 4) ? 8 * g + k : 0][lane] : 0ull;
+        unsigned long long v = wave_reduce8_u64(acc, lane);
+        const int w = 8 * g + (lane >> 3);
+        if (w < 28) v -= (unsigned long long)found * kMagicBits;
+        else v = w == 28 ? (unsigned long long)found : 0ull;
+        if ((lane & 7) == 0 && v != 0) atomicAdd(&dst[w], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // cross-wave combine + grouped atomics.  v = wave total of word ((lane>>1)&31) (wave_reduce32_u64).
 // XCD_LOCAL: the atomics are performed in the L2 of THIS XCD (workgroup scope) -- for sums that only workgroups of the same XCD add to and
 // read back (rgb_step_solve_kernel).
@@ -204,8 +258,9 @@ template <bool COMPACT> __device__ void rgb_residual_body(const RgbArgs& ra, int
 // Only the pose/flags, which the solve updates on the device every iteration, are read from
 // memory -- as scalar loads issued in parallel with the first coalesced map loads.
 //
-// VALU budget (the kernel is VALU-bound once several models share a launch): PPT pixels per lane feed ONE
-// 32 x u64 butterfly; a wave whose pixels cannot produce a correspondence (projection out of view, model map empty
+// VALU budget (the kernel is VALU-bound once several models share a launch): the lanes' products go to the workgroup's accumulators in
+// LDS and ONE butterfly per workgroup reduces them (se3_accumulate_lds / icp_lds_commit; until round 5 every wave ran a 32 x u64
+// butterfly on its registers); a wave whose pixels cannot produce a correspondence (projection out of view, model map empty
 // there -- the common case for object models, which cover a small part of the image) leaves after the projection.
 static_assert(sizeof(IcpArgs) + sizeof(RgbArgs) + 64 <= 4096, "the kernel-argument segment holds 4 KB: lower kMaxBatch");  // (rgb_slot_step_kernel takes both as well)
 //
@@ -222,7 +277,7 @@ static_assert(sizeof(IcpArgs) + sizeof(RgbArgs) + 64 <= 4096, "the kernel-argume
 extern __shared__ int gram_lds[];
 // One run of pixels of one model: the 6 plane loads, projection, gather, gates, rows, accumulation and the wave butterfly.
 // i0 = this lane's first pixel, in_range = the lane's pixels take part.  Returns false when the tracker has nothing to do at this level
-// (workgroup-uniform: the caller leaves).  v = this wave's total of word ((lane >> 1) & 31) (product form), gram_has (Gram form).
+// (workgroup-uniform: the caller leaves).  Product form: the sums are left in the workgroup's LDS accumulators (icp_lds_commit); Gram form: gram_has.
 // The tracker state is written by the solve kernel of the PREVIOUS launch and only read here: through the constant address space its
 // (wave-uniform) loads are scalar loads whatever the compiler can prove about the stores around them -- with the run loop in the kernel
 // it fell back to per-lane vector loads of the pose, 44 more VGPRs and three waves of occupancy less.
@@ -378,21 +433,13 @@ __device__ __forceinline__ bool icp_run(const IcpArgs& args, const IcpModelArgs&
             }
         } else
         if (__any(any_found) || abl != 0) {
-            // (every lane's every product carries the magic number's bits: 64 * PPT of them per word come off ONCE, behind the butterfly --
-            // wrapping 64-bit arithmetic -- instead of 28 two-instruction subtractions per lane)
-            unsigned long long acc[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) acc[k] = 0;
 #pragma unroll
             for (int p = 0; p < PPT; p++) {
-                if (!(abl & 1)) se3_accumulate<kFixICP>(row[p], acc);
-                else acc[0] += __float_as_uint(row[p][6]) + __float_as_uint(row[p][3]);
-                acc[28] += (unsigned long long)fnd[p];
+                if (fnd[p] && !(abl & 1)) se3_accumulate_lds<kFixICP>(row[p], lane);
+                const int nf = __popcll(__ballot(fnd[p] != 0));
+                if (lane == 0 && nf) (void)__hip_atomic_fetch_add(&s_icp_found, (unsigned)nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (abl & 2) { if (acc[0] + acc[28] == 0x1234567ull) ma.acc[lane] = acc[5]; done = true; return true; }
-            v = wave_reduce32_u64(acc, lane);
-            if (((lane >> 1) & 31) < 28 && !(abl & 1)) v -= 64ull * (unsigned long long)PPT * kMagicBits;
-            if (abl & 4) { if (v == 0x1234567ull) ma.acc[lane] = v; done = true; return true; }
+            if (abl & 2) { done = true; return true; }
         }
     }
     return true;
@@ -479,6 +526,7 @@ __device__ __forceinline__ void icp_reduce_body(const IcpArgs& args, const RgbAr
                  "s"(ma.cull), "s"(ma.box_blocks), "s"(args.cols), "s"(args.rows), "s"(args.flags), "s"(args.occ_shift), "s"(args.occ_w), "s"(args.cdiv.M), "s"(args.cdiv.s),
                  "s"(args.row_begin), "s"(args.row_end), "s"(args.intr.fx), "s"(args.intr.fy), "s"(args.intr.cx), "s"(args.intr.cy), "s"(args.angleSqLt), "s"(args.distSqLe));
     if (ABL(256) && !ma.cull) return;  // timing ablation (CF_ICP_REPLAY): unculled models do nothing
+    if constexpr (!GRAM) { icp_lds_zero(); __syncthreads(); }   // (behind the argument clause, in front of the first vector load: the waves of a workgroup start together)
     StatePtr st = (StatePtr)ma.st;
     const int cols = args.cols, rows = args.rows, N = cols * rows;
     const int T = blockDim.x;
@@ -487,7 +535,7 @@ __device__ __forceinline__ void icp_reduce_body(const IcpArgs& args, const RgbAr
     unsigned long long v = 0;
     bool gram_has = false, done = false;
 
-    if (ma.box_blocks > 0) {  // culled model, runs of its screen box (the launcher: PPT == 1, product form, no error surface)
+    if (ma.box_blocks > 0) {  // culled model, runs of its screen box, one pixel per lane (the launcher: product form, no error surface)
         if (ABL(8)) return;  // timing ablation: culled models do nothing
         const IcpHot hs = icp_hot(st);
         if (!hs.icp || hs.level_done) return;
@@ -516,12 +564,10 @@ __device__ __forceinline__ void icp_reduce_body(const IcpArgs& args, const RgbAr
             // model's dilated box spans in this camera, no pixel of the run can match
             if (in_range && ma.zr) { const float2 zz = ma.zr[start >> 6]; if (!(zz.x <= zhi && zz.y >= zlo)) in_range = false; }
             const int i0 = start + lane;
-            unsigned long long vr = 0;
-            if (!icp_run<1, false>(args, ma, st, hs, true, i0, in_range && i0 < N, false, 0, N, nullptr, abl, lane, wave, vr, gram_has, done)) return;
+            if (!icp_run<1, false>(args, ma, st, hs, true, i0, in_range && i0 < N, false, 0, N, nullptr, abl, lane, wave, v, gram_has, done)) return;
             if (done) return;
-            v += vr;
         }
-        if constexpr (!GRAM) block_commit32<16>(v, lane, wave, T >> 6, ma.acc + (size_t)(bx % kGroups) * 32);
+        if constexpr (!GRAM) icp_lds_commit(lane, wave, T >> 6, ma.acc + (size_t)(bx % kGroups) * 32);
         return;
     }
 
@@ -585,7 +631,7 @@ __device__ __forceinline__ void icp_reduce_body(const IcpArgs& args, const RgbAr
     if (!icp_run<PPT, GRAM>(args, ma, st, hs, cull_here, i0, in_range, whole, band0, band1, errs, abl, lane, wave, v, gram_has, done)) return;
     if (done) return;
     if constexpr (GRAM) gram_block_commit(gram_lds, gram_has, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
-    else block_commit32<16>(v, lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
+    else icp_lds_commit(lane, wave, T >> 6, ma.acc + (size_t)(lb % kGroups) * 32);
 }
 
 #ifdef CF_ABLATE
@@ -593,8 +639,10 @@ __device__ __forceinline__ void icp_reduce_body(const IcpArgs& args, const RgbAr
 // constant clock), XCC_ID | HW_ID << 8, 0
 __device__ unsigned long long* g_icp_trace = nullptr;
 #endif
+// (waves_per_eu 6: the register allocator then lands on 71 VGPRs = seven waves per SIMD with the full scalar register file; asked for
+// seven it caps the SGPRs at 94 and spills them through VGPR lanes -- 327 against 45 v_readlane / v_writelane in the kernel.)
 template <int PPT, int LEVEL_TAG, bool GRAM>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PPT == 1 && !GRAM ? 7 : 1))) icp_reduce_kernel(const IcpArgs args, const RgbArgs ra, int n_icp_blocks)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PPT <= 2 && !GRAM ? 6 : 1))) icp_reduce_kernel(const IcpArgs args, const RgbArgs ra, int n_icp_blocks)
 {
 #ifdef CF_ABLATE
     unsigned long long* const tr = g_icp_trace;
@@ -1688,12 +1736,12 @@ static void launch_icp_kernel_arith(hipStream_t s, IcpLaunch cfg, const IcpArgs&
     const int nlog = (N + per_block - 1) / per_block;
     const int full = icp ? ((nlog + 7) / 8) * 8 : 0;
     // culled models: the workgroups the caller asked for (IcpModelArgs::box_blocks, box_blocks_for), at most the whole image's.  The
-    // mapping is built for one pixel per lane and the product form, and not used on the error-surface iteration (which writes every
-    // pixel) nor with row bands.
+    // mapping walks its runs one pixel per lane whatever the launch's pixels per lane are (those apply to unculled models), is built for
+    // the product form, and not used on the error-surface iteration (which writes every pixel) nor with row bands.
     int blocks[kMaxBatch];
     for (int m = 0; m < n; m++) {
         IcpModelArgs& ma = args.m[m];
-        const bool ok = icp && ma.cull && ma.box_blocks > 0 && !GRAM && cfg.ppt == 1 && (!(args.flags & 1) || (args.flags & 2)) && args.row_end == 0 && ma.row_end == 0;
+        const bool ok = icp && ma.cull && ma.box_blocks > 0 && !GRAM && (!(args.flags & 1) || (args.flags & 2)) && args.row_end == 0 && ma.row_end == 0;
         ma.box_blocks = ok ? (ma.box_blocks < full ? ((ma.box_blocks + 7) / 8) * 8 : full) : 0;
         blocks[m] = ok ? ma.box_blocks : full;
     }
@@ -1786,6 +1834,10 @@ static void launch_icp_kernel(hipStream_t s, IcpLaunch cfg, const IcpArgs& args,
 static void launch_icp_rgbres(hipStream_t s, IcpLaunch cfg, const IcpArgs& args, const RgbArgs& ra, bool icp, bool rgb, int n, int level,
                               hipEvent_t ev0, hipEvent_t ev1)
 {
+    // pixels per lane of unculled trackers, 0 = the library's choice: two at level 0 in the product form -- half the waves of the launch's
+    // largest slot for the same loads in flight, 12.4 against 13.0 us with five trackers since the accumulators live in LDS (round 5; with
+    // them in registers two pixels cost a wave of occupancy and lost) --, one on the small levels and in the Gram form
+    if (cfg.ppt == 0) cfg.ppt = (level == 0 && !cfg.gram) ? 2 : 1;
     const int N = (icp ? args.cols * args.rows : ra.cols * ra.rows);
     const int res_per_block = cfg.threads * (ra.compact ? 4 : 1);  // compact list pass: four pixels per thread
     const int n_res_blocks = rgb ? (N + res_per_block - 1) / res_per_block : 0;

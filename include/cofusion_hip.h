@@ -458,7 +458,9 @@ int cf_seg_labels(cf_segmenter *s, void **dptr, uint64_t *bytes);
  * them to finish runs the solve (two launches per iteration; measured slower at 640x480, kept as an option); 0: the reference's
  * 16 B DataTerm record per pixel (diagnostic / comparison).  Results are bit-identical in all three. */
 int cf_set_gn_mode(cf_ctx *ctx, int mode);
-/* launch-shape tuning of the ICP reduction (GPUConfig.h:51-58 in the reference) */
+/* launch-shape tuning of the ICP reduction (GPUConfig.h:51-58 in the reference): threads per workgroup (64..1024, default 256) and
+ * pixels per lane of trackers that reduce their whole image (1, 2, 4; 0 = default: two at pyramid level 0, one below).  The sums are
+ * integers: every shape gives the same bits. */
 int cf_set_icp_launch(cf_ctx *ctx, int threads, int pixels_per_thread);
 /* Rounding specification of the ICP normal equations (icpStep's 27 products + residual, reduce.cu:334-394), a property of the context:
  *   CF_ICP_ARITH_PRODUCT (default): each product row_i*row_j is formed exactly in f64 and rounded once to 2^-CF_FIX_ICP;

@@ -1,0 +1,28 @@
+# A/B of two builds on ONE box: co_fusion_amd/lib (new) against co_fusion_amd/lib_old (the committed source built aside), then the
+# replay decomposition and the per-workgroup trace of the diagnostics build
+set -u
+O=gpurun_out/${1:-r5ag}; mkdir -p $O
+timeout 500 python -m pytest tests/test_track_gpu.py tests/test_refpin_gpu.py tests/test_icp_gram_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; echo "tests rc=$?"; tail -3 $O/pytest.log
+B="python bench.py --no-cpu-baseline --no-extras --steps 100 --warmup 20"
+: > $O/lines.jsonl
+for rep in 1 2 3; do
+for W in objects4 static objects8; do
+for L in lib lib_old; do
+  echo "# $L $W" >> $O/lines.jsonl
+  CF_LIB_DIR=$PWD/co_fusion_amd/$L timeout 120 $B --workload $W >> $O/lines.jsonl 2>> $O/err.txt
+done; done; done
+export CF_LIB_DIR=$PWD/co_fusion_amd/lib_ablate
+CF_ICP_REPLAY=180 timeout 150 $B > /dev/null 2> $O/replay.txt
+CF_ICP_TRACE=185 CF_ICP_TRACE_OUT=$O/trace.txt timeout 150 $B > /dev/null 2>> $O/err.txt
+python tools/icp_trace_summary.py $O/trace.txt > $O/trace_summary.txt 2>&1
+python - <<PY
+import json
+tag=None
+for l in open("$O/lines.jsonl"):
+    if l.startswith("#"): tag=l.strip(); continue
+    try: d=json.loads(l)
+    except Exception: continue
+    r=d["roofline"]; print(f"{tag:24s} fps {d['value']:8.2f} icp {r['avg_us']:6.2f} us  digest {d.get('parity_vs_n1',{}).get('sha256','')[:12]}")
+PY
+grep "icp replay" $O/replay.txt
+head -14 $O/trace_summary.txt

@@ -2,7 +2,7 @@
 source file so that bench.py only quotes it for the build it was taken on.
 
 usage: make_traffic_json.py <gpurun_out/dir with pmc_icp_FETCH_SIZE.txt + pmc_icp_WRITE_SIZE.txt> <profiles/rNN_icp_traffic.json> [models]
-The level-0 multi-model kernel is icp_reduce_kernel<1, 4, ...>, the one-model one <1, 0, ...>; with the box-indexed grids of round 4 the
+The level-0 multi-model kernel is icp_reduce_kernel<P, 4, ...> (P pixels per lane: 2 since round 5), the one-model one <P, 0, ...>; with the box-indexed grids of round 4 the
 grid size of the multi-model launch varies from frame to frame, so all its dispatches with `models` trackers' worth of residual workgroups
 are averaged (weighted by dispatches)."""
 import hashlib, json, os, re, sys
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def averages(path, tag):
     n, s = 0, 0.0
     for l in open(path):
-        if tag not in l:
+        if not re.search(tag, l):
             continue
         parts = l.split()
         d, avg = int(parts[-2]), float(parts[-1])
@@ -28,13 +28,13 @@ def main():
     rocprof = dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in sys.argv[3].split(",")) if len(sys.argv) > 3 else {}
     sha = hashlib.sha256(open(os.path.join(ROOT, "co_fusion_amd", "csrc", "track_reduce.hip"), "rb").read()).hexdigest()
     entries = []
-    for tag, workload, what in (("icp_reduce_kernel<1, 4, false>", "objects4", "ICP reduction of the lock-step models || their RGB residual passes, level 0, box-indexed grids"),
-                                ("icp_reduce_kernel<1, 0, false>", "static", "ICP reduction || RGB residual of the background model, level 0 (the pre-roll frames of the same run)")):
+    for tag, workload, what in ((r"icp_reduce_kernel<\d, 4, false>", "objects4", "ICP reduction of the lock-step models || their RGB residual passes, level 0, box-indexed grids"),
+                                (r"icp_reduce_kernel<\d, 0, false>", "static", "ICP reduction || RGB residual of the background model, level 0 (the pre-roll frames of the same run)")):
         f, nf = averages(os.path.join(src, "pmc_icp_FETCH_SIZE.txt"), tag)
         w, nw = averages(os.path.join(src, "pmc_icp_WRITE_SIZE.txt"), tag)
         if f is None or w is None:
             continue
-        entries.append(dict(kernel=f"cf::{tag}: {what}", workload=workload, pixels=307200, fetch_size_kb_avg=round(f, 2), write_size_kb_avg=round(w, 2),
+        entries.append(dict(kernel=f"cf::{tag.replace(chr(92) + 'd', 'P')}: {what}", workload=workload, pixels=307200, fetch_size_kb_avg=round(f, 2), write_size_kb_avg=round(w, 2),
                             dispatches=min(nf, nw), kernel_source_sha256=sha,
                             correction="traffic = 2*FETCH_SIZE*1024 + 1*WRITE_SIZE*1024 (factors measured by tools/microbench/fetch_calib.hip in the same call: pmc_calibration_*.txt)",
                             traffic_bytes_per_launch=int(2 * f * 1024 + w * 1024),
