@@ -423,7 +423,12 @@ def main(argv=None):
                         bytes_per_pixel="24 + 24*M (ICP) + 11*M (residual), M = models in the launch",
                         frac_icp_bytes_only=round(icp_only / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4),
                         bytes_processed_per_launch=int(processed), pixels_in_screen_boxes=[int(v) for v in boxed],
-                        frac_bytes_processed=round(processed / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4))
+                        frac_bytes_processed=round(processed / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4),
+                        convention="`achieved` / `frac` follow SURVEY 8(d): every pixel of the frame is credited to every tracker in the launch.  Culled "
+                                   "trackers (object models) only touch the runs inside their screen boxes (`pixels_in_screen_boxes`), so at large frames the "
+                                   "credited rate can exceed what a memory system could deliver (frac > 1 at 1280x960 with four culled trackers): it is the "
+                                   "reference's work done per second, not bytes moved -- `frac_bytes_processed` counts the pixels actually visited, `traffic` "
+                                   "what the counters saw cross the HBM interface")
         if pmc_traffic.rocprof_us:   # the same launches in the committed rocprofv3 --kernel-trace run of this build (shorter: see the file)
             roofline.update(rocprofv3_avg_us=pmc_traffic.rocprof_us, frac_rocprofv3=round(bpl / pmc_traffic.rocprof_us / 1e3 / HBM_PEAK_GBS, 4),
                             rocprofv3_source="profiles/r5*_icp_level0_timed_launches.txt: kernel durations of the timed steps' level-0 launches under rocprofv3 "
