@@ -322,6 +322,8 @@ static void launch_crf_kernel_matrix(hipStream_t st, const CrfBatch& B, int S, i
 // Measured and dropped in round 5 (both bit-identical, DESIGN-NOTES R5): message + update as ONE launch -- a 1024-thread workgroup owning
 // 8 nodes, wave = chunk, lane = (node, label), chunk sums through LDS: 13.8 us per step against 7.6 + 4.9 -- and four nodes per lane
 // with 16-byte kernel-matrix loads: 8.2 against 7.6 us.  The step is three dependent rounds of loads behind a launch, not load issue.
+// A third fusion (the workgroup's columns of both kernel matrices and all marginals staged in 106 KB of LDS with 16-byte loads, chunk sums
+// out of LDS, update in place): 13.9 us per step, 768 against 781 frames/s (profiles/r5an_*).  Two launches it stays.
 __global__ void __launch_bounds__(64) crf_message_kernel(const CrfBatch B, int n, int flip)
 {
     const CrfSeq& m = B.m[blockIdx.z];
