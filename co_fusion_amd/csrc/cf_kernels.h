@@ -209,16 +209,18 @@ __host__ __device__ inline CullRuns cull_runs(const int box[4], int L, int cols,
     const int q0 = (by0 * cols) >> 6, q1 = ((by1 + 1) * cols - 1) >> 6;
     return CullRuns{0, q0, 0, q1 - q0 + 1};
 }
-// Workgroups for a culled model at level L: the runs of the level-0 screen box the model ended its previous tracking call with
-// (box_hint; [0] == kNoBoxHint: none known -> 0 = the whole image's), + 25 % + two rows of runs -- the waves walk on if the box has
-// grown beyond that -- in multiples of 8 (slots start on XCD 0), at least 8.
+// Workgroups for a culled model at level L: HALF the runs of the level-0 screen box the model ended its previous tracking call with
+// (box_hint; [0] == kNoBoxHint: none known -> 0 = the whole image's), + 25 % + two rows of runs -- every wave walks two runs, and on
+// if the box has grown beyond that -- in multiples of 8 (slots start on XCD 0), at least 8.  Two runs per wave since the end of round 5:
+// the culled trackers' workgroups finish long before the background's, so fewer of them (a shorter dispatch ramp for everybody) is
+// worth their longer chains: 12.5 -> 12.1 us for the five-tracker launch; four runs per wave make them the tail (13.1 us).
 inline int box_blocks_for(const int box_hint[4], int L, int cols, int rows, int threads)
 {
     if (box_hint[0] == kNoBoxHint) return 0;
     const CullRuns cr = cull_runs(box_hint, L, cols, rows);
     const int wpb = threads / 64;
     const int runs = cr.total + cr.total / 4 + 2 * (cr.nrx > 0 ? cr.nrx : (cols + 63) / 64);
-    int want = (((runs + wpb - 1) / wpb + 7) / 8) * 8;
+    int want = (((runs + 2 * wpb - 1) / (2 * wpb) + 7) / 8) * 8;
     return want < 8 ? 8 : want;
 }
 // Residual workgroups for a culled tracker at one level: the record slots between the first and the last RGB candidate of the previous
