@@ -414,8 +414,14 @@ def main(argv=None):
             b = cf.model_cull_box(i)
             boxed.append(max(0, min(b[2], W - 1) - max(b[0], 0) + 1) * max(0, min(b[3], H - 1) - max(b[1], 0) + 1))
         processed = 24 * W * H + 24 * sum(boxed) + 11 * n_models * W * H
+        # (the committed counter passes and rocprofv3 durations are those of the one-GPU launch: with the trackers spread over ranks this
+        # rank's launch is another one, and neither is quoted)
+        traffic, traffic_source = pmc_traffic(args.workload, W * H) if world == 1 else (None, "counter passes exist for the one-GPU launch only; at "
+                                                                                        "N > 1 this rank's launch carries its own trackers only")
+        if world > 1:
+            pmc_traffic.rocprof_us = None
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=pmc_traffic(args.workload, W * H)[0], traffic_source=pmc_traffic(args.workload, W * H)[1],
+                        traffic=traffic, traffic_source=traffic_source,
                         kernel="cf::icp_reduce_kernel<PPT,%d>: ICP reduction of all lock-step models || their RGB residual passes, pyramid level 0"
                                % (4 if n_models > 1 else 0),
                         launches=int(prof.icp_launches), avg_us=round(avg_us, 3), bytes_per_launch=bpl,
