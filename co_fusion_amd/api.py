@@ -263,8 +263,8 @@ class Context:
         self._check(self.lib.cf_set_icp_launch(self.h, threads, ppt))
 
     def set_icp_arith(self, mode):
-        """rounding specification of the ICP sums: 0 / "product" (default) or 1 / "gram" (include/cofusion_hip.h: cf_set_icp_arith)"""
-        self._check(self.lib.cf_set_icp_arith(self.h, {"product": 0, "gram": 1}.get(mode, mode)))
+        """rounding specification of the ICP sums: 0 / "product" (default), 1 / "gram" or 2 / "reference" (the reference's own f32 trees and host loop; include/cofusion_hip.h: cf_set_icp_arith)"""
+        self._check(self.lib.cf_set_icp_arith(self.h, {"product": 0, "gram": 1, "reference": 2}.get(mode, mode)))
 
     def profile_enable(self, on=True):
         self._check(self.lib.cf_profile_enable(self.h, int(on)))

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "cf_host.h"
+#include "gn_ref_host.h"
 
 using namespace cf;
 
@@ -61,11 +62,12 @@ int cf_create(const cf_config* cfg, cf_ctx** out)
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state_pool), sizeof(OdomDev) * cf_ctx::kStateSlots, hipHostMallocCoherent));  // the last solve stores into it
     memset(ctx->h_state_pool, 0, sizeof(OdomDev) * cf_ctx::kStateSlots);
     if (int r = dmalloc(ctx, &ctx->d_so3_sync, (size_t)ctx->cfg.max_models + 1)) return r;
-    // the ONE environment switch of the library: CF_ICP_ARITH = "product" (default) / "gram", the rounding specification of the ICP sums
+    // the ONE environment switch of the library: CF_ICP_ARITH = "product" (default) / "gram" / "reference", the rounding specification of the tracker's sums
     // for every context of the process (cf_set_icp_arith sets it per context; launch shape and data path have setters only)
     if (const char* e = getenv("CF_ICP_ARITH")) {
-        if (cf_set_icp_arith(ctx, (!strcmp(e, "gram") || !strcmp(e, "1")) ? CF_ICP_ARITH_GRAM : (!strcmp(e, "product") || !strcmp(e, "0")) ? CF_ICP_ARITH_PRODUCT : -1) != CF_OK) {
-            ctx->set_error("CF_ICP_ARITH: product | gram"); return CF_EINVAL;
+        if (cf_set_icp_arith(ctx, (!strcmp(e, "gram") || !strcmp(e, "1")) ? CF_ICP_ARITH_GRAM : (!strcmp(e, "reference") || !strcmp(e, "2")) ? CF_ICP_ARITH_REFERENCE
+                                  : (!strcmp(e, "product") || !strcmp(e, "0")) ? CF_ICP_ARITH_PRODUCT : -1) != CF_OK) {
+            ctx->set_error("CF_ICP_ARITH: product | gram | reference"); return CF_EINVAL;
         }
     }
     if (int r = dmalloc(ctx, &ctx->d_cand_scratch, (size_t)cfg->width * cfg->height)) return r;
@@ -90,6 +92,8 @@ void cf_destroy(cf_ctx* ctx)
     (void)hipFree(ctx->d_scratch_state); (void)hipFree(ctx->d_so3_sync); (void)hipFree(ctx->d_cand_scratch);
     (void)hipFree(ctx->d_state_pool); (void)hipHostFree(ctx->h_state_pool);
     (void)hipHostFree(ctx->h_scratch_state); (void)hipHostFree(ctx->h_out);
+    if (ctx->d_ref) (void)hipFree(ctx->d_ref);
+    if (ctx->h_ref) (void)hipHostFree(ctx->h_ref);
     if (ctx->prof.events) {
         for (int i = 0; i < ctx->prof.capacity; i++) (void)hipEventDestroy(ctx->prof.events[i]);
         delete[] ctx->prof.events;
@@ -307,11 +311,12 @@ int cf_set_icp_launch(cf_ctx* ctx, int threads, int ppt)
 
 int cf_set_icp_arith(cf_ctx* ctx, int mode)
 {
-    if (!ctx || (mode != CF_ICP_ARITH_PRODUCT && mode != CF_ICP_ARITH_GRAM)) return CF_EINVAL;
-    ctx->icp_launch.gram = mode;
+    if (!ctx || (mode != CF_ICP_ARITH_PRODUCT && mode != CF_ICP_ARITH_GRAM && mode != CF_ICP_ARITH_REFERENCE)) return CF_EINVAL;
+    ctx->icp_arith = mode;
+    ctx->icp_launch.gram = mode == CF_ICP_ARITH_GRAM ? 1 : 0;
     return CF_OK;
 }
-int cf_get_icp_arith(cf_ctx* ctx) { return ctx ? ctx->icp_launch.gram : CF_EINVAL; }
+int cf_get_icp_arith(cf_ctx* ctx) { return ctx ? ctx->icp_arith : CF_EINVAL; }
 
 int cf_profile_enable(cf_ctx* ctx, int on) { if (!ctx || on < 0) return CF_EINVAL; ctx->prof.enabled = on; ctx->prof_calls = 0; return CF_OK; }
 int cf_profile_read(cf_ctx* ctx, cf_profile* out, int reset)
@@ -427,6 +432,18 @@ int cf_icp_step_band(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], co
 {
     if (!ctx || !vmap_curr || !nmap_curr || !vmap_g_prev || !nmap_g_prev || (cols % 4)) return CF_EINVAL;
     if (row_begin < 0 || row_end > rows || row_begin >= row_end) return CF_EINVAL;
+    if (ctx->icp_arith == CF_ICP_ARITH_REFERENCE) {   // the reference's own f32 tree (track_ref.hip): no fixed-point sums, no row bands
+        if (row_begin != 0 || row_end != rows) { ctx->set_error("cf_icp_step_band: the reference-order arithmetic has no row bands (a band is another launch shape)"); return CF_EINVAL; }
+        if (sums_host) memset(sums_host, 0, sizeof(int64_t) * 32);   // (no fixed-point sums in this mode)
+        float out29[29];
+        if (int r = ref_icp_step(ctx, Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, dist_thres, angle_thres, cols, rows, err_surface, out29)) return r;
+        float A[36], b[6], res[2];
+        refhost::unpack29(out29, A, b, res);
+        if (A_host) memcpy(A_host, A, sizeof(A));
+        if (b_host) memcpy(b_host, b, sizeof(b));
+        if (residual_host) memcpy(residual_host, res, sizeof(res));
+        return CF_OK;
+    }
     if (int r = scratch_begin(ctx, cols, rows)) return r;
     OdomDev* h = ctx->h_scratch_state;
     memcpy(h->Rcurr, Rcurr, 36); memcpy(h->tcurr, tcurr, 12); memcpy(h->Rprev_inv, Rprev_inv, 36); memcpy(h->tprev, tprev, 12);
@@ -485,6 +502,16 @@ int cf_rgb_step(cf_ctx* ctx, const cf_dataterm* corres, float sigma, const float
                 float* b_host, int64_t* sums_host)
 {
     if (!ctx || !corres) return CF_EINVAL;
+    if (ctx->icp_arith == CF_ICP_ARITH_REFERENCE) {
+        if (sums_host) memset(sums_host, 0, sizeof(int64_t) * 32);
+        float out29[29];
+        if (int r = ref_rgb_step(ctx, corres, sigma, cloud3, fx, fy, dIdx, dIdy, sobel_scale, cols, rows, out29)) return r;
+        float A[36], b[6];
+        refhost::unpack29(out29, A, b, nullptr);
+        if (A_host) memcpy(A_host, A, sizeof(A));
+        if (b_host) memcpy(b_host, b, sizeof(b));
+        return CF_OK;
+    }
     if (int r = scratch_begin(ctx, cols, rows)) return r;
     OdomDev* h = ctx->h_scratch_state;
     h->corres[0] = const_cast<cf_dataterm*>(corres); h->cloud[0] = cloud3; h->dIdx[0] = dIdx; h->dIdy[0] = dIdy;
@@ -516,6 +543,20 @@ int cf_so3_step(cf_ctx* ctx, const uint8_t* last_image, const uint8_t* next_imag
                 float* residual_host, int64_t* sums_host)
 {
     if (!ctx) return CF_EINVAL;
+    if (ctx->icp_arith == CF_ICP_ARITH_REFERENCE) {
+        if (sums_host) memset(sums_host, 0, sizeof(int64_t) * 16);
+        float o[11];
+        if (int r = ref_so3_step(ctx, last_image, next_image, image_basis, kinv, krlr, cols, rows, o)) return r;
+        int shift = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = i; j < 4; ++j) {
+                const float value = o[shift++];
+                if (j == 3) { if (b_host) b_host[i] = value; }
+                else if (A_host) A_host[j * 3 + i] = A_host[i * 3 + j] = value;
+            }
+        if (residual_host) { residual_host[0] = o[9]; residual_host[1] = o[10]; }
+        return CF_OK;
+    }
     launch_so3_step(ctx->stream, last_image, next_image, image_basis, kinv, krlr, cols, rows, ctx->d_out);
     LAUNCHCHK(ctx);
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -951,6 +992,31 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     if (!ctx || !ods || n <= 0 || n > ctx->cfg.max_models || n > kMaxBatch || !poses_in || !opts) return CF_EINVAL;
     const bool want_rgb = opts->rgb_only || opts->icp_weight < 100;
     if (ctx->state_readback_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ctx->state_readback_pending = false; }
+    if (ctx->icp_arith == CF_ICP_ARITH_REFERENCE) {
+        // THE REFERENCE'S OWN ORDER (track_ref.hip): per tracker the reference's host loop -- kernel, second-stage kernel, read-back, host
+        // solve -- over the same prepared pyramids; nothing is culled (every thread's partial sum is part of the result), nothing is
+        // split over GPUs (a rank's band would be another launch shape).  Synchronous; the results are where the default tracker's last
+        // solve leaves them, so cf_odom_fetch_result and everything behind it are unchanged.
+        for (int m = 0; m < n; m++)
+            if (ods[m]->band_end > 0) { ctx->set_error("the reference-order arithmetic (cf_set_icp_arith 2) does not split a tracker's reductions over GPUs"); return CF_ESTATE; }
+        RgbPrepBatch rp{};
+        for (int base = 0; base < n; base += kPrepBatch) {
+            const int nb = n - base < kPrepBatch ? n - base : kPrepBatch;
+            rp = RgbPrepBatch{};
+            for (int m = base; m < base + nb; m++) {
+                if (int r = odom_prepare(ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr, &rp.m[m - base])) return r;
+                ods[m]->h_state->cull = 0; ods[m]->h_state->res_range = nullptr; rp.m[m - base].res_range = nullptr;
+                ods[m]->box_hint[0] = kNoBoxHint;
+                HIPCHK(ctx, hipMemsetAsync(ods[m]->aabb, 0, 8 * sizeof(unsigned), ctx->stream));   // (the default tracker's first launch latches and clears it)
+            }
+            if (want_rgb) launch_rgb_prep(ctx->stream, rp, nb, ctx->cfg.width, ctx->cfg.height);
+        }
+        LAUNCHCHK(ctx);
+        for (int m = 0; m < n; m++)
+            if (int r = ref_track(ctx, ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr)) return r;
+        ctx->state_readback_pending = true;
+        return CF_OK;
+    }
     // a batch of <= kPrepBatch trackers with the SO3 pre-alignment: the RGB preparation rides in the pre-alignment's launch
     const bool prep_fused = want_rgb && opts->so3 != 0 && n <= kPrepBatch;
     RgbPrepBatch prep{};

@@ -20,6 +20,9 @@ struct cf_ctx {
     std::string last_error;
     std::mutex error_mutex;            // helper threads bound with cf_thread_lane may fail at the same time
     cf::IcpLaunch icp_launch{256, 0};
+    int icp_arith = 0;                 // cf_set_icp_arith: 0 product, 1 Gram (= icp_launch.gram), 2 the reference's own f32 trees + host loop (track_ref.hip)
+    float* d_ref = nullptr;            // scratch of the reference-order tracker (block partials, totals, counts), created on first use
+    float* h_ref = nullptr;            // ... and its pinned read-back
     // scratch for the stand-alone reduction steps
     unsigned long long* d_acc_a = nullptr;
     unsigned long long* d_acc_b = nullptr;
@@ -66,6 +69,18 @@ struct cf_ctx {
     void set_error(const std::string& m);
 };
 extern "C" int cf_wait_stream(cf_ctx* ctx);   // the frame's host wait (cabi.hip)
+struct cf_odom;
+namespace cf {
+// the reference-order tracker (track_ref.hip): RGBDOdometry::getIncrementalTransformation for one prepared tracker, host loop included
+int ref_track(cf_ctx* ctx, cf_odom* od, const float pose[16], const cf_track_opts* opts, float* err_surface);
+// ... and its single reductions in the reference's own f32 order (the C-ABI steps under cf_set_icp_arith 2)
+int ref_icp_step(cf_ctx* ctx, const float Rcurr[9], const float tcurr[3], const float* vc, const float* nc, const float Rprev_inv[9], const float tprev[3],
+                 cf_cam intr, const float* vp, const float* np, float dist_thres, float angle_thres, int cols, int rows, float* err, float out29[29]);
+int ref_rgb_step(cf_ctx* ctx, const cf_dataterm* corres, float sigma, const float* cloud3, float fx, float fy, const int16_t* dIdx, const int16_t* dIdy,
+                 float sobel_scale, int cols, int rows, float out29[29]);
+int ref_so3_step(cf_ctx* ctx, const uint8_t* last_image, const uint8_t* next_image, const float basis[9], const float kinv[9], const float krlr[9],
+                 int cols, int rows, float out11[11]);
+}
 
 // Device-resident RGBDOdometry (Core/Utils/RGBDOdometry.h:78-137)
 struct cf_odom {

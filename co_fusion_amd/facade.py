@@ -304,8 +304,8 @@ class CoFusion:
         assert self.abi.cf_set_icp_launch(self._ctx(), threads, ppt) == 0
 
     def set_icp_arith(self, mode):
-        """rounding specification of the ICP sums: 0 / "product" (default) or 1 / "gram" (include/cofusion_hip.h: cf_set_icp_arith)"""
-        assert self.abi.cf_set_icp_arith(self._ctx(), {"product": 0, "gram": 1}.get(mode, mode)) == 0
+        """rounding specification of the ICP sums: 0 / "product" (default), 1 / "gram" or 2 / "reference" (the reference's own f32 trees and host loop; include/cofusion_hip.h: cf_set_icp_arith)"""
+        assert self.abi.cf_set_icp_arith(self._ctx(), {"product": 0, "gram": 1, "reference": 2}.get(mode, mode)) == 0
 
     def profile_enable(self, on=True):
         """on: False / True, or N > 1 = events on the level-0 launches of every N-th tracking call"""

@@ -468,9 +468,17 @@ int cf_set_icp_launch(cf_ctx *ctx, int threads, int pixels_per_thread);
  *     integer products are summed exactly -- the Gram matrix of an integer matrix, contracted over the pixels on the matrix cores
  *     (signed 8-bit limbs, v_mfma_i32_32x32x32_i8).  Fewer vector instructions per pixel; both forms are exact integer sums
  *     (independent of launch shape and GPU count) and both have an oracle (oracle/orc.h: orc_set_icp_arith).
- * The 64-bit sums cf_icp_step returns are in the units of the chosen form.  Also: CF_ICP_ARITH=product|gram in the environment. */
+ * The 64-bit sums cf_icp_step returns are in the units of the chosen form.  Also: CF_ICP_ARITH=product|gram|reference in the environment. */
 #define CF_ICP_ARITH_PRODUCT 0
 #define CF_ICP_ARITH_GRAM 1
+/*   CF_ICP_ARITH_REFERENCE: the reference's OWN order, for every reduction of the tracker (ICP, RGB, SO3), not only the ICP sums:
+ *     thread-strided f32 partial sums, 32-lane shuffle-down tree, block tree and second-stage reduceSum of Core/Cuda/reduce.cu:90-185,
+ *     396-417, 475-499 at the launch shapes of Core/Utils/GPUConfig.h:51-58, and the host loop of RGBDOdometry.cpp:217-477 around them
+ *     (device synchronisation and a read-back per step, host LDL^T).  Not launch-shape independent -- that is the point: its poses,
+ *     and with them whole trajectories and surfel counts, equal those of the reference's RGBDOdometry class bit for bit
+ *     (tests/test_refpin_gpu.py).  A parity mode: synchronous, ~60 host round trips per tracker and frame; no culling, no split
+ *     reductions; cf_icp_step / cf_rgb_step / cf_so3_step return A, b, residual of the f32 trees (sums_host is zero-filled). */
+#define CF_ICP_ARITH_REFERENCE 2
 int cf_set_icp_arith(cf_ctx *ctx, int mode);
 int cf_get_icp_arith(cf_ctx *ctx);
 

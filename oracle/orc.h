@@ -55,6 +55,11 @@ extern "C" {
  * Process-global switch: test infrastructure. */
 #define ORC_ICP_ARITH_PRODUCT 0
 #define ORC_ICP_ARITH_GRAM 1
+/*   ORC_ICP_ARITH_REFERENCE: no fixed point at all -- EVERY reduction of the tracker (ICP, RGB, SO3) is the reference's own
+ *     launch-shape dependent f32 tree at GPUConfig.h's default shapes and the host algebra follows the order of the classes the
+ *     reference instantiates (orc_track.c: odom_track_reference_order); the mode in which whole trajectories and surfel counts
+ *     equal those of the reference's RGBDOdometry class bit for bit (cf_set_icp_arith 2 on the HIP side). */
+#define ORC_ICP_ARITH_REFERENCE 2
 void orc_set_icp_arith(int mode);
 int orc_get_icp_arith(void);
 

@@ -308,7 +308,10 @@ static void icp_ctx_fill(icp_ctx *c, const float Rcurr[9], const float tcurr[3],
 }
 
 static int g_icp_arith = ORC_ICP_ARITH_PRODUCT;
-void orc_set_icp_arith(int mode) { g_icp_arith = mode == ORC_ICP_ARITH_GRAM ? ORC_ICP_ARITH_GRAM : ORC_ICP_ARITH_PRODUCT; }
+void orc_set_icp_arith(int mode)
+{
+    g_icp_arith = mode == ORC_ICP_ARITH_GRAM ? ORC_ICP_ARITH_GRAM : mode == ORC_ICP_ARITH_REFERENCE ? ORC_ICP_ARITH_REFERENCE : ORC_ICP_ARITH_PRODUCT;
+}
 int orc_get_icp_arith(void) { return g_icp_arith; }
 
 /* ORC_ICP_ARITH_GRAM: the same 29 words as the Gram matrix of the quantised rows (wrapping 64-bit sums like the product form) */
@@ -781,10 +784,311 @@ static void k_matrix(orc_cam c, double K[9])
     K[0] = c.fx; K[4] = c.fy; K[2] = c.cx; K[5] = c.cy; K[8] = 1;
 }
 
+
+/* ======================= ORC_ICP_ARITH_REFERENCE: the reference's own order =======================
+ * The third rounding specification: every reduction of the Gauss-Newton loop is the reference's launch-shape
+ * dependent f32 tree (thread-strided partials, 32-lane shuffle-down tree, block tree, second-stage reduceSum: reduce.cu:90-185,
+ * 396-417, 475-499) at the launch shapes of GPUConfig.h:51-58 -- the constructor's defaults, which every board that is not in its
+ * table of NVIDIA names gets -- and the host algebra follows the operation ORDER of the classes the reference's text instantiates as
+ * oracle/ref_shim/eigen_fixed states it (left-looking pivoted LDL^T, cofactor inverses expanded along the first column / first row,
+ * products accumulated left to right, isometry composition) with the C library's own cos / sin (OdometryProvider.h:48-49).  Pinned
+ * BIT FOR BIT against RGBDOdometry::getIncrementalTransformation compiled from /root/reference (tests/test_cpu_refpin.py:
+ * test_reference_order_gn_loop_is_the_reference_class_bit_for_bit); the HIP path has the same mode (cf_set_icp_arith 2). */
+#define REF_ICP_THREADS 128
+#define REF_ICP_BLOCKS 112
+#define REF_RGB_THREADS 128
+#define REF_RGB_BLOCKS 112
+#define REF_SO3_THREADS 160
+#define REF_SO3_BLOCKS 64
+
+/* Matrix<T,3,3>::inverse() of the stand-in: cofactors with cyclic indices, determinant along the first COLUMN */
+#define EIG_INV33(T, NAME)                                                                                         \
+    static void NAME(const T m[9], T o[9])                                                                         \
+    {                                                                                                              \
+        T cof[3][3];                                                                                               \
+        for (int i = 0; i < 3; i++)                                                                                \
+            for (int j = 0; j < 3; j++) {                                                                          \
+                const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;                  \
+                cof[i][j] = m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];                     \
+            }                                                                                                      \
+        const T det = (cof[0][0] * m[0] + cof[1][0] * m[3]) + cof[2][0] * m[6];                                    \
+        const T invdet = (T)1 / det;                                                                               \
+        for (int r = 0; r < 3; r++)                                                                                \
+            for (int c = 0; c < 3; c++) o[r * 3 + c] = cof[c][r] * invdet;                                         \
+    }
+EIG_INV33(double, eig_inv33d)
+EIG_INV33(float, eig_inv33f)
+
+/* Matrix<double,4,4>::inverse() of the stand-in: cofactors of 3x3 minors, determinant along the first ROW */
+static double eig_minor3(const double m[16], int r, int c)
+{
+    int ri[3], ci[3];
+    for (int k = 0, t = 0; k < 4; k++) if (k != r) ri[t++] = k;
+    for (int k = 0, t = 0; k < 4; k++) if (k != c) ci[t++] = k;
+#define M_(a, b) m[(a) * 4 + (b)]
+    return M_(ri[0], ci[0]) * (M_(ri[1], ci[1]) * M_(ri[2], ci[2]) - M_(ri[1], ci[2]) * M_(ri[2], ci[1])) -
+           M_(ri[0], ci[1]) * (M_(ri[1], ci[0]) * M_(ri[2], ci[2]) - M_(ri[1], ci[2]) * M_(ri[2], ci[0])) +
+           M_(ri[0], ci[2]) * (M_(ri[1], ci[0]) * M_(ri[2], ci[1]) - M_(ri[1], ci[1]) * M_(ri[2], ci[0]));
+#undef M_
+}
+static void eig_inv44d(const double m[16], double o[16])
+{
+    double cofm[4][4];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) cofm[r][c] = ((r + c) & 1) ? -eig_minor3(m, r, c) : eig_minor3(m, r, c);
+    const double det = ((m[0] * cofm[0][0] + m[1] * cofm[0][1]) + m[2] * cofm[0][2]) + m[3] * cofm[0][3];
+    const double invdet = 1.0 / det;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) o[r * 4 + c] = cofm[c][r] * invdet;
+}
+
+/* Matrix::ldlt().solve() of the stand-in: unblocked LEFT-looking LDL^T on the lower triangle with diagonal pivoting (first maximum
+ * wins), solve = P, L^-1, D^-1 (|d| <= 1 / max -> 0), L^-T, P^T */
+#define EIG_LDLT_SOLVE(T, NAME, TMAX)                                                                              \
+    static void NAME(int N, const T *Ain, const T *b, T *x)                                                        \
+    {                                                                                                              \
+        T a[36], y[6], temp[6];                                                                                    \
+        int tr[6];                                                                                                 \
+        for (int i = 0; i < N * N; i++) a[i] = Ain[i];                                                             \
+        for (int k = 0; k < N; k++) {                                                                              \
+            int big = k;                                                                                           \
+            T best = a[k * N + k] < 0 ? -a[k * N + k] : a[k * N + k];                                              \
+            for (int i = k + 1; i < N; i++) { const T v = a[i * N + i] < 0 ? -a[i * N + i] : a[i * N + i]; if (v > best) { best = v; big = i; } } \
+            tr[k] = big;                                                                                           \
+            if (big != k) {                                                                                        \
+                for (int j = 0; j < k; j++) { const T t = a[k * N + j]; a[k * N + j] = a[big * N + j]; a[big * N + j] = t; } \
+                for (int i = big + 1; i < N; i++) { const T t = a[i * N + k]; a[i * N + k] = a[i * N + big]; a[i * N + big] = t; } \
+                { const T t = a[k * N + k]; a[k * N + k] = a[big * N + big]; a[big * N + big] = t; }               \
+                for (int i = k + 1; i < big; i++) { const T t = a[i * N + k]; a[i * N + k] = a[big * N + i]; a[big * N + i] = t; } \
+            }                                                                                                      \
+            if (k > 0) {                                                                                           \
+                for (int j = 0; j < k; j++) temp[j] = a[j * N + j] * a[k * N + j];                                 \
+                { T s = a[k * N + 0] * temp[0]; for (int j = 1; j < k; j++) s = s + a[k * N + j] * temp[j]; a[k * N + k] = a[k * N + k] - s; } \
+                for (int i = k + 1; i < N; i++) { T s = a[i * N + 0] * temp[0]; for (int j = 1; j < k; j++) s = s + a[i * N + j] * temp[j]; a[i * N + k] = a[i * N + k] - s; } \
+            }                                                                                                      \
+            const T akk = a[k * N + k];                                                                            \
+            if ((akk < 0 ? -akk : akk) > (T)0) for (int i = k + 1; i < N; i++) a[i * N + k] = a[i * N + k] / akk;  \
+        }                                                                                                          \
+        for (int i = 0; i < N; i++) y[i] = b[i];                                                                   \
+        for (int k = 0; k < N; k++) { const T t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }                           \
+        for (int i = 1; i < N; i++) { T s = a[i * N + 0] * y[0]; for (int j = 1; j < i; j++) s = s + a[i * N + j] * y[j]; y[i] = y[i] - s; } \
+        const T tol = (T)1 / (T)TMAX;                                                                              \
+        for (int i = 0; i < N; i++) { const T d = a[i * N + i]; y[i] = ((d < 0 ? -d : d) > tol) ? y[i] / d : (T)0; } \
+        for (int i = N - 2; i >= 0; i--) { T s = a[(i + 1) * N + i] * y[i + 1]; for (int j = i + 2; j < N; j++) s = s + a[j * N + i] * y[j]; y[i] = y[i] - s; } \
+        for (int k = N - 1; k >= 0; k--) { const T t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }                      \
+        for (int i = 0; i < N; i++) x[i] = y[i];                                                                   \
+    }
+EIG_LDLT_SOLVE(double, eig_ldlt_solve_d, DBL_MAX)
+EIG_LDLT_SOLVE(float, eig_ldlt_solve_f, FLT_MAX)
+
+/* OdometryProvider::rodrigues as written (OdometryProvider.h:32-67), the C library's cos / sin */
+static void ref_rodrigues(const double src[3], double R[9])
+{
+    double rx = src[0], ry = src[1], rz = src[2];
+    const double theta = sqrt((src[0] * src[0] + src[1] * src[1]) + src[2] * src[2]);
+    for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    if (theta >= DBL_EPSILON) {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+        rx *= itheta; ry *= itheta; rz *= itheta;
+        const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+        const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+        for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+    }
+}
+
+/* reduce.cu:481-498 / 1158-1175: the 29 / 11 f32 totals -> A, b, residual */
+static void ref_unpack29(const float h[29], float A[36], float b[6], float residual[2])
+{
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const float value = h[shift++];
+            if (j == 6) b[i] = value;
+            else A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+    if (residual) { residual[0] = h[27]; residual[1] = h[28]; }
+}
+
+static void odom_track_reference_order(orc_odometry *o, float trans[3], float rot[9], const orc_track_opts *opts,
+                                       float *icp_err_surface, orc_track_stats *st)
+{
+    const int rgbOnly = opts->rgb_only;
+    const float icpWeight = opts->icp_weight;
+    const int icp = !rgbOnly && icpWeight > 0;
+    const int rgb = rgbOnly || icpWeight < 100;
+    orc_track_stats local; if (!st) st = &local;
+    memset(st, 0, sizeof(*st));
+    float Rprev[9], tprev[3], Rcurr[9], tcurr[3];
+    memcpy(Rprev, rot, 36); memcpy(tprev, trans, 12); memcpy(Rcurr, rot, 36); memcpy(tcurr, trans, 12);
+    if (rgb)
+        for (int i = 0; i < ORC_NUM_PYRS; i++) orc_sobel(o->nextImage[i], o->width >> i, o->height >> i, o->dIdx[i], o->dIdy[i]);
+
+    double resultR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (opts->so3) { /* RGBDOdometry.cpp:239-310 */
+        const int L = 2, cols = o->width >> L, rows = o->height >> L;
+        float R_lr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        double K[9], Kinv[9];
+        k_matrix(cam_level(o->intr, L), K);
+        float lastError = FLT_MAX / 2, lastCount = FLT_MAX / 2;
+        double lastResultR[9]; memcpy(lastResultR, resultR, sizeof(resultR));
+        for (int it = 0; it < 10; it++) {
+            double KR[9], H[9];
+            eig_inv33d(K, Kinv);
+            orc_mul33d(K, resultR, KR); orc_mul33d(KR, Kinv, H);   /* (K * resultR) * K.inverse() */
+            float basis[9], kinvf[9], krlr[9];
+            for (int k = 0; k < 9; k++) { basis[k] = (float)H[k]; kinvf[k] = (float)Kinv[k]; krlr[k] = (float)KR[k]; }
+            float out11[11], jtj[9], jtr[3], residual[2];
+            orc_so3_step_f32tree(o->lastNextImage[L], o->nextImage[L], basis, kinvf, krlr, cols, rows, REF_SO3_THREADS, REF_SO3_BLOCKS, out11);
+            int shift = 0;
+            for (int i = 0; i < 3; ++i)
+                for (int j = i; j < 4; ++j) {
+                    const float value = out11[shift++];
+                    if (j == 3) jtr[i] = value; else jtj[j * 3 + i] = jtj[i * 3 + j] = value;
+                }
+            residual[0] = out11[9]; residual[1] = out11[10];
+            st->so3_iterations = it + 1;
+            st->last_so3_error = sqrtf(residual[0]) / residual[1];
+            st->last_so3_count = residual[1];
+            if (st->last_so3_error < lastError && (double)fabsf(lastError - st->last_so3_count) < 0.001) break;
+            else if ((double)st->last_so3_error > (double)lastError + 0.001) {
+                st->last_so3_error = lastError; st->last_so3_count = lastCount;
+                memcpy(resultR, lastResultR, sizeof(resultR));
+                break;
+            }
+            lastError = st->last_so3_error; lastCount = st->last_so3_count;
+            memcpy(lastResultR, resultR, sizeof(resultR));
+            float delta[3];
+            eig_ldlt_solve_f(3, jtj, jtr, delta);
+            double dd[3] = {delta[0], delta[1], delta[2]}, rotUpdate[9];
+            ref_rodrigues(dd, rotUpdate);
+            float ru[9], nr[9];
+            for (int k = 0; k < 9; k++) ru[k] = (float)rotUpdate[k];
+            orc_mul33f(ru, R_lr, nr);
+            memcpy(R_lr, nr, sizeof(nr));
+            for (int k = 0; k < 9; k++) resultR[k] = R_lr[k];
+        }
+    }
+
+    int iterations[ORC_NUM_PYRS];
+    iterations[0] = opts->fast_odom ? 3 : 10;
+    iterations[1] = opts->pyramid ? 5 : 0;
+    iterations[2] = opts->pyramid ? 4 : 0;
+    float Rprev_inv[9];
+    eig_inv33f(Rprev, Rprev_inv);
+    double resultRt[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (opts->so3)
+        for (int x = 0; x < 3; x++)
+            for (int y = 0; y < 3; y++) resultRt[x * 4 + y] = resultR[x * 3 + y];
+    float residual[2] = {0, 0};
+    const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+
+    for (int i = ORC_NUM_PYRS - 1; i >= 0; i--) {
+        const int cols = o->width >> i, rows = o->height >> i;
+        const orc_cam il = cam_level(o->intr, i);
+        if (rgb) orc_project_cloud(o->lastDepth[i], cols, rows, il, o->cloud[i]);
+        double K[9], Kinv[9];
+        k_matrix(il, K);
+        st->last_rgb_error = FLT_MAX;
+        for (int j = 0; j < iterations[i]; j++) {
+            double Rt[16];
+            eig_inv44d(resultRt, Rt);
+            double R[9] = {Rt[0], Rt[1], Rt[2], Rt[4], Rt[5], Rt[6], Rt[8], Rt[9], Rt[10]};
+            double tmp[9], KRK[9];
+            eig_inv33d(K, Kinv);
+            orc_mul33d(K, R, tmp); orc_mul33d(tmp, Kinv, KRK);
+            float krkInv[9];
+            for (int k = 0; k < 9; k++) krkInv[k] = (float)KRK[k];
+            const double tv[3] = {Rt[3], Rt[7], Rt[11]};
+            float kt[3];
+            for (int r = 0; r < 3; r++) { double s = K[r * 3 + 0] * tv[0]; s = s + K[r * 3 + 1] * tv[1]; s = s + K[r * 3 + 2] * tv[2]; kt[r] = (float)s; }
+
+            int sigma = 0, rgbSize = 0;
+            if (rgb) {
+                const float minScale = (float)(pow(o->minGrad[i], 2.0) / pow(o->sobelScale, 2.0));
+                orc_rgb_residual(minScale, o->dIdx[i], o->dIdy[i], o->lastDepth[i], o->nextDepth[i], o->lastImage[i],
+                                 o->nextImage[i], o->corres[i], o->maxDepthDeltaRGB, kt, krkInv, cols, rows, &sigma, &rgbSize);
+            }
+            const float tmpError = (float)(sqrt((double)sigma) / rgbSize);
+            float sigmaVal = (tmpError == 0) ? 1 : (float)rgbSize;
+            if (rgbOnly && tmpError > st->last_rgb_error) break;
+            st->last_rgb_error = tmpError; st->last_rgb_count = (float)rgbSize;
+            if (rgbOnly) sigmaVal = -1;
+
+            float A_icp[36], b_icp[6], A_rgbd[36], b_rgbd[6];
+            memset(A_icp, 0, sizeof(A_icp)); memset(b_icp, 0, sizeof(b_icp));
+            memset(A_rgbd, 0, sizeof(A_rgbd)); memset(b_rgbd, 0, sizeof(b_rgbd));
+            if (icp) {
+                float out29[29];
+                orc_icp_step_f32tree(Rcurr, tcurr, o->vmaps_curr[i], o->nmaps_curr[i], Rprev_inv, tprev, il, o->vmaps_g_prev[i],
+                                     o->nmaps_g_prev[i], o->distThres, o->angleThres, cols, rows, REF_ICP_THREADS, REF_ICP_BLOCKS, out29);
+                ref_unpack29(out29, A_icp, b_icp, residual);
+                if (i == 0 && j == iterations[i] - 1 && icp_err_surface) {   /* the optional output of the same launch (reduce.cu:303-331) */
+                    icp_ctx c;
+                    icp_ctx_fill(&c, Rcurr, tcurr, o->vmaps_curr[i], o->nmaps_curr[i], Rprev_inv, tprev, il, o->vmaps_g_prev[i], o->nmaps_g_prev[i],
+                                 o->distThres, o->angleThres, cols, rows);
+                    for (int y = 0; y < rows; y++)
+                        for (int x = 0; x < cols; x++) { float row[7], err; icp_row(&c, x, y, row, &err); icp_err_surface[y * cols + x] = err; }
+                }
+            }
+            st->last_icp_error = sqrtf(residual[0]) / residual[1];
+            st->last_icp_count = residual[1];
+            if (rgb) {
+                float out29[29];
+                orc_rgb_step_f32tree(o->corres[i], sigmaVal, o->cloud[i], il.fx, il.fy, o->dIdx[i], o->dIdy[i], o->sobelScale, cols, rows,
+                                     REF_RGB_THREADS, REF_RGB_BLOCKS, out29);
+                ref_unpack29(out29, A_rgbd, b_rgbd, 0);
+            }
+            double lastA[36], lastb[6], result[6];
+            if (icp && rgb) {
+                const double w = icpWeight;
+                for (int k = 0; k < 36; k++) lastA[k] = (double)A_rgbd[k] + (w * w) * (double)A_icp[k];
+                for (int k = 0; k < 6; k++) lastb[k] = (double)b_rgbd[k] + w * (double)b_icp[k];
+            } else if (icp) {
+                for (int k = 0; k < 36; k++) lastA[k] = A_icp[k];
+                for (int k = 0; k < 6; k++) lastb[k] = b_icp[k];
+            } else {
+                for (int k = 0; k < 36; k++) lastA[k] = A_rgbd[k];
+                for (int k = 0; k < 6; k++) lastb[k] = b_rgbd[k];
+            }
+            eig_ldlt_solve_d(6, lastA, lastb, result);
+            memcpy(st->lastA, lastA, sizeof(lastA)); memcpy(st->lastb, lastb, sizeof(lastb));
+
+            /* OdometryProvider::computeUpdateSE3 (OdometryProvider.h:69-89) */
+            double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rr[9], nrt[16];
+            const double rvec[3] = {result[3], result[4], result[5]};
+            ref_rodrigues(rvec, Rr);
+            for (int r = 0; r < 3; r++) { upd[r * 4 + 0] = Rr[r * 3 + 0]; upd[r * 4 + 1] = Rr[r * 3 + 1]; upd[r * 4 + 2] = Rr[r * 3 + 2]; upd[r * 4 + 3] = result[r]; }
+            orc_mul44d(upd, resultRt, nrt);
+            memcpy(resultRt, nrt, sizeof(nrt));
+            /* rgbOdom.setIdentity(); rgbOdom.rotate(rotation.cast<float>()): linear = Identity * R, a product like any other */
+            float Rf[9], Ro[9], to[3];
+            for (int r = 0; r < 3; r++) { Rf[r * 3 + 0] = (float)resultRt[r * 4 + 0]; Rf[r * 3 + 1] = (float)resultRt[r * 4 + 1]; Rf[r * 3 + 2] = (float)resultRt[r * 4 + 2]; to[r] = (float)resultRt[r * 4 + 3]; }
+            orc_mul33f(ident, Rf, Ro);
+            /* currentT.setIdentity(); currentT.rotate(Rprev); translation = tprev; currentT = currentT * rgbOdom.inverse() (RGBDOdometry.cpp:452-460) */
+            float Rp[9];
+            orc_mul33f(ident, Rprev, Rp);
+            const float Rinv[9] = {Ro[0], Ro[3], Ro[6], Ro[1], Ro[4], Ro[7], Ro[2], Ro[5], Ro[8]};
+            float tinv[3];
+            for (int r = 0; r < 3; r++) { float s = Rinv[r * 3 + 0] * to[0]; s = s + Rinv[r * 3 + 1] * to[1]; s = s + Rinv[r * 3 + 2] * to[2]; tinv[r] = -s; }
+            orc_mul33f(Rp, Rinv, Rcurr);
+            for (int r = 0; r < 3; r++) { float s = Rp[r * 3 + 0] * tinv[0]; s = s + Rp[r * 3 + 1] * tinv[1]; s = s + Rp[r * 3 + 2] * tinv[2]; tcurr[r] = s + tprev[r]; }
+        }
+    }
+    if (rgb) {
+        const float d[3] = {tcurr[0] - tprev[0], tcurr[1] - tprev[1], tcurr[2] - tprev[2]};
+        if ((double)sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) > 0.3) { memcpy(Rcurr, Rprev, 36); memcpy(tcurr, tprev, 12); }
+    }
+    if (opts->so3)
+        for (int i = 0; i < ORC_NUM_PYRS; i++) { uint8_t *t = o->lastNextImage[i]; o->lastNextImage[i] = o->nextImage[i]; o->nextImage[i] = t; }
+    memcpy(trans, tcurr, 12); memcpy(rot, Rcurr, 36);
+}
+
 /* RGBDOdometry::getIncrementalTransformation, RGBDOdometry.cpp:217-477 */
 void orc_odom_get_incremental_transformation(orc_odometry *o, float trans[3], float rot[9], const orc_track_opts *opts,
                                              float *icp_err_surface, orc_track_stats *st)
 {
+    if (g_icp_arith == ORC_ICP_ARITH_REFERENCE) { odom_track_reference_order(o, trans, rot, opts, icp_err_surface, st); return; }
     const int rgbOnly = opts->rgb_only;
     const float icpWeight = opts->icp_weight;
     const int icp = !rgbOnly && icpWeight > 0;

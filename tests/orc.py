@@ -250,8 +250,9 @@ def se3_to_host(sums, F=32):
 
 
 def set_icp_arith(mode):
-    """rounding specification of the ICP sums, process-global (oracle/orc.h): 0 / "product" (default) or 1 / "gram" """
-    lib.orc_set_icp_arith({"product": 0, "gram": 1}.get(mode, mode))
+    """rounding specification of the ICP sums, process-global (oracle/orc.h): 0 / "product" (default), 1 / "gram", or 2 / "reference" (the reference's own
+    f32 trees and host algebra order: every reduction of the tracker, not only the ICP sums)"""
+    lib.orc_set_icp_arith({"product": 0, "gram": 1, "reference": 2}.get(mode, mode))
 
 
 def get_icp_arith():
