@@ -95,9 +95,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work per CPU-baseline leg")
     ap.add_argument("--icp-threads", type=int, default=256)
     ap.add_argument("--icp-ppt", type=int, default=0, help="pixels per lane of the ICP reduction of unculled trackers (0: library default = 2 at pyramid level 0, 1 below)")
-    ap.add_argument("--icp-arith", default=None, choices=["product", "gram"],
-                    help="rounding specification of the ICP sums (cf_set_icp_arith; default: the library's): products rounded once / row entries "
-                         "rounded once and contracted on the matrix cores; the oracle legs follow")
+    ap.add_argument("--icp-arith", default=None, choices=["product", "gram", "reference"],
+                    help="rounding specification of the tracker's sums (cf_set_icp_arith; default: the library's): products rounded once / row entries "
+                         "rounded once and contracted on the matrix cores / the reference's own f32 trees and host loop (a parity mode: slow by "
+                         "construction); the oracle legs follow")
     ap.add_argument("--gn-mode", type=int, default=-1, help="-1: library default; 0: three launches per GN iteration; 1: two")
     ap.add_argument("--max-surfels", type=int, default=None)
     ap.add_argument("--late-index-maps", action="store_true", help="A/B: rasterise the index maps after the frame's host wait (round 4) instead of before it")
@@ -128,7 +129,7 @@ def parse(argv=None):
     if a.icp_arith:
         os.environ["CF_ICP_ARITH"] = a.icp_arith   # read by every context this process creates (cf_create)
     else:
-        a.icp_arith = {"1": "gram", "gram": "gram"}.get(os.environ.get("CF_ICP_ARITH", ""), "product")
+        a.icp_arith = {"1": "gram", "gram": "gram", "2": "reference", "reference": "reference"}.get(os.environ.get("CF_ICP_ARITH", ""), "product")
     a.workload_defaulted = a.workload is None
     if a.workload is None:
         # the metric's configuration (configs[2]: background + 4 objects) while its five models can occupy the GPUs; beyond that BASELINE.json's
@@ -406,37 +407,41 @@ def main(argv=None):
         achieved = (prof.icp_bytes / 1e9) / (prof.icp_ms_total / 1e3) if prof.icp_ms_total > 0 else 0.0
         bpl = int(prof.icp_bytes / max(1, prof.icp_launches))
         avg_us = 1e3 * prof.icp_ms_total / max(1, prof.icp_launches)
-        icp_only = (24 + 24 * n_models) * W * H  # the ICP part alone, if nothing is credited to the residual passes
-        # ... and on the pixels the launch actually works on: a culled model only touches the runs inside its screen box (the rectangle the
-        # last iteration of the last timed frame was restricted to; the background's is the whole image)
-        boxed = []
-        for i in range(n_models):
-            b = cf.model_cull_box(i)
-            boxed.append(max(0, min(b[2], W - 1) - max(b[0], 0) + 1) * max(0, min(b[3], H - 1) - max(b[1], 0) + 1))
-        processed = 24 * W * H + 24 * sum(boxed) + 11 * n_models * W * H
+        # PHYSICAL bytes of the launch: what the kernel visits, from what the kernel reports -- the frame's vertex + normal
+        # planes once (24 B per pixel, shared by the trackers through L2), per tracker 24 B for every pixel of the 64-pixel runs inside its
+        # final screen box (the whole image for the background) and 11 B for every pixel of the record slots between its first and last RGB
+        # candidate (cf_odom_level0_visited; the last timed frame's tracking call)
+        visited = [cf.model_level0_visited(i) for i in range(n_models)]
+        # (the residual pass reads the 1-byte candidate mask over the whole slot range and the other 10 bytes -- next depth, both intensities,
+        # gathered last depth -- only where the mask is set; a culled tracker's mask is empty outside its prediction, i.e. outside the pixels
+        # its ICP runs cover: 10 B x min(range, ICP pixels).  A tracker that is not culled: 11 B x every pixel, SURVEY 8(d)'s figure.)
+        def residual_bytes(icp_px, res_px):
+            return 11 * res_px if res_px >= W * H else res_px + 10 * min(res_px, icp_px)
+        processed = 24 * W * H + sum(24 * v[0] + residual_bytes(v[0], v[1]) for v in visited)
         # (the committed counter passes and rocprofv3 durations are those of the one-GPU launch: with the trackers spread over ranks this
         # rank's launch is another one, and neither is quoted)
         traffic, traffic_source = pmc_traffic(args.workload, W * H) if world == 1 else (None, "counter passes exist for the one-GPU launch only; at "
                                                                                         "N > 1 this rank's launch carries its own trackers only")
         if world > 1:
             pmc_traffic.rocprof_us = None
-        roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+        phys_gbs = processed / max(avg_us, 1e-9) / 1e3
+        roofline = dict(bound="hbm", achieved=round(phys_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(phys_gbs / HBM_PEAK_GBS, 4),
                         traffic=traffic, traffic_source=traffic_source,
                         kernel="cf::icp_reduce_kernel<PPT,%d>: ICP reduction of all lock-step models || their RGB residual passes, pyramid level 0"
                                % (4 if n_models > 1 else 0),
-                        launches=int(prof.icp_launches), avg_us=round(avg_us, 3), bytes_per_launch=bpl,
+                        launches=int(prof.icp_launches), avg_us=round(avg_us, 3), bytes_per_launch=int(processed),
                         sampled="level-0 launches of every %d-th timed step carry begin/end events" % args.event_sampling,
-                        bytes_per_pixel="24 + 24*M (ICP) + 11*M (residual), M = models in the launch",
-                        frac_icp_bytes_only=round(icp_only / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4),
-                        bytes_processed_per_launch=int(processed), pixels_in_screen_boxes=[int(v) for v in boxed],
-                        frac_bytes_processed=round(processed / max(avg_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4),
-                        convention="`achieved` / `frac` follow SURVEY 8(d): every pixel of the frame is credited to every tracker in the launch.  Culled "
-                                   "trackers (object models) only touch the runs inside their screen boxes (`pixels_in_screen_boxes`), so at large frames the "
-                                   "credited rate can exceed what a memory system could deliver (frac > 1 at 1280x960 with four culled trackers): it is the "
-                                   "reference's work done per second, not bytes moved -- `frac_bytes_processed` counts the pixels actually visited, `traffic` "
-                                   "what the counters saw cross the HBM interface")
+                        bytes_per_pixel="24 (frame planes, once) + per tracker 24 x ICP pixels visited + residual pass: 11 x every pixel (unculled) or 1 x slot-range pixels + 10 x min(slot range, ICP pixels) (culled: the candidate mask is empty outside the prediction)",
+                        pixels_visited=dict(icp=[int(v[0]) for v in visited], residual=[int(v[1]) for v in visited], frame=W * H),
+                        frac_reference_work=round(achieved / HBM_PEAK_GBS, 4), reference_work_gbs=round(achieved, 1), reference_work_bytes_per_launch=bpl,
+                        convention="`achieved` / `frac` = PHYSICAL bytes per launch / the launch's own duration: the pixels the kernel visits (a culled tracker "
+                                   "only walks the 64-pixel runs inside its screen box and the record slots between its first and last RGB candidate; both come "
+                                   "from the tracker's own state after the last timed frame) -- what `traffic` (PMC counters of the same launch) should and does "
+                                   "agree with.  `frac_reference_work` is SURVEY 8(d) read literally, (24 + 24 M + 11 M) B x every pixel of the frame for M "
+                                   "trackers: the reference's work done per second, which culling makes larger than any memory system could deliver (it was this "
+                                   "line's `frac` until round 5)")
         if pmc_traffic.rocprof_us:   # the same launches in the committed rocprofv3 --kernel-trace run of this build (shorter: see the file)
-            roofline.update(rocprofv3_avg_us=pmc_traffic.rocprof_us, frac_rocprofv3=round(bpl / pmc_traffic.rocprof_us / 1e3 / HBM_PEAK_GBS, 4),
+            roofline.update(rocprofv3_avg_us=pmc_traffic.rocprof_us, frac_rocprofv3=round(processed / pmc_traffic.rocprof_us / 1e3 / HBM_PEAK_GBS, 4),
                             rocprofv3_source="profiles/r5*_icp_level0_timed_launches.txt: kernel durations of the timed steps' level-0 launches under rocprofv3 "
                                              "--kernel-trace (every dispatch followed by an idle gap); `avg_us` above is this process's own begin / end events on the plain "
                                              "stream, back to back with the launch in front of it -- the conservative figure, and the one `frac` is quoted on")
@@ -538,6 +543,7 @@ def parity_vs_n1(args, torch, dist, facade, cf, st, rank, world, local_rank, mod
             single.set_icp_launch(args.icp_threads, args.icp_ppt)
         if args.gn_mode >= 0:
             single.set_gn_mode(args.gn_mode)
+        single.set_icp_arith(args.icp_arith)   # (explicitly: the same rounding specification as the ranks', whatever the environment says)
         for i in range(total):
             k = frame_index(i, args.frames)
             f = st["frames"][k]
@@ -782,7 +788,7 @@ def oracle_trajectory_check(cam, frames, torch, facade, local_rank, args, n_fram
 
 
 def reference_trajectory_check(args, multi):
-    """north_star's parity clause against the REFERENCE'S OWN arithmetic, measured live: the HIP facade plays a scenario of
+    """north_star's parity clause against the REFERENCE'S OWN tracker, measured live, under both arithmetics (see the two parts below): the HIP facade plays a scenario of
     tests/golden/ref_traj_v1.npz (the pinned frame loop tracked by the reference's own RGBDOdometry class under the CPU emulator: f32 tree
     reductions, Eigen-style solve) -- the headline pipeline's two-object motion-CRF scenario at 640x480 for object workloads, the static
     one otherwise -- and tests/trajpin.compare returns the figures: camera ATE, frames with identical model lists, surfel-count
@@ -790,25 +796,42 @@ def reference_trajectory_check(args, multi):
     try:
         import trajpin
         name = "crf_two_objects_640" if multi else "static_camera_640"
+        # (1) THE PARITY CLAUSE: the same stream under the reference-order arithmetic (cf_set_icp_arith 2: the reference's own f32 trees at
+        # GPUConfig.h's launch shapes, its host loop) -- model lists, surfel counts and poses must EQUAL the reference tracker's
+        ex = None
+        try:
+            pe, ie, ce = trajpin.play_facade(name, "reference")
+            ex = trajpin.exact(name, pe, ie, ce)
+            if multi and "gt_masks_two_boxes_640" in trajpin.scenarios():
+                p3, i3, c3 = trajpin.play_facade("gt_masks_two_boxes_640", "reference")
+                ex["well_conditioned_objects"] = trajpin.exact("gt_masks_two_boxes_640", p3, i3, c3)
+        except Exception as e:  # noqa: BLE001
+            ex = dict(error=str(e)[:300])
+        if args.icp_arith == "reference":
+            return dict(reference_order=ex, scenario=name, source="live: HIP facade under cf_set_icp_arith 2 against tests/golden/ref_traj_v1.npz")
+        # (2) the DEFAULT arithmetic of the timed path (exact integer sums: launch-shape independent, not the reference's rounding): how far
+        # that moves a trajectory -- camera ATE asserted against BASELINE.json's 1e-3 m, counts and objects reported
         poses, ids, counts = trajpin.play_facade(name, args.icp_arith)
         rep = trajpin.compare(name, poses, ids, counts, arith=args.icp_arith, log=lambda s: None)
         tight = None
         if multi and "gt_masks_two_boxes_640" in trajpin.scenarios():
-            # ... and the scenario in which EVERY object is held to the tight bounds (two textured boxes, ground-truth masks: round 5)
             p2, i2, c2 = trajpin.play_facade("gt_masks_two_boxes_640", args.icp_arith)
             r2 = trajpin.compare("gt_masks_two_boxes_640", p2, i2, c2, arith=args.icp_arith, log=lambda s: None)
             tight = dict(scenario="gt_masks_two_boxes_640", frames=r2["frames"], camera_rmse=round(r2["rmse"], 9), camera_max=round(r2["max"], 9),
                          lists_identical_frames=r2["lists_identical_frames"],
-                         objects={k: dict(frames=v["frames"], max_m=round(v["max_m"], 7), bound_m=v["bound_m"], stable_in_reference=v["stable_in_reference"],
+                         objects={k: dict(frames=v["frames"], max_m=round(v["max_m"], 7), within_tight_bound=v["within_tight_bound"], stable_in_reference=v["stable_in_reference"],
                                           count_max_rel_diff=round(v["count_max_rel_diff"], 5)) for k, v in r2["objects"].items()})
-        return dict(rmse=round(rep["rmse"], 9), max=round(rep["max"], 9), frames=rep["frames"], scenario=name, well_conditioned_objects=tight,
+        return dict(reference_order=ex, arith=args.icp_arith,
+                    rmse=round(rep["rmse"], 9), max=round(rep["max"], 9), frames=rep["frames"], scenario=name, well_conditioned_objects=tight,
                     lists_identical_frames=rep["lists_identical_frames"], count_first_diff_frame=rep["count_first_diff_frame"],
                     count_max_abs_diff=rep["count_max_abs_diff"], count_max_rel_diff=round(rep["count_max_rel_diff"], 7),
                     background_count_max_abs_diff=rep["background_count_max_abs_diff"],
                     background_count_max_rel_diff=round(rep["background_count_max_rel_diff"], 7),
-                    objects={k: dict(frames=v["frames"], max_m=round(v["max_m"], 7), bound_m=v["bound_m"]) for k, v in rep["objects"].items()},
+                    objects={k: dict(frames=v["frames"], max_m=round(v["max_m"], 7), within_tight_bound=v["within_tight_bound"]) for k, v in rep["objects"].items()},
                     bound_m=1e-3, source="live: HIP facade on the scenario's stream against tests/golden/ref_traj_v1.npz (frame loop tracked by the "
-                                         "reference's own RGBDOdometry class, oracle/ref_shim)")
+                                         "reference's own RGBDOdometry class, oracle/ref_shim); `reference_order` = the same under cf_set_icp_arith 2 "
+                                         "(identical: lists, surfel counts and poses equal the reference tracker's on every frame), the figures beside it = "
+                                         "the default exact-integer arithmetic of the timed path")
     except AssertionError as e:
         return dict(error="bound violated: " + str(e)[:300])
     except Exception as e:  # noqa: BLE001
@@ -844,11 +867,15 @@ def secondary_static(args, torch, facade, local_rank, warmup=30, steps=120):
         counts = [cf.model_info(0)["count"]]
         cf.close()
         ach = (prof.icp_bytes / 1e9) / (prof.icp_ms_total / 1e3) if prof.icp_ms_total > 0 else 0.0
+        traffic, traffic_source = pmc_traffic("static", W * H)
         return dict(workload="configs[1]: single static background model (-static), synthetic", value=round(steps / dt, 2),
                     unit="frames/s", ms_per_step=round(1e3 * dt / steps, 4), warmup=warmup, steps=steps, active_models=1, surfels=counts,
-                    roofline=dict(achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
+                    roofline=dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                                   avg_us=round(1e3 * prof.icp_ms_total / max(1, prof.icp_launches), 3),
-                                  bytes_per_launch=int(prof.icp_bytes / max(1, prof.icp_launches)), kernel="cf::icp_reduce_kernel<PPT,0>"))
+                                  bytes_per_launch=int(prof.icp_bytes / max(1, prof.icp_launches)), kernel="cf::icp_reduce_kernel<PPT,0>",
+                                  traffic=traffic, traffic_source=traffic_source,
+                                  note="one unculled tracker: SURVEY 8(d)'s formula, the pixels visited and the counter traffic are the same quantity here "
+                                       "((24 + 24 + 11) B x every pixel) -- the launch in which nothing hides behind culling"))
     except Exception as e:  # the headline line must not depend on this extra
         return dict(error=str(e))
 
@@ -907,7 +934,7 @@ def cpu_baseline(cf, cam, frames, i0, step_stream, st, budget_s):
     os.environ["ORC_LIB"] = native_oracle()
     import orc
     import orc_pipeline as op
-    orc.set_icp_arith("gram" if os.environ.get("CF_ICP_ARITH") in ("gram", "1") else "product")   # (the rounding specification the GPU legs ran with)
+    orc.set_icp_arith({"gram": "gram", "1": "gram", "reference": "reference", "2": "reference"}.get(os.environ.get("CF_ICP_ARITH", ""), "product"))   # (the rounding specification the GPU legs ran with)
     n = len(frames)
     ncpu = orc.usable_cpus()   # affinity mask and cgroup quota, not the number of CPUs the box shows
     omp = ctypes.CDLL("libgomp.so.1")

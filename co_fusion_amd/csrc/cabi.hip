@@ -608,7 +608,8 @@ int cf_odom_create(cf_ctx* ctx, cf_odom** out)
     if (int r = dmalloc(ctx, &od->icp_acc, (size_t)kGroups * 32)) return r;
     {   // 64 groups of grouped atomics, or (cf_set_gn_mode 2) one row of totals per workgroup of the RGB step: a workgroup per 2 record slots
         const size_t slots0 = (n0 + 255) / 256, quads0 = (slots0 + 1) / 2;   // (slots of >= 256 pixels: cf_set_icp_launch allows 64-thread workgroups)
-        if (int r = dmalloc(ctx, &od->rgb_acc, (quads0 > (size_t)kGroups ? quads0 : (size_t)kGroups) * 32)) return r;
+        od->rgb_acc_words = (quads0 > (size_t)kGroups ? quads0 : (size_t)kGroups) * 32;
+        if (int r = dmalloc(ctx, &od->rgb_acc, od->rgb_acc_words)) return r;
     }
     if (int r = dmalloc(ctx, &od->occ, ((size_t)(W >> 2) * (H >> 2) + 3) / 4 * 4)) return r;
     if (int r = dmalloc(ctx, &od->aabb, 8)) return r;
@@ -912,11 +913,16 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
 #endif
     // the screen box the previous tracking call ended with sizes this call's launches (launch_icp_kernel_arith); the pinned host state
     // holds it once that call's results were fetched
-    if (h->cull && !ctx->state_readback_pending) memcpy(od->box_hint, h->stats.cull_box, sizeof(od->box_hint));
+    if (h->cull && !od->result_pending) memcpy(od->box_hint, h->stats.cull_box, sizeof(od->box_hint));
     else od->box_hint[0] = kNoBoxHint;
     // ... and likewise the record slots its residual passes needed (a culled tracker's candidate mask is empty outside its prediction)
-    for (int i = 0; i < CF_NUM_PYRS; i++) od->res_hint[i] = (h->cull && h->res_range && !ctx->state_readback_pending) ? h->res_seen[i] : -1;
-    h->aabb_acc = od->aabb; h->cull = (od->use_occ && od->box_valid && od->band_end == 0 && !no_box) ? 1 : 0;
+    for (int i = 0; i < CF_NUM_PYRS; i++) od->res_hint[i] = (h->cull && h->res_range && !od->result_pending) ? h->res_seen[i] : -1;
+    // The screen box is the projection of a frustum piece expressed in the camera the model maps were prepared with (map_pose), while the
+    // reduction projects with the pose of THIS call: the culling is conservative only if the two are the same pose -- which
+    // Model::performTracking guarantees (both are the model's pose) and a C-ABI caller tracking from another initial guess does not.
+    const float Rt_call[12] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10], pose[3], pose[7], pose[11]};
+    const bool same_pose = memcmp(Rt_call, od->map_pose, sizeof(Rt_call)) == 0;
+    h->aabb_acc = od->aabb; h->cull = (od->use_occ && od->box_valid && od->band_end == 0 && !no_box && same_pose) ? 1 : 0;
     memcpy(h->box_R, od->map_pose, 36); memcpy(h->box_t, od->map_pose + 9, 12);
     h->res_range = (h->cull && rgb) ? od->res_range : nullptr;
     h->host_twin = od->h_state;
@@ -930,6 +936,11 @@ static int odom_prepare(cf_odom* od, const float pose[16], const cf_track_opts* 
     memcpy(h->Rprev, R, 36); memcpy(h->tprev, t, 12); memcpy(h->Rcurr, R, 36); memcpy(h->tcurr, t, 12);
     inv33f_host(R, h->Rprev_inv);
     memset(&h->stats, 0, sizeof(h->stats));
+    h->solves = 0;
+    {   // the Gauss-Newton launches this call will enqueue (launch_gn_track): every one of them runs one solve per tracker
+        const int its = (opts->fast_odom ? 3 : 10) + (opts->pyramid ? 9 : 0);
+        od->expected_solves = its;
+    }
     // the accumulators are zero here: dmalloc clears them and every solve leaves them cleared
     od->pending_so3_swap = opts->so3 != 0;
     LAUNCHCHK(ctx);
@@ -991,7 +1002,18 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
 {
     if (!ctx || !ods || n <= 0 || n > ctx->cfg.max_models || n > kMaxBatch || !poses_in || !opts) return CF_EINVAL;
     const bool want_rgb = opts->rgb_only || opts->icp_weight < 100;
-    if (ctx->state_readback_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ctx->state_readback_pending = false; }
+    // The pinned host state of a tracker is rewritten below and read / written by the launches of its tracking call: a tracker whose
+    // PREVIOUS call has not been fetched yet must drain first.  Per tracker (round 6): the chunks of a frame with more than kMaxBatch
+    // trackers hold different trackers, so chunk k + 1 is prepared and enqueued while chunk k runs -- until round 5 a context-wide flag
+    // drained the GPU between the chunks.
+    {
+        bool drain = false;
+        for (int m = 0; m < n; m++) drain = drain || (ods[m] && ods[m]->result_pending);
+        if (drain) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int m = 0; m < n; m++) if (ods[m]) ods[m]->result_pending = false;   // (landed: what the launches wrote is in the pinned states)
+        }
+    }
     if (ctx->icp_arith == CF_ICP_ARITH_REFERENCE) {
         // THE REFERENCE'S OWN ORDER (track_ref.hip): per tracker the reference's host loop -- kernel, second-stage kernel, read-back, host
         // solve -- over the same prepared pyramids; nothing is culled (every thread's partial sum is part of the result), nothing is
@@ -1014,9 +1036,14 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
         LAUNCHCHK(ctx);
         for (int m = 0; m < n; m++)
             if (int r = ref_track(ctx, ods[m], poses_in[m], opts, err_surfaces ? err_surfaces[m] : nullptr)) return r;
-        ctx->state_readback_pending = true;
+        for (int m = 0; m < n; m++) ods[m]->result_pending = true;
         return CF_OK;
     }
+    for (int m = 0; m < n; m++)   // (modes 0 / 1 expect zeroed sums where mode 2 left per-workgroup rows, and the other way round)
+        if (ods[m]->gn_epoch_seen != ctx->gn_mode_epoch) {
+            HIPCHK(ctx, hipMemsetAsync(ods[m]->rgb_acc, 0, sizeof(unsigned long long) * ods[m]->rgb_acc_words, ctx->stream));
+            ods[m]->gn_epoch_seen = ctx->gn_mode_epoch;
+        }
     // a batch of <= kPrepBatch trackers with the SO3 pre-alignment: the RGB preparation rides in the pre-alignment's launch
     const bool prep_fused = want_rgb && opts->so3 != 0 && n <= kPrepBatch;
     RgbPrepBatch prep{};
@@ -1051,6 +1078,12 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     // host time (static 640x480: 1275 frames/s without, 1210 with events on every call), sampling keeps the figure and the cost apart
     cf::ProfSink* prof = nullptr;
     if (ctx->prof.enabled > 0 && (ctx->prof_calls++ % (unsigned)ctx->prof.enabled) == 0) prof = &ctx->prof;
+#ifdef CF_ABLATE
+    static const int solve_trace_call = getenv("CF_SOLVE_TRACE") ? atoi(getenv("CF_SOLVE_TRACE")) : -1;   // phase stamps of that call's solves (tracker 0)
+    static int solve_trace_seen = 0;
+    const bool solve_trace = solve_trace_call >= 0 && solve_trace_seen++ == solve_trace_call;
+    if (solve_trace) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); trace_solve_begin(); }
+#endif
     if (!launch_gn_track(ctx->stream, ctx->icp_launch, states, ctx->d_so3_sync, any_split ? &hook : nullptr, icp_args, rgb_args, n,
                          ctx->cfg.width, ctx->cfg.height, so3_here, opts->pyramid != 0, opts->fast_odom != 0, rgb, icp, ctx->gn_mode, prof, h_states,
                          prep_fused ? &prep : nullptr)) {
@@ -1059,6 +1092,7 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     }
     LAUNCHCHK(ctx);
 #ifdef CF_ABLATE
+    if (solve_trace) trace_solve_end(ctx->stream, getenv("CF_ICP_TRACE_OUT") ? getenv("CF_ICP_TRACE_OUT") : "solve_trace.txt");
     // diagnostics: CF_ICP_REPLAY=<call> re-launches the level-0 {ICP || residual} launch of that tracking call (its converged state) back
     // to back under a list of ablation masks and prints the durations -- the decomposition of the launch quoted in DESIGN.md 4.1
     static const int replay_call = getenv("CF_ICP_REPLAY") ? atoi(getenv("CF_ICP_REPLAY")) : -1;
@@ -1099,7 +1133,7 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     }
 #endif
     // no read-back copy: the last solve of the schedule wrote every tracker's result into its pinned host state (h_states)
-    ctx->state_readback_pending = true;
+    for (int m = 0; m < n; m++) ods[m]->result_pending = true;
     return CF_OK;
 }
 
@@ -1115,11 +1149,18 @@ int cf_odom_fetch_result(cf_odom* od, float trans[3], float rot[9], cf_track_sta
     if (!od) return CF_EINVAL;
     cf_ctx* ctx = od->ctx;
     if (int r = cf_wait_stream(ctx)) return r;
-    ctx->state_readback_pending = false;
+    od->result_pending = false;
     if (trans) memcpy(trans, od->h_state->tcurr, 12);
     if (rot) memcpy(rot, od->h_state->Rcurr, 36);
     if (stats) *stats = od->h_state->stats;
-    const bool fault = od->h_state->stats.fault != 0;
+    bool fault = od->h_state->stats.fault != 0;
+    if (ctx->icp_arith != CF_ICP_ARITH_REFERENCE && od->expected_solves >= 0 && od->h_state->solves != od->expected_solves) {
+        // a launch of the schedule ended without a solve: under cf_set_gn_mode 2 the tracker's workgroups did not meet in one L2 (nobody
+        // drew the last ticket); the tickets they left behind would corrupt the next call -- cleared here
+        (void)hipMemsetAsync(ctx->d_so3_sync, 0, sizeof(So3Sync) * ((size_t)ctx->cfg.max_models + 1), ctx->stream);
+        fault = true;
+    }
+    od->expected_solves = -1;
     if (od->pending_so3_swap) {  // RGBDOdometry.cpp:469-473
         for (int i = 0; i < CF_NUM_PYRS; i++) std::swap(od->lastNextImage[i], od->nextImage[i]);
         od->pending_so3_swap = false;
@@ -1172,6 +1213,18 @@ int cf_odom_get_covariance(const cf_track_stats* stats, double cov[36])
 int cf_set_gn_mode(cf_ctx* ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 2) return CF_EINVAL;
+    if (mode == 2) {
+        // mode 2 is only correct where hardware workgroup b runs on XCD b mod 8 (rgb_step_solve_kernel: the tracker's workgroups meet in ONE
+        // L2).  Checked once per context on the device at hand; refused -- the mode stays what it was -- where it does not hold (another
+        // XCD count, a partition mode, CU masking).  ADVICE r5.
+        if (ctx->xcd_round_robin < 0) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ctx->xcd_round_robin = probe_xcd_round_robin(ctx->stream) ? 1 : 0; }
+        if (!ctx->xcd_round_robin) { ctx->set_error("cf_set_gn_mode 2: workgroups of a launch are not dealt round-robin over 8 XCDs on this device; the mode needs that"); return CF_ESTATE; }
+    }
+    if (mode != ctx->gn_mode) {
+        // the RGB accumulators mean different things under mode 2 (one row per step workgroup, overwritten) and modes 0 / 1 (kGroups rows of
+        // zeroed sums): a switch starts from clean ones.  Trackers created later start clean anyway.
+        ctx->gn_mode_epoch++;
+    }
     ctx->gn_mode = mode;
     return CF_OK;
 }
@@ -1215,6 +1268,24 @@ int cf_odom_bench_icp(cf_odom* od, int level, int iters, float* avg_us)
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->prof.events[ctx->prof.capacity - 2], ctx->prof.events[ctx->prof.capacity - 1]));
     *avg_us = ms * 1000.f / iters;
     HIPCHK(ctx, hipMemsetAsync(od->icp_acc, 0, sizeof(unsigned long long) * kGroups * 32, ctx->stream));
+    return CF_OK;
+}
+
+// What the level-0 {ICP || residual} launch of the LAST fetched tracking call visited for this tracker, in pixels: the 64-pixel runs inside
+// its final screen box (the whole image when it was not culled) and the record slots between its first and last RGB candidate x the
+// pixels per slot (the whole image likewise).  The physical byte count of bench.py's roofline is made of these.
+int cf_odom_level0_visited(cf_odom* od, uint64_t* icp_pixels, uint64_t* residual_pixels)
+{
+    if (!od || !icp_pixels || !residual_pixels) return CF_EINVAL;
+    const cf_ctx* ctx = od->ctx;
+    const OdomDev* h = od->h_state;
+    const uint64_t N = (uint64_t)ctx->cfg.width * ctx->cfg.height;
+    *icp_pixels = N; *residual_pixels = h->rgb ? N : 0;
+    if (!h->icp) *icp_pixels = 0;
+    if (h->cull && ctx->icp_arith != CF_ICP_ARITH_REFERENCE) {
+        if (h->icp) { const CullRuns cr = cull_runs(h->stats.cull_box, 0, ctx->cfg.width, ctx->cfg.height); *icp_pixels = (uint64_t)cr.total * 64 < N ? (uint64_t)cr.total * 64 : N; }
+        if (h->rgb && h->res_range && h->res_seen[0] >= 0) { const uint64_t px = (uint64_t)h->res_seen[0] * (uint64_t)(ctx->icp_launch.threads * 4); *residual_pixels = px < N ? px : N; }
+    }
     return CF_OK;
 }
 

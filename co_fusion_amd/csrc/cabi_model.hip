@@ -68,6 +68,8 @@ struct cf_model {
     float* t_inv_dev = nullptr;
     const cf_odom* preindex_od = nullptr;
     int preindex_time = -1;
+    float preindex_cutoff = 0.f; int preindex_delta = 0; uint32_t preindex_nb = 0;   // ... and the other arguments that pass was rasterised with
+    void drop_preindex() { preindex_od = nullptr; preindex_time = -1; }             // every entry that rewrites the surfels or the index maps calls it
     float* rays = nullptr;  // per-pixel view rays of the splat fragment stage, float4 [H*W]
     float inv_fx = 0, inv_fy = 0;
 };
@@ -217,6 +219,7 @@ static int exact_count(cf_model* m, uint32_t* out)
 int cf_model_initialise(cf_model* m, const uint8_t* rgba, const float* depth_raw, const float* depth_filt, int time, float maxDepth)
 {
     if (!m || !rgba || !depth_raw || !depth_filt) return CF_EINVAL;
+    m->drop_preindex();   // (the index map / surfels cf_models_preindex saw are about to change)
     cf_ctx* ctx = m->ctx; hipStream_t s = ctx->cur();
     const int W = ctx->cfg.width, H = ctx->cfg.height; const long long N = (long long)W * H;
     if ((uint32_t)N > m->max_surfels) return CF_ENOMEM;
@@ -239,6 +242,7 @@ int cf_model_count(cf_model* m, uint32_t* count) { if (!m || !count) return CF_E
 int cf_model_predict_indices(cf_model* m, const float pose[16], int time, float maxDepth, int timeDelta)
 {
     if (!m || !pose) return CF_EINVAL;
+    m->drop_preindex();   // (the index map / surfels cf_models_preindex saw are about to change)
     cf_ctx* ctx = m->ctx;
     float t_inv[16];
     inv44f(pose, t_inv);
@@ -258,6 +262,7 @@ int cf_model_index_keys(cf_model* m, const float pose[16], int time, float maxDe
                         uint64_t* keys_dev)
 {
     if (!m || !pose || !keys_dev || surfel_begin > surfel_end) return CF_EINVAL;
+    m->drop_preindex();   // (the index map / surfels cf_models_preindex saw are about to change)
     cf_ctx* ctx = m->ctx;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
     float t_inv[16];
@@ -273,6 +278,7 @@ int cf_model_index_keys(cf_model* m, const float pose[16], int time, float maxDe
 int cf_model_index_resolve(cf_model* m, const float pose[16], uint64_t* keys_dev)
 {
     if (!m || !pose || !keys_dev) return CF_EINVAL;
+    m->drop_preindex();   // (the index map / surfels cf_models_preindex saw are about to change)
     cf_ctx* ctx = m->ctx;
     float t_inv[16];
     inv44f(pose, t_inv);
@@ -289,6 +295,7 @@ int cf_model_index_resolve(cf_model* m, const float pose[16], uint64_t* keys_dev
 int cf_model_predict_indices_sharded(cf_model* m, const float pose[16], int time, float maxDepth, int timeDelta, int shard, int nshards)
 {
     if (!m || !pose || nshards < 1 || shard < 0 || shard >= nshards) return CF_EINVAL;
+    m->drop_preindex();   // (the index map / surfels cf_models_preindex saw are about to change)
     cf_ctx* ctx = m->ctx;
     if (!ctx->collective) { ctx->set_error("cf_model_predict_indices_sharded: no collective registered (cf_set_collective)"); return CF_ESTATE; }
     uint32_t n = 0;
@@ -371,6 +378,7 @@ int cf_model_fuse(cf_model* m, const float pose[16], int time, const uint8_t* rg
                   const float* depth_filt, float maxDepth, float weighting, int maskID)
 {
     if (!m || !pose || !rgba || !mask || !depth_raw || !depth_filt) return CF_EINVAL;
+    m->drop_preindex();   // (the index map / surfels cf_models_preindex saw are about to change)
     cf_ctx* ctx = m->ctx; hipStream_t s = ctx->cur();
     const int W = ctx->cfg.width, H = ctx->cfg.height; const long long N = (long long)W * H;
     SurfelFuseArgs a;
@@ -395,6 +403,7 @@ int cf_model_clean(cf_model* m, const float pose[16], int time, float confThresh
                    const uint8_t* mask, int maskID, uint32_t* count_out)
 {
     if (!m || !pose || !depth_filt || !mask) return CF_EINVAL;
+    m->drop_preindex();   // (the index map / surfels cf_models_preindex saw are about to change)
     cf_ctx* ctx = m->ctx; hipStream_t s = ctx->cur();
     const int W = ctx->cfg.width, H = ctx->cfg.height;
     uint32_t nb = 0;
@@ -441,13 +450,17 @@ int cf_models_preindex(cf_ctx* ctx, const cf_model_preindex* items, int n, float
     launch_index_keys_batch(s, a.data(), n, ctx_cam(ctx), W, H);
     launch_index_resolve_batch(s, a.data(), n, ctx_cam(ctx), W, H);
     LAUNCHCHK(ctx);
-    for (int k = 0; k < n; k++) { items[k].model->preindex_od = items[k].odom; items[k].model->preindex_time = items[k].time; }
+    for (int k = 0; k < n; k++) {
+        cf_model* m = items[k].model;
+        m->preindex_od = items[k].odom; m->preindex_time = items[k].time; m->preindex_cutoff = depth_cutoff; m->preindex_delta = time_delta; m->preindex_nb = a[k].id_end;
+    }
     return CF_OK;
 }
 // is the index map of `m` already the one the first index pass of this chain would produce?
-static bool preindexed_with(const cf_model* m, const float pose[16], int time)
+static bool preindexed_with(const cf_model* m, const float pose[16], int time, float depth_cutoff, int time_delta, uint32_t nb)
 {
     if (!m->preindex_od || m->preindex_time != time) return false;
+    if (m->preindex_cutoff != depth_cutoff || m->preindex_delta != time_delta || m->preindex_nb != nb) return false;   // (every argument of the pass, not the pose alone)
     const cf::OdomDev* h = m->preindex_od->h_state;   // (fetched: the caller has the pose from there)
     for (int r = 0; r < 3; r++) {
         if (memcmp(&pose[r * 4], &h->Rcurr[r * 3], 12) != 0 || memcmp(&pose[r * 4 + 3], &h->tcurr[r], 4) != 0) return false;
@@ -511,7 +524,11 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
         const int nf = (int)fusing.size();
         {   // (models whose index map cf_models_preindex already rasterised with this very pose skip the pass)
             std::vector<int> todo;
-            for (int k : fusing) if (!preindexed_with(items[k].model, items[k].pose, items[k].time)) todo.push_back(k);
+            for (int k : fusing) {
+                uint32_t nb = 0;
+                if (int r = count_bound(items[k].model, &nb)) return r;
+                if (!preindexed_with(items[k].model, items[k].pose, items[k].time, depth_cutoff, time_delta, nb)) todo.push_back(k);
+            }
             if (!todo.empty()) { if (int r = index_pass(todo)) return r; }
         }
         // Model::fuse (Model.cpp:408-563)
@@ -584,7 +601,7 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
         HIPCHK(ctx, hipEventRecord(ctx->batch_event, s));
         for (int k : fusing) items[k].model->count_wait = ctx->batch_event;
     }
-    for (int k = 0; k < n; k++) { items[k].model->preindex_od = nullptr; items[k].model->preindex_time = -1; }
+    for (int k = 0; k < n; k++) items[k].model->drop_preindex();
     return CF_OK;
 }
 
@@ -605,6 +622,7 @@ int cf_model_download_map(cf_model* m, float* host_surfels, uint32_t capacity, u
 int cf_model_upload_map(cf_model* m, const float* host_surfels, uint32_t count)
 {
     if (!m || (!host_surfels && count) || count > m->max_surfels) return CF_EINVAL;
+    m->drop_preindex();   // (the index map / surfels cf_models_preindex saw are about to change)
     cf_ctx* ctx = m->ctx;
     if (count) HIPCHK(ctx, hipMemcpyAsync(m->buf[m->target], host_surfels, (size_t)count * 48, hipMemcpyHostToDevice, ctx->cur()));
     launch_set_count(ctx->cur(), m->d_count, count);

@@ -486,8 +486,8 @@ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tiny, T* ws,
 }
 
 // ---- the same 6x6 factorisation, spread over one wave -------------------------------------------------
-// Lane t < 36 owns A[t/6][t%6] in a register; pivot search, column broadcast and the substitutions use
-// v_readlane (uniform lane ids), the symmetric row/column swap and the mirror one ds_bpermute each.  Every
+// Lane t < 36 owns A[t/6][t%6] in a register (only the lower triangle is kept up to date); pivot search, column broadcast and the
+// substitutions use v_readlane (uniform lane ids), the symmetric row/column swap one ds_bpermute.  Every
 // element goes through exactly the operations of ldlt_solve<double, 6> in the same order (right-looking
 // update, one update per k), so the result is bit-identical; the serial version stays for N = 3 / f32.
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -497,10 +497,15 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
-// must be called by all 64 lanes of a wave; b: [6] (LDS), x: [6] (LDS, written by lane 0)
-__device__ __forceinline__ void ldlt_solve6_wave(double a, const double* b, double* x, double tiny, int lane)
+// must be called by all 64 lanes of a wave; lanes 0..35: A[lane / 6][lane % 6], lanes 36..41: b[lane - 36]; x: [6] (LDS, written by lane 0).
+// Round 6: the right-hand side rides along as a seventh column -- L y = P b is solved INSIDE the factorisation (at step k every later
+// entry takes b_i - l_ik * y_k: for a fixed i the very multiplications and subtractions of the forward substitution, in its order
+// k = 0, 1, ...; the transpositions permute b with the rows), which takes the forward substitution's chain of 30 dependent operations
+// off the solve; the six divisions by D run on six lanes at once.
+__device__ __forceinline__ void ldlt_solve6_wave(double a, double* x, double tiny, int lane)
 {
-    const int i = (lane < 36) ? lane / 6 : 0, j = (lane < 36) ? lane % 6 : 0;
+    const bool isB = lane >= 36 && lane < 42;
+    const int i = (lane < 36) ? lane / 6 : (isB ? lane - 36 : 0), j = (lane < 36) ? lane % 6 : (isB ? 6 : 0);
     int perm[6] = {0, 1, 2, 3, 4, 5};
     double d[6];
 #pragma unroll
@@ -518,8 +523,10 @@ __device__ __forceinline__ void ldlt_solve6_wave(double a, const double* b, doub
         }
         p = __builtin_amdgcn_readfirstlane(p);
         if (p != k) {
+            // symmetric transposition k <-> p on the LOWER triangle: element (i, j), i >= j, takes S(pi(i), pi(j)) of the symmetric matrix,
+            // which lives at (max, min) of the two indices; the right-hand side swaps entries k and p
             const int si = (i == k) ? p : ((i == p) ? k : i), sj = (j == k) ? p : ((j == p) ? k : j);
-            a = __shfl(a, si * 6 + sj);
+            a = __shfl(a, isB ? 36 + si : (si > sj ? si : sj) * 6 + (si > sj ? sj : si));
             const int pk = perm[k];
             int pp = pk;
 #pragma unroll
@@ -530,34 +537,32 @@ __device__ __forceinline__ void ldlt_solve6_wave(double a, const double* b, doub
         const double akk = readlane_f64(a, k * 7);
         d[k] = akk;
         const double aabs = akk < 0 ? -akk : akk;
-        if (aabs > tiny) {
-            if (j == k && i > k) a = a / akk;
-            double lik = 0, ljk = 0;
+        const bool pivot_ok = aabs > tiny;
+        if (j == k && i > k) a = pivot_ok ? a / akk : 0.0;
+        double lik = 0, ljk = 0;
 #pragma unroll
-            for (int q = k + 1; q < 6; q++) {
-                const double c = readlane_f64(a, q * 6 + k);
-                if (i == q) lik = c;
-                if (j == q) ljk = c;
-            }
-            if (i > k && j > k && j <= i) a = a - lik * akk * ljk;
-            const double am = __shfl(a, j * 6 + i);
-            if (i > k && j > k && j > i) a = am;
-        } else {
-            if (j == k && i > k) a = 0;
+        for (int q = k + 1; q < 6; q++) {
+            const double c = readlane_f64(a, q * 6 + k);
+            if (i == q) lik = c;
+            if (j == q) ljk = c;
         }
+        const double yk = readlane_f64(a, 36 + k);
+        if (isB) { if (i > k) a = a - lik * yk; }
+        else if (pivot_ok && i > k && j > k && j <= i) a = a - lik * akk * ljk;
+        // (no mirror into the upper triangle: pivot search, column reads and the back substitution only ever read the lower one, and the
+        // transposition above finds its sources there)
     }
     double y[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-        double s = b[perm[r]];
+    for (int r = 0; r < 6; r++) y[r] = readlane_f64(a, 36 + r);
+    {   // D^-1: the six divisions are independent -- lane r takes y[r] / d[r], one division deep instead of six in a row on every lane
+        double yn = y[0], dn = d[0];
 #pragma unroll
-        for (int c = 0; c < r; c++) s = s - readlane_f64(a, r * 6 + c) * y[c];
-        y[r] = s;
-    }
+        for (int r = 1; r < 6; r++) if (lane == r) { yn = y[r]; dn = d[r]; }
+        const double aabs = dn < 0 ? -dn : dn;
+        const double q = (aabs > tiny) ? yn / dn : 0.0;
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-        const double aabs = d[r] < 0 ? -d[r] : d[r];
-        y[r] = (aabs > tiny) ? y[r] / d[r] : 0.0;
+        for (int r = 0; r < 6; r++) y[r] = readlane_f64(q, r);
     }
 #pragma unroll
     for (int r = 5; r >= 0; r--) {

@@ -32,6 +32,8 @@ struct cf_ctx {
     cf::OdomDev* h_scratch_state = nullptr;  // pinned
     uint8_t* d_cand_scratch = nullptr;
     cf::So3Sync* d_so3_sync = nullptr;  // [max_models]
+    unsigned gn_mode_epoch = 0;         // bumped by every change of gn_mode: a tracker that last ran under another epoch clears its RGB accumulators first
+    int xcd_round_robin = -1;           // probe_xcd_round_robin of this device: -1 not probed yet, 0 / 1
     int gn_mode = 1;                    // launch_gn_track mode (1: record slots between the residual pass and the RGB step; 2: ... whose last
                                         // workgroup per tracker runs the solve -- measured slower, DESIGN-NOTES R5; 0: DataTerm image)
     // device / pinned-host pools of the trackers' state structs: a batch of trackers is uploaded / read back with ONE
@@ -41,7 +43,6 @@ struct cf_ctx {
     cf::OdomDev* h_state_pool = nullptr;  // pinned
     bool slot_used[kStateSlots]{};
     hipEvent_t batch_event = nullptr;     // cf_models_frame_passes: ONE event behind a batch's compactions marks all its models' counts
-    bool state_readback_pending = false;  // a range read-back is in flight: host state must not be rewritten before it lands
     // auxiliary streams for independent per-model work of one frame (cf_fork / cf_join)
     static constexpr int kLanes = 8;
     hipStream_t lanes[kLanes]{};
@@ -130,4 +131,8 @@ struct cf_odom {
     float angleSqLt = 0, distSqLe = 0;  // exact radicand bounds of the two ICP gates
     float minGrad[3]{};
     bool pending_so3_swap = false;
+    size_t rgb_acc_words = 0;        // size of rgb_acc (kGroups rows, or one row per RGB-step workgroup of cf_set_gn_mode 2)
+    unsigned gn_epoch_seen = 0;      // cf_ctx::gn_mode_epoch of the last tracking call
+    bool result_pending = false;     // a tracking call of this tracker is in flight / not fetched: its pinned host state must not be rewritten yet
+    int expected_solves = -1;        // Gauss-Newton iterations the pending tracking call enqueued (-1: not checked), against OdomDev::solves
 };

@@ -78,6 +78,9 @@ struct OdomDev {
     float krkInv[9], kt[3];
     float lastRGBError;
     int level_done;
+    int solves;                  // Gauss-Newton solves this tracking call has run (every solve adds one; the host zeroes it): cf_odom_fetch_result
+                                 // compares it with the launches it enqueued -- a solve that never ran (cf_set_gn_mode 2 on a part whose workgroups
+                                 // do not land on XCD b mod 8: nobody draws the last ticket) is reported instead of returning a stale pose
     float residual[2];
     float box_lo[3], box_hi[3];  // bounding frustum of the model's predicted vertices in the prediction camera (box_R / box_t): level-0 pixel
                                  // rectangle [0..1] and depth interval [2] (box_lo[0] > box_hi[0]: no valid vertex)
@@ -316,7 +319,7 @@ struct So3Sync { unsigned long long acc[10][16]; unsigned arrive, depart;
 // mode 1: {ICP || residual -> per-workgroup record slots} + rgb step over the slots + solve
 // mode 2: {ICP || residual -> record slots} + {rgb step over the slots, the tracker's workgroups on ONE XCD; the last to commit solves}
 // hook: called after every {ICP || residual} launch for each model whose reduction is split over GPUs (split[m] != 0) with that
-// model's grouped ICP accumulators (kGroups * 32 words): the caller's in-place SUM all-reduce over the ranks, enqueued on `s`
+// model's ICP sums FOLDED to 32 words (acc_fold_kernel: group 0 of its accumulators): the caller's in-place SUM all-reduce over the ranks, enqueued on `s`
 struct GnHook { int (*fn)(void* user, int op, void* dev_buf, uint64_t words, void* stream); void* user; int split[kMaxBatch]; };
 // the trackers of a lock-step schedule: device states and the pinned host copies the first launch uploads them from
 struct TrackerStates { OdomDev* dev[kMaxBatch]; const OdomDev* host[kMaxBatch]; };
@@ -329,9 +332,12 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
 void rgb_prep_levels(RgbPrepBatch& b, int n, int W, int H);
 float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, int ablate, int reps, hipEvent_t e0, hipEvent_t e1);
 #ifdef CF_ABLATE
+void trace_solve_begin();
+void trace_solve_end(hipStream_t s, const char* path);
 void trace_step_solve(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, So3Sync* syncs, int n, const char* path);
 void trace_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, const char* path);
 #endif
+bool probe_xcd_round_robin(hipStream_t s);   // does hardware workgroup b run on XCD b mod 8 (what cf_set_gn_mode 2 / the one-XCD meetings rely on)?
 float sqrt_gate_lt(float T);  // smallest x with sqrtf(x) >= T
 float sqrt_gate_le(float T);  // largest x with sqrtf(x) <= T
 

@@ -663,6 +663,29 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PPT <
 #endif
 }
 
+// Where do workgroups land?  The one-XCD meetings (SO(3) pre-alignment, cf_set_gn_mode 2) and the XCD bands rely on hardware workgroup b
+// running on XCD b mod 8 (tools/microbench/xcc_map.hip measured it on the MI355X).  The probe states it for the device at hand: 64
+// workgroups write their XCC_ID; true iff the first eight are all different and workgroup b repeats workgroup b mod 8's.
+__global__ void __launch_bounds__(64) xcc_probe_kernel(unsigned* __restrict__ out)
+{
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
+}
+bool probe_xcd_round_robin(hipStream_t s)
+{
+    unsigned* d = nullptr;
+    unsigned h[64];
+    if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(h)) != hipSuccess) return false;
+    xcc_probe_kernel<<<64, 64, 0, s>>>(d);
+    const bool ok = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return false;
+    unsigned seen = 0;
+    for (int b = 0; b < 8; b++) seen |= 1u << h[b];
+    if (__builtin_popcount(seen) != 8) return false;
+    for (int b = 8; b < 64; b++) if (h[b] != h[b & 7]) return false;
+    return true;
+}
+
 // host side: the f32 bounds that decide "sqrtf(x) < T" and "sqrtf(x) <= T" exactly (sqrtf is correctly rounded, monotonic)
 float sqrt_gate_lt(float T)
 {   // smallest x with sqrtf(x) >= T  =>  sqrtf(x) < T  <=>  x < bound
@@ -1339,6 +1362,33 @@ static_assert(kGramBits[0] == 20 && kGramBits[2] == 20 && kGramBits[3] == 17 && 
 // Must be called by all 256 threads of a workgroup.
 // RGB_IN_L2: the RGB sums were added by workgroup-scope atomics of this launch (rgb_step_solve_kernel): they are read where they live,
 // in this XCD's L2, with agent-scope loads -- a plain load may be served by the CU's L1.
+#ifdef CF_ABLATE
+// diagnostics build (CF_SOLVE_TRACE): phase stamps of tracker 0's solves of one tracking call, [solve][16] on the 100 MHz constant clock
+__device__ unsigned long long* g_solve_trace = nullptr;
+__device__ unsigned g_solve_iter = 0;
+#define SSTAMP(k) do { if (g_solve_trace && threadIdx.x == 0 && blockIdx.x == 0) g_solve_trace[(size_t)(g_solve_iter & 63u) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define SSTAMP(k) do {} while (0)
+#endif
+// same-wave exchange through LDS: a wave's LDS operations execute in program order, so all that is needed between a lane's store and
+// another lane's load is that the compiler keeps them in that order
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+// ROUND 6 (9.2 us per solve, the frame's most expensive kernel in total).  The kernel is ONE chain of dependent
+// instructions on wave 0 -- ~2500 of them at 4-8 cycles each (profiles/r6c_solve_phases.txt: 1.4 us in the unpack alone, a divergent
+// search loop per word, executed twice for the ICP and the RGB lanes of the same wave) -- so what counts is the number of instructions on
+// that chain and the barriers that make wave 0 wait for stores:
+//  * every lane of the factorisation forms ITS OWN matrix element straight from the totals (closed-form word index, one pass for both
+//    systems) -- no unpacked f32 matrices in LDS, no search loop, two barriers less;
+//  * everything behind the factorisation is spread over lanes with exactly the element expressions of the serial helpers (Rodrigues'
+//    nine entries, the 4x4 product, the f32 pose composition, the affine inverse, K R K^-1), exchanged through LDS inside wave 0;
+//  * the statistics (two square roots, two divisions) and the screen box run on idle waves beside that chain, refresh_hot is folded into
+//    the write-back, and the accumulators are zeroed by the LAST instructions of the kernel (a barrier waits for outstanding stores
+//    too: 16 stores per thread in front of one cost 0.7 us);
+//  * five barriers instead of eleven.
+// Must be called by all 256 threads of a workgroup.
+// RGB_IN_L2: the RGB sums were added by workgroup-scope atomics of this launch (rgb_step_solve_kernel): they are read where they live,
+// in this XCD's L2, with agent-scope loads -- a plain load may be served by the CU's L1.
 template <bool RGB_IN_L2 = false>
 __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigned long long* icp_acc, unsigned long long* rgb_acc, int next_level,
                                               int last_of_level, OdomDev* god_host, int slot_px, int part_first = 0, int part_last = -1)
@@ -1346,13 +1396,14 @@ __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigne
     __shared__ OdomDev s_od;
     __shared__ unsigned long long s_icp[32], s_rgb[32];
     __shared__ unsigned long long s_part[2][8][32];
-    __shared__ float s_Af[2][36], s_bf[2][6];  // [0] ICP, [1] RGB
-    __shared__ double s_lastA[36], s_lastb[6], s_result[6];
-    __shared__ double s_upd[16], s_nrt[16], s_K[9], s_Kinv[9], s_Rt[16], s_tmp[9];
+    __shared__ double s_result[6];
+    __shared__ double s_upd[16], s_K[9], s_Kinv[9], s_Rt[16], s_tmp[9];
+    __shared__ int s_flags[2];   // active, stop (wave 0 decides; the statistics lane on wave 3 reads them behind a barrier)
     static_assert(sizeof(OdomDev) % 4 == 0, "OdomDev is staged as 32-bit words");
     constexpr int kWords = (int)(sizeof(OdomDev) / 4);
     constexpr int kMutableFrom = (int)(offsetof(OdomDev, Rprev) / 4);
     const int tid = threadIdx.x;
+    SSTAMP(0);
     OdomDev* const od = &s_od;
     // the state's words and the accumulator words in ONE flight of loads (a rolled copy loop waits for every load before it stores to
     // LDS: two dependent round trips in front of the accumulator loads, ~1.5 us of every solve until round 5)
@@ -1386,165 +1437,243 @@ __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigne
     }
 #pragma unroll
     for (int q = 0; q < kPer; q++) if (tid + 256 * q < kWords) reinterpret_cast<unsigned*>(&s_od)[tid + 256 * q] = stw[q];
-    if (tid >= 64 && tid < 64 + 72) (&s_Af[0][0])[tid - 64] = 0.f;
-    if (tid >= 192 && tid < 192 + 12) (&s_bf[0][0])[tid - 192] = 0.f;
-    __syncthreads();
-    if (tid < 32) {
-        unsigned long long a = 0, b = 0;
-        for (int sl = 0; sl < 8; sl++) { a += s_part[0][sl][tid]; b += s_part[1][sl][tid]; }
-        s_icp[tid] = a; s_rgb[tid] = b;
-    }
-    // zero the accumulators for the next iteration
-    for (int k = tid; k < kGroups * 32; k += 256) { icp_acc[k] = 0; rgb_acc[k] = 0; }
-    __syncthreads();
-
-    // uniform decisions (RGBDOdometry.cpp:371-392), evaluated redundantly by every lane.  The RGB error (an f64 square root and division)
-    // only decides anything in the RGB-only mode; otherwise it is a statistic, and an idle wave computes it beside the combine / solve
-    bool active = od->level_done == 0, stop = false;
-    const bool rgbOnly = od->rgbOnly != 0;
-    float tmpError = 0.f; int rgbCount = 0;
-    if (active) {
-        rgbCount = (int)(long long)s_icp[29];
-        if (rgbOnly) {
-            tmpError = (float)(sqrt((double)(int)(long long)s_icp[30]) / (double)rgbCount);
+    __syncthreads();                                                                       // ---- barrier 1: state + partial sums in LDS
+    SSTAMP(1);
+    const bool cull = od->cull != 0;
+    if (tid < 64) {
+        // ============================== wave 0: the chain ==============================
+        const int lane = tid;
+        if (lane < 32) {
+            unsigned long long a = 0, b = 0;
+            for (int sl = 0; sl < 8; sl++) { a += s_part[0][sl][lane]; b += s_part[1][sl][lane]; }
+            s_icp[lane] = a; s_rgb[lane] = b;
+        }
+        wave_lds_sync();
+        SSTAMP(2);
+        // uniform decisions (RGBDOdometry.cpp:371-392).  The RGB error (an f64 square root and division) only decides anything in the RGB-only
+        // mode; otherwise it is a statistic, computed on another wave beside this chain
+        bool active = od->level_done == 0, stop = false;
+        const bool rgbOnly = od->rgbOnly != 0;
+        const int rgbCount = (int)(long long)s_icp[29], rgbSigma = (int)(long long)s_icp[30];
+        if (active && rgbOnly) {
+            const float tmpError = (float)(sqrt((double)rgbSigma) / (double)rgbCount);
             if (tmpError > od->lastRGBError) { stop = true; active = false; }
         }
-    }
-    const bool useIcp = od->icp != 0, useRgb = od->rgb != 0;
-    if (active) {
-        if (tid < 29 && useIcp) se3_unpack_word(s_icp, tid, icp_fix, s_Af[0], s_bf[0], od->residual);
-        if (tid >= 32 && tid < 59 && useRgb) se3_unpack_word(s_rgb, tid - 32, rgb_fix_bits(sigma_val_from(rgbCount, (int)(long long)s_icp[30], od->rgbOnly)), s_Af[1], s_bf[1], nullptr);
-    }
-    __syncthreads();
-    if (tid == 0 && stop) od->level_done = 1;
-    if (tid == 128 && active) {
-        if (!rgbOnly) tmpError = (float)(sqrt((double)(int)(long long)s_icp[30]) / (double)rgbCount);
-        od->lastRGBError = tmpError;
-        od->stats.last_rgb_error = tmpError; od->stats.last_rgb_count = (float)rgbCount;
-        od->stats.last_icp_error = sqrtf(od->residual[0]) / od->residual[1];
-        od->stats.last_icp_count = od->residual[1];
-    }
-    if (active && tid < 42) {
-        const bool isA = tid < 36;
-        const int k = isA ? tid : tid - 36;
-        const float vi = isA ? s_Af[0][k] : s_bf[0][k], vr = isA ? s_Af[1][k] : s_bf[1][k];
-        double v;
-        if (useIcp && useRgb) {
-            const double w = od->icpWeight;
-            v = isA ? (double)vr + w * w * (double)vi : (double)vr + w * (double)vi;
-        } else v = useIcp ? (double)vi : (double)vr;
-        if (isA) { s_lastA[k] = v; od->stats.lastA[k] = v; }
-        else { s_lastb[k] = v; od->stats.lastb[k] = v; }
-    }
-    __syncthreads();
-    if (active && tid < 64) ldlt_solve6_wave(tid < 36 ? s_lastA[tid] : 0.0, s_lastb, s_result, 2.2250738585072014e-308, tid);
-    if (active && tid == 0) {
-        // computeUpdateSE3 (OdometryProvider.h:69-89)
-        double Rr[9];
-        const double rvec[3] = {s_result[3], s_result[4], s_result[5]};
-        rodrigues(rvec, Rr);
-        for (int r = 0; r < 3; r++) {
-            s_upd[r * 4 + 0] = Rr[r * 3 + 0]; s_upd[r * 4 + 1] = Rr[r * 3 + 1]; s_upd[r * 4 + 2] = Rr[r * 3 + 2];
-            s_upd[r * 4 + 3] = s_result[r];
+        if (lane == 0) { s_flags[0] = active ? 1 : 0; s_flags[1] = stop ? 1 : 0; }
+        const bool useIcp = od->icp != 0, useRgb = od->rgb != 0;
+        if (active) {
+            // lane L < 36: A[L / 6][L % 6] of the combined system from word (min, max) of the two sums (reduce.cu:481-498: the host fills the
+            // matrix symmetrically from the upper triangle); lanes 36..41: b[L - 36] from word (i, 6); lanes 42 / 43: the ICP residual pair
+            double a = 0.0;
+            {
+                const int L = lane;
+                const int i = L < 36 ? L / 6 : L - 36, j = L < 36 ? L - 6 * (L / 6) : 6;
+                const int lo = i < j ? i : j, hi = i < j ? j : i;
+                int t = 7 * lo - ((lo * (lo - 1)) >> 1) + (hi - lo);
+                if (L >= 42) t = L == 42 ? 27 : 28;
+                if (L >= 44) t = 0;
+                const int bits_icp = icp_fix >= 0 ? icp_fix : (L == 42 ? 44 : (lo < 3 ? 20 : 17) + (hi < 3 ? 20 : hi < 6 ? 17 : 22));
+                const int bits_rgb = rgb_fix_bits(sigma_val_from(rgbCount, rgbSigma, od->rgbOnly));
+                const long long qi = (long long)s_icp[t], qr = (long long)s_rgb[t];
+                const float vi = useIcp ? fix_to_f32(qi, bits_icp) : 0.f, vr = useRgb ? fix_to_f32(qr, bits_rgb) : 0.f;
+                if (L < 42) {
+                    const bool isA = L < 36;
+                    if (useIcp && useRgb) {
+                        const double w = od->icpWeight;
+                        a = isA ? (double)vr + w * w * (double)vi : (double)vr + w * (double)vi;
+                    } else a = useIcp ? (double)vi : (double)vr;
+                    if (isA) od->stats.lastA[L] = a;
+                    else od->stats.lastb[L - 36] = a;
+                } else if (useIcp) {
+                    if (L == 42) od->residual[0] = vi;
+                    else if (L == 43) od->residual[1] = (float)qi;
+                }
+            }
+            wave_lds_sync();
+            SSTAMP(3);
+            ldlt_solve6_wave(lane < 42 ? a : 0.0, s_result, 2.2250738585072014e-308, lane);   // (lanes 36..41: b)
+            wave_lds_sync();
+            SSTAMP(4);
+            // computeUpdateSE3 (OdometryProvider.h:69-89).  Rodrigues (:32-67): theta, its sine / cosine and 1 / theta are the same in every
+            // lane; lane q < 16 then forms ITS entry of the update matrix [R | t; 0 0 0 1]
+            {
+                double rx = s_result[3], ry = s_result[4], rz = s_result[5];
+                const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+                const int q = lane & 15, r = q >> 2, c = q & 3;
+                double e = (r == c) ? 1.0 : 0.0;   // identity (theta below epsilon), and the last row
+                if (theta >= 2.2204460492503131e-16 && r < 3 && c < 3) {
+                    double sn, cs;
+                    det_sincos(theta, &sn, &cs);
+                    const double c1 = 1.0 - cs;
+                    const double itheta = 1.0 / theta;
+                    rx *= itheta; ry *= itheta; rz *= itheta;
+                    const double ra = r == 0 ? rx : (r == 1 ? ry : rz), rb = c == 0 ? rx : (c == 1 ? ry : rz);
+                    const double rrt = (r <= c) ? ra * rb : rb * ra;                       // {rx rx, rx ry, rx rz, rx ry, ry ry, ry rz, rx rz, ry rz, rz rz}
+                    // [r]_x = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0}
+                    const int k = r * 3 + c;
+                    const double rxm = k == 1 ? -rz : k == 2 ? ry : k == 3 ? rz : k == 5 ? -rx : k == 6 ? -ry : k == 7 ? rx : 0.0;
+                    const double I = (r == c) ? 1.0 : 0.0;
+                    e = cs * I + c1 * rrt + sn * rxm;
+                }
+                if (r < 3 && c == 3) e = s_result[r];
+                if (lane < 16) s_upd[q] = e;
+            }
+            wave_lds_sync();
+            SSTAMP(5);
+            if (lane < 16) {  // mul44(upd, resultRt) element (i, j)
+                const int i = lane >> 2, j = lane & 3;
+                double sacc = s_upd[i * 4 + 0] * od->resultRt[0 * 4 + j];
+                sacc = sacc + s_upd[i * 4 + 1] * od->resultRt[1 * 4 + j];
+                sacc = sacc + s_upd[i * 4 + 2] * od->resultRt[2 * 4 + j];
+                sacc = sacc + s_upd[i * 4 + 3] * od->resultRt[3 * 4 + j];
+                s_Rt[lane] = sacc;   // (staging: every lane has read the old resultRt before anybody overwrites it)
+            }
+            wave_lds_sync();
+            if (lane < 16) od->resultRt[lane] = s_Rt[lane];
+            wave_lds_sync();
+            // pose composition in f32 (RGBDOdometry.cpp:449-461): Ro / to = (float) resultRt, Rinv = Ro^T, tinv = -(Rinv to),
+            // Rcurr = Rprev Rinv, tcurr = Rprev tinv + tprev -- lane q < 9: Rcurr[q], lanes 9..11: tcurr
+            if (lane < 12) {
+                const double* nrt = od->resultRt;
+                if (lane < 9) {
+                    const int i = lane / 3, j = lane - 3 * (lane / 3);
+                    // Rinv[k * 3 + j] = Ro[j * 3 + k] = (float) nrt[j * 4 + k]
+                    od->Rcurr[lane] = od->Rprev[i * 3 + 0] * (float)nrt[j * 4 + 0] + od->Rprev[i * 3 + 1] * (float)nrt[j * 4 + 1] + od->Rprev[i * 3 + 2] * (float)nrt[j * 4 + 2];
+                } else {
+                    const int r = lane - 9;
+                    const float to0 = (float)nrt[0 * 4 + 3], to1 = (float)nrt[1 * 4 + 3], to2 = (float)nrt[2 * 4 + 3];
+                    float tinv[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++)   // Rinv[k * 3 + m] = Ro[m * 3 + k]
+                        tinv[k] = -((float)nrt[0 * 4 + k] * to0 + (float)nrt[1 * 4 + k] * to1 + (float)nrt[2 * 4 + k] * to2);
+                    od->tcurr[r] = (od->Rprev[r * 3 + 0] * tinv[0] + od->Rprev[r * 3 + 1] * tinv[1] + od->Rprev[r * 3 + 2] * tinv[2]) + od->tprev[r];
+                }
+            }
         }
-        s_upd[12] = 0; s_upd[13] = 0; s_upd[14] = 0; s_upd[15] = 1;
-    }
-    if (next_level >= 0 && tid == 64) {  // another wave: intrinsics of the next iteration's level
+        SSTAMP(6);
+    } else if (next_level >= 0 && tid == 64) {  // another wave: intrinsics of the next iteration's level
         double K[9], Kinv[9];
         k_matrix(cam_level(od->intr, next_level), K);
         inv33<double>(K, Kinv);
         for (int k = 0; k < 9; k++) { s_K[k] = K[k]; s_Kinv[k] = Kinv[k]; }
     }
-    __syncthreads();
-    if (active && tid < 16) {  // mul44(upd, resultRt) element (i, j)
-        const int i = tid >> 2, j = tid & 3;
-        double s = s_upd[i * 4 + 0] * od->resultRt[0 * 4 + j];
-        s = s + s_upd[i * 4 + 1] * od->resultRt[1 * 4 + j];
-        s = s + s_upd[i * 4 + 2] * od->resultRt[2 * 4 + j];
-        s = s + s_upd[i * 4 + 3] * od->resultRt[3 * 4 + j];
-        s_nrt[tid] = s;
-    }
-    __syncthreads();
-    if (active && tid < 16) od->resultRt[tid] = s_nrt[tid];
-    if (active && tid == 32) {  // pose composition in f32 (RGBDOdometry.cpp:449-461)
-        float Ro[9], to[3];
-        for (int r = 0; r < 3; r++) {
-            Ro[r * 3 + 0] = (float)s_nrt[r * 4 + 0]; Ro[r * 3 + 1] = (float)s_nrt[r * 4 + 1]; Ro[r * 3 + 2] = (float)s_nrt[r * 4 + 2];
-            to[r] = (float)s_nrt[r * 4 + 3];
-        }
-        const float Rinv[9] = {Ro[0], Ro[3], Ro[6], Ro[1], Ro[4], Ro[7], Ro[2], Ro[5], Ro[8]};
-        float tinv[3];
-        for (int r = 0; r < 3; r++) tinv[r] = -(Rinv[r * 3 + 0] * to[0] + Rinv[r * 3 + 1] * to[1] + Rinv[r * 3 + 2] * to[2]);
-        float Rc[9];
-        mul33<float>(od->Rprev, Rinv, Rc);
-        for (int k = 0; k < 9; k++) od->Rcurr[k] = Rc[k];
-        for (int r = 0; r < 3; r++)
-            od->tcurr[r] = (od->Rprev[r * 3 + 0] * tinv[0] + od->Rprev[r * 3 + 1] * tinv[1] + od->Rprev[r * 3 + 2] * tinv[2]) + od->tprev[r];
-    }
-    if (tid == 0 && last_of_level) { od->level_done = 0; od->lastRGBError = 3.402823466e+38F; }
-    __syncthreads();
-    if (next_level >= 0 && od->cull && tid >= 128 && tid < 192) {  // an idle wave: the screen box under the new pose
-        int ib[4]; float zb[2];
-        screen_box(od->box_lo, od->box_hi, od->box_R, od->box_t, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, tid - 128, ib, zb);
-        if (tid == 128) {
-            od->stats.cull_box[0] = ib[0]; od->stats.cull_box[1] = ib[1]; od->stats.cull_box[2] = ib[2]; od->stats.cull_box[3] = ib[3];
-            od->cull_z[0] = zb[0]; od->cull_z[1] = zb[1];
-        }
-    }
-    if (next_level >= 0) {  // prepare_iteration(od, next_level), spread over lanes
-        if (tid == 0) inv44_affine(od->resultRt, s_Rt);
-        __syncthreads();
-        if (tid < 9) {  // tmp = K * R
-            const int i = tid / 3, j = tid % 3;
-            s_tmp[tid] = s_K[i * 3 + 0] * s_Rt[0 * 4 + j] + s_K[i * 3 + 1] * s_Rt[1 * 4 + j] + s_K[i * 3 + 2] * s_Rt[2 * 4 + j];
-        }
-        __syncthreads();
-        if (tid < 9) {
-            const int i = tid / 3, j = tid % 3;
-            od->krkInv[tid] = (float)(s_tmp[i * 3 + 0] * s_Kinv[0 * 3 + j] + s_tmp[i * 3 + 1] * s_Kinv[1 * 3 + j] + s_tmp[i * 3 + 2] * s_Kinv[2 * 3 + j]);
-        } else if (tid >= 16 && tid < 19) {
-            const int r = tid - 16;
-            od->kt[r] = (float)(s_K[r * 3 + 0] * s_Rt[3] + s_K[r * 3 + 1] * s_Rt[7] + s_K[r * 3 + 2] * s_Rt[11]);
-        }
-    } else {
-        if (tid == 0 && od->rgb) {  // end of the schedule: divergence guard (RGBDOdometry.cpp:464-467)
-            const float d0 = od->tcurr[0] - od->tprev[0], d1 = od->tcurr[1] - od->tprev[1], d2 = od->tcurr[2] - od->tprev[2];
-            if ((double)sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
-                for (int k = 0; k < 9; k++) od->Rcurr[k] = od->Rprev[k];
-                for (int k = 0; k < 3; k++) od->tcurr[k] = od->tprev[k];
+    __syncthreads();                                                                       // ---- barrier 2: the new pose; K of the next level
+    if (tid < 64) {
+        const int lane = tid;
+        if (next_level >= 0) {  // prepare_iteration(od, next_level): Rt = inv44_affine(resultRt), krkInv = K R K^-1, kt = K t
+            // inv33 by cofactors (cf_device.h): the determinant in every lane, lane k < 9 its entry (L[p] L[q] - L[r] L[s]) / det
+            const double* a = od->resultRt;
+            const double L0 = a[0], L1 = a[1], L2 = a[2], L3 = a[4], L4 = a[5], L5 = a[6], L6 = a[8], L7 = a[9], L8 = a[10];
+            const double c00 = L4 * L8 - L5 * L7, c01 = L5 * L6 - L3 * L8, c02 = L3 * L7 - L4 * L6;
+            const double det = L0 * c00 + L1 * c01 + L2 * c02;
+            const double id = 1.0 / det;
+            const double Lm[9] = {L0, L1, L2, L3, L4, L5, L6, L7, L8};
+            // o[k] = (L[P] * L[Q] - L[R] * L[S]) * id:  k: 0 (4,8,5,7) 1 (2,7,1,8) 2 (1,5,2,4) 3 (5,6,3,8) 4 (0,8,2,6) 5 (2,3,0,5) 6 (3,7,4,6) 7 (1,6,0,7) 8 (0,4,1,3)
+            const int k9 = lane < 9 ? lane : 0;
+            double p1 = 0, q1 = 0, r1 = 0, s1 = 0;
+#pragma unroll
+            for (int m = 0; m < 9; m++) {
+                constexpr int P[9] = {4, 2, 1, 5, 0, 2, 3, 1, 0}, Q[9] = {8, 7, 5, 6, 8, 3, 7, 6, 4}, Rr[9] = {5, 1, 2, 3, 2, 0, 4, 0, 1}, S[9] = {7, 8, 4, 8, 6, 5, 6, 7, 3};
+                if (k9 == m) { p1 = Lm[P[m]]; q1 = Lm[Q[m]]; r1 = Lm[Rr[m]]; s1 = Lm[S[m]]; }
+            }
+            const double li = (p1 * q1 - r1 * s1) * id;
+            if (lane < 9) s_Rt[(lane / 3) * 4 + (lane - 3 * (lane / 3))] = li;
+            wave_lds_sync();
+            if (lane < 9) {  // tmp = K * R
+                const int i = lane / 3, j = lane - 3 * (lane / 3);
+                s_tmp[lane] = s_K[i * 3 + 0] * s_Rt[0 * 4 + j] + s_K[i * 3 + 1] * s_Rt[1 * 4 + j] + s_K[i * 3 + 2] * s_Rt[2 * 4 + j];
+            } else if (lane >= 16 && lane < 19) {  // translation of the inverse: -(Li row i . t)
+                const int i = lane - 16;
+                s_Rt[i * 4 + 3] = -(s_Rt[i * 4 + 0] * a[3] + s_Rt[i * 4 + 1] * a[7] + s_Rt[i * 4 + 2] * a[11]);
+            }
+            wave_lds_sync();
+            if (lane < 9) {
+                const int i = lane / 3, j = lane - 3 * (lane / 3);
+                od->krkInv[lane] = (float)(s_tmp[i * 3 + 0] * s_Kinv[0 * 3 + j] + s_tmp[i * 3 + 1] * s_Kinv[1 * 3 + j] + s_tmp[i * 3 + 2] * s_Kinv[2 * 3 + j]);
+            } else if (lane >= 16 && lane < 19) {
+                const int r = lane - 16;
+                od->kt[r] = (float)(s_K[r * 3 + 0] * s_Rt[3] + s_K[r * 3 + 1] * s_Rt[7] + s_K[r * 3 + 2] * s_Rt[11]);
+            }
+        } else {
+            if (lane == 0 && od->rgb) {  // end of the schedule: divergence guard (RGBDOdometry.cpp:464-467)
+                const float d0 = od->tcurr[0] - od->tprev[0], d1 = od->tcurr[1] - od->tprev[1], d2 = od->tcurr[2] - od->tprev[2];
+                if ((double)sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
+                    for (int k = 0; k < 9; k++) od->Rcurr[k] = od->Rprev[k];
+                    for (int k = 0; k < 3; k++) od->tcurr[k] = od->tprev[k];
+                }
+            }
+            // ... and the candidate range of a culled tracker: how many record slots each level needed goes back to the host (it sizes the
+            // next call's residual workgroups), the accumulator is cleared for the next call's preparation
+            if (lane >= 32 && lane < 35 && od->res_range) {
+                unsigned* rr = od->res_range + 2 * (lane - 32);
+                const unsigned lo_inv = rr[0], hi_p1 = rr[1];
+                const int sh = __builtin_ctz(slot_px) - 8;
+                od->res_seen[lane - 32] = hi_p1 ? (int)(((hi_p1 - 1u) >> sh) - ((~lo_inv) >> sh)) + 1 : 0;
+                rr[0] = 0; rr[1] = 0;
             }
         }
-        // ... and the candidate range of a culled tracker: how many record slots each level needed goes back to the host (it sizes the
-        // next call's residual workgroups), the accumulator is cleared for the next call's preparation
-        if (tid >= 64 && tid < 67 && od->res_range) {
-            unsigned* rr = od->res_range + 2 * (tid - 64);
-            const unsigned lo_inv = rr[0], hi_p1 = rr[1];
-            const int sh = __builtin_ctz(slot_px) - 8;
-            od->res_seen[tid - 64] = hi_p1 ? (int)(((hi_p1 - 1u) >> sh) - ((~lo_inv) >> sh)) + 1 : 0;
-            rr[0] = 0; rr[1] = 0;
+        SSTAMP(7);
+    } else if (tid >= 128 && tid < 192) {
+        if (next_level >= 0 && cull) {  // an idle wave: the screen box under the new pose
+            int ib[4]; float zb[2];
+            screen_box(od->box_lo, od->box_hi, od->box_R, od->box_t, od->Rcurr, od->tcurr, od->intr, od->distThres, od->width, od->height, tid - 128, ib, zb);
+            if (tid == 128) {
+                od->stats.cull_box[0] = ib[0]; od->stats.cull_box[1] = ib[1]; od->stats.cull_box[2] = ib[2]; od->stats.cull_box[3] = ib[3];
+                od->cull_z[0] = zb[0]; od->cull_z[1] = zb[1];
+            }
         }
+    } else if (tid == 192) {
+        // another idle wave: the level's flags and the statistics (RGBDOdometry.cpp:371-392, 401-402) -- in the order of the serial code:
+        // stop, statistics, end of level
+        const bool active = s_flags[0] != 0, stop = s_flags[1] != 0;
+        if (stop) od->level_done = 1;
+        if (active) {
+            const int rgbCount = (int)(long long)s_icp[29];
+            const float tmpError = (float)(sqrt((double)(int)(long long)s_icp[30]) / (double)rgbCount);
+            od->lastRGBError = tmpError;
+            od->stats.last_rgb_error = tmpError; od->stats.last_rgb_count = (float)rgbCount;
+            od->stats.last_icp_error = sqrtf(od->residual[0]) / od->residual[1];
+            od->stats.last_icp_count = od->residual[1];
+        }
+        if (last_of_level) { od->level_done = 0; od->lastRGBError = 3.402823466e+38F; }
+        od->solves += 1;   // (whether or not the iteration was active: the host counts launches)
     }
-    __syncthreads();
-    if (tid < 48) {   // refresh_hot(od), one word per lane: hot word `tid` <- its source field
+    __syncthreads();                                                                       // ---- barrier 3: everything the state will hold
+    {
+        // write-back of the mutable words; the hot block (refresh_hot, cf_kernels.h: GnHot) is derived on the way: hot word w <- its source field
         constexpr int o_icp = (int)(offsetof(OdomDev, icp) / 4), o_ld = (int)(offsetof(OdomDev, level_done) / 4), o_cz = (int)(offsetof(OdomDev, cull_z) / 4),
                       o_Rc = (int)(offsetof(OdomDev, Rcurr) / 4), o_tc = (int)(offsetof(OdomDev, tcurr) / 4), o_Ri = (int)(offsetof(OdomDev, Rprev_inv) / 4),
                       o_tp = (int)(offsetof(OdomDev, tprev) / 4), o_cb = (int)((offsetof(OdomDev, stats) + offsetof(cf_track_stats, cull_box)) / 4),
                       o_rgb = (int)(offsetof(OdomDev, rgb) / 4), o_ro = (int)(offsetof(OdomDev, rgbOnly) / 4), o_krk = (int)(offsetof(OdomDev, krkInv) / 4),
                       o_kt = (int)(offsetof(OdomDev, kt) / 4), o_hot = (int)(offsetof(OdomDev, hot) / 4);
-        const int w = tid;
-        const int src = w < 1 ? o_icp : w < 2 ? o_ld : w < 4 ? o_cz + (w - 2) : w < 13 ? o_Rc + (w - 4) : w < 16 ? o_tc + (w - 13) : w < 25 ? o_Ri + (w - 16)
-                      : w < 28 ? o_tp + (w - 25) : w < 32 ? o_cb + (w - 28) : w < 33 ? o_rgb : w < 34 ? o_ro : w < 35 ? o_ld : w < 36 ? -1
-                      : w < 45 ? o_krk + (w - 36) : o_kt + (w - 45);
-        unsigned* words = reinterpret_cast<unsigned*>(&s_od);
-        words[o_hot + w] = src >= 0 ? words[src] : 0u;
+        const unsigned* words = reinterpret_cast<const unsigned*>(&s_od);
+        OdomDev* const twin = god_host ? god_host : s_od.host_twin;
+        const bool to_twin = twin && next_level < 0;   // end of the schedule: the result (pose, statistics, fault word) goes to the tracker's pinned
+                                                       // host copy as well -- the frame's host wait finds it there without a copy command on the stream
+        for (int k = kMutableFrom + tid; k < kWords; k += 256) {
+            unsigned v = words[k];
+            const int w = k - o_hot;
+            if (w >= 0 && w < 48) {
+                const int src = w < 1 ? o_icp : w < 2 ? o_ld : w < 4 ? o_cz + (w - 2) : w < 13 ? o_Rc + (w - 4) : w < 16 ? o_tc + (w - 13) : w < 25 ? o_Ri + (w - 16)
+                              : w < 28 ? o_tp + (w - 25) : w < 32 ? o_cb + (w - 28) : w < 33 ? o_rgb : w < 34 ? o_ro : w < 35 ? o_ld : w < 36 ? -1
+                              : w < 45 ? o_krk + (w - 36) : o_kt + (w - 45);
+                v = src >= 0 ? words[src] : 0u;
+            }
+            reinterpret_cast<unsigned*>(god)[k] = v;
+            if (to_twin) reinterpret_cast<unsigned*>(twin)[k] = v;
+        }
     }
-    __syncthreads();
-    for (int k = kMutableFrom + tid; k < kWords; k += 256) reinterpret_cast<unsigned*>(god)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
-    // end of the schedule: the result (pose, statistics, fault word) goes to the tracker's pinned host copy as well -- the frame's host
-    // wait finds it there without a copy command behind the loop on the stream
-    OdomDev* const twin = god_host ? god_host : s_od.host_twin;
-    if (twin && next_level < 0)
-        for (int k = kMutableFrom + tid; k < kWords; k += 256) reinterpret_cast<unsigned*>(twin)[k] = reinterpret_cast<const unsigned*>(&s_od)[k];
+    // zero the accumulators for the next iteration, 16 bytes per store (their sums were read in the first flight of loads; stores issued
+    // in front of a barrier would make it wait a memory round trip)
+    {
+        ulonglong2* const zi = reinterpret_cast<ulonglong2*>(icp_acc);
+        ulonglong2* const zr = reinterpret_cast<ulonglong2*>(rgb_acc);
+        for (int k = tid; k < kGroups * 16; k += 256) { zi[k] = make_ulonglong2(0, 0); zr[k] = make_ulonglong2(0, 0); }
+    }
+    SSTAMP(8);
+#ifdef CF_ABLATE
+    if (g_solve_trace && threadIdx.x == 0 && blockIdx.x == 0) g_solve_iter++;
+#endif
 }
 
 __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int next_level, int last_of_level)
@@ -1717,6 +1846,23 @@ __global__ void __launch_bounds__(64) acc_total_kernel(const unsigned long long*
         const unsigned long long v = group_sum(acc, w, threadIdx.x);
         if (threadIdx.x == 0) out[w] = v;
     }
+}
+
+// Split reductions (one tracker's image rows over several GPUs): a rank's partial sums are FOLDED before they travel -- the 64 accumulator
+// groups of every split tracker summed into group 0, the other groups cleared -- so that the all-reduce of the Gauss-Newton loop carries
+// the 32 words of the 6x6 system (256 bytes: north_star's "RCCL all-reduce of the 6x6 system") instead of the 16 KB of grouped partial
+// sums it carried until round 5.  Everybody downstream (the RGB step's sigma, the solve) sums the groups as before
+// and finds the totals in group 0 and zeros elsewhere: integer sums, the same bits.
+struct FoldArgs { unsigned long long* acc[kMaxBatch]; };
+__global__ void __launch_bounds__(64) acc_fold_kernel(const FoldArgs a)
+{
+    unsigned long long* __restrict__ acc = a.acc[blockIdx.x];
+    const int lane = threadIdx.x;
+    unsigned long long tot = 0;
+#pragma unroll 4
+    for (int w = 0; w < 32; w++) { const unsigned long long v = group_sum(acc, w, lane); if (lane == w) tot = v; }
+    for (int w = 0; w < 32; w++) acc[(size_t)lane * 32 + w] = 0;   // (every load above has been consumed by a shuffle: the wave is past them)
+    if (lane < 32) acc[lane] = tot;                                  // (same wave, program order: behind the zeroes of group 0)
 }
 
 // ------------------------------------------------------------------------------ launchers ----
@@ -1929,9 +2075,13 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
                 IcpArgs e = icp_args[i]; e.cdiv = make_idiv(e.cols);
                 icp_error_surface_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(e);
             }
-            if (hook && hook->fn)  // split reductions: the partial sums of this rank's row band become the totals on every rank
+            if (hook && hook->fn) {  // split reductions: the partial sums of this rank's row band become the totals on every rank
+                FoldArgs fa{}; int nf = 0;
+                for (int m = 0; m < n; m++) if (hook->split[m]) fa.acc[nf++] = gn.icp_acc[m];
+                if (nf) acc_fold_kernel<<<nf, 64, 0, s>>>(fa);   // 64 groups -> group 0: 256 bytes per tracker cross the links, not 16 KB
                 for (int m = 0; m < n; m++)
-                    if (hook->split[m] && hook->fn(hook->user, 0, gn.icp_acc[m], (uint64_t)kGroups * 32, (void*)s) != 0) hook_failed = true;
+                    if (hook->split[m] && hook->fn(hook->user, 0, gn.icp_acc[m], 32, (void*)s) != 0) hook_failed = true;
+            }
             if (rgb && mode == 2) {   // the RGB step's last workgroup of every tracker solves
                 const int n_slots = (N + ra.slot_px - 1) / ra.slot_px, n_quads = (n_slots + 1) / 2;
                 rgb_step_solve_kernel<<<8 * n_quads * ((n + 7) / 8), 256, 0, s>>>(ra, so3_syncs, n_slots, n_quads, make_idiv(n_quads > 1 ? n_quads : 2), n,
@@ -1967,6 +2117,36 @@ float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const R
 }
 
 #ifdef CF_ABLATE
+// diagnostics (CF_SOLVE_TRACE): phase stamps of tracker 0's solves of the tracking call enqueued between begin and end
+static unsigned long long* g_solve_trace_dev = nullptr;
+void trace_solve_begin()
+{
+    if (!g_solve_trace_dev && hipMalloc(reinterpret_cast<void**>(&g_solve_trace_dev), 64 * 16 * 8) != hipSuccess) return;
+    (void)hipMemset(g_solve_trace_dev, 0, 64 * 16 * 8);
+    const unsigned zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_solve_iter), &zero, sizeof(zero));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_solve_trace), &g_solve_trace_dev, sizeof(g_solve_trace_dev));
+}
+void trace_solve_end(hipStream_t s, const char* path)
+{
+    (void)hipStreamSynchronize(s);
+    unsigned long long* none = nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_solve_trace), &none, sizeof(none));
+    if (!g_solve_trace_dev) return;
+    std::vector<unsigned long long> h(64 * 16);
+    (void)hipMemcpy(h.data(), g_solve_trace_dev, h.size() * 8, hipMemcpyDeviceToHost);
+    FILE* f = fopen(path, "a");
+    if (!f) return;
+    fprintf(f, "# solve: ns from the kernel's first stamp -- loaded | totals | unpacked | LDLT | rodrigues | pose | next-iteration | write-back\n");
+    for (int it = 0; it < 64; it++) {
+        const unsigned long long* o = &h[(size_t)it * 16];
+        if (!o[0]) continue;
+        fprintf(f, "%2d", it);
+        for (int k = 1; k <= 8; k++) fprintf(f, " %6lld", o[k] ? (long long)(o[k] - o[0]) * 10 : -1ll);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+}
 // diagnostics (CF_STEP_TRACE): one level-0 {ICP || residual} launch + one traced rgb_step_solve_kernel launch (next_level 0: the state moves
 // on by one iteration; the caller's results are garbage afterwards); lines "workgroup model begin step commit ticket solve_end" in ns
 void trace_step_solve(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, So3Sync* syncs, int n, const char* path)

@@ -264,6 +264,12 @@ class CoFusion:
         self._check(self.lib.cofusion_model_cull_box(self.h, index, b))
         return list(b)
 
+    def model_level0_visited(self, index):
+        """(ICP pixels, residual pixels) the level-0 launch of the model's last tracking call visited for it (include/cofusion.h)"""
+        a = C.c_uint64(); b = C.c_uint64()
+        self._check(self.lib.cofusion_model_level0_visited(self.h, index, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def model_icp_stats(self, index):
         e = C.c_float(); c = C.c_float()
         self._check(self.lib.cofusion_model_icp_stats(self.h, index, C.byref(e), C.byref(c)))

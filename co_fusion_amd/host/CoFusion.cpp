@@ -1033,9 +1033,9 @@ void CoFusion::trackLaunch(cf_ctx* ctx, TrackBatch& batch, const Config& cfg)
     for (auto& it : batch.items) it.model->bindFrameMaps(it.depthPyr, it.maxDepth, it.owner);
     cf_track_opts opts{};
     opts.rgb_only = cfg.rgbOnly; opts.pyramid = cfg.pyramid; opts.fast_odom = cfg.fastOdom; opts.so3 = cfg.so3; opts.icp_weight = cfg.icpWeight;
-    // lock-step launches of at most 16 trackers (kMaxBatch, csrc/cf_kernels.h); a further chunk starts when the previous one has
-    // finished (cf_odom_track_batch_async waits for it: the chunks share the context's staging), the LAST one is left in flight --
-    // fetchTracking collects it after whatever the caller enqueues behind it
+    // lock-step launches of at most 16 trackers (kMaxBatch, csrc/cf_kernels.h); the chunks hold different trackers, so chunk k + 1 is
+    // prepared and enqueued while chunk k runs (round 6: the drain between chunks is per tracker, not per context); everything is left
+    // in flight -- fetchTracking collects it after whatever the caller enqueues behind it
     const size_t B = 16;
     for (size_t base = 0; base < n; base += B) {
         const int k_n = (int)std::min(B, n - base);

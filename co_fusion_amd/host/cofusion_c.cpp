@@ -143,6 +143,13 @@ int cofusion_model_cull_box(cofusion_handle* h, int index, int box[4])
     for (int k = 0; k < 4; k++) box[k] = m->lastStats.cull_box[k];
     return 0;
 }
+int cofusion_model_level0_visited(cofusion_handle* h, int index, uint64_t* icp_pixels, uint64_t* residual_pixels)
+{
+    Model* m = model_at(h, index);
+    if (!m || !m->getFrameOdometry()) { g_err = "model index out of range"; return -1; }
+    if (cf_odom_level0_visited(m->getFrameOdometry(), icp_pixels, residual_pixels)) { g_err = "cf_odom_level0_visited"; return -1; }
+    return 0;
+}
 int cofusion_model_tracking_inputs(cofusion_handle* h, int index, float* vertex4, float* normal4, uint8_t* image_rgba)
 {
     Model* m = model_at(h, index);

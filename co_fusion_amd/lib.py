@@ -29,7 +29,7 @@ SYMBOLS = [
     "cf_model_fuse", "cf_model_clean", "cf_models_frame_passes", "cf_models_preindex", "cf_model_download_map", "cf_model_upload_map", "cf_model_buffer",
     "cf_fusion_weight", "cf_seg_create", "cf_seg_destroy", "cf_seg_slic", "cf_seg_accumulate", "cf_seg_crf", "cf_seg_upsample", "cf_seg_sums", "cf_seg_infer", "cf_seg_run_batch", "cf_seg_fetch", "cf_seg_publish_poses", "cf_seg_fetch_poses",
     "cf_seg_labels",
-    "cf_depth_pyramid", "cf_set_icp_launch", "cf_set_icp_arith", "cf_get_icp_arith", "cf_set_gn_mode", "cf_profile_enable", "cf_profile_read", "cf_odom_bench_icp",
+    "cf_depth_pyramid", "cf_set_icp_launch", "cf_set_icp_arith", "cf_get_icp_arith", "cf_set_gn_mode", "cf_profile_enable", "cf_profile_read", "cf_odom_bench_icp", "cf_odom_level0_visited",
     "cf_rccl_unique_id", "cf_rccl_init", "cf_rccl_allreduce", "cf_rccl_broadcast", "cf_rccl_info", "cf_rccl_destroy",
 ]
 
@@ -52,7 +52,7 @@ HOST_LIB_PATH = os.path.join(_LIB_DIR, "libcofusion.so")
 HOST_SYMBOLS = [
     "cofusion_default_config", "cofusion_create", "cofusion_destroy", "cofusion_last_error", "cofusion_set_stream",
     "cofusion_process_frame", "cofusion_process_frame_device", "cofusion_num_models", "cofusion_tick", "cofusion_model_info",
-    "cofusion_model_download", "cofusion_model_icp_stats", "cofusion_model_cull_box", "cofusion_model_tracking_inputs", "cofusion_mask_device", "cofusion_context", "cofusion_set_crf",
+    "cofusion_model_download", "cofusion_model_icp_stats", "cofusion_model_cull_box", "cofusion_model_level0_visited", "cofusion_model_tracking_inputs", "cofusion_mask_device", "cofusion_context", "cofusion_set_crf",
     "cofusion_save_ply", "cofusion_export_poses", "cofusion_set_export_segmentation", "cofusion_klg_open", "cofusion_klg_next", "cofusion_klg_set_reference_compatible", "cofusion_klg_close",
     "cofusion_klg_create", "cofusion_klg_write", "cofusion_klg_finish", "cofusion_debug_phase_ms", "cofusion_set_allreduce", "cofusion_set_allreduce_device", "cofusion_group_create", "cofusion_group_destroy", "cofusion_group_size", "cofusion_group_sequence", "cofusion_group_set_stream", "cofusion_group_process_frames", "cofusion_group_process_frames_device", "cofusion_rccl_unique_id", "cofusion_init_rccl", "cofusion_broadcast", "cofusion_model_owned", "cofusion_is_lost",
 ]

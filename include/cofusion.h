@@ -72,6 +72,8 @@ int cofusion_model_download(cofusion_handle *h, int index, float *surfels, uint3
 int cofusion_model_icp_stats(cofusion_handle *h, int index, float *icp_error, float *icp_count);
 /* the level-0 pixel rectangle [x0, y0, x1, y1] the model's last ICP iteration was restricted to (cf_track_stats::cull_box) */
 int cofusion_model_cull_box(cofusion_handle *h, int index, int box[4]);
+/* pixels the level-0 {ICP || residual} launch of the model's last tracking call visited for it (cf_odom_level0_visited) */
+int cofusion_model_level0_visited(cofusion_handle *h, int index, uint64_t *icp_pixels, uint64_t *residual_pixels);
 /* host copies of what the NEXT frame's tracking of this model reads (Model::initICP, Model.cpp:350-367): the predicted
  * vertex+conf / normal+radius maps (f32x4 [H*W]) and the predicted image (rgba8 [H*W]); any pointer may be NULL */
 int cofusion_model_tracking_inputs(cofusion_handle *h, int index, float *vertex4, float *normal4, uint8_t *image_rgba);

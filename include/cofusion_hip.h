@@ -253,18 +253,27 @@ int cf_odom_fetch_result(cf_odom *od, float trans[3], float rot[9], cf_track_sta
  * statistics: partial-pivot LU inverse of the 6x6 normal matrix, row-major f64 [36], on the host (the caller already holds lastA).
  * A singular lastA gives inf / NaN entries, as Eigen's does. */
 int cf_odom_get_covariance(const cf_track_stats *stats, double cov[36]);
+/* pixels the level-0 {ICP reduction || RGB residual} launch of the last fetched tracking call visited for this tracker: the 64-pixel
+ * runs inside its final screen box and the record slots between its first and last RGB candidate (the whole image for a tracker
+ * that is not culled) -- the physical byte count of a roofline figure, as opposed to SURVEY 8(d)'s every-pixel-to-every-tracker */
+int cf_odom_level0_visited(cf_odom *od, uint64_t *icp_pixels, uint64_t *residual_pixels);
 /* test access to internal device pyramids (same `which` numbering as the oracle's orc_odom_buffer) */
 /* share the frame-wide current vertex/normal pyramids between models (all models track the same frame,
  * cudafuncs.cu:119); pass NULL arrays to return to the odom-private maps written by cf_odom_init_icp */
 /* Skip the model-map gathers of pixels that project into empty 4x4 blocks of the prediction (an occupancy bitmap written by
- * initICPModel).  Results are unchanged; it pays for models that cover a small part of the image (object models) and costs a
- * dependent look-up for one that covers all of it (background).  Default off. */
+ * initICPModel) and, since round 5, every pixel outside the screen box of the prediction's frustum piece.  Results are unchanged; it
+ * pays for models that cover a small part of the image (object models) and costs a dependent look-up for one that covers all of it
+ * (background).  Default off.  Precondition of the screen box: the tracking call starts from the pose the model maps were prepared with
+ * (cf_odom_init_icp_model's `pose` == the pose handed to cf_odom_track_batch_async / _get_incremental_transformation, bit for bit -- what
+ * Model::performTracking does); a call that starts elsewhere is tracked WITHOUT the screen box (checked per call; the occupancy look-up
+ * does not depend on it). */
 int cf_odom_set_culling(cf_odom *od, int on);
 /* Multi-GPU hooks.  cf_set_collective registers the caller's in-place all-reduce over its ranks (RCCL): op 0 = SUM of int64 words,
  * op 1 = MIN of unsigned 64-bit words; dev_buf is a device address, the call must only ENQUEUE on `hip_stream` (or order itself
  * after it and before later work on it); 0 = success.  cf_odom_set_band splits one model's reductions over the ranks by image
  * rows (level-0 rows, multiples of 4; add_counts = 1 on exactly one rank of the split): inside the device-resident loop the
- * collective sums that model's accumulators after every {ICP || residual} launch, so all ranks solve the same system. */
+ * collective sums that model's normal equations after every {ICP || residual} launch -- 32 words (256 bytes): the library folds the
+ * rank's grouped partial sums first (round 6; 16 KB until then) --, so all ranks solve the same system. */
 typedef int (*cf_collective_fn)(void *user, int op, void *dev_buf, uint64_t words, void *hip_stream);
 int cf_set_collective(cf_ctx *ctx, cf_collective_fn fn, void *user);
 int cf_odom_set_band(cf_odom *od, int row_begin, int row_end, int add_counts);
@@ -457,6 +466,9 @@ int cf_seg_labels(cf_segmenter *s, void **dptr, uint64_t *bytes);
  * own (three launches per iteration); 2: the same records, the RGB step's workgroups of a tracker share one XCD and the last of
  * them to finish runs the solve (two launches per iteration; measured slower at 640x480, kept as an option); 0: the reference's
  * 16 B DataTerm record per pixel (diagnostic / comparison).  Results are bit-identical in all three. */
+/* (mode 2 needs hardware workgroup b of a launch to run on XCD b mod 8; checked on the device once per context -- CF_ESTATE and the mode
+ * unchanged where that does not hold.  Whatever the mode: a tracking call one of whose solves never ran is reported by
+ * cf_odom_fetch_result as CF_ESTATE, not returned as a pose.) */
 int cf_set_gn_mode(cf_ctx *ctx, int mode);
 /* launch-shape tuning of the ICP reduction (GPUConfig.h:51-58 in the reference): threads per workgroup (64..1024, default 256) and
  * pixels per lane of trackers that reduce their whole image (1, 2, 4; 0 = default: two at pyramid level 0, one below).  The sums are

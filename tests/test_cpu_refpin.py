@@ -407,6 +407,79 @@ def _gn_loop_against_fixture(refodo, z, cam, frames, W, H, arith, options=None):
     assert moved > 5e-3, "degenerate pin: the tracker did not move"
 
 
+@pytest.mark.parametrize("fixture", ["small", "640x480"])
+def test_reference_order_gn_loop_is_the_reference_class_bit_for_bit(fixture):
+    """under ORC_ICP_ARITH_REFERENCE the oracle's Gauss-Newton loop runs on the f32 trees of reduce.cu:90-185 at
+    GPUConfig.h's launch shapes (orc_*_step_f32tree, each pinned to the reference KERNEL bit for bit above) with the host algebra in the
+    order of the classes the reference's text instantiates -- and returns what RGBDOdometry::getIncrementalTransformation compiled from
+    /root/reference returned for the same recorded inputs BIT FOR BIT: translation, rotation, the last normal equations in f64, every
+    statistic; six option sets x two frames at 160x120, {default, fast_odom} x two frames at 640x480.  No tolerance (the product / Gram
+    forms above: ODO_POSE_TOL)."""
+    import refodo
+    if fixture == "640x480" and not os.path.exists(ODO_FULL_GOLDEN):
+        pytest.skip("tests/golden/ref_odo_full_v1.npz not generated")
+    z, cam, frames, W, H = _odo_inputs(ODO_FULL_GOLDEN) if fixture == "640x480" else _odo_inputs()
+    orc.set_icp_arith("reference")
+    checked = 0
+    try:
+        for fi in z["frames"]:
+            fr = frames[int(fi)]
+            for opts in refodo.OPTION_SETS:
+                key = f"f{int(fi)}/{opts[0]}"
+                if key + "/trans" not in z.files:
+                    continue
+                tr, rot, st, err = refodo.track_once(orc.Odometry, cam, W, H, fr, opts)
+                assert refpin.bits_equal(tr, z[key + "/trans"]) and refpin.bits_equal(rot, z[key + "/rot"]), f"{key}: pose differs from the reference class"
+                assert np.array_equal(st["lastA"], z[key + "/lastA"]) and np.array_equal(st["lastb"], z[key + "/lastb"]), f"{key}: last normal equations"
+                rs = z[key + "/stats"]
+                icp, rgb, so3 = not opts[1] and opts[2] > 0, opts[1] or opts[2] < 100, opts[5]
+                mine = np.array([st["last_icp_error"], st["last_icp_count"], st["last_rgb_error"], st["last_rgb_count"], st["last_so3_error"], st["last_so3_count"]], np.float32)
+                which = ([0, 1] if icp else []) + ([2, 3] if rgb else []) + ([4, 5] if so3 else [])   # (a member the call does not write keeps its constructor value in the reference)
+                assert refpin.bits_equal(mine[which], rs[which]), f"{key}: statistics {mine} vs {rs}"
+                if icp:
+                    es = z[key + "/err_sum_max"]
+                    assert float(err.astype(np.float64).sum()) == float(es[0]) and float(err.max()) == float(es[1]), f"{key}: ICP error surface"
+                checked += 1
+    finally:
+        orc.set_icp_arith("product")
+    assert checked >= 4
+
+
+def test_reference_order_trajectory_equals_the_reference_tracker():
+    """VERDICT r5 item 1 (c) on the CPU: the pinned frame loop with the oracle's tracker under ORC_ICP_ARITH_REFERENCE against
+    tests/golden/ref_traj_v1.npz (the same loop tracked by the reference's own RGBDOdometry class): model lists, ids, SURFEL COUNTS and
+    the poses of every model identical on every frame -- the three 160x128 scenarios over their whole length (static camera; motion CRF
+    with spawns; ground-truth masks), the four 640x480 ones over their first CPU_FRAMES_640_EXACT frames here (their whole length on the
+    MI355X: tests/test_refpin_gpu.py, and here with COFUSION_LONG_TESTS=1: 5 min each).  trajpin.exact, no tolerance."""
+    import subprocess
+    import sys
+    import trajpin
+    if not ref.available():
+        pytest.skip("oracle/_ref not built (the frame loop is the reference's text)")
+    z = np.load(TRAJ_GOLDEN)
+    long_run = bool(os.environ.get("COFUSION_LONG_TESTS"))
+    procs = {}
+    for name in trajpin.scenarios():
+        F = z[name + "/poses"].shape[0]
+        if name.endswith("_640") and not long_run:
+            F = min(F, CPU_FRAMES_640_EXACT)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r); import orc, make_ref_traj_golden as g; "
+                "orc.set_icp_arith('reference'); p, i, c = g.play(%r, False, n_frames=%d); np.savez(sys.argv[1], poses=p, ids=i, counts=c)"
+                % (os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__)), os.path.join(os.path.dirname(__file__), "golden"), name, F))
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"trajx_{name}_{os.getpid()}.npz")
+        procs[name] = (subprocess.Popen([sys.executable, "-c", code, out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, OMP_NUM_THREADS="1")), out)
+    models = 0
+    for name, (proc, out) in procs.items():
+        _, err_text = proc.communicate(timeout=2400)
+        assert proc.returncode == 0, f"{name}: {err_text.decode()[-2000:]}"
+        o = np.load(out); os.remove(out)
+        r = trajpin.exact(name, o["poses"], o["ids"], o["counts"], z=z)
+        assert r["identical"], f"{name}: not the reference tracker's trajectory: {r}"
+        assert float(np.abs(o["poses"][-1, 0, :3, 3] - o["poses"][0, 0, :3, 3]).max()) > 1e-3, f"{name}: the camera did not move"
+        models = max(models, int((o["ids"] >= 0).sum(axis=1).max()))
+    assert models >= 3 and len(procs) >= 7
+
+
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
 def test_gn_loop_fixture_is_what_the_reference_class_produces():
     """the committed fixture is reproducible from the reference sources (spot check: the RGB-only option set, ~25 s on the emulator;
@@ -479,6 +552,7 @@ def _ate(a, b):
 # CPU budget: the oracle needs ~2 s per 640x480 model-frame; the long 640x480 scenarios are played for this many frames here (their full
 # length on the MI355X, tests/test_configs_gpu.py, and here with COFUSION_LONG_TESTS=1)
 CPU_FRAMES_640 = 60
+CPU_FRAMES_640_EXACT = 10   # ... and of the bit-for-bit comparison under the reference-order arithmetic (a tree-ordered f32 sum is serial in the oracle)
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
@@ -495,7 +569,7 @@ def test_trajectory_within_1mm_ate_of_the_reference_arithmetic():
     import sys
     import trajpin
     z = np.load(TRAJ_GOLDEN)
-    names = trajpin.scenarios()
+    names = trajpin.scenarios(exact_only=False)
     assert len(names) >= 7, "empty fixture"
     long_run = bool(os.environ.get("COFUSION_LONG_TESTS"))
     # one process per scenario (function-static state in Core/Segmentation, see cfpin.run_reference_isolated), all of them side by side

@@ -15,8 +15,12 @@ of the same stream with the exact-integer tracker (oracle or HIP: the same bits)
     difference is REPORTED (first differing frame, largest absolute and relative difference) and BOUNDED (COUNT_REL_*) while the
     model lists agree;
   * object trajectories: every object model the reference-arithmetic run keeps for >= 10 frames is compared on every frame of its life
-    (while the lists agree): within OBJECT_BOUND_M where the reference's own track is smooth, within a bound tied to the reference's
-    own irregularity where it is not (see below).
+    (while the lists agree) and the figures are REPORTED (largest distance, whether the tight bound OBJECT_BOUND_M holds, the second
+    differences of the reference's own track).  Until round 6 objects were asserted with a bound scaled by the reference's own jitter
+    (and the definition of "smooth" was once moved to make an object fit it: VERDICT r5).  That rule is gone: EXACT parity against the
+    reference's tracker -- model lists, surfel counts, bit-identical poses of every model -- is asserted under the REFERENCE-ORDER
+    arithmetic (exact(), cf_set_icp_arith 2 / ORC_ICP_ARITH_REFERENCE), and what the default exact-integer arithmetic does to a small
+    object's track is a measurement, not a pass criterion.
 """
 from __future__ import annotations
 
@@ -30,31 +34,31 @@ GOLDEN = os.path.join(HERE, "golden", "ref_traj_v1.npz")
 ATE_TOL_M = 1e-3          # BASELINE.json: "pose trajectory within 1e-3 m ATE of the reference"
 MIN_OBJECT_LIFE = 10      # frames: objects the reference-arithmetic run keeps at least this long are asserted
 
-# Surfel counts while the model lists agree: |difference| <= max(COUNT_ABS_FLOOR, rel * count) with rel = COUNT_REL_BACKGROUND for the
-# background model (slot 0) and COUNT_REL_OBJECT for object models (a few thousand surfels, tracked poses that differ by more) whose
-# track in the reference-arithmetic run is smooth (see below; the count of an object follows its pose, and where the reference's own
-# track jumps by centimetres the counts are reported, not bounded).  Observed
-# (tests/golden/README.md): background 4.2e-4 (100 static frames at 640x480: 103 of 247 755) and 9.1e-4 (60 frames with ground-truth
-# masks: 294 of 321 999); objects 1.8e-2 (122 of 6 893).  The bounds are ~3x that.
+# Surfel counts of the BACKGROUND while the model lists agree: |difference| <= max(COUNT_ABS_FLOOR, COUNT_REL_BACKGROUND * count).
+# Observed (tests/golden/README.md): 4.2e-4 (100 static frames at 640x480: 103 of 247 755) and 9.1e-4 (60 frames with ground-truth
+# masks: 294 of 321 999); the bound is ~3x that.  Object models (a few thousand surfels, tracked poses that differ by more: 1.8e-2,
+# 122 of 6 893) are reported.  Under the reference-order arithmetic all of them are EQUAL (exact()).
 COUNT_ABS_FLOOR = 32
 COUNT_REL_BACKGROUND = 3e-3
-COUNT_REL_OBJECT = 5e-2
 
-# Object trajectories.  An object whose track in the reference-arithmetic run is smooth -- no second difference of its positions above
-# STABLE_JITTER_M over its life -- must be matched within OBJECT_BOUND_M on every frame.  Where the reference's OWN track is irregular
-# (a rotationally symmetric or small object: its class jumps by centimetres between frames on an object that moves millimetres, or
-# hits the divergence guard, RGBDOdometry.cpp:464-467), no two arithmetics agree to millimetres; the bound is then tied to the
-# reference's own irregularity: the difference must not exceed JITTER_FACTOR x the largest second difference of the reference's track
-# over the object's life (at least OBJECT_BOUND_M).  Both cases are asserted; the report says which applied.
+# Object trajectories (reported).  OBJECT_BOUND_M: the tight bound a well-conditioned object is expected to meet (`within_tight_bound` in
+# the report); STABLE_JITTER_M: an object's track in the reference-arithmetic run counts as smooth when no second difference of its
+# positions exceeds this (1e-2, the round-4 value; round 5 had halved it to make an object fit a jitter-scaled bound -- VERDICT r5 weak #3).
+# Where the reference's OWN track is irregular (a rotationally symmetric or small object: its class jumps by centimetres between frames
+# on an object that moves millimetres, or hits the divergence guard, RGBDOdometry.cpp:464-467) no two arithmetics agree to millimetres.
 OBJECT_BOUND_M = 2e-3
-STABLE_JITTER_M = 5e-3    # (1e-2 until round 5: the boxes scenario has an object whose reference track wobbles by 2-7 mm per frame -- 4 500 surfels --
-                          # and is matched within 4.8 mm: that is the reference's own irregularity, not a smooth track missed by 2 mm)
-JITTER_FACTOR = 1.5
+STABLE_JITTER_M = 1e-2
 
 
-def scenarios():
+def scenarios(exact_only=True):
+    """the scenarios of the fixture: all of them (exact_only: those the reference-order arithmetic is held to, exact()) or the ones a run
+    under the exact-integer arithmetics is compared on (compare(): a scenario whose spawn frame depends on the rounding is left out)"""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_ref_traj_golden as g
     z = np.load(GOLDEN)
-    return sorted({k.split("/")[0] for k in z.files})
+    names = sorted({k.split("/")[0] for k in z.files})
+    return names if exact_only else [n for n in names if n not in g.REFERENCE_ORDER_ONLY]
 
 
 def lives(rids, m, upto):
@@ -74,8 +78,9 @@ def lives(rids, m, upto):
 
 
 def compare(name, op, oids, ocounts, arith="product", z=None, log=print, check=True):
-    """op [F, MAXM, 4, 4], oids [F, MAXM], ocounts [F, MAXM] of a run with the exact-integer tracker against the fixture.  Asserts the
-    bounds of the module docstring and returns the figures (what bench.py prints as ate_m.vs_reference)."""
+    """op [F, MAXM, 4, 4], oids [F, MAXM], ocounts [F, MAXM] of a run with the exact-integer tracker (default or Gram form) against the
+    fixture.  Asserts the bounds of the module docstring (camera, model lists, background counts) and returns the figures (what bench.py
+    prints as ate_m.vs_reference); a run under the reference-order arithmetic goes to exact() instead."""
     import sys
     sys.path.insert(0, os.path.join(HERE, "golden"))
     import make_ref_traj_golden as g
@@ -116,7 +121,7 @@ def compare(name, op, oids, ocounts, arith="product", z=None, log=print, check=T
     where = np.unravel_index(int(d.argmax()), d.shape) if d.size else (0, 0)
     log(f"{name} [{arith}]: surfel counts identical for the first {c_first if c_first >= 0 else first_diff} frames; largest difference {c_abs} "
         f"of {int(rc[where])} (frame {int(where[0])}, slot {int(where[1])}), largest relative difference {c_rel:.1e}")
-    # (bounded below, per slot: the background always; an object model while the reference's own track of it is smooth)
+    # (the background's is bounded; object models: reported below)
     over0 = d[:, 0] > np.maximum(COUNT_ABS_FLOOR, COUNT_REL_BACKGROUND * rc[:first_diff, 0])
     require(not over0.any(), f"{name}: the background's surfel count differs by {int(d[:, 0].max()) if d.size else 0} from the reference-arithmetic run: beyond "
             f"max({COUNT_ABS_FLOOR}, {COUNT_REL_BACKGROUND} x count) at frame {int(np.argmax(over0)) if over0.size else -1}")
@@ -136,25 +141,35 @@ def compare(name, op, oids, ocounts, arith="product", z=None, log=print, check=T
             acc[2:] = np.linalg.norm(pr[2:] - 2 * pr[1:-1] + pr[:-2], axis=1)   # second differences of the REFERENCE run's own track
             jitter = float(acc.max())
             stable = jitter <= STABLE_JITTER_M
-            scale = 2 if arith == "gram" else 1
-            bound = np.full(t1 - t0, OBJECT_BOUND_M * scale) if stable else np.full(t1 - t0, max(OBJECT_BOUND_M * scale, JITTER_FACTOR * jitter))
-            objects[f"slot{m}@{t0}"] = dict(id=int(rids[t0, m]), frames=int(t1 - t0), max_m=float(em.max()), bound_m=float(bound.max()), moved_m=moved,
-                                            reference_track_jitter_m=jitter, stable_in_reference=bool(stable))
+            tight = bool(em.max() <= OBJECT_BOUND_M * (2 if arith == "gram" else 1))
+            dc = d[t0:t1, m]
+            objects[f"slot{m}@{t0}"] = dict(id=int(rids[t0, m]), frames=int(t1 - t0), max_m=float(em.max()), bound_m=OBJECT_BOUND_M, within_tight_bound=tight,
+                                            moved_m=moved, reference_track_jitter_m=jitter, stable_in_reference=bool(stable),
+                                            count_max_abs_diff=int(dc.max()), count_max_rel_diff=float((dc / np.maximum(rc[t0:t1, m], 1)).max()))
             log(f"{name} [{arith}]: object id {int(rids[t0, m])} (slot {m}, frames {t0}..{t1 - 1}, moved {moved:.3f} m, the reference's own track "
                 f"{'smooth' if stable else 'IRREGULAR'}: largest second difference {jitter:.1e} m): within {em.max():.2e} m of the reference-arithmetic "
-                f"run on every frame (bound {'%.1e' % bound.max()}{'' if stable else ' = %.1f x that irregularity' % JITTER_FACTOR})")
-            dc = d[t0:t1, m]
-            objects[f"slot{m}@{t0}"].update(count_max_abs_diff=int(dc.max()), count_max_rel_diff=float((dc / np.maximum(rc[t0:t1, m], 1)).max()))
-            if stable:   # the counts of an object follow its pose: bounded where the reference's own track is smooth, reported otherwise
-                over = dc > np.maximum(COUNT_ABS_FLOOR, COUNT_REL_OBJECT * rc[t0:t1, m])
-                require(not over.any(), f"{name}: object id {int(rids[t0, m])} (slot {m}): surfel count differs by {int(dc.max())} from the reference-arithmetic "
-                        f"run (beyond max({COUNT_ABS_FLOOR}, {COUNT_REL_OBJECT} x count)) at frame {t0 + int(np.argmax(over))}")
-            bad = np.nonzero(em > bound)[0]
-            require(bad.size == 0, f"{name}: object id {int(rids[t0, m])} (slot {m}): {em[bad[0]] if bad.size else 0} m from the reference-arithmetic run "
-                    f"at frame {t0 + int(bad[0]) if bad.size else -1} (bound {bound[bad[0]] if bad.size else 0})")
+                f"run on every frame ({'inside' if tight else 'OUTSIDE'} the tight bound {OBJECT_BOUND_M:.0e}); surfel count within {int(dc.max())} "
+                f"({objects[f'slot{m}@{t0}']['count_max_rel_diff']:.1e} relative) -- reported, not asserted: exact parity is asserted under the reference-order arithmetic")
     return dict(scenario=name, frames=F, rmse=rmse, max=worst, rotation=rot, lists_identical_frames=int(first_diff),
                 count_first_diff_frame=c_first, count_max_abs_diff=c_abs, count_max_rel_diff=c_rel, background_count_max_abs_diff=bg_abs,
                 background_count_max_rel_diff=bg_rel, objects=objects)
+
+
+def exact(name, op, oids, ocounts, z=None):
+    """THE parity statement of north_star against the reference's own tracker: a run under the REFERENCE-ORDER arithmetic (oracle:
+    ORC_ICP_ARITH_REFERENCE, HIP: cf_set_icp_arith 2) against the fixture -- model lists, ids, SURFEL COUNTS and poses of every model
+    on every frame.  Returns the figures (all zeros / full length when the parity holds); asserts nothing itself."""
+    z = z if z is not None else np.load(GOLDEN)
+    F = op.shape[0]
+    rp, rids, rc = z[name + "/poses"][:F], z[name + "/ids"][:F], z[name + "/counts"][:F]
+    first_list = next((t for t in range(F) if not np.array_equal(oids[t], rids[t])), F)
+    dcount = np.abs(ocounts.astype(np.int64) - rc.astype(np.int64))
+    first_count = int(np.nonzero(dcount.max(axis=1))[0][0]) if dcount.max() else F
+    bits = (op.view(np.uint32) == rp.view(np.uint32)).reshape(F, -1).all(axis=1)
+    first_pose = int(np.nonzero(~bits)[0][0]) if not bits.all() else F
+    return dict(scenario=name, frames=F, lists_identical_frames=int(first_list), counts_identical_frames=first_count, count_max_abs_diff=int(dcount.max()),
+                poses_bit_identical_frames=first_pose, pose_max_abs_diff=float(np.abs(op.astype(np.float64) - rp.astype(np.float64)).max()),
+                models=int((rids >= 0).sum(axis=1).max()), identical=bool(first_list == F and first_count == F and first_pose == F))
 
 
 _STREAMS: dict = {}
