@@ -741,11 +741,71 @@ def extras(out, args, cf, cam, frames, i0, use_gt, torch, facade, local_rank):
     except Exception as e:  # noqa: BLE001
         out["host_input"] = dict(error=str(e))
     try:
+        out["klg_input"] = klg_input_leg(args, cam, frames, torch, facade, local_rank)
+    except Exception as e:  # noqa: BLE001
+        out["klg_input"] = dict(error=str(e)[:300])
+    try:
         out["ate_m"] = dict(out.get("ate_m", {}), **oracle_trajectory_check(cam, frames, torch, facade, local_rank, args))
     except Exception as e:  # noqa: BLE001
         out.setdefault("ate_m", {})["vs_oracle_error"] = str(e)
     if args.workload != "static":
         out["secondary"] = secondary_static(args, torch, facade, local_rank)
+
+
+def klg_input_leg(args, cam, frames, torch, facade, local_rank, n_frames=60):
+    """the number to compare the day car4-noise.klg is available.  The workload's synthetic stream is written as a
+    .klg log in the format of the reference's recordings (GUI/Tools/KlgLogReader.cpp:22-87: int32 frame count, per frame int64
+    timestamp, int32 sizes, zlib-compressed uint16 millimetre depth, JPEG colour) and played through the library's own reader
+    (host/KlgIO.cpp + host/Jpeg.cpp: inflate + baseline JPEG decode on the host) into the same processFrame as the headline: frames/s
+    INCLUDING log decoding and the host-input upload, and the decode cost alone."""
+    import io
+    import struct
+    import tempfile
+    import zlib
+    from co_fusion_amd import klg
+    W, H = args.width, args.height
+    n_obj = WORKLOADS[args.workload]["n_obj"]
+    F = min(n_frames, len(frames))
+    try:
+        from PIL import Image
+        def colour(rgb):
+            buf = io.BytesIO(); Image.fromarray(rgb).save(buf, format="JPEG", quality=90, subsampling=2); return buf.getvalue(), "JPEG (quality 90, 4:2:0)"
+    except ImportError:   # (Pillow is in this image; raw colour is what the reader's other branch takes, KlgLogReader.cpp:72-75)
+        def colour(rgb):
+            return np.ascontiguousarray(rgb).tobytes(), "raw RGB (Pillow not importable)"
+    path = os.path.join(tempfile.gettempdir(), f"bench_{os.getpid()}.klg")
+    fmt = ""
+    nbytes = 4
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", F))
+        for t in range(F):
+            fr = frames[t]
+            mm = np.rint(fr["depth"] * np.float32(1000.0)).astype(np.uint16)
+            zd = zlib.compress(mm.tobytes(), 6)
+            jb, fmt = colour(fr["rgb"])
+            f.write(struct.pack("<qii", t * 33333, len(zd), len(jb))); f.write(zd); f.write(jb)
+            nbytes += 16 + len(zd) + len(jb)
+    try:
+        t0 = time.perf_counter()
+        for _ in klg.KlgReader(path, W, H):
+            pass
+        decode_ms = 1e3 * (time.perf_counter() - t0) / F
+        g = facade.CoFusion(W, H, cam.fx, cam.fy, cam.cx, cam.cy, device=local_rank, max_surfels=args.max_surfels, enable_multiple_models=int(n_obj > 0))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for ts, depth, rgb in klg.KlgReader(path, W, H):
+            g.process_frame(depth, rgb, timestamp=ts)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_models = g.num_models
+        g.close()
+    finally:
+        os.remove(path)
+    return dict(value=round(F / dt, 2), unit="frames/s", ms_per_step=round(1e3 * dt / F, 4), frames=F, decode_ms_per_frame=round(decode_ms, 4),
+                log_bytes_per_frame=int(nbytes / F), depth="zlib(uint16 mm)", colour=fmt, active_models_at_end=n_models,
+                note="synthetic stream of this workload written in the reference's .klg format and read back by the library's reader (one host thread: "
+                     "inflate + baseline JPEG decode, then the host-input upload) into processFrame from frame 0 (bootstrap, models spawn on the way) -- "
+                     "decoding is serial with the GPU work here, the reference's LogReader does the same on its one thread")
 
 
 def oracle_trajectory_check(cam, frames, torch, facade, local_rank, args, n_frames=8):

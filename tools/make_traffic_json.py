@@ -28,18 +28,22 @@ def main():
     rocprof = dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in sys.argv[3].split(",")) if len(sys.argv) > 3 else {}
     sha = hashlib.sha256(open(os.path.join(ROOT, "co_fusion_amd", "csrc", "track_reduce.hip"), "rb").read()).hexdigest()
     entries = []
-    for tag, workload, what in ((r"icp_reduce_kernel<\d, 4, false>", "objects4", "ICP reduction of the lock-step models || their RGB residual passes, level 0, box-indexed grids"),
-                                (r"icp_reduce_kernel<\d, 0, false>", "static", "ICP reduction || RGB residual of the background model, level 0 (the pre-roll frames of the same run)")):
-        f, nf = averages(os.path.join(src, "pmc_icp_FETCH_SIZE.txt"), tag)
-        w, nw = averages(os.path.join(src, "pmc_icp_WRITE_SIZE.txt"), tag)
+    for tag, workload, what, stem, pixels in (
+            (r"icp_reduce_kernel<\d, 4, false>", "objects4", "ICP reduction of the lock-step models || their RGB residual passes, level 0, box-indexed grids", "pmc_icp", 307200),
+            (r"icp_reduce_kernel<\d, 0, false>", "static", "ICP reduction || RGB residual of the background model, level 0 (the pre-roll frames of the same run)", "pmc_icp", 307200),
+            (r"icp_reduce_kernel<\d, 0, false>", "big-static", "ICP reduction || RGB residual of one static model at 1280x960, level 0 (round 6: a counter pass of its own)", "pmc_icp_big_static", 1228800)):
+        if not os.path.exists(os.path.join(src, stem + "_FETCH_SIZE.txt")):
+            continue
+        f, nf = averages(os.path.join(src, stem + "_FETCH_SIZE.txt"), tag)
+        w, nw = averages(os.path.join(src, stem + "_WRITE_SIZE.txt"), tag)
         if f is None or w is None:
             continue
-        entries.append(dict(kernel=f"cf::{tag.replace(chr(92) + 'd', 'P')}: {what}", workload=workload, pixels=307200, fetch_size_kb_avg=round(f, 2), write_size_kb_avg=round(w, 2),
+        entries.append(dict(kernel=f"cf::{tag.replace(chr(92) + 'd', 'P')}: {what}", workload=workload, pixels=pixels, fetch_size_kb_avg=round(f, 2), write_size_kb_avg=round(w, 2),
                             dispatches=min(nf, nw), kernel_source_sha256=sha,
                             correction="traffic = 2*FETCH_SIZE*1024 + 1*WRITE_SIZE*1024 (factors measured by tools/microbench/fetch_calib.hip in the same call: pmc_calibration_*.txt)",
                             traffic_bytes_per_launch=int(2 * f * 1024 + w * 1024),
                             **({"rocprofv3_avg_us": rocprof[workload]} if workload in rocprof else {}),
-                            source=f"{os.path.basename(src.rstrip('/'))}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5` (tools/gpu_pmc.sh)"))
+                            source=f"{os.path.basename(src.rstrip('/'))}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py [--workload big-static] --no-cpu-baseline --no-extras --steps 20 --warmup 5` (tools/gpu_r6_measure.sh)"))
     json.dump(entries, open(out, "w"), indent=1)
     print(json.dumps(entries, indent=1))
 
