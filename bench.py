@@ -765,7 +765,7 @@ def klg_input_leg(args, cam, frames, torch, facade, local_rank, n_frames=60):
     from co_fusion_amd import klg
     W, H = args.width, args.height
     n_obj = WORKLOADS[args.workload]["n_obj"]
-    F = min(n_frames, len(frames))
+    F = n_frames   # (the generated stream is short and played back and forth, frame_index)
     try:
         from PIL import Image
         def colour(rgb):
@@ -779,7 +779,7 @@ def klg_input_leg(args, cam, frames, torch, facade, local_rank, n_frames=60):
     with open(path, "wb") as f:
         f.write(struct.pack("<i", F))
         for t in range(F):
-            fr = frames[t]
+            fr = frames[frame_index(t, len(frames))]
             mm = np.rint(fr["depth"] * np.float32(1000.0)).astype(np.uint16)
             zd = zlib.compress(mm.tobytes(), 6)
             jb, fmt = colour(fr["rgb"])
