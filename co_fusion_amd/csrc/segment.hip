@@ -442,6 +442,18 @@ struct SegUnaryArgs {
 // coalesced request; the next step's terms are already in flight), lane-uniform code then feeds the chain of additions from
 // registers through v_readlane.  term(j) -> the j-th term, 0.0f for "skip" (x + 0.0f == x for every x these sums can reach, so
 // skipping an element and adding zero agree).  Returns the sum in every lane.
+// Round 6: the chain itself runs on the vector unit's lane-shift path.  With x_0 = sum + t_0 in lane 0 and x_l = t_l elsewhere, ONE
+// instruction `x = shift_right_by_one_lane(x) + t` (v_add_f32_dpp wave_shr:1; lane 0 has no source lane and keeps its value) turns
+// lane k's value into the sequential prefix P_k = P_(k-1) + t_k once lane k-1 holds P_(k-1): after 63 of them lane 63 holds
+// ((sum + t_0) + t_1) + ... + t_63, every addition in index order (lanes that were already correct are recomputed from the same
+// operands).  63 dependent instructions per 64 terms instead of a v_readlane and an addition per term.
+__device__ __forceinline__ float wave_chain64(float sum, float cur, int lane)
+{
+    float x = lane == 0 ? sum + cur : cur;
+    // (s_nop 1: a DPP read of a VGPR the previous VALU instruction wrote needs two wait states)
+    asm volatile(".rept 63\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr" : "+&v"(x) : "v"(cur));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
 template <class F>
 __device__ __forceinline__ float wave_sequential_sum(float init, int n, int lane, F term)
 {
@@ -451,26 +463,17 @@ __device__ __forceinline__ float wave_sequential_sum(float init, int n, int lane
         const int nj = base + 64 + lane;
         const float nxt = nj < n ? term(nj) : 0.f;
         // lanes past n hold 0.0f, and a step whose 64 terms are all zero changes nothing
-        if (__ballot(cur != 0.f) != 0ull) {
-#pragma unroll
-            for (int g = 0; g < 64; g += 16) {
-                // sixteen independent lane reads into scalar registers first, THEN the dependent chain of additions: interleaved, every
-                // addition waits for its own v_readlane (a VALU-writes-SGPR hazard per term)
-                float t[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++) t[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), g + j));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 16; j++) sum += t[j];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        if (__ballot(cur != 0.f) != 0ull) sum = wave_chain64(sum, cur, lane);
         cur = nxt;
     }
     return sum;
 }
+// (Measured and dropped, round 6: fetching the terms of sixteen blocks first and running sixteen chains from registers -- 17.0 against 13.4 us
+// for the average confidences, 26.4 against 21.8 us for the depth statistics: the chain is ~12 ns per dependent addition however its terms
+// arrive -- DESIGN-NOTES R6.5, and round 4's LDS variants before it.)
 
-// two independent chains in one pass (their additions interleave in the pipeline)
+// two independent chains in one pass (their additions interleave in the pipeline: each chain's next instruction finds its wait states
+// filled by the other's)
 template <class F, class G>
 __device__ __forceinline__ void wave_sequential_sum2(float& sa, float& sb, int n, int lane, F term_a, G term_b)
 {
@@ -479,22 +482,41 @@ __device__ __forceinline__ void wave_sequential_sum2(float& sa, float& sb, int n
         const int nj = base + 64 + lane;
         const float na = nj < n ? term_a(nj) : 0.f, nb = nj < n ? term_b(nj) : 0.f;
         if (__ballot(ca != 0.f || cb != 0.f) != 0ull) {
-#pragma unroll
-            for (int g = 0; g < 64; g += 8) {
-                float ta[8], tb[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    ta[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca), g + j));
-                    tb[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb), g + j));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 8; j++) { sa += ta[j]; sb += tb[j]; }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            float xa = lane == 0 ? sa + ca : ca, xb = lane == 0 ? sb + cb : cb;
+            asm volatile("s_nop 1\n\t.rept 63\n\ts_nop 0\n\tv_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr"
+                         : "+&v"(xa), "+&v"(xb) : "v"(ca), "v"(cb));
+            sa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xa), 63));
+            sb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xb), 63));
         }
         ca = na; cb = nb;
     }
+}
+
+#ifdef CF_ABLATE
+// diagnostics build (CF_SEG_TRACE=<inference>): phase stamps of segmenter 0's two single-workgroup kernels, 100 MHz constant clock
+__device__ unsigned long long g_seg_trace[2][16];
+#define GSTAMP(which, k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) g_seg_trace[which][k] = wall_clock64(); } while (0)
+#else
+#define GSTAMP(which, k) do {} while (0)
+#endif
+// Inclusive scan of one int per thread over the workgroup (<= 1024 threads): a wave-level scan (six shuffle steps), the waves' totals
+// through LDS, every thread adds the totals of the waves in front of it -- two barriers instead of the 2 x log2(T) of the
+// Hillis-Steele loop these kernels used until round 6 (twenty with sixteen waves, a few hundred ns each).  Returns the inclusive prefix;
+// *total = the sum over the workgroup.  s_wave: >= 16 ints of LDS, free before and after.
+__device__ __forceinline__ int block_scan_inclusive(int v, int* s_wave, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x + 63) >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    __syncthreads();   // (s_wave may still be read from a previous scan)
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = 0, all = 0;
+    for (int w = 0; w < nw; w++) { const int t = s_wave[w]; all += t; if (w < wave) before += t; }
+    *total = all;
+    return incl + before;
 }
 
 // Slic::downsample<float> normalisation incl. the empty-superpixel fallback (Slic.h:63-76, 192-206) evaluated in place and in index
@@ -508,9 +530,10 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnary
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float s_min[16], s_max[16];
     __shared__ float s_range;
-    __shared__ int s_scan[1024];
+    __shared__ int s_scan[16];
     __shared__ int s_nempty[2];
     int* empties = reinterpret_cast<int*>(a.raw + (size_t)A * K);  // scratch behind the raw sums: [2][K] (depth-empty, pixel-empty)
+    GSTAMP(0, 0);
     // A: raw sums as f32, phase 1 of the normalisation
     // (eight entries per lane in flight: this workgroup is alone on the GPU, a loop of dependent round trips to HBM -- 13 of them at five
     // models -- was a third of the kernel)
@@ -537,25 +560,20 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnary
             }
         }
     }
+    GSTAMP(0, 1);   // raw sums -> f32, phase 1
     // ordered lists of the empty superpixels (which == 0: no depth sample, which == 1: no pixel at all)
     const int per = (K + T - 1) / T;
     for (int which = 0; which < 2; which++) {
         const unsigned* cnts = which == 0 ? a.depth_count : a.spix_count;
         int c = 0;
         for (int k = tid * per; k < min(K, (tid + 1) * per); k++) c += cnts[k] == 0;
-        s_scan[tid] = c;
-        __syncthreads();
-        for (int o = 1; o < T; o <<= 1) {
-            const int v = tid >= o ? s_scan[tid - o] : 0;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
-        }
-        int pos = s_scan[tid] - c;
+        int total = 0;
+        int pos = block_scan_inclusive(c, s_scan, &total) - c;
         for (int k = tid * per; k < min(K, (tid + 1) * per); k++) if (cnts[k] == 0) empties[which * K + pos++] = k;
-        if (tid == T - 1) s_nempty[which] = s_scan[tid];
+        if (tid == 0) s_nempty[which] = total;
         __syncthreads();
     }
+    GSTAMP(0, 2);   // ordered lists
     // phase 2: empty superpixels in index order, one lane per array
     if (tid < A) {
         float* low = a.low + (size_t)tid * K;
@@ -570,6 +588,7 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnary
         }
     }
     __syncthreads();
+    GSTAMP(0, 3);   // empty superpixels replayed
     // depth range over the valid low-resolution depths (Segmentation.cpp:165-176)
     {
         float mn = 3.402823466e+38f, mx = 0.f;
@@ -593,6 +612,7 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnary
             a.depth_range[0] = s_range;
         }
     }
+    GSTAMP(0, 4);   // depth range
     // average confidence per model: a sequential f32 sum in index order (:193-203), one WAVE per model; non-finite entries count as
     // zero and are zeroed in place afterwards
     for (int m = wave; m < n; m += (T >> 6)) {
@@ -602,6 +622,7 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnary
         if (lane == 0) a.avg_conf[m] = avg / (float)K;
     }
     __syncthreads();
+    GSTAMP(0, 5);   // average confidences
     const float depthRange = s_range;
     // unaries (:237-298, 458-460) and the appearance features (:441-450), one lane per superpixel
     for (int k = tid; k < K; k += T) {
@@ -632,9 +653,11 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnary
         f[5] = fminf(a.low[k] * a.scaleFeaturesDepth, 100.0f);
     }
     __syncthreads();
+    GSTAMP(0, 6);   // unaries + features
     // leave the accumulators clean for the next frame
     for (int k = tid; k < K; k += T) { a.spix_count[k] = 0; a.depth_count[k] = 0; a.depth_sum[k] = 0; }
     for (int idx = tid; idx < n * K; idx += T) { a.icp_sum[idx] = 0; a.conf_sum[idx] = 0; }
+    GSTAMP(0, 7);
 }
 
 // smoothness features of the superpixel grid: addPairwiseGaussian(2, 2) (:437)
@@ -679,7 +702,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
     const int K = a.K, gx = a.gx, L = a.L, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int n_md = a.n_models + (a.allow_new ? 1 : 0);
     __shared__ int s_changed, s_min_label;
-    __shared__ int s_scan[1024];
+    __shared__ int s_scan[16];
     __shared__ int s_id2idx[256];
     __shared__ int s_box[kMaxL + 1][4];   // top, right, bottom, left per model entry (full-resolution pixels after mapToHigh)
     __shared__ unsigned s_spc[kMaxL + 1];
@@ -690,6 +713,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
     __shared__ int comp[kSegMaxK];
     __shared__ int s_cc[6 * kCcLds];
     if (tid == 0) s_min_label = 256;
+    GSTAMP(1, 0);
     // 1. label with the highest marginal (first maximum), as model id
     for (int k = tid; k < K; k += T) {
         int m = 0; float best = a.Q[(size_t)k * L];
@@ -728,25 +752,19 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
         __syncthreads();
         if (!s_changed) break;
     }
+    GSTAMP(1, 1);   // arg-max + connected components
     // 3. number the roots in index order (exclusive scan of the root flags); a root also files its label under its number
     const int per = (K + T - 1) / T;
     int cnt3 = 0;
     for (int k = tid * per; k < min(K, (tid + 1) * per); k++) cnt3 += parent[k] == k;
-    s_scan[tid] = cnt3;
-    __syncthreads();
-    for (int o = 1; o < T; o <<= 1) {
-        const int v = tid >= o ? s_scan[tid - o] : 0;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
-    }
-    const int ncc = s_scan[T - 1];
+    int ncc = 0;
+    const int scan3 = block_scan_inclusive(cnt3, s_scan, &ncc);
     // per-component label, size, top, right, bottom, left: in LDS unless the label image is unusually fragmented
     int* const ccb = ncc <= kCcLds ? s_cc : a.cc;
     const int ccs = ncc <= kCcLds ? kCcLds : K;
     int *c_label = ccb, *c_size = ccb + ccs, *c_top = ccb + 2 * ccs, *c_right = ccb + 3 * ccs, *c_bottom = ccb + 4 * ccs, *c_left = ccb + 5 * ccs;
     {
-        int base = s_scan[tid] - cnt3;
+        int base = scan3 - cnt3;
         for (int k = tid * per; k < min(K, (tid + 1) * per); k++)
             if (parent[k] == k) { comp[k] = base; c_label[base] = map[k]; atomicMin(&s_min_label, (int)map[k]); base++; }
     }
@@ -754,6 +772,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
     __syncthreads();
     for (int k = tid; k < K; k += T) if (parent[k] != k) comp[k] = comp[parent[k]];  // roots wrote their own entry; read-only for them
     __syncthreads();
+    GSTAMP(1, 2);   // roots numbered
     // 4. component statistics.  A wave first combines the lanes that belong to the same component (usually one or two per wave), so
     //    that one lane per (wave, component) touches the shared counters: a thousand atomics on the background's five words otherwise
     //    queue up behind each other
@@ -782,6 +801,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
     }
     __threadfence_block();
     __syncthreads();
+    GSTAMP(1, 3);   // component statistics
     // 5. onlyKeepLargest (:496-517): every label but the smallest keeps its largest component, the earlier one on ties -- the
     //    sequential rule "replace the kept component only by a strictly larger one" picks exactly the maximum of (size, -index)
     if (tid < 256) s_best[tid] = 0;
@@ -833,10 +853,12 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
     }
     __threadfence_block();
     __syncthreads();
+    GSTAMP(1, 4);   // gates
     // 9. final low-resolution label map
     float* const s_depth = reinterpret_cast<float*>(parent);   // the union-find parents are dead: their storage holds the low-resolution depths
     for (int k = tid; k < K; k += T) { const unsigned char v = (unsigned char)c_label[comp[k]]; map[k] = v; a.low_map[k] = v; s_depth[k] = a.low_depth[k]; }
     __syncthreads();
+    GSTAMP(1, 5);   // label map
     // 10. depth statistics with one trimming pass (:570-621) and super-pixel counts (:624-627): sequential f32 sums in index order,
     //     one wave per model entry
     for (int ix = wave; ix < n_md; ix += (T >> 6)) {
@@ -874,6 +896,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
         }
     }
     __syncthreads();
+    GSTAMP(1, 6);   // depth statistics
     if (tid == 0) {
         int has_new = 0, n_out = n_md;
         if (a.allow_new) { if (s_spc[n_md - 1] > 0) has_new = 1; else n_out = n_md - 1; }
@@ -890,6 +913,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
     }
     if (a.low_map_host)
         for (int k = tid; k < (K + 3) / 4; k += T) a.low_map_host[k] = reinterpret_cast<const unsigned*>(map)[k];
+    GSTAMP(1, 7);
 }
 
 
@@ -1288,6 +1312,21 @@ static int enqueue_infer(cf_ctx* ctx, const cf_seg_params* P, const SegJob* jobs
     const int Npx = ctx->cfg.width * ctx->cfg.height;
     seg_upsample_kernel<<<dim3((Npx + 255) / 256, S), 256, 0, st>>>(UP, Npx);
     LAUNCHCHK(ctx);
+#ifdef CF_ABLATE
+    {
+        static const int trace_call = getenv("CF_SEG_TRACE") ? atoi(getenv("CF_SEG_TRACE")) : -1;
+        static int seen = 0;
+        if (trace_call >= 0 && seen++ == trace_call) {
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            unsigned long long h[2][16];
+            HIPCHK(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_seg_trace), sizeof(h)));
+            const char* un[] = {"raw sums", "ordered lists", "empty superpixels", "depth range", "average confidence", "unaries + features", "zeroing"};
+            const char* pn[] = {"arg-max + components", "roots numbered", "component statistics", "gates", "label map", "depth statistics", "publish"};
+            for (int k = 0; k < 7; k++) fprintf(stderr, "[seg trace] unary %-22s %6lld ns\n", un[k], (long long)(h[0][k + 1] - h[0][k]) * 10);
+            for (int k = 0; k < 7; k++) fprintf(stderr, "[seg trace] post  %-22s %6lld ns\n", pn[k], (long long)(h[1][k + 1] - h[1][k]) * 10);
+        }
+    }
+#endif
     for (int e = 0; e < S; e++) {
         cf_segmenter* s = jobs[e].s;
         if (s->poses_published) {  // the tail now holds what the caller's all-reduce made of it; the next frame starts from zeros again

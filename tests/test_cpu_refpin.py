@@ -550,8 +550,9 @@ def _ate(a, b):
 
 
 # CPU budget: the oracle needs ~2 s per 640x480 model-frame; the long 640x480 scenarios are played for this many frames here (their full
-# length on the MI355X, tests/test_configs_gpu.py, and here with COFUSION_LONG_TESTS=1)
-CPU_FRAMES_640 = 60
+# length on the MI355X, tests/test_configs_gpu.py, and here with COFUSION_LONG_TESTS=1).  36 since round 6 (60 until then: five minutes of an
+# almost ten-minute CPU suite) -- the comparison that must not lose a frame, exact parity under the reference-order arithmetic, has its own tests
+CPU_FRAMES_640 = 36
 CPU_FRAMES_640_EXACT = 10   # ... and of the bit-for-bit comparison under the reference-order arithmetic (a tree-ordered f32 sum is serial in the oracle)
 
 
@@ -591,12 +592,12 @@ def test_trajectory_within_1mm_ate_of_the_reference_arithmetic():
         assert proc.returncode == 0, f"{name}: {err_text.decode()[-2000:]}"
         o = np.load(out); os.remove(out)
         reports[name] = trajpin.compare(name, o["poses"], o["ids"], o["counts"], z=z)
-    assert reports["static_camera_640"]["frames"] >= 60 and reports["crf_two_objects_640"]["frames"] >= 40 and reports["gt_masks_two_objects_640"]["frames"] >= 40
+    assert min(reports[n]["frames"] for n in ("static_camera_640", "crf_two_objects_640", "gt_masks_two_objects_640")) >= CPU_FRAMES_640
     # round 5: two textured boxes with ground-truth masks -- lists identical throughout, both objects compared over their whole life, counts
     # within 2 %, the large one (11-21 k surfels) within the tight bound
     boxes = reports["gt_masks_two_boxes_640"]
-    assert boxes["lists_identical_frames"] == boxes["frames"] >= 60 and len(boxes["objects"]) == 2
-    assert all(o["frames"] >= 50 and o["count_max_rel_diff"] <= 0.02 for o in boxes["objects"].values()), boxes["objects"]
+    assert boxes["lists_identical_frames"] == boxes["frames"] >= CPU_FRAMES_640 and len(boxes["objects"]) == 2
+    assert all(o["frames"] >= CPU_FRAMES_640 - 10 and o["count_max_rel_diff"] <= 0.02 for o in boxes["objects"].values()), boxes["objects"]
     assert any(o["stable_in_reference"] and o["max_m"] <= trajpin.OBJECT_BOUND_M for o in boxes["objects"].values()), boxes["objects"]
     assert sum(len(r["objects"]) for r in reports.values()) >= 4, "no object trajectory was compared"
 
