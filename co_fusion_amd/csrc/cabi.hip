@@ -1093,6 +1093,11 @@ int cf_odom_track_batch_async(cf_ctx* ctx, cf_odom* const* ods, int n, const flo
     LAUNCHCHK(ctx);
 #ifdef CF_ABLATE
     if (solve_trace) trace_solve_end(ctx->stream, getenv("CF_ICP_TRACE_OUT") ? getenv("CF_ICP_TRACE_OUT") : "solve_trace.txt");
+    {
+        static const int so3_trace_call = getenv("CF_SO3_TRACE") ? atoi(getenv("CF_SO3_TRACE")) : -1;   // stamps of that call's SO(3) pre-alignment (tracker 0)
+        static int so3_seen = 0;
+        if (so3_trace_call >= 0 && so3_seen++ == so3_trace_call) trace_so3_dump(ctx->stream);
+    }
     // diagnostics: CF_ICP_REPLAY=<call> re-launches the level-0 {ICP || residual} launch of that tracking call (its converged state) back
     // to back under a list of ablation masks and prints the durations -- the decomposition of the launch quoted in DESIGN.md 4.1
     static const int replay_call = getenv("CF_ICP_REPLAY") ? atoi(getenv("CF_ICP_REPLAY")) : -1;

@@ -332,6 +332,7 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
 void rgb_prep_levels(RgbPrepBatch& b, int n, int W, int H);
 float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, int n, int slots, int ablate, int reps, hipEvent_t e0, hipEvent_t e1);
 #ifdef CF_ABLATE
+void trace_so3_dump(hipStream_t s);
 void trace_solve_begin();
 void trace_solve_end(hipStream_t s, const char* path);
 void trace_step_solve(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const RgbArgs& r0, So3Sync* syncs, int n, const char* path);

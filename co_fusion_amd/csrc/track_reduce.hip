@@ -1029,6 +1029,9 @@ __device__ __forceinline__ void so3_pass(const uint8_t* __restrict__ lastImage, 
     for (int k = 0; k < 16; k++) acc[k] = 0;
     const float a = krlr[0], b = krlr[1], c = krlr[2], d = krlr[3], e = krlr[4], f = krlr[5], g = krlr[6], h = krlr[7],
                 ii = krlr[8];
+    // (Measured and dropped, round 6: four pixels of a thread at a time -- their warps first, the 4 x 10 byte loads of the gradient stencils in
+    // flight together, then the rows: so3_prealign_kernel 82.0 against 63.1 us on one box, profiles/r6u_*.  The registers of four stencils
+    // cost the launch's other half, the RGB preparation workgroups, their occupancy; the pass itself is 4-7 us of a 9 us iteration.)
     for (int k = block * T + threadIdx.x; k < N; k += blocks * T) {
         const int y = k / cols, x = k - y * cols;
         const f3 unwarped = {(float)x, (float)y, 1.0f};
@@ -1157,6 +1160,13 @@ __device__ __forceinline__ unsigned long long l2_read_u64(unsigned long long* p)
 // The tracker state of the call arrives here as well: the host fills its pinned copy, every pre-alignment workgroup stages that copy into
 // LDS (one coalesced read over PCIe, hidden beside the preparation workgroups) and the lead workgroup of each tracker stores it into the
 // device state the rest of the schedule reads -- no copy command in front of the loop (two of them cost ~10 us on the stream per frame).
+#ifdef CF_ABLATE
+// diagnostics build (CF_SO3_TRACE): stamps of tracker 0's lead workgroup in the pre-alignment loop, [iteration][8]
+__device__ unsigned long long g_so3_trace[12][8];
+#define OSTAMP(it, k) do { if (lead && by == 0 && threadIdx.x == 0) g_so3_trace[it][k] = wall_clock64(); } while (0)
+#else
+#define OSTAMP(it, k) do {} while (0)
+#endif
 __global__ void __launch_bounds__(256) so3_prealign_kernel(const TrackerStates ts, So3Sync* __restrict__ syncs, int do_so3,
                                                            int first_level, int gx, int so3_blocks, const RgbPrepBatch prep, int prep_bx)
 {
@@ -1214,7 +1224,9 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(const TrackerStates t
     if (do_so3) {
         const uint8_t* __restrict__ lastNext = od->lastNextImage[L];
         const uint8_t* __restrict__ next = od->nextImage[L];
+        OSTAMP(11, 0);
         for (int it = 0; it < 10; it++) {
+            OSTAMP(it, 0);
             if (threadIdx.x == 0) {
                 double tmp[9], H[9];
                 mul33<double>(s_K, s_resultR, tmp);
@@ -1224,7 +1236,9 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(const TrackerStates t
             __syncthreads();
             m33 B, Ki;
             for (int k = 0; k < 9; k++) { B.m[k] = s_basis[k]; Ki.m[k] = s_kinv[k]; }
+            OSTAMP(it, 1);
             so3_pass(lastNext, next, B, Ki, s_krlr, cols, rows, lds, totals, bx, (int)G);  // ends with this workgroup's totals in LDS
+            OSTAMP(it, 2);
             if (G > 1) {
                 if (threadIdx.x < 64) {  // wave 0: publish, arrive, wait, collect -- everything in this XCD's L2
                     unsigned long long* slot = sync->acc[it];
@@ -1245,6 +1259,7 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(const TrackerStates t
                 }
                 __syncthreads();
             }
+            OSTAMP(it, 3);
             if (threadIdx.x == 0) {
                 float jtj[9], jtr[3], residual[2];
                 so3_unpack(totals, jtj, jtr, residual);
@@ -1275,8 +1290,10 @@ __global__ void __launch_bounds__(256) so3_prealign_kernel(const TrackerStates t
                 if (lead) { god->stats.last_so3_error = err; god->stats.last_so3_count = cnt; }
             }
             __syncthreads();
+            OSTAMP(it, 4);
             if (s_done) break;
         }
+        OSTAMP(11, 1);
         if (G > 1 && threadIdx.x == 0) {  // last one out resets the sync block (all workgroups are past their final read)
             if (__hip_atomic_fetch_add(&sync->depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == G - 1) {
                 for (int it = 0; it < 10; it++)
@@ -2117,6 +2134,21 @@ float replay_icp_level0(hipStream_t s, IcpLaunch cfg, const IcpArgs& a0, const R
 }
 
 #ifdef CF_ABLATE
+// diagnostics (CF_SO3_TRACE): the stamps of the last pre-alignment, printed
+void trace_so3_dump(hipStream_t s)
+{
+    (void)hipStreamSynchronize(s);
+    unsigned long long h[12][8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_so3_trace), sizeof(h)) != hipSuccess) return;
+    fprintf(stderr, "[so3 trace] loop %lld ns\n", (long long)(h[11][1] - h[11][0]) * 10);
+    for (int it = 0; it < 10; it++) {
+        if (!h[it][0] || h[it][4] < h[it][0]) continue;
+        fprintf(stderr, "[so3 trace] it %d: basis %5lld  pass %5lld  meeting %5lld  solve %5lld ns\n", it, (long long)(h[it][1] - h[it][0]) * 10,
+                (long long)(h[it][2] - h[it][1]) * 10, (long long)(h[it][3] - h[it][2]) * 10, (long long)(h[it][4] - h[it][3]) * 10);
+    }
+    unsigned long long z[12][8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_so3_trace), z, sizeof(z));
+}
 // diagnostics (CF_SOLVE_TRACE): phase stamps of tracker 0's solves of the tracking call enqueued between begin and end
 static unsigned long long* g_solve_trace_dev = nullptr;
 void trace_solve_begin()
