@@ -257,6 +257,22 @@ def test_screen_box_culling_leaves_the_gauss_newton_loop_bit_identical():
     tb, rb, sb = run_twice(True)
     assert ta.tobytes() == tb.tobytes() and ra.tobytes() == rb.tobytes() and sa.last_icp_count == sb.last_icp_count > 100
     assert list(sb.cull_box) == [0, 0, W - 1, H - 1], "second call on one preparation: whole image"
+    # a tracking call that starts from ANOTHER pose than the one the model maps were prepared with (a motion-model guess): the
+    # screen box is the projection of a frustum piece expressed in the preparation's camera, so the library must not use it -- same bits as
+    # without culling, and the box reported is the whole image
+    def run_from(start, cull):
+        g = api.Odometry(ctx)
+        g.set_culling(cull)
+        g.init_first_rgb(d(fp["rgba0"])); g.init_icp_model(d(v4), d(n4), pose); g.init_rgb_model(d(fp["img"]))
+        g.init_icp(ctx.depth_pyramid(d(fp["d1"])), 20.0); g.init_rgb(d(fp["rgba1"]))
+        out = g.track(start[:3, 3], start[:3, :3])
+        g.close()
+        return out
+    start = pose.copy(); start[:3, 3] += np.array([0.02, -0.015, 0.01], np.float32)
+    tc, rc, sc = run_from(start, False)
+    td, rd, sd = run_from(start, True)
+    assert tc.tobytes() == td.tobytes() and rc.tobytes() == rd.tobytes() and sc.last_icp_count == sd.last_icp_count > 100
+    assert list(sd.cull_box) == [0, 0, W - 1, H - 1], "a call from another pose than the preparation's: no screen box"
     # an empty prediction: everything culled
     z4 = np.zeros_like(v4)
     t2, r2, s2, _ = run(z4, z4, True)
