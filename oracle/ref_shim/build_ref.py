@@ -105,8 +105,9 @@ def main() -> int:
         subprocess.check_call(["g++", *seg_flags, "-c", os.path.join(seg_dir, "Slic.cpp"), "-o", obj])
         objs.append(obj)
         os.makedirs(os.path.join(tmp, "Segmentation")); os.makedirs(os.path.join(tmp, "Model"))
-        with open(os.path.join(tmp, "Model", "Model.h"), "w") as f:
-            f.write(open(os.path.join(HERE, "stub", "Model", "Model.h")).read())
+        for rel_src, rel_dst in ((os.path.join("Model", "Model.h"), "Model.h"), ("GPUTexture.h", "GPUTexture.h"), ("glpin.h", "glpin.h")):
+            with open(os.path.join(tmp, "Model", rel_dst), "w") as f:   # (the stand-in's own includes resolve beside it, not to Core/GPUTexture.h)
+                f.write(open(os.path.join(HERE, "stub", rel_src)).read())
         gen = os.path.join(tmp, "Segmentation", "Segmentation_gen.cpp")
         with open(gen, "w") as f:
             f.write(f'#line 1 "{os.path.join(seg_dir, "Segmentation.cpp")}"\n' + open(os.path.join(seg_dir, "Segmentation.cpp")).read() +
@@ -147,6 +148,14 @@ def main() -> int:
             start = next(i for i, l in enumerate(cofusion_cpp) if l.startswith(sig))
             end = next(i for i in range(start, len(cofusion_cpp)) if cofusion_cpp[i] == "}")
             pieces.append(f'#line {start + 1} "{os.path.join(REF, "Core", "CoFusion.cpp")}"\n' + "\n".join(cofusion_cpp[start:end + 1]))
+        # ... and, since round 6, the four Model methods the loop drives per model (Core/Model/Model.cpp, cut the same way): their OpenGL
+        # calls are recorded by stub/glpin.h and the draw handler of ref_cofusion.cpp runs the oracle's pass with what was recorded
+        model_cpp_path = os.path.join(REF, "Core", "Model", "Model.cpp")
+        model_lines = open(model_cpp_path).read().split("\n")
+        for sig in ("void Model::initICP(", "void Model::performTracking(", "void Model::fuse(", "void Model::clean("):
+            start = next(i for i, l in enumerate(model_lines) if l.startswith(sig))
+            end = next(i for i in range(start, len(model_lines)) if model_lines[i] == "}")
+            pieces.append(f'#line {start + 1} "{model_cpp_path}"\n' + "\n".join(model_lines[start:end + 1]))
         gen = os.path.join(tmp, "CoFusion_gen.cpp")
         with open(gen, "w") as f:
             f.write('#include "CoFusionPin.h"\n' + "\n".join(pieces) + f'\n#include "{os.path.join(HERE, "ref_cofusion.cpp")}"\n')

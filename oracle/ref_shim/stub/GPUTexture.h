@@ -19,6 +19,7 @@ class GPUTexture {
   public:
     struct GlTexture {
         GPUTexture* owner;
+        unsigned tid;   // the GL texture name the reference's glBindTexture calls pass around (stub/glpin.h records them)
         // glTexSubImage2D into the texture's storage: GL_RGB bytes land in an RGBA8 texture with alpha 255, luminance data as they are
         void Upload(const void* data, int format, int /*type*/)
         {
@@ -36,9 +37,17 @@ class GPUTexture {
     static constexpr const char* DEPTH_NORM = "DEPTH_NORM";
     static constexpr const char* MASK_COLOR = "MASKS_COLOR";
 
-    GPUTexture(void* texels, int width, int height) : arr{texels, width, height}, texel_bytes(0), gl{this}, texture(&gl) {}  // a view
+    GPUTexture(void* texels, int width, int height) : arr{texels, width, height}, texel_bytes(0), gl{this, enrol(this)}, texture(&gl) {}  // a view
     GPUTexture(int width, int height, int bytes_per_texel)
-        : own((size_t)width * height * bytes_per_texel, 0), arr{own.data(), width, height}, texel_bytes(bytes_per_texel), gl{this}, texture(&gl) {}
+        : own((size_t)width * height * bytes_per_texel, 0), arr{own.data(), width, height}, texel_bytes(bytes_per_texel), gl{this, enrol(this)}, texture(&gl) {}
+    ~GPUTexture() { registry()[gl.tid] = nullptr; }
+    // texture name -> object (what a recorded glBindTexture resolves to); a view may be re-pointed at new storage of the same size
+    static std::vector<GPUTexture*>& registry() { static std::vector<GPUTexture*> r(1, nullptr); return r; }
+    static unsigned enrol(GPUTexture* t) { registry().push_back(t); return (unsigned)registry().size() - 1; }
+    static GPUTexture* by_name(unsigned tid) { return tid < registry().size() ? registry()[tid] : nullptr; }
+    void repoint(void* texels) { arr.data = texels; }
+    // Model::performTracking hands the error textures to the tracker as CUDA surfaces (Model.cpp:383-384): here the object itself
+    cudaSurfaceObject_t getCudaSurface() { return (cudaSurfaceObject_t)(uintptr_t)this; }
     GPUTexture(const GPUTexture&) = delete;
     GPUTexture& operator=(const GPUTexture&) = delete;
     void cudaMap() {}

@@ -15,14 +15,27 @@
 #include <memory>
 #include <vector>
 
-class GPUTexture;
+#include "GPUTexture.h"
+#include "glpin.h"               // the recording OpenGL behind the text of Model::fuse / Model::clean (round 6)
+#include "Utils/Intrinsics.h"    // the reference's own (header-only singleton)
+#include "Utils/Resolution.h"    // the reference's own
+
 class FeedbackBuffer;
 struct ModelImpl;
+struct Vertex { static const int SIZE = sizeof(Eigen::Vector4f) * 3; };   // Shaders/Vertex.cpp:43
 
 // ModelProjection: only the prediction kind (ModelProjection.h:41) and the texture getters the dead loop-closure branch names
 class ModelProjection {
   public:
     enum Prediction { ACTIVE, INACTIVE };
+    static const int FACTOR = 1;                                           // ModelProjection.cpp:22
+    // the index-map textures Model::fuse / Model::clean bind (ModelProjection.h:60-70): views of the owning model's buffers (ref_cofusion.cpp)
+    GPUTexture* getSparseIndexTex() { return sparseIndex; }
+    GPUTexture* getSparseVertConfTex() { return sparseVertConf; }
+    GPUTexture* getSparseColorTimeTex() { return sparseColorTime; }
+    GPUTexture* getSparseNormalRadTex() { return sparseNormalRad; }
+    GPUTexture* getDepthTex() { return depthTex; }
+    GPUTexture *sparseIndex = nullptr, *sparseVertConf = nullptr, *sparseColorTime = nullptr, *sparseNormalRad = nullptr, *depthTex = nullptr;
     GPUTexture* getOldVertexTex() { return nullptr; }
     GPUTexture* getOldNormalTex() { return nullptr; }
     GPUTexture* getOldImageTex() { return nullptr; }
@@ -41,11 +54,15 @@ class PinOdometry {
     PinOdometry(const PinOdometry&) = delete;
     void initFirstRGB(GPUTexture* rgb);
     Eigen::MatrixXd getCovariance();                       // ref_cofusion.cpp: orc_covariance of the last tracking call's lastA
-    template <class... A> void initICPModel(A&&...) {}   // (dead loop-closure branch of processFrame)
-    template <class... A> void initRGBModel(A&&...) {}
-    template <class... A> void initICP(A&&...) {}
-    template <class... A> void initRGB(A&&...) {}
-    template <class... A> void getIncrementalTransformation(A&&...) {}
+    // the five calls of Model::initICP / performTracking (Model.cpp:350-389: that text drives them since round 6), RGBDOdometry.h:42-64
+    void initICPModel(GPUTexture* predictedVertices, GPUTexture* predictedNormals, const float depthCutoff, const Eigen::Matrix4f& modelPose);
+    void initRGBModel(GPUTexture* rgb);
+    void initICP(const std::vector<std::vector<float>>& depthPyramid, const std::vector<std::vector<unsigned char>>& maskPyramid, const float depthCutoff);
+    void initICP(GPUTexture*, GPUTexture*, const float) {}   // (the texture flavour: only the dead loop-closure branch of processFrame calls it)
+    void initRGB(GPUTexture* rgb);
+    void getIncrementalTransformation(Eigen::Vector3f& trans, Eigen::Matrix<float, 3, 3, Eigen::RowMajor>& rot, const bool& rgbOnly, const float& icpWeight,
+                                      const bool& pyramid, const bool& fastOdom, const bool& so3, const cudaSurfaceObject_t& icpErrorSurface = 0,
+                                      const cudaSurfaceObject_t& rgbErrorSurface = 0);
     float lastICPError = 0, lastICPCount = 0;
     double lastA[36] = {0};
     void* orc = nullptr;  // orc_odometry*
@@ -55,6 +72,23 @@ class PinOdometry {
 class Model {
   public:
     enum class MatchingType { Drost };
+    // ---- what the TEXT of Model::initICP / performTracking / fuse / clean uses (Model.h:52-330), round 6 ----
+    struct OutputBuffer { GLuint dataBuffer = 0, stateObject = 0; };       // Shaders/Shaders.h
+    struct GPUSetup {
+        static GPUSetup& getInstance() { static GPUSetup g; return g; }
+        std::shared_ptr<Shader> dataProgram{new Shader("data")}, updateProgram{new Shader("update")}, unstableProgram{new Shader("unstable")};
+        struct { int width = 0, height = 0; } renderBuffer;
+        struct { void Bind() const {} void Unbind() const {} } frameBuffer;
+        GPUTexture updateMapVertsConfs{1, 1, 16}, updateMapColorsTime{1, 1, 16}, updateMapNormsRadii{1, 1, 16};
+        std::vector<std::vector<float>> depth_tmp{3};
+        std::vector<std::vector<unsigned char>> mask_tmp{3};
+        float outlierCoefficient = 0.9;
+    };
+    static const int TEXTURE_DIMENSION = 3072, NODE_TEXTURE_DIMENSION = 16384, MAX_NODES = 16384 / 16;   // Model.cpp:95-100
+    void initICP(bool doFillIn, bool frameToFrameRGB, float depthCutoff, GPUTexture* rgb);
+    float computeFusionWeight(float weightMultiplier) const;   // ref_cofusion.cpp: the oracle's (its text is pinned on its own: ref_weight.cpp)
+    GPUTexture* getVertexConfProjection();
+    GPUTexture* getNormalProjection();
     // Segmentation pin (ref_seg.cpp): a model that only carries the two images the segmentation downloads
     Model(unsigned char id, cv::Mat vertConf /* CV_32FC4 */, cv::Mat icpError /* CV_32FC1 */) : id_(id), vc_(vertConf), icp_(icpError) {}
     // Model.h:117-119
@@ -85,9 +119,9 @@ class Model {
     void setConfidenceThreshold(float confThresh) { confidenceThreshold = confThresh; }
     void setMaxDepth(float d) { maxDepth = d; }
     GPUTexture* getRGBProjection();
-    GPUTexture* getFillInImageTexture() { return nullptr; }   // (dead loop-closure branch)
-    GPUTexture* getFillInNormalTexture() { return nullptr; }
-    GPUTexture* getFillInVertexTexture() { return nullptr; }
+    GPUTexture* getFillInImageTexture();
+    GPUTexture* getFillInNormalTexture();
+    GPUTexture* getFillInVertexTexture();
     int getModel() { return 0; }
     const Eigen::Matrix4f& getPose() const { return pose; }                                                         // Model.h:215-222
     void overridePose(const Eigen::Matrix4f& p) { pose = p; lastPose = p; }
@@ -107,14 +141,29 @@ class Model {
     Eigen::Matrix4f pose, lastPose;
     float confidenceThreshold = 0, maxDepth = 0;
     unsigned unseenCount = 0;
+    // members the pasted text names (Model.h:236-330)
+    OutputBuffer vbos[2], newUnstableBuffer;
+    int target = 0, renderSource = 1;      // swapped after FUSE and CLEAN
+    GLuint countQuery = 0;
+    unsigned int count = 0;
+    static GPUTexture deformationNodes;
+    GLuint uvo = 0;
+    int uvSize = 0;
+    unsigned int id = 0;
+    std::unique_ptr<GPUTexture> icpError, rgbError;
+    const GPUSetup& gpu = GPUSetup::getInstance();
+    ModelProjection indexMap;
+    PinOdometry* frameToModelPtr = nullptr;
+    std::unique_ptr<char> fillIn;          // non-null: the model allows fill-in (the text only tests it)
 
   private:
     unsigned int id_;
     cv::Mat vc_, icp_;
     bool fillIn_ = false;
     std::vector<PoseLogItem> poseLog;
-    ModelProjection indexMap;
 };
+// `frameToModel` is a member object in the reference; the pasted text reaches the stand-in's tracker through this
+#define frameToModel (*frameToModelPtr)
 typedef std::shared_ptr<Model> ModelPointer;
 typedef std::list<ModelPointer> ModelList;
 typedef ModelList::iterator ModelListIterator;

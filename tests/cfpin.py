@@ -114,7 +114,7 @@ def run_oracle(name):
 CONF_RTOL = 1e-4
 
 
-def run_reference_isolated(name):
+def run_reference_isolated(name, glpin_mutation=0):
     """run_reference in a process of its own.  Core/Segmentation/Segmentation.cpp:64 keeps the ground-truth label -> model id table
     in a FUNCTION-STATIC vector and indexes an uninitialised `modelIdToIndex[256]` with whatever it finds there: a second CoFusion
     instance in the same process inherits the first one's table, writes labels of models it does not have and then runs off the
@@ -127,7 +127,11 @@ def run_reference_isolated(name):
     code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import cfpin; rows = cfpin.run_reference(%r); "
             "[r.__setitem__('pose_log', [list(map(float, p)) for p in r['pose_log']]) for r in rows]; print('CFPIN_JSON' + json.dumps(rows))"
             % (here, os.path.dirname(here), name))
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+    env = dict(os.environ)
+    env.pop("COFUSION_GLPIN_MUTATE", None)
+    if glpin_mutation:   # corrupt the recorded OpenGL state behind the pasted Model::fuse / Model::clean text (ref_cofusion.cpp)
+        env["COFUSION_GLPIN_MUTATE"] = str(int(glpin_mutation))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=env).stdout
     line = [l for l in out.split("\n") if l.startswith("CFPIN_JSON")][-1]
     return json.loads(line[len("CFPIN_JSON"):])
 

@@ -63,3 +63,9 @@ class RefCoFusion:
         m = np.zeros((self.h, self.w), np.uint8)
         self.lib.ref_cf_mask(C.c_void_p(self.h_), P(m))
         return m
+
+    def gl_draws(self):
+        """draw calls of the pasted Model::fuse / Model::clean text served so far in this process: (data, update, unstable)"""
+        d = (C.c_uint * 3)()
+        self.lib.ref_cf_glpin_draws(d)
+        return tuple(int(x) for x in d)

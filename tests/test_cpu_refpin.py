@@ -8,6 +8,7 @@ CPU SIMT emulator of oracle/ref_shim and executed on seeded inputs (tests/golden
     second-stage reduceSum) is bit-exact; the order-independent exact fixed-point sums the HIP path uses agree to f32 rounding
     of that tree (refpin.SUM_RTOL of the largest entry)."""
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -534,6 +535,33 @@ def test_frame_loop_fixture_is_what_the_reference_text_produces():
     for name in ("crf_two_objects", "gt_masks_three_objects"):
         rows = cfpin.run_reference_isolated(name)
         assert rows == gold[name], f"{name}: the reference frame loop no longer produces the committed fixture"
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_model_argument_plumbing_runs_on_the_reference_text_and_the_pin_has_teeth():
+    """Model::initICP / performTracking / fuse / clean (Core/Model/Model.cpp:350-389, 408-697) are compiled as TEXT behind a recording
+    OpenGL (oracle/ref_shim/stub/glpin.h): which uniform gets which value, which texture sits on which sampler, which buffer is read and
+    which written is decided by that text, and the draw handler runs the oracle's pass with what was recorded.  The frame-loop fixture
+    (which the C++ facade reproduces bit for bit, tests/test_configs_gpu.py) comes out of that path -- the test above -- and stops coming
+    out of it when the recorded state is corrupted the way a plumbing mistake would: depth textures on each other's units, the clean
+    pass's depth sampler on the wrong unit, a time uniform one frame late."""
+    import refcofusion
+    import cfpin
+    gold = _cf_golden()
+    cam, frames = cfpin.frames_of("static")
+    cf = refcofusion.RefCoFusion(cam, conf_global=10.0, spawn_offset=20, multi=False)
+    before = cf.gl_draws()
+    for t, (d, rgb, _, _) in enumerate(frames[:3]):
+        cf.process_frame(d, rgb, timestamp=t)
+    after = cf.gl_draws()
+    # frame 0 initialises the map (no fuse / clean); each later frame: one data + one update draw in fuse, two feedback draws in clean
+    assert tuple(a - b for a, b in zip(after, before)) == (2, 2, 4)
+    for mutation in (1, 2, 3):
+        try:
+            rows = cfpin.run_reference_isolated("crf_two_objects", glpin_mutation=mutation)
+        except subprocess.CalledProcessError:
+            continue   # the handler's own cross-checks (e.g. both passes of fuse must name the same time) stopped the run: noticed
+        assert rows != gold["crf_two_objects"], f"corruption {mutation} of the recorded GL state went unnoticed"
 
 
 # ---- trajectory level: the reference's own arithmetic as the tracker of the frame loop (VERDICT r2, item 3) ----------------------------
