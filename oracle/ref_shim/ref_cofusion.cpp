@@ -158,7 +158,7 @@ Model::Model(unsigned char id_arg, float confidenceThresh, bool enableFillIn, bo
     newUnstableBuffer.dataBuffer = glpin::new_id(); newUnstableBuffer.stateObject = glpin::new_id();
     g_buffers[newUnstableBuffer.dataBuffer] = BufferName{this, 2}; g_buffers[newUnstableBuffer.stateObject] = BufferName{this, 2};
     uvo = glpin::new_id(); g_buffers[uvo] = BufferName{this, 3};
-    uvSize = (g_w / 2) * (g_h / 2) > 0 ? g_w * g_h : 0;   // one texcoord per pixel (Model.cpp:166-170); only handed to glDrawArrays
+    uvSize = g_w * g_h;   // one texture coordinate per pixel, column-major (Model.cpp:164-172); the text only hands the count to glDrawArrays
     countQuery = glpin::new_id();
     icpError.reset(new GPUTexture(impl->icp_error.data(), g_w, g_h));
     rgbError.reset(new GPUTexture(1, 1, 4));
