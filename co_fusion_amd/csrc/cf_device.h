@@ -486,8 +486,8 @@ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tiny, T* ws,
 }
 
 // ---- the same 6x6 factorisation, spread over one wave -------------------------------------------------
-// Lane t < 36 owns A[t/6][t%6] in a register (only the lower triangle is kept up to date); pivot search, column broadcast and the
-// substitutions use v_readlane (uniform lane ids), the symmetric row/column swap one ds_bpermute.  Every
+// Lane t < 36 owns A[t/6][t%6] in a register (only the lower triangle is kept up to date); pivot search and the substitutions use
+// v_readlane (uniform lane ids), the column broadcast and the symmetric row/column swap ds_bpermute.  Every
 // element goes through exactly the operations of ldlt_solve<double, 6> in the same order (right-looking
 // update, one update per k), so the result is bit-identical; the serial version stays for N = 3 / f32.
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -497,6 +497,12 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ double bpermute_f64(double v, int byte_addr)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 // must be called by all 64 lanes of a wave; lanes 0..35: A[lane / 6][lane % 6], lanes 36..41: b[lane - 36]; x: [6] (LDS, written by lane 0).
 // Round 6: the right-hand side rides along as a seventh column -- L y = P b is solved INSIDE the factorisation (at step k every later
 // entry takes b_i - l_ik * y_k: for a fixed i the very multiplications and subtractions of the forward substitution, in its order
@@ -510,23 +516,27 @@ __device__ __forceinline__ void ldlt_solve6_wave(double a, double* x, double tin
     double d[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        int p = k;
+        // Pivot: the first q >= k whose |a_qq| is the largest (the serial scan `if (v > best)` keeps the first of equal values).  The
+        // entries are finite (integer sums, scaled), so that is the lowest q with |a_qq| == max: five v_max_f64 on lane values read
+        // into scalar registers, then one compare + select per candidate -- the scan itself was thirteen instructions per candidate,
+        // a fifth of the factorisation (round 6, from the ISA).
+        int p = 5;
         {
-            const double akk0 = readlane_f64(a, k * 7);
-            double best = akk0 < 0 ? -akk0 : akk0;
+            double dq[6];
 #pragma unroll
-            for (int q = k + 1; q < 6; q++) {
-                const double aqq = readlane_f64(a, q * 7);
-                const double v = aqq < 0 ? -aqq : aqq;
-                if (v > best) { best = v; p = q; }
-            }
+            for (int q = k; q < 6; q++) dq[q] = __builtin_fabs(readlane_f64(a, q * 7));
+            double M = dq[k];
+#pragma unroll
+            for (int q = k + 1; q < 6; q++) M = __builtin_fmax(M, dq[q]);
+#pragma unroll
+            for (int q = 5; q >= k; q--) p = (dq[q] == M) ? q : p;
         }
         p = __builtin_amdgcn_readfirstlane(p);
         if (p != k) {
             // symmetric transposition k <-> p on the LOWER triangle: element (i, j), i >= j, takes S(pi(i), pi(j)) of the symmetric matrix,
             // which lives at (max, min) of the two indices; the right-hand side swaps entries k and p
             const int si = (i == k) ? p : ((i == p) ? k : i), sj = (j == k) ? p : ((j == p) ? k : j);
-            a = __shfl(a, isB ? 36 + si : (si > sj ? si : sj) * 6 + (si > sj ? sj : si));
+            a = bpermute_f64(a, (isB ? 36 + si : (si > sj ? si : sj) * 6 + (si > sj ? sj : si)) * 4);
             const int pk = perm[k];
             int pp = pk;
 #pragma unroll
@@ -539,13 +549,11 @@ __device__ __forceinline__ void ldlt_solve6_wave(double a, double* x, double tin
         const double aabs = akk < 0 ? -akk : akk;
         const bool pivot_ok = aabs > tiny;
         if (j == k && i > k) a = pivot_ok ? a / akk : 0.0;
-        double lik = 0, ljk = 0;
-#pragma unroll
-        for (int q = k + 1; q < 6; q++) {
-            const double c = readlane_f64(a, q * 6 + k);
-            if (i == q) lik = c;
-            if (j == q) ljk = c;
-        }
+        // column k of L for this lane's row and column: two shuffles (lane i*6+k, lane j*6+k; the constant 4k rides in the instruction's
+        // offset field).  Until round 6 a chain of lane reads and selects, ten instructions per remaining row: 2040 -> 1840 ns for the
+        // factorisation (in-kernel clocks, profiles/r6ld_*); shuffling only the first two or three steps: 1880.
+        const double lik = bpermute_f64(a, (i * 6 + k) * 4);
+        const double ljk = bpermute_f64(a, (j * 6 + k) * 4);   // (the right-hand side's lanes, "column 6", read a lane they do not use)
         const double yk = readlane_f64(a, 36 + k);
         if (isB) { if (i > k) a = a - lik * yk; }
         else if (pivot_ok && i > k && j > k && j <= i) a = a - lik * akk * ljk;
