@@ -438,15 +438,48 @@ struct SegUnaryArgs {
     float* depth_range;              // [1]
 };
 
-// Sequential f32 sum init + t[0] + t[1] + ... + t[n-1] (this order) by ONE wave: the lanes fetch 64 consecutive terms per step (one
-// coalesced request; the next step's terms are already in flight), lane-uniform code then feeds the chain of additions from
-// registers through v_readlane.  term(j) -> the j-th term, 0.0f for "skip" (x + 0.0f == x for every x these sums can reach, so
-// skipping an element and adding zero agree).  Returns the sum in every lane.
-// Round 6: the chain itself runs on the vector unit's lane-shift path.  With x_0 = sum + t_0 in lane 0 and x_l = t_l elsewhere, ONE
-// instruction `x = shift_right_by_one_lane(x) + t` (v_add_f32_dpp wave_shr:1; lane 0 has no source lane and keeps its value) turns
-// lane k's value into the sequential prefix P_k = P_(k-1) + t_k once lane k-1 holds P_(k-1): after 63 of them lane 63 holds
-// ((sum + t_0) + t_1) + ... + t_63, every addition in index order (lanes that were already correct are recomputed from the same
-// operands).  63 dependent instructions per 64 terms instead of a v_readlane and an addition per term.
+// Sequential f32 sum init + t[0] + t[1] + ... + t[n-1] (this order) by ONE wave.  term(j) -> the j-th term, 0.0f for "skip" (x + 0.0f == x
+// for every x these sums can reach -- a running sum that starts at +0.0f is never -0.0f --, so skipping an element and adding zero agree).
+// Returns the sum in every lane.
+// Rounds 3-6 moved ONE term per step to the adder (v_readlane, an LDS broadcast, a lane shift): 11-14 ns per addition whichever way, because
+// every step pays a cross-lane operation on top of the addition.  Late in round 6 the terms are BLOCKED instead: lane l owns kSeqBlock
+// consecutive terms of a super-block of 64 x kSeqBlock; in "phase" l every lane adds its own block to the running sum -- sixteen dependent
+// plain v_add_f32 from registers -- and the value lane l arrives at (the only one that started from the true prefix and added the right
+// terms) is read back as the running sum of phase l + 1.  One cross-lane operation per sixteen additions: 8 ns per addition (what a
+// dependent v_add_f32 of a lone wave costs here), 13.4 -> 9.8 us for the average confidences of 1 200 superpixels.  A lane whose block
+// holds only zeros has no phase at all.  The additions and their order are exactly those of the serial loop.
+constexpr int kSeqBlock = 16;
+template <class F>
+__device__ __forceinline__ float wave_sequential_sum(float init, int n, int lane, F term)
+{
+    float sum = init;
+    for (int base = 0; base < n; base += 64 * kSeqBlock) {
+        float t[kSeqBlock];
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < kSeqBlock; c++) {
+            const int j = base + lane * kSeqBlock + c;
+            t[c] = j < n ? term(j) : 0.f;
+            any = any || (t[c] != 0.f);
+        }
+        unsigned long long nz = __ballot(any);
+        while (nz) {   // (uniform)
+            const int ph = __builtin_ctzll(nz);
+            nz &= nz - 1;
+            float x = sum;
+#pragma unroll
+            for (int c = 0; c < kSeqBlock; c++) x = x + t[c];
+            sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), ph));
+        }
+    }
+    return sum;
+}
+
+// The lane-shift flavour of the same sums (rounds 5-6): ONE term per step reaches the adder, by `v_add_f32_dpp wave_shr:1` -- with x_0 = sum + t_0
+// in lane 0 and x_l = t_l elsewhere, `x = shift_right_by_one_lane(x) + t` turns lane k's value into the prefix P_k once lane k-1 holds
+// P_(k-1); 63 of them per 64 terms, 11 ns each.  seg_post_kernel keeps it: its terms are predicates over three LDS arrays, and
+// evaluating sixteen of them per lane with a lane stride of sixteen (bank conflicts, three passes) costs more than the blocked chain
+// saves there (depth statistics 25.1 against 21.8 us; seg_unary_kernel's average confidences, plain loads: 9.8 against 13.4 us).
 __device__ __forceinline__ float wave_chain64(float sum, float cur, int lane)
 {
     float x = lane == 0 ? sum + cur : cur;
@@ -455,7 +488,7 @@ __device__ __forceinline__ float wave_chain64(float sum, float cur, int lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 template <class F>
-__device__ __forceinline__ float wave_sequential_sum(float init, int n, int lane, F term)
+__device__ __forceinline__ float wave_sequential_sum_shift(float init, int n, int lane, F term)
 {
     float sum = init;
     float cur = lane < n ? term(lane) : 0.f;
@@ -468,14 +501,10 @@ __device__ __forceinline__ float wave_sequential_sum(float init, int n, int lane
     }
     return sum;
 }
-// (Measured and dropped, round 6: fetching the terms of sixteen blocks first and running sixteen chains from registers -- 17.0 against 13.4 us
-// for the average confidences, 26.4 against 21.8 us for the depth statistics: the chain is ~12 ns per dependent addition however its terms
-// arrive -- DESIGN-NOTES R6.5, and round 4's LDS variants before it.)
-
 // two independent chains in one pass (their additions interleave in the pipeline: each chain's next instruction finds its wait states
 // filled by the other's)
 template <class F, class G>
-__device__ __forceinline__ void wave_sequential_sum2(float& sa, float& sb, int n, int lane, F term_a, G term_b)
+__device__ __forceinline__ void wave_sequential_sum2_shift(float& sa, float& sb, int n, int lane, F term_a, G term_b)
 {
     float ca = lane < n ? term_a(lane) : 0.f, cb = lane < n ? term_b(lane) : 0.f;
     for (int base = 0; base < n; base += 64) {
@@ -869,9 +898,9 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
         const unsigned spc = cnt;
-        float sumDepth = wave_sequential_sum(0.f, K, lane, [&](int i) { return mine(i) ? lowDepth[i] : 0.f; });
+        float sumDepth = wave_sequential_sum_shift(0.f, K, lane, [&](int i) { return mine(i) ? lowDepth[i] : 0.f; });
         float mean = cnt ? sumDepth / (float)cnt : 0;
-        float sumDev = wave_sequential_sum(0.f, K, lane, [&](int i) { return mine(i) ? fabsf(mean - lowDepth[i]) : 0.f; });
+        float sumDev = wave_sequential_sum_shift(0.f, K, lane, [&](int i) { return mine(i) ? fabsf(mean - lowDepth[i]) : 0.f; });
         float dev = cnt ? sumDev / (float)cnt : 0;
         if (ix != 0) {
             // trimming pass: elements beyond mean + 1.1 dev are taken out of the running sums, in index order (x - d == x + (-d))
@@ -881,7 +910,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) out += __shfl_xor(out, o, 64);
             if (out)
-                wave_sequential_sum2(sumDepth, sumDev, K, lane, [&](int i) { return trimmed(i) ? -lowDepth[i] : 0.f; },
+                wave_sequential_sum2_shift(sumDepth, sumDev, K, lane, [&](int i) { return trimmed(i) ? -lowDepth[i] : 0.f; },
                                      [&](int i) { return trimmed(i) ? -fabsf(mean - lowDepth[i]) : 0.f; });
             cnt -= out;
         }

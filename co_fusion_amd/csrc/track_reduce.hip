@@ -929,6 +929,18 @@ __device__ __forceinline__ unsigned long long group_sum(const unsigned long long
     return v;
 }
 
+// wrapping 32-bit sum over the 64 lanes of a wave, the same value in every lane: DPP inside each row of 16 lanes (two quad permutations, the
+// mirrors of the half row and of the row), then the four row totals through scalar registers
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm [1, 0, 3, 2]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2, 3, 0, 1]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);   // row_mirror
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16) + (unsigned)__builtin_amdgcn_readlane((int)v, 32) +
+           (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+}
+
 // sigma handed to rgbStep (RGBDOdometry.cpp:373-385): (tmpError == 0) ? 1 : count   (sic: the COUNT)
 __device__ __forceinline__ float sigma_val_from(int count, int sigma, int rgbOnly)
 {
@@ -1712,19 +1724,29 @@ __global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra, in
                  "s"(ra.cols), "s"(ra.rows), "s"(ra.slot_px), "s"(ra.sobelScale), "s"(ra.il.fx), "s"(ra.il.fy));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t slot0 = (size_t)blockIdx.x * ra.slot_px;
+    // ONE flight of loads: the slot's count, this thread's record (speculative: valid if tid < n) and -- first wave -- the two words of the
+    // accumulator groups that give sigma, all pinned in front of the uniform `n == 0` exit.  Without the pin the compiler sinks the record
+    // and accumulator loads below that exit: three dependent round trips (count -> records + sums -> gathers) where two will do (round 6,
+    // from the ISA: the `speculative` load of round 2 had not been speculative in the binary).
     unsigned n = m.slot_counts[blockIdx.x];
+    const size_t Npx = (size_t)ra.cols * ra.rows;
+    uint2 rc = m.recs[slot0 + tid < Npx ? slot0 + tid : Npx - 1];   // (unconditional, address clamped: a load under a branch is waited for at its end)
+    unsigned long long g_cnt = 0, g_sig = 0;
+    if (tid < 64) { g_cnt = m.icp_acc[(size_t)tid * 32 + 29]; g_sig = m.icp_acc[(size_t)tid * 32 + 30]; }   // kGroups == 64 == lanes
+    asm volatile("" ::: "memory");   // (the vector loads are issued in front of the scalar round trip of the tracker's hot state, not behind it)
     SlotRange sr;
     const RgbHot hs = rgb_hot_and_range(ra, m, n_slots, sr);
+    asm volatile("" : "+v"(n), "+v"(rc.x), "+v"(rc.y), "+v"(g_cnt), "+v"(g_sig));
     // (a slot outside a culled tracker's candidate range was not visited by the residual pass: its count is stale, it holds nothing)
     if ((int)blockIdx.x < sr.first || (int)blockIdx.x > sr.last) n = 0;
-    uint2 rc = make_uint2(0, 0);
-    if (tid < ra.slot_px && slot0 + tid < (size_t)ra.cols * ra.rows) rc = m.recs[slot0 + tid];   // speculative: valid if tid < n
     if (!(hs.rgb && !hs.level_done) || n == 0) return;  // uniform
     __shared__ float s_sigma;
     if (tid < 64) {
-        const long long cnt = (long long)group_sum(m.icp_acc, 29, tid);
-        const long long sg = (long long)group_sum(m.icp_acc, 30, tid);
-        if (tid == 0) s_sigma = sigma_val_from((int)cnt, (int)sg, hs.rgbOnly);
+        // sigma_val_from takes the LOW 32 bits of the two totals (the reference's `int` count and sigma), and the low word of a sum is the
+        // wrapping sum of the low words: a 32-bit reduction over the 64 groups -- four DPP steps inside the rows of 16 lanes, the four row
+        // totals added on the scalar unit -- instead of twelve dependent LDS shuffles of 64-bit values (0.35 us of this launch)
+        const unsigned c32 = wave_sum_u32((unsigned)g_cnt), s32 = wave_sum_u32((unsigned)g_sig);
+        if (tid == 0) s_sigma = sigma_val_from((int)c32, (int)s32, hs.rgbOnly);
     }
     __syncthreads();
     const float sigma = s_sigma;
