@@ -128,18 +128,33 @@ struct ScanArgs {   // one ordered compaction: flags [n] -> block sums -> the fl
     const float4* rec; const unsigned* flags; long long n; unsigned* block_sums; unsigned* total; unsigned add_to_total; float4* out;
     unsigned* total_host;
 };
+// eight consecutive flags of a thread (i0 = element index of the first); one flight of loads: two 16-byte loads for a full group, the
+// guarded tail otherwise
+__device__ __forceinline__ void scan_load_flags(const unsigned* __restrict__ flags, long long i0, long long n, unsigned (&f)[8])
+{
+    if (i0 + 8 <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(flags + i0), c = *reinterpret_cast<const uint4*>(flags + i0 + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+    } else {
+        unsigned t[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) t[e] = flags[i0 + e < n ? i0 + e : n - 1];   // (unconditional, address clamped: a load under a branch is waited for at its end)
+#pragma unroll
+        for (int e = 0; e < 8; e++) f[e] = (i0 + e < n) ? t[e] : 0u;
+    }
+}
 __global__ void __launch_bounds__(256) scan_block_sums_kernel(const Batch<ScanArgs> B)
 {
     const VBlock vb = batch_decode(B.h);
     const ScanArgs& a = B.m[vb.model];
     const unsigned* __restrict__ flags = a.flags; const long long n = a.n; unsigned* __restrict__ block_sums = a.block_sums;
     if ((long long)vb.bid * kScanItems >= n) return;   // (padding workgroups of the batch layout)
-    const long long base = (long long)vb.bid * kScanItems;
+    // (round 6: the thread's eight flags as two vector loads -- eight guarded loads had been eight dependent round trips in the binary)
+    unsigned f[8];
+    scan_load_flags(flags, (long long)vb.bid * kScanItems + (long long)threadIdx.x * 8, n, f);
     unsigned s = 0;
-    for (int k = 0; k < 8; k++) {
-        const long long i = base + k * 256 + threadIdx.x;
-        if (i < n) s += flags[i];
-    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) s += f[e];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor((int)s, o, 64);
     __shared__ unsigned w[4];
     if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
@@ -150,8 +165,13 @@ __global__ void set_count_kernel(unsigned* out, unsigned v);
 __global__ void set_count2_kernel(unsigned* out, unsigned* out_host, unsigned v);
 // Ordered compaction in TWO launches (scan_block_sums_kernel, then this): every workgroup derives its own base from the block
 // sums of the workgroups before it (at most a few hundred values), scans its 2048 flags -- eight consecutive flags per thread, so
-// one pass and two barriers -- and moves the flagged 48 B records straight to their place; the last workgroup publishes the total.
+// one pass and two barriers -- and moves the flagged 48 B records to their place; the last workgroup publishes the total.
 // Replaces {spine scan, per-element offsets, scatter} = three launches and an offsets array.
+// Round 6, the move: until then every thread copied its own flagged records one after the other -- up to eight dependent load -> store
+// round trips, reads 384 bytes apart between neighbouring lanes.  Now the threads list the block's flagged elements in LDS (the
+// compaction keeps the order, so they fill ONE contiguous range of the output) and the workgroup copies that range as a stream of
+// 16-byte words: thread t writes word t, t + 256, ... of the range -- contiguous stores, reads contiguous wherever the flags are dense --
+// twelve independent loads in flight per thread.
 __global__ void __launch_bounds__(256) scan_scatter_kernel(const Batch<ScanArgs> B)
 {
     const VBlock vb = batch_decode(B.h);
@@ -162,42 +182,55 @@ __global__ void __launch_bounds__(256) scan_scatter_kernel(const Batch<ScanArgs>
     const int nb = (int)((n + kScanItems - 1) / kScanItems);   // workgroups that hold elements (the batch layout pads to a multiple of 8)
     if (vb.bid >= nb) return;
     __shared__ unsigned wsum[4], s_base;
+    __shared__ unsigned short s_src[kScanItems];   // element (within the block) behind every output slot of the block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long i0 = (long long)vb.bid * kScanItems + (long long)tid * 8;
+    unsigned f[8];
+    scan_load_flags(flags, i0, n, f);   // (in the same flight as the block sums below)
     unsigned b = 0;
     for (int k = tid; k < vb.bid; k += 256) b += block_sums[k];
     for (int o = 32; o > 0; o >>= 1) b += __shfl_xor((int)b, o, 64);
     if (lane == 0) wsum[wave] = b;
     __syncthreads();
     if (tid == 0) s_base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    const long long i0 = (long long)vb.bid * kScanItems + (long long)tid * 8;
-    unsigned f[8];
-    if (i0 + 8 <= n) {
-        const uint4 a = *reinterpret_cast<const uint4*>(flags + i0), c = *reinterpret_cast<const uint4*>(flags + i0 + 4);
-        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; e++) f[e] = (i0 + e < n) ? flags[i0 + e] : 0u;
-    }
     unsigned mine = 0;
 #pragma unroll
-    for (int e = 0; e < 8; e++) mine += f[e];
+    for (int e = 0; e < 8; e++) mine += f[e];   // (flags are 0 / 1)
     unsigned incl = mine;
     for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
     __syncthreads();  // s_base written, wsum free again
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    unsigned off = s_base + incl - mine;
-    for (int w = 0; w < wave; w++) off += wsum[w];
+    unsigned rel = incl - mine;
+    for (int w = 0; w < wave; w++) rel += wsum[w];
 #pragma unroll
     for (int e = 0; e < 8; e++)
-        if (f[e]) {
-            const size_t o = (size_t)off * 3, r = (size_t)(i0 + e) * 3;
-            out[o] = rec[r]; out[o + 1] = rec[r + 1]; out[o + 2] = rec[r + 2];
-            off++;
+        if (f[e]) s_src[rel++] = (unsigned short)(tid * 8 + e);
+    const unsigned count = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const unsigned base = s_base;
+    __syncthreads();
+    const float4* __restrict__ in0 = rec + (size_t)vb.bid * kScanItems * 3;
+    float4* __restrict__ out0 = out + (size_t)base * 3;
+    const unsigned words = count * 3;
+#ifndef CF_SCAN_FLY
+#define CF_SCAN_FLY 4
+#endif
+    constexpr int kFly = CF_SCAN_FLY;   // 16-byte words in flight per thread (a full block is 24 per thread)
+    for (unsigned m0 = tid; m0 < words; m0 += kFly * 256) {
+        float4 v[kFly];
+#pragma unroll
+        for (int u = 0; u < kFly; u++) {
+            const unsigned m = m0 + u * 256;
+            const unsigned mc = m < words ? m : words - 1;      // (clamped: the loads stay one flight)
+            const unsigned j = mc / 3u;
+            v[u] = in0[(size_t)s_src[j] * 3 + (mc - 3u * j)];
         }
-    if (vb.bid == nb - 1 && tid == 255) {  // the last thread's running offset is the total
-        *total = off + add_to_total;
-        if (total_host) *total_host = off + add_to_total;  // pinned host memory: the read-back needs no copy command on the stream
+#pragma unroll
+        for (int u = 0; u < kFly; u++) { const unsigned m = m0 + u * 256; if (m < words) out0[m] = v[u]; }
+    }
+    if (vb.bid == nb - 1 && tid == 255) {  // the last workgroup's end is the total
+        *total = base + count + add_to_total;
+        if (total_host) *total_host = base + count + add_to_total;  // pinned host memory: the read-back needs no copy command on the stream
     }
 }
 
