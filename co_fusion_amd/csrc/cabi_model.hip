@@ -47,6 +47,7 @@ struct cf_model {
     float* records = nullptr;         // [N*12]
     float* fresh = nullptr;           // new unstable surfels [N/4 * 12] (Model::newUnstableBuffer)
     unsigned* new_flags = nullptr;    // [N]
+    bool new_flags_clean = true;      // all zeros (allocated so; the association's compaction clears what it reads): no fill launch in front of the next association
     unsigned* owner = nullptr;        // [max_surfels]
     float* fb_rec = nullptr;          // feedback records (raw), [N*12]
     float* fb_raw = nullptr;          // compacted raw feedback [N*12]
@@ -232,6 +233,7 @@ int cf_model_initialise(cf_model* m, const uint8_t* rgba, const float* depth_raw
     launch_feedback(s, rgba, depth_filt, W, H, cam, m->inv_fx, m->inv_fy, m->tcx, m->tcy, time, maxDepth, m->fb_rec, m->new_flags);
     HIPCHK(ctx, hipMemsetAsync(m->fb_filt, 0, sizeof(float) * 12 * N, s));
     launch_scan_scatter(s, m->fb_rec, m->new_flags, N, m->block_sums, m->d_tmp2, 0, m->fb_filt);
+    m->new_flags_clean = false;   // (the feedback passes wrote every flag)
     launch_init(s, m->fb_raw, m->fb_filt, m->d_count, N, m->buf[m->target]);
     LAUNCHCHK(ctx);
     return sync_count(m);
@@ -385,10 +387,15 @@ int cf_model_fuse(cf_model* m, const float pose[16], int time, const uint8_t* rg
     a.index = m->index; a.vertConf = m->vertConf; a.normRad = m->normRad; a.rgba = rgba; a.depth_raw = depth_raw; a.depth_filt = depth_filt;
     a.mask = mask; a.tcx = m->tcx; a.tcy = m->tcy; memcpy(a.pose, pose, sizeof(a.pose)); a.cam = ctx_cam(ctx); a.inv_fx = m->inv_fx;
     a.inv_fy = m->inv_fy; a.cols = W; a.rows = H; a.time = time; a.weighting = weighting; a.maskID = maskID; a.maxDepth = maxDepth;
-    a.records = m->records; a.new_flags = m->new_flags; a.owner = m->owner;
+    a.records = m->records; a.new_flags = m->new_flags; a.owner = m->owner; a.flags_clean = m->new_flags_clean ? 1 : 0;
     launch_associate(s, a);
-    // append the new unstable vertices in column-major draw order (transform feedback of data.geom)
-    launch_scan_scatter(s, m->records, m->new_flags, N, m->block_sums, m->d_nfresh, 0, m->fresh);
+    // append the new unstable vertices in column-major draw order (transform feedback of data.geom); the flags are left cleared
+    {
+        ScanPassArgs sp{m->records, m->new_flags, N, m->block_sums, m->d_nfresh, 0, m->fresh, nullptr};
+        sp.zero_flags = 1;
+        launch_scan_scatter_batch(s, &sp, 1);
+        m->new_flags_clean = true;
+    }
     // update.vert over all surfels into the other buffer, then swap (Model.cpp:559)
     uint32_t nb = 0;
     if (int r = count_bound(m, &nb)) return r;
@@ -541,8 +548,10 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
             a.index = m->index; a.vertConf = m->vertConf; a.normRad = m->normRad; a.rgba = it.rgba; a.depth_raw = it.depth_raw; a.depth_filt = it.depth_filtered;
             a.mask = it.mask; a.tcx = m->tcx; a.tcy = m->tcy; memcpy(a.pose, it.pose, sizeof(a.pose)); a.cam = cam; a.inv_fx = m->inv_fx;
             a.inv_fy = m->inv_fy; a.cols = W; a.rows = H; a.time = it.time; a.weighting = it.weighting; a.maskID = it.mask_id; a.maxDepth = it.fuse_max_depth;
-            a.records = m->records; a.new_flags = m->new_flags; a.owner = m->owner;
+            a.records = m->records; a.new_flags = m->new_flags; a.owner = m->owner; a.flags_clean = m->new_flags_clean ? 1 : 0;
             sa[q] = ScanPassArgs{m->records, m->new_flags, N, m->block_sums, m->d_nfresh, 0, m->fresh, nullptr};
+            sa[q].zero_flags = 1;   // (the compaction leaves the flags it read cleared: the next frame's association starts from zeros without a fill launch)
+            m->new_flags_clean = true;
             uint32_t nb = 0;
             if (int r = count_bound(m, &nb)) return r;
             ua[q] = UpdatePassArgs{m->buf[m->target], m->d_count, nb, m->owner, m->records, it.time, m->buf[1 - m->target]};

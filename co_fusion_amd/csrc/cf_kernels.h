@@ -385,6 +385,7 @@ struct SurfelFuseArgs {
     float pose[16]; cf_cam cam; float inv_fx, inv_fy;
     int cols, rows, time; float weighting; int maskID; float maxDepth;
     float* records; unsigned* new_flags; unsigned* owner;
+    int flags_clean = 0;  // 1: new_flags is known to hold zeros (left so by the last compaction): launch_associate_batch does not clear it
 };
 struct SurfelCleanArgs {
     const unsigned* index; const float* vertConf; const float* colorTime;
@@ -397,11 +398,12 @@ struct CleanPassArgs {   // Model::clean of one model
 };
 struct ScanPassArgs {    // one ordered compaction (transform feedback): the flagged 48 B records of rec [n] to out, their number (+ add) to *total
     const float* rec; const unsigned* flags; long long n; unsigned* block_sums; unsigned* total; unsigned add_to_total; float* out; unsigned* total_host;
+    int zero_flags = 0;   // 1: the pass leaves the flags it has read cleared (the association's new-surfel flags: the next frame's pass finds zeros, no fill launch)
 };
 void launch_index_keys_batch(hipStream_t s, const IndexPassArgs* items, int n, cf_cam cam, int cols, int rows);
 void launch_index_resolve_batch(hipStream_t s, const IndexPassArgs* items, int n, cf_cam cam, int cols, int rows);
 void launch_combined_predict_batch(hipStream_t s, const SplatPassArgs* items, int n, cf_cam cam, int cols, int rows);
-void launch_associate_batch(hipStream_t s, const SurfelFuseArgs* items, int n);   // zeroes every model's new_flags first
+void launch_associate_batch(hipStream_t s, const SurfelFuseArgs* items, int n);   // zeroes the new_flags of every model that is not flags_clean first
 void launch_update_batch(hipStream_t s, const UpdatePassArgs* items, int n);
 void launch_clean_batch(hipStream_t s, const CleanPassArgs* items, int n);
 void launch_scan_scatter_batch(hipStream_t s, const ScanPassArgs* items, int n);

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(kB) bilateral_kernel(const float* __restrict__
 static constexpr int kScanItems = 2048;  // 256 threads x 8
 struct ScanArgs {   // one ordered compaction: flags [n] -> block sums -> the flagged 48 B records of rec moved to out, in order
     const float4* rec; const unsigned* flags; long long n; unsigned* block_sums; unsigned* total; unsigned add_to_total; float4* out;
-    unsigned* total_host;
+    unsigned* total_host; int zero_flags;
 };
 // eight consecutive flags of a thread (i0 = element index of the first); one flight of loads: two 16-byte loads for a full group, the
 // guarded tail otherwise
@@ -187,6 +187,12 @@ __global__ void __launch_bounds__(256) scan_scatter_kernel(const Batch<ScanArgs>
     const long long i0 = (long long)vb.bid * kScanItems + (long long)tid * 8;
     unsigned f[8];
     scan_load_flags(flags, i0, n, f);   // (in the same flight as the block sums below)
+    if (a.zero_flags) {   // the flags are consumed: leave zeros behind for the next pass that sets some of them (no fill launch per frame)
+        unsigned* fz = const_cast<unsigned*>(flags);
+        if (i0 + 8 <= n) { *reinterpret_cast<uint4*>(fz + i0) = make_uint4(0, 0, 0, 0); *reinterpret_cast<uint4*>(fz + i0 + 4) = make_uint4(0, 0, 0, 0); }
+        else
+            for (int e = 0; e < 8; e++) if (i0 + e < n) fz[i0 + e] = 0;
+    }
     unsigned b = 0;
     for (int k = tid; k < vb.bid; k += 256) b += block_sums[k];
     for (int o = 32; o > 0; o >>= 1) b += __shfl_xor((int)b, o, 64);
@@ -243,7 +249,7 @@ void launch_scan_scatter_batch(hipStream_t s, const ScanPassArgs* items, int n_i
         int blocks[kSurfBatch], any = 0;
         for (int k = 0; k < nb; k++) {
             const ScanPassArgs& h = items[base + k];
-            B.m[k] = ScanArgs{reinterpret_cast<const float4*>(h.rec), h.flags, h.n, h.block_sums, h.total, h.add_to_total, reinterpret_cast<float4*>(h.out), h.total_host};
+            B.m[k] = ScanArgs{reinterpret_cast<const float4*>(h.rec), h.flags, h.n, h.block_sums, h.total, h.add_to_total, reinterpret_cast<float4*>(h.out), h.total_host, h.zero_flags};
             blocks[k] = (int)((B.m[k].n + kScanItems - 1) / kScanItems);
             any += blocks[k];
             if (blocks[k] == 0) set_count2_kernel<<<1, 1, 0, s>>>(B.m[k].total, B.m[k].total_host, B.m[k].add_to_total);
@@ -1052,7 +1058,7 @@ void launch_associate_batch(hipStream_t s, const SurfelFuseArgs* items, int n_it
         const int nb = n_items - base < kSurfBatch ? n_items - base : kSurfBatch;
         Batch<FuseArgs> B;
         Batch<FillArgs> Z;
-        int blocks[kSurfBatch], zblocks[kSurfBatch];
+        int blocks[kSurfBatch], zblocks[kSurfBatch], zany = 0;
         for (int k = 0; k < nb; k++) {
             const SurfelFuseArgs& h = items[base + k];
             FuseArgs& a = B.m[k];
@@ -1066,9 +1072,10 @@ void launch_associate_batch(hipStream_t s, const SurfelFuseArgs* items, int n_it
             blocks[k] = gridXcd(4 * n, chunk);
             const long long n16 = ((long long)h.cols * h.rows + 3) / 4;   // (new_flags holds cols * rows words: cf_model_create rounds it up)
             Z.m[k] = FillArgs{reinterpret_cast<uint4*>(h.new_flags), n16};
-            zblocks[k] = gridFor(n16);
+            zblocks[k] = h.flags_clean ? 0 : gridFor(n16);   // (left clean by the last compaction: ScanPassArgs::zero_flags)
+            zany += zblocks[k];
         }
-        fill_zero_kernel<<<batch_layout(Z, zblocks, nb), kB, 0, s>>>(Z);
+        if (zany) fill_zero_kernel<<<batch_layout(Z, zblocks, nb), kB, 0, s>>>(Z);
         associate_kernel<<<batch_layout(B, blocks, nb), kB, 0, s>>>(B, chunk);
     }
 }
