@@ -439,21 +439,18 @@ int cf_models_preindex(cf_ctx* ctx, const cf_model_preindex* items, int n, float
     if (!ctx || !items || n <= 0) return CF_EINVAL;
     hipStream_t s = ctx->cur();
     const int W = ctx->cfg.width, H = ctx->cfg.height;
-    std::vector<const cf::OdomDev*> states((size_t)n);
-    std::vector<float*> outs((size_t)n);
     std::vector<IndexPassArgs> a((size_t)n);
     for (int k = 0; k < n; k++) {
         cf_model* m = items[k].model; const cf_odom* od = items[k].odom;
         if (!m || !od || m->ctx != ctx || od->ctx != ctx) return CF_EINVAL;
         uint32_t nb = 0;
         if (int r = count_bound(m, &nb)) return r;
-        states[k] = od->d_state; outs[k] = m->t_inv_dev;
+        const float* pinv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(od->d_state) + offsetof(cf::OdomDev, pose_inv));
         IndexPassArgs& p = a[k];
         p.surfels = m->buf[m->target]; p.count = m->d_count; p.id_begin = 0; p.id_end = nb; p.maxDepth = depth_cutoff; p.time = items[k].time;
         p.timeDelta = time_delta; p.keys = m->keys; p.index = m->index; p.vertConf = m->vertConf; p.colorTime = m->colorTime; p.normRad = m->normRad;
-        p.t_inv_dev = m->t_inv_dev;
+        p.t_inv_dev = pinv;   // (the inverse of the tracked pose, left in the tracker's state by the last solve of its schedule)
     }
-    launch_pose_tinv(s, states.data(), outs.data(), n);
     launch_index_keys_batch(s, a.data(), n, ctx_cam(ctx), W, H);
     launch_index_resolve_batch(s, a.data(), n, ctx_cam(ctx), W, H);
     LAUNCHCHK(ctx);

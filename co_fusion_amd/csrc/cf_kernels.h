@@ -88,6 +88,8 @@ struct OdomDev {
                                  // tracked): sizes the residual part of the next call's launches (the last solve writes it)
     float cull_z[2];             // depth interval (current camera) of that box dilated by distThres: a 64-pixel run of the current frame
                                  // whose valid depths all lie outside cannot find a correspondence (-inf, +inf: no depth culling)
+    float pose_inv[16];          // inverse of the tracked pose [Rcurr | tcurr] (row-major 4x4, inv44f), written by the LAST solve of a schedule: the index
+                                 // pass enqueued before the host has seen the pose reads it here (cf_models_preindex; a launch of its own until round 6)
     // (the screen box itself -- the level-0 pixel rectangle outside of which no pixel of the current frame can find a correspondence
     // under Rcurr / tcurr -- is stats.cull_box)
     // outputs
@@ -349,7 +351,7 @@ constexpr int kSurfBatch = 16;   // models per launch (their arguments travel in
 struct IndexPassArgs {   // Model::predictIndices of one model: rasterise surfels [id_begin, id_end) into the z-keys, resolve
     const float* surfels; const unsigned* count; unsigned id_begin, id_end; float t_inv[16]; float maxDepth; int time, timeDelta;
     unsigned long long* keys; unsigned* index; float* vertConf; float* colorTime; float* normRad;
-    const float* t_inv_dev;   // nullable: the inverse pose in device memory (launch_pose_tinv) instead of t_inv -- an index pass enqueued
+    const float* t_inv_dev;   // nullable: the inverse pose in device memory (OdomDev::pose_inv) instead of t_inv -- an index pass enqueued
                               // before the host has seen the tracked pose (cf_models_preindex)
 };
 // pose.inverse() of a rigid transform: linear part by cofactors (the statement of the oracle, orc_surfel.c); host and device
@@ -372,7 +374,6 @@ __host__ __device__ inline void inv44f(const float a[16], float o[16])
 }
 // the tracked poses of n trackers (their device states, as the last solve left them), inverted into out[k][16]: what the index pass of a
 // model needs of its pose, without the host
-void launch_pose_tinv(hipStream_t s, const OdomDev* const* states, float* const* out, int n);
 struct SplatPassArgs {   // ModelProjection::combinedPredict of one model
     const float* surfels; const unsigned* count; unsigned count_bound; float t_inv[16]; float maxDepth, confThreshold; int time, maxTime, timeDelta;
     const float* rays; unsigned long long* keys; uint8_t* image; float* vertexConf; float* normalRad; uint16_t* time16;

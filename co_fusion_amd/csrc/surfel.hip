@@ -330,27 +330,8 @@ __device__ __forceinline__ Mat4 index_matrix(const IndexArgs& a)
     for (int k = 0; k < 16; k++) m.m[k] = a.t_inv_dev[k];   // (uniform address: one request per wave)
     return m;
 }
-struct PoseTinvBatch { const OdomDev* st[kSurfBatch]; float* out[kSurfBatch]; };
-__global__ void __launch_bounds__(64) pose_tinv_kernel(const PoseTinvBatch B, int n)
-{
-    const int k = threadIdx.x;
-    if (k >= n) return;
-    const OdomDev* st = B.st[k];
-    float pose[16], inv[16];
-    for (int r = 0; r < 3; r++) { pose[r * 4 + 0] = st->Rcurr[r * 3 + 0]; pose[r * 4 + 1] = st->Rcurr[r * 3 + 1]; pose[r * 4 + 2] = st->Rcurr[r * 3 + 2]; pose[r * 4 + 3] = st->tcurr[r]; }
-    pose[12] = 0; pose[13] = 0; pose[14] = 0; pose[15] = 1;   // (the facade's Model::pose after a tracking call: CoFusion::fetchTracking)
-    inv44f(pose, inv);
-    for (int q = 0; q < 16; q++) B.out[k][q] = inv[q];
-}
-void launch_pose_tinv(hipStream_t s, const OdomDev* const* states, float* const* out, int n)
-{
-    for (int base = 0; base < n; base += kSurfBatch) {
-        const int nb = n - base < kSurfBatch ? n - base : kSurfBatch;
-        PoseTinvBatch B{};
-        for (int k = 0; k < nb; k++) { B.st[k] = states[base + k]; B.out[k] = out[base + k]; }
-        pose_tinv_kernel<<<1, 64, 0, s>>>(B, nb);
-    }
-}
+// (the inverse of a tracked pose is left in the tracker's state by the last solve of its schedule -- OdomDev::pose_inv -- since round 6: a
+// kernel of its own, pose_tinv_kernel, until then)
 struct FrameGeom { cf_cam cam; int cols, rows; };   // what the models of a launch share
 
 __global__ void __launch_bounds__(kB) index_splat_kernel(const Batch<IndexArgs> B, const FrameGeom g)

@@ -1631,6 +1631,13 @@ __device__ __forceinline__ void gn_solve_body(int icp_fix, OdomDev* god, unsigne
                     for (int k = 0; k < 3; k++) od->tcurr[k] = od->tprev[k];
                 }
             }
+            if (lane == 0) {  // ... and the inverse of the pose the call ends with, for the index pass that is enqueued before the host sees it
+                float pose[16], inv[16];
+                for (int r = 0; r < 3; r++) { pose[r * 4 + 0] = od->Rcurr[r * 3 + 0]; pose[r * 4 + 1] = od->Rcurr[r * 3 + 1]; pose[r * 4 + 2] = od->Rcurr[r * 3 + 2]; pose[r * 4 + 3] = od->tcurr[r]; }
+                pose[12] = 0; pose[13] = 0; pose[14] = 0; pose[15] = 1;   // (the facade's Model::pose after a tracking call: CoFusion::fetchTracking)
+                inv44f(pose, inv);
+                for (int q = 0; q < 16; q++) od->pose_inv[q] = inv[q];
+            }
             // ... and the candidate range of a culled tracker: how many record slots each level needed goes back to the host (it sizes the
             // next call's residual workgroups), the accumulator is cleared for the next call's preparation
             if (lane >= 32 && lane < 35 && od->res_range) {

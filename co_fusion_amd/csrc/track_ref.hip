@@ -535,6 +535,10 @@ int ref_track(cf_ctx* ctx, cf_odom* od, const float pose[16], const cf_track_opt
     OdomDev* h = od->h_state;
     memcpy(h->Rprev, Rprev, 36); memcpy(h->tprev, tprev, 12); memcpy(h->Rprev_inv, Rprev_inv, 36);
     memcpy(h->Rcurr, Rcurr, 36); memcpy(h->tcurr, tcurr, 12);
+    {   // the inverse of the final pose, where the default tracker's last solve leaves it (OdomDev::pose_inv: cf_models_preindex reads it)
+        float pose[16] = {Rcurr[0], Rcurr[1], Rcurr[2], tcurr[0], Rcurr[3], Rcurr[4], Rcurr[5], tcurr[1], Rcurr[6], Rcurr[7], Rcurr[8], tcurr[2], 0, 0, 0, 1};
+        inv44f(pose, h->pose_inv);
+    }
     memcpy(h->resultRt, resultRt, sizeof(resultRt));
     h->stats = st;
     refresh_hot(h);
