@@ -1724,7 +1724,7 @@ __global__ void __launch_bounds__(256) gn_solve_kernel(const GnArgs args, int ne
 // Measured and dropped (round 2, profiles/r02b): running this pass and the solve in ONE launch -- 32 workgroups per model reduce a
 // global list, fence, arrive at a counter, workgroup 0 waits and solves.  22.6 us per launch against 6.3 + 8.4 us for the two
 // separate kernels plus one boundary: the device-scope release fence and the arrival wait cost more than a kernel boundary does.
-__global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra, int n_slots)
+__device__ __forceinline__ void rgb_slot_step_body(const RgbArgs& ra, int n_slots)
 {
     const RgbModelArgs m = ra.m[blockIdx.y];
     asm volatile("" :: "s"(m.st), "s"(m.icp_acc), "s"(m.rgb_acc), "s"(m.recs), "s"(m.slot_counts), "s"(m.res_range), "s"(m.cloud), "s"(m.dIdx), "s"(m.dIdy),
@@ -1778,6 +1778,15 @@ __global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra, in
         v = wave_reduce32_u64(acc, lane);
     }
     block_commit32<4>(v, lane, wave, 4, m.rgb_acc + (size_t)(blockIdx.x % kGroups) * 32);
+}
+__global__ void __launch_bounds__(256) rgb_slot_step_kernel(const RgbArgs ra, int n_slots) { rgb_slot_step_body(ra, n_slots); }
+// ... and, on the last level-0 iteration, the error surfaces of the culled trackers in the SAME launch (workgroups behind the record
+// slots; until late in round 6 icp_error_surface_kernel ran as a launch of its own between the {ICP || residual} launch and this one:
+// 6.5 us + a launch boundary on the Gauss-Newton chain of every frame).  Both read the tracker state the solve has not touched yet.
+__global__ void __launch_bounds__(256) rgb_slot_step_err_kernel(const RgbArgs ra, int n_slots, const IcpArgs e)
+{
+    if ((int)blockIdx.x >= n_slots) { icp_error_surface_body(e, e.m[blockIdx.y], (int)blockIdx.x - n_slots); return; }
+    rgb_slot_step_body(ra, n_slots);
 }
 
 // MODE 2 (round 5): the RGB step and the solve in ONE launch.  Rounds 2-3 measured this twice with device-scope synchronisation and lost
@@ -2117,7 +2126,10 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
                     prof->launches += 1;
                 }
             }
-            if (err_aside && i == 0 && last_of_level) {
+            // (the culled trackers' error surfaces ride in the RGB step's launch when there is one: rgb_slot_step_err_kernel)
+            const bool err_here = err_aside && i == 0 && last_of_level;
+            const bool err_with_step = err_here && rgb && slots && mode != 2;
+            if (err_here && !err_with_step) {
                 IcpArgs e = icp_args[i]; e.cdiv = make_idiv(e.cols);
                 icp_error_surface_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(e);
             }
@@ -2137,7 +2149,10 @@ bool launch_gn_track(hipStream_t s, IcpLaunch cfg, const TrackerStates& states, 
             if (rgb) {
                 if (slots) {
                     const int n_slots = (N + ra.slot_px - 1) / ra.slot_px;
-                    rgb_slot_step_kernel<<<dim3(n_slots, n), 256, 0, s>>>(ra, n_slots);
+                    if (err_with_step) {
+                        IcpArgs e = icp_args[i]; e.cdiv = make_idiv(e.cols);
+                        rgb_slot_step_err_kernel<<<dim3(n_slots + (N + 255) / 256, n), 256, 0, s>>>(ra, n_slots, e);
+                    } else rgb_slot_step_kernel<<<dim3(n_slots, n), 256, 0, s>>>(ra, n_slots);
                 }
                 else rgb_step_kernel<<<dim3((N + 255) / 256, n), 256, 0, s>>>(ra);
             }
