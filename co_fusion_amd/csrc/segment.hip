@@ -449,6 +449,20 @@ struct SegUnaryArgs {
 // dependent v_add_f32 of a lone wave costs here), 13.4 -> 9.8 us for the average confidences of 1 200 superpixels.  A lane whose block
 // holds only zeros has no phase at all.  The additions and their order are exactly those of the serial loop.
 constexpr int kSeqBlock = 16;
+// the phases of one super-block: lane l holds its kSeqBlock consecutive terms in t[], `any` = one of them is not zero
+__device__ __forceinline__ float seq_block_phases(float sum, const float (&t)[kSeqBlock], bool any)
+{
+    unsigned long long nz = __ballot(any);
+    while (nz) {   // (uniform)
+        const int ph = __builtin_ctzll(nz);
+        nz &= nz - 1;
+        float x = sum;
+#pragma unroll
+        for (int c = 0; c < kSeqBlock; c++) x = x + t[c];
+        sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), ph));
+    }
+    return sum;
+}
 template <class F>
 __device__ __forceinline__ float wave_sequential_sum(float init, int n, int lane, F term)
 {
@@ -462,63 +476,106 @@ __device__ __forceinline__ float wave_sequential_sum(float init, int n, int lane
             t[c] = j < n ? term(j) : 0.f;
             any = any || (t[c] != 0.f);
         }
-        unsigned long long nz = __ballot(any);
-        while (nz) {   // (uniform)
-            const int ph = __builtin_ctzll(nz);
-            nz &= nz - 1;
-            float x = sum;
+        sum = seq_block_phases(sum, t, any);
+    }
+    return sum;
+}
+// What a dependent addition really costs (tools/microbench/dep_chain.hip, late in round 6): 1.70 ns -- four cycles at 2.35 GHz, the same
+// with the rest of the chip busy or idle, cold or warm; v_add_f64 / v_fma_f64 1.97 ns; `s_nop 1` + v_add_f32_dpp wave_shr:1 5.1 ns; two
+// interleaved chains on one wave 3.4 ns per pair (a lone wave issues one VALU instruction per four cycles whatever it depends on).  The
+// "8 ns per addition" above was the whole pass divided by its terms: at K = 1 200 most of it were the two flights of sixteen strided
+// 4-byte loads per lane in front of each super-block's phases and a second walk over the array to zero the non-finite entries.  This
+// flavour -- n a multiple of kSeqBlock, p 16-byte aligned -- fetches a lane's block as four 16-byte loads, has the NEXT super-block's
+// loads in flight during the phases of the current one, and takes the non-finite entries out on the way (zero in the sum, zero stored
+// back: what the caller's second walk did).  Same additions, same order.
+__device__ __forceinline__ float wave_sequential_sum_finite16(float* __restrict__ p, int n, int lane)
+{
+    const int nch = n / kSeqBlock;
+    float sum = 0.f;
+    float4 cur[4], nxt[4];
 #pragma unroll
-            for (int c = 0; c < kSeqBlock; c++) x = x + t[c];
-            sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), ph));
+    for (int q = 0; q < 4; q++) cur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < nch) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = reinterpret_cast<const float4*>(p + (size_t)lane * kSeqBlock)[q];
+    }
+    for (int j0 = 0; j0 < nch; j0 += 64) {
+        const int jn = j0 + 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; q++) nxt[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (jn < nch) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) nxt[q] = reinterpret_cast<const float4*>(p + (size_t)jn * kSeqBlock)[q];
         }
+        float t[kSeqBlock];
+        bool any = false, bad = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { t[q * 4] = cur[q].x; t[q * 4 + 1] = cur[q].y; t[q * 4 + 2] = cur[q].z; t[q * 4 + 3] = cur[q].w; }
+#pragma unroll
+        for (int c = 0; c < kSeqBlock; c++) {
+            if (!is_finite(t[c])) { t[c] = 0.f; bad = true; }
+            any = any || (t[c] != 0.f);
+        }
+        if (bad) {   // (rare)
+            float4* o = reinterpret_cast<float4*>(p + (size_t)(j0 + lane) * kSeqBlock);
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[q] = make_float4(t[q * 4], t[q * 4 + 1], t[q * 4 + 2], t[q * 4 + 3]);
+        }
+        sum = seq_block_phases(sum, t, any);
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
     }
     return sum;
 }
 
-// The lane-shift flavour of the same sums (rounds 5-6): ONE term per step reaches the adder, by `v_add_f32_dpp wave_shr:1` -- with x_0 = sum + t_0
-// in lane 0 and x_l = t_l elsewhere, `x = shift_right_by_one_lane(x) + t` turns lane k's value into the prefix P_k once lane k-1 holds
-// P_(k-1); 63 of them per 64 terms, 11 ns each.  seg_post_kernel keeps it: its terms are predicates over three LDS arrays, and
-// evaluating sixteen of them per lane with a lane stride of sixteen (bank conflicts, three passes) costs more than the blocked chain
-// saves there (depth statistics 25.1 against 21.8 us; seg_unary_kernel's average confidences, plain loads: 9.8 against 13.4 us).
-__device__ __forceinline__ float wave_chain64(float sum, float cur, int lane)
+// seg_post_kernel's sums: the terms are predicates over arrays in LDS.  Rounds 5-6 moved them to the adder one by one with a lane shift
+// (`s_nop 1` + `v_add_f32_dpp wave_shr:1`: 5.1 ns per term by the micro-benchmark, 63 per 64 terms), because the blocked chain read its
+// sixteen terms per lane with a lane stride of sixteen words -- bank conflicts in three arrays, 25.1 against 21.8 us.  Now the arrays are
+// LAID OUT for the blocked chain: the depths padded by four words per sixteen (entry k at k + 4 * (k >> 4): lane l's block starts at
+// word 20 l, four conflict-free 16-byte reads), the model entry of every superpixel as 16 bits (lane l's sixteen are 32 consecutive bytes).
+// `term(mine, depth, out[NCH])` forms the NCH chains' terms of one superpixel; a lane whose block holds only zeros has no phase.
+constexpr int kSegDepthPad(int k) { return k + 4 * (k >> 4); }
+template <int NCH, class F>
+__device__ __forceinline__ void lds_blocked_sums(float (&sum)[NCH], int nch, int lane, const float* s_depth, const unsigned short* s_entry, unsigned entry, F term)
 {
-    float x = lane == 0 ? sum + cur : cur;
-    // (s_nop 1: a DPP read of a VGPR the previous VALU instruction wrote needs two wait states)
-    asm volatile(".rept 63\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr" : "+&v"(x) : "v"(cur));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
-}
-template <class F>
-__device__ __forceinline__ float wave_sequential_sum_shift(float init, int n, int lane, F term)
-{
-    float sum = init;
-    float cur = lane < n ? term(lane) : 0.f;
-    for (int base = 0; base < n; base += 64) {
-        const int nj = base + 64 + lane;
-        const float nxt = nj < n ? term(nj) : 0.f;
-        // lanes past n hold 0.0f, and a step whose 64 terms are all zero changes nothing
-        if (__ballot(cur != 0.f) != 0ull) sum = wave_chain64(sum, cur, lane);
-        cur = nxt;
-    }
-    return sum;
-}
-// two independent chains in one pass (their additions interleave in the pipeline: each chain's next instruction finds its wait states
-// filled by the other's)
-template <class F, class G>
-__device__ __forceinline__ void wave_sequential_sum2_shift(float& sa, float& sb, int n, int lane, F term_a, G term_b)
-{
-    float ca = lane < n ? term_a(lane) : 0.f, cb = lane < n ? term_b(lane) : 0.f;
-    for (int base = 0; base < n; base += 64) {
-        const int nj = base + 64 + lane;
-        const float na = nj < n ? term_a(nj) : 0.f, nb = nj < n ? term_b(nj) : 0.f;
-        if (__ballot(ca != 0.f || cb != 0.f) != 0ull) {
-            float xa = lane == 0 ? sa + ca : ca, xb = lane == 0 ? sb + cb : cb;
-            asm volatile("s_nop 1\n\t.rept 63\n\ts_nop 0\n\tv_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t.endr"
-                         : "+&v"(xa), "+&v"(xb) : "v"(ca), "v"(cb));
-            sa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xa), 63));
-            sb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xb), 63));
+    for (int j0 = 0; j0 < nch; j0 += 64) {
+        const int j = j0 + lane;
+        float t[NCH][kSeqBlock];
+        bool any = false;
+#pragma unroll
+        for (int h = 0; h < NCH; h++)
+#pragma unroll
+            for (int c = 0; c < kSeqBlock; c++) t[h][c] = 0.f;
+        if (j < nch) {
+            const float4* dq = reinterpret_cast<const float4*>(s_depth + 20 * j);
+            const uint4* eq = reinterpret_cast<const uint4*>(s_entry + 16 * j);
+            const float4 d0 = dq[0], d1 = dq[1], d2 = dq[2], d3 = dq[3];
+            const uint4 e0 = eq[0], e1 = eq[1];
+            const float d[kSeqBlock] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x, d3.y, d3.z, d3.w};
+            const unsigned w[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+            for (int c = 0; c < kSeqBlock; c++) {
+                const bool mine = ((w[c >> 1] >> ((c & 1) * 16)) & 0xffffu) == entry;
+                float v[NCH];
+                term(mine, d[c], v);
+#pragma unroll
+                for (int h = 0; h < NCH; h++) { t[h][c] = v[h]; any = any || (v[h] != 0.f); }
+            }
         }
-        ca = na; cb = nb;
+        unsigned long long nz = __ballot(any);
+        while (nz) {   // (uniform)
+            const int ph = __builtin_ctzll(nz);
+            nz &= nz - 1;
+            float x[NCH];
+#pragma unroll
+            for (int h = 0; h < NCH; h++) x[h] = sum[h];
+#pragma unroll
+            for (int c = 0; c < kSeqBlock; c++)
+#pragma unroll
+                for (int h = 0; h < NCH; h++) x[h] = x[h] + t[h][c];
+#pragma unroll
+            for (int h = 0; h < NCH; h++) sum[h] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[h]), ph));
+        }
     }
 }
 
@@ -646,8 +703,12 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnary
     // zero and are zeroed in place afterwards
     for (int m = wave; m < n; m += (T >> 6)) {
         float* conf = a.low + (size_t)(1 + n + m) * K;
-        const float avg = wave_sequential_sum(0.f, K, lane, [&](int j) { const float c = conf[j]; return is_finite(c) ? c : 0.f; });
-        for (int j = lane; j < K; j += 64) if (!is_finite(conf[j])) conf[j] = 0;
+        float avg;
+        if ((K % kSeqBlock) == 0 && (reinterpret_cast<size_t>(conf) & 15) == 0) avg = wave_sequential_sum_finite16(conf, K, lane);
+        else {
+            avg = wave_sequential_sum(0.f, K, lane, [&](int j) { const float c = conf[j]; return is_finite(c) ? c : 0.f; });
+            for (int j = lane; j < K; j += 64) if (!is_finite(conf[j])) conf[j] = 0;
+        }
         if (lane == 0) a.avg_conf[m] = avg / (float)K;
     }
     __syncthreads();
@@ -738,8 +799,9 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
     __shared__ unsigned s_best[256];
     __shared__ int s_reject[kMaxL + 1];
     __shared__ __attribute__((aligned(4))) unsigned char map[kSegMaxK];
-    __shared__ int parent[kSegMaxK];
-    __shared__ int comp[kSegMaxK];
+    __shared__ __attribute__((aligned(16))) int s_pc[2 * kSegMaxK];   // union-find parents | component numbers; later the statistics' arrays
+    int* const parent = s_pc;
+    int* const comp = s_pc + kSegMaxK;
     __shared__ int s_cc[6 * kCcLds];
     if (tid == 0) s_min_label = 256;
     GSTAMP(1, 0);
@@ -884,34 +946,52 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
     __syncthreads();
     GSTAMP(1, 4);   // gates
     // 9. final low-resolution label map
-    float* const s_depth = reinterpret_cast<float*>(parent);   // the union-find parents are dead: their storage holds the low-resolution depths
-    for (int k = tid; k < K; k += T) { const unsigned char v = (unsigned char)c_label[comp[k]]; map[k] = v; a.low_map[k] = v; s_depth[k] = a.low_depth[k]; }
+    for (int k = tid; k < K; k += T) { const unsigned char v = (unsigned char)c_label[comp[k]]; map[k] = v; a.low_map[k] = v; }
+    __syncthreads();
+    // (parents and component numbers are dead: their storage holds the low-resolution depths and every superpixel's model entry in the
+    // layout of lds_blocked_sums; the tail up to a multiple of sixteen belongs to nobody)
+    float* const s_depth = reinterpret_cast<float*>(s_pc);
+    unsigned short* const s_entry = reinterpret_cast<unsigned short*>(s_pc + kSegDepthPad(kSegMaxK));
+    const int nch = (K + kSeqBlock - 1) / kSeqBlock;
+    for (int k = tid; k < nch * kSeqBlock; k += T) {
+        const unsigned char v = k < K ? map[k] : (unsigned char)255;
+        s_entry[k] = v == 255 ? (unsigned short)0xffff : (unsigned short)s_id2idx[v];
+        s_depth[kSegDepthPad(k)] = k < K ? a.low_depth[k] : 0.f;
+    }
     __syncthreads();
     GSTAMP(1, 5);   // label map
     // 10. depth statistics with one trimming pass (:570-621) and super-pixel counts (:624-627): sequential f32 sums in index order,
     //     one wave per model entry
     for (int ix = wave; ix < n_md; ix += (T >> 6)) {
-        const float* lowDepth = s_depth;
-        auto mine = [&](int i) { const unsigned char v = map[i]; return v != 255 && s_id2idx[v] == ix; };
+        auto mine_at = [&](int i) { return s_entry[i] == (unsigned short)ix; };
         unsigned cnt = 0;
-        for (int i = lane; i < K; i += 64) cnt += mine(i) ? 1u : 0u;
+        for (int i = lane; i < K; i += 64) cnt += mine_at(i) ? 1u : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
         const unsigned spc = cnt;
-        float sumDepth = wave_sequential_sum_shift(0.f, K, lane, [&](int i) { return mine(i) ? lowDepth[i] : 0.f; });
+        float s1[1] = {0.f};
+        lds_blocked_sums<1>(s1, nch, lane, s_depth, s_entry, (unsigned)ix, [&](bool mine, float d, float (&v)[1]) { v[0] = mine ? d : 0.f; });
+        float sumDepth = s1[0];
         float mean = cnt ? sumDepth / (float)cnt : 0;
-        float sumDev = wave_sequential_sum_shift(0.f, K, lane, [&](int i) { return mine(i) ? fabsf(mean - lowDepth[i]) : 0.f; });
+        s1[0] = 0.f;
+        lds_blocked_sums<1>(s1, nch, lane, s_depth, s_entry, (unsigned)ix, [&](bool mine, float d, float (&v)[1]) { v[0] = mine ? fabsf(mean - d) : 0.f; });
+        float sumDev = s1[0];
         float dev = cnt ? sumDev / (float)cnt : 0;
         if (ix != 0) {
             // trimming pass: elements beyond mean + 1.1 dev are taken out of the running sums, in index order (x - d == x + (-d))
-            auto trimmed = [&](int i) { return mine(i) && (double)lowDepth[i] > 1.1 * (double)dev + (double)mean; };
+            const double limit = 1.1 * (double)dev + (double)mean;
             unsigned out = 0;
-            for (int i = lane; i < K; i += 64) out += trimmed(i) ? 1u : 0u;
+            for (int i = lane; i < K; i += 64) out += (mine_at(i) && (double)s_depth[kSegDepthPad(i)] > limit) ? 1u : 0u;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) out += __shfl_xor(out, o, 64);
-            if (out)
-                wave_sequential_sum2_shift(sumDepth, sumDev, K, lane, [&](int i) { return trimmed(i) ? -lowDepth[i] : 0.f; },
-                                     [&](int i) { return trimmed(i) ? -fabsf(mean - lowDepth[i]) : 0.f; });
+            if (out) {
+                float s2[2] = {sumDepth, sumDev};
+                lds_blocked_sums<2>(s2, nch, lane, s_depth, s_entry, (unsigned)ix, [&](bool mine, float d, float (&v)[2]) {
+                    const bool trimmed = mine && (double)d > limit;
+                    v[0] = trimmed ? -d : 0.f; v[1] = trimmed ? -fabsf(mean - d) : 0.f;
+                });
+                sumDepth = s2[0]; sumDev = s2[1];
+            }
             cnt -= out;
         }
         mean = cnt ? sumDepth / (float)cnt : 0;
