@@ -324,6 +324,10 @@ static void launch_crf_kernel_matrix(hipStream_t st, const CrfBatch& B, int S, i
 // with 16-byte kernel-matrix loads: 8.2 against 7.6 us.  The step is three dependent rounds of loads behind a launch, not load issue.
 // A third fusion (the workgroup's columns of both kernel matrices and all marginals staged in 106 KB of LDS with 16-byte loads, chunk sums
 // out of LDS, update in place): 13.9 us per step, 768 against 781 frames/s (profiles/r5an_*).  Two launches it stays.
+// Late in round 6, on top of the lean addresses below (bit-identical all): the whole 75-node chunk in one flight of loads (159 VGPRs, three
+// waves per SIMD: message 7.2 + update 4.1 us against 6.65 + 4.64, the same sum) and two / three labels per lane, so that a (node block,
+// chunk)'s kernel-matrix tiles leave the L2 once per two / three labels instead of once per label (839 / 811 against 843 frames/s on one
+// box): the step waits neither for round trips nor for L2 bandwidth any more.
 __global__ void __launch_bounds__(64) crf_message_kernel(const CrfBatch B, int n, int flip)
 {
     const CrfSeq& m = B.m[blockIdx.z];
@@ -337,25 +341,34 @@ __global__ void __launch_bounds__(64) crf_message_kernel(const CrfBatch B, int n
     float a = 0, b = 0;
     int j = j0;
     // the chunk is a chain of dependent additions but its loads are independent: 25 nodes' worth in flight at a time (a 75-node chunk
-    // is three memory round trips instead of fifteen)
-    for (; j + 25 <= j1; j += 25) {
+    // is three memory round trips instead of fifteen).
+    // Addresses (late in round 6): `K1t[(j + u) * n + i]` made every load form a 64-bit address on the vector unit -- 65 v_lshl_add_u64 and
+    // 93 v_add_u32 for 50 loads, ~1 300 instructions per wave and two waves per SIMD: the kernel was waiting for instruction issue as much
+    // as for memory.  A uniform row pointer plus the lane's 32-bit node offset leaves one 64-bit addition per load (the uniform part is
+    // formed on the scalar unit): 743 -> 488 instructions, 7.6 -> 6.5 us.
+    const unsigned ib = (unsigned)i * 4u;
+    auto at = [ib](const float* row) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + ib); };
+    const float* r1 = K1t + (size_t)j0 * n;   // row j of the transposed kernels (uniform)
+    const float* r2 = K2t + (size_t)j0 * n;
+    const float* qp = Q + (size_t)j0 * L + l;  // (uniform: scalar loads)
+    for (; j + 25 <= j1; j += 25, r1 += (size_t)25 * n, r2 += (size_t)25 * n, qp += (size_t)25 * L) {
         float k1[25], k2[25], q[25];
 #pragma unroll
-        for (int u = 0; u < 25; u++) { k1[u] = K1t[(j + u) * n + i]; k2[u] = K2t[(j + u) * n + i]; q[u] = Q[(j + u) * L + l]; }
+        for (int u = 0; u < 25; u++) { k1[u] = at(r1 + (size_t)u * n); k2[u] = at(r2 + (size_t)u * n); q[u] = qp[(size_t)u * L]; }
 #pragma unroll
         for (int u = 0; u < 25; u++) { a += k1[u] * q[u]; b += k2[u] * q[u]; }
     }
-    for (; j + 5 <= j1; j += 5) {
+    for (; j + 5 <= j1; j += 5, r1 += (size_t)5 * n, r2 += (size_t)5 * n, qp += (size_t)5 * L) {
         float k1[5], k2[5], q[5];
 #pragma unroll
-        for (int u = 0; u < 5; u++) { k1[u] = K1t[(j + u) * n + i]; k2[u] = K2t[(j + u) * n + i]; q[u] = Q[(j + u) * L + l]; }
+        for (int u = 0; u < 5; u++) { k1[u] = at(r1 + (size_t)u * n); k2[u] = at(r2 + (size_t)u * n); q[u] = qp[(size_t)u * L]; }
 #pragma unroll
         for (int u = 0; u < 5; u++) { a += k1[u] * q[u]; b += k2[u] * q[u]; }
     }
-    for (; j < j1; j++) {
-        const float q = Q[j * L + l];
-        a += K1t[j * n + i] * q;
-        b += K2t[j * n + i] * q;
+    for (; j < j1; j++, r1 += n, r2 += n, qp += L) {
+        const float q = qp[0];
+        a += at(r1) * q;
+        b += at(r2) * q;
     }
     float* out = partial + ((size_t)(c * n + i) * 2) * L;
     out[l] = a; out[L + l] = b;
@@ -621,7 +634,7 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnary
     int* empties = reinterpret_cast<int*>(a.raw + (size_t)A * K);  // scratch behind the raw sums: [2][K] (depth-empty, pixel-empty)
     GSTAMP(0, 0);
     // A: raw sums as f32, phase 1 of the normalisation
-    // (eight entries per lane in flight: this workgroup is alone on the GPU, a loop of dependent round trips to HBM -- 13 of them at five
+    // (eight entries per lane in flight -- sixteen, one round at five models, measured slower late in round 6: 9.6 against 7.2 us --: this workgroup is alone on the GPU, a loop of dependent round trips to HBM -- 13 of them at five
     // models -- was a third of the kernel)
     for (int base = 0; base < A * K; base += 8 * T) {
         unsigned long long sv[8]; int cv[8];
@@ -647,16 +660,20 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnary
         }
     }
     GSTAMP(0, 1);   // raw sums -> f32, phase 1
-    // ordered lists of the empty superpixels (which == 0: no depth sample, which == 1: no pixel at all)
+    // ordered lists of the empty superpixels (which == 0: no depth sample, which == 1: no pixel at all): both counts ride through ONE
+    // scan, sixteen bits each (K <= 4800)
     const int per = (K + T - 1) / T;
-    for (int which = 0; which < 2; which++) {
-        const unsigned* cnts = which == 0 ? a.depth_count : a.spix_count;
-        int c = 0;
-        for (int k = tid * per; k < min(K, (tid + 1) * per); k++) c += cnts[k] == 0;
+    {
+        int c0 = 0, c1 = 0;
+        for (int k = tid * per; k < min(K, (tid + 1) * per); k++) { c0 += a.depth_count[k] == 0; c1 += a.spix_count[k] == 0; }
         int total = 0;
-        int pos = block_scan_inclusive(c, s_scan, &total) - c;
-        for (int k = tid * per; k < min(K, (tid + 1) * per); k++) if (cnts[k] == 0) empties[which * K + pos++] = k;
-        if (tid == 0) s_nempty[which] = total;
+        const int incl = block_scan_inclusive(c0 | (c1 << 16), s_scan, &total);
+        int pos0 = (incl & 0xffff) - c0, pos1 = (incl >> 16) - c1;
+        for (int k = tid * per; k < min(K, (tid + 1) * per); k++) {
+            if (a.depth_count[k] == 0) empties[pos0++] = k;
+            if (a.spix_count[k] == 0) empties[K + pos1++] = k;
+        }
+        if (tid == 0) { s_nempty[0] = total & 0xffff; s_nempty[1] = total >> 16; }
         __syncthreads();
     }
     GSTAMP(0, 2);   // ordered lists
@@ -675,33 +692,12 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnary
     }
     __syncthreads();
     GSTAMP(0, 3);   // empty superpixels replayed
-    // depth range over the valid low-resolution depths (Segmentation.cpp:165-176)
-    {
-        float mn = 3.402823466e+38f, mx = 0.f;
-        for (int k = tid; k < K; k += T) {
-            const float d = a.low[k];
-            if (d > kSegMaxDepth || d < 0 || !is_finite(d)) continue;
-            if (mx < d) mx = d;
-            if (mn > d) mn = d;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float omn = __shfl_xor(mn, o, 64), omx = __shfl_xor(mx, o, 64);
-            if (omn < mn) mn = omn;
-            if (mx < omx) mx = omx;
-        }
-        if (lane == 0) { s_min[wave] = mn; s_max[wave] = mx; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < (T >> 6); w++) { if (s_min[w] < mn) mn = s_min[w]; if (mx < s_max[w]) mx = s_max[w]; }
-            s_range = mx - mn;
-            a.depth_range[0] = s_range;
-        }
-    }
-    GSTAMP(0, 4);   // depth range
-    // average confidence per model: a sequential f32 sum in index order (:193-203), one WAVE per model; non-finite entries count as
-    // zero and are zeroed in place afterwards
-    for (int m = wave; m < n; m += (T >> 6)) {
+    // depth range over the valid low-resolution depths (Segmentation.cpp:165-176) BESIDE the average confidence per model (a sequential
+    // f32 sum in index order, :193-203, one WAVE per model; non-finite entries count as zero and are zeroed in place): with fewer models
+    // than waves, waves [0, n) take the sums and waves [n, T / 64) the range -- neither reads what the other writes
+    const int nw = T >> 6;
+    const bool beside = n < nw;
+    auto average_confidence = [&](int m) {
         float* conf = a.low + (size_t)(1 + n + m) * K;
         float avg;
         if ((K % kSeqBlock) == 0 && (reinterpret_cast<size_t>(conf) & 15) == 0) avg = wave_sequential_sum_finite16(conf, K, lane);
@@ -710,37 +706,102 @@ __global__ void __launch_bounds__(1024) seg_unary_kernel(const SegBatch<SegUnary
             for (int j = lane; j < K; j += 64) if (!is_finite(conf[j])) conf[j] = 0;
         }
         if (lane == 0) a.avg_conf[m] = avg / (float)K;
+    };
+    {
+        float mn = 3.402823466e+38f, mx = 0.f;
+        if (beside && wave < n) average_confidence(wave);
+        else {
+            const int first = beside ? n * 64 : 0;
+            for (int k = tid - first; k < K; k += T - first) {
+                const float d = a.low[k];
+                if (d > kSegMaxDepth || d < 0 || !is_finite(d)) continue;
+                if (mx < d) mx = d;
+                if (mn > d) mn = d;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float omn = __shfl_xor(mn, o, 64), omx = __shfl_xor(mx, o, 64);
+                if (omn < mn) mn = omn;
+                if (mx < omx) mx = omx;
+            }
+        }
+        if (lane == 0) { s_min[wave] = mn; s_max[wave] = mx; }   // (the waves with the sums file the neutral elements)
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < nw; w++) { if (s_min[w] < mn) mn = s_min[w]; if (mx < s_max[w]) mx = s_max[w]; }
+            s_range = mx - mn;
+            a.depth_range[0] = s_range;
+        }
     }
+    GSTAMP(0, 4);   // depth range (+ the average confidences beside it)
+    if (!beside)
+        for (int m = wave; m < n; m += nw) average_confidence(m);
     __syncthreads();
     GSTAMP(0, 5);   // average confidences
     const float depthRange = s_range;
-    // unaries (:237-298, 458-460) and the appearance features (:441-450), one lane per superpixel
-    for (int k = tid; k < K; k += T) {
-        float* icp = a.low + (size_t)K;           // [n][K]
-        const float* conf = a.low + (size_t)(1 + n) * K;
-        if ((double)conf[k] < 0.3) icp[k] = (float)((double)depthRange * 0.01);
-        for (int i = 1; i < n; i++)
-            if ((double)conf[(size_t)i * K + k] <= 0.4) icp[(size_t)i * K + k] = depthRange * a.unaryKError;
-        float lowestError = icp[k] / depthRange;
-        for (int i = 0; i < n; i++) {
-            float error = icp[(size_t)i * K + k];
-            error /= depthRange;
-            if (error < lowestError) lowestError = error;
-            float u = a.unaryWeightError * error;
-            if (u <= 1e-5f) u = 1e-5f;
-            a.unary[(size_t)k * L + i] = u;
+    // unaries (:237-298, 458-460) and the appearance features (:441-450), one lane per superpixel -- and per lane TWO superpixels (k and
+    // k + T: K = 1200 against 1024 lanes was two rounds) with every input of both in one flight of loads: the confidences and errors of
+    // eight models at a time instead of one dependent round trip per model (8.8 -> 4.5 us, late in round 6).  The stores go to elements only
+    // this lane reads.
+    {
+        float* const icp = a.low + (size_t)K;           // [n][K]
+        const float* const conf = a.low + (size_t)(1 + n) * K;
+        const float fill0 = (float)((double)depthRange * 0.01), fillN = depthRange * a.unaryKError;
+        const int nn = n > 0 ? n : 1;   // (model 0's rule and the first lowest error are formed whatever n is)
+        for (int k0 = tid; k0 < K; k0 += 2 * T) {
+            const int kk[2] = {k0, k0 + T};
+            const bool ok[2] = {true, k0 + T < K};
+            const int kc[2] = {k0, ok[1] ? k0 + T : k0};
+            uchar4 px[2]; float lowd[2], lowest[2] = {0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 2; r++) { px[r] = a.rgba[kc[r]]; lowd[r] = a.low[kc[r]]; }
+            for (int i0 = 0; i0 < nn; i0 += 8) {
+                float cf[8][2], ic[8][2];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const size_t at = (size_t)min(i0 + u, nn - 1) * K + kc[r];
+                        cf[u][r] = conf[at]; ic[u][r] = icp[at];
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u;
+                    if (i < nn) {   // (uniform)
+#pragma unroll
+                        for (int r = 0; r < 2; r++)
+                            if (ok[r]) {
+                                float e = ic[u][r];
+                                const bool weak = i == 0 ? (double)cf[u][r] < 0.3 : (double)cf[u][r] <= 0.4;
+                                if (weak) { e = i == 0 ? fill0 : fillN; icp[(size_t)i * K + kk[r]] = e; }
+                                if (i == 0) lowest[r] = e / depthRange;
+                                if (i < n) {
+                                    const float error = e / depthRange;
+                                    if (error < lowest[r]) lowest[r] = error;
+                                    float un = a.unaryWeightError * error;
+                                    if (un <= 1e-5f) un = 1e-5f;
+                                    a.unary[(size_t)kk[r] * L + i] = un;
+                                }
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                if (ok[r]) {
+                    const int k = kk[r];
+                    if (a.allow_new) {
+                        float un = fmaxf(a.unaryThresholdNew - a.unaryWeightError * lowest[r], 0.01f);
+                        if (un <= 1e-5f) un = 1e-5f;
+                        a.unary[(size_t)k * L + n] = un;
+                    }
+                    const int i = k % a.gx, j = k / a.gx;
+                    float* f = a.feat2 + (size_t)k * 6;
+                    f[0] = (float)i * a.scaleFeaturesPos; f[1] = (float)j * a.scaleFeaturesPos;
+                    f[2] = (float)px[r].x * a.scaleFeaturesRGB; f[3] = (float)px[r].y * a.scaleFeaturesRGB; f[4] = (float)px[r].z * a.scaleFeaturesRGB;
+                    f[5] = fminf(lowd[r] * a.scaleFeaturesDepth, 100.0f);
+                }
         }
-        if (a.allow_new) {
-            float u = fmaxf(a.unaryThresholdNew - a.unaryWeightError * lowestError, 0.01f);
-            if (u <= 1e-5f) u = 1e-5f;
-            a.unary[(size_t)k * L + n] = u;
-        }
-        const int i = k % a.gx, j = k / a.gx;
-        const uchar4 p = a.rgba[k];
-        float* f = a.feat2 + (size_t)k * 6;
-        f[0] = (float)i * a.scaleFeaturesPos; f[1] = (float)j * a.scaleFeaturesPos;
-        f[2] = (float)p.x * a.scaleFeaturesRGB; f[3] = (float)p.y * a.scaleFeaturesRGB; f[4] = (float)p.z * a.scaleFeaturesRGB;
-        f[5] = fminf(a.low[k] * a.scaleFeaturesDepth, 100.0f);
     }
     __syncthreads();
     GSTAMP(0, 6);   // unaries + features
@@ -806,6 +867,8 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
     if (tid == 0) s_min_label = 256;
     GSTAMP(1, 0);
     // 1. label with the highest marginal (first maximum), as model id
+    // (two superpixels per lane with eight marginals of each in one flight of loads instead of two rounds: 3.0 us of this phase either
+    // way, late in round 6; the three sweeps of the component loop below are the other 8.7 us)
     for (int k = tid; k < K; k += T) {
         int m = 0; float best = a.Q[(size_t)k * L];
         for (int l = 1; l < L; l++) { const float q = a.Q[(size_t)k * L + l]; if (q > best) { best = q; m = l; } }
@@ -817,6 +880,7 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
     if (tid < a.n_models) s_id2idx[a.ids[tid] & 255] = tid;
     __syncthreads();
     if (tid == 0 && a.allow_new) s_id2idx[a.next_id & 255] = a.n_models;
+    GSTAMP(1, 8);   // (arg-max alone)
     // 2. connected components: min-label propagation over the 4-neighbourhood + pointer jumping until nothing changes; the root of a
     //    component is its smallest index = its first pixel in raster order
     for (;;) {
@@ -841,6 +905,9 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
             parent[k] = p;
         }
         __syncthreads();
+#ifdef CF_ABLATE
+        if (tid == 0 && blockIdx.x == 0) g_seg_trace[1][9]++;   // (sweeps of the component loop)
+#endif
         if (!s_changed) break;
     }
     GSTAMP(1, 1);   // arg-max + connected components
@@ -1433,6 +1500,7 @@ static int enqueue_infer(cf_ctx* ctx, const cf_seg_params* P, const SegJob* jobs
             const char* pn[] = {"arg-max + components", "roots numbered", "component statistics", "gates", "label map", "depth statistics", "publish"};
             for (int k = 0; k < 7; k++) fprintf(stderr, "[seg trace] unary %-22s %6lld ns\n", un[k], (long long)(h[0][k + 1] - h[0][k]) * 10);
             for (int k = 0; k < 7; k++) fprintf(stderr, "[seg trace] post  %-22s %6lld ns\n", pn[k], (long long)(h[1][k + 1] - h[1][k]) * 10);
+            fprintf(stderr, "[seg trace] post  arg-max alone %6lld ns; component sweeps since the start: %lld\n", (long long)(h[1][8] - h[1][0]) * 10, (long long)h[1][9]);
         }
     }
 #endif
