@@ -883,6 +883,9 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
     GSTAMP(1, 8);   // (arg-max alone)
     // 2. connected components: min-label propagation over the 4-neighbourhood + pointer jumping until nothing changes; the root of a
     //    component is its smallest index = its first pixel in raster order
+#ifdef CF_ABLATE
+    int cc_sweep = 0;
+#endif
     for (;;) {
         __syncthreads();
         if (tid == 0) s_changed = 0;
@@ -899,17 +902,31 @@ __global__ void __launch_bounds__(1024) seg_post_kernel(const SegBatch<SegPostAr
             if (p < own) { atomicMin(&parent[own], p); atomicMin(&parent[k], p); s_changed = 1; }
         }
         __syncthreads();
-        for (int k = tid; k < K; k += T) {  // pointer jumping
+#ifdef CF_ABLATE
+        if (tid == 0 && blockIdx.x == 0 && cc_sweep < 3) g_seg_trace[1][10 + 2 * cc_sweep] = wall_clock64();   // (hooks of this sweep done)
+#endif
+        if (!s_changed) break;   // (nothing hooked: every entry is still the root the last sweep's walk left -- or itself, in the first sweep)
+        // walks to the roots.  After the first sweep's hooks a superpixel's chain runs up its column and along a row -- up to 70 hops of one
+        // dependent LDS read each, 4.5 of this loop's 8.7 us (per-sweep stamps, late in round 6).  Every step of a walk is now WRITTEN to the
+        // walker's own entry: the walkers that pass through it later jump where it has got to, so the lanes double each other's strides
+        // (pointer jumping without its barriers).  Racy and monotone: during this pass nothing hooks, an entry only ever moves to an ancestor,
+        // and a walk ends at an entry that is its own parent -- the same roots.
+        for (int k = tid; k < K; k += T) {
             int p = parent[k];
-            while (parent[p] != p) p = parent[p];
+            for (;;) {
+                const int q = parent[p];
+                if (q == p) break;
+                parent[k] = q;
+                p = q;
+            }
             parent[k] = p;
         }
-        __syncthreads();
 #ifdef CF_ABLATE
-        if (tid == 0 && blockIdx.x == 0) g_seg_trace[1][9]++;   // (sweeps of the component loop)
+        __syncthreads();
+        if (tid == 0 && blockIdx.x == 0) { g_seg_trace[1][9]++; if (cc_sweep < 3) g_seg_trace[1][11 + 2 * cc_sweep] = wall_clock64(); }   // (sweeps of the component loop; walks done)
+        cc_sweep++;
 #endif
-        if (!s_changed) break;
-    }
+    }   // (the barrier at the top of the next sweep stands between this sweep's walks and its hooks)
     GSTAMP(1, 1);   // arg-max + connected components
     // 3. number the roots in index order (exclusive scan of the root flags); a root also files its label under its number
     const int per = (K + T - 1) / T;
@@ -1501,6 +1518,9 @@ static int enqueue_infer(cf_ctx* ctx, const cf_seg_params* P, const SegJob* jobs
             for (int k = 0; k < 7; k++) fprintf(stderr, "[seg trace] unary %-22s %6lld ns\n", un[k], (long long)(h[0][k + 1] - h[0][k]) * 10);
             for (int k = 0; k < 7; k++) fprintf(stderr, "[seg trace] post  %-22s %6lld ns\n", pn[k], (long long)(h[1][k + 1] - h[1][k]) * 10);
             fprintf(stderr, "[seg trace] post  arg-max alone %6lld ns; component sweeps since the start: %lld\n", (long long)(h[1][8] - h[1][0]) * 10, (long long)h[1][9]);
+            for (int k = 0; k < 3; k++)
+                fprintf(stderr, "[seg trace] post  component sweep %d: hooks done at %6lld ns, walks done at %6lld ns (from the kernel's first stamp; stale if the sweep did not run)\n", k,
+                        (long long)(h[1][10 + 2 * k] - h[1][0]) * 10, (long long)(h[1][11 + 2 * k] - h[1][0]) * 10);
         }
     }
 #endif

@@ -204,3 +204,32 @@ def test_batched_segmentation_of_several_segmenters_matches_the_oracle():
                 ctx.lib.cf_seg_destroy(seg)
     assert max(sizes) >= 2
     ctx.close()
+
+
+def test_segmentation_stage_with_a_ragged_superpixel_count(monkeypatch):
+    """176 x 144: 11 x 9 = 99 superpixels, not a multiple of sixteen -- the blocked sequential sums of the statistics pad their last block
+    (seg_post_kernel) or fall back to the strided flavour (seg_unary_kernel's average confidences); and a single wave's worth of superpixels
+    per row of lanes instead of 1200 against 1024."""
+    import sys
+    from co_fusion_amd import api, synth
+    me = sys.modules[__name__]
+    w, h = 176, 144
+    for k, v in (("W", w), ("H", h), ("GX", w // 16), ("GY", h // 16)):
+        monkeypatch.setattr(me, k, v)
+    monkeypatch.setattr(me, "_REFS", {})
+    cam = synth.Camera.scaled(w, h)
+    ctx = api.Context(w, h, cam.fx, cam.fy, cam.cx, cam.cy, max_models=48)
+    seg = C.c_void_p()
+    ctx._check(ctx.lib.cf_seg_create(ctx.h, C.byref(seg)))
+    ran = 0
+    for sc in _scenarios()[:6]:
+        name, params, rgba, depth, ids, icp, vcs, next_id, allow_new = sc
+        ref = _ref(sc)
+        p = params.__class__.from_buffer_copy(params)
+        for rep in range(2):
+            res, low, full = _run_hip(ctx, seg, p, rgba, depth, ids, icp, vcs, next_id, allow_new)
+            _compare(f"{name} at {w}x{h} (pass {rep})", res, low, full, ref)
+        ran += 1
+    assert ran == 6 and (me.GX * me.GY) % 16 != 0
+    ctx.lib.cf_seg_destroy(seg)
+    ctx.close()
