@@ -56,6 +56,7 @@ struct cf_model {
     unsigned long long* keys = nullptr;
     unsigned* index = nullptr;
     float *vertConf = nullptr, *colorTime = nullptr, *normRad = nullptr;
+    float* clean_rec = nullptr;   // [H*W][8]: vertConf | colorTime.zw, index, filtered depth per texel, packed by the index pass in front of the clean stage (cf_models_frame_passes)
     uint8_t* splat_image = nullptr;
     float *splat_vertex = nullptr, *splat_normal = nullptr;
     uint16_t* splat_time = nullptr;
@@ -128,6 +129,7 @@ int cf_model_create(cf_ctx* ctx, int max_surfels, cf_model** out)
     if (int r = dmalloc(ctx, &m->vertConf, N * 4)) return r;
     if (int r = dmalloc(ctx, &m->colorTime, N * 4)) return r;
     if (int r = dmalloc(ctx, &m->normRad, N * 4)) return r;
+    if (int r = dmalloc(ctx, &m->clean_rec, N * 8)) return r;
     if (int r = dmalloc(ctx, &m->splat_image, N * 4)) return r;
     if (int r = dmalloc(ctx, &m->splat_vertex, N * 4)) return r;
     if (int r = dmalloc(ctx, &m->splat_normal, N * 4)) return r;
@@ -161,7 +163,7 @@ void cf_model_destroy(cf_model* m)
     void* ptrs[] = {m->buf[0], m->buf[1], m->staged, m->flags, m->block_sums, m->d_count, m->d_nfresh, m->d_tmp2, m->records,
                     m->fresh, m->new_flags, m->owner, m->fb_rec, m->fb_raw, m->fb_filt, m->keys, m->index, m->vertConf,
                     m->colorTime, m->normRad, m->splat_image, m->splat_vertex, m->splat_normal, m->splat_time, m->fill_vertex,
-                    m->fill_normal, m->fill_image, m->tcx, m->tcy, m->rays, m->t_inv_dev};
+                    m->fill_normal, m->fill_image, m->tcx, m->tcy, m->rays, m->t_inv_dev, m->clean_rec};
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(m->h_counts);
     if (m->count_event) (void)hipEventDestroy(m->count_event);
@@ -418,7 +420,7 @@ int cf_model_clean(cf_model* m, const float pose[16], int time, float confThresh
     const unsigned bound = nb + (unsigned)((W / 2) * (H / 2));
     if (bound > m->max_surfels + (unsigned)(W * H / 4 + 64)) return CF_ENOMEM;
     SurfelCleanArgs a;
-    a.index = m->index; a.vertConf = m->vertConf; a.colorTime = m->colorTime; a.depth_filt = depth_filt; a.mask = mask;
+    a.index = m->index; a.vertConf = m->vertConf; a.colorTime = m->colorTime; a.depth_filt = depth_filt; a.mask = mask; a.rec = nullptr;
     inv44f(pose, a.t_inv); a.cam = ctx_cam(ctx); a.cols = W; a.rows = H; a.time = time; a.confThreshold = confThreshold;
     a.outlierCoeff = outlierCoeff; a.timeDelta = timeDelta; a.maskID = maskID;
     launch_clean(s, m->buf[m->target], m->d_count, m->fresh, m->d_nfresh, bound, a, m->staged, m->flags);
@@ -509,7 +511,8 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
         for (int k = 0; k < n; k++) ctx->surf_bytes += (uint64_t)items[k].model->count_host * 48u * (items[k].do_fuse ? 8u : 2u);
         ctx->surf_calls++;
     }
-    auto index_pass = [&](const std::vector<int>& which) -> int {
+    static const bool clean_rec_on = getenv("CF_NO_CLEAN_REC") == nullptr;   // (diagnostic: the clean stage stages from the three index-map arrays as until round 6)
+    auto index_pass = [&](const std::vector<int>& which, bool feeds_clean = false) -> int {
         std::vector<IndexPassArgs> a(which.size());
         for (size_t q = 0; q < which.size(); q++) {
             const cf_model_pass& it = items[which[q]]; cf_model* m = it.model;
@@ -519,6 +522,9 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
             p.surfels = m->buf[m->target]; p.count = m->d_count; p.id_begin = 0; p.id_end = nb; inv44f(it.pose, p.t_inv); p.maxDepth = depth_cutoff;
             p.time = it.time; p.timeDelta = time_delta; p.keys = m->keys; p.index = m->index; p.vertConf = m->vertConf; p.colorTime = m->colorTime;
             p.normRad = m->normRad;
+            // the pass in front of the clean stage also packs what that stage reads per texel -- with this frame's filtered depth -- into
+            // one 32-byte record (clean_kernel stages a 4x4 neighbourhood per surfel: one array and 16-byte pieces instead of three arrays)
+            if (feeds_clean && clean_rec_on) { p.clean_rec = m->clean_rec; p.clean_depth = it.depth_filtered; }
         }
         launch_index_keys_batch(s, a.data(), (int)a.size(), cam, W, H);
         launch_index_resolve_batch(s, a.data(), (int)a.size(), cam, W, H);
@@ -557,7 +563,7 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
         launch_scan_scatter_batch(s, sa.data(), nf);   // the new unstable vertices in column-major draw order (transform feedback of data.geom)
         launch_update_batch(s, ua.data(), nf);          // update.vert over all surfels into the other buffer, then swap (Model.cpp:559)
         for (int q = 0; q < nf; q++) items[fusing[q]].model->target = 1 - items[fusing[q]].model->target;
-        if (int r = index_pass(fusing)) return r;
+        if (int r = index_pass(fusing, true)) return r;
         // Model::clean (Model.cpp:565-697)
         std::vector<CleanPassArgs> ca(nf);
         std::vector<uint32_t> upper(nf);
@@ -569,6 +575,7 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
             if (bound > m->max_surfels + (unsigned)(W * H / 4 + 64)) return CF_ENOMEM;
             CleanPassArgs& c = ca[q];
             c.h.index = m->index; c.h.vertConf = m->vertConf; c.h.colorTime = m->colorTime; c.h.depth_filt = it.depth_filtered; c.h.mask = it.mask;
+            c.h.rec = clean_rec_on ? m->clean_rec : nullptr;
             inv44f(it.pose, c.h.t_inv); c.h.cam = cam; c.h.cols = W; c.h.rows = H; c.h.time = it.time; c.h.confThreshold = it.conf_threshold;
             c.h.outlierCoeff = outlier_coeff; c.h.timeDelta = time_delta; c.h.maskID = it.mask_id;
             c.surfels = m->buf[m->target]; c.count = m->d_count; c.fresh = m->fresh; c.n_fresh = m->d_nfresh; c.total_bound = bound; c.staged = m->staged;

@@ -353,6 +353,8 @@ struct IndexPassArgs {   // Model::predictIndices of one model: rasterise surfel
     unsigned long long* keys; unsigned* index; float* vertConf; float* colorTime; float* normRad;
     const float* t_inv_dev;   // nullable: the inverse pose in device memory (OdomDev::pose_inv) instead of t_inv -- an index pass enqueued
                               // before the host has seen the tracked pose (cf_models_preindex)
+    float* clean_rec;         // nullable: [rows * cols][8] -- what the clean pass stages per texel, packed by the resolve pass that feeds it:
+    const float* clean_depth; // vertConf.xyzw | colorTime.z, colorTime.w, index, this filtered depth (SurfelCleanArgs::rec)
 };
 // pose.inverse() of a rigid transform: linear part by cofactors (the statement of the oracle, orc_surfel.c); host and device
 __host__ __device__ inline void inv44f(const float a[16], float o[16])
@@ -391,6 +393,7 @@ struct SurfelFuseArgs {
 struct SurfelCleanArgs {
     const unsigned* index; const float* vertConf; const float* colorTime;
     const float* depth_filt; const uint8_t* mask;
+    const float* rec;   // nullable: the packed records of the index pass in front of this call (IndexPassArgs::clean_rec, written with depth_filt)
     float t_inv[16]; cf_cam cam; int cols, rows, time; float confThreshold, outlierCoeff; int timeDelta, maskID;
 };
 struct CleanPassArgs {   // Model::clean of one model

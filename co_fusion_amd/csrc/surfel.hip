@@ -321,6 +321,7 @@ struct IndexArgs {   // predictIndices of one model (both kernels)
     const float4* surfels; const unsigned* count; Mat4 t_inv; float maxDepth; int time, timeDelta; unsigned id_begin, id_end;
     unsigned long long* keys; unsigned* index; float4* vertConf; float4* colorTime; float4* normRad;
     const float* t_inv_dev;   // nullable: the matrix in device memory instead (IndexPassArgs::t_inv_dev)
+    float4* clean_rec; const float* clean_depth;   // nullable: the clean pass's packed per-texel records (IndexPassArgs::clean_rec)
 };
 __device__ __forceinline__ Mat4 index_matrix(const IndexArgs& a)
 {
@@ -358,9 +359,16 @@ __global__ void __launch_bounds__(kB) index_resolve_kernel(const Batch<IndexArgs
     if (q >= g.cols * g.rows) return;
     const unsigned long long k = keys[q];
     keys[q] = kEmptyKey;  // leave the z-buffer cleared for the next pass (no memset launch per projection)
+    // The pass in front of the clean stage also leaves what clean_kernel stages per texel as ONE 32-byte record (vertConf | colorTime.zw, index,
+    // the frame's filtered depth) beside the arrays the other passes read (late in round 6: +7 us here, -17 us there).  Measured as well:
+    // the two halves changing lanes so that every store instruction of a wave writes 1 KB in one piece (no gain: 23.4 against 22.8 us -- it
+    // is the bytes, not the store pattern), and a 16-byte record without vertConf (clean_kernel's comment).
+    float4* __restrict__ const rec = a.clean_rec;
+    const float dflt = rec ? a.clean_depth[q] : 0.f;
     if (k == kEmptyKey) {
         index[q] = 0;
         vertConf[q] = colorTime[q] = normRad[q] = make_float4(0, 0, 0, 0);
+        if (rec) { rec[2 * q] = make_float4(0, 0, 0, 0); rec[2 * q + 1] = make_float4(0, 0, __uint_as_float(0u), dflt); }
         return;
     }
     const unsigned id = (unsigned)k;
@@ -372,6 +380,7 @@ __global__ void __launch_bounds__(kB) index_resolve_kernel(const Batch<IndexArgs
     vertConf[q] = make_float4(ph.x, ph.y, ph.z, pc.w);
     colorTime[q] = ct;
     normRad[q] = make_float4(n.x, n.y, n.z, nr.w);
+    if (rec) { rec[2 * q] = make_float4(ph.x, ph.y, ph.z, pc.w); rec[2 * q + 1] = make_float4(ct.z, ct.w, __uint_as_float(id), dflt); }
 }
 
 // ============================================================================ splat prediction ====
@@ -761,9 +770,13 @@ struct CleanArgs {
     const unsigned* index; const float4* vertConf; const float4* colorTime;
     const float* depth_filt; const unsigned char* mask;
     Mat4 t_inv; cf_cam cam; int cols, rows, time; float confThreshold, outlierCoeff; int timeDelta, maskID;
+    const float4* rec;   // nullable: [rows * cols][2] vertConf | colorTime.zw, index, filtered depth per texel, packed by the index pass in front of this one (IndexArgs::clean_rec)
     // (the launch's per-model buffers, kernel parameters until round 4)
     const float4* surfels; const unsigned* count; const float4* fresh; const unsigned* n_fresh; unsigned total_bound; float4* staged; unsigned* flags;
     int xcd;   // workgroup order of THIS model's share (xcd_block): runs of 64 per XCD for a large map, the hardware's order for a small one
+#ifdef CF_ABLATE
+    int abl;   // diagnostics build (CF_CLEAN_ABLATE): 1 no staging of the texel patch, 2 no 4x4 window, 4 no 3x3 depth window -- timing only, results are wrong
+#endif
 };
 
 // The 4x4 half-pixel window touches at most a 4x4 texel neighbourhood of the index map textures.  Reading it
@@ -773,18 +786,36 @@ struct CleanArgs {
 // loads, splits the outer window loop (lane s takes iterations s, s+4, ...; the shader's f32 loop counters are
 // kept), and adds up the two vote counts, which do not depend on the order.  Texels outside the staged patch
 // (only reachable through the f32 loop-counter corner cases) fall back to the global fetch.
-static constexpr int kCleanItems = kB / 4;
+// Late in round 6 ("measure the rewrite"): timing ablations of this kernel (diagnostics build, CF_CLEAN_ABLATE;
+// profiles/r6zd_*) put its 70 us at 17 us for loading / projecting / storing the surfels, 24 us for STAGING the neighbourhood -- twelve loads
+// per lane from three arrays, every lane of a wave on a row of its own: 64 segments per instruction --, 14 us for the 4x4 window's
+// arithmetic and 12 us for the 3x3 depth window's nine gathers per lane.  So the staging reads ONE array now, packed by the index pass in
+// front of this one (index_resolve_kernel: vertConf | colorTime.zw, index, filtered depth = 32 bytes per texel), in 16-byte pieces dealt to the
+// quad's lanes so that a quad reads 64 consecutive bytes per instruction (eight loads per lane, 16 segments per instruction), and the depth
+// window is served from the staged patch (an eighth word per texel).  Without the records (cf_model_clean called alone) the old staging runs.
+// (Measured as well: only colorTime.zw | index | depth in the record, 16 bytes, vertConf staged from its own array -- the index pass cheaper
+// by 2.4 us, this kernel 64.9 against 52.2 us.)
+// The eighth word makes a 256-thread workgroup's patches 33 KB: four workgroups per CU where 29 KB allowed five, and the kernel lives on its
+// occupancy (81 against 70 us for the old staging with the larger stride).  Workgroups of kCleanB threads (8.3 KB each at 64) fill the
+// CU's 160 KB to within a wave of the old occupancy.
+#ifndef CF_CLEAN_B
+#define CF_CLEAN_B 64
+#endif
+static constexpr int kCleanB = CF_CLEAN_B;
+static constexpr int kCleanItems = kCleanB / 4;
+static constexpr int kCleanStride = 8 * 16 + 1;  // words per staged neighbourhood: 8 words x 16 texels (+1: odd stride)
 
-__global__ void __launch_bounds__(kB) clean_kernel(const Batch<CleanArgs> B)
+__global__ void __launch_bounds__(kCleanB) clean_kernel(const Batch<CleanArgs> B)
 {
-    __shared__ float s_patch[kCleanItems * kPatchStride];
+    __shared__ float s_patch[kCleanItems * kCleanStride];
     const VBlock vb = batch_decode(B.h);
     const CleanArgs& a = B.m[vb.model];
     const float4* __restrict__ surfels = a.surfels; const unsigned* __restrict__ count = a.count; const float4* __restrict__ fresh = a.fresh;
     const unsigned* __restrict__ n_fresh = a.n_fresh; const unsigned total_bound = a.total_bound; float4* __restrict__ staged = a.staged;
     unsigned* __restrict__ flags = a.flags;
-    float* const P = s_patch + (threadIdx.x >> 2) * kPatchStride;  // word c of texel t: P[c * 16 + t]
-    const unsigned gt = (unsigned)xcd_block(a.xcd, vb.bid, vb.nblk) * kB + threadIdx.x;
+    float* const P = s_patch + (threadIdx.x >> 2) * kCleanStride;  // word c of texel t: P[c * 16 + t]
+    const float4* __restrict__ const rec = a.rec;
+    const unsigned gt = (unsigned)xcd_block(a.xcd, vb.bid, vb.nblk) * kCleanB + threadIdx.x;
     const unsigned k = gt >> 2;
     const int sub = (int)(gt & 3u);
     const unsigned n_old = *count, n_all = n_old + *n_fresh;
@@ -810,7 +841,23 @@ __global__ void __launch_bounds__(kB) clean_kernel(const Batch<CleanArgs> B)
     }
     const float iBeg = x_n - (scale * indexXStep * windowMultiplier), jBeg = y_n - (scale * indexYStep * windowMultiplier);
     const int X0 = (int)floorf(iBeg * (float)cols - 0.5f), Y0 = (int)floorf(jBeg * (float)rows - 0.5f);
-    if (window) {  // patch row `sub`
+#ifdef CF_ABLATE
+    const int abl = a.abl;
+#else
+    constexpr int abl = 0;
+#endif
+    if (window && rec && !(abl & 1)) {  // the quad's 32 pieces of 16 bytes (4 rows x 4 texels x 2 halves): lane `sub` takes pieces sub, sub + 4, ...
+        const int half = sub & 1;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int row = q >> 1, tex = (sub >> 1) + 2 * (q & 1), t = row * 4 + tex;
+            const int g = iclamp(Y0 + row, 0, rows - 1) * cols + iclamp(X0 + tex, 0, cols - 1);
+            const float4 v = rec[2 * g + half];
+            float* const o = P + half * 64 + t;   // words 0..3 (vertConf) or 4..7 (colorTime.z, .w, index, depth)
+            o[0] = v.x; o[16] = v.y; o[32] = v.z; o[48] = v.w;
+        }
+    } else
+    if (window && !(abl & 1)) {  // patch row `sub`
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int t = sub * 4 + c;
@@ -828,7 +875,7 @@ __global__ void __launch_bounds__(kB) clean_kernel(const Batch<CleanArgs> B)
     int test = 1;
     int cnt = 0, zCount = 0, violationCount = 0;
     float avgViolation = 0;
-    if (window) {
+    if (window && !(abl & 2)) {
         // lane `sub` owns the outer iterations sub, sub+4, ... (see associate_kernel)
         float i = iBeg;
         for (int s4 = 0; s4 < sub; s4++) i += indexXStep;
@@ -866,10 +913,15 @@ __global__ void __launch_bounds__(kB) clean_kernel(const Batch<CleanArgs> B)
                 }
             }
         }
+    }
+    if (window && !(abl & 4)) {
         // every lane of the quad walks the 3x3 depth window (sequential f32 sum) so that all four hold the result
         for (float i = x_n - stepX; i <= x_n + stepX; i += stepX)
             for (float j = y_n - stepY; j <= y_n + stepY; j += stepY) {
-                const float d = a.depth_filt[nearest_texel(j, rows) * cols + nearest_texel(i, cols)] - localPos.z;
+                const int tx = nearest_texel(i, cols), ty = nearest_texel(j, rows);
+                const int lx = tx - X0, ly = ty - Y0;   // (inside the staged patch unless the f32 loop counters stray)
+                const float dv = (rec && (unsigned)lx < 4u && (unsigned)ly < 4u) ? P[7 * 16 + ly * 4 + lx] : a.depth_filt[ty * cols + tx];
+                const float d = dv - localPos.z;
                 if (d > 0.03f) { violationCount++; avgViolation += d; }
             }
     }
@@ -932,7 +984,7 @@ static IndexArgs index_args(const IndexPassArgs& h)
 {
     return IndexArgs{reinterpret_cast<const float4*>(h.surfels), h.count, mat4_from(h.t_inv), h.maxDepth, h.time, h.timeDelta, h.id_begin, h.id_end,
                      h.keys, h.index, reinterpret_cast<float4*>(h.vertConf), reinterpret_cast<float4*>(h.colorTime), reinterpret_cast<float4*>(h.normRad),
-                     h.t_inv_dev};
+                     h.t_inv_dev, reinterpret_cast<float4*>(h.clean_rec), h.clean_depth};
 }
 void launch_index_keys_batch(hipStream_t s, const IndexPassArgs* items, int n_items, cf_cam cam, int cols, int rows)
 {
@@ -1096,17 +1148,25 @@ void launch_clean_batch(hipStream_t s, const CleanPassArgs* items, int n_items)
             const SurfelCleanArgs& h = p.h;
             CleanArgs& a = B.m[k];
             a.index = h.index; a.vertConf = reinterpret_cast<const float4*>(h.vertConf); a.colorTime = reinterpret_cast<const float4*>(h.colorTime);
+            a.rec = reinterpret_cast<const float4*>(h.rec);
             a.depth_filt = h.depth_filt; a.mask = h.mask; a.t_inv = mat4_from(h.t_inv); a.cam = h.cam; a.cols = h.cols; a.rows = h.rows; a.time = h.time;
             a.confThreshold = h.confThreshold; a.outlierCoeff = h.outlierCoeff; a.timeDelta = h.timeDelta; a.maskID = h.maskID;
             a.surfels = reinterpret_cast<const float4*>(p.surfels); a.count = p.count; a.fresh = reinterpret_cast<const float4*>(p.fresh);
             a.n_fresh = p.n_fresh; a.total_bound = p.total_bound; a.staged = reinterpret_cast<float4*>(p.staged); a.flags = p.flags;
             // (the XCD-ordered runs need a share that is a multiple of 8 x 64 workgroups: for an object model of a few thousand surfels
             // that padding would be a third again of its workgroups, all of them empty)
-            a.xcd = gridFor(4ll * p.total_bound) >= 4 * 8 * chunk ? chunk : 0;
-            blocks[k] = p.total_bound > 0 ? gridXcd(4ll * p.total_bound, a.xcd) : 0;
+            // (in workgroups of kCleanB threads: the runs cover the same surfels as `chunk` workgroups of kB did)
+            const int cchunk = chunk * (kB / kCleanB);
+            const long long cgrid = (4ll * p.total_bound + kCleanB - 1) / kCleanB;
+            a.xcd = cgrid >= 4ll * 8 * cchunk ? cchunk : 0;
+#ifdef CF_ABLATE
+            static const int clean_abl = getenv("CF_CLEAN_ABLATE") ? atoi(getenv("CF_CLEAN_ABLATE")) : 0;
+            a.abl = clean_abl;
+#endif
+            { const int q = 8 * (a.xcd > 1 ? a.xcd : 1); blocks[k] = p.total_bound > 0 ? (int)((cgrid + q - 1) / q * q) : 0; }
             any += blocks[k];
         }
-        if (any) clean_kernel<<<batch_layout(B, blocks, nb), kB, 0, s>>>(B);
+        if (any) clean_kernel<<<batch_layout(B, blocks, nb), kCleanB, 0, s>>>(B);
     }
 }
 void launch_clean(hipStream_t s, const float* surfels, const unsigned* count, const float* fresh, const unsigned* n_fresh, unsigned total_bound,
