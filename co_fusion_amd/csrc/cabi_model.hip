@@ -512,8 +512,8 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
         ctx->surf_calls++;
     }
     static const bool clean_rec_on = getenv("CF_NO_CLEAN_REC") == nullptr;   // (diagnostic: the clean stage stages from the three index-map arrays as until round 6)
-    auto index_pass = [&](const std::vector<int>& which, bool feeds_clean = false) -> int {
-        std::vector<IndexPassArgs> a(which.size());
+    auto index_args_of = [&](const std::vector<int>& which, bool feeds_clean, std::vector<IndexPassArgs>& a) -> int {
+        a.assign(which.size(), IndexPassArgs{});
         for (size_t q = 0; q < which.size(); q++) {
             const cf_model_pass& it = items[which[q]]; cf_model* m = it.model;
             uint32_t nb = 0;
@@ -526,6 +526,11 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
             // one 32-byte record (clean_kernel stages a 4x4 neighbourhood per surfel: one array and 16-byte pieces instead of three arrays)
             if (feeds_clean && clean_rec_on) { p.clean_rec = m->clean_rec; p.clean_depth = it.depth_filtered; }
         }
+        return CF_OK;
+    };
+    auto index_pass = [&](const std::vector<int>& which) -> int {
+        std::vector<IndexPassArgs> a;
+        if (int r = index_args_of(which, false, a)) return r;
         launch_index_keys_batch(s, a.data(), (int)a.size(), cam, W, H);
         launch_index_resolve_batch(s, a.data(), (int)a.size(), cam, W, H);
         return CF_OK;
@@ -560,10 +565,21 @@ int cf_models_frame_passes(cf_ctx* ctx, const cf_model_pass* items, int n, float
             ua[q] = UpdatePassArgs{m->buf[m->target], m->d_count, nb, m->owner, m->records, it.time, m->buf[1 - m->target]};
         }
         launch_associate_batch(s, fa.data(), nf);
-        launch_scan_scatter_batch(s, sa.data(), nf);   // the new unstable vertices in column-major draw order (transform feedback of data.geom)
-        launch_update_batch(s, ua.data(), nf);          // update.vert over all surfels into the other buffer, then swap (Model.cpp:559)
+        // the new unstable vertices in column-major draw order (transform feedback of data.geom) || update.vert over all surfels into the
+        // other buffer, then swap (Model.cpp:559) || the rasterisation of the index pass in front of the clean stage: three stages that do
+        // not read each other's outputs except update -> rasterisation, as two launches (launch_update_compaction_index_keys)
         for (int q = 0; q < nf; q++) items[fusing[q]].model->target = 1 - items[fusing[q]].model->target;
-        if (int r = index_pass(fusing, true)) return r;
+        {
+            std::vector<IndexPassArgs> ia;
+            if (int r = index_args_of(fusing, true, ia)) return r;   // (of the swapped buffers: what the update writes)
+            static const bool side_by_side = getenv("CF_NO_SIDE_BY_SIDE") == nullptr;   // (diagnostic: the four separate launches)
+            if (!(side_by_side && launch_update_compaction_index_keys(s, ua.data(), sa.data(), ia.data(), nf, cam, W, H))) {
+                launch_scan_scatter_batch(s, sa.data(), nf);
+                launch_update_batch(s, ua.data(), nf);
+                launch_index_keys_batch(s, ia.data(), nf, cam, W, H);
+            }
+            launch_index_resolve_batch(s, ia.data(), nf, cam, W, H);
+        }
         // Model::clean (Model.cpp:565-697)
         std::vector<CleanPassArgs> ca(nf);
         std::vector<uint32_t> upper(nf);

@@ -405,6 +405,8 @@ struct ScanPassArgs {    // one ordered compaction (transform feedback): the fla
     int zero_flags = 0;   // 1: the pass leaves the flags it has read cleared (the association's new-surfel flags: the next frame's pass finds zeros, no fill launch)
 };
 void launch_index_keys_batch(hipStream_t s, const IndexPassArgs* items, int n, cf_cam cam, int cols, int rows);
+bool launch_update_compaction_index_keys(hipStream_t s, const UpdatePassArgs* up, const ScanPassArgs* sc, const IndexPassArgs* ix, int n, cf_cam cam, int cols,
+                                         int rows);   // the three stages as two launches (surfel.hip); false = not enqueued, use the separate launches
 void launch_index_resolve_batch(hipStream_t s, const IndexPassArgs* items, int n, cf_cam cam, int cols, int rows);
 void launch_combined_predict_batch(hipStream_t s, const SplatPassArgs* items, int n, cf_cam cam, int cols, int rows);
 void launch_associate_batch(hipStream_t s, const SurfelFuseArgs* items, int n);   // zeroes the new_flags of every model that is not flags_clean first

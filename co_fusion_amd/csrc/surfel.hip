@@ -47,15 +47,15 @@ static constexpr int xcd_env(const char*, int dflt) { return dflt; }
 struct BatchHdr { int n; int blk_end[kSurfBatch]; };
 template <class A> struct Batch { BatchHdr h; A m[kSurfBatch]; };
 struct VBlock { int model, bid, nblk; };
-__device__ __forceinline__ VBlock batch_decode(const BatchHdr& h)
+__device__ __forceinline__ VBlock batch_decode_at(const BatchHdr& h, int b)
 {
-    const int b = blockIdx.x;
     int slot = 0;
 #pragma unroll
     for (int k = 0; k < kSurfBatch - 1; k++) slot += (b >= h.blk_end[k]) ? 1 : 0;
     const int start = slot ? h.blk_end[slot - 1] : 0;
     return VBlock{slot, b - start, h.blk_end[slot] - start};
 }
+__device__ __forceinline__ VBlock batch_decode(const BatchHdr& h) { return batch_decode_at(h, (int)blockIdx.x); }
 // host side: the table of a launch from the models' workgroup counts (each padded to a multiple of 8); returns the grid size
 template <class A>
 static int batch_layout(Batch<A>& B, const int* blocks, int n)
@@ -143,9 +143,9 @@ __device__ __forceinline__ void scan_load_flags(const unsigned* __restrict__ fla
         for (int e = 0; e < 8; e++) f[e] = (i0 + e < n) ? t[e] : 0u;
     }
 }
-__global__ void __launch_bounds__(256) scan_block_sums_kernel(const Batch<ScanArgs> B)
+__device__ __forceinline__ void scan_block_sums_body(const Batch<ScanArgs>& B, int blk)
 {
-    const VBlock vb = batch_decode(B.h);
+    const VBlock vb = batch_decode_at(B.h, blk);
     const ScanArgs& a = B.m[vb.model];
     const unsigned* __restrict__ flags = a.flags; const long long n = a.n; unsigned* __restrict__ block_sums = a.block_sums;
     if ((long long)vb.bid * kScanItems >= n) return;   // (padding workgroups of the batch layout)
@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(256) scan_block_sums_kernel(const Batch<ScanAr
     __syncthreads();
     if (threadIdx.x == 0) block_sums[vb.bid] = w[0] + w[1] + w[2] + w[3];
 }
+__global__ void __launch_bounds__(256) scan_block_sums_kernel(const Batch<ScanArgs> B) { scan_block_sums_body(B, (int)blockIdx.x); }
 __global__ void set_count_kernel(unsigned* out, unsigned v);
 __global__ void set_count2_kernel(unsigned* out, unsigned* out_host, unsigned v);
 // Ordered compaction in TWO launches (scan_block_sums_kernel, then this): every workgroup derives its own base from the block
@@ -172,9 +173,9 @@ __global__ void set_count2_kernel(unsigned* out, unsigned* out_host, unsigned v)
 // compaction keeps the order, so they fill ONE contiguous range of the output) and the workgroup copies that range as a stream of
 // 16-byte words: thread t writes word t, t + 256, ... of the range -- contiguous stores, reads contiguous wherever the flags are dense --
 // twelve independent loads in flight per thread.
-__global__ void __launch_bounds__(256) scan_scatter_kernel(const Batch<ScanArgs> B)
+__device__ __forceinline__ void scan_scatter_body(const Batch<ScanArgs>& B, int blk)
 {
-    const VBlock vb = batch_decode(B.h);
+    const VBlock vb = batch_decode_at(B.h, blk);
     const ScanArgs& a = B.m[vb.model];
     const float4* __restrict__ rec = a.rec; const unsigned* __restrict__ flags = a.flags; const long long n = a.n;
     const unsigned* __restrict__ block_sums = a.block_sums; unsigned* __restrict__ total = a.total; const unsigned add_to_total = a.add_to_total;
@@ -239,6 +240,7 @@ __global__ void __launch_bounds__(256) scan_scatter_kernel(const Batch<ScanArgs>
         if (total_host) *total_host = base + count + add_to_total;  // pinned host memory: the read-back needs no copy command on the stream
     }
 }
+__global__ void __launch_bounds__(256) scan_scatter_kernel(const Batch<ScanArgs> B) { scan_scatter_body(B, (int)blockIdx.x); }
 
 // n models' compactions in two launches; a model without elements (n == 0) only has its total set
 void launch_scan_scatter_batch(hipStream_t s, const ScanPassArgs* items, int n_items)
@@ -335,9 +337,9 @@ __device__ __forceinline__ Mat4 index_matrix(const IndexArgs& a)
 // kernel of its own, pose_tinv_kernel, until then)
 struct FrameGeom { cf_cam cam; int cols, rows; };   // what the models of a launch share
 
-__global__ void __launch_bounds__(kB) index_splat_kernel(const Batch<IndexArgs> B, const FrameGeom g)
+__device__ __forceinline__ void index_splat_body(const Batch<IndexArgs>& B, const FrameGeom& g, int blk)
 {
-    const VBlock vb = batch_decode(B.h);
+    const VBlock vb = batch_decode_at(B.h, blk);
     const IndexArgs& a = B.m[vb.model];
     const float4* __restrict__ surfels = a.surfels;
     // [id_begin, id_end): the surfel range of this launch (the whole map, or a rank's shard of it)
@@ -348,6 +350,7 @@ __global__ void __launch_bounds__(kB) index_splat_kernel(const Batch<IndexArgs> 
     if (!index_project(surfels[id * 3], surfels[id * 3 + 1], T, g.cam, g.cols, g.rows, a.maxDepth, a.time, a.timeDelta, ph, q)) return;
     atomicMin(&a.keys[q], zkey(ph.z, id));
 }
+__global__ void __launch_bounds__(kB) index_splat_kernel(const Batch<IndexArgs> B, const FrameGeom g) { index_splat_body(B, g, (int)blockIdx.x); }
 
 __global__ void __launch_bounds__(kB) index_resolve_kernel(const Batch<IndexArgs> B, const FrameGeom g)
 {
@@ -726,9 +729,9 @@ __global__ void __launch_bounds__(kB) associate_kernel(const Batch<FuseArgs> B, 
 
 // update.vert:38-111 (reads the winning record through the owner index; resets the owner slot)
 struct UpdateArgs { const float4* in; const unsigned* count; unsigned* owner; const float4* records; int time; float4* out; };
-__global__ void __launch_bounds__(kB) update_kernel(const Batch<UpdateArgs> B)
+__device__ __forceinline__ void update_body(const Batch<UpdateArgs>& B, int blk)
 {
-    const VBlock vb = batch_decode(B.h);
+    const VBlock vb = batch_decode_at(B.h, blk);
     const UpdateArgs& ua = B.m[vb.model];
     const float4* __restrict__ in = ua.in; unsigned* __restrict__ owner = ua.owner; const float4* __restrict__ records = ua.records;
     float4* __restrict__ out = ua.out; const int time = ua.time;
@@ -760,6 +763,25 @@ __global__ void __launch_bounds__(kB) update_kernel(const Batch<UpdateArgs> B)
         out[id * 3 + 1] = make_float4(ct.x, ct.y, ct.z, (float)time);
         out[id * 3 + 2] = nr;
     }
+}
+__global__ void __launch_bounds__(kB) update_kernel(const Batch<UpdateArgs> B) { update_body(B, (int)blockIdx.x); }
+
+// Launches that do not depend on each other, side by side in ONE grid (late in round 6).  Behind the association the frame's chain was
+// block sums -> compaction -> update -> index keys -> ...: the compaction of the new surfels (flags / records of the association -> `fresh`)
+// and the update of the old ones (-> the other surfel buffer) never read what the other writes, and neither does the second index pass's
+// rasterisation, which only needs the update.  So: {update || block sums}, then {index keys || compaction} -- two launches of 5-6 us and their
+// boundaries off the chain.  The longer part comes first in the grid.
+__global__ void __launch_bounds__(kB) update_blocksums_kernel(const Batch<UpdateArgs> U, const Batch<ScanArgs> S, int u_blocks)
+{
+    const int b = (int)blockIdx.x;
+    if (b < u_blocks) update_body(U, b);
+    else scan_block_sums_body(S, b - u_blocks);
+}
+__global__ void __launch_bounds__(kB) indexsplat_scatter_kernel(const Batch<IndexArgs> I, const FrameGeom g, const Batch<ScanArgs> S, int i_blocks)
+{
+    const int b = (int)blockIdx.x;
+    if (b < i_blocks) index_splat_body(I, g, b);
+    else scan_scatter_body(S, b - i_blocks);
 }
 
 // ====================================================================================== clean ====
@@ -1134,6 +1156,32 @@ void launch_update(hipStream_t s, const float* in, const unsigned* count, unsign
 {
     const UpdatePassArgs a{in, count, count_bound, owner, records, time, out};
     launch_update_batch(s, &a, 1);
+}
+// {update || block sums of the new surfels' compaction}, {index keys of the pass behind the update || that compaction} (update_blocksums_kernel):
+// what launch_scan_scatter_batch + launch_update_batch + launch_index_keys_batch enqueue as four launches, as two.  false (nothing
+// enqueued) when the batch does not fit one launch or a compaction has no elements: the caller then takes the separate launches.
+bool launch_update_compaction_index_keys(hipStream_t s, const UpdatePassArgs* up, const ScanPassArgs* sc, const IndexPassArgs* ix, int n, cf_cam cam, int cols,
+                                         int rows)
+{
+    if (n <= 0 || n > kSurfBatch) return false;
+    Batch<UpdateArgs> U; Batch<ScanArgs> S; Batch<IndexArgs> I;
+    int ub[kSurfBatch], sb[kSurfBatch], ib[kSurfBatch];
+    for (int k = 0; k < n; k++) {
+        U.m[k] = UpdateArgs{reinterpret_cast<const float4*>(up[k].in), up[k].count, up[k].owner, reinterpret_cast<const float4*>(up[k].records), up[k].time,
+                            reinterpret_cast<float4*>(up[k].out)};
+        ub[k] = up[k].count_bound > 0 ? gridFor(up[k].count_bound) : 0;
+        const ScanPassArgs& h = sc[k];
+        S.m[k] = ScanArgs{reinterpret_cast<const float4*>(h.rec), h.flags, h.n, h.block_sums, h.total, h.add_to_total, reinterpret_cast<float4*>(h.out), h.total_host, h.zero_flags};
+        sb[k] = (int)((h.n + kScanItems - 1) / kScanItems);
+        if (sb[k] == 0) return false;
+        I.m[k] = index_args(ix[k]);
+        ib[k] = I.m[k].id_end > I.m[k].id_begin ? gridFor(I.m[k].id_end - I.m[k].id_begin) : 0;
+    }
+    const int ug = batch_layout(U, ub, n), sg = batch_layout(S, sb, n), ig = batch_layout(I, ib, n);
+    const FrameGeom g{cam, cols, rows};
+    update_blocksums_kernel<<<ug + sg, kB, 0, s>>>(U, S, ug);
+    indexsplat_scatter_kernel<<<ig + sg, kB, 0, s>>>(I, g, S, ig);
+    return true;
 }
 // ---- clean ----------------------------------------------------------------------------------------------------------------------
 void launch_clean_batch(hipStream_t s, const CleanPassArgs* items, int n_items)
