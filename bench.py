@@ -452,10 +452,10 @@ def main(argv=None):
             s_us = 1e3 * prof.surfel_ms_total / prof.surfel_calls
             s_gbs = (prof.surfel_bytes / 1e9) / (prof.surfel_ms_total / 1e3)
             surf = dict(bound="hbm", achieved=round(s_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(s_gbs / HBM_PEAK_GBS, 4),
-                        stage="cf_models_frame_passes: 2 index maps + association + update + clean + 2 compactions + prediction of all models, 12 batched launches",
+                        stage="cf_models_frame_passes: 2 index maps + association + update + clean + 2 compactions + prediction of all models, 10 batched launches (the update beside the first compaction's block sums, the second index pass's rasterisation beside that compaction)",
                         chains=int(prof.surfel_calls), avg_us=round(s_us, 1), bytes_per_chain=int(prof.surfel_bytes / prof.surfel_calls), surfels=int(sum(counts)),
                         bytes_per_surfel="8 passes x 48 B for a fusing model (SURVEY 8d: 2 index + 2 splat reads, update R+W, clean R+W)",
-                        note="latency-bound: ~330 k surfels are 0.13 GB per frame -- 16 us at the HBM peak -- behind twelve dependent launches with scatter / "
+                        note="latency-bound: ~330 k surfels are 0.13 GB per frame -- 16 us at the HBM peak -- behind ten dependent launches with scatter / "
                              "gather passes (atomicMin z-keys, 4x4 window gathers); the image-space outputs (56 B per pixel and index map, 38 B per pixel "
                              "of the prediction) are not in the byte count")
         out = dict(metric="frames/sec at 640x480 (N active models) + ICP-reduce achieved HBM GB/s vs peak", value=round(fps, 2),
