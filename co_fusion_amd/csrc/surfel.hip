@@ -474,7 +474,14 @@ __global__ void __launch_bounds__(kB) splat_raster_kernel(const Batch<SplatArgs>
     while (fy < h) {
         const int px = s.x_lo + fx, py = s.y_lo + fy;
         float z;
-        if (splat_fragment(s, rays, cols, px, py, a.maxDepth, z)) atomicMin(&keys[py * cols + px], zkey(z, id));
+        if (splat_fragment(s, rays, cols, px, py, a.maxDepth, z)) {
+            const unsigned long long zk = zkey(z, id);
+#ifdef CF_SPLAT_PRECHECK
+            // (a key only ever decreases: a fragment that does not beat what the pixel holds now never will)
+            if (zk < keys[py * cols + px])
+#endif
+            atomicMin(&keys[py * cols + px], zk);
+        }
         fx += 4;
         while (fx >= w) { fx -= w; fy++; }
     }
