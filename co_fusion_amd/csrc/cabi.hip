@@ -765,19 +765,33 @@ int cf_odom_init_models_batch_select(cf_ctx* ctx, cf_odom* const* ods, int n, co
             cf_odom* od = ods[base + k];
             if (!od || !pred_v4[base + k] || !pred_n4[base + k] || !pred_rgba[base + k] || !poses[base + k] || !frame_rgba[base + k]) return CF_EINVAL;
             mb.m[k] = model_maps_args(od, pred_v4[base + k], pred_n4[base + k], poses[base + k]);
-            rb.c[2 * k] = rgbd_chain(od, pred_rgba[base + k], od->lastDepth, od->lastImage);   // initRGBModel
-            rb.c[2 * k].v4 = pred_v4[base + k];  // (the snapshot vmaps_tmp is written by the same launch: read the prediction it copies)
+            rb.c[k] = rgbd_chain(od, pred_rgba[base + k], od->lastDepth, od->lastImage);   // initRGBModel
+            rb.c[k].v4 = pred_v4[base + k];  // (the snapshot vmaps_tmp is written by the same launch: read the prediction it copies)
             if (choose && fill_counts[base + k]) {
                 if (!alt_v4[base + k] || !alt_n4[base + k] || !alt_rgba[base + k]) return CF_EINVAL;
                 mb.m[k].alt_v4 = alt_v4[base + k]; mb.m[k].alt_n4 = alt_n4[base + k]; mb.m[k].sel = fill_counts[base + k]; mb.m[k].sel_ratio = ratio;
-                rb.c[2 * k].alt_v4 = alt_v4[base + k]; rb.c[2 * k].alt_rgba = alt_rgba[base + k]; rb.c[2 * k].sel = fill_counts[base + k]; rb.c[2 * k].sel_ratio = ratio;
+                rb.c[k].alt_v4 = alt_v4[base + k]; rb.c[k].alt_rgba = alt_rgba[base + k]; rb.c[k].sel = fill_counts[base + k]; rb.c[k].sel_ratio = ratio;
             }
-            rb.c[2 * k + 1] = rgbd_chain(od, frame_rgba[base + k], od->nextDepth, od->nextImage);        // initRGB
-            // ... whose depth pyramid would be a second copy of the first chain's (same source, same cutoff): intensity only
-            for (int i = 0; i < CF_NUM_PYRS; ++i) rb.c[2 * k + 1].depth[i] = nullptr;
             od->next_depth_is_last = true;
         }
-        launch_model_maps_and_pyramids(s, mb, nb, rb, 2 * nb, W, H, ods[base]->maxDepthRGB);
+        // initRGB: the intensity pyramid of the tracker's frame (its depth pyramid would be a second copy of the first chain's -- same source,
+        // same cutoff --: intensity only).  The trackers of one sequence track the same frame: ONE chain per distinct frame, which stores every
+        // level into the pyramids of all trackers of that frame (RgbdBatch::fan_owner) -- five models were five identical full-resolution grid rows
+        int n_chains = nb;
+        for (int k = 0; k < nb; k++) {
+            cf_odom* od = ods[base + k];
+            int owner = -1;
+            for (int j = nb; j < n_chains; j++)
+                if (rb.c[j].rgba == frame_rgba[base + k]) { owner = j; break; }
+            if (owner < 0) {
+                owner = n_chains++;
+                rb.c[owner] = rgbd_chain(od, frame_rgba[base + k], od->nextDepth, od->nextImage);
+                for (int i = 0; i < CF_NUM_PYRS; ++i) rb.c[owner].depth[i] = nullptr;
+            }
+            rb.fan_owner[k] = (signed char)(owner + 1);
+            for (int i = 0; i < CF_NUM_PYRS; ++i) rb.fan_image[i][k] = od->nextImage[i];
+        }
+        launch_model_maps_and_pyramids(s, mb, nb, rb, n_chains, W, H, ods[base]->maxDepthRGB);
     }
     LAUNCHCHK(ctx);
     return CF_OK;

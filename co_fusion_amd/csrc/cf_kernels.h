@@ -157,7 +157,14 @@ struct RgbdChain {  // verticesToDepth + intensity + pyramids
     const float* v4; const uint8_t* rgba; float* depth[3]; uint8_t* image[3];
     const float* alt_v4; const uint8_t* alt_rgba; const unsigned* sel; float sel_ratio;  // the choice of ModelMapsArgs
 };
-struct RgbdBatch { RgbdChain c[2 * kPrepBatch]; };
+struct RgbdBatch {
+    RgbdChain c[2 * kPrepBatch];
+    // Trackers that track the SAME frame (all models of a sequence) need the same intensity pyramid of it, each in its own buffers: one
+    // chain computes it and stores every level to all of them (late in round 6; until then one chain -- a full-resolution grid row -- per
+    // tracker).  fan_owner[t]: 1 + the chain that also writes tracker t's pyramid fan_image[level][t]; 0: nobody (its own chain does).
+    uint8_t* fan_image[3][kPrepBatch];
+    signed char fan_owner[kPrepBatch];
+};
 void launch_model_maps(hipStream_t s, const ModelMapsBatch& b, int n);  // needs cols % 4 == 0 && rows % 4 == 0
 void launch_frame_maps(hipStream_t s, FrameMapsArgs a, int W, int H);
 void launch_rgbd_pyramids(hipStream_t s, const RgbdBatch& b, int n_chains, int W, int H, float cutoff);

@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(kBlock) pyrdown_f32_kernel(const float* __rest
 }
 
 // pyrDownKernelIntensityGauss, cudafuncs.cu:534-564
-__device__ __forceinline__ void pyrdown_u8_px(const uint8_t* __restrict__ src, int scols, int srows, uint8_t* __restrict__ dst, int i)
+__device__ __forceinline__ uint8_t pyrdown_u8_val(const uint8_t* __restrict__ src, int scols, int srows, int i)
 {
     const int dcols = scols / 2;
     const int y = i / dcols, x = i - y * dcols;
@@ -209,7 +209,20 @@ __device__ __forceinline__ void pyrdown_u8_px(const uint8_t* __restrict__ src, i
         }
     }
     const float q = sum / (float)count;
-    dst[i] = is_nan(q) ? (uint8_t)0 : (uint8_t)(int)q;
+    return is_nan(q) ? (uint8_t)0 : (uint8_t)(int)q;
+}
+__device__ __forceinline__ void pyrdown_u8_px(const uint8_t* __restrict__ src, int scols, int srows, uint8_t* __restrict__ dst, int i)
+{
+    dst[i] = pyrdown_u8_val(src, scols, srows, i);
+}
+// a chain's intensity value of pixel i at `level` to its own pyramid and to those of the trackers it also serves (RgbdBatch::fan_owner)
+__device__ __forceinline__ void rgbd_store_image(const RgbdBatch& b, int by, int level, int i, uint8_t v)
+{
+    uint8_t* const own = b.c[by].image[level];
+    own[i] = v;
+#pragma unroll
+    for (int t = 0; t < kPrepBatch; t++)
+        if (b.fan_owner[t] == by + 1 && b.fan_image[level][t] != own) b.fan_image[level][t][i] = v;   // (uniform)
 }
 __global__ void __launch_bounds__(kBlock) pyrdown_u8_kernel(const uint8_t* __restrict__ src, int scols, int srows,
                                                             uint8_t* __restrict__ dst)
@@ -236,7 +249,7 @@ __device__ __forceinline__ void rgbd_base_body(const RgbdBatch& b, int N, float 
         const int i = (bx - nb) * kBlock + threadIdx.x;
         if (i >= N) return;
         const uchar4 s = rgba[i];
-        c.image[0][i] = (uint8_t)(int)((float)s.x * 0.114f + (float)s.y * 0.299f + (float)s.z * 0.587f);
+        rgbd_store_image(b, by, 0, i, (uint8_t)(int)((float)s.x * 0.114f + (float)s.y * 0.299f + (float)s.z * 0.587f));
     }
 }
 __global__ void __launch_bounds__(kBlock) rgbd_base_kernel(const RgbdBatch b, int N, float cutoff) { rgbd_base_body(b, N, cutoff, (int)blockIdx.x, (int)blockIdx.y); }
@@ -249,7 +262,7 @@ __global__ void __launch_bounds__(kBlock) rgbd_pyrdown_kernel(const RgbdBatch b,
         if (i < n && c.depth[level]) pyrdown_f32_px(c.depth[level], scols, srows, c.depth[level + 1], i);
     } else {
         const int i = (blockIdx.x - nb) * kBlock + threadIdx.x;
-        if (i < n) pyrdown_u8_px(c.image[level], scols, srows, c.image[level + 1], i);
+        if (i < n) rgbd_store_image(b, (int)blockIdx.y, level + 1, i, pyrdown_u8_val(c.image[level], scols, srows, i));
     }
 }
 
