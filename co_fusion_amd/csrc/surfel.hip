@@ -776,6 +776,8 @@ __global__ void __launch_bounds__(kB) update_kernel(const Batch<UpdateArgs> B) {
 // and the update of the old ones (-> the other surfel buffer) never read what the other writes, and neither does the second index pass's
 // rasterisation, which only needs the update.  So: {update || block sums}, then {index keys || compaction} -- two launches of 5-6 us and their
 // boundaries off the chain.  The longer part comes first in the grid.
+static_assert(sizeof(Batch<IndexArgs>) + sizeof(FrameGeom) + sizeof(Batch<ScanArgs>) + 16 <= 4096 && sizeof(Batch<UpdateArgs>) + sizeof(Batch<ScanArgs>) + 16 <= 4096,
+              "the side-by-side launches carry two batches' arguments in one 4 KB kernel-argument segment");
 __global__ void __launch_bounds__(kB) update_blocksums_kernel(const Batch<UpdateArgs> U, const Batch<ScanArgs> S, int u_blocks)
 {
     const int b = (int)blockIdx.x;
